@@ -1,0 +1,100 @@
+"""Oracle: one training step of the reference driver (experiments.py:143-151, 196-267).
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Adam / exponential_decay are TensorFlow-1.3 internals
+(not in the reference tree); they are restated from the TF-1.3 documentation:
+    lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t);  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+    var -= lr_t * m / (sqrt(v) + eps)                      (tf.train.AdamOptimizer)
+    lrcvi = lrcvi0 * decay_rate ** (global_step / 1000)    (tf.train.exponential_decay, staircase=False)
+"""
+import math
+
+import torch
+
+from . import nets, svae_ref
+
+
+class State(object):
+    """All mutable state of the reference's training graph."""
+
+    def __init__(self, phi_gmm, enc_w, dec_w, theta, gmm_prior, smm=False):
+        self.phi_gmm = [p.detach().clone().requires_grad_(True) for p in phi_gmm]
+        self.enc_w = {k: v.detach().clone().requires_grad_(True) for k, v in enc_w.items()}
+        self.dec_w = {k: v.detach().clone().requires_grad_(True) for k, v in dec_w.items()}
+        self.theta = [t.detach().clone() for t in theta]
+        if smm:                                                    # experiments.py:160-161: mu_k, L_k trainable
+            self.theta[1].requires_grad_(True)
+            self.theta[2].requires_grad_(True)
+        self.gmm_prior = gmm_prior
+        self.smm = smm
+        self.global_step = 0
+        self.adam_m = None
+        self.adam_v = None
+
+    def trainables(self):
+        """Order used by the fixtures: phi_gmm (3), [theta mu_k, L_k], encoder (9), decoder (9)."""
+        names = ['phi_gmm/mu_k', 'phi_gmm/L_k', 'phi_gmm/log_pi_k']
+        ts = list(self.phi_gmm)
+        if self.smm:
+            names += ['theta/mu_k', 'theta/L_k']
+            ts += [self.theta[1], self.theta[2]]
+        for net, w in (('encoder_net', self.enc_w), ('decoder_net', self.dec_w)):
+            for v in nets.NET_VARS:
+                names.append(net + '/' + v)
+                ts.append(w[v])
+        return names, ts
+
+
+def tower_forward(st, y, noise, z_draws):
+    """experiments.py:208-229 for one tower: inference + ELBO (sum over the shard)."""
+    y_rec, phi_enc, x_k, x_s, log_z, _, phi_tilde = svae_ref.inference(y, st.phi_gmm, st.enc_w, st.dec_w, noise, z_draws)
+    if st.smm:
+        elbo, details = svae_ref.compute_elbo_smm(y, y_rec, st.theta, phi_tilde, x_k, log_z)
+    else:
+        elbo, details = svae_ref.compute_elbo(y, y_rec, st.theta, phi_tilde, x_k, log_z)
+    return elbo, details, x_s, log_z
+
+
+def train_step(st, y, noise, z_draws, lr, lrcvi0, decay_rate, towers=1, b1=0.9, b2=0.999, eps=1e-8):
+    """One `sess.run(training_step)`.  With towers=G the minibatch is split in G contiguous shards
+    (data.py:174-175), per-tower gradients of -elbo are AVERAGED (helpers/tf_utils.py:52-87), log_z and
+    x_samples are concatenated for the M-step (experiments.py:247-260).  Everything reads OLD values.
+    Returns dict(elbo (sum over towers), details, grads (averaged), theta_star, lrcvi)."""
+    names, params = st.trainables()
+    ys, ns, zs = torch.chunk(y, towers), torch.chunk(noise, towers), torch.chunk(z_draws, towers)
+    grads_sum, elbos, details, xs_all, lz_all = None, [], [], [], []
+    for g in range(towers):
+        elbo, det, x_s, log_z = tower_forward(st, ys[g], ns[g], zs[g])
+        gr = torch.autograd.grad(-elbo, params, allow_unused=True)
+        gr = [torch.zeros_like(p) if g_ is None else g_ for g_, p in zip(gr, params)]
+        grads_sum = gr if grads_sum is None else [a + b for a, b in zip(grads_sum, gr)]
+        elbos.append(elbo.detach())
+        details.append(torch.stack([d.detach() for d in det]))
+        xs_all.append(x_s.detach())
+        lz_all.append(log_z.detach())
+    grads = [g_ / towers for g_ in grads_sum]
+    lrcvi = lrcvi0 * decay_rate ** (st.global_step / 1000.0)
+    r_nk = torch.exp(torch.cat(lz_all))
+    if st.smm:
+        theta_star = [svae_ref.m_step_smm(st.gmm_prior, r_nk)]
+        new_theta0 = svae_ref.update_gmm_params([st.theta[0]], theta_star, lrcvi)
+    else:
+        theta_star = svae_ref.m_step(st.gmm_prior, torch.cat(xs_all), r_nk)
+        new_theta = svae_ref.update_gmm_params(st.theta, theta_star, lrcvi)
+    # Adam (TF form)
+    if st.adam_m is None:
+        st.adam_m = [torch.zeros_like(p) for p in params]
+        st.adam_v = [torch.zeros_like(p) for p in params]
+    t = st.global_step + 1
+    lr_t = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+    with torch.no_grad():
+        for p, g_, m_, v_ in zip(params, grads, st.adam_m, st.adam_v):
+            m_.mul_(b1).add_(g_, alpha=1 - b1)
+            v_.mul_(b2).addcmul_(g_, g_, value=1 - b2)
+            p.sub_(lr_t * m_ / (v_.sqrt() + eps))
+    if st.smm:
+        st.theta[0] = new_theta0[0].detach()
+    else:
+        st.theta = [t_.detach() for t_ in new_theta]
+    st.global_step += 1
+    return dict(elbo=torch.stack(elbos).sum(), details=torch.stack(details).sum(0), grads=dict(zip(names, grads)),
+                theta_star=theta_star, lrcvi=lrcvi, x_samples=torch.cat(xs_all), log_z=torch.cat(lz_all))

@@ -1,0 +1,184 @@
+"""The oracle (oracle/*.py) against the golden vectors produced by executing the reference's own
+functions (tests/golden/make_fixtures.py), plus independent known-answer checks.  CPU only."""
+import numpy as np
+import pytest
+import scipy.special
+import scipy.stats
+import torch
+
+from oracle import dists, mixtures, nets, svae_ref, train_ref
+
+F64_RTOL = 1e-9
+
+
+def T(a, dtype=torch.float64):
+    return torch.as_tensor(np.asarray(a)).to(dtype) if np.asarray(a).dtype.kind == 'f' else torch.as_tensor(np.asarray(a))
+
+
+def close(got, want, rtol=F64_RTOL, atol=None, what=''):
+    got = got.detach().numpy() if torch.is_tensor(got) else np.asarray(got)
+    want = np.asarray(want)
+    scale = max(np.abs(want).max(), 1e-300)
+    err = np.abs(got - want).max() / scale if atol is None else np.abs(got - want).max()
+    tol = rtol if atol is None else atol
+    assert err <= tol, '%s: err %.3e > %.1e' % (what, err, tol)
+
+
+@pytest.mark.parametrize('case', ['dist_tiny', 'dist_l8'])
+@pytest.mark.parametrize('dtype,suf,rtol', [(torch.float64, '', 1e-9), (torch.float32, '__f32', 2e-4)])
+def test_distributions(golden, case, dtype, suf, rtol):
+    g = golden(case)
+    i = {k[3:]: T(g[k], dtype) for k in g.files if k.startswith('in_')}
+    e1, e2 = dists.gauss_standard_to_natural(i['mu'], i['sigma'])
+    close(e1, g['s2n_eta1' + suf], rtol, what='s2n eta1')
+    close(e2, g['s2n_eta2' + suf], rtol, what='s2n eta2')
+    mu2, sg2 = dists.gauss_natural_to_standard(e1, e2)
+    close(mu2, g['n2s_mu' + suf], rtol), close(sg2, g['n2s_sigma' + suf], rtol)
+    close(dists.gauss_log_probability_nat(i['x'], i['eta1_nk'], i['eta2_nk'], i['w']), g['logprob_nat' + suf], rtol)
+    close(dists.gauss_log_probability_nat(i['x'], i['eta1_nk'], i['eta2_nk']), g['logprob_nat_now' + suf], rtol)
+    close(dists.gauss_log_probability_nat_per_samp(i['xs'], i['eta1_nk'], i['eta2_nk']), g['logprob_per_samp' + suf], rtol)
+    close(dists.logdet(i['sigma']), g['logdet' + suf], rtol)
+    em, eC = dists.niw_expected_values(i['beta'], i['m'], i['C'], i['v'])
+    close(em, g['niw_exp_m' + suf], rtol), close(eC, g['niw_exp_C' + suf], rtol)
+    A, b, be, vh = dists.niw_standard_to_natural(i['beta'], i['m'], i['C'], i['v'])
+    close(A, g['niw_A' + suf], rtol), close(b, g['niw_b' + suf], rtol), close(vh, g['niw_vhat' + suf], rtol)
+    _, m2, C2, v2 = dists.niw_natural_to_standard(A, b, be, vh)
+    close(m2, g['niw_back_m' + suf], rtol), close(C2, g['niw_back_C' + suf], rtol), close(v2, g['niw_back_v' + suf], rtol)
+    close(dists.dir_expected_log_pi(i['alpha']), g['dir_elogpi' + suf], rtol)
+    close(dists.dir_standard_to_natural(i['alpha']), g['dir_nat' + suf], rtol)
+    close(dists.dir_natural_to_standard(i['alpha']), g['dir_std' + suf], rtol)
+    close(dists.student_t_log_probability_per_samp(i['xs'], i['mu'], i['sigma'], i['dof']), g['student_t' + suf], rtol)
+
+
+def test_known_answers(golden):
+    """Independent of the reference: scipy densities / special functions."""
+    g = golden('dist_tiny')
+    xs, mu, sigma, dof = g['in_xs'], g['in_mu'], g['in_sigma'], g['in_dof']
+    N, K, S, L = xs.shape
+    got = dists.student_t_log_probability_per_samp(T(xs), T(mu), T(sigma), T(dof)).numpy()
+    for k in range(K):
+        want = scipy.stats.multivariate_t(loc=mu[k], shape=sigma[k], df=dof[k]).logpdf(xs[:, k].reshape(-1, L))
+        assert np.abs(got[:, k].reshape(-1) - want).max() < 1e-12
+    e1, e2 = g['in_eta1_nk'], g['in_eta2_nk']
+    got = dists.gauss_log_probability_nat_per_samp(T(xs), T(e1), T(e2)).numpy()
+    for n in range(N):
+        for k in range(K):
+            Sg = np.linalg.inv(-2 * e2[n, k])
+            want = scipy.stats.multivariate_normal(Sg @ e1[n, k], Sg).logpdf(xs[n, k])
+            assert np.abs(got[n, k] - want).max() < 1e-11
+    a = g['in_alpha']
+    assert np.abs(dists.dir_expected_log_pi(T(a)).numpy() - (scipy.special.digamma(a) - scipy.special.digamma(a.sum()))).max() < 1e-13
+    lz = dists.gauss_log_probability_nat(T(g['in_x']), T(e1), T(e2), T(g['in_w']))
+    assert np.abs(np.exp(lz.numpy()).sum(1) - 1).max() < 1e-12
+
+
+@pytest.mark.parametrize('case', ['gmm_tiny', 'gmm_d6k10', 'gmm_d8k16'])
+@pytest.mark.parametrize('dtype,suf,rtol,atol_r', [(torch.float64, '', 1e-9, 1e-10), (torch.float32, '__f32', 5e-4, 2e-4)])
+def test_gmm_smm_steps(golden, case, dtype, suf, rtol, atol_r):
+    g = golden(case)
+    x, r = T(g['in_x'], dtype), T(g['in_r0'], dtype)
+    for it in range(3):
+        r, log_r, theta, (xk, Sk, pi) = mixtures.gmm_inference_step(x, r)
+        for n_, t_ in zip(('alpha', 'beta', 'm', 'C', 'v'), theta):
+            close(t_, g['gmm%d_%s%s' % (it, n_, suf)], rtol, what='gmm%d %s' % (it, n_))
+        close(xk, g['gmm%d_xk%s' % (it, suf)], rtol), close(Sk, g['gmm%d_Sk%s' % (it, suf)], rtol)
+        close(pi, g['gmm%d_pi%s' % (it, suf)], rtol)
+        close(r, g['gmm%d_r%s' % (it, suf)], atol=atol_r, what='gmm r')
+    # stand-alone pieces on step-0 quantities
+    prior = mixtures.vmp_prior(x.shape[1] and g['in_r0'].shape[1], x.shape[1], dtype)
+    r0 = T(g['in_r0'], dtype)
+    ak, bk, mk, Ck, vk, _, _ = mixtures.gmm_m_step(x, r0, *prior)
+    Pk = dists.inv(Ck)
+    close(Pk, g['P0' + suf], rtol * 10)
+    close(mixtures.gmm_expct_log_det_prec(vk, Pk), g['elogdet0' + suf], rtol * 10)
+    close(mixtures.gmm_expct_mahalanobis(x, bk, mk, Pk, vk), g['maha0' + suf], rtol * 10)
+    rm, pim = mixtures.gmm_e_step(x, ak, bk, mk, Pk, vk, torch.as_tensor(g['in_miss']))
+    close(rm, g['miss_r' + suf], atol=atol_r), close(pim, g['miss_pi' + suf], rtol * 10)
+    # SMM
+    r, u = r0, torch.ones_like(r0)
+    for it in range(3):
+        r, u, theta, (xk, Sk, pi) = mixtures.smm_inference_step(x, r, u, float(g['in_kappa']))
+        for n_, t_ in zip(('alpha', 'beta', 'm', 'C', 'v'), theta):
+            close(t_, g['smm%d_%s%s' % (it, n_, suf)], rtol * 10, what='smm%d %s' % (it, n_))
+        close(r, g['smm%d_r%s' % (it, suf)], atol=atol_r * 5, what='smm r')
+        close(u, g['smm%d_u%s' % (it, suf)], rtol * 50, what='smm u')
+
+
+def _svae_state(g, dtype, suf=''):
+    N, K, L, S, Dy, U, steps, smm = [int(v) for v in g['in_dims']]
+    enc = {v: T(g['in_w_encoder_net/' + v], dtype) for v in nets.NET_VARS}
+    dec = {v: T(g['in_w_decoder_net/' + v], dtype) for v in nets.NET_VARS}
+    prior, theta = svae_ref.init_mm(K, L, T(g['in_m_unif'], dtype), dtype)
+    phi = svae_ref.init_recognition_params(theta, T(g['in_pi_norm'], dtype))
+    phi[1] = phi[1] + T(g['in_Lk_low'], dtype)
+    if smm:
+        mu_k, L_k = svae_ref.make_loc_scale(prior)
+        theta = [theta[0], mu_k, L_k, torch.full((K,), float(g['in_dof0']), dtype=dtype)]
+        prior = prior[0]
+    return train_ref.State(phi, enc, dec, theta, prior, smm=bool(smm)), (N, K, L, S, Dy, U, steps, smm)
+
+
+@pytest.mark.parametrize('case', ['svae_tiny', 'svae_paper', 'svae_c1', 'svae_l8', 'svae_smm_tiny', 'svae_smm_l8'])
+def test_svae_init_matches_reference(golden, case):
+    g = golden(case)
+    st, dims = _svae_state(g, torch.float64)
+    for n_, t_ in zip(('mu_k', 'L_k', 'log_pi_k'), st.phi_gmm):
+        close(t_, g['phi_init_' + n_], what='phi ' + n_)
+    if dims[-1]:
+        close(st.gmm_prior, g['prior_alpha'])
+        for n_, t_ in zip(('alpha', 'mu', 'L', 'dof'), st.theta):
+            close(t_, g['theta_init_' + n_], what='theta ' + n_)
+    else:
+        for n_, p_, t_ in zip(('alpha', 'A', 'b', 'beta', 'vhat'), st.gmm_prior, st.theta):
+            close(p_, g['prior_' + n_]), close(t_, g['theta_init_' + n_])
+
+
+@pytest.mark.parametrize('case', ['svae_tiny', 'svae_paper', 'svae_c1', 'svae_l8', 'svae_smm_tiny', 'svae_smm_l8'])
+@pytest.mark.parametrize('dtype,suf,rtol', [(torch.float64, '', 1e-8), (torch.float32, '__f32', 2e-3)])
+def test_svae_training_steps(golden, case, dtype, suf, rtol):
+    """Full training steps (inference, ELBO, 21/23 gradients, CVI update, TF-Adam) vs the reference run."""
+    g = golden(case)
+    st, (N, K, L, S, Dy, U, steps, smm) = _svae_state(g, dtype)
+    y = T(g['in_y'], dtype)
+    for it in range(steps):
+        pre = 'step%d_' % it
+        noise, zd = T(g['in_noise'][it], dtype), T(g['in_zdraw'][it])
+        # forward pieces first (before the step mutates the state)
+        y_rec, phi_enc, x_k, x_s, log_z, _, phi_tilde = svae_ref.inference(y, st.phi_gmm, st.enc_w, st.dec_w, noise, zd)
+        close(phi_enc[0], g[pre + 'enc_eta1' + suf], rtol), close(phi_enc[1], g[pre + 'enc_eta2' + suf], rtol)
+        close(x_k, g[pre + 'x_k' + suf], rtol), close(x_s, g[pre + 'x_s' + suf], rtol)
+        close(torch.exp(log_z), np.exp(g[pre + 'log_z' + suf]), atol=max(rtol * 0.1, 1e-10), what='r_nk')
+        close(y_rec[0], g[pre + 'rec_mean' + suf], rtol), close(y_rec[1], g[pre + 'rec_var' + suf], rtol)
+        close(phi_tilde[0], g[pre + 'phi_tilde_eta1' + suf], rtol), close(phi_tilde[1], g[pre + 'phi_tilde_eta2' + suf], rtol)
+        out = train_ref.train_step(st, y, noise, zd, float(g['in_lr']), float(g['in_lrcvi']), float(g['in_decay']))
+        close(out['elbo'], g[pre + 'elbo' + suf], rtol, what='elbo')
+        close(out['details'], g[pre + 'details' + suf], rtol, what='details')
+        assert abs(out['lrcvi'] - float(g[pre + 'lrcvi'])) < 1e-15
+        for n_, gr in out['grads'].items():
+            close(gr, g[pre + 'grad_' + n_ + suf], rtol * 5, what='grad ' + n_)
+        names, params = st.trainables()
+        for n_, p in zip(names, params):
+            close(p, g[pre + 'param_' + n_ + suf], rtol, what='param ' + n_)
+        if smm:
+            close(out['theta_star'][0], g[pre + 'theta_star_alpha' + suf], rtol)
+            close(st.theta[0], g[pre + 'theta_alpha' + suf], rtol)
+        else:
+            for n_, ts, t_ in zip(('alpha', 'A', 'b', 'beta', 'vhat'), out['theta_star'], st.theta):
+                close(ts, g[pre + 'theta_star_' + n_ + suf], rtol, what='theta* ' + n_)
+                close(t_, g[pre + 'theta_' + n_ + suf], rtol, what='theta ' + n_)
+
+
+def test_towers_average_gradients(golden):
+    """experiments.py:196-265 semantics: G towers -> mean of per-tower gradients, summed ELBO, M-step on the
+    concatenation.  (No multi-tower golden exists: the reference needs real GPUs for nb_gpu > 1.)"""
+    g = golden('svae_paper')
+    st1, (N, K, L, S, Dy, U, steps, smm) = _svae_state(g, torch.float64)
+    st2, _ = _svae_state(g, torch.float64)
+    y, noise, zd = T(g['in_y']), T(g['in_noise'][0]), T(g['in_zdraw'][0])
+    o1 = train_ref.train_step(st1, y, noise, zd, 3e-4, 0.2, 0.95, towers=1)
+    o2 = train_ref.train_step(st2, y, noise, zd, 3e-4, 0.2, 0.95, towers=2)
+    close(o2['elbo'], o1['elbo'].numpy(), 1e-12)
+    for n_ in o1['grads']:
+        close(o2['grads'][n_] * 2, o1['grads'][n_].numpy(), 1e-9, what=n_)
+    for a, b in zip(st1.theta, st2.theta):
+        close(b, a.numpy(), 1e-12)
