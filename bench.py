@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the VMP hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gmm|smm] [--n ROWS --d D --k K]
+
+A "step" is one VMP iteration (M-step -> E-step -> assign; reference models/gmm.py:258-263) over one batch
+of synthetic Gaussian-mixture data resident in HBM.  Default workload = BASELINE.json configs[2]:
+synthetic GMM N=1e6, D=8, K=16 per GPU (weak scaling: every rank holds N rows; the K-sized sufficient
+statistics are summed across ranks with one RCCL all-reduce per step).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def synth(N, D, K, seed):
+    """SURVEY 8d generator: centres ~ N(0, 25 I), uniform labels, unit covariance; r0 = softmax(3 N(0,1))."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    c = rng.standard_normal((K, D)) * 5.0
+    z = rng.integers(0, K, size=N)
+    x = (c[z] + rng.standard_normal((N, D), dtype=np.float32)).astype(np.float32)
+    r0 = np.exp(3.0 * rng.standard_normal((N, K), dtype=np.float32))
+    r0 = (r0 / r0.sum(1, keepdims=True)).astype(np.float32)
+    return x, r0
+
+
+def cpu_baseline(x, r0, workload, chunk=1 << 15, reps=3):
+    """The reference CPU path = the oracle (op-for-op torch-CPU fp32 restatement of models/gmm.py /
+    models/smm.py, pinned by tests/golden), timed on this host in N-chunks (the literal graph materialises
+    (N,K,D,D) temporaries).  One VMP step over a bounded sample of the workload; best of `reps`."""
+    from oracle import mixtures, dists
+    torch.set_num_threads(os.cpu_count() or 1)
+    Ns = min(x.shape[0], 1 << 18)                      # bounded sample: 262144 rows (about 10-20 s total)
+    xs, rs = torch.as_tensor(x[:Ns]), torch.as_tensor(r0[:Ns])
+    K, D = rs.shape[1], xs.shape[1]
+    prior = mixtures.vmp_prior(K, D, torch.float32)
+    us = torch.ones_like(rs)
+    kap = torch.full((K,), 5.0)
+
+    def one_step():
+        # M-step, two passes over the chunks exactly as update_xk / update_Sk are written
+        w = rs * us if workload == 'smm' else rs
+        N_k = rs.sum(0)
+        W_k = w.sum(0)
+        sx = torch.zeros(K, D)
+        for i in range(0, Ns, chunk):
+            sx += torch.einsum('nk,nd->kd', w[i:i + chunk], xs[i:i + chunk])
+        x_k = sx / (W_k.unsqueeze(1) + (1e-20 if workload == 'smm' else 0.0))
+        S = torch.zeros(K, D, D)
+        for i in range(0, Ns, chunk):
+            d = xs[i:i + chunk].unsqueeze(1) - x_k.unsqueeze(0)
+            S += torch.einsum('nk,nkde->kde', w[i:i + chunk], torch.einsum('nkd,nke->nkde', d, d))
+        S_k = S / W_k.view(-1, 1, 1)
+        a0, b0, m0, C0, v0 = prior
+        alpha_k, beta_k = a0 + N_k, b0 + W_k
+        m_k = (b0.reshape(-1, 1) * m0 + W_k.unsqueeze(1) * x_k) / beta_k.unsqueeze(1)
+        q0 = x_k - m0
+        C_k = C0 + W_k.view(-1, 1, 1) * S_k + torch.einsum('k,kde->kde', b0 * W_k / beta_k, torch.einsum('kd,ke->kde', q0, q0))
+        v_k = v0 + N_k + (0 if workload == 'smm' else 1)
+        P_k = dists.inv(C_k)
+        out = []
+        for i in range(0, Ns, chunk):
+            if workload == 'smm':
+                out.append(mixtures.smm_e_step(xs[i:i + chunk], alpha_k, beta_k, m_k, P_k, v_k, kap)[0])
+            else:
+                out.append(mixtures.gmm_e_step(xs[i:i + chunk], alpha_k, beta_k, m_k, P_k, v_k)[0])
+        return torch.cat(out)
+
+    one_step()
+    best = float('inf')
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        one_step()
+        best = min(best, time.perf_counter() - t0)
+    return {'value': Ns / best, 'unit': 'datapoints/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'steps_per_sec_at_sample': 1.0 / best,
+            'sample': 'one %s VMP step (oracle, fp32, torch-CPU %d threads, N-chunks of %d) on the first %d rows of the '
+                      'workload; best of %d after warm-up' % (workload, torch.get_num_threads(), chunk, Ns, reps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', default='gmm', choices=['gmm', 'smm'])
+    ap.add_argument('--n', type=int, default=1_000_000)
+    ap.add_argument('--d', type=int, default=8)
+    ap.add_argument('--k', type=int, default=16)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    import vmp_for_svae_amd as V
+    from vmp_for_svae_amd.models import _mix
+    from vmp_for_svae_amd.models.parallel_mix import DistributedVMPLoop
+    L = V._lib
+    L.lib()                                              # fail loudly if the HIP library is missing
+
+    N, D, K = args.n, args.d, args.k
+    flav = L.VMP_SMM if args.workload == 'smm' else L.VMP_GMM
+    x_h, r0_h = synth(N, D, K, seed=rank)                # every rank: its own shard of the (virtual) N*world rows
+    x, r0 = torch.as_tensor(x_h).to(dev), torch.as_tensor(r0_h).to(dev)
+    kappa = torch.full((K,), 5.0, device=dev) if flav == L.VMP_SMM else None
+    if world > 1:
+        loop = DistributedVMPLoop(x, r0, flav, kappa=kappa)
+    else:
+        loop = _mix.VMPLoop(x, r0, flav, kappa=kappa)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loop.step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loop.finalize_phase()
+        ev[i][0].record()
+        loop.estep()                                     # exactly one launch: the fused streaming pass
+        ev[i][1].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    assert torch.isfinite(loop.r).all()
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        words = (2 * D + 2 * K) if flav == L.VMP_GMM else (2 * D + 4 * K)
+        alg_bytes = 4.0 * N * words                      # T1 algorithmic bytes per step (per GPU)
+        min_bytes = alg_bytes / 2                        # what the fused pass has to move: read x, write r (u)
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % args.workload)
+        if os.path.exists(tf) and (N, D, K) == (1_000_000, 8, 16):
+            traffic = json.load(open(tf)).get('hbm_bytes_per_launch')
+        out = {
+            'metric': 'vmp_step_datapoints_per_sec', 'value': N * world / (dt / args.steps), 'unit': 'datapoints/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
+            'steps_per_sec': args.steps / dt, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'T1 %s VMP step (M-step + E-step), synthetic GMM N=%d per GPU, D=%d, K=%d'
+                                   % (args.workload, N, D, K), 'N_per_gpu': N, 'D': D, 'K': K,
+                       'parallelism': 'dp%d (rows sharded, 1 all-reduce of K-sized stats per step)' % world},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'kernel': 'pass_kernel<E-step + fused moments>', 'kernel_ms': kern_ms,
+                         'algorithmic_bytes_per_launch': alg_bytes,
+                         'moved_bytes_min_per_launch': min_bytes,
+                         'moved_GBps': min_bytes / (kern_ms * 1e-3) / 1e9,
+                         'moved_frac': min_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(x_h, r0_h, args.workload)
+            out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

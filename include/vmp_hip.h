@@ -1,0 +1,121 @@
+/*
+ * vmp_hip.h - C ABI of libvmp_hip.so: the MI355X (gfx950) implementation of the VMP hot path of
+ * emtiyaz/vmp-for-svae (GMM / SMM structured VAE).
+ *
+ * The reference has no FFI: its boundary is the Python function surface of distributions/{gaussian,niw,dirichlet,student_t}.py and
+ * models/{gmm,smm,svae,vae}.py.  This library sits UNDER the package's mirror of that
+ * surface (vmp-for-svae_amd/{distributions,models}); each entry point names the reference code it replaces.
+ *
+ * Conventions (all entry points)
+ *   - plain C symbols; every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - row-major, batch-leading fp32 tensors exactly as the reference lays them out: x (N,D), r (N,K),
+ *     (K,D,D), (N,K,S,L) ...; integer sizes: N int64, everything else int;
+ *   - caller allocates inputs, outputs and workspace; the library never allocates device memory;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return 0 = ok, <0 = invalid argument (VMP_E_*), >0 = hipError_t of a failed launch;
+ *     vmp_last_error() returns a thread-local message for the last non-zero return;
+ *   - no global mutable state: callable concurrently from any host thread.
+ */
+#ifndef VMP_HIP_H
+#define VMP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMP_ABI_VERSION 1
+
+#define VMP_E_BADARG   (-1)   /* null pointer / non-positive size            */
+#define VMP_E_DIM      (-2)   /* D or K outside the compiled range           */
+#define VMP_E_WS       (-3)   /* workspace too small                         */
+
+#define VMP_MAX_D 8           /* latent / data dimension of the mixture (compiled range 1..8)  */
+#define VMP_MAX_K 64          /* mixture components                                             */
+
+/* mixture flavour */
+#define VMP_GMM 0             /* models/gmm.py  (Bishop 10.2)                */
+#define VMP_SMM 1             /* models/smm.py  (Archambeau & Verleysen)     */
+
+int         vmp_abi_version(void);
+const char* vmp_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * T1: pure mixture VMP (models/gmm.py:25-269, models/smm.py:25-245)
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Number of fp32 words per component of the E-step parameter pack written by vmp_mix_finalize and
+ * consumed by vmp_mix_estep: [ m_k (D) | W_k packed lower-triangular, row-major (D(D+1)/2) | c | h | ua | ub ]
+ * with  q_nk = || W_k (x_n - m_k) ||^2,  log rho_nk = c - h*q_nk,  u_nk = ua / (q_nk + ub).           */
+int    vmp_mix_pack_words(int D);
+
+/* Raw sufficient statistics layout (fp64), per component k:  [ Nk | Wk | sx (D) | sxx (D*D, symmetric) ].
+ * Nk = sum_n r_nk, Wk = sum_n w_nk, sx = sum_n w_nk x_n, sxx = sum_n w_nk x_n x_n^T, w = r (GMM) or r*u (SMM). */
+int    vmp_mix_stats_words(int D);
+
+/* Bytes of workspace needed by vmp_mix_stats / vmp_mix_estep(with stats) for N rows. */
+size_t vmp_mix_workspace_bytes(int64_t N, int D, int K);
+
+/* M-pass over the data: weighted raw moments.
+ * Replaces the N-sized part of gmm.update_Nk/xk/Sk (models/gmm.py:25-46) and smm.update_Nk/Wk/xk/Sk
+ * (models/smm.py:25-50); the centring (x - x_k) the reference does in a second pass is done in fp64 in
+ * vmp_mix_finalize / on the host side from the raw moments.
+ *   x (N,D), r (N,K), u (N,K) or NULL (then w = r).   stats: (K, vmp_mix_stats_words(D)) fp64, overwritten.  */
+int    vmp_mix_stats(const float* x, const float* r, const float* u, int64_t N, int D, int K,
+                     double* stats, void* ws, size_t ws_bytes, void* stream);
+
+/* K-sized posterior update + E-step parameter pack, all in fp64 on the device, rounded to fp32 on output.
+ * Replaces gmm.update_alphak/betak/mk/Ck/vk (models/gmm.py:49-81), P_k = matrix_inverse(C_k) (gmm.py:260),
+ * compute_expct_log_det_prec (gmm.py:117-131, including its det<=1e-20 guard), compute_log_pi (gmm.py:134-138);
+ * SMM flavour: models/smm.py:53-85, 99-116 and the constants of compute_rnk/compute_expct_unk (smm.py:119-137).
+ *   prior (standard form): alpha0 (K), beta0 (K), m0 (K,D), C0 (K,D,D), v0 (K); kappa (K) or NULL (GMM).
+ *   outputs (any may be NULL): alpha,beta,v (K); m, xbar (K,D); C, S (K,D,D); pi = exp(E log pi) (K);
+ *   pack (K, vmp_mix_pack_words(D)).                                                                     */
+int    vmp_mix_finalize(const double* stats, int D, int K, int flavour,
+                        const float* alpha0, const float* beta0, const float* m0, const float* C0, const float* v0,
+                        const float* kappa,
+                        float* alpha, float* beta, float* m, float* C, float* v, float* xbar, float* S, float* pi,
+                        float* pack, void* stream);
+
+/* E-step parameter pack from explicit posterior parameters (for the stand-alone e_step API):
+ * gmm.e_step(x, alpha_k, beta_k, m_k, P_k, v_k) (models/gmm.py:154-174) / smm.e_step (models/smm.py:140-164).
+ *   P (K,D,D) is the precision the reference passes in.                                                   */
+int    vmp_mix_pack_from_params(int D, int K, int flavour, const float* alpha, const float* beta, const float* m,
+                                const float* P, const float* v, const float* kappa, float* pack, float* pi,
+                                void* stream);
+
+/* E-pass over the data: responsibilities (and SMM scales), optionally FUSED with the raw moments of the
+ * NEW responsibilities (= the next M-pass), so that one VMP iteration streams x once and writes r once.
+ * Replaces compute_expct_mahalanobis_dist + compute_rnk (models/gmm.py:84-94,141-151), the missing-data variant
+ * (gmm.py:97-114) when miss_mask != NULL, and smm.expct_mahalanobis_dist/compute_rnk/compute_expct_unk
+ * (models/smm.py:88-96,119-137).
+ *   x (N,D); pack from vmp_mix_finalize / vmp_mix_pack_from_params; miss_mask (N,D) uint8 or NULL;
+ *   r_out (N,K); u_out (N,K) (SMM, else NULL); logr_out (N,K) or NULL (= log r_out as gmm.py:267);
+ *   stats_out (K, vmp_mix_stats_words(D)) fp64 or NULL; ws needed only when stats_out != NULL.            */
+int    vmp_mix_estep(const float* x, int64_t N, int D, int K, int flavour, const float* pack,
+                     const uint8_t* miss_mask, float* r_out, float* u_out, float* logr_out,
+                     double* stats_out, void* ws, size_t ws_bytes, void* stream);
+
+/* Fast path of the VMP iteration - exactly two launches per iteration, no intermediate stats buffer:
+ *   vmp_mix_estep_fused : the E-pass kernel with fused raw moments; leaves per-block fp64 partials in `ws`
+ *   vmp_mix_finalize_ws : reduces those partials in a fixed order (deterministic), then does what
+ *                         vmp_mix_finalize does; stats_out (K, stats_words) is optional.
+ * Both must be given the same (N, D, K, flavour) and the same ws.  vmp_mix_stats_ws is the stand-alone
+ * M-pass leaving partials in ws (first iteration).  Reference: the loop body of gmm.inference
+ * (models/gmm.py:258-263) / smm.inference (models/smm.py:232-238).                                          */
+int    vmp_mix_estep_fused(const float* x, int64_t N, int D, int K, int flavour, const float* pack,
+                           float* r_out, float* u_out, float* logr_out, void* ws, size_t ws_bytes, void* stream);
+int    vmp_mix_stats_ws(const float* x, const float* r, const float* u, int64_t N, int D, int K,
+                        void* ws, size_t ws_bytes, void* stream);
+int    vmp_mix_finalize_ws(const void* ws, int64_t N, int D, int K, int flavour,
+                           const float* alpha0, const float* beta0, const float* m0, const float* C0, const float* v0,
+                           const float* kappa,
+                           float* alpha, float* beta, float* m, float* C, float* v, float* xbar, float* S, float* pi,
+                           float* pack, double* stats_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMP_HIP_H */

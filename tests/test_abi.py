@@ -1,0 +1,55 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol that
+include/vmp_hip.h declares, and the product path refuses to run without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, 'include', 'vmp_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(vmp_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_header_symbols_exported():
+    import vmp_for_svae_amd as V
+    lib = ctypes.CDLL(V._lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 9
+    for n in names:
+        assert hasattr(lib, n), 'libvmp_hip.so does not export %s' % n
+    assert sorted(V._lib.exported_symbols()) == names, 'ctypes table and header out of sync'
+    assert lib.vmp_abi_version() == 1
+
+
+def test_size_helpers():
+    import vmp_for_svae_amd as V
+    lib = V._lib.lib()
+    assert lib.vmp_mix_pack_words(8) == 8 + 36 + 4
+    assert lib.vmp_mix_stats_words(8) == 2 + 8 + 64
+    assert lib.vmp_mix_workspace_bytes(10**6, 8, 16) > 0
+
+
+def test_no_cpu_fallback():
+    import vmp_for_svae_amd as V
+    from vmp_for_svae_amd.models import gmm, _mix
+    x = torch.zeros(8, 2)
+    r = torch.full((8, 3), 1 / 3.)
+    with pytest.raises(V._lib.VmpError):
+        gmm.m_step(x, r, *_mix.default_prior(3, 2, 'cpu'))
+    with pytest.raises(V._lib.VmpError):
+        gmm.inference(x, 3, 0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'vmp-for-svae_amd')
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                src = open(os.path.join(dp, f)).read()
+                assert 'import oracle' not in src and 'from oracle' not in src, f

@@ -1,0 +1,179 @@
+"""T1 parity on the GPU: pure GMM / SMM VMP through the reference-shaped surface (models.gmm / models.smm),
+i.e. through the C ABI, against (a) the golden vectors produced by the reference itself and (b) the oracle
+in fp64 on seeded inputs.  Tolerances: parameters 1e-5 relative to the fp64 truth,
+responsibilities 1e-5 absolute - unless the reference's own fp32 arithmetic is further away than that, in which
+case 'no worse than 2x the reference's fp32 error' is the bar."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL_R = 1e-5, 1e-5
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(a)).to('cuda', dtype)
+
+
+def relerr(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    got = got.detach().double().cpu().numpy()
+    return np.abs(got - want).max() / max(np.abs(want).max(), 1e-300)
+
+
+def abserr(got, want):
+    return np.abs(got.detach().double().cpu().numpy() - np.asarray(want, dtype=np.float64)).max()
+
+
+def bar(g, key, base, rel=True):
+    """tolerance: max(base, 2 x the reference's own fp32-vs-fp64 error on this output)"""
+    a, b = g[key], g[key + '__f32'].astype(np.float64)
+    e = np.abs(a - b).max()
+    if rel:
+        e = e / max(np.abs(a).max(), 1e-300)
+    return max(base, 2 * e)
+
+
+@pytest.mark.parametrize('case', ['gmm_tiny', 'gmm_d6k10', 'gmm_d8k16'])
+def test_gmm_golden(golden, case):
+    from vmp_for_svae_amd.models import gmm, _mix
+    g = golden(case)
+    x, r0 = dev(g['in_x']), dev(g['in_r0'])
+    N, D = x.shape
+    K = r0.shape[1]
+    prior = _mix.default_prior(K, D, x.device)
+    out = gmm.m_step(x, r0, *prior)
+    for n_, t in zip(('alpha', 'beta', 'm', 'C', 'v', 'xk', 'Sk'), out):
+        assert relerr(t, g['gmm0_' + n_]) <= bar(g, 'gmm0_' + n_, RTOL), n_
+    # stand-alone E-step from the reference's own step-0 posterior
+    th = [dev(g['gmm0_' + n_]) for n_ in ('alpha', 'beta', 'm')]
+    r, pi = gmm.e_step(x, th[0], th[1], th[2], dev(g['P0']), dev(g['gmm0_v']))
+    assert abserr(r, g['gmm0_r']) <= bar(g, 'gmm0_r', ATOL_R, rel=False)
+    assert relerr(pi, g['gmm0_pi']) <= bar(g, 'gmm0_pi', RTOL)
+    rm, _ = gmm.e_step_missing_data(x, th[0], th[1], th[2], dev(g['P0']), dev(g['gmm0_v']), dev(g['in_miss'], torch.bool))
+    assert abserr(rm, g['miss_r']) <= bar(g, 'miss_r', ATOL_R, rel=False)
+    # the iteration gmm.inference builds, 3 consecutive steps
+    step, log_r, theta, aux = gmm.inference(x, K, seed=0, r_init=r0)
+    for it in range(3):
+        r = step()
+        assert abserr(r, g['gmm%d_r' % it]) <= bar(g, 'gmm%d_r' % it, ATOL_R, rel=False), it
+        for n_, t in zip(('alpha', 'beta', 'm', 'C', 'v'), theta()):
+            assert relerr(t, g['gmm%d_%s' % (it, n_)]) <= bar(g, 'gmm%d_%s' % (it, n_), RTOL), (it, n_)
+        xk, Sk, pi = aux()
+        assert relerr(xk, g['gmm%d_xk' % it]) <= bar(g, 'gmm%d_xk' % it, RTOL)
+        assert relerr(Sk, g['gmm%d_Sk' % it]) <= bar(g, 'gmm%d_Sk' % it, RTOL)
+        assert relerr(pi, g['gmm%d_pi' % it]) <= bar(g, 'gmm%d_pi' % it, RTOL)
+        lr, want = log_r().double().cpu().numpy(), g['gmm%d_logr' % it]
+        fin = np.isfinite(want) & (want > -80)
+        assert np.abs(lr[fin] - want[fin]).max() <= 1e-3
+
+
+@pytest.mark.parametrize('case', ['gmm_tiny', 'gmm_d6k10', 'gmm_d8k16'])
+def test_smm_golden(golden, case):
+    from vmp_for_svae_amd.models import smm, _mix
+    g = golden(case)
+    x, r0 = dev(g['in_x']), dev(g['in_r0'])
+    N, D = x.shape
+    K = r0.shape[1]
+    kappa = float(g['in_kappa'])
+    prior = _mix.default_prior(K, D, x.device)
+    out = smm.m_step(x, r0, torch.ones_like(r0), *prior)
+    for n_, t in zip(('alpha', 'beta', 'm', 'C', 'v', 'xk', 'Sk'), out):
+        assert relerr(t, g['smm0_' + n_]) <= bar(g, 'smm0_' + n_, RTOL), n_
+    step, log_r, theta, aux = smm.inference(x, K, kappa, seed=0, r_init=r0)
+    for it in range(3):
+        r = step()
+        assert abserr(r, g['smm%d_r' % it]) <= bar(g, 'smm%d_r' % it, ATOL_R, rel=False), it
+        th = theta()
+        for n_, t in zip(('alpha', 'beta', 'm', 'C', 'v'), th):
+            assert relerr(t, g['smm%d_%s' % (it, n_)]) <= bar(g, 'smm%d_%s' % (it, n_), RTOL), (it, n_)
+
+
+def _synth(N, D, K, seed, spread=5.0):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    c = rng.standard_normal((K, D)) * spread
+    x = c[rng.integers(0, K, size=N)] + rng.standard_normal((N, D))
+    r0 = np.exp(3.0 * rng.standard_normal((N, K)))
+    r0 /= r0.sum(1, keepdims=True)
+    return x.astype(np.float32), r0.astype(np.float32)
+
+
+@pytest.mark.parametrize('N,D,K', [(1, 2, 3), (63, 3, 5), (64, 8, 16), (65, 8, 16), (1000, 1, 1), (5000, 5, 17),
+                                   (20000, 8, 16), (20000, 2, 10), (7777, 7, 33), (3000, 4, 64), (4097, 6, 10)])
+def test_vmp_steps_vs_oracle(N, D, K):
+    """ragged tiles, odd K (scalar store path), K > 16 (two/four MFMA row tiles), K=1, D=1 ..."""
+    from oracle import mixtures
+    from vmp_for_svae_amd.models import gmm, smm
+    x, r0 = _synth(N, D, K, seed=N + D + K)
+    xo, ro = torch.as_tensor(x).double(), torch.as_tensor(r0).double()
+    step, _, theta, aux = gmm.inference(dev(x), K, 0, r_init=dev(r0))
+    for it in range(2):
+        ro, _, th_o, aux_o = mixtures.gmm_inference_step(xo, ro)
+        r = step()
+        assert abserr(r, ro.numpy()) <= 2e-5, ('gmm r', it)
+        for t, o in zip(theta(), th_o):
+            assert relerr(t, o.numpy()) <= 2e-5
+        assert relerr(aux()[1], aux_o[1].numpy()) <= 2e-5
+    ro, uo = torch.as_tensor(r0).double(), torch.ones(N, K, dtype=torch.float64)
+    step, _, theta, aux = smm.inference(dev(x), K, 5.0, 0, r_init=dev(r0))
+    for it in range(2):
+        ro, uo, th_o, aux_o = mixtures.smm_inference_step(xo, ro, uo, 5.0)
+        r = step()
+        assert abserr(r, ro.numpy()) <= 5e-5, ('smm r', it)
+        for t, o in zip(theta()[:5], th_o[:5]):
+            assert relerr(t, o.numpy()) <= 5e-5
+
+
+def test_empty_component_and_far_offsets():
+    """N_k == 0 exercises the NaN->un-normalised fallback (gmm.py:34-36,44-46); a 1e3 offset of the data
+    exercises the raw-moment centring in fp64."""
+    from oracle import mixtures, dists
+    from vmp_for_svae_amd.models import gmm, _mix
+    N, D, K = 3000, 4, 6
+    x, r0 = _synth(N, D, K, seed=11)
+    r0[:, 2] = 0.0
+    r0 /= r0.sum(1, keepdims=True)
+    x = x + 1000.0
+    prior = _mix.default_prior(K, D, 'cuda')
+    out = gmm.m_step(dev(x), dev(r0), *prior)
+    want = mixtures.gmm_m_step(torch.as_tensor(x).double(), torch.as_tensor(r0).double(),
+                               *[p.double().cpu() for p in prior])
+    for n_, t, o in zip(('alpha', 'beta', 'm', 'C', 'v', 'xk', 'Sk'), out, want):
+        assert torch.isfinite(t).all(), n_
+        tol = 2e-3 if n_ in ('C', 'Sk') else 2e-5         # centred moments of data offset by 1e3 in fp32 inputs
+        assert relerr(t, o.numpy()) <= tol, n_
+
+
+def test_full_size_properties():
+    """BASELINE config 3 size (N=1e6, D=8, K=16): size-independent invariants."""
+    from vmp_for_svae_amd.models import _mix
+    from vmp_for_svae_amd import _lib as L
+    N, D, K = 1_000_000, 8, 16
+    g = torch.Generator(device='cuda').manual_seed(0)
+    c = torch.randn(K, D, device='cuda', generator=g) * 5
+    z = torch.randint(0, K, (N,), device='cuda', generator=g)
+    x = c[z] + torch.randn(N, D, device='cuda', generator=g)
+    r0 = torch.softmax(3 * torch.randn(N, K, device='cuda', generator=g), dim=1)
+    loop = _mix.VMPLoop(x, r0, L.VMP_GMM)
+    for _ in range(3):
+        r = loop.step()
+    rs = r.double().sum(1)
+    assert (rs - 1).abs().max().item() < 1e-5                       # rows are distributions
+    assert (r >= 0).all()
+    st = loop.stats
+    assert abs(st[:, 0].sum().item() - rs.sum().item()) < 1e-6 * N   # sum_k N_k = sum_nk r
+    # fused statistics == stand-alone statistics of the r that was written
+    st2 = _mix.raw_stats(x, r)
+    assert ((st - st2).abs().max() / st.abs().max()).item() < 1e-12
+    # and they equal a straightforward fp64 evaluation
+    xd, rd = x.double(), r.double()
+    assert ((st[:, 2:2 + D] - rd.t() @ xd).abs().max() / st[:, 2:2 + D].abs().max()).item() < 1e-6
+    sxx = torch.einsum('nk,nd,ne->kde', rd[:200000], xd[:200000], xd[:200000])
+    st3 = _mix.raw_stats(x[:200000].contiguous(), r[:200000].contiguous())
+    assert ((st3[:, 2 + D:].reshape(K, D, D) - sxx).abs().max() / sxx.abs().max()).item() < 1e-6
+    # idempotence at the fixed point is not guaranteed after 3 steps, but determinism is:
+    loop2 = _mix.VMPLoop(x, r0, L.VMP_GMM)
+    for _ in range(3):
+        r2 = loop2.step()
+    assert torch.equal(r, r2)

@@ -1,0 +1,101 @@
+"""ctypes binding of lib/libvmp_hip.so (C ABI: include/vmp_hip.h).  No fallback: if the library is
+missing or a tensor is not a contiguous fp32 GPU tensor, the call raises."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libvmp_hip.so')
+
+VMP_GMM, VMP_SMM = 0, 1
+MAX_D, MAX_K = 8, 64
+
+_lib = None
+
+_c = ctypes
+_P = _c.c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    'vmp_abi_version': (_c.c_int, []),
+    'vmp_last_error': (_c.c_char_p, []),
+    'vmp_mix_pack_words': (_c.c_int, [_c.c_int]),
+    'vmp_mix_stats_words': (_c.c_int, [_c.c_int]),
+    'vmp_mix_workspace_bytes': (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int]),
+    'vmp_mix_stats': (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _P, _P, _c.c_size_t, _P]),
+    'vmp_mix_finalize': (_c.c_int, [_P, _c.c_int, _c.c_int, _c.c_int] + [_P] * 6 + [_P] * 9 + [_P]),
+    'vmp_mix_pack_from_params': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int] + [_P] * 6 + [_P, _P, _P]),
+    'vmp_mix_estep': (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _P, _P,
+                                 _c.c_size_t, _P]),
+    'vmp_mix_estep_fused': (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
+    'vmp_mix_stats_ws': (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _P, _c.c_size_t, _P]),
+    'vmp_mix_finalize_ws': (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int] + [_P] * 6 + [_P] * 9 + [_P, _P]),
+}
+
+
+class VmpError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    """Names include/vmp_hip.h declares (kept in sync by tests/test_abi.py)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load libvmp_hip.so once.  Raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VmpError('libvmp_hip.so not found at %s - build it with `make -C %s` '
+                           '(there is no CPU fallback)' % (LIB_PATH, os.path.join(_HERE, 'csrc')))
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.vmp_abi_version() != 1:
+            raise VmpError('libvmp_hip.so ABI version %d, expected 1' % handle.vmp_abi_version())
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().vmp_last_error()
+        raise VmpError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def dev_f32(t, name, shape=None):
+    """Validate a kernel operand: fp32, contiguous, on a GPU; returns the tensor (made contiguous)."""
+    if not torch.is_tensor(t):
+        raise VmpError('%s must be a torch tensor' % name)
+    if not t.is_cuda:
+        raise VmpError('%s is on %s: the N-sized VMP ops only run in HIP kernels on a GPU (no CPU fallback)'
+                       % (name, t.device))
+    if t.dtype != torch.float32:
+        raise VmpError('%s must be float32 (got %s)' % (name, t.dtype))
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise VmpError('%s has shape %s, expected %s' % (name, tuple(t.shape), tuple(shape)))
+    return t.contiguous()
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_WS = {}
+
+
+def workspace(device, nbytes):
+    """Per-device scratch buffer owned by the host side (the library never allocates)."""
+    key = (device.type, device.index)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf

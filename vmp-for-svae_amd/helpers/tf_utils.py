@@ -1,0 +1,19 @@
+"""Mirror of the hot-path part of reference helpers/tf_utils.py (logdet :25-49, average_gradients :52-87)."""
+import torch
+
+
+def logdet(A, name='logdet'):
+    """log det of SPD matrices (..., D, D) = 2 * sum log diag chol(A)  (reference tf_utils.py:25-49).
+    K-sized use only; the per-(n,k) log-determinants of the hot path live inside the HIP kernels."""
+    return 2.0 * torch.linalg.cholesky(A).diagonal(dim1=-2, dim2=-1).log().sum(-1)
+
+
+def average_gradients(tower_grads):
+    """reference tf_utils.py:52-87: list over towers of [(grad, var), ...] -> [(mean grad, var), ...].
+    In the one-process-per-GPU design the towers are ranks and this mean is one packed RCCL all-reduce
+    (see vmp_for_svae_amd.models.driver); this in-process form is kept for API parity and tests."""
+    out = []
+    for gv in zip(*tower_grads):
+        g = torch.stack([g_ for g_, _ in gv], dim=0).mean(dim=0)
+        out.append((g, gv[0][1]))
+    return out

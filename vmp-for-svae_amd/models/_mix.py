@@ -1,0 +1,191 @@
+"""Host-side engine of the pure mixture VMP (T1): thin wrappers over the vmp_mix_* C ABI
+(include/vmp_hip.h) shared by models/gmm.py and models/smm.py."""
+import torch
+
+from .. import _lib as L
+
+
+def _dims(x, K):
+    N, D = x.shape
+    if not (1 <= D <= L.MAX_D):
+        raise L.VmpError('D=%d outside the compiled range 1..%d' % (D, L.MAX_D))
+    if not (1 <= K <= L.MAX_K):
+        raise L.VmpError('K=%d outside the compiled range 1..%d' % (K, L.MAX_K))
+    return N, D
+
+
+def _ws(x, N, D, K):
+    nbytes = L.lib().vmp_mix_workspace_bytes(N, D, K)
+    return L.workspace(x.device, nbytes), nbytes
+
+
+def raw_stats(x, r, u=None):
+    """(K, 2+D+D*D) fp64 raw moments [Nk | Wk | sum w x | sum w x x^T] (vmp_mix_stats)."""
+    x = L.dev_f32(x, 'x')
+    N, K = r.shape
+    _, D = _dims(x, K)
+    r = L.dev_f32(r, 'r_nk', (N, K))
+    if u is not None:
+        u = L.dev_f32(u, 'u_nk', (N, K))
+    stats = torch.empty((K, L.lib().vmp_mix_stats_words(D)), dtype=torch.float64, device=x.device)
+    ws, nb = _ws(x, N, D, K)
+    L.check(L.lib().vmp_mix_stats(L.ptr(x), L.ptr(r), L.ptr(u), N, D, K, L.ptr(stats), L.ptr(ws), nb, L.stream()),
+            'vmp_mix_stats')
+    return stats
+
+
+def _prior(prior, K, D, dev):
+    a0, b0, m0, C0, v0 = prior
+    return (L.dev_f32(a0.to(dev, torch.float32), 'alpha_0', (K,)), L.dev_f32(b0.to(dev, torch.float32).reshape(K), 'beta_0', (K,)),
+            L.dev_f32(m0.to(dev, torch.float32), 'm_0', (K, D)), L.dev_f32(C0.to(dev, torch.float32), 'C_0', (K, D, D)),
+            L.dev_f32(v0.to(dev, torch.float32), 'v_0', (K,)))
+
+
+def finalize(stats, prior, flavour, kappa=None, want_pack=True):
+    """Posterior (alpha, beta, m, C, v, xbar, S, pi) and the E-step pack from raw stats (vmp_mix_finalize)."""
+    K = stats.shape[0]
+    dev = stats.device
+    D = prior[2].shape[1]
+    a0, b0, m0, C0, v0 = _prior(prior, K, D, dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    out = dict(alpha=torch.empty(K, **f32), beta=torch.empty(K, **f32), m=torch.empty(K, D, **f32),
+               C=torch.empty(K, D, D, **f32), v=torch.empty(K, **f32), xbar=torch.empty(K, D, **f32),
+               S=torch.empty(K, D, D, **f32), pi=torch.empty(K, **f32))
+    pack = torch.empty(K, L.lib().vmp_mix_pack_words(D), **f32) if want_pack else None
+    kap = None if kappa is None else L.dev_f32(kappa.to(dev, torch.float32), 'kappa', (K,))
+    L.check(L.lib().vmp_mix_finalize(L.ptr(stats), D, K, flavour, L.ptr(a0), L.ptr(b0), L.ptr(m0), L.ptr(C0), L.ptr(v0),
+                                     L.ptr(kap), L.ptr(out['alpha']), L.ptr(out['beta']), L.ptr(out['m']),
+                                     L.ptr(out['C']), L.ptr(out['v']), L.ptr(out['xbar']), L.ptr(out['S']),
+                                     L.ptr(out['pi']), L.ptr(pack), L.stream()), 'vmp_mix_finalize')
+    out['pack'] = pack
+    return out
+
+
+def pack_from_params(alpha_k, beta_k, m_k, P_k, v_k, flavour, kappa=None):
+    K, D = m_k.shape
+    dev = m_k.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    args = [L.dev_f32(t.to(torch.float32), n) for t, n in ((alpha_k, 'alpha_k'), (beta_k, 'beta_k'), (m_k, 'm_k'),
+                                                           (P_k, 'P_k'), (v_k, 'v_k'))]
+    kap = None if kappa is None else L.dev_f32(kappa.to(dev, torch.float32), 'kappa', (K,))
+    pack = torch.empty(K, L.lib().vmp_mix_pack_words(D), **f32)
+    pi = torch.empty(K, **f32)
+    L.check(L.lib().vmp_mix_pack_from_params(D, K, flavour, *[L.ptr(t) for t in args], L.ptr(kap), L.ptr(pack),
+                                             L.ptr(pi), L.stream()), 'vmp_mix_pack_from_params')
+    return pack, pi
+
+
+def estep(x, pack, flavour, miss_mask=None, want_logr=False, want_stats=False, r_out=None, u_out=None):
+    """Responsibilities (and SMM scales) for all rows; optionally fused raw stats of the new r."""
+    x = L.dev_f32(x, 'x')
+    K = pack.shape[0]
+    N, D = _dims(x, K)
+    f32 = dict(dtype=torch.float32, device=x.device)
+    r = torch.empty(N, K, **f32) if r_out is None else r_out
+    u = None
+    if flavour == L.VMP_SMM:
+        u = torch.empty(N, K, **f32) if u_out is None else u_out
+    logr = torch.empty(N, K, **f32) if want_logr else None
+    stats = torch.empty((K, L.lib().vmp_mix_stats_words(D)), dtype=torch.float64, device=x.device) if want_stats else None
+    ws, nb = (None, 0)
+    if want_stats:
+        ws, nb = _ws(x, N, D, K)
+    mask = None
+    if miss_mask is not None:
+        if not miss_mask.is_cuda:
+            raise L.VmpError('missing_data_mask must be on the GPU')
+        mask = miss_mask.to(torch.uint8).contiguous()
+    L.check(L.lib().vmp_mix_estep(L.ptr(x), N, D, K, flavour, L.ptr(pack), L.ptr(mask), L.ptr(r), L.ptr(u), L.ptr(logr),
+                                  L.ptr(stats), L.ptr(ws), nb, L.stream()), 'vmp_mix_estep')
+    return r, u, logr, stats
+
+
+def default_prior(K, D, device):
+    """The prior gmm.inference / smm.inference hard-code (reference gmm.py:252-256): init_mm_params(K, D,
+    alpha_scale=0.05/K, beta_scale=0.5, m_scale=0, C_scale=D+0.5, v_init=D+0.5), in standard form."""
+    f32 = dict(dtype=torch.float32, device=device)
+    alpha_0 = torch.full((K,), 0.05 / K, **f32)
+    beta_0 = torch.full((K,), 0.5, **f32)
+    m_0 = torch.zeros(K, D, **f32)
+    C_0 = (D + 0.5) * torch.eye(D, **f32).expand(K, D, D).contiguous()
+    v_0 = torch.full((K,), float(D + D + 0.5), **f32)
+    return alpha_0, beta_0, m_0, C_0, v_0
+
+
+class VMPLoop(object):
+    """The iteration `sess.run(step)` drives in the reference (gmm.py:258-263 / smm.py:232-238):
+    M-step from the current (r, u) -> E-step -> assign.  Here one iteration is TWO launches:
+      vmp_mix_finalize_ws  (K blocks)   reduce the per-block fp64 partial moments + posterior + E-step pack
+      vmp_mix_estep_fused  (streaming)  E-pass that also accumulates the raw moments of ITS OWN output,
+    which are exactly the M-pass input of the next iteration; only the very first iteration needs a
+    stand-alone M-pass (vmp_mix_stats_ws)."""
+
+    def __init__(self, x, r_init, flavour, kappa=None, u_init=None, prior=None):
+        self.x = L.dev_f32(x, 'x')
+        self.N, self.D = self.x.shape
+        self.K = K = r_init.shape[1]
+        _dims(self.x, K)
+        dev = self.x.device
+        self.flavour = flavour
+        self.kappa = None if kappa is None else L.dev_f32(kappa.to(dev, torch.float32), 'kappa', (K,))
+        prior = prior if prior is not None else default_prior(K, self.D, dev)
+        self.prior = _prior(prior, K, self.D, dev)
+        self.r = L.dev_f32(r_init, 'r_nk', (self.N, K)).clone()
+        self.u = None
+        if flavour == L.VMP_SMM:
+            self.u = (torch.ones_like(self.r) if u_init is None else L.dev_f32(u_init, 'u_nk', (self.N, K)).clone())
+        f32 = dict(dtype=torch.float32, device=dev)
+        D = self.D
+        self.post = dict(alpha=torch.empty(K, **f32), beta=torch.empty(K, **f32), m=torch.empty(K, D, **f32),
+                         C=torch.empty(K, D, D, **f32), v=torch.empty(K, **f32), xbar=torch.empty(K, D, **f32),
+                         S=torch.empty(K, D, D, **f32), pi=torch.empty(K, **f32),
+                         pack=torch.empty(K, L.lib().vmp_mix_pack_words(D), **f32))
+        self.logr = None
+        self.nb = L.lib().vmp_mix_workspace_bytes(self.N, D, K)
+        self.ws = torch.empty(self.nb, dtype=torch.uint8, device=dev)      # private: partials live across calls
+        L.check(L.lib().vmp_mix_stats_ws(L.ptr(self.x), L.ptr(self.r), L.ptr(self.u), self.N, D, K, L.ptr(self.ws),
+                                         self.nb, L.stream()), 'vmp_mix_stats_ws')
+        self.iterations = 0
+
+    def finalize(self, stats_out=None):
+        p, pr = self.post, self.prior
+        L.check(L.lib().vmp_mix_finalize_ws(L.ptr(self.ws), self.N, self.D, self.K, self.flavour, L.ptr(pr[0]),
+                                            L.ptr(pr[1]), L.ptr(pr[2]), L.ptr(pr[3]), L.ptr(pr[4]), L.ptr(self.kappa),
+                                            L.ptr(p['alpha']), L.ptr(p['beta']), L.ptr(p['m']), L.ptr(p['C']),
+                                            L.ptr(p['v']), L.ptr(p['xbar']), L.ptr(p['S']), L.ptr(p['pi']),
+                                            L.ptr(p['pack']), L.ptr(stats_out), L.stream()), 'vmp_mix_finalize_ws')
+
+    def finalize_phase(self):
+        """everything of an iteration that is not the streaming pass (bench.py brackets the pass with events)"""
+        self.finalize()
+
+    def estep(self, want_logr=False):
+        if want_logr and self.logr is None:
+            self.logr = torch.empty_like(self.r)
+        L.check(L.lib().vmp_mix_estep_fused(L.ptr(self.x), self.N, self.D, self.K, self.flavour, L.ptr(self.post['pack']),
+                                            L.ptr(self.r), L.ptr(self.u), L.ptr(self.logr if want_logr else None),
+                                            L.ptr(self.ws), self.nb, L.stream()), 'vmp_mix_estep_fused')
+
+    def step(self, want_logr=False):
+        self.finalize_phase()
+        self.estep(want_logr)
+        self.iterations += 1
+        return self.r
+
+    @property
+    def stats(self):
+        """Raw moments of the current r (reduces the partials the last pass left in the workspace)."""
+        st = torch.empty((self.K, L.lib().vmp_mix_stats_words(self.D)), dtype=torch.float64, device=self.x.device)
+        keep = {k: v.clone() for k, v in self.post.items()}
+        self.finalize(stats_out=st)
+        for k, v in keep.items():
+            self.post[k].copy_(v)
+        return st
+
+    def theta(self):
+        p = self.post
+        return p['alpha'], p['beta'], p['m'], p['C'], p['v']
+
+    def aux(self):
+        p = self.post
+        return p['xbar'], p['S'], p['pi']
