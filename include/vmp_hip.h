@@ -63,8 +63,14 @@ size_t vmp_mix_workspace_bytes(int64_t N, int D, int K);
  * (models/smm.py:25-50); the centring (x - x_k) the reference does in a second pass is done in fp64 in
  * vmp_mix_finalize / on the host side from the raw moments.
  *   x (N,D), r (N,K), u (N,K) or NULL (then w = r).   stats: (K, vmp_mix_stats_words(D)) fp64, overwritten.  */
-int    vmp_mix_stats(const float* x, const float* r, const float* u, int64_t N, int D, int K,
+int    vmp_mix_stats(const float* x, const float* r, const float* u, const float* pivot, int64_t N, int D, int K,
                      double* stats, void* ws, size_t ws_bytes, void* stream);
+
+/* Pivot for the moment accumulation (D floats): the mean of up to 4096 evenly strided rows of x.  The moment
+ * kernels accumulate products of (x - pivot) in fp32 and the finalize kernels un-shift exactly in fp64, which
+ * makes the one-pass raw-moment form as accurate as the reference's two-pass centred update_Sk (gmm.py:39-46)
+ * for data far from the origin.  `pivot` arguments below may be NULL (no shift).                           */
+int    vmp_mix_pivot(const float* x, int64_t N, int D, float* pivot_out, void* stream);
 
 /* K-sized posterior update + E-step parameter pack, all in fp64 on the device, rounded to fp32 on output.
  * Replaces gmm.update_alphak/betak/mk/Ck/vk (models/gmm.py:49-81), P_k = matrix_inverse(C_k) (gmm.py:260),
@@ -96,7 +102,7 @@ int    vmp_mix_pack_from_params(int D, int K, int flavour, const float* alpha, c
  *   stats_out (K, vmp_mix_stats_words(D)) fp64 or NULL; ws needed only when stats_out != NULL.            */
 int    vmp_mix_estep(const float* x, int64_t N, int D, int K, int flavour, const float* pack,
                      const uint8_t* miss_mask, float* r_out, float* u_out, float* logr_out,
-                     double* stats_out, void* ws, size_t ws_bytes, void* stream);
+                     const float* pivot, double* stats_out, void* ws, size_t ws_bytes, void* stream);
 
 /* Fast path of the VMP iteration - exactly two launches per iteration, no intermediate stats buffer:
  *   vmp_mix_estep_fused : the E-pass kernel with fused raw moments; leaves per-block fp64 partials in `ws`
@@ -106,10 +112,11 @@ int    vmp_mix_estep(const float* x, int64_t N, int D, int K, int flavour, const
  * M-pass leaving partials in ws (first iteration).  Reference: the loop body of gmm.inference
  * (models/gmm.py:258-263) / smm.inference (models/smm.py:232-238).                                          */
 int    vmp_mix_estep_fused(const float* x, int64_t N, int D, int K, int flavour, const float* pack,
-                           float* r_out, float* u_out, float* logr_out, void* ws, size_t ws_bytes, void* stream);
-int    vmp_mix_stats_ws(const float* x, const float* r, const float* u, int64_t N, int D, int K,
+                           float* r_out, float* u_out, float* logr_out, const float* pivot,
+                           void* ws, size_t ws_bytes, void* stream);
+int    vmp_mix_stats_ws(const float* x, const float* r, const float* u, const float* pivot, int64_t N, int D, int K,
                         void* ws, size_t ws_bytes, void* stream);
-int    vmp_mix_finalize_ws(const void* ws, int64_t N, int D, int K, int flavour,
+int    vmp_mix_finalize_ws(const void* ws, const float* pivot, int64_t N, int D, int K, int flavour,
                            const float* alpha0, const float* beta0, const float* m0, const float* C0, const float* v0,
                            const float* kappa,
                            float* alpha, float* beta, float* m, float* C, float* v, float* xbar, float* S, float* pi,

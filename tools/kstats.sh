@@ -1,0 +1,11 @@
+#!/bin/bash
+# usage: tools/kstats.sh <tag> <script> : rocprofv3 kernel stats (true GPU durations) for our kernels
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/ks_$1; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o k -- python3 $R/$2 > /dev/null 2>&1
+python3 - <<PY
+import csv
+for row in csv.DictReader(open('$OUT/k_kernel_stats.csv')):
+    n=row['Name']
+    if 'pass_kernel' in n or 'finalize' in n or 'pivot' in n or 'pack_kernel' in n:
+        print('%-70s calls %4s avg %9.1f us  min %9.1f' % (n[28:98], row['Calls'], float(row['AverageNs'])/1e3, float(row['MinNs'])/1e3))
+PY

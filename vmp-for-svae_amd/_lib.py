@@ -22,14 +22,15 @@ _SIGNATURES = {
     'vmp_mix_pack_words': (_c.c_int, [_c.c_int]),
     'vmp_mix_stats_words': (_c.c_int, [_c.c_int]),
     'vmp_mix_workspace_bytes': (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int]),
-    'vmp_mix_stats': (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _P, _P, _c.c_size_t, _P]),
+    'vmp_mix_stats': (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _P, _P, _c.c_size_t, _P]),
+    'vmp_mix_pivot': (_c.c_int, [_P, _c.c_int64, _c.c_int, _P, _P]),
     'vmp_mix_finalize': (_c.c_int, [_P, _c.c_int, _c.c_int, _c.c_int] + [_P] * 6 + [_P] * 9 + [_P]),
     'vmp_mix_pack_from_params': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int] + [_P] * 6 + [_P, _P, _P]),
-    'vmp_mix_estep': (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _P, _P,
+    'vmp_mix_estep': (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _P, _P, _P,
                                  _c.c_size_t, _P]),
-    'vmp_mix_estep_fused': (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
-    'vmp_mix_stats_ws': (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _P, _c.c_size_t, _P]),
-    'vmp_mix_finalize_ws': (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int] + [_P] * 6 + [_P] * 9 + [_P, _P]),
+    'vmp_mix_estep_fused': (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
+    'vmp_mix_stats_ws': (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _P, _c.c_size_t, _P]),
+    'vmp_mix_finalize_ws': (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int] + [_P] * 6 + [_P] * 9 + [_P, _P]),
 }
 
 

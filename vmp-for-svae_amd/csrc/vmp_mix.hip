@@ -1,30 +1,39 @@
 // T1: pure mixture VMP (GMM: reference models/gmm.py:25-269; SMM: models/smm.py:25-245) for gfx950.
 //
-// One streaming "pass" kernel does, per wave, tiles of 64 data rows (one row per lane):
-//   E-part  (VALU, per lane):  q_nk = ||W_k (x_n - m_k)||^2  for all k,  softmax over k  -> r_nk (u_nk)
-//   M-part  (MFMA, per wave):  sum_n w_nk * [1 | x_n | x_n x_n^T]  as a 16x16x4 fp32 MFMA GEMM whose inner
-//                              index is the data row: A = w (K x rows), B = features (rows x F)
-// Both parts exchange data through a per-wave LDS image laid out [row-of-values][64 lanes] with stride 66
-// floats (66 = 2 mod 32 makes the MFMA operand reads (16 components x 4 rows per instruction) bank-conflict
-// free, and lane-private accesses are conflict free by construction).  fp32 MFMA accumulators are flushed
-// into fp64 registers after every tile; per-block fp64 partials go to the workspace and are reduced in a
-// fixed order by the finalize kernel (deterministic, no atomics).
+// One streaming "pass" kernel.  A wave processes tiles of 64 data rows; inside a tile it walks 8 steps of
+// 8 rows.  Lane l = (i16 = l & 15, kk = l >> 4) owns mixture component k = i16 (+16 per extra component tile)
+// and data rows n0+kk and n0+4+kk of the step - which is exactly the operand layout of the 16x16x4 fp32 MFMA
+// (A[i = l&15][inner = l>>4]), so the two parts of the pass share registers:
+//   E-part  (packed fp32 VALU): q = ||W_k (x_n - m_k)||^2 with W_k, m_k resident in the lane's VGPRs (loaded once
+//            per kernel), the two rows of the lane packed into v_pk_fma_f32; softmax over k = all-reduce over the
+//            16 lanes of a DPP row (v_*_dpp row_ror), no LDS, no scalar loads in the loop;
+//   M-part  (MFMA): sum_n w_nk * [1 | x_n | x_n x_n^T] as a GEMM with the data row as inner index: A = w straight
+//            from the E-part's registers, B = features built from the per-wave LDS image of the x tile.
+// r_nk leaves the E-part in a layout whose 64 lanes cover 4 consecutive rows x 16 components = contiguous
+// memory, so it is stored coalesced without a transpose.  The x tile is staged once per tile in LDS as
+// [d][row] with stride 66 floats (66 = 2 mod 32: the (16 feature columns x 4 rows) operand reads hit 32
+// distinct banks per half-wave).  fp32 MFMA accumulators are flushed into fp64 registers after every tile;
+// per-block fp64 partials go to the workspace and are reduced in a fixed order by the finalize kernel
+// (deterministic, no atomics).
 #include "vmp_common.h"
+#include <stdlib.h>
 
 using namespace vmp;
 
 namespace {
 
 constexpr int TR = 64;        // data rows per wave tile
-constexpr int LS = 66;        // LDS stride (floats) between value-rows
+constexpr int LS = 66;        // LDS stride (floats) between value-rows of the x image
 constexpr int MAX_NW = 8;     // waves per block
-constexpr int MAX_BLOCKS = 512;
+constexpr int MAX_BLOCKS = 1024;   // upper bound (workspace sizing); the plan uses tuned_blocks
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct PassArgs {
     const float* x;
     const float* r_in;
     const float* u_in;
     const uint8_t* mask;
+    const float* pivot;   // D floats subtracted from x before anything is formed (NULL: none)
     const float* pack;
     float* r_out;
     float* u_out;
@@ -33,7 +42,7 @@ struct PassArgs {
     long long N;
     long long ntiles;
     int K;
-    int vec_ok;       // x / r pointers 16-byte aligned (vector path allowed)
+    int vec_ok;       // x pointer 16-byte aligned (vector row loads allowed)
 };
 
 template <int D>
@@ -61,50 +70,27 @@ __device__ __forceinline__ void load_row(const float* __restrict__ p, float (&o)
     for (int j = 0; j < D; ++j) o[j] = p[j];
 }
 
-// LDS area [K][LS] (64 rows of a tile, transposed)  ->  global row-major chunk g[rows*K], coalesced.
-__device__ __forceinline__ void tile_store(float* __restrict__ g, const float* area, int K, float invK, int rows,
-                                           int lane, bool vec, bool as_log) {
-    const int tot = rows * K;
-    if (vec && (K & 3) == 0) {
-        for (int q = 4 * lane; q < tot; q += 4 * WAVE) {
-            const int n = (int)(((float)q + 0.5f) * invK);
-            const int k = q - n * K;
-            float4 v;
-            v.x = area[(k + 0) * LS + n]; v.y = area[(k + 1) * LS + n];
-            v.z = area[(k + 2) * LS + n]; v.w = area[(k + 3) * LS + n];
-            if (as_log) { v.x = logf(v.x); v.y = logf(v.y); v.z = logf(v.z); v.w = logf(v.w); }
-            *reinterpret_cast<float4*>(g + q) = v;
-        }
-    } else {
-        for (int q = lane; q < tot; q += WAVE) {
-            const int n = (int)(((float)q + 0.5f) * invK);
-            const int k = q - n * K;
-            float v = area[k * LS + n];
-            g[q] = as_log ? logf(v) : v;
-        }
-    }
+// all-reduce over the 16 lanes of a DPP row (= the 16 components of one data row) by row rotations.
+// Hand-written DPP: one instruction per butterfly step.  The two wait states a DPP read needs after a VALU
+// write of the same VGPR are explicit (hipcc's hazard recogniser does not look inside asm).
+#define VMP_DPP2(OP, CTRL)                                                   \
+    "v_" OP "_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"  \
+    "v_" OP "_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"  \
+    "s_nop 0\n\t"
+// two independent reductions interleaved: the partner's instruction is one of the two wait states
+__device__ __forceinline__ v2f row16_max2(v2f v) {
+    float a = v.x, b = v.y;
+    asm("s_nop 1\n\t" VMP_DPP2("max", "row_ror:8") VMP_DPP2("max", "row_ror:4") VMP_DPP2("max", "row_ror:2")
+        VMP_DPP2("max", "row_ror:1")
+        : "+v"(a), "+v"(b));
+    return v2f{a, b};
 }
-
-// global row-major chunk -> LDS area (transposed); rows beyond `rows` are zero-filled.
-__device__ __forceinline__ void tile_load(const float* __restrict__ g, float* area, int K, float invK, int rows,
-                                          int lane, bool vec) {
-    const int tot = rows * K, full = TR * K;
-    if (vec && (K & 3) == 0) {
-        for (int q = 4 * lane; q < full; q += 4 * WAVE) {
-            const int n = (int)(((float)q + 0.5f) * invK);
-            const int k = q - n * K;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < tot) v = *reinterpret_cast<const float4*>(g + q);
-            area[(k + 0) * LS + n] = v.x; area[(k + 1) * LS + n] = v.y;
-            area[(k + 2) * LS + n] = v.z; area[(k + 3) * LS + n] = v.w;
-        }
-    } else {
-        for (int q = lane; q < full; q += WAVE) {
-            const int n = (int)(((float)q + 0.5f) * invK);
-            const int k = q - n * K;
-            area[k * LS + n] = (q < tot) ? g[q] : 0.f;
-        }
-    }
+__device__ __forceinline__ v2f row16_sum2(v2f v) {
+    float a = v.x, b = v.y;
+    asm("s_nop 1\n\t" VMP_DPP2("add", "row_ror:8") VMP_DPP2("add", "row_ror:4") VMP_DPP2("add", "row_ror:2")
+        VMP_DPP2("add", "row_ror:1")
+        : "+v"(a), "+v"(b));
+    return v2f{a, b};
 }
 
 template <int D, int KT, int FLAV, bool ESTEP, bool STATS, bool MASK>
@@ -116,21 +102,37 @@ __global__ __launch_bounds__(MAX_NW * WAVE) void pass_kernel(PassArgs a) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int K = a.K;
-    const float invK = 1.0f / (float)K;
-    const int nareas = SMM ? 3 : 1;
-    const int wreg = (G::XROWS + nareas * K) * LS;
-    float* xl = smem + wave * wreg;            // [XROWS][LS]: x columns, ones, zeros
-    float* wl = xl + G::XROWS * LS;            // [K][LS]: logits -> e -> w (= r, or r*u for SMM)
-    float* rl = wl + K * LS;                   // SMM: r
-    float* ul = rl + K * LS;                   // SMM: u
+    float* xl = smem + wave * (G::XROWS * LS);     // [XROWS][LS]: (x - pivot) columns, ones, zeros
     constexpr int ONE = D, ZERO = D + 1;
     xl[ONE * LS + lane] = 1.0f;
     xl[ZERO * LS + lane] = 0.0f;
-    if (lane < LS - WAVE) { xl[ONE * LS + WAVE + lane] = 0.f; xl[ZERO * LS + WAVE + lane] = 0.f; }
 
-    // ---- per-lane MFMA operand addressing: lane = (i16 = M/N index, kk = inner index = data row n0+kk)
     const int i16 = lane & 15, kk = lane >> 4;
-    int offA[FT], offB[FT], offW[KT], offR[KT];
+    float pv[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) pv[j] = a.pivot ? a.pivot[j] : 0.f;
+
+    // ---- this lane's component parameters, resident for the whole kernel
+    float pm[KT][D], pw[KT][G::TRI], pc[KT], ph[KT], pua[KT], pub[KT];
+    if constexpr (ESTEP) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const int k = kt * 16 + i16;
+            const bool on = k < K;
+            const float* __restrict__ p = a.pack + (on ? k : 0) * G::PACK;
+#pragma unroll
+            for (int j = 0; j < D; ++j) pm[kt][j] = on ? p[j] - pv[j] : 0.f;
+#pragma unroll
+            for (int j = 0; j < G::TRI; ++j) pw[kt][j] = on ? p[D + j] : 0.f;
+            pc[kt] = on ? p[D + G::TRI] : -INFINITY;          // log2-domain constant; -inf switches the lane off
+            ph[kt] = on ? p[D + G::TRI + 1] : 0.f;
+            pua[kt] = on ? p[D + G::TRI + 2] : 0.f;
+            pub[kt] = on ? p[D + G::TRI + 3] : 1.f;
+        }
+    }
+
+    // ---- MFMA B-operand addressing: lane = (feature column i16, inner index kk = data row n0+kk)
+    int offA[FT], offB[FT];
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft) {
         const int f = ft * 16 + i16;
@@ -144,12 +146,6 @@ __global__ __launch_bounds__(MAX_NW * WAVE) void pass_kernel(PassArgs a) {
         }
         offA[ft] = ra * LS + kk;
         offB[ft] = rb * LS + kk;
-    }
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-        const int k = kt * 16 + i16;
-        offW[kt] = (k < K) ? (G::XROWS + k) * LS + kk : ZERO * LS + kk;
-        offR[kt] = (k < K) ? (G::XROWS + K + k) * LS + kk : ZERO * LS + kk;
     }
 
     f32x4 acc[KT][FT];
@@ -180,102 +176,140 @@ __global__ __launch_bounds__(MAX_NW * WAVE) void pass_kernel(PassArgs a) {
         if (t < a.ntiles && n < a.N) load_row<D>(a.x + n * D, xr, vec);
     }
     for (; t < a.ntiles; t += tstride) {
-        const long long n = t * TR + lane;
-        const bool valid = n < a.N;
-        const long long rem = a.N - t * TR;
-        const int rows = rem < TR ? (int)rem : TR;
-        // prefetch the next tile's row while this one is processed
-        float xn[D];
+        const long long row0 = t * TR;
+        // stage this tile's rows (transposed, pivot-shifted), then prefetch the next tile's row
         {
+            const bool valid = row0 + lane < a.N;
+#pragma unroll
+            for (int j = 0; j < D; ++j) xl[j * LS + lane] = valid ? xr[j] - pv[j] : 0.f;
             const long long n2 = (t + tstride) * TR + lane;
 #pragma unroll
-            for (int j = 0; j < D; ++j) xn[j] = 0.f;
-            if (t + tstride < a.ntiles && n2 < a.N) load_row<D>(a.x + n2 * D, xn, vec);
+            for (int j = 0; j < D; ++j) xr[j] = 0.f;
+            if (t + tstride < a.ntiles && n2 < a.N) load_row<D>(a.x + n2 * D, xr, vec);
         }
+        __builtin_amdgcn_wave_barrier();
 
-        if constexpr (ESTEP) {
-            bool mk[D];
-            if constexpr (MASK) {
+        // this lane's element of r/u/logr for (row0 + kk, component i16) - everything else is a 32-bit offset
+        const long long tbase = (row0 + kk) * K + i16;
+        const int K4 = 4 * K;
+#pragma unroll 1
+        for (int n0 = 0; n0 < TR; n0 += 8) {
+            const long long ra = row0 + n0 + kk, rb = ra + 4;             // this lane's two data rows
+            const bool va = ra < a.N, vb = rb < a.N;
+            const int so = n0 * K;                                        // wave-uniform
+            v2f w[KT], rr[KT];
+            if constexpr (ESTEP) {
+                v2f xv[D];
 #pragma unroll
-                for (int j = 0; j < D; ++j) mk[j] = valid ? (a.mask[n * D + j] != 0) : false;
-            }
-            float mx = -INFINITY;
-            for (int k = 0; k < K; ++k) {
-                const float* __restrict__ p = a.pack + k * G::PACK;      // wave-uniform -> scalar loads
-                float dv[D];
+                for (int j = 0; j < D; ++j) xv[j] = v2f{xl[j * LS + n0 + kk], xl[j * LS + n0 + 4 + kk]};
+                v2f keep[D];
+                if constexpr (MASK) {
 #pragma unroll
-                for (int j = 0; j < D; ++j) {
-                    dv[j] = xr[j] - p[j];
-                    if constexpr (MASK) dv[j] = mk[j] ? 0.f : dv[j];
+                    for (int j = 0; j < D; ++j)
+                        keep[j] = v2f{(va && a.mask[ra * D + j] != 0) ? 0.f : 1.f, (vb && a.mask[rb * D + j] != 0) ? 0.f : 1.f};
                 }
-                float q = 0.f;
-                int idx = D;
+                v2f lg[KT], uu[KT];
+                v2f mx = v2f{-INFINITY, -INFINITY};
 #pragma unroll
-                for (int i = 0; i < D; ++i) {
-                    float y = 0.f;
+                for (int kt = 0; kt < KT; ++kt) {
+                    v2f dv[D];
 #pragma unroll
-                    for (int j = 0; j <= i; ++j) y = fmaf(p[idx++], dv[j], y);
-                    q = fmaf(y, y, q);
+                    for (int j = 0; j < D; ++j) {
+                        dv[j] = xv[j] - pm[kt][j];
+                        if constexpr (MASK) dv[j] = dv[j] * keep[j];
+                    }
+                    // y = W (x - m), W lower triangular packed row-major; walked by COLUMNS so that the D
+                    // accumulators form independent dependency chains (a row-wise walk is latency-bound)
+                    v2f y[D];
+#pragma unroll
+                    for (int i = 0; i < D; ++i) y[i] = dv[0] * pw[kt][i * (i + 1) / 2];
+#pragma unroll
+                    for (int j = 1; j < D; ++j)
+#pragma unroll
+                        for (int i = j; i < D; ++i) {
+                            const float wij = pw[kt][i * (i + 1) / 2 + j];
+                            y[i] = __builtin_elementwise_fma(dv[j], v2f{wij, wij}, y[i]);
+                        }
+                    v2f q = y[0] * y[0], q1 = v2f{0.f, 0.f};
+#pragma unroll
+                    for (int i = 1; i < D; ++i) {
+                        if (i & 1) q1 = __builtin_elementwise_fma(y[i], y[i], q1);
+                        else q = __builtin_elementwise_fma(y[i], y[i], q);
+                    }
+                    q += q1;
+                    lg[kt] = v2f{pc[kt], pc[kt]} - q * ph[kt];            // log2 rho
+                    mx = __builtin_elementwise_max(mx, lg[kt]);
+                    if constexpr (SMM) uu[kt] = v2f{pua[kt] * __builtin_amdgcn_rcpf(q.x + pub[kt]), pua[kt] * __builtin_amdgcn_rcpf(q.y + pub[kt])};
                 }
-                const float lg = fmaf(-p[D + G::TRI + 1], q, p[D + G::TRI]);
-                wl[k * LS + lane] = lg;
-                mx = fmaxf(mx, lg);
-                if constexpr (SMM) ul[k * LS + lane] = p[D + G::TRI + 2] / (q + p[D + G::TRI + 3]);
-            }
-            float s = 0.f;
-            for (int k = 0; k < K; ++k) {
-                const float e = __expf(wl[k * LS + lane] - mx);
-                wl[k * LS + lane] = e;
-                s += e;
-            }
-            const float inv = 1.0f / s;
-            for (int k = 0; k < K; ++k) {
-                const float r = wl[k * LS + lane] * inv;
-                if constexpr (SMM) {
-                    rl[k * LS + lane] = valid ? r : 0.f;
-                    wl[k * LS + lane] = valid ? r * ul[k * LS + lane] : 0.f;
-                } else {
-                    wl[k * LS + lane] = valid ? r : 0.f;
+                mx = row16_max2(mx);
+                v2f ssum = v2f{0.f, 0.f};
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    lg[kt] = v2f{__builtin_amdgcn_exp2f(lg[kt].x - mx.x), __builtin_amdgcn_exp2f(lg[kt].y - mx.y)};
+                    ssum += lg[kt];
                 }
-            }
-            __builtin_amdgcn_wave_barrier();
-            const float* rsrc = SMM ? rl : wl;
-            tile_store(a.r_out + t * TR * K, rsrc, K, invK, rows, lane, vec, false);
-            if (a.logr_out) tile_store(a.logr_out + t * TR * K, rsrc, K, invK, rows, lane, vec, true);
-            if constexpr (SMM) tile_store(a.u_out + t * TR * K, ul, K, invK, rows, lane, vec, false);
-        } else {
-            // stats only: bring r (and u) in, coalesced, transposed into LDS
-            if constexpr (SMM) {
-                tile_load(a.r_in + t * TR * K, rl, K, invK, rows, lane, vec);
-                tile_load(a.u_in + t * TR * K, ul, K, invK, rows, lane, vec);
-                __builtin_amdgcn_wave_barrier();
-                for (int k = 0; k < K; ++k) wl[k * LS + lane] = rl[k * LS + lane] * ul[k * LS + lane];
+                ssum = row16_sum2(ssum);
+                const v2f inv = v2f{va ? __builtin_amdgcn_rcpf(ssum.x) : 0.f, vb ? __builtin_amdgcn_rcpf(ssum.y) : 0.f};
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    const int k = kt * 16 + i16;
+                    rr[kt] = lg[kt] * inv;
+                    w[kt] = SMM ? rr[kt] * uu[kt] : rr[kt];
+                    const bool sa = va && k < K, sb = vb && k < K;
+                    float* __restrict__ ro = a.r_out + tbase + kt * 16;
+                    if (sa) ro[so] = rr[kt].x;
+                    if (sb) ro[so + K4] = rr[kt].y;
+                    if constexpr (SMM) {
+                        float* __restrict__ uo = a.u_out + tbase + kt * 16;
+                        if (sa) uo[so] = uu[kt].x;
+                        if (sb) uo[so + K4] = uu[kt].y;
+                    }
+                    if (a.logr_out) {
+                        float* __restrict__ lo = a.logr_out + tbase + kt * 16;
+                        if (sa) lo[so] = logf(rr[kt].x);
+                        if (sb) lo[so + K4] = logf(rr[kt].y);
+                    }
+                }
             } else {
-                tile_load(a.r_in + t * TR * K, wl, K, invK, rows, lane, vec);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    const int k = kt * 16 + i16;
+                    const bool on = k < K;
+                    const float* __restrict__ ri = a.r_in + tbase + kt * 16;
+                    rr[kt] = v2f{(on && va) ? ri[so] : 0.f, (on && vb) ? ri[so + K4] : 0.f};
+                    if constexpr (SMM) {
+                        const float* __restrict__ ui = a.u_in + tbase + kt * 16;
+                        const v2f u2 = v2f{(on && va) ? ui[so] : 0.f, (on && vb) ? ui[so + K4] : 0.f};
+                        w[kt] = rr[kt] * u2;
+                    } else {
+                        w[kt] = rr[kt];
+                    }
+                }
+            }
+
+            if constexpr (STATS) {
+                float b0[FT], b4[FT];
+#pragma unroll
+                for (int ft = 0; ft < FT; ++ft) {
+                    b0[ft] = xl[offA[ft] + n0] * xl[offB[ft] + n0];
+                    b4[ft] = xl[offA[ft] + n0 + 4] * xl[offB[ft] + n0 + 4];
+                }
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+                    for (int ft = 0; ft < FT; ++ft) {
+                        acc[kt][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[kt].x, b0[ft], acc[kt][ft], 0, 0, 0);
+                        acc[kt][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[kt].y, b4[ft], acc[kt][ft], 0, 0, 0);
+                    }
+                    if constexpr (SMM) {
+                        nacc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(rr[kt].x, b0[0], nacc[kt], 0, 0, 0);
+                        nacc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(rr[kt].y, b4[0], nacc[kt], 0, 0, 0);
+                    }
+                }
             }
         }
 
         if constexpr (STATS) {
-#pragma unroll
-            for (int j = 0; j < D; ++j) xl[j * LS + lane] = valid ? xr[j] : 0.f;
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-            for (int n0 = 0; n0 < TR; n0 += 4) {
-                float b[FT];
-#pragma unroll
-                for (int ft = 0; ft < FT; ++ft) b[ft] = xl[offA[ft] + n0] * xl[offB[ft] + n0];
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt) {
-                    const float aw = xl[offW[kt] + n0];
-#pragma unroll
-                    for (int ft = 0; ft < FT; ++ft)
-                        acc[kt][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, b[ft], acc[kt][ft], 0, 0, 0);
-                    if constexpr (SMM) {
-                        const float ar = xl[offR[kt] + n0];
-                        nacc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar, b[0], nacc[kt], 0, 0, 0);
-                    }
-                }
-            }
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
@@ -288,10 +322,8 @@ __global__ __launch_bounds__(MAX_NW * WAVE) void pass_kernel(PassArgs a) {
 #pragma unroll
                 for (int ft = 0; ft < FT; ++ft) acc[kt][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            __builtin_amdgcn_wave_barrier();
         }
-#pragma unroll
-        for (int j = 0; j < D; ++j) xr[j] = xn[j];
+        __builtin_amdgcn_wave_barrier();
     }
 
     if constexpr (STATS) {
@@ -346,6 +378,7 @@ struct FinArgs {
     const double* stats_in;    // [K][SW]         (src == 1)
     int nblk, K, flavour, src, do_post;
     const float *alpha0, *beta0, *m0, *C0, *v0, *kappa;
+    const float* pivot;        // the shift the pass kernel applied to x (src == 0 only; NULL: none)
     float *alpha, *beta, *m, *C, *v, *xbar, *S, *pi, *pack;
     double* stats_out;
 };
@@ -359,39 +392,96 @@ __device__ void write_pack(float* pack, int k, const double* m, const double* W 
     for (int j = 0; j < D; ++j) p[j] = (float)m[j];
     for (int i = 0; i < D; ++i)
         for (int j = 0; j <= i; ++j) p[idx++] = (float)W[i * D + j];
-    p[idx++] = (float)c; p[idx++] = (float)h; p[idx++] = (float)ua; p[idx++] = (float)ub;
+    const double LOG2E = 1.4426950408889634074;          // the pass kernel evaluates 2^(c - h q)
+    p[idx++] = (float)(c * LOG2E); p[idx++] = (float)(h * LOG2E); p[idx++] = (float)ua; p[idx++] = (float)ub;
 }
 
 // Cholesky of SPD A (DxD, row-major) -> lower L (in place, upper zeroed).  Returns false if not SPD.
+// Fully unrolled so that the matrix lives in registers (runtime-indexed local arrays would go to scratch).
 template <int D>
-__device__ bool chol_lower(double* A) {
+__device__ __forceinline__ bool chol_lower(double (&A)[D * D]) {
+    bool ok = true;
+#pragma unroll
     for (int j = 0; j < D; ++j) {
         double s = A[j * D + j];
+#pragma unroll
         for (int p = 0; p < j; ++p) s -= A[j * D + p] * A[j * D + p];
-        if (!(s > 0.0)) return false;
+        ok = ok && (s > 0.0);
         const double d = sqrt(s);
+        const double rd = 1.0 / d;
         A[j * D + j] = d;
+#pragma unroll
         for (int i = j + 1; i < D; ++i) {
             double t = A[i * D + j];
+#pragma unroll
             for (int p = 0; p < j; ++p) t -= A[i * D + p] * A[j * D + p];
-            A[i * D + j] = t / d;
+            A[i * D + j] = t * rd;
         }
+#pragma unroll
         for (int i = 0; i < j; ++i) A[i * D + j] = 0.0;
     }
-    return true;
+    return ok;
 }
 
 // inverse of lower-triangular L -> Li (lower)
 template <int D>
-__device__ void tri_inv_lower(const double* L, double* Li) {
+__device__ __forceinline__ void tri_inv_lower(const double (&L)[D * D], double (&Li)[D * D]) {
+#pragma unroll
     for (int i = 0; i < D * D; ++i) Li[i] = 0.0;
+#pragma unroll
     for (int j = 0; j < D; ++j) {
         Li[j * D + j] = 1.0 / L[j * D + j];
+#pragma unroll
         for (int i = j + 1; i < D; ++i) {
             double s = 0.0;
+#pragma unroll
             for (int p = j; p < i; ++p) s += L[i * D + p] * Li[p * D + j];
             Li[i * D + j] = -s / L[i * D + i];
         }
+    }
+}
+
+
+__device__ __forceinline__ double readlane_d(double v, int src_lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src_lane);
+    hi = __builtin_amdgcn_readlane(hi, src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Wave-parallel factorisation of the SPD matrix A (DxD in LDS): lane i owns row i.  Cholesky A = L L^T by
+// columns (finished entries are broadcast with v_readlane, so the code is uniform across lanes), then lane c
+// solves L X = e_c, i.e. holds column c of L^{-1}.  Returns X (column `lane`), sum_i log L_ii and SPD-ness.
+template <int D>
+__device__ __forceinline__ void wave_chol_inverse(const double* A, int lane, double (&X)[D], double& sumlog, bool& ok) {
+    double row[D], rd[D];
+#pragma unroll
+    for (int e = 0; e < D; ++e)
+        row[e] = lane < D ? 0.5 * (A[lane * D + e] + A[e * D + lane]) : (e == lane ? 1.0 : 0.0);
+    ok = true;
+    double mydiag = 1.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        double t = row[j];
+#pragma unroll
+        for (int p = 0; p < j; ++p) t -= row[p] * readlane_d(row[p], j);
+        const double sj = readlane_d(t, j);              // A_jj - sum_p L_jp^2   (the serial chain: keep it short)
+        ok = ok && (sj > 0.0);
+        rd[j] = rsqrt(sj);                               // 1 / L_jj
+        if (lane == j) mydiag = sj;
+        row[j] = lane >= j ? t * rd[j] : 0.0;            // lane j: sj / sqrt(sj) = L_jj
+    }
+    // sum_j log L_jj = 0.5 sum_j log s_j : one log per lane, off the serial chain
+    double lg = lane < D ? 0.5 * log(mydiag) : 0.0;
+    sumlog = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) sumlog += readlane_d(lg, j);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        double acc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+        for (int p = 0; p < i; ++p) acc -= readlane_d(row[p], i) * X[p];
+        X[i] = acc * rd[i];
     }
 }
 
@@ -421,109 +511,190 @@ __device__ void estep_constants(int k, int flavour, double alpha_k, double alpha
     }
 }
 
+constexpr int FIN_THREADS = 1024;
+constexpr int FIN_GROUPS = FIN_THREADS / 64;
+
+// One block per component.  Phase A: all 1024 threads reduce the per-block partials in a fixed order.
+// Phase B: 64 lanes build S_k, C_k element-wise.  Phase C: thread 0 factorises C_k while lanes 64.. evaluate
+// the digamma / lgamma terms.  Phase D: constants + pack.
 template <int D>
-__global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
+__global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
     using G = Geo<D>;
-    __shared__ double part[4][G::PF];
+    __shared__ double part[FIN_GROUPS][64];
+    __shared__ double npart[FIN_GROUPS][64];
     __shared__ double st[G::SW];           // canonical: Nk, Wk, sx[D], sxx[D*D]
     __shared__ double nall[VMP_MAX_K];
+    __shared__ double Ck[D * D], mk[D], sp[D + 4], scal[8];
+    __shared__ double alpha0s[VMP_MAX_K];
     const int k = blockIdx.x, tid = threadIdx.x, K = a.K;
+    // issue every small prior load up front so that its latency overlaps the partial-sum loads below
+    const bool post = a.do_post != 0;
+    const bool smm = a.flavour == VMP_SMM;
+    const double beta0 = post ? (double)a.beta0[k] : 0.0, v0 = post ? (double)a.v0[k] : 0.0;
+    const double alpha0 = post ? (double)a.alpha0[k] : 0.0;
+    const double kap = (post && smm) ? (double)a.kappa[k] : 0.0;
+    const bool shifted = (a.src == 0) && (a.pivot != nullptr);
+    double m0d = 0.0, m0e = 0.0, C0de = 0.0, cd = 0.0, ce = 0.0;
+    if (tid < D * D) {
+        const int d = tid / D, e = tid % D;
+        if (post) { m0d = a.m0[k * D + d]; m0e = a.m0[k * D + e]; C0de = a.C0[(k * D + d) * D + e]; }
+        if (shifted) { cd = a.pivot[d]; ce = a.pivot[e]; }
+    }
+    if (post && tid < K) alpha0s[tid] = a.alpha0[tid];
 
     if (a.src == 0) {
         const int f = tid & 63, g = tid >> 6;
-        if (f < G::PF) {
-            double s = 0.0;
-            for (int b = g; b < a.nblk; b += 4) s += a.partials[((long long)b * K + k) * G::PF + f];
-            part[g][f] = s;
+        double s = 0.0, s2 = 0.0;
+        // all loads of a chunk are issued before the first add (fixed summation order: b ascending)
+        for (int b0 = g; b0 < a.nblk; b0 += FIN_GROUPS * 16) {
+            double v1[16], v2[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int b = b0 + i * FIN_GROUPS;
+                const bool in = b < a.nblk;
+                v1[i] = (in && f < G::PF) ? a.partials[((long long)b * K + k) * G::PF + f] : 0.0;
+                v2[i] = (in && f < K) ? a.partials[((long long)b * K + f) * G::PF + G::F] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s += v1[i]; s2 += v2[i]; }
         }
-        for (int j = tid; j < K; j += 256) {
-            double s = 0.0;
-            for (int b = 0; b < a.nblk; ++b) s += a.partials[((long long)b * K + j) * G::PF + G::F];
-            nall[j] = s;
+        part[g][f] = s;
+        npart[g][f] = s2;
+        __syncthreads();
+        if (tid < 64) {
+            double t1 = 0.0, t2 = 0.0;
+            for (int gg = 0; gg < FIN_GROUPS; ++gg) { t1 += part[gg][tid]; t2 += npart[gg][tid]; }
+            part[0][tid] = t1;
+            if (tid < K) nall[tid] = t2;
         }
         __syncthreads();
-        if (tid < G::PF) part[0][tid] = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
-        __syncthreads();
-        if (tid == 0) {
-            st[0] = part[0][G::F];
-            st[1] = part[0][0];
-            for (int d = 0; d < D; ++d) st[2 + d] = part[0][1 + d];
-            int p = 1 + D;
-            for (int d = 0; d < D; ++d)
-                for (int e = d; e < D; ++e) {
-                    st[2 + D + d * D + e] = part[0][p];
-                    st[2 + D + e * D + d] = part[0][p];
-                    ++p;
-                }
+        if (tid == 0) { st[0] = part[0][G::F]; st[1] = part[0][0]; }
+        if (tid < D) st[2 + tid] = part[0][1 + tid];
+        if (tid < D * D) {
+            const int d = tid / D, e = tid % D;
+            const int lo = d < e ? d : e, hi = d < e ? e : d;
+            st[2 + D + tid] = part[0][1 + D + lo * D - lo * (lo - 1) / 2 + (hi - lo)];
         }
     } else {
-        for (int i = tid; i < G::SW; i += 256) st[i] = a.stats_in[(long long)k * G::SW + i];
-        for (int j = tid; j < K; j += 256) nall[j] = a.stats_in[(long long)j * G::SW];
+        for (int i = tid; i < G::SW; i += FIN_THREADS) st[i] = a.stats_in[(long long)k * G::SW + i];
+        for (int j = tid; j < K; j += FIN_THREADS) nall[j] = a.stats_in[(long long)j * G::SW];
     }
     __syncthreads();
-    if (a.stats_out)
-        for (int i = tid; i < G::SW; i += 256) a.stats_out[(long long)k * G::SW + i] = st[i];
-    if (!a.do_post || tid != 0) return;
+    // st holds the moments of the SHIFTED data x - c (c = pivot, 0 if none); the public layout is un-shifted:
+    //   sum w x = sx' + W c,   sum w x x^T = sxx' + c sx'^T + sx' c^T + W c c^T        (fp64)
+    if (a.stats_out) {
+        for (int i = tid; i < G::SW; i += FIN_THREADS) {
+            double val = st[i];
+            if (shifted && i >= 2) {
+                const double W = st[1];
+                if (i < 2 + D) {
+                    val += W * (double)a.pivot[i - 2];
+                } else {
+                    const int d = (i - 2 - D) / D, e = (i - 2 - D) % D;
+                    const double pd = a.pivot[d], pe = a.pivot[e];
+                    val += pd * st[2 + e] + st[2 + d] * pe + W * pd * pe;
+                }
+            }
+            a.stats_out[(long long)k * G::SW + i] = val;
+        }
+    }
+    if (!a.do_post) return;
 
-    // ---------------- single-thread fp64 posterior for component k ----------------
-    const bool smm = a.flavour == VMP_SMM;
     const double Nk = st[0], Wk = smm ? st[1] : st[0];
     const double* sx = st + 2;
     const double* sxx = st + 2 + D;
-    const double beta0 = a.beta0[k], v0 = a.v0[k], alpha0 = a.alpha0[k];
-    double xb[D], Sk[D * D], mk[D], Ck[D * D];
     // x_k: gmm.py:30-36 (NaN -> un-normalised when N_k == 0);  smm.py:32-38 (eps = 1e-20)
     const double den = smm ? (Wk + 1e-20) : Wk;
     const bool empty = (!smm) && !(Wk != 0.0);
-    for (int d = 0; d < D; ++d) xb[d] = empty ? sx[d] : sx[d] / den;
-    // S_k = sum_n w (x - x_k)(x - x_k)^T / W_k  from raw moments (gmm.py:39-46, smm.py:41-50)
-    for (int d = 0; d < D; ++d)
-        for (int e = 0; e < D; ++e) {
-            const double cen = sxx[d * D + e] - xb[d] * sx[e] - sx[d] * xb[e] + Wk * xb[d] * xb[e];
-            Sk[d * D + e] = empty ? cen : cen / den;
-        }
     const double alpha_k = alpha0 + Nk;                              // gmm.py:49-51 / smm.py:53-55
     const double beta_k = beta0 + Wk;                                // gmm.py:54-56 / smm.py:58-60
     const double v_k = smm ? (v0 + Nk) : (v0 + Nk + 1.0);            // smm.py:73-76 / gmm.py:79-81 (+1 quirk)
-    for (int d = 0; d < D; ++d) mk[d] = (beta0 * a.m0[k * D + d] + Wk * xb[d]) / beta_k;     // gmm.py:59-68
-    const double cf = beta0 * Wk / beta_k;
-    for (int d = 0; d < D; ++d)
-        for (int e = 0; e < D; ++e) {
-            const double q0d = xb[d] - a.m0[k * D + d], q0e = xb[e] - a.m0[k * D + e];
-            Ck[d * D + e] = a.C0[(k * D + d) * D + e] + Wk * Sk[d * D + e] + cf * q0d * q0e;  // gmm.py:71-76
-        }
-    double asum = 0.0;
-    for (int j = 0; j < K; ++j) asum += a.alpha0[j] + nall[j];
-    if (a.alpha) a.alpha[k] = (float)alpha_k;
-    if (a.beta) a.beta[k] = (float)beta_k;
-    if (a.v) a.v[k] = (float)v_k;
-    for (int d = 0; d < D; ++d) {
-        if (a.m) a.m[k * D + d] = (float)mk[d];
-        if (a.xbar) a.xbar[k * D + d] = (float)xb[d];
-        for (int e = 0; e < D; ++e) {
-            if (a.C) a.C[(k * D + d) * D + e] = (float)Ck[d * D + e];
-            if (a.S) a.S[(k * D + d) * D + e] = (float)Sk[d * D + e];
+    // ---- phase B: element (d,e) per lane
+    if (tid < D * D) {
+        const int d = tid / D, e = tid % D;
+        const double xd = empty ? sx[d] : sx[d] / den, xe = empty ? sx[e] : sx[e] / den;
+        // S_k = sum_n w (x - x_k)(x - x_k)^T / W_k from raw moments (gmm.py:39-46, smm.py:41-50)
+        const double cen = sxx[d * D + e] - xd * sx[e] - sx[d] * xe + Wk * xd * xe;
+        const double Sde = empty ? cen : cen / den;
+        // x_k in the caller's coordinates (an empty component keeps the reference's un-normalised 0)
+        const double xrd = empty ? sx[d] + Wk * cd : xd + cd, xre = empty ? sx[e] + Wk * ce : xe + ce;
+        const double q0d = xrd - m0d, q0e = xre - m0e;
+        const double Cde = C0de + Wk * Sde + (beta0 * Wk / beta_k) * q0d * q0e;                        // gmm.py:71-76
+        Ck[d * D + e] = Cde;
+        if (a.S) a.S[(k * D + d) * D + e] = (float)Sde;
+        if (a.C) a.C[(k * D + d) * D + e] = (float)Cde;
+        if (e == 0) {
+            const double md = (beta0 * m0d + Wk * xrd) / beta_k;                     // gmm.py:59-68
+            mk[d] = md;
+            if (a.m) a.m[k * D + d] = (float)md;
+            if (a.xbar) a.xbar[k * D + d] = (float)xrd;
         }
     }
+    if (tid == 0) {
+        if (a.alpha) a.alpha[k] = (float)alpha_k;
+        if (a.beta) a.beta[k] = (float)beta_k;
+        if (a.v) a.v[k] = (float)v_k;
+    }
+    __syncthreads();
+    // ---- phase C: factorisation (thread 0)  ||  special functions (threads 64..)
     // P_k = inv(C_k) (gmm.py:260) is never formed: with C = Lc Lc^T,
     //   v (x-m)^T P (x-m) = || sqrt(v) Lc^{-1} (x-m) ||^2   and   log det P = -2 sum log diag Lc.
-    double Lc[D * D], Li[D * D];
-    for (int i = 0; i < D * D; ++i) Lc[i] = 0.5 * (Ck[i] + Ck[(i % D) * D + i / D]);
-    double c = 0, h = 0.5, ua = 1, ub = 1, elp = 0;
-    if (chol_lower<D>(Lc)) {
-        tri_inv_lower<D>(Lc, Li);
-        double ld = 0.0;
-        for (int i = 0; i < D; ++i) ld += log(Lc[i * D + i]);
-        const double sv = sqrt(v_k);
-        for (int i = 0; i < D * D; ++i) Li[i] *= sv;
-        const double kap = smm ? (double)a.kappa[k] : 0.0;
-        estep_constants<D>(k, a.flavour, alpha_k, asum, beta_k, v_k, -2.0 * ld, kap, c, h, ua, ub, elp);
-    } else {
-        for (int i = 0; i < D * D; ++i) Li[i] = nan("");
-        c = nan("");
+    if (tid < 64) {
+        double X[D], sumlog;
+        bool ok;
+        wave_chol_inverse<D>(Ck, tid, X, sumlog, ok);
+        const double sv = ok ? sqrt(v_k) : nan("");
+        if (a.pack && tid < D) {
+            float* p = a.pack + k * G::PACK + D;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+                if (i >= tid) p[i * (i + 1) / 2 + tid] = (float)(X[i] * sv);      // W = sqrt(v) L^{-1}, lower
+        }
+        if (tid == 0) { scal[0] = -2.0 * sumlog; scal[1] = ok ? 1.0 : 0.0; }
+    } else if (tid >= 64 && tid < 64 + D) {
+        const int i = tid - 64;
+        sp[i] = digamma_d(0.5 * (v_k + (smm ? 0.0 : 1.0) + i));     // gmm.py:128-129 / smm.py:107-108
+    } else if (tid == 64 + D) {
+        sp[D] = digamma_d(alpha_k);
+    } else if (tid == 64 + D + 1) {
+        double asum = 0.0;
+        for (int j = 0; j < K; ++j) asum += alpha0s[j] + nall[j];
+        sp[D + 1] = digamma_d(asum);
+    } else if (tid == 64 + D + 2 && smm) {
+        sp[D + 2] = lgamma(0.5 * (D + kap)) - lgamma(0.5 * kap);
     }
-    if (a.pi) a.pi[k] = (float)exp(elp);
-    if (a.pack) write_pack<D>(a.pack, k, mk, Li, c, h, ua, ub);
+    __syncthreads();
+    // ---- phase D
+    if (tid == 0) {
+        const double LOG2 = 0.69314718055994530942, PI = 3.14159265358979323846;
+        const double elp = sp[D] - sp[D + 1];
+        double sdg = 0.0;
+        for (int i = 0; i < D; ++i) sdg += sp[i];
+        double c, h = 0.5, ua = 1.0, ub = 1.0;
+        const double logdetP = scal[0];
+        if (!smm) {
+            // gmm.py:120-121: log det P replaced by 0 when det P <= 1e-20
+            const double ld = (logdetP > log(1e-20)) ? logdetP : 0.0;
+            c = elp + 0.5 * (sdg + D * LOG2 + ld) - 0.5 * (D / beta_k);
+        } else {
+            h = 0.5 * (D + kap);
+            // smm.py:122-124 (note the precedence of line 124: ... - (0.5 (D+kappa) m - log kappa))
+            c = sp[D + 2] - 0.5 * D * log(kap * PI) + elp + 0.5 * (sdg + D * LOG2 + logdetP) - h * (D / beta_k) + log(kap);
+            ua = D + kap;                                                                   // smm.py:134-137
+            ub = D / beta_k + kap;
+        }
+        if (scal[1] == 0.0) c = nan("");
+        if (a.pi) a.pi[k] = (float)exp(elp);
+        if (a.pack) {
+            float* p = a.pack + k * G::PACK + D + G::TRI;
+            const double LOG2E = 1.4426950408889634074;  // the pass kernel evaluates 2^(c - h q)
+            p[0] = (float)(c * LOG2E); p[1] = (float)(h * LOG2E); p[2] = (float)ua; p[3] = (float)ub;
+        }
+    }
+    if (a.pack) {
+        float* p = a.pack + k * G::PACK;
+        if (tid < D) p[tid] = (float)mk[tid];
+    }
 }
 
 // E-step pack from explicit (alpha, beta, m, P, v): gmm.e_step / smm.e_step signature.
@@ -569,6 +740,32 @@ __global__ void pack_kernel(PackArgs a) {
     write_pack<D>(a.pack, k, mk, W, c, h, ua, ub);
 }
 
+
+// Pivot for the moment accumulation: mean of up to 4096 evenly strided rows of x (deterministic, one block).
+// Any fixed vector is a valid pivot (the finalize kernel un-shifts exactly in fp64); a vector near the data mean
+// keeps the fp32 products x_d x_e small, which is what makes raw-moment accumulation as accurate as the
+// reference's two-pass centred form (gmm.py:39-46).
+struct PivotArgs { const float* x; long long N; int D; float* out; };
+
+__global__ __launch_bounds__(1024) void pivot_kernel(PivotArgs a) {
+    __shared__ double red[1024];
+    const int tid = threadIdx.x;
+    const long long S = a.N < 4096 ? a.N : 4096;
+    const long long step = a.N / S;
+    for (int d = 0; d < a.D; ++d) {
+        double s = 0.0;
+        for (long long i = tid; i < S; i += 1024) s += (double)a.x[(i * step) * a.D + d];
+        red[tid] = s;
+        __syncthreads();
+        for (int w = 512; w > 0; w >>= 1) {
+            if (tid < w) red[tid] += red[tid + w];
+            __syncthreads();
+        }
+        if (tid == 0) a.out[d] = (float)(red[0] / (double)S);
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
@@ -578,16 +775,24 @@ struct Plan {
     long long ntiles;
 };
 
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 Plan make_plan(long long N, int D, int K, int flavour, bool stats) {
     Plan p;
-    const int nareas = flavour == VMP_SMM ? 3 : 1;
-    const size_t wreg = (size_t)(D + 2 + nareas * K) * LS * sizeof(float);
-    int nw = (int)((60 * 1024) / wreg);
+    static const int tuned_blocks = env_int("VMP_MIX_BLOCKS", 256);   // one 12-wave block per CU
+    static const int tuned_nw = env_int("VMP_MIX_NW", MAX_NW);
+    (void)flavour;
+    const size_t wreg = (size_t)(D + 2) * LS * sizeof(float);
+    int nw = tuned_nw;
     if (nw > MAX_NW) nw = MAX_NW;
     if (nw < 1) nw = 1;
     p.ntiles = (N + TR - 1) / TR;
     if ((long long)nw > p.ntiles) nw = (int)p.ntiles;
     long long blocks = (p.ntiles + nw - 1) / nw;
+    if (blocks > tuned_blocks) blocks = tuned_blocks;
     if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
     p.nw = nw;
     p.blocks = (int)blocks;
@@ -620,7 +825,7 @@ int launch_pass_dk(const PassArgs& a, const Plan& p, int flavour, bool estep, bo
 template <int D>
 int launch_pass_d(const PassArgs& a, const Plan& p, int flavour, bool estep, bool stats, bool mask, hipStream_t s) {
     const int KT = (a.K + 15) / 16;
-    if (!stats || KT == 1) return launch_pass_dk<D, 1>(a, p, flavour, estep, stats, mask, s);
+    if (KT == 1) return launch_pass_dk<D, 1>(a, p, flavour, estep, stats, mask, s);
     if (KT == 2) return launch_pass_dk<D, 2>(a, p, flavour, estep, stats, mask, s);
     return launch_pass_dk<D, 4>(a, p, flavour, estep, stats, mask, s);
 }
@@ -650,6 +855,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 int run_pass(PassArgs a, int D, int flavour, bool estep, bool stats, bool mask, hipStream_t s) {
     Plan p = make_plan(a.N, D, a.K, flavour, stats);
     a.ntiles = p.ntiles;
+
     int rc = -1;
     VMP_DISPATCH_D(D, rc = launch_pass_d<DD>(a, p, flavour, estep, stats, mask, s));
     return rc;
@@ -657,8 +863,9 @@ int run_pass(PassArgs a, int D, int flavour, bool estep, bool stats, bool mask, 
 
 int run_finalize(FinArgs f, int D, hipStream_t s) {
     int rc = -1;
+
     VMP_DISPATCH_D(D, {
-        hipLaunchKernelGGL((finalize_kernel<DD>), dim3(f.K), dim3(256), 0, s, f);
+        hipLaunchKernelGGL((finalize_kernel<DD>), dim3(f.K), dim3(FIN_THREADS), 0, s, f);
         rc = check_launch("finalize_kernel");
     });
     return rc;
@@ -679,8 +886,17 @@ size_t vmp_mix_workspace_bytes(int64_t N, int D, int K) {
     return (size_t)MAX_BLOCKS * K * partial_words(D) * sizeof(double);
 }
 
-int vmp_mix_stats(const float* x, const float* r, const float* u, int64_t N, int D, int K, double* stats, void* ws,
-                  size_t ws_bytes, void* stream) {
+int vmp_mix_pivot(const float* x, int64_t N, int D, float* pivot_out, void* stream) {
+    int rc = check_dims(N, D, 1);
+    if (rc) return rc;
+    if (!x || !pivot_out) { set_error("vmp_mix_pivot: null pointer"); return VMP_E_BADARG; }
+    PivotArgs a{x, N, D, pivot_out};
+    hipLaunchKernelGGL(pivot_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch("pivot_kernel");
+}
+
+int vmp_mix_stats(const float* x, const float* r, const float* u, const float* pivot, int64_t N, int D, int K,
+                  double* stats, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_dims(N, D, K);
     if (rc) return rc;
     if (!x || !r || !stats || !ws) { set_error("vmp_mix_stats: null pointer"); return VMP_E_BADARG; }
@@ -688,13 +904,13 @@ int vmp_mix_stats(const float* x, const float* r, const float* u, int64_t N, int
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int flavour = u ? VMP_SMM : VMP_GMM;
     PassArgs a{};
-    a.x = x; a.r_in = r; a.u_in = u; a.N = N; a.K = K; a.partials = static_cast<double*>(ws);
+    a.x = x; a.r_in = r; a.u_in = u; a.pivot = pivot; a.N = N; a.K = K; a.partials = static_cast<double*>(ws);
     a.vec_ok = aligned16(x) && aligned16(r) && (!u || aligned16(u));
     rc = run_pass(a, D, flavour, false, true, false, s);
     if (rc) return rc;
     FinArgs f{};
     f.partials = a.partials; f.nblk = make_plan(N, D, K, flavour, true).blocks; f.K = K; f.flavour = flavour;
-    f.src = 0; f.do_post = 0; f.stats_out = stats;
+    f.src = 0; f.do_post = 0; f.stats_out = stats; f.pivot = pivot;
     return run_finalize(f, D, s);
 }
 
@@ -729,8 +945,8 @@ int vmp_mix_pack_from_params(int D, int K, int flavour, const float* alpha, cons
 }
 
 int vmp_mix_estep(const float* x, int64_t N, int D, int K, int flavour, const float* pack, const uint8_t* miss_mask,
-                  float* r_out, float* u_out, float* logr_out, double* stats_out, void* ws, size_t ws_bytes,
-                  void* stream) {
+                  float* r_out, float* u_out, float* logr_out, const float* pivot, double* stats_out, void* ws,
+                  size_t ws_bytes, void* stream) {
     int rc = check_dims(N, D, K);
     if (rc) return rc;
     if (!x || !pack || !r_out) { set_error("vmp_mix_estep: null pointer"); return VMP_E_BADARG; }
@@ -747,18 +963,18 @@ int vmp_mix_estep(const float* x, int64_t N, int D, int K, int flavour, const fl
     hipStream_t s = static_cast<hipStream_t>(stream);
     PassArgs a{};
     a.x = x; a.mask = miss_mask; a.pack = pack; a.r_out = r_out; a.u_out = u_out; a.logr_out = logr_out;
-    a.N = N; a.K = K; a.partials = static_cast<double*>(ws);
+    a.pivot = pivot; a.N = N; a.K = K; a.partials = static_cast<double*>(ws);
     a.vec_ok = aligned16(x) && aligned16(r_out) && (!u_out || aligned16(u_out)) && (!logr_out || aligned16(logr_out));
     rc = run_pass(a, D, flavour, true, stats_out != nullptr, miss_mask != nullptr, s);
     if (rc || !stats_out) return rc;
     FinArgs f{};
     f.partials = a.partials; f.nblk = make_plan(N, D, K, flavour, true).blocks; f.K = K; f.flavour = flavour;
-    f.src = 0; f.do_post = 0; f.stats_out = stats_out;
+    f.src = 0; f.do_post = 0; f.stats_out = stats_out; f.pivot = pivot;
     return run_finalize(f, D, s);
 }
 
 int vmp_mix_estep_fused(const float* x, int64_t N, int D, int K, int flavour, const float* pack, float* r_out,
-                        float* u_out, float* logr_out, void* ws, size_t ws_bytes, void* stream) {
+                        float* u_out, float* logr_out, const float* pivot, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_dims(N, D, K);
     if (rc) return rc;
     if (!x || !pack || !r_out || !ws) { set_error("vmp_mix_estep_fused: null pointer"); return VMP_E_BADARG; }
@@ -766,25 +982,25 @@ int vmp_mix_estep_fused(const float* x, int64_t N, int D, int K, int flavour, co
     if (flavour == VMP_SMM && !u_out) { set_error("vmp_mix_estep_fused: SMM needs u_out"); return VMP_E_BADARG; }
     if (ws_bytes < vmp_mix_workspace_bytes(N, D, K)) { set_error("vmp_mix_estep_fused: workspace too small"); return VMP_E_WS; }
     PassArgs a{};
-    a.x = x; a.pack = pack; a.r_out = r_out; a.u_out = u_out; a.logr_out = logr_out;
+    a.x = x; a.pack = pack; a.r_out = r_out; a.u_out = u_out; a.logr_out = logr_out; a.pivot = pivot;
     a.N = N; a.K = K; a.partials = static_cast<double*>(ws);
     a.vec_ok = aligned16(x) && aligned16(r_out) && (!u_out || aligned16(u_out)) && (!logr_out || aligned16(logr_out));
     return run_pass(a, D, flavour, true, true, false, static_cast<hipStream_t>(stream));
 }
 
-int vmp_mix_stats_ws(const float* x, const float* r, const float* u, int64_t N, int D, int K, void* ws,
-                     size_t ws_bytes, void* stream) {
+int vmp_mix_stats_ws(const float* x, const float* r, const float* u, const float* pivot, int64_t N, int D, int K,
+                     void* ws, size_t ws_bytes, void* stream) {
     int rc = check_dims(N, D, K);
     if (rc) return rc;
     if (!x || !r || !ws) { set_error("vmp_mix_stats_ws: null pointer"); return VMP_E_BADARG; }
     if (ws_bytes < vmp_mix_workspace_bytes(N, D, K)) { set_error("vmp_mix_stats_ws: workspace too small"); return VMP_E_WS; }
     PassArgs a{};
-    a.x = x; a.r_in = r; a.u_in = u; a.N = N; a.K = K; a.partials = static_cast<double*>(ws);
+    a.x = x; a.r_in = r; a.u_in = u; a.pivot = pivot; a.N = N; a.K = K; a.partials = static_cast<double*>(ws);
     a.vec_ok = aligned16(x) && aligned16(r) && (!u || aligned16(u));
     return run_pass(a, D, u ? VMP_SMM : VMP_GMM, false, true, false, static_cast<hipStream_t>(stream));
 }
 
-int vmp_mix_finalize_ws(const void* ws, int64_t N, int D, int K, int flavour, const float* alpha0, const float* beta0,
+int vmp_mix_finalize_ws(const void* ws, const float* pivot, int64_t N, int D, int K, int flavour, const float* alpha0, const float* beta0,
                         const float* m0, const float* C0, const float* v0, const float* kappa, float* alpha,
                         float* beta, float* m, float* C, float* v, float* xbar, float* S, float* pi, float* pack,
                         double* stats_out, void* stream) {
@@ -798,7 +1014,7 @@ int vmp_mix_finalize_ws(const void* ws, int64_t N, int D, int K, int flavour, co
     f.K = K; f.flavour = flavour; f.src = 0; f.do_post = 1;
     f.alpha0 = alpha0; f.beta0 = beta0; f.m0 = m0; f.C0 = C0; f.v0 = v0; f.kappa = kappa;
     f.alpha = alpha; f.beta = beta; f.m = m; f.C = C; f.v = v; f.xbar = xbar; f.S = S; f.pi = pi; f.pack = pack;
-    f.stats_out = stats_out;
+    f.stats_out = stats_out; f.pivot = pivot;
     return run_finalize(f, D, static_cast<hipStream_t>(stream));
 }
 

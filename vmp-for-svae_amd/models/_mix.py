@@ -19,9 +19,20 @@ def _ws(x, N, D, K):
     return L.workspace(x.device, nbytes), nbytes
 
 
-def raw_stats(x, r, u=None):
+def pivot_of(x):
+    """(D,) fp32 pivot near the data mean (vmp_mix_pivot) - see include/vmp_hip.h."""
+    x = L.dev_f32(x, 'x')
+    N, D = x.shape
+    pv = torch.empty(D, dtype=torch.float32, device=x.device)
+    L.check(L.lib().vmp_mix_pivot(L.ptr(x), N, D, L.ptr(pv), L.stream()), 'vmp_mix_pivot')
+    return pv
+
+
+def raw_stats(x, r, u=None, pivot=None):
     """(K, 2+D+D*D) fp64 raw moments [Nk | Wk | sum w x | sum w x x^T] (vmp_mix_stats)."""
     x = L.dev_f32(x, 'x')
+    if pivot is None:
+        pivot = pivot_of(x)
     N, K = r.shape
     _, D = _dims(x, K)
     r = L.dev_f32(r, 'r_nk', (N, K))
@@ -29,8 +40,8 @@ def raw_stats(x, r, u=None):
         u = L.dev_f32(u, 'u_nk', (N, K))
     stats = torch.empty((K, L.lib().vmp_mix_stats_words(D)), dtype=torch.float64, device=x.device)
     ws, nb = _ws(x, N, D, K)
-    L.check(L.lib().vmp_mix_stats(L.ptr(x), L.ptr(r), L.ptr(u), N, D, K, L.ptr(stats), L.ptr(ws), nb, L.stream()),
-            'vmp_mix_stats')
+    L.check(L.lib().vmp_mix_stats(L.ptr(x), L.ptr(r), L.ptr(u), L.ptr(pivot), N, D, K, L.ptr(stats), L.ptr(ws), nb,
+                                  L.stream()), 'vmp_mix_stats')
     return stats
 
 
@@ -87,16 +98,17 @@ def estep(x, pack, flavour, miss_mask=None, want_logr=False, want_stats=False, r
         u = torch.empty(N, K, **f32) if u_out is None else u_out
     logr = torch.empty(N, K, **f32) if want_logr else None
     stats = torch.empty((K, L.lib().vmp_mix_stats_words(D)), dtype=torch.float64, device=x.device) if want_stats else None
-    ws, nb = (None, 0)
+    ws, nb, pivot = (None, 0, None)
     if want_stats:
         ws, nb = _ws(x, N, D, K)
+        pivot = pivot_of(x)
     mask = None
     if miss_mask is not None:
         if not miss_mask.is_cuda:
             raise L.VmpError('missing_data_mask must be on the GPU')
         mask = miss_mask.to(torch.uint8).contiguous()
     L.check(L.lib().vmp_mix_estep(L.ptr(x), N, D, K, flavour, L.ptr(pack), L.ptr(mask), L.ptr(r), L.ptr(u), L.ptr(logr),
-                                  L.ptr(stats), L.ptr(ws), nb, L.stream()), 'vmp_mix_estep')
+                                  L.ptr(pivot), L.ptr(stats), L.ptr(ws), nb, L.stream()), 'vmp_mix_estep')
     return r, u, logr, stats
 
 
@@ -143,13 +155,14 @@ class VMPLoop(object):
         self.logr = None
         self.nb = L.lib().vmp_mix_workspace_bytes(self.N, D, K)
         self.ws = torch.empty(self.nb, dtype=torch.uint8, device=dev)      # private: partials live across calls
-        L.check(L.lib().vmp_mix_stats_ws(L.ptr(self.x), L.ptr(self.r), L.ptr(self.u), self.N, D, K, L.ptr(self.ws),
-                                         self.nb, L.stream()), 'vmp_mix_stats_ws')
+        self.pivot = pivot_of(self.x)                                     # once per dataset
+        L.check(L.lib().vmp_mix_stats_ws(L.ptr(self.x), L.ptr(self.r), L.ptr(self.u), L.ptr(self.pivot), self.N, D, K,
+                                         L.ptr(self.ws), self.nb, L.stream()), 'vmp_mix_stats_ws')
         self.iterations = 0
 
     def finalize(self, stats_out=None):
         p, pr = self.post, self.prior
-        L.check(L.lib().vmp_mix_finalize_ws(L.ptr(self.ws), self.N, self.D, self.K, self.flavour, L.ptr(pr[0]),
+        L.check(L.lib().vmp_mix_finalize_ws(L.ptr(self.ws), L.ptr(self.pivot), self.N, self.D, self.K, self.flavour, L.ptr(pr[0]),
                                             L.ptr(pr[1]), L.ptr(pr[2]), L.ptr(pr[3]), L.ptr(pr[4]), L.ptr(self.kappa),
                                             L.ptr(p['alpha']), L.ptr(p['beta']), L.ptr(p['m']), L.ptr(p['C']),
                                             L.ptr(p['v']), L.ptr(p['xbar']), L.ptr(p['S']), L.ptr(p['pi']),
@@ -164,7 +177,7 @@ class VMPLoop(object):
             self.logr = torch.empty_like(self.r)
         L.check(L.lib().vmp_mix_estep_fused(L.ptr(self.x), self.N, self.D, self.K, self.flavour, L.ptr(self.post['pack']),
                                             L.ptr(self.r), L.ptr(self.u), L.ptr(self.logr if want_logr else None),
-                                            L.ptr(self.ws), self.nb, L.stream()), 'vmp_mix_estep_fused')
+                                            L.ptr(self.pivot), L.ptr(self.ws), self.nb, L.stream()), 'vmp_mix_estep_fused')
 
     def step(self, want_logr=False):
         self.finalize_phase()
