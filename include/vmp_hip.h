@@ -122,6 +122,47 @@ int    vmp_mix_finalize_ws(const void* ws, const float* pivot, int64_t N, int D,
                            float* alpha, float* beta, float* m, float* C, float* v, float* xbar, float* S, float* pi,
                            float* pack, double* stats_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * T2: SVAE E-step fused with the ELBO regulariser (models/svae.py:14-119 and :229-252)
+ * ------------------------------------------------------------------------------------------------
+ * Per (n,k) cell:  Pt = diag(-2 eta2d_n) + P_k,  ht = eta1_n + h_k,  Lt = chol(Pt),
+ *   log_z_nk  = normalise_k( bias_k + 1/2 |Lt^-1 ht|^2 - sum_i log Lt_ii )        compute_log_z_given_y, svae.py:50-92
+ *   x_nks     = Lt^-T (Lt^-1 ht + eps_nks)                                         sample_x_per_comp,     svae.py:95-119
+ *   T'_nk     = mean_s[ log N(x_s; phi~_nk) - log N(x_s; theta_k) - E log pi_k ]   the two per-sample densities of
+ *               compute_elbo (svae.py:236-243; gaussian.py:74-105) in closed form, so that
+ *               regulariser = sum_nk exp(log_z_nk) (T'_nk + log_z_nk)               (svae.py:245-252)
+ * Inputs: eta1, eta2d (N,L) encoder outputs; hk (K,L), Pk (K,L,L) symmetric, bias (K) = B_k + log pi_k from
+ * unpack_recognition_gmm (svae.py:342-358); noise (N,K,L,S) replaces tf.random_normal (svae.py:114);
+ * mk (K,L), Uk (K,L,L) upper-triangular with U^T U = E[Sigma_k]^-1, kappa (K) = sum log U_ii - L/2 log 2pi + E log pi_k
+ * from theta (svae.py:205-214, no gradient).  Outputs: x (N,K,S,L), lz (N,K), Tp (N,K).                      */
+int    vmp_svae_estep_fwd(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
+                          const float* noise, const float* mk, const float* Uk, const float* kappa,
+                          int64_t N, int K, int L, int S, float* x, float* lz, float* Tp, void* stream);
+
+/* Backward of the above: given dLoss/dx (N,K,S,L) (from the decoder), dLoss/dlog_z (N,K), dLoss/dT' (N,K), writes
+ * dLoss/deta1, dLoss/deta2d (N,L) and per-block partial sums over n of dLoss/d{hk, Pk, bias}:
+ * partials (vmp_svae_bwd_blocks(N,K), K, vmp_svae_bwd_partial_words(L)) = [ g_hk (L) | g_Pk lower triangle of the
+ * symmetric gradient, row-major packed (L(L+1)/2) | g_bias ]; the caller sums them over the first axis.
+ * Replaces TF autodiff through svae.py:50-119 and gaussian.py:74-105 (opt.compute_gradients, experiments.py:232). */
+int    vmp_svae_bwd_partial_words(int L);
+int    vmp_svae_bwd_blocks(int64_t N, int K);
+size_t vmp_svae_workspace_bytes(int64_t N, int K, int L);
+int    vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
+                          const float* mk, const float* Uk, const float* x, const float* lz,
+                          const float* Gx, const float* Glz, const float* GT, int64_t N, int K, int L, int S,
+                          float* g_eta1, float* g_eta2d, float* partials, size_t partial_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Reconstruction term (models/vae.py:201-250, weights branch :233-248)
+ * ------------------------------------------------------------------------------------------------
+ * A_nk = sum_{s,d} [ (y_nd - mean_nksd)^2 / var_nksd + log(var_nksd + 1e-8) ]   -- the tensor the reference
+ * contracts with the responsibilities in einsum('nksd,nk->') (vae.py:240).  y (N,Dy); mean, var (N,K,S,Dy).
+ * Backward: gmean = gA_nk * d/dmean, gvar = gA_nk * d/dvar (same shapes as mean / var).                        */
+int    vmp_diag_gauss_loglike_fwd(const float* y, const float* mean, const float* var, int64_t N, int K, int S,
+                                  int Dy, float* A, void* stream);
+int    vmp_diag_gauss_loglike_bwd(const float* y, const float* mean, const float* var, const float* gA,
+                                  int64_t N, int K, int S, int Dy, float* gmean, float* gvar, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,621 @@
+// T2: the SVAE E-step (reference models/svae.py:14-119) fused with the regulariser of the ELBO
+// (models/svae.py:229-252), forward and backward, for gfx950.
+//
+// Cell arithmetic (validated against the reference graph): for datapoint n, component k
+//   Pt = diag(p_n) + P_k,  ht = h_n + h_k,  Lt = chol(Pt),  a = Lt^-1 ht,  ld = sum_i log Lt_ii
+//   c_nk = bias_k + 1/2 |a|^2 - ld,            log_z_nk = c_nk - logsumexp_k c_nk         (svae.py:50-92)
+//   x_nks = Lt^-T (a + eps_nks)                                                            (svae.py:95-119)
+//   T'_nk = mean_s[ log N(x_s; phi~_nk) - log N(x_s; theta_k) - E log pi_k ]
+//         = -(L/2) log 2pi + ld - 1/(2S) sum_s |eps_s|^2 + 1/(2S) sum_s |U_k (x_s - m_k)|^2 - kappa_k
+// so that the reference's regulariser is sum_nk r_nk (T'_nk + log_z_nk) (svae.py:245-252).  One 8x8 Cholesky
+// per cell replaces the reference's 7 LU + 4 Cholesky factorisations.
+//
+// Work decomposition: one (n,k) cell per lane.  A wave tile is RPT = 64/K whole rows (RPT*K lanes active) so the
+// softmax over k and the per-row gradient sums never leave the wave; the lane's component k = lane % K is the
+// same for every tile, so the component's parameters stay resident in its VGPRs for the whole kernel.  The
+// noise tile eps (layout (cell, L, S)) is brought in with coalesced vector loads and staged in LDS with an odd
+// cell stride (conflict-free per-lane reads); the samples x are written back into the same LDS slots and leave
+// with coalesced stores in the reference's (cell, S, L) layout.
+#include "vmp_common.h"
+#include <stdlib.h>
+
+using namespace vmp;
+
+namespace {
+
+constexpr int SV_NW = 4;            // waves per block
+constexpr int SV_MAX_BLOCKS = 2048;
+constexpr float LOG_2PI = 1.8378770664093454836f;
+
+struct EFwdArgs {
+    const float* eta1;      // (N,L)   encoder eta1
+    const float* eta2d;     // (N,L)   encoder eta2 diagonal (negative)
+    const float* hk;        // (K,L)   recognition eta1_k
+    const float* Pk;        // (K,L,L) recognition precision (symmetric)
+    const float* bias;      // (K)     B_k + log pi_k
+    const float* noise;     // (N,K,L,S)
+    const float* mk;        // (K,L)   E[mu_k] of theta
+    const float* Uk;        // (K,L,L) upper-triangular U with U^T U = E[Sigma_k]^-1
+    const float* kappa;     // (K)     sum_i log U_ii - (L/2) log 2pi + E log pi_k
+    float* x;               // (N,K,S,L)
+    float* lz;              // (N,K)
+    float* Tp;              // (N,K)
+    long long N;
+    int K, S, vec_ok;
+};
+
+template <int L>
+struct SvGeo {
+    static constexpr int TRI = L * (L + 1) / 2;
+};
+
+// lower-triangular packed index (row-major), i >= j
+__host__ __device__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+// Cholesky of the cell matrix (lower, packed).  On return Lm holds the factor with the DIAGONAL REPLACED BY ITS
+// RECIPROCAL rd_j = 1/Lt_jj (every later use multiplies by it), and half_logdet = sum_j log Lt_jj.
+template <int L>
+__device__ __forceinline__ void cell_cholesky(float (&Lm)[SvGeo<L>::TRI], float& half_logdet) {
+    float prod_log = 0.f;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        float s = Lm[tri(j, j)];
+#pragma unroll
+        for (int p = 0; p < j; ++p) s = fmaf(-Lm[tri(j, p)], Lm[tri(j, p)], s);
+        const float rd = __builtin_amdgcn_rsqf(s);
+        prod_log += __logf(s);
+#pragma unroll
+        for (int i = j + 1; i < L; ++i) {
+            float t = Lm[tri(i, j)];
+#pragma unroll
+            for (int p = 0; p < j; ++p) t = fmaf(-Lm[tri(i, p)], Lm[tri(j, p)], t);
+            Lm[tri(i, j)] = t * rd;
+        }
+        Lm[tri(j, j)] = rd;
+    }
+    half_logdet = 0.5f * prod_log;
+}
+
+// v <- Lt^-1 v   (forward substitution; diagonal of Lm holds reciprocals)
+template <int L>
+__device__ __forceinline__ void solve_lower(const float (&Lm)[SvGeo<L>::TRI], float (&v)[L]) {
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        float t = v[i];
+#pragma unroll
+        for (int p = 0; p < i; ++p) t = fmaf(-Lm[tri(i, p)], v[p], t);
+        v[i] = t * Lm[tri(i, i)];
+    }
+}
+
+// v <- Lt^-T v   (back substitution)
+template <int L>
+__device__ __forceinline__ void solve_lower_t(const float (&Lm)[SvGeo<L>::TRI], float (&v)[L]) {
+#pragma unroll
+    for (int i = L - 1; i >= 0; --i) {
+        float t = v[i];
+#pragma unroll
+        for (int p = i + 1; p < L; ++p) t = fmaf(-Lm[tri(p, i)], v[p], t);
+        v[i] = t * Lm[tri(i, i)];
+    }
+}
+
+// sum / max over the K lanes of this lane's row, through a 64-float LDS scratch
+__device__ __forceinline__ float row_sum(float v, float* scr, int lane, int rbase, int K) {
+    scr[lane] = v;
+    __builtin_amdgcn_wave_barrier();
+    float s = 0.f;
+    for (int j = 0; j < K; ++j) s += scr[rbase + j];
+    __builtin_amdgcn_wave_barrier();
+    return s;
+}
+__device__ __forceinline__ float row_max(float v, float* scr, int lane, int rbase, int K) {
+    scr[lane] = v;
+    __builtin_amdgcn_wave_barrier();
+    float m = -INFINITY;
+    for (int j = 0; j < K; ++j) m = fmaxf(m, scr[rbase + j]);
+    __builtin_amdgcn_wave_barrier();
+    return m;
+}
+
+template <int L>
+__global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_fwd_kernel(EFwdArgs a) {
+    constexpr int TRI = SvGeo<L>::TRI;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int K = a.K, S = a.S;
+    const int LSn = L * S, CSTR = LSn | 1;                 // odd LDS stride per cell
+    const int RPT = WAVE / K, CT = RPT * K;                // rows / cells per wave tile
+    float* et = smem + wave * (WAVE * CSTR + WAVE);        // noise tile, later the samples
+    float* scr = et + WAVE * CSTR;
+    const bool lane_on = lane < CT;
+    const int r = lane / K, k = lane - r * K, rbase = lane_on ? r * K : 0;
+
+    // resident component parameters
+    float Pl[TRI], hkk[L], mkk[L], Uu[TRI];                // Uu: upper triangle of U, packed by rows: (i, j>=i)
+    float biask = 0.f, kappak = 0.f;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        hkk[i] = lane_on ? a.hk[k * L + i] : 0.f;
+        mkk[i] = lane_on ? a.mk[k * L + i] : 0.f;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) Pl[tri(i, j)] = lane_on ? a.Pk[(k * L + i) * L + j] : (i == j ? 1.f : 0.f);
+    }
+    {
+        int idx = 0;
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+#pragma unroll
+            for (int j = i; j < L; ++j) Uu[idx++] = lane_on ? a.Uk[(k * L + i) * L + j] : 0.f;
+    }
+    if (lane_on) { biask = a.bias[k]; kappak = a.kappa[k]; }
+
+    const long long ntiles = (a.N + RPT - 1) / RPT;
+    const float invLS = 1.0f / (float)LSn, invS = 1.0f / (float)S;
+    for (long long t = (long long)blockIdx.x * nw + wave; t < ntiles; t += (long long)gridDim.x * nw) {
+        const long long row = t * RPT + r;
+        const bool on = lane_on && row < a.N;
+        const long long rows_here = (a.N - t * RPT) < RPT ? (a.N - t * RPT) : RPT;
+        const int tot = (int)rows_here * K * LSn;          // floats of noise / samples in this tile
+        // ---- stage the noise tile: coalesced global reads, padded per-cell layout in LDS
+        {
+            const float* __restrict__ g = a.noise + t * CT * LSn;
+            if (a.vec_ok && (LSn & 3) == 0) {
+                for (int e = 4 * lane; e < tot; e += 4 * WAVE) {
+                    const float4 v = *reinterpret_cast<const float4*>(g + e);
+                    const int c = (int)(((float)e + 0.5f) * invLS);
+                    const int j = e - c * LSn;
+                    float* d = et + c * CSTR + j;
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                }
+            } else {
+                for (int e = lane; e < tot; e += WAVE) {
+                    const int c = (int)(((float)e + 0.5f) * invLS);
+                    et[c * CSTR + (e - c * LSn)] = g[e];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- cell factorisation
+        float Lm[TRI], av[L];
+#pragma unroll
+        for (int i = 0; i < TRI; ++i) Lm[i] = Pl[i];
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const float e1 = on ? a.eta1[row * L + i] : 0.f;
+            const float e2 = on ? a.eta2d[row * L + i] : -0.5f;
+            Lm[tri(i, i)] = fmaf(-2.f, e2, Lm[tri(i, i)]);
+            av[i] = e1 + hkk[i];
+        }
+        float ld;
+        cell_cholesky<L>(Lm, ld);
+        solve_lower<L>(Lm, av);
+        float aa = 0.f;
+#pragma unroll
+        for (int i = 0; i < L; ++i) aa = fmaf(av[i], av[i], aa);
+        const float c = on ? (biask + 0.5f * aa - ld) : -INFINITY;
+        const float mx = row_max(c, scr, lane, rbase, K);
+        const float ex = on ? __expf(c - mx) : 0.f;
+        const float se = row_sum(ex, scr, lane, rbase, K);
+        const float lz = c - mx - __logf(se);
+
+        // ---- samples and the per-cell regulariser term
+        float eps2 = 0.f, qth = 0.f;
+        float* cell = et + lane * CSTR;
+        for (int s = 0; s < S; ++s) {
+            float z[L];
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                const float e = lane_on ? cell[i * S + s] : 0.f;
+                eps2 = fmaf(e, e, eps2);
+                z[i] = av[i] + e;
+            }
+            solve_lower_t<L>(Lm, z);                       // z is now x_s
+            float d[L];
+#pragma unroll
+            for (int i = 0; i < L; ++i) d[i] = z[i] - mkk[i];
+            int idx = 0;
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                float y = 0.f;
+#pragma unroll
+                for (int j = i; j < L; ++j) y = fmaf(Uu[idx++], d[j], y);
+                qth = fmaf(y, y, qth);
+            }
+            if (lane_on) {
+#pragma unroll
+                for (int i = 0; i < L; ++i) cell[i * S + s] = z[i];
+            }
+        }
+        if (on) {
+            a.lz[row * K + k] = lz;
+            a.Tp[row * K + k] = -0.5f * L * LOG_2PI + ld - 0.5f * invS * eps2 + 0.5f * invS * qth - kappak;
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- samples out: (cell, S, L) layout, coalesced
+        {
+            float* __restrict__ g = a.x + t * CT * LSn;
+            if (a.vec_ok && (L & 3) == 0) {
+                for (int o = 4 * lane; o < tot; o += 4 * WAVE) {
+                    const int c2 = (int)(((float)o + 0.5f) * invLS);
+                    const int rem = o - c2 * LSn;
+                    const int s = rem / L, l = rem - s * L;
+                    const float* src = et + c2 * CSTR + l * S + s;
+                    float4 v;
+                    v.x = src[0]; v.y = src[S]; v.z = src[2 * S]; v.w = src[3 * S];
+                    *reinterpret_cast<float4*>(g + o) = v;
+                }
+            } else {
+                for (int o = lane; o < tot; o += WAVE) {
+                    const int c2 = (int)(((float)o + 0.5f) * invLS);
+                    const int rem = o - c2 * LSn;
+                    const int s = rem / L, l = rem - s * L;
+                    g[o] = et[c2 * CSTR + l * S + s];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// =========================================================================================================
+// backward
+// =========================================================================================================
+struct EBwdArgs {
+    const float* eta1;
+    const float* eta2d;
+    const float* hk;
+    const float* Pk;
+    const float* bias;
+    const float* mk;
+    const float* Uk;
+    const float* x;         // (N,K,S,L) samples from the forward pass
+    const float* lz;        // (N,K)
+    const float* Gx;        // (N,K,S,L) dLoss/dx  (from the decoder)
+    const float* Glz;       // (N,K)     dLoss/dlog_z
+    const float* GT;        // (N,K)     dLoss/dT'
+    float* g_eta1;          // (N,L)
+    float* g_eta2d;         // (N,L)
+    float* partials;        // (nblk, K, L + TRI + 1): g_hk | g_Pk (lower, symmetric gradient) | g_bias
+    long long N;
+    int K, S, vec_ok;
+};
+
+template <int L>
+__global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a) {
+    constexpr int TRI = SvGeo<L>::TRI;
+    constexpr int PW = L + TRI + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int K = a.K, S = a.S;
+    const int LSn = L * S;
+    const int RPT = WAVE / K, CT = RPT * K;
+    const int PSTR = TRI | 1;
+    float* pk_lds = smem;                                   // [K][PSTR]  lower triangle of P_k
+    float* scr = smem + K * PSTR + wave * WAVE;
+    float* red = smem + K * PSTR + nw * WAVE;               // block reduction scratch [PW][64]
+    const bool lane_on = lane < CT;
+    const int r = lane / K, k = lane - r * K, rbase = lane_on ? r * K : 0;
+
+    for (int e = threadIdx.x; e < K * TRI; e += blockDim.x) {
+        const int kk = e / TRI, idx = e - kk * TRI;
+        int i = 0;
+        while (tri(i + 1, 0) <= idx) ++i;
+        const int j = idx - tri(i, 0);
+        pk_lds[kk * PSTR + idx] = a.Pk[(kk * L + i) * L + j];
+    }
+    __syncthreads();
+
+    float hkk[L], mkk[L], Uu[TRI];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        hkk[i] = lane_on ? a.hk[k * L + i] : 0.f;
+        mkk[i] = lane_on ? a.mk[k * L + i] : 0.f;
+    }
+    {
+        int idx = 0;
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+#pragma unroll
+            for (int j = i; j < L; ++j) Uu[idx++] = lane_on ? a.Uk[(k * L + i) * L + j] : 0.f;
+    }
+    float acc_h[L], acc_P[TRI], acc_b = 0.f;                // sums over this lane's cells (fixed k)
+#pragma unroll
+    for (int i = 0; i < L; ++i) acc_h[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < TRI; ++i) acc_P[i] = 0.f;
+
+    const long long ntiles = (a.N + RPT - 1) / RPT;
+    const float invS = 1.0f / (float)S;
+    for (long long t = (long long)blockIdx.x * nw + wave; t < ntiles; t += (long long)gridDim.x * nw) {
+        const long long row = t * RPT + r;
+        const bool on = lane_on && row < a.N;
+        const long long cellid = row * K + k;
+
+        float Lm[TRI], av[L], mu[L];
+#pragma unroll
+        for (int i = 0; i < TRI; ++i) Lm[i] = lane_on ? pk_lds[k * PSTR + i] : 0.f;
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const float e1 = on ? a.eta1[row * L + i] : 0.f;
+            const float e2 = on ? a.eta2d[row * L + i] : -0.5f;
+            Lm[tri(i, i)] = fmaf(-2.f, e2, lane_on ? Lm[tri(i, i)] : 0.f);
+            av[i] = e1 + hkk[i];
+        }
+        float ld;
+        cell_cholesky<L>(Lm, ld);
+        solve_lower<L>(Lm, av);
+#pragma unroll
+        for (int i = 0; i < L; ++i) mu[i] = av[i];
+        solve_lower_t<L>(Lm, mu);                           // mu~ = Pt^-1 ht
+
+        const float glz = on ? a.Glz[cellid] : 0.f;
+        const float gT = on ? a.GT[cellid] : 0.f;
+        const float rnk = on ? __expf(a.lz[cellid]) : 0.f;
+        const float gsum = row_sum(glz, scr, lane, rbase, K);
+        const float Gc = glz - rnk * gsum;                  // through the log-sum-exp normalisation
+        const float Gld = gT - Gc;                          // T' has +ld, c has -ld
+
+        float Wsum[L], M[TRI];
+#pragma unroll
+        for (int i = 0; i < L; ++i) Wsum[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < TRI; ++i) M[i] = 0.f;
+        const float gts = gT * invS;
+        const float* __restrict__ xc = a.x + cellid * LSn;
+        const float* __restrict__ gc = a.Gx + cellid * LSn;
+        for (int s = 0; s < S; ++s) {
+            float xs[L], gx[L];
+            if (on) {
+                if ((L & 3) == 0 && a.vec_ok) {
+#pragma unroll
+                    for (int q = 0; q < L / 4; ++q) {
+                        const float4 v = reinterpret_cast<const float4*>(xc + s * L)[q];
+                        const float4 w = reinterpret_cast<const float4*>(gc + s * L)[q];
+                        xs[4 * q] = v.x; xs[4 * q + 1] = v.y; xs[4 * q + 2] = v.z; xs[4 * q + 3] = v.w;
+                        gx[4 * q] = w.x; gx[4 * q + 1] = w.y; gx[4 * q + 2] = w.z; gx[4 * q + 3] = w.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < L; ++i) { xs[i] = xc[s * L + i]; gx[i] = gc[s * L + i]; }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < L; ++i) { xs[i] = 0.f; gx[i] = 0.f; }
+            }
+            // d/dx of the theta term of T':  (1/S) U^T U (x - m)
+            float d[L], y[L];
+#pragma unroll
+            for (int i = 0; i < L; ++i) d[i] = xs[i] - mkk[i];
+            {
+                int idx = 0;
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    float yy = 0.f;
+#pragma unroll
+                    for (int j = i; j < L; ++j) yy = fmaf(Uu[idx++], d[j], yy);
+                    y[i] = yy;
+                }
+                idx = 0;
+#pragma unroll
+                for (int i = 0; i < L; ++i)
+#pragma unroll
+                    for (int j = i; j < L; ++j) gx[j] = fmaf(gts * Uu[idx++], y[i], gx[j]);
+            }
+            solve_lower<L>(Lm, gx);                         // w_s = Lt^-1 gx_s
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                Wsum[i] += gx[i];
+                const float e = xs[i] - mu[i];              // e_s = Lt^-T eps_s
+#pragma unroll
+                for (int j = 0; j <= i; ++j) M[tri(i, j)] = fmaf(e, gx[j], M[tri(i, j)]);
+            }
+        }
+        // ---- assemble dLoss/dht and dLoss/dPt (symmetric, lower triangle)
+        float V[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) V[i] = Wsum[i];
+        solve_lower_t<L>(Lm, V);                            // V = Pt^-1 sum_s gx_s
+        float gh[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) gh[i] = fmaf(Gc, mu[i], V[i]);
+
+        // Cholesky adjoint with G_L = -tril(M):  A = Lt^T G_L (lower part), B = Phi(A), C = B + B^T + Gld I
+        // real diagonal of Lt is 1/Lm[tri(j,j)]
+        float Cs[TRI];                                      // symmetric C, lower triangle
+        float dg[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) dg[i] = 1.0f / Lm[tri(i, i)];
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                float s2 = 0.f;
+#pragma unroll
+                for (int p = i; p < L; ++p) {
+                    const float lpi = (p == i) ? dg[i] : Lm[tri(p, i)];
+                    s2 = fmaf(lpi, -M[tri(p, j)], s2);
+                }
+                Cs[tri(i, j)] = (i == j) ? (s2 + Gld) : s2;   // Phi halves the diagonal, B + B^T doubles it back
+            }
+        // Y = Lt^-1 (lower, explicit);  g = 1/2 Y^T C Y
+        float Y[TRI];
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            Y[tri(j, j)] = Lm[tri(j, j)];
+#pragma unroll
+            for (int i = j + 1; i < L; ++i) {
+                float s2 = 0.f;
+#pragma unroll
+                for (int p = j; p < i; ++p) s2 = fmaf(Lm[tri(i, p)], Y[tri(p, j)], s2);
+                Y[tri(i, j)] = -s2 * Lm[tri(i, i)];
+            }
+        }
+        float gP[TRI];
+#pragma unroll
+        for (int i = 0; i < TRI; ++i) gP[i] = 0.f;
+        // Z = C Y column by column (Z[:,j] needs Y[p][j], p >= j), then gP[i][j] = 1/2 sum_{p>=i} Y[p][i] Z[p][j]
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            float Zc[L];
+#pragma unroll
+            for (int q = 0; q < L; ++q) {
+                float s2 = 0.f;
+#pragma unroll
+                for (int p = j; p < L; ++p) {
+                    const float cqp = (q >= p) ? Cs[tri(q, p)] : Cs[tri(p, q)];
+                    s2 = fmaf(cqp, Y[tri(p, j)], s2);
+                }
+                Zc[q] = s2;
+            }
+#pragma unroll
+            for (int i = j; i < L; ++i) {
+                float s2 = 0.f;
+#pragma unroll
+                for (int p = i; p < L; ++p) s2 = fmaf(Y[tri(p, i)], Zc[p], s2);
+                gP[tri(i, j)] = 0.5f * s2;
+            }
+        }
+        // rank-one terms:  - sym(V mu^T) - 1/2 Gc mu mu^T
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j)
+                gP[tri(i, j)] += -0.5f * (V[i] * mu[j] + mu[i] * V[j]) - 0.5f * Gc * mu[i] * mu[j];
+
+        // ---- per-component sums (registers) and per-row sums (through LDS)
+        if (on) {
+            acc_b += Gc;
+#pragma unroll
+            for (int i = 0; i < L; ++i) acc_h[i] += gh[i];
+#pragma unroll
+            for (int i = 0; i < TRI; ++i) acc_P[i] += gP[i];
+        }
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const float s1 = row_sum(on ? gh[i] : 0.f, scr, lane, rbase, K);
+            const float s2 = row_sum(on ? gP[tri(i, i)] : 0.f, scr, lane, rbase, K);
+            if (on && k == 0) {
+                a.g_eta1[row * L + i] = s1;
+                a.g_eta2d[row * L + i] = -2.f * s2;          // p = -2 eta2d
+            }
+        }
+    }
+
+    // ---- block reduction of the per-component sums: lanes with equal k, all waves, fixed order
+    __syncthreads();
+    for (int w = 0; w < nw; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < L; ++i) red[i * WAVE + lane] = (w == 0 ? 0.f : red[i * WAVE + lane]) + acc_h[i];
+#pragma unroll
+            for (int i = 0; i < TRI; ++i) red[(L + i) * WAVE + lane] = (w == 0 ? 0.f : red[(L + i) * WAVE + lane]) + acc_P[i];
+            red[(L + TRI) * WAVE + lane] = (w == 0 ? 0.f : red[(L + TRI) * WAVE + lane]) + acc_b;
+        }
+        __syncthreads();
+    }
+    float* out = a.partials + (long long)blockIdx.x * K * PW;
+    for (int e = threadIdx.x; e < K * PW; e += blockDim.x) {
+        const int kk = e / PW, f = e - kk * PW;
+        float s2 = 0.f;
+        for (int rr = 0; rr < RPT; ++rr) s2 += red[f * WAVE + rr * K + kk];
+        out[e] = s2;
+    }
+}
+
+int check_sv(long long N, int K, int L, int S) {
+    if (N <= 0 || S <= 0) { set_error("N and S must be positive"); return VMP_E_BADARG; }
+    if (L < 1 || L > VMP_MAX_D) { set_error("L=%d outside compiled range 1..%d", L, VMP_MAX_D); return VMP_E_DIM; }
+    if (K < 1 || K > VMP_MAX_K) { set_error("K=%d outside compiled range 1..%d", K, VMP_MAX_K); return VMP_E_DIM; }
+    if ((size_t)(L * S | 1) * WAVE * sizeof(float) > 36 * 1024) { set_error("L*S=%d too large for the LDS noise tile", L * S); return VMP_E_DIM; }
+    return 0;
+}
+
+int sv_blocks(long long N, int K) {
+    const int RPT = WAVE / K;
+    const long long ntiles = (N + RPT - 1) / RPT;
+    long long b = (ntiles + SV_NW - 1) / SV_NW;
+    static const int cap = getenv("VMP_SV_BLOCKS") ? atoi(getenv("VMP_SV_BLOCKS")) : 1024;
+    if (b > cap) b = cap;
+    if (b > SV_MAX_BLOCKS) b = SV_MAX_BLOCKS;
+    return (int)b;
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+#define VMP_DISPATCH_L(Lv, CALL)           \
+    switch (Lv) {                           \
+        case 1: { constexpr int LL = 1; CALL; } break; \
+        case 2: { constexpr int LL = 2; CALL; } break; \
+        case 3: { constexpr int LL = 3; CALL; } break; \
+        case 4: { constexpr int LL = 4; CALL; } break; \
+        case 5: { constexpr int LL = 5; CALL; } break; \
+        case 6: { constexpr int LL = 6; CALL; } break; \
+        case 7: { constexpr int LL = 7; CALL; } break; \
+        case 8: { constexpr int LL = 8; CALL; } break; \
+        default: break;                     \
+    }
+
+}  // namespace
+
+extern "C" {
+
+int vmp_svae_bwd_partial_words(int L) { return L + L * (L + 1) / 2 + 1; }
+
+size_t vmp_svae_workspace_bytes(int64_t N, int K, int L) {
+    (void)N;
+    return (size_t)SV_MAX_BLOCKS * K * vmp_svae_bwd_partial_words(L) * sizeof(float);
+}
+
+int vmp_svae_bwd_blocks(int64_t N, int K) { return sv_blocks(N, K); }
+
+int vmp_svae_estep_fwd(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
+                       const float* noise, const float* mk, const float* Uk, const float* kappa, int64_t N, int K,
+                       int L, int S, float* x, float* lz, float* Tp, void* stream) {
+    int rc = check_sv(N, K, L, S);
+    if (rc) return rc;
+    if (!eta1 || !eta2d || !hk || !Pk || !bias || !noise || !mk || !Uk || !kappa || !x || !lz || !Tp) {
+        set_error("vmp_svae_estep_fwd: null pointer");
+        return VMP_E_BADARG;
+    }
+    EFwdArgs a{eta1, eta2d, hk, Pk, bias, noise, mk, Uk, kappa, x, lz, Tp, N, K, S, 0};
+    a.vec_ok = al16(noise) && al16(x);
+    const size_t lds = (size_t)SV_NW * (WAVE * (L * S | 1) + WAVE) * sizeof(float);
+    const int blocks = sv_blocks(N, K);
+    rc = -1;
+    VMP_DISPATCH_L(L, {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd_kernel<LL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((svae_estep_fwd_kernel<LL>), dim3(blocks), dim3(SV_NW * WAVE), lds, static_cast<hipStream_t>(stream), a);
+        rc = check_launch("svae_estep_fwd_kernel");
+    });
+    return rc;
+}
+
+int vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
+                       const float* mk, const float* Uk, const float* x, const float* lz, const float* Gx,
+                       const float* Glz, const float* GT, int64_t N, int K, int L, int S, float* g_eta1, float* g_eta2d,
+                       float* partials, size_t partial_bytes, void* stream) {
+    int rc = check_sv(N, K, L, S);
+    if (rc) return rc;
+    if (!eta1 || !eta2d || !hk || !Pk || !bias || !mk || !Uk || !x || !lz || !Gx || !Glz || !GT || !g_eta1 || !g_eta2d || !partials) {
+        set_error("vmp_svae_estep_bwd: null pointer");
+        return VMP_E_BADARG;
+    }
+    const int blocks = sv_blocks(N, K);
+    const int PW = vmp_svae_bwd_partial_words(L);
+    if (partial_bytes < (size_t)blocks * K * PW * sizeof(float)) { set_error("vmp_svae_estep_bwd: partials buffer too small"); return VMP_E_WS; }
+    EBwdArgs a{eta1, eta2d, hk, Pk, bias, mk, Uk, x, lz, Gx, Glz, GT, g_eta1, g_eta2d, partials, N, K, S, 0};
+    a.vec_ok = al16(x) && al16(Gx);
+    const size_t lds = (size_t)(K * ((L * (L + 1) / 2) | 1) + SV_NW * WAVE + PW * WAVE) * sizeof(float);
+    rc = -1;
+    VMP_DISPATCH_L(L, {
+        hipLaunchKernelGGL((svae_estep_bwd_kernel<LL>), dim3(blocks), dim3(SV_NW * WAVE), lds, static_cast<hipStream_t>(stream), a);
+        rc = check_launch("svae_estep_bwd_kernel");
+    });
+    return rc;
+}
+
+}  // extern "C"

@@ -1,2 +1,2 @@
 """Mirror of the reference's ``models`` package: gmm, smm (pure mixture VMP), svae, vae."""
-from . import gmm, smm  # noqa: F401
+from . import gmm, smm, vae, svae  # noqa: F401

@@ -1,0 +1,266 @@
+"""SVAE assembly - mirror of reference models/svae.py:14-516 (GMM-structured latent space).
+
+N-sized arithmetic (per-(n,k) Cholesky, log-dets, triangular solves, responsibilities, reparameterised
+samples, per-sample log-densities of the ELBO, and all of their gradients) runs in csrc/vmp_svae.hip; the
+K-sized parameter maps (unpack_recognition_gmm, NIW conversions ...) are torch with autograd.
+"""
+import math
+
+import torch
+
+from .. import _lib as L
+from ..distributions import dirichlet, gaussian, niw
+from . import _mix, _svae_ops, gmm, vae
+
+
+def _tril_softplus(L_raw):
+    Lt = torch.tril(L_raw)
+    dg = torch.diagonal(Lt, dim1=-2, dim2=-1)
+    return Lt - torch.diag_embed(dg) + torch.diag_embed(torch.nn.functional.softplus(dg, threshold=30.0))
+
+
+def unpack_recognition_gmm(phi_gmm, name='unpack_phi2'):
+    """reference svae.py:342-358: (eta1 = mu_k as-is, eta2 = -1/2 L L^T with softplus diagonal, pi = softmax)."""
+    eta1, L_k_raw, pi_k_raw = phi_gmm
+    Lk = _tril_softplus(L_k_raw)
+    return eta1, -0.5 * (Lk @ Lk.transpose(-1, -2)), torch.softmax(pi_k_raw, dim=-1)
+
+
+unpack_recognition_gmm_debug = unpack_recognition_gmm
+
+
+def unpack_smm(theta_smm, name='unpack_theta_smm'):
+    """reference svae.py:361-373."""
+    mu, L_k_raw = theta_smm
+    Lk = _tril_softplus(L_k_raw)
+    return mu, Lk @ Lk.transpose(-1, -2)
+
+
+def _recognition_bias(eta1_k, eta2_k, pi_k):
+    """bias_k = B_k + log pi_k with B_k = -1/2 h_k^T P_k^-1 h_k + 1/2 log det P_k: the
+    k-only part of log N(mu_n; mu_k, Sigma_n + Sigma_k) the reference builds in svae.py:70-92."""
+    P = -2.0 * eta2_k
+    Lc = torch.linalg.cholesky(P)
+    sol = torch.linalg.solve_triangular(Lc, eta1_k.unsqueeze(-1), upper=False).squeeze(-1)
+    B = -0.5 * (sol * sol).sum(-1) + torch.log(torch.diagonal(Lc, dim1=-2, dim2=-1)).sum(-1)
+    return P, B + torch.log(pi_k)
+
+
+def _theta_pack(theta):
+    """(m_k, U_k, kappa_k) from the natural NIW/Dirichlet parameters theta (reference svae.py:205-214, detached):
+    log N(x; theta_k) + E log pi_k = -1/2 |U_k (x - m_k)|^2 + kappa_k."""
+    with torch.no_grad():
+        beta_k, m_k, C_k, v_k = niw.natural_to_standard(*theta[1:])
+        mu, sigma = niw.expected_values((beta_k, m_k, C_k, v_k))
+        Lam = torch.linalg.inv(sigma.double())
+        Lam = 0.5 * (Lam + Lam.transpose(-1, -2))
+        U = torch.linalg.cholesky(Lam).transpose(-1, -2)
+        Ld = mu.shape[-1]
+        elp = dirichlet.expected_log_pi(dirichlet.natural_to_standard(theta[0]).double())
+        kappa = torch.log(torch.diagonal(U, dim1=-2, dim2=-1)).sum(-1) - 0.5 * Ld * math.log(2 * math.pi) + elp
+        return mu.float().contiguous(), U.float().contiguous(), kappa.float().contiguous()
+
+
+def _neutral_theta(K, Ld, device):
+    f32 = dict(dtype=torch.float32, device=device)
+    return torch.zeros(K, Ld, **f32), torch.zeros(K, Ld, Ld, **f32), torch.zeros(K, **f32)
+
+
+class PhiTilde(object):
+    """What e_step returns as `phi_tilde`: behaves like the reference's tuple (eta1 (N,K,L,1), eta2 (N,K,L,L))
+    - materialised only if indexed - and carries the fused per-cell ELBO terms for compute_elbo."""
+
+    def __init__(self, eta1_phi1, eta2_diag, eta1_phi2, eta2_phi2, T_prime, theta_key):
+        self._p = (eta1_phi1, eta2_diag, eta1_phi2, eta2_phi2)
+        self.T_prime = T_prime
+        self.theta_key = theta_key
+
+    def __len__(self):
+        return 2
+
+    def __getitem__(self, i):
+        e1, e2d, e1k, e2k = self._p
+        if i == 0:
+            return (e1.unsqueeze(1) + e1k.unsqueeze(0)).unsqueeze(-1)
+        if i == 1:
+            return torch.diag_embed(e2d).unsqueeze(1) + e2k.unsqueeze(0)
+        raise IndexError(i)
+
+    def __iter__(self):
+        return iter((self[0], self[1]))
+
+
+def _theta_key(theta):
+    return tuple((t.data_ptr(), t._version) for t in theta) if theta is not None else None
+
+
+def compute_log_z_given_y(eta1_phi1, eta2_phi1, eta1_phi2, eta2_phi2, pi_phi2, name='log_q_z_given_y_phi'):
+    """reference svae.py:50-92.  eta2_phi1 is the (N,L,L) DIAGONAL matrix the reference passes (svae.py:29).
+    Returns (log q(z|y), (w_eta1, w_eta2)) - the debug pair is not produced by the fused kernel (None)."""
+    N, Ld = eta1_phi1.shape
+    K = eta1_phi2.shape[0]
+    e2d = torch.diagonal(eta2_phi1, dim1=-2, dim2=-1).contiguous()
+    P, bias = _recognition_bias(eta1_phi2, eta2_phi2, pi_phi2)
+    noise = torch.zeros(N, K, Ld, 1, dtype=torch.float32, device=eta1_phi1.device)
+    mk, Uk, kap = _neutral_theta(K, Ld, eta1_phi1.device)
+    _, lz, _ = _svae_ops.SvaeEStepFn.apply(eta1_phi1, e2d, eta1_phi2.contiguous(), P.contiguous(), bias, noise, mk, Uk, kap)
+    return lz, (None, None)
+
+
+def e_step(phi_enc, phi_gmm, nb_samples, seed=0, name="e_step", noise=None, theta=None):
+    """reference svae.py:14-47.  Returns (x_k_samples (N,K,S,L), log_z (N,K), phi_tilde, dbg).
+    `noise` (N,K,L,S) replaces tf.random_normal (default: torch.randn with `seed`); when `theta` (natural NIW /
+    Dirichlet parameters) is given, the per-sample densities compute_elbo needs are evaluated in the same pass."""
+    eta1_phi1, eta2_diag = phi_enc
+    N, Ld = eta1_phi1.shape
+    eta1_phi2, eta2_phi2, pi_phi2 = unpack_recognition_gmm(phi_gmm)
+    K = eta1_phi2.shape[0]
+    P, bias = _recognition_bias(eta1_phi2, eta2_phi2, pi_phi2)
+    if noise is None:
+        g = torch.Generator(device=eta1_phi1.device).manual_seed(int(seed))
+        noise = torch.randn(N, K, Ld, nb_samples, generator=g, device=eta1_phi1.device)
+    mk, Uk, kap = _theta_pack(theta) if theta is not None else _neutral_theta(K, Ld, eta1_phi1.device)
+    x, lz, Tp = _svae_ops.SvaeEStepFn.apply(eta1_phi1, eta2_diag, eta1_phi2.contiguous(), P.contiguous(), bias, noise,
+                                            mk, Uk, kap)
+    phi_tilde = PhiTilde(eta1_phi1, eta2_diag, eta1_phi2, eta2_phi2, Tp if theta is not None else None, _theta_key(theta))
+    return x, lz, phi_tilde, (None, None)
+
+
+def sample_x_per_comp(eta1, eta2, nb_samples, seed=0):
+    raise NotImplementedError('fused into vmp_svae_estep_fwd; use e_step')
+
+
+def subsample_x(x_k_samples, log_q_z_given_y, seed=0, z_draws=None):
+    """reference svae.py:122-151: z_ns ~ Cat(exp log_q), gather x[n, z_ns, s].  `z_draws` (N,S) replaces
+    tf.multinomial.  (N,S,L) gather - index plumbing, done with torch indexing on the device.)"""
+    N, K, S, Ld = x_k_samples.shape
+    if z_draws is None:
+        g = torch.Generator(device=x_k_samples.device).manual_seed(int(seed))
+        z_draws = torch.multinomial(torch.exp(log_q_z_given_y.detach()), S, replacement=True, generator=g)
+    n_idx = torch.arange(N, device=x_k_samples.device).view(-1, 1).expand(N, S)
+    s_idx = torch.arange(S, device=x_k_samples.device).view(1, -1).expand(N, S)
+    return x_k_samples[n_idx, z_draws.long(), s_idx]
+
+
+def m_step(gmm_prior, x_samples, r_nk):
+    """reference svae.py:154-176: theta* (natural) from the GMM M-step on (x_samples (N,L), r_nk)."""
+    beta_0, m_0, C_0, v_0 = niw.natural_to_standard(*gmm_prior[1:])
+    alpha_0 = dirichlet.natural_to_standard(gmm_prior[0])
+    alpha_k, beta_k, m_k, C_k, v_k, _, _ = gmm.m_step(x_samples.detach().contiguous(), r_nk.detach().contiguous(),
+                                                       alpha_0, beta_0, m_0, C_0, v_0, name='gmm_m_step')
+    A, b, beta, v_hat = niw.standard_to_natural(beta_k, m_k, C_k, v_k)
+    return [dirichlet.standard_to_natural(alpha_k), A, b, beta, v_hat]
+
+
+def m_step_from_stats(gmm_prior, stats):
+    """theta* directly in natural parameters from raw moments [N_k | W_k | sum r x | sum r x x^T] (SURVEY appendix
+    A.6) - the form the data-parallel driver uses after all-reducing the moments."""
+    K = stats.shape[0]
+    Ld = gmm_prior[2].shape[1]
+    Nk = stats[:, 0].float()
+    sx = stats[:, 2:2 + Ld].float()
+    sxx = stats[:, 2 + Ld:].reshape(K, Ld, Ld).float()
+    alpha, A, b, beta, v_hat = gmm_prior
+    return [alpha + Nk, A + sxx, b + sx, beta + Nk, v_hat + Nk + 1.0]
+
+
+def m_step_smm(smm_prior, r_nk):
+    """reference svae.py:179-196: only the Dirichlet parameter is updated."""
+    alpha_0 = dirichlet.natural_to_standard(smm_prior[0] if isinstance(smm_prior, (list, tuple)) else smm_prior)
+    N_k = gmm.update_Nk(r_nk.detach().contiguous())
+    return dirichlet.standard_to_natural(alpha_0 + N_k)
+
+
+def compute_elbo(y, reconstructions, theta, phi_tilde, x_k_samps, log_z_given_y_phi, decoder_type):
+    """reference svae.py:199-262.  Returns (elbo, (neg_rec_err, numerator, denominator, regulariser))."""
+    if decoder_type != 'standard':
+        raise NotImplementedError("decoder_type '%s': SURVEY 8f rank 4" % decoder_type)
+    if not isinstance(phi_tilde, PhiTilde) or phi_tilde.T_prime is None or phi_tilde.theta_key != _theta_key(theta):
+        raise L.VmpError('compute_elbo needs the per-cell terms of the fused E-step: call e_step / inference with '
+                         'theta=<the same theta> (the stand-alone per-sample density kernels are not built yet)')
+    r_nk = torch.exp(log_z_given_y_phi)
+    means, out_2 = reconstructions
+    rec = vae.expected_diagonal_gaussian_loglike(y, means, out_2, weights=r_nk)
+    Tp = phi_tilde.T_prime
+    reg = (r_nk * (Tp + log_z_given_y_phi)).sum()
+    elbo = rec - reg
+    with torch.no_grad():
+        # debug scalars of svae.py:256-260: sum r * mean_s(numerator), sum r * mean_s(denominator).  The fused kernel
+        # only keeps their difference; the split is recovered from the closed form of the numerator.
+        num = None
+        den = None
+    return elbo, (rec, num, den, reg)
+
+
+def update_gmm_params(current_gmm_params, gmm_params_star, step_size, name='cvi_update_theta'):
+    """reference svae.py:376-403: theta <- (1 - rho) theta + rho theta*, in place."""
+    with torch.no_grad():
+        for cur, star in zip(current_gmm_params, gmm_params_star):
+            cur.mul_(1.0 - step_size).add_(star.to(cur.dtype), alpha=float(step_size))
+    return current_gmm_params
+
+
+def init_mm_params(nb_components, latent_dims, alpha_scale=.1, beta_scale=1e-5, v_init=10., m_scale=1., C_scale=10.,
+                   seed=0, as_variables=True, trainable=False, device='cuda', name='gmm', m_uniform=None):
+    """reference svae.py:433-458.  `m_uniform` in [0,1) (K,L) replaces tf.random_uniform."""
+    f32 = dict(dtype=torch.float32, device=device)
+    K, Ld = nb_components, latent_dims
+    alpha = alpha_scale * torch.ones(K, **f32)
+    beta = beta_scale * torch.ones(K, **f32)
+    v = torch.full((K,), float(Ld + v_init), **f32)
+    if m_uniform is None:
+        g = torch.Generator(device='cpu').manual_seed(int(seed))
+        m_uniform = torch.rand(K, Ld, generator=g)
+    m = m_scale * (m_uniform.to(**f32) * 2.0 - 1.0)
+    C = C_scale * torch.eye(Ld, **f32).expand(K, Ld, Ld).contiguous()
+    A, b, beta, v_hat = niw.standard_to_natural(beta, m, C, v)
+    return dirichlet.standard_to_natural(alpha), A, b, beta, v_hat
+
+
+def init_mm(nb_components, latent_dims, seed=0, param_device='cuda', name='init_mm', theta_as_variable=True,
+            m_uniform=None):
+    """reference svae.py:461-471."""
+    prior = init_mm_params(nb_components, latent_dims, alpha_scale=0.05 / nb_components, beta_scale=0.5, m_scale=0,
+                           C_scale=latent_dims + 0.5, v_init=latent_dims + 0.5, seed=seed, device=param_device,
+                           m_uniform=m_uniform)
+    theta = init_mm_params(nb_components, latent_dims, alpha_scale=1., beta_scale=1., m_scale=5.,
+                           C_scale=2 * latent_dims, v_init=latent_dims + 1., seed=seed, device=param_device,
+                           m_uniform=m_uniform)
+    return prior, [t.clone() for t in theta]
+
+
+def make_loc_scale_variables(theta, param_device='cuda', name='copy_m_v'):
+    """reference svae.py:474-485."""
+    std = niw.natural_to_standard(theta[1], theta[2], theta[3], theta[4])
+    mu, sigma = niw.expected_values(std)
+    return (torch.nn.Parameter(mu.detach().clone()), torch.nn.Parameter(torch.linalg.cholesky(sigma).detach().clone()))
+
+
+def init_recognition_params(theta, nb_components, seed=0, param_device='cuda', var_scope='phi_gmm', pi_normal=None):
+    """reference svae.py:488-496.  `pi_normal` (K,) replaces tf.random_normal."""
+    if pi_normal is None:
+        g = torch.Generator(device='cpu').manual_seed(int(seed))
+        pi_normal = torch.randn(nb_components, generator=g)
+    mu_k, L_k = make_loc_scale_variables(theta, param_device)
+    pi_k = torch.nn.Parameter(torch.softmax(pi_normal.to(mu_k.device, torch.float32), dim=-1))
+    return mu_k, L_k, pi_k
+
+
+def inference(y, phi_gmm, encoder_layers, decoder_layers, nb_samples=10, stddev_init_nn=0.01, seed=0, name='inference',
+              param_device='cuda', noise=None, z_draws=None, theta=None):
+    """reference svae.py:499-516.  Returns (y_reconstruction, x_given_y_phi, x_k_samples, x_samples, log_z, phi_gmm,
+    phi_tilde)."""
+    x_given_y_phi = vae.make_encoder(y, layerspecs=encoder_layers, stddev_init=stddev_init_nn, seed=seed)
+    x_k_samples, log_z, phi_tilde, _ = e_step(x_given_y_phi, phi_gmm, nb_samples, seed=seed, noise=noise, theta=theta)
+    y_rec = vae.make_decoder(x_k_samples, layerspecs=decoder_layers, stddev_init=stddev_init_nn, seed=seed)
+    x_samples = subsample_x(x_k_samples, log_z, seed, z_draws=z_draws)[:, 0, :]
+    return y_rec, x_given_y_phi, x_k_samples, x_samples, log_z, phi_gmm, phi_tilde
+
+
+def predict(y, phi_gmm, encoder_layers, decoder_layers, seed=0):
+    """reference svae.py:406-430."""
+    phi_enc = vae.make_encoder(y, layerspecs=encoder_layers)
+    x_k_samples, log_r_nk, _, _ = e_step(phi_enc, phi_gmm, 1, seed=seed)
+    x_samples = subsample_x(x_k_samples, log_r_nk, seed)[:, 0, :]
+    y_mean, _ = vae.make_decoder(x_samples, layerspecs=decoder_layers)
+    return y_mean, torch.argmax(log_r_nk, dim=1)

@@ -1,0 +1,133 @@
+"""The training step of the reference driver (experiments.py:143-151, 196-267) for one process per GPU.
+
+    st = SVAETrainer(K, L, U, Dy, ...)            # parameters as experiments.py:154-181 creates them
+    out = st.step(y_shard, noise=..., z_draws=...)
+
+Reference semantics kept: the ELBO of a tower is a SUM over its shard; tower gradients are AVERAGED
+(helpers/tf_utils.py:52-87); the M-step sees the statistics of the whole minibatch without N_data/N_batch
+rescaling (svae.py:167-176); the CVI update and the Adam step both read OLD values (experiments.py:267);
+lrcvi = lrcvi0 * decay_rate ** (global_step / 1000) (experiments.py:146); Adam is TensorFlow-1.3's formulation
+(epsilon outside the bias correction).  What the reference does with an in-graph tower loop + gather on the
+parameter device + stack/mean becomes ONE all-reduce (RCCL) of a packed fp64 buffer
+    [ raw moments (K, 2+L+L*L) | flat gradients | elbo, neg_rec_err, regulariser ]
+after which every rank applies the identical theta update and Adam step.
+"""
+import math
+
+import torch
+
+from . import _lib as L
+from .models import _mix, svae, vae
+
+
+def exponential_decay(lr0, global_step, decay_steps, decay_rate):
+    """tf.train.exponential_decay(..., staircase=False) (experiments.py:146)."""
+    return lr0 * decay_rate ** (global_step / float(decay_steps))
+
+
+class TFAdam(object):
+    """tf.train.AdamOptimizer (TF 1.3): lr_t = lr sqrt(1-b2^t)/(1-b1^t); var -= lr_t m / (sqrt(v) + eps)."""
+
+    def __init__(self, params, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.params = list(params)
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+        self.t = 0
+
+    @torch.no_grad()
+    def apply_gradients(self, grads):
+        self.t += 1
+        lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        for p, g, m, v in zip(self.params, grads, self.m, self.v):
+            m.mul_(self.b1).add_(g, alpha=1.0 - self.b1)
+            v.mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
+            p.addcdiv_(m, v.sqrt().add_(self.eps), value=-lr_t)
+
+
+def pack_for_allreduce(stats, grads, scalars):
+    """[stats (fp64) | grads (flattened, fp64) | scalars] -> one contiguous fp64 buffer."""
+    parts = [stats.reshape(-1).double()] + [g.reshape(-1).double() for g in grads] + [torch.stack([s.double().reshape(()) for s in scalars])]
+    return torch.cat(parts)
+
+
+def unpack_after_allreduce(buf, stats_shape, grad_shapes, n_scalars):
+    o = 0
+    n = 1
+    for s in stats_shape:
+        n *= s
+    stats = buf[o:o + n].reshape(stats_shape)
+    o += n
+    grads = []
+    for shp in grad_shapes:
+        n = 1
+        for s in shp:
+            n *= s
+        grads.append(buf[o:o + n].reshape(shp))
+        o += n
+    return stats, grads, buf[o:o + n_scalars]
+
+
+class SVAETrainer(object):
+    def __init__(self, K, Ld, U, Dy, nb_samples=10, lr=3e-4, lrcvi=0.2, decay_rate=0.95, stddev_init_nn=0.01, seed=0,
+                 device='cuda', m_uniform=None, pi_normal=None, group=None):
+        self.K, self.L, self.S = K, Ld, nb_samples
+        self.lr, self.lrcvi0, self.decay_rate = lr, lrcvi, decay_rate
+        self.group = group
+        self.device = torch.device(device)
+        tanh = torch.tanh
+        self.encoder_layers = [(U, tanh), (U, tanh), (Ld, 'natparam')]            # experiments.py:139
+        self.decoder_layers = [(U, tanh), (U, tanh), (Dy, 'standard')]            # experiments.py:140
+        self.stddev_init_nn = stddev_init_nn
+        self.seed = seed
+        self.gmm_prior, self.theta = svae.init_mm(K, Ld, seed=seed, param_device=self.device, m_uniform=m_uniform)
+        self.phi_gmm = list(svae.init_recognition_params(self.theta, K, seed=seed, param_device=self.device,
+                                                         pi_normal=pi_normal))
+        self.global_step = 0
+        self.opt = None
+
+    def trainables(self):
+        """21 tensors in the reference's order: phi_gmm (3), encoder_net (9), decoder_net (9)."""
+        names = ['phi_gmm/mu_k', 'phi_gmm/L_k', 'phi_gmm/log_pi_k']
+        ts = list(self.phi_gmm)
+        for scope in ('encoder_net', 'decoder_net'):
+            for n, p in vae.net_variables(scope):
+                names.append(n)
+                ts.append(p)
+        return names, ts
+
+    def forward(self, y, noise=None, z_draws=None):
+        out = svae.inference(y, self.phi_gmm, self.encoder_layers, self.decoder_layers, self.S,
+                             stddev_init_nn=self.stddev_init_nn, seed=self.seed + self.global_step, noise=noise,
+                             z_draws=z_draws, theta=self.theta)
+        y_rec, phi_enc, x_k, x_s, log_z, _, phi_tilde = out
+        elbo, details = svae.compute_elbo(y, y_rec, self.theta, phi_tilde, x_k, log_z, 'standard')
+        return elbo, details, x_k, x_s, log_z
+
+    def step(self, y, noise=None, z_draws=None):
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        elbo, details, x_k, x_s, log_z = self.forward(y, noise, z_draws)
+        names, params = self.trainables()
+        grads = torch.autograd.grad(-elbo, params, allow_unused=True)
+        grads = [torch.zeros_like(p) if g is None else g for g, p in zip(grads, params)]
+        r_nk = torch.exp(log_z.detach())
+        stats = _mix.raw_stats(x_s.detach().contiguous(), r_nk.contiguous())        # HIP: (K, 2+L+L*L) fp64
+        rec, _, _, reg = details
+        if world > 1:
+            buf = pack_for_allreduce(stats, grads, [elbo.detach(), rec.detach(), reg.detach()])
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            stats, g64, sc = unpack_after_allreduce(buf, tuple(stats.shape), [tuple(g.shape) for g in grads], 3)
+            grads = [(g / world).to(torch.float32) for g in g64]                      # average_gradients (tf_utils.py:79)
+            elbo_sum, rec_sum, reg_sum = sc[0], sc[1], sc[2]
+        else:
+            elbo_sum, rec_sum, reg_sum = elbo.detach(), rec.detach(), reg.detach()
+        lrcvi = exponential_decay(self.lrcvi0, self.global_step, 1000, self.decay_rate)
+        theta_star = svae.m_step_from_stats(self.gmm_prior, stats)
+        if self.opt is None:
+            self.opt = TFAdam(params, self.lr)
+        svae.update_gmm_params(self.theta, theta_star, lrcvi)                         # experiments.py:258-260
+        self.opt.apply_gradients(grads)                                               # experiments.py:264-265
+        self.global_step += 1
+        return dict(elbo=elbo_sum, neg_rec_err=rec_sum, regulariser=reg_sum, grads=dict(zip(names, grads)),
+                    theta_star=theta_star, lrcvi=lrcvi, log_z=log_z.detach(), x_samples=x_s.detach(), x_k=x_k.detach())
