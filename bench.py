@@ -88,6 +88,94 @@ def cpu_baseline(x, r0, workload, chunk=1 << 15, reps=3):
                       'workload; best of %d after warm-up' % (workload, torch.get_num_threads(), chunk, Ns, reps)}
 
 
+
+def bench_t2(N, Ld, K, S, steps, warmup, dev, dist=None, world=1):
+    """T2: SVAE VMP step without the MLPs - fused E-step forward (log_z, samples, regulariser terms),
+    its backward (given decoder-side gradients), categorical sub-sampling, M-step moments and the CVI update."""
+    import vmp_for_svae_amd as V
+    from vmp_for_svae_amd.models import svae, _mix
+    g = torch.Generator(device=dev).manual_seed(1234)
+    eta1 = torch.randn(N, Ld, device=dev, generator=g).requires_grad_(True)
+    eta2d = (-0.5 * torch.nn.functional.softplus(torch.randn(N, Ld, device=dev, generator=g))).requires_grad_(True)
+    prior, theta = svae.init_mm(K, Ld, seed=0, param_device=dev)
+    phi = [p.detach().requires_grad_(True) for p in svae.init_recognition_params(theta, K, seed=0, param_device=dev)]
+    noise = torch.randn(N, K, Ld, S, device=dev, generator=g)
+    Gx = torch.randn(N, K, S, Ld, device=dev, generator=g) * 0.01
+    Glz = torch.randn(N, K, device=dev, generator=g) * 0.1
+    evf = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    evb = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+
+    def one(i, timed):
+        if timed:
+            evf[i][0].record()
+        x, lz, pt, _ = svae.e_step((eta1, eta2d), phi, S, noise=noise, theta=theta)
+        if timed:
+            evf[i][1].record()
+        r = torch.exp(lz.detach())
+        if timed:
+            evb[i][0].record()
+        grads = torch.autograd.grad([x, lz, pt.T_prime], [eta1, eta2d] + phi, [Gx, Glz, r])
+        if timed:
+            evb[i][1].record()
+        xs = svae.subsample_x(x, lz, seed=i, nb_out=1)[:, 0, :].contiguous()
+        st = _mix.raw_stats(xs, r)
+        if dist is not None:
+            buf = torch.cat([st.reshape(-1)] + [gg.reshape(-1).double() for gg in grads[2:]])
+            dist.all_reduce(buf)
+            st = buf[:st.numel()].reshape(st.shape)
+        svae.update_gmm_params(theta, svae.m_step_from_stats(prior, st), 0.2)
+
+    for i in range(warmup):
+        one(i, False)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(i, True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    f_ms = float(np.mean([a.elapsed_time(b) for a, b in evf]))
+    b_ms = float(np.mean([a.elapsed_time(b) for a, b in evb]))
+    alg = 4.0 * N * (4.0 * K * S * Ld + 2 * K + 4 * Ld)         # SURVEY 8d T2 bytes per step, injected noise
+    fwd_bytes = 4.0 * N * (2.0 * K * S * Ld + 2 * Ld + 2 * K)   # reads eps + eta, writes x + log_z + T'
+    bwd_bytes = 4.0 * N * (2.0 * K * S * Ld + 4 * Ld + 3 * K)   # reads x + dx + (lz, dlz, dT'), writes d eta
+    return {'steps_per_sec': steps / dt, 'ms_per_step': dt / steps * 1e3, 'datapoints_per_sec': N * world * steps / dt,
+            'algorithmic_bytes_per_step': alg, 'algorithmic_GBps_whole_step': alg / (dt / steps) / 1e9,
+            'fwd_kernel_ms': f_ms, 'bwd_kernel_ms': b_ms,
+            'fwd_GBps': fwd_bytes / (f_ms * 1e-3) / 1e9, 'bwd_GBps': bwd_bytes / (b_ms * 1e-3) / 1e9,
+            'fwd_frac_hbm': fwd_bytes / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'bwd_frac_hbm': bwd_bytes / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            'config': 'T2 svae-vmp N=%d per GPU, L=%d, K=%d, S=%d (fwd+bwd of the fused E-step, sub-sampling, M-step, CVI)' % (N, Ld, K, S)}
+
+
+def bench_t3(N, Ld, K, S, U, steps, warmup, dev, chunk):
+    """T3: the full training step of experiments.py:196-267 (encoder/decoder MLPs in torch fp32, reconstruction
+    term, all gradients, TF-Adam, CVI) on synthetic y = GMM data with Dy = L."""
+    from vmp_for_svae_amd.models import vae
+    from vmp_for_svae_amd.training import SVAETrainer
+    vae.reset_variables()
+    x_h, _ = synth(N, Ld, K, seed=7)
+    y = torch.as_tensor(x_h).to(dev)
+    tr = SVAETrainer(K, Ld, U, Ld, nb_samples=S, device=dev)
+    for _ in range(warmup):
+        tr.step(y, chunk=chunk)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = tr.step(y, chunk=chunk)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {'steps_per_sec': steps / dt, 'ms_per_step': dt / steps * 1e3, 'datapoints_per_sec': N * steps / dt,
+            'elbo_per_datapoint': float(out['elbo']) / N,
+            'config': 'T3 svae-train N=%d (chunks of %d), L=Dy=%d, K=%d, S=%d, U=%d' % (N, chunk, Ld, K, S, U)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -98,6 +186,9 @@ def main():
     ap.add_argument('--d', type=int, default=8)
     ap.add_argument('--k', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the T2 / T3 side measurements')
+    ap.add_argument('--s', type=int, default=10)
+    ap.add_argument('--u', type=int, default=50)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -150,6 +241,15 @@ def main():
         dt = tt.item()
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     assert torch.isfinite(loop.r).all()
+    extra = {}
+    if not args.no_extra:
+        del loop, x, r0
+        torch.cuda.empty_cache()
+        extra['t2_svae_vmp'] = bench_t2(N, D, K, args.s, 5, 2, dev, dist, world)
+        torch.cuda.empty_cache()
+        if world == 1:
+            extra['t3_svae_train'] = bench_t3(1 << 16, D, K, args.s, args.u, 3, 1, dev, 1 << 14)
+            torch.cuda.empty_cache()
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -177,6 +277,8 @@ def main():
                          'moved_GBps': min_bytes / (kern_ms * 1e-3) / 1e9,
                          'moved_frac': min_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        if extra:
+            out['extra'] = extra
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(x_h, r0_h, args.workload)
             out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']

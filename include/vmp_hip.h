@@ -152,6 +152,12 @@ int    vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk
                           const float* Gx, const float* Glz, const float* GT, int64_t N, int K, int L, int S,
                           float* g_eta1, float* g_eta2d, float* partials, size_t partial_bytes, void* stream);
 
+/* subsample_x (models/svae.py:122-151): z_ns ~ Cat(exp lz_n) and x_samples[n,s,:] = x[n, z_ns, s, :] for s < S_out
+ * (the reference draws all S and keeps s = 0, svae.py:514).  The draw is the inverse CDF of the supplied uniform
+ * u (N,S_out) - replacing tf.multinomial - or the supplied index z (N,S_out) when z != NULL.  out (N,S_out,L).  */
+int    vmp_svae_subsample(const float* x, const float* lz, const float* u, const int64_t* z, int64_t N, int K, int S,
+                          int L, int S_out, float* out, int64_t* z_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Reconstruction term (models/vae.py:201-250, weights branch :233-248)
  * ------------------------------------------------------------------------------------------------

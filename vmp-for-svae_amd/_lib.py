@@ -35,6 +35,7 @@ _SIGNATURES = {
     'vmp_svae_bwd_blocks': (_c.c_int, [_c.c_int64, _c.c_int]),
     'vmp_svae_workspace_bytes': (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int]),
     'vmp_svae_estep_bwd': (_c.c_int, [_P] * 12 + [_c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _c.c_size_t, _P]),
+    'vmp_svae_subsample': (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
     'vmp_diag_gauss_loglike_fwd': (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
     'vmp_diag_gauss_loglike_bwd': (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
     'vmp_mix_finalize_ws': (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int] + [_P] * 6 + [_P] * 9 + [_P, _P]),

@@ -23,7 +23,8 @@ using namespace vmp;
 
 namespace {
 
-constexpr int SV_NW = 4;            // waves per block
+constexpr int SV_NW = 4;            // waves per block (backward); forward: as many as the LDS noise tiles allow
+constexpr int SV_FWD_MAX_NW = 8;
 constexpr int SV_MAX_BLOCKS = 2048;
 constexpr float LOG_2PI = 1.8378770664093454836f;
 
@@ -119,7 +120,7 @@ __device__ __forceinline__ float row_max(float v, float* scr, int lane, int rbas
 }
 
 template <int L>
-__global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_fwd_kernel(EFwdArgs a) {
+__global__ __launch_bounds__(SV_FWD_MAX_NW * WAVE) void svae_estep_fwd_kernel(EFwdArgs a) {
     constexpr int TRI = SvGeo<L>::TRI;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -296,6 +297,7 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
     float* pk_lds = smem;                                   // [K][PSTR]  lower triangle of P_k
     float* scr = smem + K * PSTR + wave * WAVE;
     float* red = smem + K * PSTR + nw * WAVE;               // block reduction scratch [PW][64]
+    float* accl = red + PW * WAVE + wave * (PW * WAVE);     // this wave's accumulators [PW][64], lane-private columns
     const bool lane_on = lane < CT;
     const int r = lane / K, k = lane - r * K, rbase = lane_on ? r * K : 0;
 
@@ -321,11 +323,7 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
 #pragma unroll
             for (int j = i; j < L; ++j) Uu[idx++] = lane_on ? a.Uk[(k * L + i) * L + j] : 0.f;
     }
-    float acc_h[L], acc_P[TRI], acc_b = 0.f;                // sums over this lane's cells (fixed k)
-#pragma unroll
-    for (int i = 0; i < L; ++i) acc_h[i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < TRI; ++i) acc_P[i] = 0.f;
+    for (int i = 0; i < PW; ++i) accl[i * WAVE + lane] = 0.f;   // sums over this lane's cells (fixed k)
 
     const long long ntiles = (a.N + RPT - 1) / RPT;
     const float invS = 1.0f / (float)S;
@@ -487,11 +485,11 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
 
         // ---- per-component sums (registers) and per-row sums (through LDS)
         if (on) {
-            acc_b += Gc;
 #pragma unroll
-            for (int i = 0; i < L; ++i) acc_h[i] += gh[i];
+            for (int i = 0; i < L; ++i) accl[i * WAVE + lane] += gh[i];
 #pragma unroll
-            for (int i = 0; i < TRI; ++i) acc_P[i] += gP[i];
+            for (int i = 0; i < TRI; ++i) accl[(L + i) * WAVE + lane] += gP[i];
+            accl[(L + TRI) * WAVE + lane] += Gc;
         }
 #pragma unroll
         for (int i = 0; i < L; ++i) {
@@ -508,11 +506,7 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
     __syncthreads();
     for (int w = 0; w < nw; ++w) {
         if (wave == w) {
-#pragma unroll
-            for (int i = 0; i < L; ++i) red[i * WAVE + lane] = (w == 0 ? 0.f : red[i * WAVE + lane]) + acc_h[i];
-#pragma unroll
-            for (int i = 0; i < TRI; ++i) red[(L + i) * WAVE + lane] = (w == 0 ? 0.f : red[(L + i) * WAVE + lane]) + acc_P[i];
-            red[(L + TRI) * WAVE + lane] = (w == 0 ? 0.f : red[(L + TRI) * WAVE + lane]) + acc_b;
+            for (int i = 0; i < PW; ++i) red[i * WAVE + lane] = (w == 0 ? 0.f : red[i * WAVE + lane]) + accl[i * WAVE + lane];
         }
         __syncthreads();
     }
@@ -522,6 +516,46 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
         float s2 = 0.f;
         for (int rr = 0; rr < RPT; ++rr) s2 += red[f * WAVE + rr * K + kk];
         out[e] = s2;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// subsample_x (reference svae.py:122-151): z_ns ~ Cat(exp log_z_n), x_samples[n,s,:] = x[n, z_ns, s, :].
+// The categorical draw is the inverse CDF of a supplied uniform (or a supplied index, for parity tests).
+// ---------------------------------------------------------------------------------------------------------
+struct SubArgs {
+    const float* x;         // (N,K,S,L)
+    const float* lz;        // (N,K)
+    const float* u;         // (N,S_out) uniforms in [0,1) or NULL
+    const long long* z;     // (N,S_out) indices or NULL
+    float* out;             // (N,S_out,L)
+    long long* z_out;       // (N,S_out) chosen component (may be NULL)
+    long long N;
+    int K, S, L, S_out;
+};
+
+__global__ __launch_bounds__(256) void subsample_kernel(SubArgs a) {
+    const long long tot = a.N * a.S_out;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < tot; g += (long long)gridDim.x * blockDim.x) {
+        const long long n = g / a.S_out;
+        const int s = (int)(g - n * a.S_out);
+        int zk;
+        if (a.z) {
+            zk = (int)a.z[g];
+        } else {
+            const float uu = a.u[g];
+            float cum = 0.f;
+            zk = a.K - 1;
+            for (int k = 0; k < a.K; ++k) {
+                cum += __expf(a.lz[n * a.K + k]);
+                if (uu < cum) { zk = k; break; }
+            }
+        }
+        if (a.z_out) a.z_out[g] = zk;
+        const float* src = a.x + ((n * a.K + zk) * a.S + s) * a.L;
+        float* dst = a.out + g * a.L;
+        for (int l = 0; l < a.L; ++l) dst[l] = src[l];
     }
 }
 
@@ -582,13 +616,19 @@ int vmp_svae_estep_fwd(const float* eta1, const float* eta2d, const float* hk, c
     }
     EFwdArgs a{eta1, eta2d, hk, Pk, bias, noise, mk, Uk, kappa, x, lz, Tp, N, K, S, 0};
     a.vec_ok = al16(noise) && al16(x);
-    const size_t lds = (size_t)SV_NW * (WAVE * (L * S | 1) + WAVE) * sizeof(float);
-    const int blocks = sv_blocks(N, K);
+    const size_t per_wave = (size_t)(WAVE * (L * S | 1) + WAVE) * sizeof(float);
+    int nw = (int)((150 * 1024) / per_wave);                 // one block per CU, as many waves as 160 KiB of LDS hold
+    if (nw > SV_FWD_MAX_NW) nw = SV_FWD_MAX_NW;
+    if (nw < 1) nw = 1;
+    const size_t lds = per_wave * nw;
+    const int RPT = WAVE / K;
+    long long blocks = ((N + RPT - 1) / RPT + nw - 1) / nw;
+    if (blocks > 256) blocks = 256;
     rc = -1;
     VMP_DISPATCH_L(L, {
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd_kernel<LL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((svae_estep_fwd_kernel<LL>), dim3(blocks), dim3(SV_NW * WAVE), lds, static_cast<hipStream_t>(stream), a);
+        hipLaunchKernelGGL((svae_estep_fwd_kernel<LL>), dim3((int)blocks), dim3(nw * WAVE), lds, static_cast<hipStream_t>(stream), a);
         rc = check_launch("svae_estep_fwd_kernel");
     });
     return rc;
@@ -609,13 +649,26 @@ int vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk, c
     if (partial_bytes < (size_t)blocks * K * PW * sizeof(float)) { set_error("vmp_svae_estep_bwd: partials buffer too small"); return VMP_E_WS; }
     EBwdArgs a{eta1, eta2d, hk, Pk, bias, mk, Uk, x, lz, Gx, Glz, GT, g_eta1, g_eta2d, partials, N, K, S, 0};
     a.vec_ok = al16(x) && al16(Gx);
-    const size_t lds = (size_t)(K * ((L * (L + 1) / 2) | 1) + SV_NW * WAVE + PW * WAVE) * sizeof(float);
+    const size_t lds = (size_t)(K * ((L * (L + 1) / 2) | 1) + SV_NW * WAVE + PW * WAVE + SV_NW * PW * WAVE) * sizeof(float);
     rc = -1;
     VMP_DISPATCH_L(L, {
         hipLaunchKernelGGL((svae_estep_bwd_kernel<LL>), dim3(blocks), dim3(SV_NW * WAVE), lds, static_cast<hipStream_t>(stream), a);
         rc = check_launch("svae_estep_bwd_kernel");
     });
     return rc;
+}
+
+int vmp_svae_subsample(const float* x, const float* lz, const float* u, const int64_t* z, int64_t N, int K, int S, int L,
+                       int S_out, float* out, int64_t* z_out, void* stream) {
+    if (!x || !lz || (!u && !z) || !out || N <= 0 || K <= 0 || S <= 0 || L <= 0 || S_out <= 0 || S_out > S) {
+        set_error("vmp_svae_subsample: bad argument");
+        return VMP_E_BADARG;
+    }
+    SubArgs a{x, lz, u, reinterpret_cast<const long long*>(z), out, reinterpret_cast<long long*>(z_out), N, K, S, L, S_out};
+    long long blocks = (N * S_out + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(subsample_kernel, dim3((int)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch("subsample_kernel");
 }
 
 }  // extern "C"

@@ -130,16 +130,24 @@ def sample_x_per_comp(eta1, eta2, nb_samples, seed=0):
     raise NotImplementedError('fused into vmp_svae_estep_fwd; use e_step')
 
 
-def subsample_x(x_k_samples, log_q_z_given_y, seed=0, z_draws=None):
-    """reference svae.py:122-151: z_ns ~ Cat(exp log_q), gather x[n, z_ns, s].  `z_draws` (N,S) replaces
-    tf.multinomial.  (N,S,L) gather - index plumbing, done with torch indexing on the device.)"""
-    N, K, S, Ld = x_k_samples.shape
-    if z_draws is None:
-        g = torch.Generator(device=x_k_samples.device).manual_seed(int(seed))
-        z_draws = torch.multinomial(torch.exp(log_q_z_given_y.detach()), S, replacement=True, generator=g)
-    n_idx = torch.arange(N, device=x_k_samples.device).view(-1, 1).expand(N, S)
-    s_idx = torch.arange(S, device=x_k_samples.device).view(1, -1).expand(N, S)
-    return x_k_samples[n_idx, z_draws.long(), s_idx]
+def subsample_x(x_k_samples, log_q_z_given_y, seed=0, z_draws=None, nb_out=None):
+    """reference svae.py:122-151: z_ns ~ Cat(exp log_q), gather x[n, z_ns, s].  HIP kernel vmp_svae_subsample;
+    `z_draws` (N,S) replaces tf.multinomial (default: inverse CDF of torch.rand with `seed`).  `nb_out` < S only
+    produces the first nb_out sample columns (the reference's caller keeps s = 0, svae.py:514)."""
+    x = L.dev_f32(x_k_samples.detach(), 'x_k_samples')
+    N, K, S, Ld = x.shape
+    lz = L.dev_f32(log_q_z_given_y.detach(), 'log_q_z_given_y', (N, K))
+    So = S if nb_out is None else int(nb_out)
+    u = z = None
+    if z_draws is not None:
+        z = z_draws[:, :So].to(torch.int64).contiguous()
+    else:
+        g = torch.Generator(device=x.device).manual_seed(int(seed))
+        u = torch.rand(N, So, generator=g, device=x.device)
+    out = torch.empty(N, So, Ld, dtype=torch.float32, device=x.device)
+    L.check(L.lib().vmp_svae_subsample(L.ptr(x), L.ptr(lz), L.ptr(u), L.ptr(z), N, K, S, Ld, So, L.ptr(out), None,
+                                       L.stream()), 'vmp_svae_subsample')
+    return out
 
 
 def m_step(gmm_prior, x_samples, r_nk):
@@ -253,7 +261,7 @@ def inference(y, phi_gmm, encoder_layers, decoder_layers, nb_samples=10, stddev_
     x_given_y_phi = vae.make_encoder(y, layerspecs=encoder_layers, stddev_init=stddev_init_nn, seed=seed)
     x_k_samples, log_z, phi_tilde, _ = e_step(x_given_y_phi, phi_gmm, nb_samples, seed=seed, noise=noise, theta=theta)
     y_rec = vae.make_decoder(x_k_samples, layerspecs=decoder_layers, stddev_init=stddev_init_nn, seed=seed)
-    x_samples = subsample_x(x_k_samples, log_z, seed, z_draws=z_draws)[:, 0, :]
+    x_samples = subsample_x(x_k_samples, log_z, seed, z_draws=z_draws, nb_out=1)[:, 0, :]
     return y_rec, x_given_y_phi, x_k_samples, x_samples, log_z, phi_gmm, phi_tilde
 
 

@@ -104,30 +104,49 @@ class SVAETrainer(object):
         elbo, details = svae.compute_elbo(y, y_rec, self.theta, phi_tilde, x_k, log_z, 'standard')
         return elbo, details, x_k, x_s, log_z
 
-    def step(self, y, noise=None, z_draws=None):
+    def step(self, y, noise=None, z_draws=None, chunk=None):
+        """One training step.  `chunk` rows at a time (the ELBO is a sum over datapoints, so gradients and
+        moments simply accumulate over chunks) - needed when N*K*S decoder rows do not fit at once."""
         import torch.distributed as dist
         world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
-        elbo, details, x_k, x_s, log_z = self.forward(y, noise, z_draws)
-        names, params = self.trainables()
-        grads = torch.autograd.grad(-elbo, params, allow_unused=True)
-        grads = [torch.zeros_like(p) if g is None else g for g, p in zip(grads, params)]
-        r_nk = torch.exp(log_z.detach())
-        stats = _mix.raw_stats(x_s.detach().contiguous(), r_nk.contiguous())        # HIP: (K, 2+L+L*L) fp64
-        rec, _, _, reg = details
+        rows = y.shape[0]
+        chunk = rows if chunk is None else int(chunk)
+        names, params = None, None
+        grads = stats = None
+        elbo_t = rec_t = reg_t = 0.0
+        keep = {}
+        for ci, i in enumerate(range(0, rows, chunk)):
+            ys = y[i:i + chunk]
+            ns = None if noise is None else noise[i:i + chunk]
+            zs = None if z_draws is None else z_draws[i:i + chunk]
+            elbo, details, x_k, x_s, log_z = self.forward(ys, ns, zs)
+            if params is None:
+                names, params = self.trainables()
+            g = torch.autograd.grad(-elbo, params, allow_unused=True)
+            g = [torch.zeros_like(p) if gi is None else gi for gi, p in zip(g, params)]
+            r_nk = torch.exp(log_z.detach())
+            st = _mix.raw_stats(x_s.detach().contiguous(), r_nk.contiguous())      # HIP: (K, 2+L+L*L) fp64
+            grads = g if grads is None else [a + b for a, b in zip(grads, g)]
+            stats = st if stats is None else stats + st
+            rec, _, _, reg = details
+            elbo_t, rec_t, reg_t = elbo_t + elbo.detach(), rec_t + rec.detach(), reg_t + reg.detach()
+            if rows <= chunk:
+                keep = dict(log_z=log_z.detach(), x_samples=x_s.detach(), x_k=x_k.detach())
+            del elbo, details, x_k, x_s, log_z
         if world > 1:
-            buf = pack_for_allreduce(stats, grads, [elbo.detach(), rec.detach(), reg.detach()])
+            buf = pack_for_allreduce(stats, grads, [elbo_t, rec_t, reg_t])
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
             stats, g64, sc = unpack_after_allreduce(buf, tuple(stats.shape), [tuple(g.shape) for g in grads], 3)
-            grads = [(g / world).to(torch.float32) for g in g64]                      # average_gradients (tf_utils.py:79)
-            elbo_sum, rec_sum, reg_sum = sc[0], sc[1], sc[2]
-        else:
-            elbo_sum, rec_sum, reg_sum = elbo.detach(), rec.detach(), reg.detach()
+            grads = [(g / world).to(torch.float32) for g in g64]                    # average_gradients (tf_utils.py:79)
+            elbo_t, rec_t, reg_t = sc[0], sc[1], sc[2]
         lrcvi = exponential_decay(self.lrcvi0, self.global_step, 1000, self.decay_rate)
         theta_star = svae.m_step_from_stats(self.gmm_prior, stats)
         if self.opt is None:
             self.opt = TFAdam(params, self.lr)
-        svae.update_gmm_params(self.theta, theta_star, lrcvi)                         # experiments.py:258-260
-        self.opt.apply_gradients(grads)                                               # experiments.py:264-265
+        svae.update_gmm_params(self.theta, theta_star, lrcvi)                       # experiments.py:258-260
+        self.opt.apply_gradients(grads)                                             # experiments.py:264-265
         self.global_step += 1
-        return dict(elbo=elbo_sum, neg_rec_err=rec_sum, regulariser=reg_sum, grads=dict(zip(names, grads)),
-                    theta_star=theta_star, lrcvi=lrcvi, log_z=log_z.detach(), x_samples=x_s.detach(), x_k=x_k.detach())
+        out = dict(elbo=elbo_t, neg_rec_err=rec_t, regulariser=reg_t, grads=dict(zip(names, grads)),
+                   theta_star=theta_star, lrcvi=lrcvi)
+        out.update(keep)
+        return out
