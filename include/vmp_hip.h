@@ -122,6 +122,15 @@ int    vmp_mix_finalize_ws(const void* ws, const float* pivot, int64_t N, int D,
                            float* alpha, float* beta, float* m, float* C, float* v, float* xbar, float* S, float* pi,
                            float* pack, double* stats_out, void* stream);
 
+/* `iterations` VMP iterations enqueued back-to-back from one call (2 launches each, no host round trip):
+ * the loop `for i in range(nb_iters): sess.run(update)` of models/gmm.py:377-379.  ws must hold the partial moments
+ * of the current (r, u) (vmp_mix_stats_ws or a previous iteration).                                             */
+int    vmp_mix_iterate(const float* x, int64_t N, int D, int K, int flavour,
+                       const float* alpha0, const float* beta0, const float* m0, const float* C0, const float* v0,
+                       const float* kappa, const float* pivot, float* r, float* u,
+                       float* alpha, float* beta, float* m, float* C, float* v, float* xbar, float* S, float* pi,
+                       float* pack, void* ws, size_t ws_bytes, int iterations, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * T2: SVAE E-step fused with the ELBO regulariser (models/svae.py:14-119 and :229-252)
  * ------------------------------------------------------------------------------------------------

@@ -191,3 +191,6 @@ def test_full_size_properties():
     for _ in range(3):
         r2 = loop2.step()
     assert torch.equal(r, r2)
+    # the C-side loop (vmp_mix_iterate) enqueues the same launches
+    loop3 = _mix.VMPLoop(x, r0, L.VMP_GMM)
+    assert torch.equal(loop3.run(3), r)

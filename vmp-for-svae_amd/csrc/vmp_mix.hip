@@ -1018,4 +1018,19 @@ int vmp_mix_finalize_ws(const void* ws, const float* pivot, int64_t N, int D, in
     return run_finalize(f, D, static_cast<hipStream_t>(stream));
 }
 
+int vmp_mix_iterate(const float* x, int64_t N, int D, int K, int flavour, const float* alpha0, const float* beta0,
+                    const float* m0, const float* C0, const float* v0, const float* kappa, const float* pivot,
+                    float* r, float* u, float* alpha, float* beta, float* m, float* C, float* v, float* xbar, float* S,
+                    float* pi, float* pack, void* ws, size_t ws_bytes, int iterations, void* stream) {
+    if (iterations < 0 || !pack) { set_error("vmp_mix_iterate: bad argument"); return VMP_E_BADARG; }
+    for (int it = 0; it < iterations; ++it) {
+        int rc = vmp_mix_finalize_ws(ws, pivot, N, D, K, flavour, alpha0, beta0, m0, C0, v0, kappa, alpha, beta, m, C, v,
+                                     xbar, S, pi, pack, nullptr, stream);
+        if (rc) return rc;
+        rc = vmp_mix_estep_fused(x, N, D, K, flavour, pack, r, u, nullptr, pivot, ws, ws_bytes, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -185,6 +185,18 @@ class VMPLoop(object):
         self.iterations += 1
         return self.r
 
+    def run(self, iterations):
+        """`iterations` VMP iterations enqueued by one C call (vmp_mix_iterate): no host work between launches."""
+        p, pr = self.post, self.prior
+        L.check(L.lib().vmp_mix_iterate(L.ptr(self.x), self.N, self.D, self.K, self.flavour, L.ptr(pr[0]), L.ptr(pr[1]),
+                                        L.ptr(pr[2]), L.ptr(pr[3]), L.ptr(pr[4]), L.ptr(self.kappa), L.ptr(self.pivot),
+                                        L.ptr(self.r), L.ptr(self.u), L.ptr(p['alpha']), L.ptr(p['beta']), L.ptr(p['m']),
+                                        L.ptr(p['C']), L.ptr(p['v']), L.ptr(p['xbar']), L.ptr(p['S']), L.ptr(p['pi']),
+                                        L.ptr(p['pack']), L.ptr(self.ws), self.nb, int(iterations), L.stream()),
+                'vmp_mix_iterate')
+        self.iterations += int(iterations)
+        return self.r
+
     @property
     def stats(self):
         """Raw moments of the current r (reduces the partials the last pass left in the workspace)."""
