@@ -142,22 +142,26 @@ int    vmp_mix_iterate(const float* x, int64_t N, int D, int K, int flavour,
  *               regulariser = sum_nk exp(log_z_nk) (T'_nk + log_z_nk)               (svae.py:245-252)
  * Inputs: eta1, eta2d (N,L) encoder outputs; hk (K,L), Pk (K,L,L) symmetric, bias (K) = B_k + log pi_k from
  * unpack_recognition_gmm (svae.py:342-358); noise (N,K,L,S) replaces tf.random_normal (svae.py:114);
- * mk (K,L), Uk (K,L,L) upper-triangular with U^T U = E[Sigma_k]^-1, kappa (K) = sum log U_ii - L/2 log 2pi + E log pi_k
- * from theta (svae.py:205-214, no gradient).  Outputs: x (N,K,S,L), lz (N,K), Tp (N,K).                      */
+ * theta side: log p(x, z=k | theta) = kappa_k - 1/2 |W_k (x - m_k)|^2 with W_k (K,L,L) LOWER triangular,
+ * W^T W = E[Sigma_k]^-1, kappa_k = sum log W_ii - L/2 log 2pi + E log pi_k (GMM theta, svae.py:205-214, no gradient);
+ * with nu != NULL the Student-t of compute_elbo_smm (svae.py:265-322, student_t.py:31-37):
+ * kappa_k - 1/2 (nu_k + L) log1p(|W_k (x - m_k)|^2 / nu_k), W = chol(Sigma_k)^-1, kappa_k = lgamma terms - sum log L_ii
+ * + E log pi_k (mu_k, L_k trainable: experiments.py:160-161).  Outputs: x (N,K,S,L), lz (N,K), Tp (N,K).     */
 int    vmp_svae_estep_fwd(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
-                          const float* noise, const float* mk, const float* Uk, const float* kappa,
+                          const float* noise, const float* mk, const float* Wk, const float* kappa, const float* nu,
                           int64_t N, int K, int L, int S, float* x, float* lz, float* Tp, void* stream);
 
 /* Backward of the above: given dLoss/dx (N,K,S,L) (from the decoder), dLoss/dlog_z (N,K), dLoss/dT' (N,K), writes
  * dLoss/deta1, dLoss/deta2d (N,L) and per-block partial sums over n of dLoss/d{hk, Pk, bias}:
  * partials (vmp_svae_bwd_blocks(N,K), K, vmp_svae_bwd_partial_words(L)) = [ g_hk (L) | g_Pk lower triangle of the
- * symmetric gradient, row-major packed (L(L+1)/2) | g_bias ]; the caller sums them over the first axis.
+ * symmetric gradient, row-major packed (L(L+1)/2) | g_bias | g_mk (L) | g_Wk lower packed | g_kappa ] (the last three
+ * are zero except g_kappa unless nu != NULL); the caller sums them over the first axis.
  * Replaces TF autodiff through svae.py:50-119 and gaussian.py:74-105 (opt.compute_gradients, experiments.py:232). */
 int    vmp_svae_bwd_partial_words(int L);
 int    vmp_svae_bwd_blocks(int64_t N, int K);
 size_t vmp_svae_workspace_bytes(int64_t N, int K, int L);
 int    vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
-                          const float* mk, const float* Uk, const float* x, const float* lz,
+                          const float* mk, const float* Wk, const float* nu, const float* x, const float* lz,
                           const float* Gx, const float* Glz, const float* GT, int64_t N, int K, int L, int S,
                           float* g_eta1, float* g_eta2d, float* partials, size_t partial_bytes, void* stream);
 

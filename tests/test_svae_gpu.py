@@ -35,7 +35,8 @@ def make_trainer(g):
         for v in NET_VARS:
             vae.VARIABLES[scope + '/' + v] = torch.nn.Parameter(dev(g['in_w_%s/%s' % (scope, v)]))
     tr = SVAETrainer(K, Ld, U, Dy, nb_samples=S, lr=float(g['in_lr']), lrcvi=float(g['in_lrcvi']),
-                     decay_rate=float(g['in_decay']), m_uniform=dev(g['in_m_unif']), pi_normal=dev(g['in_pi_norm']))
+                     decay_rate=float(g['in_decay']), m_uniform=dev(g['in_m_unif']), pi_normal=dev(g['in_pi_norm']),
+                     smm=bool(smm), dof=float(g['in_dof0']))
     with torch.no_grad():
         tr.phi_gmm[1].add_(dev(g['in_Lk_low']))
     return tr, (N, K, Ld, S, Dy, U, steps)
@@ -127,3 +128,33 @@ def test_estep_vs_oracle_shapes():
         assert rel(pt_p.T_prime, Tp_o.detach().numpy()) < 5e-5, tag
         for a_, b_, n_ in zip(gp, go, ('eta1', 'eta2d', 'mu_k', 'L_k', 'log_pi_k')):
             assert rel(a_, b_.numpy()) < 2e-4, (tag, n_, rel(a_, b_.numpy()))
+
+
+@pytest.mark.parametrize('case', ['svae_smm_tiny', 'svae_smm_l8'])
+def test_smm_training_steps_vs_reference(golden, case):
+    """Student-t mixture SVAE (BASELINE config 5 model): compute_elbo_smm, trainable theta/mu_k, theta/L_k,
+    Dirichlet-only CVI update (experiments.py:154-176, 252-256; svae.py:265-322; student_t.py:7-39)."""
+    g = golden(case)
+    tr, (N, K, Ld, S, Dy, U, steps) = make_trainer(g)
+    assert rel(tr.gmm_prior, g['prior_alpha']) < 1e-6
+    for n_, t in zip(('alpha', 'mu', 'L', 'dof'), tr.theta):
+        assert rel(t, g['theta_init_' + n_]) < 1e-6, n_
+    y = dev(g['in_y'])
+    for it in range(steps):
+        pre = 'step%d_' % it
+        out = tr.step(y, noise=dev(g['in_noise'][it]), z_draws=dev(g['in_zdraw'][it], torch.int64))
+        slack = 1 + 2 * it
+        e_true, e_f32 = float(g[pre + 'elbo']), float(g[pre + 'elbo__f32'])
+        assert abs(out['elbo'].item() - e_true) <= slack * max(1e-5 * abs(e_true), 3 * abs(e_f32 - e_true)), (it, 'elbo')
+        det = g[pre + 'details']
+        assert abs(out['regulariser'].item() - det[3]) <= slack * 2e-5 * max(abs(det[3]), abs(det[0]) * 0.1)
+        assert rel(out['x_k'], g[pre + 'x_k']) <= slack * bar(g, pre + 'x_k', 1e-5)
+        for n_, gr in out['grads'].items():
+            e = rel(gr, g[pre + 'grad_' + n_])
+            assert e <= slack * bar(g, pre + 'grad_' + n_, 3e-5), (it, 'grad', n_, e)
+        assert rel(out['theta_star'][0], g[pre + 'theta_star_alpha']) <= slack * 1e-5
+        assert rel(tr.theta[0], g[pre + 'theta_alpha']) <= slack * 1e-5
+        names, params = tr.trainables()
+        assert 'theta/mu_k' in names and 'theta/L_k' in names
+        for n_, p in zip(names, params):
+            assert rel(p, g[pre + 'param_' + n_]) <= slack * bar(g, pre + 'param_' + n_, 2e-5), (it, 'param', n_)

@@ -31,11 +31,11 @@ _SIGNATURES = {
     'vmp_mix_estep_fused': (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
     'vmp_mix_stats_ws': (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _P, _c.c_size_t, _P]),
     'vmp_mix_iterate': (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int] + [_P] * 7 + [_P] * 11 + [_P, _c.c_size_t, _c.c_int, _P]),
-    'vmp_svae_estep_fwd': (_c.c_int, [_P] * 9 + [_c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P]),
+    'vmp_svae_estep_fwd': (_c.c_int, [_P] * 10 + [_c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P]),
     'vmp_svae_bwd_partial_words': (_c.c_int, [_c.c_int]),
     'vmp_svae_bwd_blocks': (_c.c_int, [_c.c_int64, _c.c_int]),
     'vmp_svae_workspace_bytes': (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int]),
-    'vmp_svae_estep_bwd': (_c.c_int, [_P] * 12 + [_c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _c.c_size_t, _P]),
+    'vmp_svae_estep_bwd': (_c.c_int, [_P] * 13 + [_c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _c.c_size_t, _P]),
     'vmp_svae_subsample': (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
     'vmp_diag_gauss_loglike_fwd': (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
     'vmp_diag_gauss_loglike_bwd': (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),

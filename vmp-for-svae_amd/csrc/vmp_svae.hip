@@ -6,7 +6,8 @@
 //   c_nk = bias_k + 1/2 |a|^2 - ld,            log_z_nk = c_nk - logsumexp_k c_nk         (svae.py:50-92)
 //   x_nks = Lt^-T (a + eps_nks)                                                            (svae.py:95-119)
 //   T'_nk = mean_s[ log N(x_s; phi~_nk) - log N(x_s; theta_k) - E log pi_k ]
-//         = -(L/2) log 2pi + ld - 1/(2S) sum_s |eps_s|^2 + 1/(2S) sum_s |U_k (x_s - m_k)|^2 - kappa_k
+//         = -(L/2) log 2pi + ld - 1/(2S) sum_s |eps_s|^2 + 1/(2S) sum_s |W_k (x_s - m_k)|^2 - kappa_k
+//   (Student-t theta, svae.py:265-322 / student_t.py:31-37:  ... + 1/(2S) sum_s (nu_k + L) log1p(|W_k (x_s - m_k)|^2 / nu_k) - kappa_k)
 // so that the reference's regulariser is sum_nk r_nk (T'_nk + log_z_nk) (svae.py:245-252).  One 8x8 Cholesky
 // per cell replaces the reference's 7 LU + 4 Cholesky factorisations.
 //
@@ -36,8 +37,9 @@ struct EFwdArgs {
     const float* bias;      // (K)     B_k + log pi_k
     const float* noise;     // (N,K,L,S)
     const float* mk;        // (K,L)   E[mu_k] of theta
-    const float* Uk;        // (K,L,L) upper-triangular U with U^T U = E[Sigma_k]^-1
-    const float* kappa;     // (K)     sum_i log U_ii - (L/2) log 2pi + E log pi_k
+    const float* Wk;        // (K,L,L) lower-triangular W with W^T W = E[Sigma_k]^-1 (GMM) / Sigma_k^-1 (SMM)
+    const float* kappa;     // (K)     the x-independent part of log p(x, z=k | theta)
+    const float* nu;        // (K)     Student-t degrees of freedom, or NULL for the Gaussian theta
     float* x;               // (N,K,S,L)
     float* lz;              // (N,K)
     float* Tp;              // (N,K)
@@ -133,23 +135,21 @@ __global__ __launch_bounds__(SV_FWD_MAX_NW * WAVE) void svae_estep_fwd_kernel(EF
     const int r = lane / K, k = lane - r * K, rbase = lane_on ? r * K : 0;
 
     // resident component parameters
-    float Pl[TRI], hkk[L], mkk[L], Uu[TRI];                // Uu: upper triangle of U, packed by rows: (i, j>=i)
-    float biask = 0.f, kappak = 0.f;
+    float Pl[TRI], hkk[L], mkk[L], Wt[TRI];                // Wt: lower triangle of W_k, packed
+    float biask = 0.f, kappak = 0.f, nuk = 0.f;
+    const bool student = a.nu != nullptr;
 #pragma unroll
     for (int i = 0; i < L; ++i) {
         hkk[i] = lane_on ? a.hk[k * L + i] : 0.f;
         mkk[i] = lane_on ? a.mk[k * L + i] : 0.f;
 #pragma unroll
-        for (int j = 0; j <= i; ++j) Pl[tri(i, j)] = lane_on ? a.Pk[(k * L + i) * L + j] : (i == j ? 1.f : 0.f);
+        for (int j = 0; j <= i; ++j) {
+            Pl[tri(i, j)] = lane_on ? a.Pk[(k * L + i) * L + j] : (i == j ? 1.f : 0.f);
+            Wt[tri(i, j)] = lane_on ? a.Wk[(k * L + i) * L + j] : 0.f;
+        }
     }
-    {
-        int idx = 0;
-#pragma unroll
-        for (int i = 0; i < L; ++i)
-#pragma unroll
-            for (int j = i; j < L; ++j) Uu[idx++] = lane_on ? a.Uk[(k * L + i) * L + j] : 0.f;
-    }
-    if (lane_on) { biask = a.bias[k]; kappak = a.kappa[k]; }
+    if (lane_on) { biask = a.bias[k]; kappak = a.kappa[k]; nuk = student ? a.nu[k] : 1.f; }
+    const float inv_nu = 1.0f / nuk;
 
     const long long ntiles = (a.N + RPT - 1) / RPT;
     const float invLS = 1.0f / (float)LSn, invS = 1.0f / (float)S;
@@ -216,14 +216,15 @@ __global__ __launch_bounds__(SV_FWD_MAX_NW * WAVE) void svae_estep_fwd_kernel(EF
             float d[L];
 #pragma unroll
             for (int i = 0; i < L; ++i) d[i] = z[i] - mkk[i];
-            int idx = 0;
+            float del2 = 0.f;
 #pragma unroll
             for (int i = 0; i < L; ++i) {
                 float y = 0.f;
 #pragma unroll
-                for (int j = i; j < L; ++j) y = fmaf(Uu[idx++], d[j], y);
-                qth = fmaf(y, y, qth);
+                for (int j = 0; j <= i; ++j) y = fmaf(Wt[tri(i, j)], d[j], y);
+                del2 = fmaf(y, y, del2);
             }
+            qth += student ? (nuk + (float)L) * log1pf(del2 * inv_nu) : del2;
             if (lane_on) {
 #pragma unroll
                 for (int i = 0; i < L; ++i) cell[i * S + s] = z[i];
@@ -271,7 +272,8 @@ struct EBwdArgs {
     const float* Pk;
     const float* bias;
     const float* mk;
-    const float* Uk;
+    const float* Wk;
+    const float* nu;        // (K) or NULL
     const float* x;         // (N,K,S,L) samples from the forward pass
     const float* lz;        // (N,K)
     const float* Gx;        // (N,K,S,L) dLoss/dx  (from the decoder)
@@ -279,7 +281,7 @@ struct EBwdArgs {
     const float* GT;        // (N,K)     dLoss/dT'
     float* g_eta1;          // (N,L)
     float* g_eta2d;         // (N,L)
-    float* partials;        // (nblk, K, L + TRI + 1): g_hk | g_Pk (lower, symmetric gradient) | g_bias
+    float* partials;        // (nblk, K, 2(L+TRI+1)): g_hk | g_Pk (lower, symmetric gradient) | g_bias | g_mk | g_Wk (lower) | g_kappa
     long long N;
     int K, S, vec_ok;
 };
@@ -287,7 +289,8 @@ struct EBwdArgs {
 template <int L>
 __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a) {
     constexpr int TRI = SvGeo<L>::TRI;
-    constexpr int PW = L + TRI + 1;
+    constexpr int PW = 2 * (L + TRI + 1);
+    constexpr int TH = L + TRI + 1;                         // offset of the theta-side sums
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int K = a.K, S = a.S;
@@ -310,19 +313,16 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
     }
     __syncthreads();
 
-    float hkk[L], mkk[L], Uu[TRI];
+    float hkk[L], mkk[L], Wt[TRI];
+    const bool student = a.nu != nullptr;
 #pragma unroll
     for (int i = 0; i < L; ++i) {
         hkk[i] = lane_on ? a.hk[k * L + i] : 0.f;
         mkk[i] = lane_on ? a.mk[k * L + i] : 0.f;
-    }
-    {
-        int idx = 0;
 #pragma unroll
-        for (int i = 0; i < L; ++i)
-#pragma unroll
-            for (int j = i; j < L; ++j) Uu[idx++] = lane_on ? a.Uk[(k * L + i) * L + j] : 0.f;
+        for (int j = 0; j <= i; ++j) Wt[tri(i, j)] = lane_on ? a.Wk[(k * L + i) * L + j] : 0.f;
     }
+    const float nuk = (student && lane_on) ? a.nu[k] : 1.f;
     for (int i = 0; i < PW; ++i) accl[i * WAVE + lane] = 0.f;   // sums over this lane's cells (fixed k)
 
     const long long ntiles = (a.N + RPT - 1) / RPT;
@@ -383,24 +383,42 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
 #pragma unroll
                 for (int i = 0; i < L; ++i) { xs[i] = 0.f; gx[i] = 0.f; }
             }
-            // d/dx of the theta term of T':  (1/S) U^T U (x - m)
+            // d/dx of the theta term of T':  (1/S) c_s W^T W (x - m),  c_s = 1 (Gaussian) or (nu+L)/(nu+delta^2)
             float d[L], y[L];
 #pragma unroll
             for (int i = 0; i < L; ++i) d[i] = xs[i] - mkk[i];
-            {
-                int idx = 0;
+            float del2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                float yy = 0.f;
+#pragma unroll
+                for (int j = 0; j <= i; ++j) yy = fmaf(Wt[tri(i, j)], d[j], yy);
+                y[i] = yy;
+                del2 = fmaf(yy, yy, del2);
+            }
+            const float gc = student ? gts * (nuk + (float)L) / (nuk + del2) : gts;
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                const float gy = gc * y[i];
+#pragma unroll
+                for (int j = 0; j <= i; ++j) gx[j] = fmaf(Wt[tri(i, j)], gy, gx[j]);
+            }
+            if (student && on) {
+                // theta is trainable in the SMM model: d/dm = -(the x-gradient of the theta term), d/dW = c y d^T
+                float tx[L];
+#pragma unroll
+                for (int j = 0; j < L; ++j) tx[j] = 0.f;
 #pragma unroll
                 for (int i = 0; i < L; ++i) {
-                    float yy = 0.f;
+                    const float gy = gc * y[i];
 #pragma unroll
-                    for (int j = i; j < L; ++j) yy = fmaf(Uu[idx++], d[j], yy);
-                    y[i] = yy;
+                    for (int j = 0; j <= i; ++j) {
+                        tx[j] = fmaf(Wt[tri(i, j)], gy, tx[j]);
+                        accl[(TH + L + tri(i, j)) * WAVE + lane] += gy * d[j];
+                    }
                 }
-                idx = 0;
 #pragma unroll
-                for (int i = 0; i < L; ++i)
-#pragma unroll
-                    for (int j = i; j < L; ++j) gx[j] = fmaf(gts * Uu[idx++], y[i], gx[j]);
+                for (int j = 0; j < L; ++j) accl[(TH + j) * WAVE + lane] -= tx[j];
             }
             solve_lower<L>(Lm, gx);                         // w_s = Lt^-1 gx_s
 #pragma unroll
@@ -490,6 +508,7 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
 #pragma unroll
             for (int i = 0; i < TRI; ++i) accl[(L + i) * WAVE + lane] += gP[i];
             accl[(L + TRI) * WAVE + lane] += Gc;
+            accl[(TH + L + TRI) * WAVE + lane] -= gT;          // T' has -kappa_k
         }
 #pragma unroll
         for (int i = 0; i < L; ++i) {
@@ -596,7 +615,7 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" {
 
-int vmp_svae_bwd_partial_words(int L) { return L + L * (L + 1) / 2 + 1; }
+int vmp_svae_bwd_partial_words(int L) { return 2 * (L + L * (L + 1) / 2 + 1); }
 
 size_t vmp_svae_workspace_bytes(int64_t N, int K, int L) {
     (void)N;
@@ -606,15 +625,15 @@ size_t vmp_svae_workspace_bytes(int64_t N, int K, int L) {
 int vmp_svae_bwd_blocks(int64_t N, int K) { return sv_blocks(N, K); }
 
 int vmp_svae_estep_fwd(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
-                       const float* noise, const float* mk, const float* Uk, const float* kappa, int64_t N, int K,
-                       int L, int S, float* x, float* lz, float* Tp, void* stream) {
+                       const float* noise, const float* mk, const float* Wk, const float* kappa, const float* nu,
+                       int64_t N, int K, int L, int S, float* x, float* lz, float* Tp, void* stream) {
     int rc = check_sv(N, K, L, S);
     if (rc) return rc;
-    if (!eta1 || !eta2d || !hk || !Pk || !bias || !noise || !mk || !Uk || !kappa || !x || !lz || !Tp) {
+    if (!eta1 || !eta2d || !hk || !Pk || !bias || !noise || !mk || !Wk || !kappa || !x || !lz || !Tp) {
         set_error("vmp_svae_estep_fwd: null pointer");
         return VMP_E_BADARG;
     }
-    EFwdArgs a{eta1, eta2d, hk, Pk, bias, noise, mk, Uk, kappa, x, lz, Tp, N, K, S, 0};
+    EFwdArgs a{eta1, eta2d, hk, Pk, bias, noise, mk, Wk, kappa, nu, x, lz, Tp, N, K, S, 0};
     a.vec_ok = al16(noise) && al16(x);
     const size_t per_wave = (size_t)(WAVE * (L * S | 1) + WAVE) * sizeof(float);
     int nw = (int)((150 * 1024) / per_wave);                 // one block per CU, as many waves as 160 KiB of LDS hold
@@ -635,19 +654,19 @@ int vmp_svae_estep_fwd(const float* eta1, const float* eta2d, const float* hk, c
 }
 
 int vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
-                       const float* mk, const float* Uk, const float* x, const float* lz, const float* Gx,
+                       const float* mk, const float* Wk, const float* nu, const float* x, const float* lz, const float* Gx,
                        const float* Glz, const float* GT, int64_t N, int K, int L, int S, float* g_eta1, float* g_eta2d,
                        float* partials, size_t partial_bytes, void* stream) {
     int rc = check_sv(N, K, L, S);
     if (rc) return rc;
-    if (!eta1 || !eta2d || !hk || !Pk || !bias || !mk || !Uk || !x || !lz || !Gx || !Glz || !GT || !g_eta1 || !g_eta2d || !partials) {
+    if (!eta1 || !eta2d || !hk || !Pk || !bias || !mk || !Wk || !x || !lz || !Gx || !Glz || !GT || !g_eta1 || !g_eta2d || !partials) {
         set_error("vmp_svae_estep_bwd: null pointer");
         return VMP_E_BADARG;
     }
     const int blocks = sv_blocks(N, K);
     const int PW = vmp_svae_bwd_partial_words(L);
     if (partial_bytes < (size_t)blocks * K * PW * sizeof(float)) { set_error("vmp_svae_estep_bwd: partials buffer too small"); return VMP_E_WS; }
-    EBwdArgs a{eta1, eta2d, hk, Pk, bias, mk, Uk, x, lz, Gx, Glz, GT, g_eta1, g_eta2d, partials, N, K, S, 0};
+    EBwdArgs a{eta1, eta2d, hk, Pk, bias, mk, Wk, nu, x, lz, Gx, Glz, GT, g_eta1, g_eta2d, partials, N, K, S, 0};
     a.vec_ok = al16(x) && al16(Gx);
     const size_t lds = (size_t)(K * ((L * (L + 1) / 2) | 1) + SV_NW * WAVE + PW * WAVE + SV_NW * PW * WAVE) * sizeof(float);
     rc = -1;

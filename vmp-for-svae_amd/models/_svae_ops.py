@@ -9,13 +9,35 @@ def _c(t, name, shape=None):
     return L.dev_f32(t, name, shape)
 
 
+def _unpack_partials(red, Ld, device):
+    """(K, 2(L+TRI+1)) fp64 sums -> g_hk, g_Pk (symmetric), g_bias, g_mk, g_Wk (lower), g_kappa."""
+    K = red.shape[0]
+    T = Ld * (Ld + 1) // 2
+    il = torch.tril_indices(Ld, Ld, device=device)
+
+    def lower(tri):
+        M = torch.zeros(K, Ld, Ld, dtype=torch.float64, device=device)
+        M[:, il[0], il[1]] = tri
+        return M
+    g_hk = red[:, :Ld]
+    gp = lower(red[:, Ld:Ld + T])
+    g_P = gp + gp.transpose(1, 2) - torch.diag_embed(torch.diagonal(gp, dim1=1, dim2=2))
+    g_bias = red[:, Ld + T]
+    o = Ld + T + 1
+    g_mk = red[:, o:o + Ld]
+    g_W = lower(red[:, o + Ld:o + Ld + T])
+    g_kappa = red[:, o + Ld + T]
+    return [t.float() for t in (g_hk, g_P, g_bias, g_mk, g_W, g_kappa)]
+
+
 class SvaeEStepFn(torch.autograd.Function):
-    """(eta1, eta2d, hk, Pk, bias, noise, mk, Uk, kappa) -> (x (N,K,S,L), log_z (N,K), T' (N,K)).
-    Gradients flow to eta1, eta2d (N,L) and hk, Pk, bias (K-sized, summed over n); theta-side inputs
-    (mk, Uk, kappa) are treated as constants (reference svae.py:211-214 stop_gradient)."""
+    """(eta1, eta2d, hk, Pk, bias, noise, mk, Wk, kappa, nu) -> (x (N,K,S,L), log_z (N,K), T' (N,K)).
+    Gradients flow to eta1, eta2d (N,L), to hk, Pk, bias (K-sized, summed over n) and - for the Student-t theta of the
+    SMM model (nu is not None), whose mu_k, L_k are trainable (experiments.py:160-161) - to mk, Wk, kappa.  For the
+    Gaussian theta the reference stops the gradient (svae.py:211-214)."""
 
     @staticmethod
-    def forward(ctx, eta1, eta2d, hk, Pk, bias, noise, mk, Uk, kappa):
+    def forward(ctx, eta1, eta2d, hk, Pk, bias, noise, mk, Wk, kappa, nu):
         eta1 = _c(eta1, 'eta1')
         N, Ld = eta1.shape
         eta2d = _c(eta2d, 'eta2_diag', (N, Ld))
@@ -25,21 +47,24 @@ class SvaeEStepFn(torch.autograd.Function):
         if noise.dim() != 4 or tuple(noise.shape[:3]) != (N, K, Ld):
             raise L.VmpError('noise must have shape (N,K,L,S), got %s' % (tuple(noise.shape),))
         S = noise.shape[3]
-        mk, Uk, kappa = _c(mk, 'm_k', (K, Ld)), _c(Uk, 'U_k', (K, Ld, Ld)), _c(kappa, 'kappa_k', (K,))
+        mk, Wk, kappa = _c(mk, 'm_k', (K, Ld)), _c(Wk, 'W_k', (K, Ld, Ld)), _c(kappa, 'kappa_k', (K,))
+        nu = None if nu is None else _c(nu, 'nu_k', (K,))
         f32 = dict(dtype=torch.float32, device=eta1.device)
         x = torch.empty(N, K, S, Ld, **f32)
         lz = torch.empty(N, K, **f32)
         Tp = torch.empty(N, K, **f32)
         L.check(L.lib().vmp_svae_estep_fwd(L.ptr(eta1), L.ptr(eta2d), L.ptr(hk), L.ptr(Pk), L.ptr(bias), L.ptr(noise),
-                                           L.ptr(mk), L.ptr(Uk), L.ptr(kappa), N, K, Ld, S, L.ptr(x), L.ptr(lz),
-                                           L.ptr(Tp), L.stream()), 'vmp_svae_estep_fwd')
-        ctx.save_for_backward(eta1, eta2d, hk, Pk, bias, mk, Uk, x, lz)
+                                           L.ptr(mk), L.ptr(Wk), L.ptr(kappa), L.ptr(nu), N, K, Ld, S, L.ptr(x),
+                                           L.ptr(lz), L.ptr(Tp), L.stream()), 'vmp_svae_estep_fwd')
+        ctx.save_for_backward(eta1, eta2d, hk, Pk, bias, mk, Wk, x, lz, *([nu] if nu is not None else []))
         ctx.dims = (N, K, Ld, S)
         return x, lz, Tp
 
     @staticmethod
     def backward(ctx, g_x, g_lz, g_T):
-        eta1, eta2d, hk, Pk, bias, mk, Uk, x, lz = ctx.saved_tensors
+        sv = ctx.saved_tensors
+        eta1, eta2d, hk, Pk, bias, mk, Wk, x, lz = sv[:9]
+        nu = sv[9] if len(sv) > 9 else None
         N, K, Ld, S = ctx.dims
         f32 = dict(dtype=torch.float32, device=eta1.device)
         g_x = torch.zeros_like(x) if g_x is None else g_x.contiguous()
@@ -51,18 +76,14 @@ class SvaeEStepFn(torch.autograd.Function):
         PW = L.lib().vmp_svae_bwd_partial_words(Ld)
         partials = torch.empty(nblk, K, PW, **f32)
         L.check(L.lib().vmp_svae_estep_bwd(L.ptr(eta1), L.ptr(eta2d), L.ptr(hk), L.ptr(Pk), L.ptr(bias), L.ptr(mk),
-                                           L.ptr(Uk), L.ptr(x), L.ptr(lz), L.ptr(g_x), L.ptr(g_lz), L.ptr(g_T), N, K, Ld,
-                                           S, L.ptr(g_eta1), L.ptr(g_eta2d), L.ptr(partials), partials.numel() * 4,
-                                           L.stream()), 'vmp_svae_estep_bwd')
+                                           L.ptr(Wk), L.ptr(nu), L.ptr(x), L.ptr(lz), L.ptr(g_x), L.ptr(g_lz), L.ptr(g_T),
+                                           N, K, Ld, S, L.ptr(g_eta1), L.ptr(g_eta2d), L.ptr(partials),
+                                           partials.numel() * 4, L.stream()), 'vmp_svae_estep_bwd')
         red = partials.double().sum(0)                       # (K, PW): K-sized, fixed order
-        g_hk = red[:, :Ld].float()
-        tri = red[:, Ld:Ld + Ld * (Ld + 1) // 2]
-        il = torch.tril_indices(Ld, Ld, device=eta1.device)
-        g_P = torch.zeros(K, Ld, Ld, dtype=torch.float64, device=eta1.device)
-        g_P[:, il[0], il[1]] = tri
-        g_P = g_P + g_P.transpose(1, 2) - torch.diag_embed(torch.diagonal(g_P, dim1=1, dim2=2))
-        g_bias = red[:, -1].float()
-        return g_eta1, g_eta2d, g_hk, g_P.float(), g_bias, None, None, None, None
+        g_hk, g_P, g_bias, g_mk, g_W, g_kappa = _unpack_partials(red, Ld, eta1.device)
+        if nu is None:
+            g_mk = g_W = g_kappa = None
+        return g_eta1, g_eta2d, g_hk, g_P, g_bias, None, g_mk, g_W, g_kappa, None
 
 
 class DiagGaussLoglikeFn(torch.autograd.Function):

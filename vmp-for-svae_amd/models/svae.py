@@ -47,23 +47,37 @@ def _recognition_bias(eta1_k, eta2_k, pi_k):
 
 
 def _theta_pack(theta):
-    """(m_k, U_k, kappa_k) from the natural NIW/Dirichlet parameters theta (reference svae.py:205-214, detached):
-    log N(x; theta_k) + E log pi_k = -1/2 |U_k (x - m_k)|^2 + kappa_k."""
+    """(m_k, W_k, kappa_k, nu_k) such that log p(x, z=k | theta) = kappa_k - 1/2 f(|W_k (x - m_k)|^2), W lower.
+    GMM theta = natural NIW / Dirichlet 5-tuple (reference svae.py:205-214, stop_gradient): f = identity,
+    W = chol(E[Sigma])^-1.  SMM theta = (alpha_nat, mu_k, L_k_raw, DoF) (svae.py:268-277): Student-t,
+    f(d) = (nu+L) log1p(d/nu), W = L_k^-1, gradients flow to mu_k and L_k."""
+    if len(theta) == 4:
+        alpha_nat, mu_k, L_raw, dof = theta
+        Ld = mu_k.shape[-1]
+        Lk = _tril_softplus(L_raw)
+        eye = torch.eye(Ld, dtype=Lk.dtype, device=Lk.device).expand_as(Lk)
+        W = torch.linalg.solve_triangular(Lk, eye, upper=False)
+        elp = dirichlet.expected_log_pi(dirichlet.natural_to_standard(alpha_nat)).detach()
+        nu = dof.detach().float()
+        kappa = (torch.lgamma(0.5 * (nu + Ld)) - torch.lgamma(0.5 * nu) - 0.5 * Ld * torch.log(math.pi * nu)
+                 - torch.log(torch.diagonal(Lk, dim1=-2, dim2=-1)).sum(-1) + elp)
+        return mu_k, W, kappa, nu.contiguous()
     with torch.no_grad():
         beta_k, m_k, C_k, v_k = niw.natural_to_standard(*theta[1:])
         mu, sigma = niw.expected_values((beta_k, m_k, C_k, v_k))
-        Lam = torch.linalg.inv(sigma.double())
-        Lam = 0.5 * (Lam + Lam.transpose(-1, -2))
-        U = torch.linalg.cholesky(Lam).transpose(-1, -2)
+        sig = sigma.double()
+        Lc = torch.linalg.cholesky(0.5 * (sig + sig.transpose(-1, -2)))
         Ld = mu.shape[-1]
+        eye = torch.eye(Ld, dtype=Lc.dtype, device=Lc.device).expand_as(Lc)
+        W = torch.linalg.solve_triangular(Lc, eye, upper=False)
         elp = dirichlet.expected_log_pi(dirichlet.natural_to_standard(theta[0]).double())
-        kappa = torch.log(torch.diagonal(U, dim1=-2, dim2=-1)).sum(-1) - 0.5 * Ld * math.log(2 * math.pi) + elp
-        return mu.float().contiguous(), U.float().contiguous(), kappa.float().contiguous()
+        kappa = torch.log(torch.diagonal(W, dim1=-2, dim2=-1)).sum(-1) - 0.5 * Ld * math.log(2 * math.pi) + elp
+        return mu.float().contiguous(), W.float().contiguous(), kappa.float().contiguous(), None
 
 
 def _neutral_theta(K, Ld, device):
     f32 = dict(dtype=torch.float32, device=device)
-    return torch.zeros(K, Ld, **f32), torch.zeros(K, Ld, Ld, **f32), torch.zeros(K, **f32)
+    return torch.zeros(K, Ld, **f32), torch.zeros(K, Ld, Ld, **f32), torch.zeros(K, **f32), None
 
 
 class PhiTilde(object):
@@ -102,8 +116,8 @@ def compute_log_z_given_y(eta1_phi1, eta2_phi1, eta1_phi2, eta2_phi2, pi_phi2, n
     e2d = torch.diagonal(eta2_phi1, dim1=-2, dim2=-1).contiguous()
     P, bias = _recognition_bias(eta1_phi2, eta2_phi2, pi_phi2)
     noise = torch.zeros(N, K, Ld, 1, dtype=torch.float32, device=eta1_phi1.device)
-    mk, Uk, kap = _neutral_theta(K, Ld, eta1_phi1.device)
-    _, lz, _ = _svae_ops.SvaeEStepFn.apply(eta1_phi1, e2d, eta1_phi2.contiguous(), P.contiguous(), bias, noise, mk, Uk, kap)
+    mk, Wk, kap, nu = _neutral_theta(K, Ld, eta1_phi1.device)
+    _, lz, _ = _svae_ops.SvaeEStepFn.apply(eta1_phi1, e2d, eta1_phi2.contiguous(), P.contiguous(), bias, noise, mk, Wk, kap, nu)
     return lz, (None, None)
 
 
@@ -119,9 +133,9 @@ def e_step(phi_enc, phi_gmm, nb_samples, seed=0, name="e_step", noise=None, thet
     if noise is None:
         g = torch.Generator(device=eta1_phi1.device).manual_seed(int(seed))
         noise = torch.randn(N, K, Ld, nb_samples, generator=g, device=eta1_phi1.device)
-    mk, Uk, kap = _theta_pack(theta) if theta is not None else _neutral_theta(K, Ld, eta1_phi1.device)
+    mk, Wk, kap, nu = _theta_pack(theta) if theta is not None else _neutral_theta(K, Ld, eta1_phi1.device)
     x, lz, Tp = _svae_ops.SvaeEStepFn.apply(eta1_phi1, eta2_diag, eta1_phi2.contiguous(), P.contiguous(), bias, noise,
-                                            mk, Uk, kap)
+                                            mk, Wk, kap, nu)
     phi_tilde = PhiTilde(eta1_phi1, eta2_diag, eta1_phi2, eta2_phi2, Tp if theta is not None else None, _theta_key(theta))
     return x, lz, phi_tilde, (None, None)
 
@@ -198,6 +212,12 @@ def compute_elbo(y, reconstructions, theta, phi_tilde, x_k_samps, log_z_given_y_
         num = None
         den = None
     return elbo, (rec, num, den, reg)
+
+
+def compute_elbo_smm(y, reconstructions, theta, phi_tilde, x_k_samps, log_z_given_y_phi, decoder_type):
+    """reference svae.py:265-322: as compute_elbo with the Student-t density of theta = (alpha, mu_k, L_k, DoF)
+    (distributions/student_t.py:7-39); the per-sample densities come from the fused E-step (e_step(theta=theta))."""
+    return compute_elbo(y, reconstructions, theta, phi_tilde, x_k_samps, log_z_given_y_phi, decoder_type)
 
 
 def update_gmm_params(current_gmm_params, gmm_params_star, step_size, name='cvi_update_theta'):

@@ -70,7 +70,7 @@ def unpack_after_allreduce(buf, stats_shape, grad_shapes, n_scalars):
 
 class SVAETrainer(object):
     def __init__(self, K, Ld, U, Dy, nb_samples=10, lr=3e-4, lrcvi=0.2, decay_rate=0.95, stddev_init_nn=0.01, seed=0,
-                 device='cuda', m_uniform=None, pi_normal=None, group=None):
+                 device='cuda', m_uniform=None, pi_normal=None, group=None, smm=False, dof=5.0):
         self.K, self.L, self.S = K, Ld, nb_samples
         self.lr, self.lrcvi0, self.decay_rate = lr, lrcvi, decay_rate
         self.group = group
@@ -80,9 +80,17 @@ class SVAETrainer(object):
         self.decoder_layers = [(U, tanh), (U, tanh), (Dy, 'standard')]            # experiments.py:140
         self.stddev_init_nn = stddev_init_nn
         self.seed = seed
+        self.smm = smm
         self.gmm_prior, self.theta = svae.init_mm(K, Ld, seed=seed, param_device=self.device, m_uniform=m_uniform)
         self.phi_gmm = list(svae.init_recognition_params(self.theta, K, seed=seed, param_device=self.device,
                                                          pi_normal=pi_normal))
+        if smm:
+            # experiments.py:154-176: Student-t point estimates mu_k, L_k (trainable, initialised from the PRIOR),
+            # constant DoF, Dirichlet alpha_k updated by CVI; only the Dirichlet part of the prior is kept
+            mu_k, L_k = svae.make_loc_scale_variables(self.gmm_prior, self.device)
+            DoF = torch.full((K,), float(dof), dtype=torch.float32, device=self.device)
+            self.theta = [self.theta[0].clone(), mu_k, L_k, DoF]
+            self.gmm_prior = self.gmm_prior[0]
         self.global_step = 0
         self.opt = None
 
@@ -90,6 +98,9 @@ class SVAETrainer(object):
         """21 tensors in the reference's order: phi_gmm (3), encoder_net (9), decoder_net (9)."""
         names = ['phi_gmm/mu_k', 'phi_gmm/L_k', 'phi_gmm/log_pi_k']
         ts = list(self.phi_gmm)
+        if self.smm:                                             # experiments.py:160-161
+            names += ['theta/mu_k', 'theta/L_k']
+            ts += [self.theta[1], self.theta[2]]
         for scope in ('encoder_net', 'decoder_net'):
             for n, p in vae.net_variables(scope):
                 names.append(n)
@@ -101,7 +112,8 @@ class SVAETrainer(object):
                              stddev_init_nn=self.stddev_init_nn, seed=self.seed + self.global_step, noise=noise,
                              z_draws=z_draws, theta=self.theta)
         y_rec, phi_enc, x_k, x_s, log_z, _, phi_tilde = out
-        elbo, details = svae.compute_elbo(y, y_rec, self.theta, phi_tilde, x_k, log_z, 'standard')
+        elbo_fn = svae.compute_elbo_smm if self.smm else svae.compute_elbo
+        elbo, details = elbo_fn(y, y_rec, self.theta, phi_tilde, x_k, log_z, 'standard')
         return elbo, details, x_k, x_s, log_z
 
     def step(self, y, noise=None, z_draws=None, chunk=None):
@@ -125,7 +137,11 @@ class SVAETrainer(object):
             g = torch.autograd.grad(-elbo, params, allow_unused=True)
             g = [torch.zeros_like(p) if gi is None else gi for gi, p in zip(g, params)]
             r_nk = torch.exp(log_z.detach())
-            st = _mix.raw_stats(x_s.detach().contiguous(), r_nk.contiguous())      # HIP: (K, 2+L+L*L) fp64
+            if self.smm:                                                              # svae.m_step_smm: N_k only
+                from .models import gmm as _gmm
+                st = _gmm.update_Nk(r_nk.contiguous()).double().reshape(-1, 1)
+            else:
+                st = _mix.raw_stats(x_s.detach().contiguous(), r_nk.contiguous())  # HIP: (K, 2+L+L*L) fp64
             grads = g if grads is None else [a + b for a, b in zip(grads, g)]
             stats = st if stats is None else stats + st
             rec, _, _, reg = details
@@ -140,10 +156,13 @@ class SVAETrainer(object):
             grads = [(g / world).to(torch.float32) for g in g64]                    # average_gradients (tf_utils.py:79)
             elbo_t, rec_t, reg_t = sc[0], sc[1], sc[2]
         lrcvi = exponential_decay(self.lrcvi0, self.global_step, 1000, self.decay_rate)
-        theta_star = svae.m_step_from_stats(self.gmm_prior, stats)
+        if self.smm:                                                                # experiments.py:252-256
+            theta_star = [self.gmm_prior + stats[:, 0].float()]
+        else:
+            theta_star = svae.m_step_from_stats(self.gmm_prior, stats)
         if self.opt is None:
             self.opt = TFAdam(params, self.lr)
-        svae.update_gmm_params(self.theta, theta_star, lrcvi)                       # experiments.py:258-260
+        svae.update_gmm_params(self.theta[:1] if self.smm else self.theta, theta_star, lrcvi)   # experiments.py:258-260
         self.opt.apply_gradients(grads)                                             # experiments.py:264-265
         self.global_step += 1
         out = dict(elbo=elbo_t, neg_rec_err=rec_t, regulariser=reg_t, grads=dict(zip(names, grads)),
