@@ -182,6 +182,24 @@ int    vmp_diag_gauss_loglike_fwd(const float* y, const float* mean, const float
 int    vmp_diag_gauss_loglike_bwd(const float* y, const float* mean, const float* var, const float* gA,
                                   int64_t N, int K, int S, int Dy, float* gmean, float* gvar, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Stand-alone per-cell log-densities (forward only; the training step uses the fused kernels above)
+ * ------------------------------------------------------------------------------------------------
+ * vmp_gauss_logprob_nat_per_samp : gaussian.log_probability_nat_per_samp (distributions/gaussian.py:74-105)
+ *     x (N,K,S,D), eta1 (N,K,D), eta2 (N,K,D,D) -> out (N,K,S)
+ * vmp_gauss_logprob_nat          : gaussian.log_probability_nat (gaussian.py:30-71), normalised over k
+ *     x (N,D), eta1 (N,K,D), eta2 (N,K,D,D), log_weights (K) or NULL -> out (N,K)
+ * vmp_student_t_logprob          : student_t.log_probability_per_samp (distributions/student_t.py:7-39,59-61)
+ *     y (N,K,S,D), mu (K,D), W (K,D,D) lower with W^T W = sigma^-1, cst (K) = lgamma((v+D)/2) - lgamma(v/2)
+ *     - D/2 log(pi v) - 1/2 logdet sigma, nu (K) -> out (N,K,S)   (the K distinct scale matrices are factorised
+ *     once on the host side instead of N*K*S times, student_t.py:26-36)                                        */
+int    vmp_gauss_logprob_nat_per_samp(const float* x, const float* eta1, const float* eta2, int64_t N, int K, int S,
+                                      int D, float* out, void* stream);
+int    vmp_gauss_logprob_nat(const float* x, const float* eta1, const float* eta2, const float* log_weights,
+                             int64_t N, int K, int D, float* out, void* stream);
+int    vmp_student_t_logprob(const float* y, const float* mu, const float* W, const float* cst, const float* nu,
+                             int64_t N, int K, int S, int D, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

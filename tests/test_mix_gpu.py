@@ -194,3 +194,32 @@ def test_full_size_properties():
     # the C-side loop (vmp_mix_iterate) enqueues the same launches
     loop3 = _mix.VMPLoop(x, r0, L.VMP_GMM)
     assert torch.equal(loop3.run(3), r)
+
+
+@pytest.mark.parametrize('case', ['dist_tiny', 'dist_l8'])
+def test_distributions_golden(golden, case):
+    """Stand-alone densities and the K-sized parameter algebra of the distributions package vs the reference run."""
+    from vmp_for_svae_amd.distributions import gaussian, niw, dirichlet, student_t
+    from vmp_for_svae_amd.helpers import tf_utils
+    g = golden(case)
+    i = {k[3:]: dev(g[k]) for k in g.files if k.startswith('in_')}
+    e1, e2 = gaussian.standard_to_natural(i['mu'], i['sigma'])
+    assert relerr(e1, g['s2n_eta1']) < 2e-5 and relerr(e2, g['s2n_eta2']) < 2e-5
+    mu2, sg2 = gaussian.natural_to_standard(e1, e2)
+    assert relerr(mu2, g['n2s_mu']) < 5e-5 and relerr(sg2, g['n2s_sigma']) < 5e-5
+    lp = gaussian.log_probability_nat(i['x'], i['eta1_nk'], i['eta2_nk'], i['w'])
+    assert abserr(torch.exp(lp), np.exp(g['logprob_nat'])) < 1e-5
+    lp0 = gaussian.log_probability_nat(i['x'], i['eta1_nk'], i['eta2_nk'], None)
+    assert abserr(torch.exp(lp0), np.exp(g['logprob_nat_now'])) < 1e-5
+    ps = gaussian.log_probability_nat_per_samp(i['xs'], i['eta1_nk'], i['eta2_nk'])
+    assert relerr(ps, g['logprob_per_samp']) <= bar(g, 'logprob_per_samp', 1e-5)
+    st = student_t.log_probability_per_samp(i['xs'], i['mu'], i['sigma'], i['dof'])
+    assert relerr(st, g['student_t']) <= bar(g, 'student_t', 1e-5)
+    assert relerr(tf_utils.logdet(i['sigma']), g['logdet']) < 1e-5
+    em, eC = niw.expected_values((i['beta'], i['m'], i['C'], i['v']))
+    assert relerr(eC, g['niw_exp_C']) < 2e-5
+    A, b, be, vh = niw.standard_to_natural(i['beta'], i['m'], i['C'], i['v'])
+    assert relerr(A, g['niw_A']) < 1e-6 and relerr(b, g['niw_b']) < 1e-6 and relerr(vh, g['niw_vhat']) < 1e-6
+    _, m2, C2, v2 = niw.natural_to_standard(A, b, be, vh)
+    assert relerr(C2, g['niw_back_C']) < 1e-5 and relerr(v2, g['niw_back_v']) < 1e-6
+    assert relerr(dirichlet.expected_log_pi(i['alpha']), g['dir_elogpi']) < 1e-5

@@ -115,14 +115,51 @@ class DiagGaussLoglikeFn(torch.autograd.Function):
 
 
 def gauss_logprob_nat(x, eta1, eta2, weights=None):
-    raise NotImplementedError('stand-alone gaussian.log_probability_nat: fused into vmp_svae_estep_fwd '
-                              '(use models.svae.e_step / compute_log_z_given_y)')
+    """gaussian.log_probability_nat (reference gaussian.py:30-71): (N,K) log N(x_n | eta_nk) + log w_k, normalised
+    over k.  Forward only."""
+    x = _c(x.detach(), 'x')
+    N, D = x.shape
+    if eta1.dim() != 3:
+        raise AssertionError("eta1 must be of shape (N,K,D). Its shape is %s." % str(tuple(eta1.shape)))
+    K = eta1.shape[1]
+    eta1 = _c(eta1.detach(), 'eta1', (N, K, D))
+    eta2 = _c(eta2.detach(), 'eta2', (N, K, D, D))
+    lw = None if weights is None else _c(torch.log(weights.detach()).float(), 'weights', (K,))
+    out = torch.empty(N, K, dtype=torch.float32, device=x.device)
+    L.check(L.lib().vmp_gauss_logprob_nat(L.ptr(x), L.ptr(eta1), L.ptr(eta2), L.ptr(lw), N, K, D, L.ptr(out), L.stream()),
+            'vmp_gauss_logprob_nat')
+    return out
 
 
 def gauss_logprob_per_samp(x_samps, eta1, eta2):
-    raise NotImplementedError('stand-alone gaussian.log_probability_nat_per_samp: fused into vmp_svae_estep_fwd '
-                              '(use models.svae.e_step(..., theta=theta) + compute_elbo)')
+    """gaussian.log_probability_nat_per_samp (reference gaussian.py:74-105): (N,K,S).  Forward only."""
+    x = _c(x_samps.detach(), 'x_samps')
+    N, K, S, D = x.shape
+    eta1 = _c(eta1.detach(), 'eta1', (N, K, D))
+    eta2 = _c(eta2.detach(), 'eta2', (N, K, D, D))
+    out = torch.empty(N, K, S, dtype=torch.float32, device=x.device)
+    L.check(L.lib().vmp_gauss_logprob_nat_per_samp(L.ptr(x), L.ptr(eta1), L.ptr(eta2), N, K, S, D, L.ptr(out),
+                                                   L.stream()), 'vmp_gauss_logprob_nat_per_samp')
+    return out
 
 
 def student_t_logprob(y, mu, sigma, v):
-    raise NotImplementedError('student_t.log_probability_per_samp: scheduled (SURVEY 8a row a8)')
+    """student_t.log_probability_per_samp (reference student_t.py:7-39,59-61): (N,K,S).  The K scale matrices are
+    factorised once (K-sized, torch) instead of being tiled to (N,K,S,D,D).  Forward only."""
+    import math
+    y = _c(y.detach(), 'y')
+    N, K, S, D = y.shape
+    if tuple(mu.shape) != (K, D) or tuple(sigma.shape) != (K, D, D) or tuple(v.shape) != (K,):
+        raise AssertionError('shape mismatch')
+    sig = sigma.detach().double()
+    Lc = torch.linalg.cholesky(0.5 * (sig + sig.transpose(-1, -2)))
+    eye = torch.eye(D, dtype=Lc.dtype, device=Lc.device).expand_as(Lc)
+    W = torch.linalg.solve_triangular(Lc, eye, upper=False)
+    vd = v.detach().double()
+    cst = (torch.lgamma(0.5 * (vd + D)) - torch.lgamma(0.5 * vd) - 0.5 * D * torch.log(math.pi * vd)
+           - torch.log(torch.diagonal(Lc, dim1=-2, dim2=-1)).sum(-1))
+    out = torch.empty(N, K, S, dtype=torch.float32, device=y.device)
+    L.check(L.lib().vmp_student_t_logprob(L.ptr(y), L.ptr(_c(mu.detach().float(), 'mu')), L.ptr(W.float().contiguous()),
+                                          L.ptr(cst.float().contiguous()), L.ptr(_c(v.detach().float(), 'v')), N, K, S, D,
+                                          L.ptr(out), L.stream()), 'vmp_student_t_logprob')
+    return out
