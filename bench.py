@@ -195,7 +195,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
-    if world > 1:
+    force_dist = os.environ.get('VMP_FORCE_DIST') == '1'        # exercise the RCCL path with a single rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
@@ -213,7 +214,7 @@ def main():
     x_h, r0_h = synth(N, D, K, seed=rank)                # every rank: its own shard of the (virtual) N*world rows
     x, r0 = torch.as_tensor(x_h).to(dev), torch.as_tensor(r0_h).to(dev)
     kappa = torch.full((K,), 5.0, device=dev) if flav == L.VMP_SMM else None
-    if world > 1:
+    if world > 1 or force_dist:
         loop = DistributedVMPLoop(x, r0, flav, kappa=kappa)
     else:
         loop = _mix.VMPLoop(x, r0, flav, kappa=kappa)
