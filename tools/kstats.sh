@@ -6,6 +6,6 @@ python3 - <<PY
 import csv
 for row in csv.DictReader(open('$OUT/k_kernel_stats.csv')):
     n=row['Name']
-    if 'pass_kernel' in n or 'finalize' in n or 'pivot' in n or 'pack_kernel' in n:
+    if any(t in n for t in ('pass_kernel', 'finalize', 'pivot', 'pack_kernel', 'svae_estep', 'loglike', 'subsample')):
         print('%-70s calls %4s avg %9.1f us  min %9.1f' % (n[28:98], row['Calls'], float(row['AverageNs'])/1e3, float(row['MinNs'])/1e3))
 PY

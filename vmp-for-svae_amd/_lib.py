@@ -6,7 +6,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libvmp_hip.so')
+LIB_PATH = os.environ.get('VMP_LIB_PATH') or os.path.join(_HERE, 'lib', 'libvmp_hip.so')   # override: A/B builds
 
 VMP_GMM, VMP_SMM = 0, 1
 MAX_D, MAX_K = 8, 64

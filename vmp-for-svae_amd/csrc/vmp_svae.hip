@@ -364,25 +364,32 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
         const float gts = gT * invS;
         const float* __restrict__ xc = a.x + cellid * LSn;
         const float* __restrict__ gc = a.Gx + cellid * LSn;
-        for (int s = 0; s < S; ++s) {
-            float xs[L], gx[L];
-            if (on) {
+        float nxs[L], ngx[L];                               // next sample's rows, in flight while this one is used
+        auto load_rows = [&](int s2, float (&xo)[L], float (&go)[L]) {
+            if (on && s2 < S) {
                 if ((L & 3) == 0 && a.vec_ok) {
 #pragma unroll
                     for (int q = 0; q < L / 4; ++q) {
-                        const float4 v = reinterpret_cast<const float4*>(xc + s * L)[q];
-                        const float4 w = reinterpret_cast<const float4*>(gc + s * L)[q];
-                        xs[4 * q] = v.x; xs[4 * q + 1] = v.y; xs[4 * q + 2] = v.z; xs[4 * q + 3] = v.w;
-                        gx[4 * q] = w.x; gx[4 * q + 1] = w.y; gx[4 * q + 2] = w.z; gx[4 * q + 3] = w.w;
+                        const float4 v = reinterpret_cast<const float4*>(xc + s2 * L)[q];
+                        const float4 w = reinterpret_cast<const float4*>(gc + s2 * L)[q];
+                        xo[4 * q] = v.x; xo[4 * q + 1] = v.y; xo[4 * q + 2] = v.z; xo[4 * q + 3] = v.w;
+                        go[4 * q] = w.x; go[4 * q + 1] = w.y; go[4 * q + 2] = w.z; go[4 * q + 3] = w.w;
                     }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < L; ++i) { xs[i] = xc[s * L + i]; gx[i] = gc[s * L + i]; }
+                    for (int i = 0; i < L; ++i) { xo[i] = xc[s2 * L + i]; go[i] = gc[s2 * L + i]; }
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < L; ++i) { xs[i] = 0.f; gx[i] = 0.f; }
+                for (int i = 0; i < L; ++i) { xo[i] = 0.f; go[i] = 0.f; }
             }
+        };
+        load_rows(0, nxs, ngx);
+        for (int s = 0; s < S; ++s) {
+            float xs[L], gx[L];
+#pragma unroll
+            for (int i = 0; i < L; ++i) { xs[i] = nxs[i]; gx[i] = ngx[i]; }
+            load_rows(s + 1, nxs, ngx);
             // d/dx of the theta term of T':  (1/S) c_s W^T W (x - m),  c_s = 1 (Gaussian) or (nu+L)/(nu+delta^2)
             float d[L], y[L];
 #pragma unroll
