@@ -158,3 +158,50 @@ def test_smm_training_steps_vs_reference(golden, case):
         assert 'theta/mu_k' in names and 'theta/L_k' in names
         for n_, p in zip(names, params):
             assert rel(p, g[pre + 'param_' + n_]) <= slack * bar(g, pre + 'param_' + n_, 2e-5), (it, 'param', n_)
+
+
+def test_t2_full_size_properties():
+    """BASELINE config-3 shaped E-step (L=8, K=16, S=10) at N=2e5 rows (3.2e6 cells): size-independent invariants."""
+    from vmp_for_svae_amd.models import svae
+    N, K, Ld, S = 200_000, 16, 8, 10
+    g = torch.Generator(device='cuda').manual_seed(3)
+    e1 = torch.randn(N, Ld, device='cuda', generator=g).requires_grad_(True)
+    e2 = (-0.5 * torch.nn.functional.softplus(torch.randn(N, Ld, device='cuda', generator=g))).requires_grad_(True)
+    prior, theta = svae.init_mm(K, Ld, seed=0, param_device='cuda')
+    phi = [p.detach().requires_grad_(True) for p in svae.init_recognition_params(theta, K, seed=0, param_device='cuda')]
+    with torch.no_grad():
+        phi[1].add_(torch.tril(torch.randn(K, Ld, Ld, device='cuda', generator=g) * 0.2, -1))
+    # (a) zero noise: every sample equals the cell mean mu~ = Pt^-1 ht   (checked as Pt x = ht in fp64)
+    x0, lz0, pt0, _ = svae.e_step((e1, e2), phi, S, noise=torch.zeros(N, K, Ld, S, device='cuda'), theta=theta)
+    assert (x0[:, :, 1:, :] - x0[:, :, :1, :]).abs().max().item() == 0.0
+    eta1_k, eta2_k, _ = svae.unpack_recognition_gmm(phi)
+    idx = torch.randint(0, N, (4096,), device='cuda', generator=g)
+    Pt = (torch.diag_embed(-2.0 * e2[idx]).unsqueeze(1) + (-2.0 * eta2_k).unsqueeze(0)).double()
+    ht = (e1[idx].unsqueeze(1) + eta1_k.unsqueeze(0)).double()
+    res = torch.einsum('nkij,nkj->nki', Pt, x0[idx, :, 0, :].double()) - ht
+    assert (res.abs().max() / ht.abs().max()).item() < 2e-5
+    # (b) responsibilities are distributions; T' finite
+    r = torch.exp(lz0.double())
+    assert (r.sum(1) - 1).abs().max().item() < 1e-5 and torch.isfinite(pt0.T_prime).all()
+    # (c) run-to-run determinism, forward and backward
+    noise = torch.randn(N, K, Ld, S, device='cuda', generator=g)
+    Gx = torch.randn(N, K, S, Ld, device='cuda', generator=g)
+    Glz = torch.randn(N, K, device='cuda', generator=g)
+
+    def run(scale):
+        x, lz, pt, _ = svae.e_step((e1, e2), phi, S, noise=noise, theta=theta)
+        gr = torch.autograd.grad([x, lz, pt.T_prime], [e1, e2] + phi, [scale * Gx, scale * Glz, scale * torch.exp(lz.detach())])
+        return x, lz, gr
+    x1, lz1, g1 = run(1.0)
+    x2, lz2, g2 = run(1.0)
+    assert torch.equal(x1, x2) and torch.equal(lz1, lz2)
+    for a_, b_ in zip(g1, g2):
+        assert torch.equal(a_, b_)
+    # (d) the backward pass is linear in the upstream gradients
+    _, _, g3 = run(2.0)
+    for a_, b_ in zip(g1, g3):
+        assert ((2 * a_ - b_).abs().max() / b_.abs().max()).item() < 1e-5
+    # (e) shift invariance of the softmax: adding a constant to the component log-weights leaves log_z unchanged
+    phi_s = [phi[0], phi[1], (phi[2] + 3.0).detach()]
+    _, lz_s, _, _ = svae.e_step((e1, e2), phi_s, S, noise=noise, theta=theta)
+    assert (torch.exp(lz_s) - torch.exp(lz1)).abs().max().item() < 1e-6
