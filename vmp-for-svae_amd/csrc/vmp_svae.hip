@@ -162,12 +162,26 @@ __global__ __launch_bounds__(SV_FWD_MAX_NW * WAVE) void svae_estep_fwd_kernel(EF
         {
             const float* __restrict__ g = a.noise + t * CT * LSn;
             if (a.vec_ok && (LSn & 3) == 0) {
-                for (int e = 4 * lane; e < tot; e += 4 * WAVE) {
-                    const float4 v = *reinterpret_cast<const float4*>(g + e);
-                    const int c = (int)(((float)e + 0.5f) * invLS);
-                    const int j = e - c * LSn;
-                    float* d = et + c * CSTR + j;
-                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                // 5 vector loads in flight per lane before the first LDS write (a one-load-at-a-time copy loop
+                // exposes the full memory latency 20 times per tile)
+                constexpr int UN = 10;
+                for (int e0 = 4 * lane; e0 < tot; e0 += UN * 4 * WAVE) {
+                    float4 v[UN];
+#pragma unroll
+                    for (int u = 0; u < UN; ++u) {
+                        const int e = e0 + u * 4 * WAVE;
+                        v[u] = (e < tot) ? *reinterpret_cast<const float4*>(g + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UN; ++u) {
+                        const int e = e0 + u * 4 * WAVE;
+                        if (e < tot) {
+                            const int c = (int)(((float)e + 0.5f) * invLS);
+                            const int j = e - c * LSn;
+                            float* d = et + c * CSTR + j;
+                            d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                        }
+                    }
                 }
             } else {
                 for (int e = lane; e < tot; e += WAVE) {
@@ -262,6 +276,152 @@ __global__ __launch_bounds__(SV_FWD_MAX_NW * WAVE) void svae_estep_fwd_kernel(EF
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Forward, sample-parallel form (the fast path): lane = (cell, pair of samples).  The SP = ceil(S/2) lanes of a
+// cell each repeat the cell's small factorisation (cheap, and it keeps every lane busy) and then own two samples,
+// so that a lane's dependent chain is one Cholesky + two back-substitutions instead of one Cholesky + S of them,
+// and there are SP times more independent chains in flight.  A block covers RPB whole rows (RPB*K cells): the
+// softmax over k and the per-cell sums of the regulariser go through LDS.  Noise is read straight from global
+// memory (issued before the factorisation, so its latency hides behind it); a cell's SP lanes write its S samples
+// as one contiguous (S x L) block, i.e. the wave's stores are fully coalesced without staging.
+// ---------------------------------------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(512) void svae_estep_fwd2_kernel(EFwdArgs a, int RPB, int SP) {
+    constexpr int TRI = SvGeo<L>::TRI;
+    constexpr int PSTR = TRI | 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int K = a.K, S = a.S;
+    const int CB = RPB * K;                                 // cells per block tile
+    float* pk_lds = smem;                                   // [K][PSTR]
+    float* c_lds = smem + K * PSTR;                         // [CB]   c_nk of the tile
+    float* e_lds = c_lds + CB;                              // [CB*SP] eps^2 partial sums
+    float* q_lds = e_lds + CB * SP;                         // [CB*SP] theta-term partial sums
+    const int tid = threadIdx.x;
+    const int cib = tid / SP, pair = tid - cib * SP;        // cell in block, sample pair
+    const bool lane_on = cib < CB;
+    const int r = lane_on ? cib / K : 0, k = lane_on ? cib - r * K : 0;
+    const int s0 = 2 * pair;
+    const bool two = s0 + 1 < S;
+
+    for (int e = tid; e < K * TRI; e += blockDim.x) {
+        const int kk = e / TRI, idx = e - kk * TRI;
+        int i = 0;
+        while (tri(i + 1, 0) <= idx) ++i;
+        pk_lds[kk * PSTR + idx] = a.Pk[(kk * L + i) * L + (idx - tri(i, 0))];
+    }
+    float hkk[L], mkk[L], Wt[TRI];
+    const bool student = a.nu != nullptr;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        hkk[i] = lane_on ? a.hk[k * L + i] : 0.f;
+        mkk[i] = lane_on ? a.mk[k * L + i] : 0.f;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) Wt[tri(i, j)] = lane_on ? a.Wk[(k * L + i) * L + j] : 0.f;
+    }
+    const float biask = lane_on ? a.bias[k] : 0.f, kappak = lane_on ? a.kappa[k] : 0.f;
+    const float nuk = (student && lane_on) ? a.nu[k] : 1.f, inv_nu = 1.0f / nuk;
+    const float invS = 1.0f / (float)S;
+    __syncthreads();
+
+    const long long ntiles = (a.N + RPB - 1) / RPB;
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long long row = t * RPB + r;
+        const bool on = lane_on && row < a.N;
+        const long long cell = row * K + k;
+        // noise for this lane's two samples: issued first, consumed after the factorisation
+        float e0[L], e1[L];
+        {
+            const float* __restrict__ nz = a.noise + cell * (L * S) + s0;
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                e0[i] = on ? nz[i * S] : 0.f;
+                e1[i] = (on && two) ? nz[i * S + 1] : 0.f;
+            }
+        }
+        float Lm[TRI], av[L];
+#pragma unroll
+        for (int i = 0; i < TRI; ++i) Lm[i] = lane_on ? pk_lds[k * PSTR + i] : 0.f;
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const float x1 = on ? a.eta1[row * L + i] : 0.f;
+            const float x2 = on ? a.eta2d[row * L + i] : -0.5f;
+            Lm[tri(i, i)] = fmaf(-2.f, x2, Lm[tri(i, i)]);
+            av[i] = x1 + hkk[i];
+        }
+        float ld;
+        cell_cholesky<L>(Lm, ld);
+        solve_lower<L>(Lm, av);
+        float aa = 0.f;
+#pragma unroll
+        for (int i = 0; i < L; ++i) aa = fmaf(av[i], av[i], aa);
+        const float c = on ? (biask + 0.5f * aa - ld) : -INFINITY;
+        if (lane_on && pair == 0) c_lds[cib] = c;
+
+        // two samples: z = a + eps, x = Lt^-T z (two independent chains), theta term
+        float z0[L], z1[L];
+        float eps2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            eps2 = fmaf(e0[i], e0[i], fmaf(e1[i], e1[i], eps2));
+            z0[i] = av[i] + e0[i];
+            z1[i] = av[i] + e1[i];
+        }
+#pragma unroll
+        for (int i = L - 1; i >= 0; --i) {
+            float t0 = z0[i], t1 = z1[i];
+#pragma unroll
+            for (int p = i + 1; p < L; ++p) {
+                t0 = fmaf(-Lm[tri(p, i)], z0[p], t0);
+                t1 = fmaf(-Lm[tri(p, i)], z1[p], t1);
+            }
+            z0[i] = t0 * Lm[tri(i, i)];
+            z1[i] = t1 * Lm[tri(i, i)];
+        }
+        if (on) {
+            float* __restrict__ xo = a.x + (cell * S + s0) * L;
+            if ((L & 3) == 0 && a.vec_ok) {
+#pragma unroll
+                for (int q = 0; q < L / 4; ++q) reinterpret_cast<float4*>(xo)[q] = make_float4(z0[4 * q], z0[4 * q + 1], z0[4 * q + 2], z0[4 * q + 3]);
+                if (two) {
+#pragma unroll
+                    for (int q = 0; q < L / 4; ++q) reinterpret_cast<float4*>(xo + L)[q] = make_float4(z1[4 * q], z1[4 * q + 1], z1[4 * q + 2], z1[4 * q + 3]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < L; ++i) { xo[i] = z0[i]; if (two) xo[L + i] = z1[i]; }
+            }
+        }
+        float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < L; ++i) { z0[i] -= mkk[i]; z1[i] -= mkk[i]; }
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            float y0 = 0.f, y1 = 0.f;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) { y0 = fmaf(Wt[tri(i, j)], z0[j], y0); y1 = fmaf(Wt[tri(i, j)], z1[j], y1); }
+            d0 = fmaf(y0, y0, d0);
+            d1 = fmaf(y1, y1, d1);
+        }
+        float qth;
+        if (student) qth = (nuk + (float)L) * (log1pf(d0 * inv_nu) + (two ? log1pf(d1 * inv_nu) : 0.f));
+        else qth = d0 + (two ? d1 : 0.f);
+        if (lane_on) { e_lds[tid] = eps2; q_lds[tid] = qth; }
+        __syncthreads();
+        if (on && pair == 0) {
+            float mx = -INFINITY;
+            for (int j = 0; j < K; ++j) mx = fmaxf(mx, c_lds[r * K + j]);
+            float se = 0.f;
+            for (int j = 0; j < K; ++j) se += __expf(c_lds[r * K + j] - mx);
+            float es = 0.f, qs = 0.f;
+            for (int p = 0; p < SP; ++p) { es += e_lds[tid + p]; qs += q_lds[tid + p]; }
+            a.lz[cell] = c - mx - __logf(se);
+            a.Tp[cell] = -0.5f * L * LOG_2PI + ld - 0.5f * invS * es + 0.5f * invS * qs - kappak;
+        }
+        __syncthreads();
+    }
+}
+
 // =========================================================================================================
 // backward
 // =========================================================================================================
@@ -299,8 +459,9 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
     const int PSTR = TRI | 1;
     float* pk_lds = smem;                                   // [K][PSTR]  lower triangle of P_k
     float* scr = smem + K * PSTR + wave * WAVE;
-    float* red = smem + K * PSTR + nw * WAVE;               // block reduction scratch [PW][64]
-    float* accl = red + PW * WAVE + wave * (PW * WAVE);     // this wave's accumulators [PW][64], lane-private columns
+    const int PWa = (a.nu != nullptr) ? PW : TH;            // accumulator rows in use (theta-side sums only for Student-t)
+    float* red = smem + K * PSTR + nw * WAVE;               // block reduction scratch [PWa][64]
+    float* accl = red + PWa * WAVE + wave * (PWa * WAVE);   // this wave's accumulators [PWa][64], lane-private columns
     const bool lane_on = lane < CT;
     const int r = lane / K, k = lane - r * K, rbase = lane_on ? r * K : 0;
 
@@ -323,7 +484,7 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
         for (int j = 0; j <= i; ++j) Wt[tri(i, j)] = lane_on ? a.Wk[(k * L + i) * L + j] : 0.f;
     }
     const float nuk = (student && lane_on) ? a.nu[k] : 1.f;
-    for (int i = 0; i < PW; ++i) accl[i * WAVE + lane] = 0.f;   // sums over this lane's cells (fixed k)
+    for (int i = 0; i < PWa; ++i) accl[i * WAVE + lane] = 0.f;  // sums over this lane's cells (fixed k)
 
     const long long ntiles = (a.N + RPT - 1) / RPT;
     const float invS = 1.0f / (float)S;
@@ -384,12 +545,14 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
                 for (int i = 0; i < L; ++i) { xo[i] = 0.f; go[i] = 0.f; }
             }
         };
+        float nxs2[L], ngx2[L];                             // ... and the one after it
         load_rows(0, nxs, ngx);
+        load_rows(1, nxs2, ngx2);
         for (int s = 0; s < S; ++s) {
             float xs[L], gx[L];
 #pragma unroll
-            for (int i = 0; i < L; ++i) { xs[i] = nxs[i]; gx[i] = ngx[i]; }
-            load_rows(s + 1, nxs, ngx);
+            for (int i = 0; i < L; ++i) { xs[i] = nxs[i]; gx[i] = ngx[i]; nxs[i] = nxs2[i]; ngx[i] = ngx2[i]; }
+            load_rows(s + 2, nxs2, ngx2);
             // d/dx of the theta term of T':  (1/S) c_s W^T W (x - m),  c_s = 1 (Gaussian) or (nu+L)/(nu+delta^2)
             float d[L], y[L];
 #pragma unroll
@@ -515,7 +678,7 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
 #pragma unroll
             for (int i = 0; i < TRI; ++i) accl[(L + i) * WAVE + lane] += gP[i];
             accl[(L + TRI) * WAVE + lane] += Gc;
-            accl[(TH + L + TRI) * WAVE + lane] -= gT;          // T' has -kappa_k
+            if (student) accl[(TH + L + TRI) * WAVE + lane] -= gT;   // T' has -kappa_k
         }
 #pragma unroll
         for (int i = 0; i < L; ++i) {
@@ -532,7 +695,7 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
     __syncthreads();
     for (int w = 0; w < nw; ++w) {
         if (wave == w) {
-            for (int i = 0; i < PW; ++i) red[i * WAVE + lane] = (w == 0 ? 0.f : red[i * WAVE + lane]) + accl[i * WAVE + lane];
+            for (int i = 0; i < PWa; ++i) red[i * WAVE + lane] = (w == 0 ? 0.f : red[i * WAVE + lane]) + accl[i * WAVE + lane];
         }
         __syncthreads();
     }
@@ -540,7 +703,8 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
     for (int e = threadIdx.x; e < K * PW; e += blockDim.x) {
         const int kk = e / PW, f = e - kk * PW;
         float s2 = 0.f;
-        for (int rr = 0; rr < RPT; ++rr) s2 += red[f * WAVE + rr * K + kk];
+        if (f < PWa)
+            for (int rr = 0; rr < RPT; ++rr) s2 += red[f * WAVE + rr * K + kk];
         out[e] = s2;
     }
 }
@@ -642,6 +806,25 @@ int vmp_svae_estep_fwd(const float* eta1, const float* eta2d, const float* hk, c
     }
     EFwdArgs a{eta1, eta2d, hk, Pk, bias, noise, mk, Wk, kappa, nu, x, lz, Tp, N, K, S, 0};
     a.vec_ok = al16(noise) && al16(x);
+    {
+        const int SP = (S + 1) / 2;
+        static const int use_v2 = getenv("VMP_SV_FWD_V2") ? 1 : 0;   // measured slower than the staged form at C3 (4.1 vs 3.6 ms)
+        if (use_v2 && K * SP <= 512) {
+            int RPB = 512 / (K * SP);
+            if (RPB > 8) RPB = 8;
+            const int threads = ((RPB * K * SP + WAVE - 1) / WAVE) * WAVE;
+            const int CB = RPB * K;
+            const size_t lds2 = (size_t)(K * ((L * (L + 1) / 2) | 1) + CB + 2 * CB * SP + 2 * WAVE) * sizeof(float);
+            long long blocks2 = (N + RPB - 1) / RPB;
+            if (blocks2 > 256 * 6) blocks2 = 256 * 6;
+            rc = -1;
+            VMP_DISPATCH_L(L, {
+                hipLaunchKernelGGL((svae_estep_fwd2_kernel<LL>), dim3((int)blocks2), dim3(threads), lds2, static_cast<hipStream_t>(stream), a, RPB, SP);
+                rc = check_launch("svae_estep_fwd2_kernel");
+            });
+            return rc;
+        }
+    }
     const size_t per_wave = (size_t)(WAVE * (L * S | 1) + WAVE) * sizeof(float);
     int nw = (int)((150 * 1024) / per_wave);                 // one block per CU, as many waves as 160 KiB of LDS hold
     if (nw > SV_FWD_MAX_NW) nw = SV_FWD_MAX_NW;
@@ -675,7 +858,8 @@ int vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk, c
     if (partial_bytes < (size_t)blocks * K * PW * sizeof(float)) { set_error("vmp_svae_estep_bwd: partials buffer too small"); return VMP_E_WS; }
     EBwdArgs a{eta1, eta2d, hk, Pk, bias, mk, Wk, nu, x, lz, Gx, Glz, GT, g_eta1, g_eta2d, partials, N, K, S, 0};
     a.vec_ok = al16(x) && al16(Gx);
-    const size_t lds = (size_t)(K * ((L * (L + 1) / 2) | 1) + SV_NW * WAVE + PW * WAVE + SV_NW * PW * WAVE) * sizeof(float);
+    const int PWa = nu ? PW : PW / 2;
+    const size_t lds = (size_t)(K * ((L * (L + 1) / 2) | 1) + SV_NW * WAVE + PWa * WAVE + SV_NW * PWa * WAVE) * sizeof(float);
     rc = -1;
     VMP_DISPATCH_L(L, {
         hipLaunchKernelGGL((svae_estep_bwd_kernel<LL>), dim3(blocks), dim3(SV_NW * WAVE), lds, static_cast<hipStream_t>(stream), a);
