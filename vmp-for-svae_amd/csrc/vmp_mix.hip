@@ -43,6 +43,7 @@ struct PassArgs {
     long long ntiles;
     int K;
     int vec_ok;       // x pointer 16-byte aligned (vector row loads allowed)
+    int par_reduce;   // LDS holds one fp64 slab per wave: reduce the waves in one parallel step
 };
 
 template <int D>
@@ -108,9 +109,16 @@ __global__ __launch_bounds__(MAX_NW * WAVE) void pass_kernel(PassArgs a) {
     xl[ZERO * LS + lane] = 0.0f;
 
     const int i16 = lane & 15, kk = lane >> 4;
+    // NOTE on every "cond ? load : 0" below: a load under a per-element condition compiles to a branch plus a full
+    // s_waitcnt per element (serialised round trips).  Loads are therefore issued unconditionally from an address
+    // that is always valid, and the condition selects the VALUE afterwards.
     float pv[D];
+    {
+        const float* __restrict__ pp = a.pivot ? a.pivot : a.x;      // a.x: any valid address
+        const bool hasp = a.pivot != nullptr;
 #pragma unroll
-    for (int j = 0; j < D; ++j) pv[j] = a.pivot ? a.pivot[j] : 0.f;
+        for (int j = 0; j < D; ++j) { const float v = pp[j]; pv[j] = hasp ? v : 0.f; }
+    }
 
     // ---- this lane's component parameters, resident for the whole kernel
     float pm[KT][D], pw[KT][G::TRI], pc[KT], ph[KT], pua[KT], pub[KT];
@@ -120,14 +128,17 @@ __global__ __launch_bounds__(MAX_NW * WAVE) void pass_kernel(PassArgs a) {
             const int k = kt * 16 + i16;
             const bool on = k < K;
             const float* __restrict__ p = a.pack + (on ? k : 0) * G::PACK;
+            float raw[G::PACK];
 #pragma unroll
-            for (int j = 0; j < D; ++j) pm[kt][j] = on ? p[j] - pv[j] : 0.f;
+            for (int j = 0; j < G::PACK; ++j) raw[j] = p[j];                  // all loads in flight together
 #pragma unroll
-            for (int j = 0; j < G::TRI; ++j) pw[kt][j] = on ? p[D + j] : 0.f;
-            pc[kt] = on ? p[D + G::TRI] : -INFINITY;          // log2-domain constant; -inf switches the lane off
-            ph[kt] = on ? p[D + G::TRI + 1] : 0.f;
-            pua[kt] = on ? p[D + G::TRI + 2] : 0.f;
-            pub[kt] = on ? p[D + G::TRI + 3] : 1.f;
+            for (int j = 0; j < D; ++j) pm[kt][j] = on ? raw[j] - pv[j] : 0.f;
+#pragma unroll
+            for (int j = 0; j < G::TRI; ++j) pw[kt][j] = on ? raw[D + j] : 0.f;
+            pc[kt] = on ? raw[D + G::TRI] : -INFINITY;        // log2-domain constant; -inf switches the lane off
+            ph[kt] = on ? raw[D + G::TRI + 1] : 0.f;
+            pua[kt] = on ? raw[D + G::TRI + 2] : 0.f;
+            pub[kt] = on ? raw[D + G::TRI + 3] : 1.f;
         }
     }
 
@@ -276,10 +287,12 @@ __global__ __launch_bounds__(MAX_NW * WAVE) void pass_kernel(PassArgs a) {
                     const int k = kt * 16 + i16;
                     const bool on = k < K;
                     const float* __restrict__ ri = a.r_in + tbase + kt * 16;
-                    rr[kt] = v2f{(on && va) ? ri[so] : 0.f, (on && vb) ? ri[so + K4] : 0.f};
+                    const float r0v = *((on && va) ? ri + so : a.r_in), r1v = *((on && vb) ? ri + so + K4 : a.r_in);
+                    rr[kt] = v2f{(on && va) ? r0v : 0.f, (on && vb) ? r1v : 0.f};
                     if constexpr (SMM) {
                         const float* __restrict__ ui = a.u_in + tbase + kt * 16;
-                        const v2f u2 = v2f{(on && va) ? ui[so] : 0.f, (on && vb) ? ui[so + K4] : 0.f};
+                        const float u0v = *((on && va) ? ui + so : a.u_in), u1v = *((on && vb) ? ui + so + K4 : a.u_in);
+                        const v2f u2 = v2f{(on && va) ? u0v : 0.f, (on && vb) ? u1v : 0.f};
                         w[kt] = rr[kt] * u2;
                     } else {
                         w[kt] = rr[kt];
@@ -327,25 +340,47 @@ __global__ __launch_bounds__(MAX_NW * WAVE) void pass_kernel(PassArgs a) {
     }
 
     if constexpr (STATS) {
-        // ---- block reduction in fp64, waves in fixed order, then one partial per block
+        // ---- block reduction in fp64 (waves summed in a fixed order), then one partial per block
         __syncthreads();
         double* sc = reinterpret_cast<double*>(smem);          // [KT][FT+1][4][64]
-        for (int w = 0; w < nw; ++w) {
-            if (wave == w) {
+        constexpr int SLAB = KT * (FT + 1) * 4 * WAVE;
+        if (a.par_reduce) {
+            // every wave drops its accumulators into its own slab, then each thread sums the nw slabs of its
+            // elements: one LDS round trip instead of nw dependent read-modify-write rounds
+            double* mine = sc + wave * SLAB;
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt)
+            for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < 4; ++c) {
 #pragma unroll
-                        for (int ft = 0; ft < FT; ++ft) {
-                            const int idx = ((kt * (FT + 1) + ft) * 4 + c) * WAVE + lane;
-                            sc[idx] = (w == 0 ? 0.0 : sc[idx]) + dacc[kt][ft][c];
-                        }
-                        const int idn = ((kt * (FT + 1) + FT) * 4 + c) * WAVE + lane;
-                        sc[idn] = (w == 0 ? 0.0 : sc[idn]) + (SMM ? dn[kt][c] : dacc[kt][0][c]);
-                    }
+                    for (int ft = 0; ft < FT; ++ft) mine[((kt * (FT + 1) + ft) * 4 + c) * WAVE + lane] = dacc[kt][ft][c];
+                    mine[((kt * (FT + 1) + FT) * 4 + c) * WAVE + lane] = SMM ? dn[kt][c] : dacc[kt][0][c];
+                }
+            __syncthreads();
+            for (int e = threadIdx.x; e < SLAB; e += blockDim.x) {
+                double t2 = sc[e];
+                for (int w = 1; w < nw; ++w) t2 += sc[w * SLAB + e];
+                sc[e] = t2;
             }
             __syncthreads();
+        } else {
+            for (int w = 0; w < nw; ++w) {
+                if (wave == w) {
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                            for (int ft = 0; ft < FT; ++ft) {
+                                const int idx = ((kt * (FT + 1) + ft) * 4 + c) * WAVE + lane;
+                                sc[idx] = (w == 0 ? 0.0 : sc[idx]) + dacc[kt][ft][c];
+                            }
+                            const int idn = ((kt * (FT + 1) + FT) * 4 + c) * WAVE + lane;
+                            sc[idn] = (w == 0 ? 0.0 : sc[idn]) + (SMM ? dn[kt][c] : dacc[kt][0][c]);
+                        }
+                }
+                __syncthreads();
+            }
         }
         double* out = a.partials + (long long)blockIdx.x * K * G::PF;
         for (int e = threadIdx.x; e < KT * (FT + 1) * 4 * WAVE; e += blockDim.x) {
@@ -357,6 +392,7 @@ __global__ __launch_bounds__(MAX_NW * WAVE) void pass_kernel(PassArgs a) {
                 if (f < G::F) out[k * G::PF + f] = sc[e];
             } else if ((l & 15) == 0) {
                 out[k * G::PF + G::F] = sc[e];                 // Nk = sum_n r_nk
+                a.partials[(long long)MAX_BLOCKS * K * G::PF + (long long)blockIdx.x * K + k] = sc[e];   // compact copy (all k)
             }
         }
     }
@@ -381,6 +417,7 @@ struct FinArgs {
     const float* pivot;        // the shift the pass kernel applied to x (src == 0 only; NULL: none)
     float *alpha, *beta, *m, *C, *v, *xbar, *S, *pi, *pack;
     double* stats_out;
+    long long* dbg_t;          // exploration only: 8 timestamps of block 0 / thread 0
 };
 
 template <int D>
@@ -542,18 +579,28 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
     }
     if (post && tid < K) alpha0s[tid] = a.alpha0[tid];
 
+    if (a.dbg_t && blockIdx.x == 0 && tid == 0) a.dbg_t[0] = clock64();
     if (a.src == 0) {
         const int f = tid & 63, g = tid >> 6;
         double s = 0.0, s2 = 0.0;
         // all loads of a chunk are issued before the first add (fixed summation order: b ascending)
         for (int b0 = g; b0 < a.nblk; b0 += FIN_GROUPS * 16) {
             double v1[16], v2[16];
+            // unconditional loads from clamped (always valid) addresses, masked afterwards: a load under a
+            // per-element condition becomes a branch + full wait per element (32 serialised round trips)
+            const int fc = f < G::PF ? f : G::PF - 1, kc = f < K ? f : K - 1;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int b = b0 + i * FIN_GROUPS;
-                const bool in = b < a.nblk;
-                v1[i] = (in && f < G::PF) ? a.partials[((long long)b * K + k) * G::PF + f] : 0.0;
-                v2[i] = (in && f < K) ? a.partials[((long long)b * K + f) * G::PF + G::F] : 0.0;
+                const int bc = b < a.nblk ? b : a.nblk - 1;
+                v1[i] = a.partials[((long long)bc * K + k) * G::PF + fc];
+                v2[i] = a.partials[(long long)MAX_BLOCKS * K * G::PF + (long long)bc * K + kc];      // compact N_j of block bc
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const bool in = b0 + i * FIN_GROUPS < a.nblk;
+                v1[i] = (in && f < G::PF) ? v1[i] : 0.0;
+                v2[i] = (in && f < K) ? v2[i] : 0.0;
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s += v1[i]; s2 += v2[i]; }
@@ -561,6 +608,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
         part[g][f] = s;
         npart[g][f] = s2;
         __syncthreads();
+        if (a.dbg_t && blockIdx.x == 0 && tid == 0) a.dbg_t[1] = clock64();
         if (tid < 64) {
             double t1 = 0.0, t2 = 0.0;
             for (int gg = 0; gg < FIN_GROUPS; ++gg) { t1 += part[gg][tid]; t2 += npart[gg][tid]; }
@@ -609,6 +657,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
     const double alpha_k = alpha0 + Nk;                              // gmm.py:49-51 / smm.py:53-55
     const double beta_k = beta0 + Wk;                                // gmm.py:54-56 / smm.py:58-60
     const double v_k = smm ? (v0 + Nk) : (v0 + Nk + 1.0);            // smm.py:73-76 / gmm.py:79-81 (+1 quirk)
+    if (a.dbg_t && blockIdx.x == 0 && tid == 0) a.dbg_t[2] = clock64();
     // ---- phase B: element (d,e) per lane
     if (tid < D * D) {
         const int d = tid / D, e = tid % D;
@@ -636,6 +685,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
         if (a.v) a.v[k] = (float)v_k;
     }
     __syncthreads();
+    if (a.dbg_t && blockIdx.x == 0 && tid == 0) a.dbg_t[3] = clock64();
     // ---- phase C: factorisation (thread 0)  ||  special functions (threads 64..)
     // P_k = inv(C_k) (gmm.py:260) is never formed: with C = Lc Lc^T,
     //   v (x-m)^T P (x-m) = || sqrt(v) Lc^{-1} (x-m) ||^2   and   log det P = -2 sum log diag Lc.
@@ -664,6 +714,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
         sp[D + 2] = lgamma(0.5 * (D + kap)) - lgamma(0.5 * kap);
     }
     __syncthreads();
+    if (a.dbg_t && blockIdx.x == 0 && tid == 0) a.dbg_t[4] = clock64();
     // ---- phase D
     if (tid == 0) {
         const double LOG2 = 0.69314718055994530942, PI = 3.14159265358979323846;
@@ -695,6 +746,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
         float* p = a.pack + k * G::PACK;
         if (tid < D) p[tid] = (float)mk[tid];
     }
+    if (a.dbg_t && blockIdx.x == 0 && tid == 0) a.dbg_t[5] = clock64();
 }
 
 // E-step pack from explicit (alpha, beta, m, P, v): gmm.e_step / smm.e_step signature.
@@ -770,7 +822,7 @@ __global__ __launch_bounds__(1024) void pivot_kernel(PivotArgs a) {
 // host side
 // ---------------------------------------------------------------------------------------------------------
 struct Plan {
-    int nw, blocks;
+    int nw, blocks, par_reduce;
     size_t lds;
     long long ntiles;
 };
@@ -799,7 +851,13 @@ Plan make_plan(long long N, int D, int K, int flavour, bool stats) {
     const int FTn = (1 + D + D * (D + 1) / 2 + 15) / 16, KTn = (K + 15) / 16;
     const size_t scratch = stats ? (size_t)(KTn <= 2 ? KTn : 4) * (FTn + 1) * 4 * WAVE * sizeof(double) : 0;
     p.lds = wreg * nw;
-    if (scratch > p.lds) p.lds = scratch;
+    p.par_reduce = 0;
+    if (scratch * nw <= 64 * 1024) {          // one slab per wave fits: parallel block reduction
+        p.par_reduce = 1;
+        if (scratch * nw > p.lds) p.lds = scratch * nw;
+    } else if (scratch > p.lds) {
+        p.lds = scratch;
+    }
     return p;
 }
 
@@ -855,14 +913,17 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 int run_pass(PassArgs a, int D, int flavour, bool estep, bool stats, bool mask, hipStream_t s) {
     Plan p = make_plan(a.N, D, a.K, flavour, stats);
     a.ntiles = p.ntiles;
+    a.par_reduce = p.par_reduce;
 
     int rc = -1;
     VMP_DISPATCH_D(D, rc = launch_pass_d<DD>(a, p, flavour, estep, stats, mask, s));
     return rc;
 }
 
+static long long* g_dbg_t = nullptr;
 int run_finalize(FinArgs f, int D, hipStream_t s) {
     int rc = -1;
+    f.dbg_t = g_dbg_t;
 
     VMP_DISPATCH_D(D, {
         hipLaunchKernelGGL((finalize_kernel<DD>), dim3(f.K), dim3(FIN_THREADS), 0, s, f);
@@ -878,12 +939,14 @@ int run_finalize(FinArgs f, int D, hipStream_t s) {
 // =========================================================================================================
 extern "C" {
 
+void vmp_debug_set_finalize_timestamps(long long* p) { g_dbg_t = p; }
+
 int vmp_mix_pack_words(int D) { return pack_words(D); }
 int vmp_mix_stats_words(int D) { return stats_words(D); }
 
 size_t vmp_mix_workspace_bytes(int64_t N, int D, int K) {
     (void)N;
-    return (size_t)MAX_BLOCKS * K * partial_words(D) * sizeof(double);
+    return (size_t)MAX_BLOCKS * K * (partial_words(D) + 1) * sizeof(double);   // per-block partials + compact N_k table
 }
 
 int vmp_mix_pivot(const float* x, int64_t N, int D, float* pivot_out, void* stream) {

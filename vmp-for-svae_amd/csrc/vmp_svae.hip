@@ -138,17 +138,25 @@ __global__ __launch_bounds__(SV_FWD_MAX_NW * WAVE) void svae_estep_fwd_kernel(EF
     float Pl[TRI], hkk[L], mkk[L], Wt[TRI];                // Wt: lower triangle of W_k, packed
     float biask = 0.f, kappak = 0.f, nuk = 0.f;
     const bool student = a.nu != nullptr;
+    // unconditional loads from clamped indices + value selects (a load under a per-element condition costs a
+    // branch and a full wait per element)
+    const int kc = lane_on ? k : 0;
 #pragma unroll
     for (int i = 0; i < L; ++i) {
-        hkk[i] = lane_on ? a.hk[k * L + i] : 0.f;
-        mkk[i] = lane_on ? a.mk[k * L + i] : 0.f;
+        const float hv = a.hk[kc * L + i], mv = a.mk[kc * L + i];
+        hkk[i] = lane_on ? hv : 0.f;
+        mkk[i] = lane_on ? mv : 0.f;
 #pragma unroll
         for (int j = 0; j <= i; ++j) {
-            Pl[tri(i, j)] = lane_on ? a.Pk[(k * L + i) * L + j] : (i == j ? 1.f : 0.f);
-            Wt[tri(i, j)] = lane_on ? a.Wk[(k * L + i) * L + j] : 0.f;
+            const float pvv = a.Pk[(kc * L + i) * L + j], wv = a.Wk[(kc * L + i) * L + j];
+            Pl[tri(i, j)] = lane_on ? pvv : (i == j ? 1.f : 0.f);
+            Wt[tri(i, j)] = lane_on ? wv : 0.f;
         }
     }
-    if (lane_on) { biask = a.bias[k]; kappak = a.kappa[k]; nuk = student ? a.nu[k] : 1.f; }
+    {
+        const float bv = a.bias[kc], kv = a.kappa[kc], nv = *(student ? a.nu + kc : a.bias);
+        biask = lane_on ? bv : 0.f; kappak = lane_on ? kv : 0.f; nuk = (student && lane_on) ? nv : 1.f;
+    }
     const float inv_nu = 1.0f / nuk;
 
     const long long ntiles = (a.N + RPT - 1) / RPT;
@@ -196,10 +204,12 @@ __global__ __launch_bounds__(SV_FWD_MAX_NW * WAVE) void svae_estep_fwd_kernel(EF
         float Lm[TRI], av[L];
 #pragma unroll
         for (int i = 0; i < TRI; ++i) Lm[i] = Pl[i];
+        const long long rowc = on ? row : 0;
 #pragma unroll
         for (int i = 0; i < L; ++i) {
-            const float e1 = on ? a.eta1[row * L + i] : 0.f;
-            const float e2 = on ? a.eta2d[row * L + i] : -0.5f;
+            const float e1v = a.eta1[rowc * L + i], e2v = a.eta2d[rowc * L + i];
+            const float e1 = on ? e1v : 0.f;
+            const float e2 = on ? e2v : -0.5f;
             Lm[tri(i, i)] = fmaf(-2.f, e2, Lm[tri(i, i)]);
             av[i] = e1 + hkk[i];
         }
@@ -476,14 +486,17 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
 
     float hkk[L], mkk[L], Wt[TRI];
     const bool student = a.nu != nullptr;
+    const int kc = lane_on ? k : 0;                         // unconditional loads from clamped indices + selects
 #pragma unroll
     for (int i = 0; i < L; ++i) {
-        hkk[i] = lane_on ? a.hk[k * L + i] : 0.f;
-        mkk[i] = lane_on ? a.mk[k * L + i] : 0.f;
+        const float hv = a.hk[kc * L + i], mv = a.mk[kc * L + i];
+        hkk[i] = lane_on ? hv : 0.f;
+        mkk[i] = lane_on ? mv : 0.f;
 #pragma unroll
-        for (int j = 0; j <= i; ++j) Wt[tri(i, j)] = lane_on ? a.Wk[(k * L + i) * L + j] : 0.f;
+        for (int j = 0; j <= i; ++j) { const float wv = a.Wk[(kc * L + i) * L + j]; Wt[tri(i, j)] = lane_on ? wv : 0.f; }
     }
-    const float nuk = (student && lane_on) ? a.nu[k] : 1.f;
+    const float nuv = *(student ? a.nu + kc : a.bias);
+    const float nuk = (student && lane_on) ? nuv : 1.f;
     for (int i = 0; i < PWa; ++i) accl[i * WAVE + lane] = 0.f;  // sums over this lane's cells (fixed k)
 
     const long long ntiles = (a.N + RPT - 1) / RPT;
@@ -491,15 +504,17 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
     for (long long t = (long long)blockIdx.x * nw + wave; t < ntiles; t += (long long)gridDim.x * nw) {
         const long long row = t * RPT + r;
         const bool on = lane_on && row < a.N;
-        const long long cellid = row * K + k;
+        const long long rowc = on ? row : 0;
+        const long long cellid = rowc * K + kc;             // clamped: always a valid cell
 
         float Lm[TRI], av[L], mu[L];
 #pragma unroll
         for (int i = 0; i < TRI; ++i) Lm[i] = lane_on ? pk_lds[k * PSTR + i] : 0.f;
 #pragma unroll
         for (int i = 0; i < L; ++i) {
-            const float e1 = on ? a.eta1[row * L + i] : 0.f;
-            const float e2 = on ? a.eta2d[row * L + i] : -0.5f;
+            const float e1v = a.eta1[rowc * L + i], e2v = a.eta2d[rowc * L + i];
+            const float e1 = on ? e1v : 0.f;
+            const float e2 = on ? e2v : -0.5f;
             Lm[tri(i, i)] = fmaf(-2.f, e2, lane_on ? Lm[tri(i, i)] : 0.f);
             av[i] = e1 + hkk[i];
         }
@@ -510,9 +525,10 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
         for (int i = 0; i < L; ++i) mu[i] = av[i];
         solve_lower_t<L>(Lm, mu);                           // mu~ = Pt^-1 ht
 
-        const float glz = on ? a.Glz[cellid] : 0.f;
-        const float gT = on ? a.GT[cellid] : 0.f;
-        const float rnk = on ? __expf(a.lz[cellid]) : 0.f;
+        const float glzv = a.Glz[cellid], gTv = a.GT[cellid], lzv = a.lz[cellid];
+        const float glz = on ? glzv : 0.f;
+        const float gT = on ? gTv : 0.f;
+        const float rnk = on ? __expf(lzv) : 0.f;
         const float gsum = row_sum(glz, scr, lane, rbase, K);
         const float Gc = glz - rnk * gsum;                  // through the log-sum-exp normalisation
         const float Gld = gT - Gc;                          // T' has +ld, c has -ld
@@ -526,8 +542,11 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
         const float* __restrict__ xc = a.x + cellid * LSn;
         const float* __restrict__ gc = a.Gx + cellid * LSn;
         float nxs[L], ngx[L];                               // next sample's rows, in flight while this one is used
+        // (one branch around the whole group of row loads: skipping the tail prefetches matters, this kernel is
+        //  bound by the per-lane row loads - an unconditional clamped version measured 27% slower)
         auto load_rows = [&](int s2, float (&xo)[L], float (&go)[L]) {
-            if (on && s2 < S) {
+            const bool live = on && s2 < S;
+            if (live) {
                 if ((L & 3) == 0 && a.vec_ok) {
 #pragma unroll
                     for (int q = 0; q < L / 4; ++q) {
@@ -540,10 +559,9 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
 #pragma unroll
                     for (int i = 0; i < L; ++i) { xo[i] = xc[s2 * L + i]; go[i] = gc[s2 * L + i]; }
                 }
-            } else {
-#pragma unroll
-                for (int i = 0; i < L; ++i) { xo[i] = 0.f; go[i] = 0.f; }
             }
+#pragma unroll
+            for (int i = 0; i < L; ++i) { xo[i] = live ? xo[i] : 0.f; go[i] = live ? go[i] : 0.f; }
         };
         float nxs2[L], ngx2[L];                             // ... and the one after it
         load_rows(0, nxs, ngx);
