@@ -307,17 +307,21 @@ __global__ __launch_bounds__(MAX_NW * WAVE) void pass_kernel(PassArgs a) {
                     b0[ft] = xl[offA[ft] + n0] * xl[offB[ft] + n0];
                     b4[ft] = xl[offA[ft] + n0 + 4] * xl[offB[ft] + n0 + 4];
                 }
+                // all MFMAs of the first 4-row group, then all of the second: back-to-back MFMAs never share an
+                // accumulator (a dependent pair would stall ~40 cycles)
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
-                    for (int ft = 0; ft < FT; ++ft) {
+                    for (int ft = 0; ft < FT; ++ft)
                         acc[kt][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[kt].x, b0[ft], acc[kt][ft], 0, 0, 0);
+                    if constexpr (SMM) nacc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(rr[kt].x, b0[0], nacc[kt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+                    for (int ft = 0; ft < FT; ++ft)
                         acc[kt][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[kt].y, b4[ft], acc[kt][ft], 0, 0, 0);
-                    }
-                    if constexpr (SMM) {
-                        nacc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(rr[kt].x, b0[0], nacc[kt], 0, 0, 0);
-                        nacc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(rr[kt].y, b4[0], nacc[kt], 0, 0, 0);
-                    }
+                    if constexpr (SMM) nacc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(rr[kt].y, b4[0], nacc[kt], 0, 0, 0);
                 }
             }
         }
