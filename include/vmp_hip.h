@@ -200,6 +200,17 @@ int    vmp_gauss_logprob_nat(const float* x, const float* eta1, const float* eta
 int    vmp_student_t_logprob(const float* y, const float* mu, const float* W, const float* cst, const float* nu,
                              int64_t N, int K, int S, int D, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Evaluation metrics: the (N,K,S,Dy)-sized part of losses.weighted_mse (losses.py:9-38) and
+ * losses.diagonal_gaussian_logprob (losses.py:83-145)
+ * ------------------------------------------------------------------------------------------------
+ *   mse (N,K) = mean_s sum_d (y - mean)^2                                             (may be NULL)
+ *   lse (N,K) = log 1/S sum_s exp( logw_nk(s) - 1/2 sum_d mask_nd [(y-mean)^2/var + log var + log 2pi] )   (may be NULL)
+ * logw: (N,K), or (N,K,S) when logw_per_sample, or NULL; mask (N,Dy) uint8 or NULL (losses.py:118-124).       */
+int    vmp_eval_cell_metrics(const float* y, const float* mean, const float* var, const float* logw,
+                             int logw_per_sample, const uint8_t* mask, int64_t N, int K, int S, int Dy,
+                             float* mse, float* lse, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,7 @@ def _install():
     from distributions import gaussian, niw, dirichlet, student_t
     from helpers import tf_utils
     from models import gmm, smm, svae, vae
+    import losses
 
     class _NP(object):          # gmm.py:66,76 / smm.py:70,85 apply np.multiply/np.divide to tensors
         def __getattr__(self, k):
@@ -57,7 +58,7 @@ def _install():
     gmm.np = _NP()
     smm.np = _NP()
     return types.SimpleNamespace(tf=tf, gaussian=gaussian, niw=niw, dirichlet=dirichlet, student_t=student_t,
-                                 tf_utils=tf_utils, gmm=gmm, smm=smm, svae=svae, vae=vae)
+                                 tf_utils=tf_utils, gmm=gmm, smm=smm, svae=svae, vae=vae, losses=losses)
 
 
 R = _install()
@@ -380,6 +381,35 @@ def case_svae(seed, N, K, L, S, Dy, U, smm=False, steps=3, lr=3e-4, lrcvi=0.2, d
     return out
 
 
+# ============================================================================ evaluation metrics (losses.py)
+def case_metrics(seed, N, K, S, D, C):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    y = f32(rng.standard_normal((N, D)))
+    mean = f32(y[:, None, None, :] + 0.7 * rng.standard_normal((N, K, S, D)))
+    var = f32(0.2 + rng.random((N, K, S, D)))
+    lw = rng.standard_normal((N, K))
+    lw = f32(lw - np.log(np.exp(lw).sum(1, keepdims=True)))
+    lws = f32(lw[:, :, None] + 0.1 * rng.standard_normal((N, K, S)))
+    mask = rng.random((N, D)) < 0.4
+    lab = np.eye(C)[rng.integers(0, C, size=N)]
+    inputs = dict(y=y, mean=mean, var=var, lw=lw, lws=lws, mask=mask, labels=f32(lab))
+
+    def run():
+        o = {}
+        r = tf.exp(T(lw))
+        o['weighted_mse'] = npy(R.losses.weighted_mse(T(y), T(mean), r))
+        o['loli'] = npy(R.losses.diagonal_gaussian_logprob(T(y), T(mean), T(var), T(lw)))
+        o['loli_s'] = npy(R.losses.diagonal_gaussian_logprob(T(y), T(mean), T(var), T(lws)))
+        o['loli_mask'] = npy(R.losses.diagonal_gaussian_logprob(T(y), T(mean), T(var), T(lw), mask=tf._T(torch.as_tensor(mask))))
+        e, p_ = R.losses.purity(r, T(lab))
+        o['entropy'], o['purity'] = npy(e), npy(p_)
+        return o
+
+    out = both(run)
+    out.update({'in_' + k: v for k, v in inputs.items()})
+    return out
+
+
 def main():
     cases = {
         'dist_tiny': lambda: case_distributions(1, N=6, K=4, L=3, S=5),
@@ -392,6 +422,8 @@ def main():
         'svae_c1': lambda: case_svae(8, N=40, K=5, L=2, S=10, Dy=2, U=20),
         'svae_l8': lambda: case_svae(9, N=10, K=16, L=8, S=10, Dy=8, U=50, steps=2),
         'svae_smm_tiny': lambda: case_svae(10, N=7, K=4, L=3, S=5, Dy=2, U=5, smm=True),
+        'metrics': lambda: case_metrics(12, N=50, K=5, S=7, D=3, C=4),
+        'metrics_s100': lambda: case_metrics(13, N=12, K=10, S=100, D=6, C=3),
         'svae_smm_l8': lambda: case_svae(11, N=10, K=16, L=8, S=10, Dy=8, U=50, smm=True, steps=2),
     }
     only = sys.argv[1:]

@@ -6,7 +6,7 @@ import scipy.special
 import scipy.stats
 import torch
 
-from oracle import dists, mixtures, nets, svae_ref, train_ref
+from oracle import dists, metrics, mixtures, nets, svae_ref, train_ref
 
 F64_RTOL = 1e-9
 
@@ -182,3 +182,17 @@ def test_towers_average_gradients(golden):
         close(o2['grads'][n_] * 2, o1['grads'][n_].numpy(), 1e-9, what=n_)
     for a, b in zip(st1.theta, st2.theta):
         close(b, a.numpy(), 1e-12)
+
+
+@pytest.mark.parametrize('case', ['metrics', 'metrics_s100'])
+@pytest.mark.parametrize('dtype,suf,rtol', [(torch.float64, '', 1e-12), (torch.float32, '__f32', 1e-4)])
+def test_metrics(golden, case, dtype, suf, rtol):
+    g = golden(case)
+    y, mean, var, lw, lws = [T(g['in_' + k], dtype) for k in ('y', 'mean', 'var', 'lw', 'lws')]
+    r = torch.exp(lw)
+    close(metrics.weighted_mse(y, mean, r), g['weighted_mse' + suf], rtol)
+    close(metrics.diagonal_gaussian_logprob(y, mean, var, lw), g['loli' + suf], rtol)
+    close(metrics.diagonal_gaussian_logprob(y, mean, var, lws), g['loli_s' + suf], rtol)
+    close(metrics.diagonal_gaussian_logprob(y, mean, var, lw, mask=T(g['in_mask'])), g['loli_mask' + suf], rtol)
+    e, p_ = metrics.purity(r, T(g['in_labels'], dtype))
+    close(e, g['entropy' + suf], rtol), close(p_, g['purity' + suf], rtol)

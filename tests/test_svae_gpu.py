@@ -205,3 +205,19 @@ def test_t2_full_size_properties():
     phi_s = [phi[0], phi[1], (phi[2] + 3.0).detach()]
     _, lz_s, _, _ = svae.e_step((e1, e2), phi_s, S, noise=noise, theta=theta)
     assert (torch.exp(lz_s) - torch.exp(lz1)).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize('case', ['metrics', 'metrics_s100'])
+def test_eval_metrics_golden(golden, case):
+    """weighted_mse, diagonal_gaussian_logprob (incl. per-sample weights and the missing-data mask)
+    and purity vs the reference run (losses.py)."""
+    from vmp_for_svae_amd import losses
+    g = golden(case)
+    y, mean, var, lw, lws = [dev(g['in_' + k]) for k in ('y', 'mean', 'var', 'lw', 'lws')]
+    r = torch.exp(lw)
+    assert rel(losses.weighted_mse(y, mean, r), g['weighted_mse']) < 1e-5
+    assert rel(losses.diagonal_gaussian_logprob(y, mean, var, lw), g['loli']) < 1e-5
+    assert rel(losses.diagonal_gaussian_logprob(y, mean, var, lws), g['loli_s']) < 1e-5
+    assert rel(losses.diagonal_gaussian_logprob(y, mean, var, lw, mask=dev(g['in_mask'], torch.bool)), g['loli_mask']) < 1e-5
+    e, p_ = losses.purity(r, dev(g['in_labels']))
+    assert rel(e, g['entropy']) < 1e-5 and rel(p_, g['purity']) < 1e-5

@@ -15,5 +15,6 @@ The directory name contains '-' so it is not importable by name; the top-level s
 """
 from . import _lib  # noqa: F401
 from . import distributions, helpers, models  # noqa: F401
+from . import losses, training  # noqa: F401
 
-__all__ = ['distributions', 'helpers', 'models', '_lib']
+__all__ = ['distributions', 'helpers', 'models', 'losses', 'training', '_lib']

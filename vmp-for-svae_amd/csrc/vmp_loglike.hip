@@ -91,6 +91,85 @@ __global__ __launch_bounds__(256) void loglike_kernel(LLArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Evaluation metrics, per-cell part (reference losses.py:9-38 weighted_mse, :83-145 diagonal_gaussian_logprob):
+//   mse_nk = mean_s sum_d (y_nd - mean_nksd)^2
+//   lse_nk = log( 1/S sum_s exp( lw_nk(s) - 1/2 sum_d m_nd [ (y-mean)^2/var + log var + log 2pi ] ) )
+// (m = 1, or the missing-data mask).  The K-cheap contractions over k (sum_k r_nk mse_nk; log-sum-exp over k) and
+// the means over n stay on the host side.  Same lane mapping as the reconstruction kernel above.
+// ---------------------------------------------------------------------------------------------------------
+struct EvArgs {
+    const float* y;
+    const float* mean;
+    const float* var;       // may be NULL (mse only)
+    const float* logw;      // (N,K) or (N,K,S) or NULL
+    const uint8_t* mask;    // (N,Dy) or NULL
+    float* mse;             // (N,K) or NULL
+    float* lse;             // (N,K) or NULL
+    long long cells;
+    int K, S, Dy, logw_per_sample;
+};
+
+__global__ __launch_bounds__(256) void eval_kernel(EvArgs a) {
+    __shared__ float s_mx[4][WAVE], s_se[4][WAVE], s_sq[4][WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int S = a.S, Dy = a.Dy;
+    const int SL = S < WAVE ? S : WAVE;
+    const int CPT = WAVE / SL;
+    const int c_in = lane / SL, sub = lane - c_in * SL;
+    const bool lane_on = c_in < CPT;
+    const long long ntiles = (a.cells + CPT - 1) / CPT;
+    const float LOG2PI = 1.8378770664093454836f;
+    for (long long t = (long long)blockIdx.x * nw + wave; t < ntiles; t += (long long)gridDim.x * nw) {
+        const long long cell = t * CPT + c_in;
+        const bool on = lane_on && cell < a.cells;
+        const long long cc = on ? cell : 0;
+        const long long n = cc / a.K;
+        const float* __restrict__ yr = a.y + n * Dy;
+        float mx = -INFINITY, se = 0.f, sq = 0.f;
+        if (on) {
+            for (int s = sub; s < S; s += SL) {
+                const long long base = (cc * S + s) * Dy;
+                float q = 0.f, lp = 0.f;
+                for (int d = 0; d < Dy; ++d) {
+                    const float df = yr[d] - a.mean[base + d];
+                    q = fmaf(df, df, q);
+                    if (a.var) {
+                        const float v = a.var[base + d];
+                        const float term = df * df / v + logf(v) + LOG2PI;
+                        const float m = a.mask ? (a.mask[n * Dy + d] ? 1.f : 0.f) : 1.f;
+                        lp = fmaf(-0.5f * m, term, lp);
+                    }
+                }
+                sq += q;
+                if (a.var) {
+                    if (a.logw) lp += a.logw_per_sample ? a.logw[cc * S + s] : a.logw[cc];
+                    const float nm = fmaxf(mx, lp);                 // online log-sum-exp
+                    se = se * __expf(mx - nm) + __expf(lp - nm);
+                    mx = nm;
+                }
+            }
+        }
+        s_mx[wave][lane] = mx; s_se[wave][lane] = se; s_sq[wave][lane] = sq;
+        __builtin_amdgcn_wave_barrier();
+        if (on && sub == 0) {
+            float M = -INFINITY, Q = 0.f;
+            for (int j = 0; j < SL; ++j) { M = fmaxf(M, s_mx[wave][c_in * SL + j]); Q += s_sq[wave][c_in * SL + j]; }
+            if (a.mse) a.mse[cell] = Q / (float)S;
+            if (a.lse) {
+                float E = 0.f;
+                for (int j = 0; j < SL; ++j) {
+                    const float mj = s_mx[wave][c_in * SL + j];
+                    if (mj > -INFINITY) E += s_se[wave][c_in * SL + j] * __expf(mj - M);
+                }
+                a.lse[cell] = M + logf(E) - logf((float)S);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 bool al16b(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int ll_launch(LLArgs a, bool bwd, hipStream_t s) {
@@ -121,6 +200,20 @@ int vmp_diag_gauss_loglike_bwd(const float* y, const float* mean, const float* v
     LLArgs a{y, mean, var, gA, nullptr, gmean, gvar, (long long)N * K, K, S, Dy, 0};
     a.vec_ok = al16b(y) && al16b(mean) && al16b(var) && al16b(gmean) && al16b(gvar);
     return ll_launch(a, true, static_cast<hipStream_t>(stream));
+}
+
+int vmp_eval_cell_metrics(const float* y, const float* mean, const float* var, const float* logw, int logw_per_sample,
+                          const uint8_t* mask, int64_t N, int K, int S, int Dy, float* mse, float* lse, void* stream) {
+    if (!y || !mean || N <= 0 || K <= 0 || S <= 0 || Dy <= 0 || (!mse && !lse) || (lse && !var)) {
+        set_error("vmp_eval_cell_metrics: bad argument");
+        return VMP_E_BADARG;
+    }
+    EvArgs a{y, mean, var, logw, mask, mse, lse, (long long)N * K, K, S, Dy, logw_per_sample};
+    const int SL = S < WAVE ? S : WAVE, CPT = WAVE / SL;
+    long long blocks = (((long long)N * K + CPT - 1) / CPT + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(eval_kernel, dim3((int)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch("eval_kernel");
 }
 
 }  // extern "C"
