@@ -223,3 +223,28 @@ def test_distributions_golden(golden, case):
     _, m2, C2, v2 = niw.natural_to_standard(A, b, be, vh)
     assert relerr(C2, g['niw_back_C']) < 1e-5 and relerr(v2, g['niw_back_v']) < 1e-6
     assert relerr(dirichlet.expected_log_pi(i['alpha']), g['dir_elogpi']) < 1e-5
+
+
+def test_distributed_loop_single_rank_rccl():
+    """The data-parallel loop (local reduction -> RCCL all-reduce of the fp64 moments -> identical posterior) with a
+    1-rank nccl group must reproduce the single-GPU loop (the multi-rank exchange itself is covered on CPU/gloo)."""
+    import socket
+    import torch.distributed as dist
+    from vmp_for_svae_amd.models import _mix
+    from vmp_for_svae_amd.models.parallel_mix import DistributedVMPLoop
+    from vmp_for_svae_amd import _lib as L
+    s_ = socket.socket(); s_.bind(('127.0.0.1', 0)); port = s_.getsockname()[1]; s_.close()
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    try:
+        x, r0 = _synth(30000, 8, 16, seed=21)
+        for flav, kap in ((L.VMP_GMM, None), (L.VMP_SMM, torch.full((16,), 5.0, device='cuda'))):
+            a = _mix.VMPLoop(dev(x), dev(r0), flav, kappa=kap)
+            b = DistributedVMPLoop(dev(x), dev(r0), flav, kappa=kap)
+            for _ in range(3):
+                ra, rb = a.step(), b.step()
+            assert (ra - rb).abs().max().item() < 1e-6
+            for ta, tb in zip(a.theta(), b.theta()):
+                assert relerr(tb, ta.double().cpu().numpy()) < 1e-6
+    finally:
+        dist.destroy_process_group()

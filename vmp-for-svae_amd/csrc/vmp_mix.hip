@@ -1078,7 +1078,8 @@ int vmp_mix_finalize_ws(const void* ws, const float* pivot, int64_t N, int D, in
     FinArgs f{};
     f.partials = static_cast<const double*>(ws);
     f.nblk = make_plan(N, D, K, flavour, true).blocks;
-    f.K = K; f.flavour = flavour; f.src = 0; f.do_post = 1;
+    f.K = K; f.flavour = flavour; f.src = 0;
+    f.do_post = (alpha || beta || m || C || v || xbar || S || pi || pack) ? 1 : 0;   // stats_out only: reduction only
     f.alpha0 = alpha0; f.beta0 = beta0; f.m0 = m0; f.C0 = C0; f.v0 = v0; f.kappa = kappa;
     f.alpha = alpha; f.beta = beta; f.m = m; f.C = C; f.v = v; f.xbar = xbar; f.S = S; f.pi = pi; f.pack = pack;
     f.stats_out = stats_out; f.pivot = pivot;

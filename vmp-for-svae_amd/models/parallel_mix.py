@@ -32,7 +32,11 @@ class DistributedVMPLoop(_mix.VMPLoop):
 
     def finalize(self, stats_out=None):
         # local reduction of the per-block partials -> (K, SW) fp64; sum over ranks; global posterior + pack
-        super().finalize(stats_out=self._stats)
+        pr = self.prior
+        L.check(L.lib().vmp_mix_finalize_ws(L.ptr(self.ws), L.ptr(self.pivot), self.N, self.D, self.K, self.flavour,
+                                            L.ptr(pr[0]), L.ptr(pr[1]), L.ptr(pr[2]), L.ptr(pr[3]), L.ptr(pr[4]),
+                                            L.ptr(self.kappa), *([None] * 9), L.ptr(self._stats), L.stream()),
+                'vmp_mix_finalize_ws')                   # all outputs NULL: fixed-order reduction of the partials only
         allreduce_sum_(self._stats, self.group)
         p, pr = self.post, self.prior
         L.check(L.lib().vmp_mix_finalize(L.ptr(self._stats), self.D, self.K, self.flavour, L.ptr(pr[0]), L.ptr(pr[1]),
