@@ -89,7 +89,8 @@ def test_estep_vs_oracle_shapes():
     from oracle import svae_ref, dists
     from vmp_for_svae_amd.models import svae
     rng = np.random.Generator(np.random.PCG64(5))
-    for (N, K, Ld, S) in [(5, 3, 2, 3), (37, 10, 6, 10), (64, 16, 8, 10), (130, 7, 5, 4), (9, 33, 3, 2), (20, 5, 1, 7), (3, 64, 4, 5)]:
+    for (N, K, Ld, S) in [(5, 3, 2, 3), (37, 10, 6, 10), (64, 16, 8, 10), (130, 7, 5, 4), (9, 33, 3, 2), (20, 5, 1, 7), (3, 64, 4, 5),
+                          (21, 10, 2, 100), (11, 5, 8, 100), (7, 16, 6, 37)]:   # last three: S-chunked forward (L*S > 144)
         e1 = rng.standard_normal((N, Ld))
         e2 = -0.5 * (0.3 + rng.random((N, Ld)))
         mu_k = rng.standard_normal((K, Ld)) * 2
@@ -127,7 +128,8 @@ def test_estep_vs_oracle_shapes():
         assert np.abs(np.exp(lz_p.detach().double().cpu().numpy()) - np.exp(lz_o.detach().numpy())).max() < 2e-5, tag
         assert rel(pt_p.T_prime, Tp_o.detach().numpy()) < 5e-5, tag
         for a_, b_, n_ in zip(gp, go, ('eta1', 'eta2d', 'mu_k', 'L_k', 'log_pi_k')):
-            assert rel(a_, b_.numpy()) < 2e-4, (tag, n_, rel(a_, b_.numpy()))
+            # fp32 accumulation over N*S sample adjoints: tolerance 2e-4 at S<=10, growing as sqrt(S/10)
+            assert rel(a_, b_.numpy()) < 2e-4 * max(1.0, S / 10.0) ** 0.5, (tag, n_, rel(a_, b_.numpy()))
 
 
 @pytest.mark.parametrize('case', ['svae_smm_tiny', 'svae_smm_l8'])
@@ -221,3 +223,18 @@ def test_eval_metrics_golden(golden, case):
     assert rel(losses.diagonal_gaussian_logprob(y, mean, var, lw, mask=dev(g['in_mask'], torch.bool)), g['loli_mask']) < 1e-5
     e, p_ = losses.purity(r, dev(g['in_labels']))
     assert rel(e, g['entropy']) < 1e-5 and rel(p_, g['purity']) < 1e-5
+
+
+def test_driver_pinwheel_converges():
+    """End-to-end (8f rank 3): the experiments driver on pinwheel (reference config: K=10, L=2, U=50, minibatch 100,
+    lr 0.01, lrcvi 0.1).  The negative normalised ELBO must fall and the held-out log-likelihood must rise."""
+    from vmp_for_svae_amd import experiments
+    cfg = {'dataset': 'pinwheel', 'method': 'svae-cvi', 'lr': 0.01, 'lrcvi': 0.1, 'K': 10, 'L': 2, 'U': 50, 'seed': 0}
+    tr, hist, log_id = experiments.run(cfg, nb_iters=400, measurement_freq=100, verbose=False)
+    assert log_id.startswith('svae-cvi_pinwheel_K10')
+    first, last = hist[0], hist[-1]
+    assert all(np.isfinite(list(h.values())).all() for h in hist)
+    assert last['neg_normed_elbo'] < first['neg_normed_elbo'] - 1.0
+    assert last['loli'] > first['loli'] + 1.0
+    assert last['mse'] < 0.5 * first['mse']
+    assert 0.2 <= last['purity'] <= 1.0

@@ -732,6 +732,124 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
 // subsample_x (reference svae.py:122-151): z_ns ~ Cat(exp log_z_n), x_samples[n,s,:] = x[n, z_ns, s, :].
 // The categorical draw is the inverse CDF of a supplied uniform (or a supplied index, for parity tests).
 // ---------------------------------------------------------------------------------------------------------
+// Large-S form of the forward kernel (evaluation runs use S=100, experiments.py:283): the cell's L*S noise block no
+// longer fits the per-wave LDS tile, so the samples are processed SC at a time.  Same lane mapping and arithmetic
+// order per sample as svae_estep_fwd_kernel; eps^2 / q_theta accumulate across chunks in sample order.
+template <int L>
+__global__ __launch_bounds__(SV_FWD_MAX_NW * WAVE) void svae_estep_fwd_chunked_kernel(EFwdArgs a, int SC) {
+    constexpr int TRI = SvGeo<L>::TRI;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int K = a.K, S = a.S;
+    const int LSn = L * S, CSTR = (L * SC) | 1;
+    const int RPT = WAVE / K, CT = RPT * K;
+    float* et = smem + wave * (WAVE * CSTR + WAVE);
+    float* scr = et + WAVE * CSTR;
+    const bool lane_on = lane < CT;
+    const int r = lane / K, k = lane - r * K, rbase = lane_on ? r * K : 0;
+    float Pl[TRI], hkk[L], mkk[L], Wt[TRI];
+    const bool student = a.nu != nullptr;
+    const int kc = lane_on ? k : 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const float hv = a.hk[kc * L + i], mv = a.mk[kc * L + i];
+        hkk[i] = lane_on ? hv : 0.f;
+        mkk[i] = lane_on ? mv : 0.f;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            const float pvv = a.Pk[(kc * L + i) * L + j], wv = a.Wk[(kc * L + i) * L + j];
+            Pl[tri(i, j)] = lane_on ? pvv : (i == j ? 1.f : 0.f);
+            Wt[tri(i, j)] = lane_on ? wv : 0.f;
+        }
+    }
+    const float bv = a.bias[kc], kv = a.kappa[kc], nv = *(student ? a.nu + kc : a.bias);
+    const float biask = lane_on ? bv : 0.f, kappak = lane_on ? kv : 0.f, nuk = (student && lane_on) ? nv : 1.f;
+    const float inv_nu = 1.0f / nuk, invS = 1.0f / (float)S;
+
+    const long long ntiles = (a.N + RPT - 1) / RPT;
+    for (long long t = (long long)blockIdx.x * nw + wave; t < ntiles; t += (long long)gridDim.x * nw) {
+        const long long row = t * RPT + r;
+        const bool on = lane_on && row < a.N;
+        const long long rows_here = (a.N - t * RPT) < RPT ? (a.N - t * RPT) : RPT;
+        const int cells = (int)rows_here * K;
+        float Lm[TRI], av[L];
+#pragma unroll
+        for (int i = 0; i < TRI; ++i) Lm[i] = Pl[i];
+        const long long rowc = on ? row : 0;
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const float e1v = a.eta1[rowc * L + i], e2v = a.eta2d[rowc * L + i];
+            const float e1 = on ? e1v : 0.f;
+            const float e2 = on ? e2v : -0.5f;
+            Lm[tri(i, i)] = fmaf(-2.f, e2, Lm[tri(i, i)]);
+            av[i] = e1 + hkk[i];
+        }
+        float ld;
+        cell_cholesky<L>(Lm, ld);
+        solve_lower<L>(Lm, av);
+        float aa = 0.f;
+#pragma unroll
+        for (int i = 0; i < L; ++i) aa = fmaf(av[i], av[i], aa);
+        const float c = on ? (biask + 0.5f * aa - ld) : -INFINITY;
+        const float mx = row_max(c, scr, lane, rbase, K);
+        const float ex = on ? __expf(c - mx) : 0.f;
+        const float se = row_sum(ex, scr, lane, rbase, K);
+        const float lz = c - mx - __logf(se);
+
+        float eps2 = 0.f, qth = 0.f;
+        float* cell = et + lane * CSTR;
+        const float* __restrict__ gin = a.noise + t * CT * LSn;
+        float* __restrict__ gout = a.x + t * CT * LSn;
+        for (int c0 = 0; c0 < S; c0 += SC) {
+            const int sc = (S - c0) < SC ? (S - c0) : SC;
+            const int per = L * sc, tot = cells * per;
+            for (int e = lane; e < tot; e += WAVE) {       // noise (cell, L, S) -> LDS (cell, L, sc)
+                const int c2 = e / per, rem = e - c2 * per;
+                const int i = rem / sc, s = rem - i * sc;
+                et[c2 * CSTR + i * sc + s] = gin[c2 * LSn + i * S + c0 + s];
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int s = 0; s < sc; ++s) {
+                float z[L];
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    const float e = lane_on ? cell[i * sc + s] : 0.f;
+                    eps2 = fmaf(e, e, eps2);
+                    z[i] = av[i] + e;
+                }
+                solve_lower_t<L>(Lm, z);
+                float d[L];
+#pragma unroll
+                for (int i = 0; i < L; ++i) d[i] = z[i] - mkk[i];
+                float del2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    float y = 0.f;
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) y = fmaf(Wt[tri(i, j)], d[j], y);
+                    del2 = fmaf(y, y, del2);
+                }
+                qth += student ? (nuk + (float)L) * log1pf(del2 * inv_nu) : del2;
+                if (lane_on) {
+#pragma unroll
+                    for (int i = 0; i < L; ++i) cell[i * sc + s] = z[i];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int o = lane; o < tot; o += WAVE) {       // LDS (cell, L, sc) -> x (cell, S, L)
+                const int c2 = o / per, rem = o - c2 * per;
+                const int s = rem / L, l = rem - s * L;
+                gout[c2 * LSn + (c0 + s) * L + l] = et[c2 * CSTR + l * sc + s];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (on) {
+            a.lz[row * K + k] = lz;
+            a.Tp[row * K + k] = -0.5f * L * LOG_2PI + ld - 0.5f * invS * eps2 + 0.5f * invS * qth - kappak;
+        }
+    }
+}
+
 struct SubArgs {
     const float* x;         // (N,K,S,L)
     const float* lz;        // (N,K)
@@ -771,7 +889,7 @@ int check_sv(long long N, int K, int L, int S) {
     if (N <= 0 || S <= 0) { set_error("N and S must be positive"); return VMP_E_BADARG; }
     if (L < 1 || L > VMP_MAX_D) { set_error("L=%d outside compiled range 1..%d", L, VMP_MAX_D); return VMP_E_DIM; }
     if (K < 1 || K > VMP_MAX_K) { set_error("K=%d outside compiled range 1..%d", K, VMP_MAX_K); return VMP_E_DIM; }
-    if ((size_t)(L * S | 1) * WAVE * sizeof(float) > 36 * 1024) { set_error("L*S=%d too large for the LDS noise tile", L * S); return VMP_E_DIM; }
+    if (S > (1 << 16)) { set_error("S=%d too large", S); return VMP_E_DIM; }
     return 0;
 }
 
@@ -842,6 +960,22 @@ int vmp_svae_estep_fwd(const float* eta1, const float* eta2d, const float* hk, c
             });
             return rc;
         }
+    }
+    if ((size_t)(L * S | 1) * WAVE * sizeof(float) > 36 * 1024) {
+        // the cell's noise block does not fit the LDS tile: process the samples SC at a time
+        int SC = (32 * 1024 / (int)(WAVE * sizeof(float))) / L;   // L*SC*64*4 B <= 32 KiB per wave
+        const size_t pw = (size_t)(WAVE * ((L * SC) | 1) + WAVE) * sizeof(float);
+        const int nwc = 4;
+        const int RPTc = WAVE / K;
+        long long bl = ((N + RPTc - 1) / RPTc + nwc - 1) / nwc;
+        if (bl > 1024) bl = 1024;
+        rc = -1;
+        VMP_DISPATCH_L(L, {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd_chunked_kernel<LL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(pw * nwc));
+            hipLaunchKernelGGL((svae_estep_fwd_chunked_kernel<LL>), dim3((int)bl), dim3(nwc * WAVE), pw * nwc, static_cast<hipStream_t>(stream), a, SC);
+            rc = check_launch("svae_estep_fwd_chunked_kernel");
+        });
+        return rc;
     }
     const size_t per_wave = (size_t)(WAVE * (L * S | 1) + WAVE) * sizeof(float);
     int nw = (int)((150 * 1024) / per_wave);                 // one block per CU, as many waves as 160 KiB of LDS hold

@@ -1,0 +1,74 @@
+"""Small host-side data utilities - the part of reference data.py a driver needs:
+the pinwheel generator (data.py:216-235, after Johnson et al. 2016), train/test split + scaling
+(data.py:82-120) and shuffled minibatches (the TF shuffle queue of data.py:130-171 becomes a generator).
+Host I/O only; nothing here is on the hot path."""
+import numpy as np
+
+
+def make_pinwheel_data(radial_std, tangential_std, num_classes, num_per_class, rate):
+    """Same construction and RNG call order as the reference (np.random.seed(1); one randn; one permutation), so the
+    generated points are identical."""
+    np.random.seed(1)
+    n = num_classes * num_per_class
+    base = np.random.randn(n, 2) * np.array([radial_std, tangential_std])
+    base[:, 0] += 1.0
+    labels = np.repeat(np.arange(num_classes), num_per_class)
+    spoke = np.linspace(0.0, 2.0 * np.pi, num_classes, endpoint=False)[labels]
+    ang = spoke + rate * np.exp(base[:, 0])
+    c, s = np.cos(ang), np.sin(ang)
+    pts = 10.0 * np.stack([base[:, 0] * c + base[:, 1] * s, -base[:, 0] * s + base[:, 1] * c], axis=1)
+    shuffled = np.random.permutation(np.hstack([pts, labels[:, None]]))
+    return shuffled[:, 0:2], shuffled[:, 2].astype(int)
+
+
+def load_dataset(dataset, path_datadir=None):
+    """(data (N,Dy) float64, labels (N,) int or None).  'pinwheel' is generated; 'auto' / 'aggregation' / 'geyser' are
+    read from `path_datadir` laid out like the reference's datasets/ directory (data.py:40-70)."""
+    if dataset in ('pinwheel', 'noisy-pinwheel'):
+        return make_pinwheel_data(0.3, 0.05, 5, 200, 0.25)
+    if path_datadir is None:
+        raise ValueError("dataset '%s' needs path_datadir" % dataset)
+    import pandas as pd
+    if dataset == 'auto':
+        raw = pd.read_csv(path_datadir + '/Auto/auto-mpg.csv', sep=',', header=None).values
+        raw = raw[raw[:, 3] != '?']
+        cyl = raw[:, 1].astype(int)
+        labels = np.searchsorted(np.array([3, 4, 5, 6, 8]), cyl)               # cylinders {3,4,5,6,8} -> 0..4
+        return raw[:, [0, 2, 3, 4, 5, 6]].astype(np.float64), labels
+    if dataset == 'aggregation':
+        raw = pd.read_csv(path_datadir + '/Aggregation.txt', sep='\t', header=None).values
+        return raw[:, 0:2], raw[:, 2].astype(int) - 1
+    if dataset == 'geyser':
+        raw = pd.read_csv(path_datadir + '/geyser', sep=' ', header=None).values[:, [1, 2]]
+        return raw, (raw[:, 1] > 20).astype(int)
+    raise Exception("Dataset '%s' does not exist." % dataset)
+
+
+def split_and_scale(dataset, data, labels, ratio_tr=0.7, seed_split=0):
+    """data.py:82-120: sklearn train_test_split; 'auto' is standardised and scaled by 5, pinwheel is left as is,
+    everything else is standardised.  Returns (X_tr, y_tr, X_te, y_te) with one-hot labels (or None)."""
+    from sklearn.model_selection import train_test_split
+    from sklearn.preprocessing import StandardScaler
+    onehot = None
+    if labels is not None:
+        onehot = np.zeros((data.shape[0], np.unique(labels).size))
+        onehot[np.arange(data.shape[0]), labels] = 1
+        X_tr, X_te, y_tr, y_te = train_test_split(data, onehot, test_size=1 - ratio_tr, random_state=seed_split)
+    else:
+        X_tr, X_te = train_test_split(data, test_size=1 - ratio_tr, random_state=seed_split)
+        y_tr = y_te = None
+    if dataset not in ('pinwheel', 'noisy-pinwheel'):
+        sc = StandardScaler().fit(X_tr)
+        mult = 5.0 if dataset == 'auto' else 1.0
+        X_tr, X_te = sc.transform(X_tr) * mult, sc.transform(X_te) * mult
+    return X_tr.astype(np.float32), y_tr, X_te.astype(np.float32), y_te
+
+
+def minibatches(X, size_minibatch, seed=0):
+    """Endless generator of shuffled minibatches (index arrays)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    N = X.shape[0]
+    while True:
+        perm = rng.permutation(N)
+        for i in range(0, N - size_minibatch + 1, size_minibatch):
+            yield perm[i:i + size_minibatch]

@@ -1,1 +1,1 @@
-from . import tf_utils  # noqa: F401
+from . import logging_utils, scheduling, tf_utils  # noqa: F401
