@@ -40,7 +40,7 @@ struct PassArgs {
     float* logr_out;
     double* partials;
     long long N;
-    long long ntiles;
+    long long rpw;        // rows per wave (multiple of 8): wave g owns rows [g*rpw, min(N, (g+1)*rpw))
     int K;
     int vec_ok;       // x pointer 16-byte aligned (vector row loads allowed)
     int par_reduce;   // LDS holds one fp64 slab per wave: reduce the waves in one parallel step
@@ -94,6 +94,35 @@ __device__ __forceinline__ v2f row16_sum2(v2f v) {
     return v2f{a, b};
 }
 
+// Packed-fp32 arithmetic of a row PAIR (x.lo = row a, x.hi = row b) against ONE component parameter.  Parameters
+// live two to a 64-bit register pair and are broadcast to both halves with op_sel - a {p, p} splat written in C++
+// is hoisted out of the loop by the compiler and doubles the resident parameter registers (88 -> 44 VGPRs at D=8,
+// which is the difference between 2 and 3 waves per SIMD).  h selects the half of `p` that holds the parameter.
+__device__ __forceinline__ v2f pk_fma_b(v2f x, v2f p, v2f acc, int h) {
+    v2f d;
+    if (h) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(x), "v"(p), "v"(acc));
+    else   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(x), "v"(p), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ v2f pk_mul_b(v2f x, v2f p, int h) {
+    v2f d;
+    if (h) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(x), "v"(p));
+    else   asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(x), "v"(p));
+    return d;
+}
+__device__ __forceinline__ v2f pk_sub_b(v2f x, v2f p, int h) {                      // x - p
+    v2f d;
+    if (h) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(p));
+    else   asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(p));
+    return d;
+}
+// c.lo - q * c.hi on both halves of q  (c = {log2-domain constant, half-scale})
+__device__ __forceinline__ v2f pk_const_minus_scaled(v2f q, v2f c) {
+    v2f d;
+    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(q), "v"(c));
+    return d;
+}
+
 template <int D, int KT, int FLAV, bool ESTEP, bool STATS, bool MASK>
 __global__ __launch_bounds__(MAX_NW * WAVE) void pass_kernel(PassArgs a) {
     using G = Geo<D>;
@@ -121,7 +150,9 @@ __global__ __launch_bounds__(MAX_NW * WAVE) void pass_kernel(PassArgs a) {
     }
 
     // ---- this lane's component parameters, resident for the whole kernel
-    float pm[KT][D], pw[KT][G::TRI], pc[KT], ph[KT], pua[KT], pub[KT];
+    constexpr int MP = (D + 1) / 2, WP = (G::TRI + 1) / 2;
+    v2f pm2[KT][MP], pw2[KT][WP], pch[KT];
+    float pua[KT], pub[KT];
     if constexpr (ESTEP) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
@@ -132,11 +163,11 @@ __global__ __launch_bounds__(MAX_NW * WAVE) void pass_kernel(PassArgs a) {
 #pragma unroll
             for (int j = 0; j < G::PACK; ++j) raw[j] = p[j];                  // all loads in flight together
 #pragma unroll
-            for (int j = 0; j < D; ++j) pm[kt][j] = on ? raw[j] - pv[j] : 0.f;
+            for (int j = 0; j < 2 * MP; ++j) pm2[kt][j >> 1][j & 1] = (on && j < D) ? raw[j < D ? j : 0] - pv[j < D ? j : 0] : 0.f;
 #pragma unroll
-            for (int j = 0; j < G::TRI; ++j) pw[kt][j] = on ? raw[D + j] : 0.f;
-            pc[kt] = on ? raw[D + G::TRI] : -INFINITY;        // log2-domain constant; -inf switches the lane off
-            ph[kt] = on ? raw[D + G::TRI + 1] : 0.f;
+            for (int j = 0; j < 2 * WP; ++j) pw2[kt][j >> 1][j & 1] = (on && j < G::TRI) ? raw[D + (j < G::TRI ? j : 0)] : 0.f;
+            pch[kt].x = on ? raw[D + G::TRI] : -INFINITY;     // log2-domain constant; -inf switches the lane off
+            pch[kt].y = on ? raw[D + G::TRI + 1] : 0.f;
             pua[kt] = on ? raw[D + G::TRI + 2] : 0.f;
             pub[kt] = on ? raw[D + G::TRI + 3] : 1.f;
         }
@@ -176,27 +207,29 @@ __global__ __launch_bounds__(MAX_NW * WAVE) void pass_kernel(PassArgs a) {
         }
     }
 
-    const long long tstride = (long long)gridDim.x * nw;
+    // Each wave owns a CONTIGUOUS row range of the same length (a multiple of 8 rows): with whole 64-row tiles dealt
+    // round-robin the waves of a full chip get 5 or 6 tiles each at N=1e6 and everyone waits for the 6s.
     const bool vec = a.vec_ok != 0;
-    long long t = (long long)blockIdx.x * nw + wave;
+    const long long lo = ((long long)blockIdx.x * nw + wave) * a.rpw;
+    const long long hi = (lo + a.rpw < a.N) ? lo + a.rpw : a.N;
     float xr[D];
     {
-        const long long n = t * TR + lane;
+        const long long n = lo + lane;
 #pragma unroll
         for (int j = 0; j < D; ++j) xr[j] = 0.f;
-        if (t < a.ntiles && n < a.N) load_row<D>(a.x + n * D, xr, vec);
+        if (n < hi) load_row<D>(a.x + n * D, xr, vec);
     }
-    for (; t < a.ntiles; t += tstride) {
-        const long long row0 = t * TR;
+    for (long long row0 = lo; row0 < hi; row0 += TR) {
+        const int trows = (hi - row0 < TR) ? (int)(hi - row0) : TR;      // rows of this (possibly partial) tile
         // stage this tile's rows (transposed, pivot-shifted), then prefetch the next tile's row
         {
-            const bool valid = row0 + lane < a.N;
+            const bool valid = row0 + lane < hi;
 #pragma unroll
             for (int j = 0; j < D; ++j) xl[j * LS + lane] = valid ? xr[j] - pv[j] : 0.f;
-            const long long n2 = (t + tstride) * TR + lane;
+            const long long n2 = row0 + TR + lane;
 #pragma unroll
             for (int j = 0; j < D; ++j) xr[j] = 0.f;
-            if (t + tstride < a.ntiles && n2 < a.N) load_row<D>(a.x + n2 * D, xr, vec);
+            if (n2 < hi) load_row<D>(a.x + n2 * D, xr, vec);
         }
         __builtin_amdgcn_wave_barrier();
 
@@ -204,9 +237,9 @@ __global__ __launch_bounds__(MAX_NW * WAVE) void pass_kernel(PassArgs a) {
         const long long tbase = (row0 + kk) * K + i16;
         const int K4 = 4 * K;
 #pragma unroll 1
-        for (int n0 = 0; n0 < TR; n0 += 8) {
+        for (int n0 = 0; n0 < trows; n0 += 8) {
             const long long ra = row0 + n0 + kk, rb = ra + 4;             // this lane's two data rows
-            const bool va = ra < a.N, vb = rb < a.N;
+            const bool va = ra < hi, vb = rb < hi;
             const int so = n0 * K;                                        // wave-uniform
             v2f w[KT], rr[KT];
             if constexpr (ESTEP) {
@@ -226,20 +259,20 @@ __global__ __launch_bounds__(MAX_NW * WAVE) void pass_kernel(PassArgs a) {
                     v2f dv[D];
 #pragma unroll
                     for (int j = 0; j < D; ++j) {
-                        dv[j] = xv[j] - pm[kt][j];
+                        dv[j] = pk_sub_b(xv[j], pm2[kt][j >> 1], j & 1);
                         if constexpr (MASK) dv[j] = dv[j] * keep[j];
                     }
                     // y = W (x - m), W lower triangular packed row-major; walked by COLUMNS so that the D
                     // accumulators form independent dependency chains (a row-wise walk is latency-bound)
                     v2f y[D];
 #pragma unroll
-                    for (int i = 0; i < D; ++i) y[i] = dv[0] * pw[kt][i * (i + 1) / 2];
+                    for (int i = 0; i < D; ++i) y[i] = pk_mul_b(dv[0], pw2[kt][(i * (i + 1) / 2) >> 1], (i * (i + 1) / 2) & 1);
 #pragma unroll
                     for (int j = 1; j < D; ++j)
 #pragma unroll
                         for (int i = j; i < D; ++i) {
-                            const float wij = pw[kt][i * (i + 1) / 2 + j];
-                            y[i] = __builtin_elementwise_fma(dv[j], v2f{wij, wij}, y[i]);
+                            const int e = i * (i + 1) / 2 + j;
+                            y[i] = pk_fma_b(dv[j], pw2[kt][e >> 1], y[i], e & 1);
                         }
                     v2f q = y[0] * y[0], q1 = v2f{0.f, 0.f};
 #pragma unroll
@@ -248,7 +281,7 @@ __global__ __launch_bounds__(MAX_NW * WAVE) void pass_kernel(PassArgs a) {
                         else q = __builtin_elementwise_fma(y[i], y[i], q);
                     }
                     q += q1;
-                    lg[kt] = v2f{pc[kt], pc[kt]} - q * ph[kt];            // log2 rho
+                    lg[kt] = pk_const_minus_scaled(q, pch[kt]);           // log2 rho
                     mx = __builtin_elementwise_max(mx, lg[kt]);
                     if constexpr (SMM) uu[kt] = v2f{pua[kt] * __builtin_amdgcn_rcpf(q.x + pub[kt]), pua[kt] * __builtin_amdgcn_rcpf(q.y + pub[kt])};
                 }
@@ -828,7 +861,7 @@ __global__ __launch_bounds__(1024) void pivot_kernel(PivotArgs a) {
 struct Plan {
     int nw, blocks, par_reduce;
     size_t lds;
-    long long ntiles;
+    long long rpw;
 };
 
 int env_int(const char* name, int dflt) {
@@ -845,11 +878,17 @@ Plan make_plan(long long N, int D, int K, int flavour, bool stats) {
     int nw = tuned_nw;
     if (nw > MAX_NW) nw = MAX_NW;
     if (nw < 1) nw = 1;
-    p.ntiles = (N + TR - 1) / TR;
-    if ((long long)nw > p.ntiles) nw = (int)p.ntiles;
-    long long blocks = (p.ntiles + nw - 1) / nw;
+    const long long ntiles = (N + TR - 1) / TR;
+    if ((long long)nw > ntiles) nw = (int)ntiles;
+    long long blocks = (ntiles + nw - 1) / nw;
     if (blocks > tuned_blocks) blocks = tuned_blocks;
     if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
+    // equal contiguous row ranges, at least one full tile each
+    long long rpw = (N + blocks * nw - 1) / (blocks * nw);
+    rpw = (rpw + 7) / 8 * 8;
+    if (rpw < TR) rpw = TR;
+    blocks = ((N + rpw - 1) / rpw + nw - 1) / nw;
+    p.rpw = rpw;
     p.nw = nw;
     p.blocks = (int)blocks;
     const int FTn = (1 + D + D * (D + 1) / 2 + 15) / 16, KTn = (K + 15) / 16;
@@ -916,7 +955,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 int run_pass(PassArgs a, int D, int flavour, bool estep, bool stats, bool mask, hipStream_t s) {
     Plan p = make_plan(a.N, D, a.K, flavour, stats);
-    a.ntiles = p.ntiles;
+    a.rpw = p.rpw;
     a.par_reduce = p.par_reduce;
 
     int rc = -1;
