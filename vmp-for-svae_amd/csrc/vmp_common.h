@@ -13,6 +13,62 @@ namespace vmp {
 
 constexpr int WAVE = 64;
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// ---- packed fp32 (v_pk_*_f32) against a broadcast parameter -------------------------------------------
+// x holds two independent values (two data rows, or two samples of one cell); the parameter is ONE float,
+// stored two to a 64-bit register pair and broadcast to both halves with op_sel.  A {p, p} splat written in
+// C++ is hoisted out of the loop by the compiler and doubles the resident parameter registers.  h selects
+// the half of `p` that holds the parameter (a compile-time constant after unrolling).
+__device__ __forceinline__ v2f pk_fma_b(v2f x, v2f p, v2f acc, int h) {            // acc + x * p.h
+    v2f d;
+    if (h) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(x), "v"(p), "v"(acc));
+    else   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(x), "v"(p), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ v2f pk_fnma_b(v2f x, v2f p, v2f acc, int h) {           // acc - x * p.h
+    v2f d;
+    if (h) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(d) : "v"(x), "v"(p), "v"(acc));
+    else   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(d) : "v"(x), "v"(p), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ v2f pk_mul_b(v2f x, v2f p, int h) {                     // x * p.h
+    v2f d;
+    if (h) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(x), "v"(p));
+    else   asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(x), "v"(p));
+    return d;
+}
+__device__ __forceinline__ v2f pk_add_b(v2f x, v2f p, int h) {                     // x + p.h
+    v2f d;
+    if (h) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(x), "v"(p));
+    else   asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(x), "v"(p));
+    return d;
+}
+__device__ __forceinline__ v2f pk_sub_b(v2f x, v2f p, int h) {                     // x - p.h
+    v2f d;
+    if (h) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(p));
+    else   asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(p));
+    return d;
+}
+// c.lo - q * c.hi on both halves of q  (c = {constant, scale})
+__device__ __forceinline__ v2f pk_const_minus_scaled(v2f q, v2f c) {
+    v2f d;
+    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(q), "v"(c));
+    return d;
+}
+
+// all-reduce over the 16 lanes of a DPP row by row rotations, one value per lane.  The two wait states a DPP read
+// needs after a VALU write of the same VGPR are explicit (hipcc's hazard recogniser does not look inside asm).
+#define VMP_DPP1(OP, CTRL) "v_" OP "_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+__device__ __forceinline__ float row16_max(float v) {
+    asm("s_nop 1\n\t" VMP_DPP1("max", "row_ror:8") VMP_DPP1("max", "row_ror:4") VMP_DPP1("max", "row_ror:2") VMP_DPP1("max", "row_ror:1") : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    asm("s_nop 1\n\t" VMP_DPP1("add", "row_ror:8") VMP_DPP1("add", "row_ror:4") VMP_DPP1("add", "row_ror:2") VMP_DPP1("add", "row_ror:1") : "+v"(v));
+    return v;
+}
+
 // ---- error plumbing (thread-local message) ------------------------------------------------
 void set_error(const char* fmt, ...);
 int  check_launch(const char* what);

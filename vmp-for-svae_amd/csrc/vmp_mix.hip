@@ -26,7 +26,6 @@ constexpr int TR = 64;        // data rows per wave tile
 constexpr int LS = 66;        // LDS stride (floats) between value-rows of the x image
 constexpr int MAX_NW = 8;     // waves per block
 constexpr int MAX_BLOCKS = 1024;   // upper bound (workspace sizing); the plan uses tuned_blocks
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct PassArgs {
     const float* x;
@@ -92,35 +91,6 @@ __device__ __forceinline__ v2f row16_sum2(v2f v) {
         VMP_DPP2("add", "row_ror:1")
         : "+v"(a), "+v"(b));
     return v2f{a, b};
-}
-
-// Packed-fp32 arithmetic of a row PAIR (x.lo = row a, x.hi = row b) against ONE component parameter.  Parameters
-// live two to a 64-bit register pair and are broadcast to both halves with op_sel - a {p, p} splat written in C++
-// is hoisted out of the loop by the compiler and doubles the resident parameter registers (88 -> 44 VGPRs at D=8,
-// which is the difference between 2 and 3 waves per SIMD).  h selects the half of `p` that holds the parameter.
-__device__ __forceinline__ v2f pk_fma_b(v2f x, v2f p, v2f acc, int h) {
-    v2f d;
-    if (h) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(x), "v"(p), "v"(acc));
-    else   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(x), "v"(p), "v"(acc));
-    return d;
-}
-__device__ __forceinline__ v2f pk_mul_b(v2f x, v2f p, int h) {
-    v2f d;
-    if (h) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(x), "v"(p));
-    else   asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(x), "v"(p));
-    return d;
-}
-__device__ __forceinline__ v2f pk_sub_b(v2f x, v2f p, int h) {                      // x - p
-    v2f d;
-    if (h) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(p));
-    else   asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(p));
-    return d;
-}
-// c.lo - q * c.hi on both halves of q  (c = {log2-domain constant, half-scale})
-__device__ __forceinline__ v2f pk_const_minus_scaled(v2f q, v2f c) {
-    v2f d;
-    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(q), "v"(c));
-    return d;
 }
 
 template <int D, int KT, int FLAV, bool ESTEP, bool STATS, bool MASK>

@@ -541,11 +541,15 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
         const float gts = gT * invS;
         const float* __restrict__ xc = a.x + cellid * LSn;
         const float* __restrict__ gc = a.Gx + cellid * LSn;
-        float nxs[L], ngx[L];                               // next sample's rows, in flight while this one is used
-        // (one branch around the whole group of row loads: skipping the tail prefetches matters, this kernel is
-        //  bound by the per-lane row loads - an unconditional clamped version measured 27% slower)
-        auto load_rows = [&](int s2, float (&xo)[L], float (&go)[L]) {
+        // Rows are fetched TWO samples at a time: 2*L floats = one 64-byte segment per array per lane, requested by
+        // back-to-back loads.  Fetching a single 32-byte row per iteration made every row its own L2 request (the
+        // other half of the segment is evicted from the 32 KiB L1 before the next sample needs it): 329 M requests
+        // of ~31 B per launch at C3 (TCP_TCC_READ_REQ), i.e. the kernel was bound by L1<->L2 requests, not by HBM.
+        // (one branch around the whole group of loads: skipping the tail prefetches matters - an unconditional
+        //  clamped version measured 27% slower)
+        auto load_pair = [&](int s2, float (&xo)[2 * L], float (&go)[2 * L]) {
             const bool live = on && s2 < S;
+            const bool both = s2 + 1 < S;
             if (live) {
                 if ((L & 3) == 0 && a.vec_ok) {
 #pragma unroll
@@ -555,22 +559,43 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
                         xo[4 * q] = v.x; xo[4 * q + 1] = v.y; xo[4 * q + 2] = v.z; xo[4 * q + 3] = v.w;
                         go[4 * q] = w.x; go[4 * q + 1] = w.y; go[4 * q + 2] = w.z; go[4 * q + 3] = w.w;
                     }
+                    if (both) {
+#pragma unroll
+                        for (int q = 0; q < L / 4; ++q) {
+                            const float4 v = reinterpret_cast<const float4*>(xc + (s2 + 1) * L)[q];
+                            const float4 w = reinterpret_cast<const float4*>(gc + (s2 + 1) * L)[q];
+                            xo[L + 4 * q] = v.x; xo[L + 4 * q + 1] = v.y; xo[L + 4 * q + 2] = v.z; xo[L + 4 * q + 3] = v.w;
+                            go[L + 4 * q] = w.x; go[L + 4 * q + 1] = w.y; go[L + 4 * q + 2] = w.z; go[L + 4 * q + 3] = w.w;
+                        }
+                    }
                 } else {
 #pragma unroll
                     for (int i = 0; i < L; ++i) { xo[i] = xc[s2 * L + i]; go[i] = gc[s2 * L + i]; }
+                    if (both) {
+#pragma unroll
+                        for (int i = 0; i < L; ++i) { xo[L + i] = xc[(s2 + 1) * L + i]; go[L + i] = gc[(s2 + 1) * L + i]; }
+                    }
                 }
             }
 #pragma unroll
-            for (int i = 0; i < L; ++i) { xo[i] = live ? xo[i] : 0.f; go[i] = live ? go[i] : 0.f; }
+            for (int i = 0; i < L; ++i) {
+                xo[i] = live ? xo[i] : 0.f; go[i] = live ? go[i] : 0.f;
+                xo[L + i] = (live && both) ? xo[L + i] : 0.f; go[L + i] = (live && both) ? go[L + i] : 0.f;
+            }
         };
-        float nxs2[L], ngx2[L];                             // ... and the one after it
-        load_rows(0, nxs, ngx);
-        load_rows(1, nxs2, ngx2);
-        for (int s = 0; s < S; ++s) {
+        float nxs[2 * L], ngx[2 * L];                       // next pair, in flight while this one is used
+        load_pair(0, nxs, ngx);
+        for (int s0 = 0; s0 < S; s0 += 2) {
+            float xp[2 * L], gp[2 * L];
+#pragma unroll
+            for (int i = 0; i < 2 * L; ++i) { xp[i] = nxs[i]; gp[i] = ngx[i]; }
+            load_pair(s0 + 2, nxs, ngx);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+            if (h == 1 && s0 + 1 >= S) break;
             float xs[L], gx[L];
 #pragma unroll
-            for (int i = 0; i < L; ++i) { xs[i] = nxs[i]; gx[i] = ngx[i]; nxs[i] = nxs2[i]; ngx[i] = ngx2[i]; }
-            load_rows(s + 2, nxs2, ngx2);
+            for (int i = 0; i < L; ++i) { xs[i] = xp[h * L + i]; gx[i] = gp[h * L + i]; }
             // d/dx of the theta term of T':  (1/S) c_s W^T W (x - m),  c_s = 1 (Gaussian) or (nu+L)/(nu+delta^2)
             float d[L], y[L];
 #pragma unroll
@@ -615,6 +640,7 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
                 const float e = xs[i] - mu[i];              // e_s = Lt^-T eps_s
 #pragma unroll
                 for (int j = 0; j <= i; ++j) M[tri(i, j)] = fmaf(e, gx[j], M[tri(i, j)]);
+            }
             }
         }
         // ---- assemble dLoss/dht and dLoss/dPt (symmetric, lower triangle)
@@ -732,6 +758,591 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
 // subsample_x (reference svae.py:122-151): z_ns ~ Cat(exp log_z_n), x_samples[n,s,:] = x[n, z_ns, s, :].
 // The categorical draw is the inverse CDF of a supplied uniform (or a supplied index, for parity tests).
 // ---------------------------------------------------------------------------------------------------------
+// Forward kernel, packed form: the sample loop handles TWO samples per iteration as the two halves of
+// v_pk_*_f32 operands ({eps_i,s ; eps_i,s+1} are adjacent in the (cell, L, S) noise layout, so one ds_read2_b32
+// delivers the pair), with the cell factor / theta parameters broadcast by op_sel (vmp_common.h).  P_k comes
+// from an LDS table once per tile instead of living in 36 VGPRs.  ST is a compile-time S (0 = run-time): with
+// it every LDS offset in the sample loop is an immediate.  Full tiles take check-free staging / copy-out loops
+// whose (cell, offset) indices advance incrementally.
+template <int L, int ST>
+__global__ __launch_bounds__(SV_FWD_MAX_NW * WAVE) void svae_estep_fwd3_kernel(EFwdArgs a) {
+    constexpr int TRI = SvGeo<L>::TRI;
+    constexpr int TP = (TRI + 1) / 2, LP = (L + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int K = a.K;
+    const int S = ST ? ST : a.S;
+    const int LSn = L * S, CSTR = LSn | 1;                 // odd LDS stride per cell
+    const int RPT = WAVE / K, CT = RPT * K;                // rows / cells per wave tile
+    constexpr int PSTR = TRI | 1;
+    float* pk_lds = smem;                                  // [K][PSTR] lower triangle of P_k
+    float* et = smem + K * PSTR + wave * (WAVE * CSTR + WAVE);
+    float* scr = et + WAVE * CSTR;
+    const bool lane_on = lane < CT;
+    const int r = lane / K, k = lane - r * K, rbase = lane_on ? r * K : 0;
+    const bool k16 = (K == 16);                            // lane row of 16 = one data row: DPP reductions
+
+    for (int e = threadIdx.x; e < K * TRI; e += blockDim.x) {
+        const int kk = e / TRI, idx = e - kk * TRI;
+        int i = 0;
+        while (tri(i + 1, 0) <= idx) ++i;
+        const int j = idx - tri(i, 0);
+        pk_lds[kk * PSTR + idx] = a.Pk[(kk * L + i) * L + j];
+    }
+    __syncthreads();
+
+    // resident component parameters (unconditional loads from clamped indices + value selects)
+    float hkk[L];
+    v2f mk2[LP], Wt2[TP];
+    const bool student = a.nu != nullptr;
+    const int kc = lane_on ? k : 0;
+#pragma unroll
+    for (int i = 0; i < 2 * LP; ++i) {
+        const float mv = a.mk[kc * L + (i < L ? i : 0)];
+        mk2[i >> 1][i & 1] = (lane_on && i < L) ? mv : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const float hv = a.hk[kc * L + i];
+        hkk[i] = lane_on ? hv : 0.f;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            const float wv = a.Wk[(kc * L + i) * L + j];
+            Wt2[tri(i, j) >> 1][tri(i, j) & 1] = lane_on ? wv : 0.f;
+        }
+    }
+    if (TRI & 1) Wt2[TP - 1][1] = 0.f;
+    float biask, kappak, nuk;
+    {
+        const float bv = a.bias[kc], kv = a.kappa[kc], nv = *(student ? a.nu + kc : a.bias);
+        biask = lane_on ? bv : 0.f; kappak = lane_on ? kv : 0.f; nuk = (student && lane_on) ? nv : 1.f;
+    }
+    const float inv_nu = 1.0f / nuk;
+
+    const long long ntiles = (a.N + RPT - 1) / RPT;
+    const float invLS = 1.0f / (float)LSn, invS = 1.0f / (float)S;
+    const int Q = LSn >> 2;                                // float4s per cell (fast paths need LSn % 4 == 0)
+    const bool fastio = a.vec_ok && (LSn & 3) == 0 && (L & 3) == 0 && CT == WAVE;
+    const int c_first = lane / (Q > 0 ? Q : 1), rem_first = lane - c_first * Q;
+    const int dc = WAVE / (Q > 0 ? Q : 1), dr = WAVE - dc * Q;
+    for (long long t = (long long)blockIdx.x * nw + wave; t < ntiles; t += (long long)gridDim.x * nw) {
+        const long long row = t * RPT + r;
+        const bool on = lane_on && row < a.N;
+        const long long rows_here = (a.N - t * RPT) < RPT ? (a.N - t * RPT) : RPT;
+        const int tot = (int)rows_here * K * LSn;          // floats of noise / samples in this tile
+        const bool full = fastio && rows_here == RPT;
+        // ---- stage the noise tile: coalesced global reads, padded per-cell layout in LDS
+        {
+            const float* __restrict__ g = a.noise + t * CT * LSn;
+            if (full) {
+                // every lane moves exactly Q float4s; float4 q = it*64 + lane belongs to cell q / Q at offset 4*(q % Q)
+                const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g) + lane;
+                int c = c_first, rem = rem_first;
+                constexpr int UN = 10;
+                for (int it0 = 0; it0 < Q; it0 += UN) {
+                    float4 v[UN];
+#pragma unroll
+                    for (int u = 0; u < UN; ++u)
+                        if (it0 + u < Q) v[u] = g4[(it0 + u) * WAVE];
+#pragma unroll
+                    for (int u = 0; u < UN; ++u) {
+                        if (it0 + u < Q) {
+                            float* d = et + c * CSTR + 4 * rem;
+                            d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                            c += dc; rem += dr;
+                            if (rem >= Q) { rem -= Q; c += 1; }
+                        }
+                    }
+                }
+            } else if (a.vec_ok && (LSn & 3) == 0) {
+                constexpr int UN = 10;
+                for (int e0 = 4 * lane; e0 < tot; e0 += UN * 4 * WAVE) {
+                    float4 v[UN];
+#pragma unroll
+                    for (int u = 0; u < UN; ++u) {
+                        const int e = e0 + u * 4 * WAVE;
+                        v[u] = (e < tot) ? *reinterpret_cast<const float4*>(g + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UN; ++u) {
+                        const int e = e0 + u * 4 * WAVE;
+                        if (e < tot) {
+                            const int c = (int)(((float)e + 0.5f) * invLS);
+                            const int j = e - c * LSn;
+                            float* d = et + c * CSTR + j;
+                            d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                        }
+                    }
+                }
+            } else {
+                for (int e = lane; e < tot; e += WAVE) {
+                    const int c = (int)(((float)e + 0.5f) * invLS);
+                    et[c * CSTR + (e - c * LSn)] = g[e];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- cell factorisation
+        float Lm[TRI], av[L];
+        const long long rowc = on ? row : 0;
+#pragma unroll
+        for (int i = 0; i < TRI; ++i) { const float pvv = pk_lds[kc * PSTR + i]; Lm[i] = lane_on ? pvv : 0.f; }
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const float e1v = a.eta1[rowc * L + i], e2v = a.eta2d[rowc * L + i];
+            const float e1 = on ? e1v : 0.f;
+            const float e2 = on ? e2v : -0.5f;
+            Lm[tri(i, i)] = fmaf(-2.f, e2, Lm[tri(i, i)]);
+            av[i] = e1 + hkk[i];
+        }
+        float ld;
+        cell_cholesky<L>(Lm, ld);
+        solve_lower<L>(Lm, av);
+        float aa = 0.f;
+#pragma unroll
+        for (int i = 0; i < L; ++i) aa = fmaf(av[i], av[i], aa);
+        const float c = on ? (biask + 0.5f * aa - ld) : -INFINITY;
+        float mx, se, ex;
+        if (k16) {
+            mx = row16_max(c);
+            ex = on ? __expf(c - mx) : 0.f;
+            se = row16_sum(ex);
+        } else {
+            mx = row_max(c, scr, lane, rbase, K);
+            ex = on ? __expf(c - mx) : 0.f;
+            se = row_sum(ex, scr, lane, rbase, K);
+        }
+        const float lz = c - mx - __logf(se);
+
+        // factor and a = Lt^-1 ht as broadcastable pairs
+        v2f Lm2[TP], av2[LP];
+#pragma unroll
+        for (int i = 0; i < 2 * TP; ++i) Lm2[i >> 1][i & 1] = (i < TRI) ? Lm[i < TRI ? i : 0] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2 * LP; ++i) av2[i >> 1][i & 1] = (i < L) ? av[i < L ? i : 0] : 0.f;
+
+        // ---- samples (two at a time) and the per-cell regulariser term
+        v2f eps2 = v2f{0.f, 0.f}, qth = v2f{0.f, 0.f};
+        float* cell = et + lane * CSTR;
+#pragma unroll 1
+        for (int s = 0; s < S; s += 2) {
+            const bool hv = s + 1 < S;                     // second half valid (uniform)
+            v2f z[L];
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                v2f e = v2f{cell[i * S + s], cell[i * S + s + 1]};   // the element after the last one is padding / scratch
+                if (!lane_on) e = v2f{0.f, 0.f};
+                if (!hv) e.y = 0.f;
+                eps2 = __builtin_elementwise_fma(e, e, eps2);
+                z[i] = pk_add_b(e, av2[i >> 1], i & 1);
+            }
+            // z <- Lt^-T z (back substitution; diagonal of Lm holds reciprocals)
+#pragma unroll
+            for (int i = L - 1; i >= 0; --i) {
+                v2f tt = z[i];
+#pragma unroll
+                for (int p2 = i + 1; p2 < L; ++p2) tt = pk_fnma_b(z[p2], Lm2[tri(p2, i) >> 1], tt, tri(p2, i) & 1);
+                z[i] = pk_mul_b(tt, Lm2[tri(i, i) >> 1], tri(i, i) & 1);
+            }
+            v2f d[L];
+#pragma unroll
+            for (int i = 0; i < L; ++i) d[i] = pk_sub_b(z[i], mk2[i >> 1], i & 1);
+            v2f del2 = v2f{0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                v2f y = pk_mul_b(d[0], Wt2[tri(i, 0) >> 1], tri(i, 0) & 1);
+#pragma unroll
+                for (int j = 1; j <= i; ++j) y = pk_fma_b(d[j], Wt2[tri(i, j) >> 1], y, tri(i, j) & 1);
+                del2 = __builtin_elementwise_fma(y, y, del2);
+            }
+            if (!hv) del2.y = 0.f;
+            if (student) {
+                const float sc = nuk + (float)L;
+                qth.x += sc * log1pf(del2.x * inv_nu);
+                qth.y += sc * log1pf(del2.y * inv_nu);
+            } else {
+                qth += del2;
+            }
+            if (lane_on) {
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    cell[i * S + s] = z[i].x;
+                    if (hv) cell[i * S + s + 1] = z[i].y;
+                }
+            }
+        }
+        if (on) {
+            a.lz[row * K + k] = lz;
+            a.Tp[row * K + k] = -0.5f * L * LOG_2PI + ld - 0.5f * invS * (eps2.x + eps2.y) + 0.5f * invS * (qth.x + qth.y) - kappak;
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- samples out: (cell, S, L) layout, coalesced
+        {
+            float* __restrict__ g = a.x + t * CT * LSn;
+            if (full) {
+                // float4 q = it*64 + lane of the tile = (cell q / Q, sample (q % Q) / (L/4), 4 dims from 4*((q % Q) % (L/4)))
+                float4* __restrict__ g4 = reinterpret_cast<float4*>(g) + lane;
+                int c2 = c_first, rem = rem_first;
+                constexpr int L4 = (L / 4 > 0) ? L / 4 : 1;
+                for (int it = 0; it < Q; ++it) {
+                    const int s = rem / L4, l4 = rem - s * L4;
+                    const float* src = et + c2 * CSTR + (4 * l4) * S + s;
+                    float4 v;
+                    v.x = src[0]; v.y = src[S]; v.z = src[2 * S]; v.w = src[3 * S];
+                    g4[it * WAVE] = v;
+                    c2 += dc; rem += dr;
+                    if (rem >= Q) { rem -= Q; c2 += 1; }
+                }
+            } else if (a.vec_ok && (L & 3) == 0) {
+                for (int o = 4 * lane; o < tot; o += 4 * WAVE) {
+                    const int c2 = (int)(((float)o + 0.5f) * invLS);
+                    const int rem = o - c2 * LSn;
+                    const int s = rem / L, l = rem - s * L;
+                    const float* src = et + c2 * CSTR + l * S + s;
+                    float4 v;
+                    v.x = src[0]; v.y = src[S]; v.z = src[2 * S]; v.w = src[3 * S];
+                    *reinterpret_cast<float4*>(g + o) = v;
+                }
+            } else {
+                for (int o = lane; o < tot; o += WAVE) {
+                    const int c2 = (int)(((float)o + 0.5f) * invLS);
+                    const int rem = o - c2 * LSn;
+                    const int s = rem / L, l = rem - s * L;
+                    g[o] = et[c2 * CSTR + l * S + s];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Forward kernel, LDS-DMA form.  Measured on the single-buffered kernels above (C3): loads+compute 1.3 ms,
+// compute+stores 1.4 ms, everything 2.8 ms - a wave's load phase and store phase do not overlap, and 7 waves per CU
+// with <=10 KB each in flight cannot hide it.  Here every wave owns TWO noise buffers: the next tile streams in with
+// global_load_lds_dwordx4 (no VGPRs, a full 20 KB tile in flight per wave) while the current one is computed and
+// written back.  The LDS image is lane-linear (dest = base + lane*16 B), so the padding goes into the SOURCE
+// addresses: slot q = w*64 + lane of instruction w is float4 (q % QS) of cell (q / QS), QS = CS/4 with CS/4 odd,
+// i.e. a cell stride of CS dwords whose 64-bit accesses are 2-way conflict-free at worst; pad slots re-fetch the
+// cell's last float4.  One s_waitcnt vmcnt(0) per tile retires the tile's DMA (issued a whole tile earlier) and
+// the previous tile's stores; the row loads of the tile are consumed BEFORE the next DMA is issued, so no
+// compiler-generated wait ever covers a DMA in flight.
+template <int L, int ST>
+__global__ __launch_bounds__(4 * WAVE) void svae_estep_fwd4_kernel(EFwdArgs a, int CS_rt) {
+    constexpr int TRI = SvGeo<L>::TRI;
+    constexpr int TP = (TRI + 1) / 2, LP = (L + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int K = a.K;
+    const int S = ST ? ST : a.S;
+    const int LSn = L * S;
+    constexpr int CS_ct = ST ? (L * ST + ((((L * ST) >> 2) & 1) ? 0 : 4)) : 0;   // same rule as the host (CS/4 odd)
+    const int CS = ST ? CS_ct : CS_rt;
+    const int Q = LSn >> 2, QS = CS >> 2;                  // data / total float4 slots per cell
+    constexpr int QSc = ST ? (CS_ct >> 2) : 1, Qc = ST ? ((L * ST) >> 2) : 1;
+    const int RPT = WAVE / K, CT = RPT * K;
+    constexpr int PSTR = TRI | 1;
+    const int tab = (K * PSTR + 3) & ~3;
+    float* pk_lds = smem;
+    float* buf0 = smem + tab + wave * (2 * WAVE * CS + WAVE);
+    float* scr = buf0 + 2 * WAVE * CS;
+    const bool lane_on = lane < CT;
+    const int r = lane / K, k = lane - r * K, rbase = lane_on ? r * K : 0;
+    const bool k16 = (K == 16);
+
+    for (int e = threadIdx.x; e < K * TRI; e += blockDim.x) {
+        const int kk = e / TRI, idx = e - kk * TRI;
+        int i = 0;
+        while (tri(i + 1, 0) <= idx) ++i;
+        const int j = idx - tri(i, 0);
+        pk_lds[kk * PSTR + idx] = a.Pk[(kk * L + i) * L + j];
+    }
+    __syncthreads();
+
+    float hkk[L];
+    v2f mk2[LP], Wt2[TP];
+    const bool student = a.nu != nullptr;
+    const int kc = lane_on ? k : 0;
+#pragma unroll
+    for (int i = 0; i < 2 * LP; ++i) {
+        const float mv = a.mk[kc * L + (i < L ? i : 0)];
+        mk2[i >> 1][i & 1] = (lane_on && i < L) ? mv : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const float hv = a.hk[kc * L + i];
+        hkk[i] = lane_on ? hv : 0.f;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            const float wv = a.Wk[(kc * L + i) * L + j];
+            Wt2[tri(i, j) >> 1][tri(i, j) & 1] = lane_on ? wv : 0.f;
+        }
+    }
+    if (TRI & 1) Wt2[TP - 1][1] = 0.f;
+    float biask, kappak, nuk;
+    {
+        const float bv = a.bias[kc], kv = a.kappa[kc], nv = *(student ? a.nu + kc : a.bias);
+        biask = lane_on ? bv : 0.f; kappak = lane_on ? kv : 0.f; nuk = (student && lane_on) ? nv : 1.f;
+    }
+    const float inv_nu = 1.0f / nuk;
+
+    const long long ntiles = (a.N + RPT - 1) / RPT;
+    const float invLS = 1.0f / (float)LSn, invS = 1.0f / (float)S;
+    const long long tstride = (long long)gridDim.x * nw;
+    // slot walk of this lane: slot q = w*64 + lane -> (cell q / QS, slot q % QS), advanced incrementally
+    const int c_first = lane / QS, sl_first = lane - c_first * QS;
+    const int dcs = WAVE / QS, drs = WAVE - dcs * QS;
+    // same walk over the DATA float4s (copy-out of full tiles)
+    const int o_first = lane / Q, orem_first = lane - o_first * Q;
+    const int dco = WAVE / Q, dro = WAVE - dco * Q;
+
+    // per-lane source offset of DMA instruction w within a tile (floats); fixed for the whole kernel, so with a
+    // compile-time S it is computed once and kept in registers (one wave per SIMD: there are 512 of them)
+    int dma_off[QSc];
+    if constexpr (ST != 0) {
+        int c = c_first, sl = sl_first;
+#pragma unroll
+        for (int w = 0; w < QSc; ++w) {
+            dma_off[w] = c * LSn + 4 * (sl < Q ? sl : Q - 1);
+            c += dcs; sl += drs;
+            if (sl >= QS) { sl -= QS; c += 1; }
+        }
+    }
+    int co_off[Qc];                                        // LDS offset of output float4 (it*64 + lane) of a full tile
+    if constexpr (ST != 0) {
+        constexpr int L4c = (L / 4 > 0) ? L / 4 : 1;
+        int c2 = o_first, rem = orem_first;
+#pragma unroll
+        for (int it = 0; it < Qc; ++it) {
+            const int s = rem / L4c, l4 = rem - s * L4c;
+            co_off[it] = c2 * CS + (4 * l4) * S + s;
+            c2 += dco; rem += dro;
+            if (rem >= Q) { rem -= Q; c2 += 1; }
+        }
+    }
+    auto issue_dma = [&](long long tt, float* buf) {
+        const long long cells_left = (a.N - tt * RPT) * K;
+        const int ncell = cells_left < CT ? (int)cells_left : CT;          // valid cells of the tile (>= 1)
+        const float* __restrict__ g = a.noise + tt * CT * LSn;
+        if constexpr (ST != 0) {
+            if (ncell == WAVE) {
+#pragma unroll
+                for (int w = 0; w < QSc; ++w)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + dma_off[w]),
+                                                     (__attribute__((address_space(3))) void*)(buf + w * (4 * WAVE)), 16, 0, 0);
+                return;
+            }
+        }
+        int c = c_first, sl = sl_first;
+        for (int w = 0; w < QS; ++w) {
+            const int cc = c < ncell ? c : ncell - 1;
+            const int ss = sl < Q ? sl : Q - 1;
+            const float* src = g + (long long)cc * LSn + 4 * ss;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(buf + w * (4 * WAVE)), 16, 0, 0);
+            c += dcs; sl += drs;
+            if (sl >= QS) { sl -= QS; c += 1; }
+        }
+    };
+
+    long long t = (long long)blockIdx.x * nw + wave;
+    if (t < ntiles) issue_dma(t, buf0);
+    int cur = 0;
+    // the encoder rows of a tile are fetched one tile ahead as well (plain loads, consumed before the next DMA is issued)
+    float e1r[L], e2r[L];
+    {
+        const long long row0 = t * RPT + r;
+        const long long rc0 = (t < ntiles && lane_on && row0 < a.N) ? row0 : 0;
+#pragma unroll
+        for (int i = 0; i < L; ++i) { e1r[i] = a.eta1[rc0 * L + i]; e2r[i] = a.eta2d[rc0 * L + i]; }
+    }
+    for (; t < ntiles; t += tstride) {
+        float* et = buf0 + cur * (WAVE * CS);
+        const long long row = t * RPT + r;
+        const bool on = lane_on && row < a.N;
+        const long long rows_here = (a.N - t * RPT) < RPT ? (a.N - t * RPT) : RPT;
+        const int tot = (int)rows_here * K * LSn;
+        const bool full = a.vec_ok && (L & 3) == 0 && CT == WAVE && rows_here == RPT;
+
+        // ---- cell factorisation
+        float Lm[TRI], av[L];
+#pragma unroll
+        for (int i = 0; i < TRI; ++i) { const float pvv = pk_lds[kc * PSTR + i]; Lm[i] = lane_on ? pvv : 0.f; }
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const float e1 = on ? e1r[i] : 0.f;
+            const float e2 = on ? e2r[i] : -0.5f;
+            Lm[tri(i, i)] = fmaf(-2.f, e2, Lm[tri(i, i)]);
+            av[i] = e1 + hkk[i];
+        }
+        float ld;
+        cell_cholesky<L>(Lm, ld);
+        solve_lower<L>(Lm, av);
+        float aa = 0.f;
+#pragma unroll
+        for (int i = 0; i < L; ++i) aa = fmaf(av[i], av[i], aa);
+        const float c = on ? (biask + 0.5f * aa - ld) : -INFINITY;
+        float mx, se, ex;
+        if (k16) {
+            mx = row16_max(c);
+            ex = on ? __expf(c - mx) : 0.f;
+            se = row16_sum(ex);
+        } else {
+            mx = row_max(c, scr, lane, rbase, K);
+            ex = on ? __expf(c - mx) : 0.f;
+            se = row_sum(ex, scr, lane, rbase, K);
+        }
+        const float lz = c - mx - __logf(se);
+
+        // The factorisation above needed no noise: the previous tile's stores had that long to drain.  Now: next tile's
+        // rows (plain loads), then ONE wait that retires this tile's DMA (issued a tile ago), the old stores and those
+        // rows - consumed right here so that no compiler-generated wait ever covers the DMA issued next.
+        {
+            const long long rown = (t + tstride) * RPT + r;
+            const long long rcn = (t + tstride < ntiles && lane_on && rown < a.N) ? rown : 0;
+#pragma unroll
+            for (int i = 0; i < L; ++i) { e1r[i] = a.eta1[rcn * L + i]; e2r[i] = a.eta2d[rcn * L + i]; }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < L; ++i) asm volatile("" : "+v"(e1r[i]), "+v"(e2r[i]));
+        if (t + tstride < ntiles) issue_dma(t + tstride, buf0 + (cur ^ 1) * (WAVE * CS));
+
+        v2f Lm2[TP], av2[LP];
+#pragma unroll
+        for (int i = 0; i < 2 * TP; ++i) Lm2[i >> 1][i & 1] = (i < TRI) ? Lm[i < TRI ? i : 0] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2 * LP; ++i) av2[i >> 1][i & 1] = (i < L) ? av[i < L ? i : 0] : 0.f;
+
+        // ---- samples (two at a time) and the per-cell regulariser term
+        v2f eps2 = v2f{0.f, 0.f}, qth = v2f{0.f, 0.f};
+        float* cell = et + lane * CS;
+        auto read_pair = [&](int s2, v2f (&eo)[L]) {
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                if constexpr (ST != 0 && (ST & 1) == 0) eo[i] = *reinterpret_cast<const v2f*>(cell + i * S + s2);   // 8-byte aligned: CS, S, s even
+                else eo[i] = v2f{cell[i * S + s2], cell[i * S + s2 + 1]};
+            }
+        };
+        v2f en[L];                                         // next pair's noise, read while this pair is computed
+        read_pair(0, en);
+#pragma unroll 1
+        for (int s = 0; s < S; s += 2) {
+            const bool hv = s + 1 < S;
+            v2f z[L], ec[L];
+#pragma unroll
+            for (int i = 0; i < L; ++i) ec[i] = en[i];
+            read_pair((s + 2 < S) ? s + 2 : s, en);
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                v2f e = ec[i];
+                if (!lane_on) e = v2f{0.f, 0.f};
+                if (!hv) e.y = 0.f;
+                eps2 = __builtin_elementwise_fma(e, e, eps2);
+                z[i] = pk_add_b(e, av2[i >> 1], i & 1);
+            }
+#pragma unroll
+            for (int i = L - 1; i >= 0; --i) {
+                v2f tt = z[i];
+#pragma unroll
+                for (int p2 = i + 1; p2 < L; ++p2) tt = pk_fnma_b(z[p2], Lm2[tri(p2, i) >> 1], tt, tri(p2, i) & 1);
+                z[i] = pk_mul_b(tt, Lm2[tri(i, i) >> 1], tri(i, i) & 1);
+            }
+            v2f d[L];
+#pragma unroll
+            for (int i = 0; i < L; ++i) d[i] = pk_sub_b(z[i], mk2[i >> 1], i & 1);
+            v2f del2 = v2f{0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                v2f y = pk_mul_b(d[0], Wt2[tri(i, 0) >> 1], tri(i, 0) & 1);
+#pragma unroll
+                for (int j = 1; j <= i; ++j) y = pk_fma_b(d[j], Wt2[tri(i, j) >> 1], y, tri(i, j) & 1);
+                del2 = __builtin_elementwise_fma(y, y, del2);
+            }
+            if (!hv) del2.y = 0.f;
+            if (student) {
+                const float sc = nuk + (float)L;
+                qth.x += sc * log1pf(del2.x * inv_nu);
+                qth.y += sc * log1pf(del2.y * inv_nu);
+            } else {
+                qth += del2;
+            }
+            if (lane_on) {
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    if constexpr (ST != 0 && (ST & 1) == 0) {
+                        *reinterpret_cast<v2f*>(cell + i * S + s) = z[i];
+                    } else {
+                        cell[i * S + s] = z[i].x;
+                        if (hv) cell[i * S + s + 1] = z[i].y;
+                    }
+                }
+            }
+        }
+        if (on) {
+            a.lz[row * K + k] = lz;
+            a.Tp[row * K + k] = -0.5f * L * LOG_2PI + ld - 0.5f * invS * (eps2.x + eps2.y) + 0.5f * invS * (qth.x + qth.y) - kappak;
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- samples out: (cell, S, L) layout, coalesced
+        {
+            float* __restrict__ g = a.x + t * CT * LSn;
+            if (full) {
+                float4* __restrict__ g4 = reinterpret_cast<float4*>(g) + lane;
+                constexpr int L4 = (L / 4 > 0) ? L / 4 : 1;
+                // batches of CB float4s: all their LDS reads in flight before the first store (one wave per SIMD: nobody
+                // else hides the LDS latency)
+                constexpr int CB = 5;
+                if constexpr (ST != 0) {
+#pragma unroll
+                    for (int it0 = 0; it0 < Qc; it0 += CB) {
+                        float4 v[CB];
+#pragma unroll
+                        for (int u = 0; u < CB; ++u) {
+                            if (it0 + u < Qc) {
+                                const float* src = et + co_off[it0 + u];
+                                v[u].x = src[0]; v[u].y = src[S]; v[u].z = src[2 * S]; v[u].w = src[3 * S];
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < CB; ++u)
+                            if (it0 + u < Qc) g4[(it0 + u) * WAVE] = v[u];
+                    }
+                } else {
+                    int c2 = o_first, rem = orem_first;
+                    for (int it0 = 0; it0 < Q; it0 += CB) {
+                        float4 v[CB];
+#pragma unroll
+                        for (int u = 0; u < CB; ++u) {
+                            if (it0 + u < Q) {
+                                const int s = rem / L4, l4 = rem - s * L4;
+                                const float* src = et + c2 * CS + (4 * l4) * S + s;
+                                v[u].x = src[0]; v[u].y = src[S]; v[u].z = src[2 * S]; v[u].w = src[3 * S];
+                                c2 += dco; rem += dro;
+                                if (rem >= Q) { rem -= Q; c2 += 1; }
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < CB; ++u)
+                            if (it0 + u < Q) g4[(it0 + u) * WAVE] = v[u];
+                    }
+                }
+            } else {
+                for (int o = lane; o < tot; o += WAVE) {
+                    const int c2 = (int)(((float)o + 0.5f) * invLS);
+                    const int rem = o - c2 * LSn;
+                    const int s = rem / L, l = rem - s * L;
+                    g[o] = et[c2 * CS + l * S + s];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        cur ^= 1;
+    }
+}
+
 // Large-S form of the forward kernel (evaluation runs use S=100, experiments.py:283): the cell's L*S noise block no
 // longer fits the per-wave LDS tile, so the samples are processed SC at a time.  Same lane mapping and arithmetic
 // order per sample as svae_estep_fwd_kernel; eps^2 / q_theta accumulate across chunks in sample order.
@@ -974,6 +1585,60 @@ int vmp_svae_estep_fwd(const float* eta1, const float* eta2d, const float* hk, c
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd_chunked_kernel<LL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(pw * nwc));
             hipLaunchKernelGGL((svae_estep_fwd_chunked_kernel<LL>), dim3((int)bl), dim3(nwc * WAVE), pw * nwc, static_cast<hipStream_t>(stream), a, SC);
             rc = check_launch("svae_estep_fwd_chunked_kernel");
+        });
+        return rc;
+    }
+    static const int use_old = getenv("VMP_SV_FWD_OLD") ? 1 : 0;
+    static const int no_dma = getenv("VMP_SV_FWD_NODMA") ? 1 : 0;
+    if (!use_old && !no_dma && (L * S) % 4 == 0 && al16(noise)) {
+        // LDS-DMA kernel: cell stride CS = L*S rounded so that CS/4 is odd
+        int CS = L * S;
+        if (((CS >> 2) & 1) == 0) CS += 4;
+        const size_t table = (size_t)((K * ((L * (L + 1) / 2) | 1) + 3) & ~3) * sizeof(float);
+        const size_t pw = (size_t)(2 * WAVE * CS + WAVE) * sizeof(float);
+        int nw4 = (int)((158 * 1024 - table) / pw);
+        if (nw4 > 4) nw4 = 4;
+        if (nw4 >= 1) {
+            const size_t lds4 = table + pw * nw4;
+            const int RPT4 = WAVE / K;
+            long long bl = ((N + RPT4 - 1) / RPT4 + nw4 - 1) / nw4;
+            if (bl > 256) bl = 256;
+            rc = -1;
+            VMP_DISPATCH_L(L, {
+                if (S == 10) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<LL, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                    hipLaunchKernelGGL((svae_estep_fwd4_kernel<LL, 10>), dim3((int)bl), dim3(nw4 * WAVE), lds4, static_cast<hipStream_t>(stream), a, CS);
+                } else {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<LL, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                    hipLaunchKernelGGL((svae_estep_fwd4_kernel<LL, 0>), dim3((int)bl), dim3(nw4 * WAVE), lds4, static_cast<hipStream_t>(stream), a, CS);
+                }
+                rc = check_launch("svae_estep_fwd4_kernel");
+            });
+            return rc;
+        }
+    }
+    if (!use_old) {
+        const size_t table = (size_t)K * ((L * (L + 1) / 2) | 1) * sizeof(float);
+        const size_t pw = (size_t)(WAVE * (L * S | 1) + WAVE) * sizeof(float);
+        int nw3 = (int)((150 * 1024 - table) / pw);        // one block per CU, as many waves as 160 KiB of LDS hold
+        if (nw3 > SV_FWD_MAX_NW) nw3 = SV_FWD_MAX_NW;
+        if (nw3 < 1) nw3 = 1;
+        const size_t lds3 = table + pw * nw3;
+        const int RPT3 = WAVE / K;
+        long long bl = ((N + RPT3 - 1) / RPT3 + nw3 - 1) / nw3;
+        if (bl > 256) bl = 256;
+        rc = -1;
+        VMP_DISPATCH_L(L, {
+            if (S == 10) {
+                if (lds3 > 64 * 1024)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd3_kernel<LL, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+                hipLaunchKernelGGL((svae_estep_fwd3_kernel<LL, 10>), dim3((int)bl), dim3(nw3 * WAVE), lds3, static_cast<hipStream_t>(stream), a);
+            } else {
+                if (lds3 > 64 * 1024)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd3_kernel<LL, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+                hipLaunchKernelGGL((svae_estep_fwd3_kernel<LL, 0>), dim3((int)bl), dim3(nw3 * WAVE), lds3, static_cast<hipStream_t>(stream), a);
+            }
+            rc = check_launch("svae_estep_fwd3_kernel");
         });
         return rc;
     }
