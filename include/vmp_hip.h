@@ -183,6 +183,33 @@ int    vmp_diag_gauss_loglike_bwd(const float* y, const float* mean, const float
                                   int64_t N, int K, int S, int Dy, float* gmean, float* gvar, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused decoder MLP + reconstruction term (models/vae.py:75-128 make_nnet, :138-151 make_decoder, :233-248)
+ * ------------------------------------------------------------------------------------------------
+ * The decoder the SVAE driver builds (experiments.py:140: [(U,tanh),(U,tanh),(Dy,'standard')]) applied to the
+ * N*K*S sample rows x (N,K,S,L), fused with the per-row part of vae.expected_diagonal_gaussian_loglike:
+ *   h0 = tanh(x W0 + b0), h1 = tanh(h0 W1 + b1), [raw1|raw2] = h1 W2 + b2            (vae.py:17-25, 86-93)
+ *   mean = raw1 + x Ws + bs1,  var = softplus(raw2) + log1p(exp(bs2))                 (vae.py:28-49, 97-116)
+ *   ll_nks = sum_d [ (y_nd - mean_d)^2 / var_d + log(var_d + 1e-8) ]                  (vae.py:236-240)
+ * so that A_nk of vmp_diag_gauss_loglike_fwd = sum_s ll_nks, without the (rows x U) activations or the
+ * (N,K,S,Dy) decoder outputs ever reaching HBM.  fp32 MFMA (v_mfma_f32_16x16x4_f32), L, Dy <= 8, U <= 64.
+ * Parameters in the reference's variable layout: W0 (L,U) 'layer_0/kernel', b0 (U), W1 (U,U), b1 (U),
+ * W2 (U,2Dy) 'gaussian_output/kernel', b2 (2Dy), Ws (L,Dy) 'shortcut/W', bs1 (Dy) 'shortcut/b1', bs2 (Dy).
+ *   fwd: ll (N,K,S) and/or (mean, var) (N,K,S,Dy) - either may be NULL (K = S = 1 gives the plain decoder);
+ *        y may be NULL when ll is.
+ *   bwd: given gA (N,K) = dLoss/dA_nk writes dx (N,K,S,L) and the flat parameter gradient
+ *        dparams [W0|b0|W1|b1|W2|b2|Ws|bs1|bs2] (vmp_decoder_param_words floats); deterministic.            */
+int    vmp_decoder_param_words(int L, int U, int Dy);
+size_t vmp_decoder_workspace_bytes(int64_t N, int K, int S, int L, int U, int Dy);
+int    vmp_decoder_loglike_fwd(const float* x, const float* y, const float* W0, const float* b0, const float* W1,
+                               const float* b1, const float* W2, const float* b2, const float* Ws, const float* bs1,
+                               const float* bs2, int64_t N, int K, int S, int L, int Dy, int U, float* ll, float* mean,
+                               float* var, void* stream);
+int    vmp_decoder_loglike_bwd(const float* x, const float* y, const float* gA, const float* W0, const float* b0,
+                               const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws,
+                               const float* bs1, const float* bs2, int64_t N, int K, int S, int L, int Dy, int U,
+                               float* dx, float* dparams, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Stand-alone per-cell log-densities (forward only; the training step uses the fused kernels above)
  * ------------------------------------------------------------------------------------------------
  * vmp_gauss_logprob_nat_per_samp : gaussian.log_probability_nat_per_samp (distributions/gaussian.py:74-105)

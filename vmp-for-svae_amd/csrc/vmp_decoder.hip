@@ -1,0 +1,641 @@
+// Fused decoder MLP + expected diagonal-Gaussian log-likelihood for gfx950 (reference models/vae.py:75-128
+// make_nnet with layerspecs [(U,tanh),(U,tanh),(Dy,'standard')] - experiments.py:140 - followed by the per-row part
+// of vae.expected_diagonal_gaussian_loglike, vae.py:233-248):
+//
+//   h0 = tanh(x W0 + b0);  h1 = tanh(h0 W1 + b1);  [raw1 | raw2] = h1 W2 + b2
+//   mean = raw1 + x Ws + bs1;  var = softplus(raw2) + log1p(exp(bs2))
+//   ll_row = sum_d [ (y_nd - mean_d)^2 / var_d + log(var_d + 1e-8) ]             row = (n, k, s)
+//
+// The reference evaluates this on N*K*S rows with three tiny GEMMs whose (rows x U) activations go through memory
+// five times forward and as often backward.  Here one wave owns 16 rows at a time and the activations never leave
+// its registers:
+//   * every layer is a chain of v_mfma_f32_16x16x4_f32 (exact fp32) with M = output unit, N = data row,
+//     K = input unit.  The accumulator layout of layer l (lane (g,c), register v  <->  unit 16t+4g+v, row c) IS the
+//     B-operand layout of layer l+1 when its k-steps are enumerated as (t, v) - the contraction order is free - so
+//     the layers chain without any transpose or LDS round trip; the weights are pre-permuted into that order once
+//     per block ("operand images" in LDS, read as conflict-free ds_read_b128).
+//   * the backward pass recomputes the forward (cheaper than storing 2 x rows x U floats), back-propagates with the
+//     transposed operand images, and accumulates ALL weight gradients in MFMA accumulators with the data row as the
+//     contraction index; the two operands of those products need (unit,row) -> (row,unit) transposes, done 16x16 at
+//     a time through a per-wave LDS scratch.  Per-wave accumulators are reduced in a fixed order: waves of a block
+//     through LDS, blocks through a workspace and a second tiny kernel in fp64 (deterministic, no atomics).
+// MFMA work per 16 rows at U=50: 90 (fwd) / 290 (bwd incl. recompute) instructions of 32 cycles.
+#include "vmp_common.h"
+
+using namespace vmp;
+
+namespace {
+
+constexpr int DEC_THREADS = 256;
+constexpr int DEC_WAVES = DEC_THREADS / WAVE;
+constexpr int TS = 20;                 // row stride (floats) of a 16x16 transpose scratch block
+constexpr int TBLK = 16 * TS;
+
+struct DecArgs {
+    const float* x;        // (R, L)  rows = N*K*S
+    const float* y;        // (N, Dy)
+    const float* gA;       // (N, K)  backward: upstream gradient of A_nk = sum_s ll_row
+    const float *W0, *b0, *W1, *b1, *W2, *b2, *Ws, *bs1, *bs2;
+    float* ll;             // (R)      forward (nullable)
+    float* mean;           // (R, Dy)  forward (nullable)
+    float* var;            // (R, Dy)  forward (nullable)
+    float* dx;             // (R, L)   backward
+    float* part;           // (blocks, PW) backward: per-block partial parameter gradients
+    unsigned R;            // rows
+    unsigned K, S;
+    int L, Dy, U;
+};
+
+struct DecGeo {
+    int oW0, ob0, oW1, ob1, oW2, ob2, oWs, obs1, obs2, PW;
+};
+__host__ __device__ inline DecGeo dec_geo(int L, int U, int Dy) {
+    DecGeo q;
+    q.oW0 = 0;
+    q.ob0 = q.oW0 + L * U;
+    q.oW1 = q.ob0 + U;
+    q.ob1 = q.oW1 + U * U;
+    q.oW2 = q.ob1 + U;
+    q.ob2 = q.oW2 + U * 2 * Dy;
+    q.oWs = q.ob2 + 2 * Dy;
+    q.obs1 = q.oWs + L * Dy;
+    q.obs2 = q.obs1 + Dy;
+    q.PW = q.obs2 + Dy;
+    return q;
+}
+
+// LDS layout (floats).  Operand image entry for MFMA operand `e`, lane l, sub-step v:  (e*64 + l)*4 + v.
+template <int UT>
+struct Img {
+    static constexpr int F0 = 0;                        // [t'][lane][kk<2 (pad 4)]      layer 0
+    static constexpr int F1 = F0 + UT * 256;            // [t'][t][lane][v]               layer 1
+    static constexpr int F2 = F1 + UT * UT * 256;       // [t][lane][v]                   output layer
+    static constexpr int F2S = F2 + UT * 256;           // [lane][kk<2 (pad 4)]           shortcut into the output layer
+    static constexpr int BIAS0 = F2S + 256;             // 16*UT   b0 zero-padded
+    static constexpr int BIAS1 = BIAS0 + 16 * UT;       // 16*UT   b1
+    static constexpr int BIASO = BIAS1 + 16 * UT;       // 16      output bias in slot order
+    static constexpr int SP2 = BIASO + 16;              // 8       log1p(exp(bs2_d))
+    static constexpr int SG2 = SP2 + 8;                 // 8       sigmoid(bs2_d)
+    static constexpr int FWD_END = SG2 + 8;
+    static constexpr int B1 = FWD_END;                  // [t'][lane][v]      dh1 = W2 . dO
+    static constexpr int B2 = B1 + UT * 256;            // [t'][t][lane][v]   dh0 = W1 . dh1pre
+    static constexpr int B3 = B2 + UT * UT * 256;       // [t][lane][v]       dx  = W0 . dh0pre
+    static constexpr int B3S = B3 + UT * 256;           // [lane][v]          dx += Ws . dO(mean slots)
+    static constexpr int BWD_END = B3S + 256;
+    static constexpr int SCR = BWD_END;                 // per wave: UT transpose blocks
+    static constexpr int BWD_TOTAL = SCR + DEC_WAVES * UT * TBLK;
+};
+
+// output slot m (0..15) of the last layer: lane group g = m>>2 owns slots 4g..4g+3 = (mean d0, mean d1, var d0, var d1)
+// with d0 = 2g, d1 = 2g+1 - so that a lane finds mean and variance of the same output dimension in its own registers.
+__device__ __forceinline__ int slot_d(int m) { return 2 * (m >> 2) + (m & 1); }
+__device__ __forceinline__ int slot_ty(int m) { return (m >> 1) & 1; }
+
+__device__ __forceinline__ float softplus_f(float v) { return v > 30.f ? v : log1pf(__expf(v)); }
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+template <int UT, bool BWD>
+__device__ void fill_images(float* __restrict__ sm, const DecArgs& a) {
+    using I = Img<UT>;
+    const int L = a.L, U = a.U, Dy = a.Dy;
+    const int tid = threadIdx.x;
+    // F0: A[i = unit 16t'+c][k = dim 4kk+g] = W0[dim][unit]
+    for (int i = tid; i < UT * 256; i += DEC_THREADS) {
+        const int v = i & 3, l = (i >> 2) & 63, tp = i >> 8, g = l >> 4, c = l & 15;
+        const int dim = 4 * v + g, unit = 16 * tp + c;
+        sm[I::F0 + i] = (v < 2 && dim < L && unit < U) ? a.W0[dim * U + unit] : 0.f;
+    }
+    // F1: A[i = out 16t'+c][k = in 16t+4g+v] = W1[in][out]
+    for (int i = tid; i < UT * UT * 256; i += DEC_THREADS) {
+        const int v = i & 3, l = (i >> 2) & 63, e = i >> 8, t = e % UT, tp = e / UT, g = l >> 4, c = l & 15;
+        const int in = 16 * t + 4 * g + v, out = 16 * tp + c;
+        sm[I::F1 + i] = (in < U && out < U) ? a.W1[in * U + out] : 0.f;
+    }
+    // F2: A[i = slot c][k = in 16t+4g+v] = W2[in][ty*Dy + d]
+    for (int i = tid; i < UT * 256; i += DEC_THREADS) {
+        const int v = i & 3, l = (i >> 2) & 63, t = i >> 8, g = l >> 4, c = l & 15;
+        const int in = 16 * t + 4 * g + v, d = slot_d(c), ty = slot_ty(c);
+        sm[I::F2 + i] = (in < U && d < Dy) ? a.W2[in * 2 * Dy + ty * Dy + d] : 0.f;
+    }
+    // F2S: A[i = slot c][k = dim 4kk+g] = Ws[dim][d] for the mean slots
+    for (int i = tid; i < 256; i += DEC_THREADS) {
+        const int v = i & 3, l = i >> 2, g = l >> 4, c = l & 15;
+        const int dim = 4 * v + g, d = slot_d(c), ty = slot_ty(c);
+        sm[I::F2S + i] = (v < 2 && dim < L && d < Dy && ty == 0) ? a.Ws[dim * Dy + d] : 0.f;
+    }
+    for (int i = tid; i < 16 * UT; i += DEC_THREADS) {
+        sm[I::BIAS0 + i] = i < U ? a.b0[i] : 0.f;
+        sm[I::BIAS1 + i] = i < U ? a.b1[i] : 0.f;
+    }
+    if (tid < 16) {
+        const int d = slot_d(tid), ty = slot_ty(tid);
+        sm[I::BIASO + tid] = d < Dy ? (ty == 0 ? a.b2[d] + a.bs1[d] : a.b2[Dy + d]) : 0.f;
+    }
+    if (tid < 8) {
+        const float b = tid < Dy ? a.bs2[tid] : 0.f;
+        sm[I::SP2 + tid] = log1pf(expf(b));            // the reference's naive form (vae.py:116)
+        sm[I::SG2 + tid] = sigmoid_f(b);
+    }
+    if (BWD) {
+        // B1: A[i = unit 16t'+c][k = slot 4g+v] = W2[unit][o(slot)]
+        for (int i = tid; i < UT * 256; i += DEC_THREADS) {
+            const int v = i & 3, l = (i >> 2) & 63, tp = i >> 8, g = l >> 4, c = l & 15;
+            const int unit = 16 * tp + c, m = 4 * g + v, d = slot_d(m), ty = slot_ty(m);
+            sm[I::B1 + i] = (unit < U && d < Dy) ? a.W2[unit * 2 * Dy + ty * Dy + d] : 0.f;
+        }
+        // B2: A[i = in 16t'+c][k = out 16t+4g+v] = W1[in][out]
+        for (int i = tid; i < UT * UT * 256; i += DEC_THREADS) {
+            const int v = i & 3, l = (i >> 2) & 63, e = i >> 8, t = e % UT, tp = e / UT, g = l >> 4, c = l & 15;
+            const int in = 16 * tp + c, out = 16 * t + 4 * g + v;
+            sm[I::B2 + i] = (in < U && out < U) ? a.W1[in * U + out] : 0.f;
+        }
+        // B3: A[i = dim c][k = unit 16t+4g+v] = W0[dim][unit]
+        for (int i = tid; i < UT * 256; i += DEC_THREADS) {
+            const int v = i & 3, l = (i >> 2) & 63, t = i >> 8, g = l >> 4, c = l & 15;
+            const int unit = 16 * t + 4 * g + v;
+            sm[I::B3 + i] = (c < L && unit < U) ? a.W0[c * U + unit] : 0.f;
+        }
+        // B3S: A[i = dim c][k = slot 4g+v] = Ws[dim][d] for the mean slots
+        for (int i = tid; i < 256; i += DEC_THREADS) {
+            const int v = i & 3, l = i >> 2, g = l >> 4, c = l & 15;
+            const int m = 4 * g + v, d = slot_d(m), ty = slot_ty(m);
+            sm[I::B3S + i] = (c < L && d < Dy && ty == 0) ? a.Ws[c * Dy + d] : 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma4(float av, float bv, f32x4 cv) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, cv, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// forward of one 16-row tile; xb0/xb1 = x[row c][g], x[row c][4+g] (B operand of layer 0)
+template <int UT>
+__device__ __forceinline__ void dec_forward_tile(const float* __restrict__ sm, int lane, float xb0, float xb1,
+                                                 f32x4 (&h0)[UT], f32x4 (&h1)[UT], f32x4& O) {
+    using I = Img<UT>;
+    const int g = lane >> 4;
+#pragma unroll
+    for (int tp = 0; tp < UT; ++tp) {
+        f32x4 acc = lds4(sm + I::BIAS0 + 16 * tp + 4 * g);
+        const f32x4 w = lds4(sm + I::F0 + (tp * 64 + lane) * 4);
+        acc = mfma4(w[0], xb0, acc);
+        acc = mfma4(w[1], xb1, acc);
+        h0[tp] = acc;
+    }
+#pragma unroll
+    for (int tp = 0; tp < UT; ++tp)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) h0[tp][v] = tanhf(h0[tp][v]);
+#pragma unroll
+    for (int tp = 0; tp < UT; ++tp) h1[tp] = lds4(sm + I::BIAS1 + 16 * tp + 4 * g);
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+        f32x4 w[UT];
+#pragma unroll
+        for (int tp = 0; tp < UT; ++tp) w[tp] = lds4(sm + I::F1 + ((tp * UT + t) * 64 + lane) * 4);
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int tp = 0; tp < UT; ++tp) h1[tp] = mfma4(w[tp][v], h0[t][v], h1[tp]);
+    }
+#pragma unroll
+    for (int tp = 0; tp < UT; ++tp)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) h1[tp][v] = tanhf(h1[tp][v]);
+    f32x4 o0 = lds4(sm + I::BIASO + 4 * g), o1 = {0.f, 0.f, 0.f, 0.f};
+    {
+        const f32x4 w = lds4(sm + I::F2S + lane * 4);
+        o0 = mfma4(w[0], xb0, o0);
+        o1 = mfma4(w[1], xb1, o1);
+    }
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+        const f32x4 w = lds4(sm + I::F2 + (t * 64 + lane) * 4);
+        o0 = mfma4(w[0], h1[t][0], o0);
+        o1 = mfma4(w[1], h1[t][1], o1);
+        o0 = mfma4(w[2], h1[t][2], o0);
+        o1 = mfma4(w[3], h1[t][3], o1);
+    }
+    O = o0 + o1;
+}
+
+template <int UT>
+__global__ __launch_bounds__(DEC_THREADS) void dec_fwd_kernel(DecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    using I = Img<UT>;
+    fill_images<UT, false>(sm, a);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+    const unsigned ntiles = (a.R + 15u) / 16u;
+    const unsigned nwaves = gridDim.x * DEC_WAVES;
+    const int L = a.L, Dy = a.Dy;
+    for (unsigned tile = blockIdx.x * DEC_WAVES + wave; tile < ntiles; tile += nwaves) {
+        const unsigned row = tile * 16u + c;
+        const bool ok = row < a.R;
+        const unsigned rr = ok ? row : a.R - 1u;
+        const float* __restrict__ xr = a.x + (size_t)rr * L;
+        const float xb0 = g < L ? xr[g] : 0.f;
+        const float xb1 = 4 + g < L ? xr[4 + g] : 0.f;
+        f32x4 h0[UT], h1[UT], O;
+        dec_forward_tile<UT>(sm, lane, xb0, xb1, h0, h1, O);
+        const unsigned cell = rr / a.S, n = cell / a.K;
+        float acc = 0.f;
+        float mu[2], vr[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int d = 2 * g + j;
+            const bool dv = d < Dy;
+            mu[j] = O[j];
+            vr[j] = softplus_f(O[2 + j]) + sm[I::SP2 + (d & 7)];
+            const float yv = (dv && a.ll) ? a.y[(size_t)n * Dy + d] : 0.f;
+            const float df = yv - mu[j];
+            const float term = df * df / vr[j] + logf(vr[j] + 1e-8f);
+            acc += dv ? term : 0.f;
+        }
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+        if (ok && g == 0 && a.ll) a.ll[row] = acc;
+        if (ok && a.mean) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int d = 2 * g + j;
+                if (d < Dy) {
+                    a.mean[(size_t)row * Dy + d] = mu[j];
+                    a.var[(size_t)row * Dy + d] = vr[j];
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// (unit 4g+v, row c) accumulator block  ->  operand form: lane (g,c) gets block[unit c][rows 4g..4g+3]
+__device__ __forceinline__ void tr_write(float* __restrict__ T, int g, int c, f32x4 z) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) T[(4 * g + v) * TS + c] = z[v];
+}
+__device__ __forceinline__ f32x4 tr_read(const float* __restrict__ T, int g, int c) { return lds4(T + c * TS + 4 * g); }
+
+template <int UT>
+__device__ __forceinline__ void transpose_set(float* __restrict__ scr, int g, int c, const f32x4 (&in)[UT], f32x4 (&out)[UT]) {
+    wave_lds_sync();                                    // previous readers of the scratch are done
+#pragma unroll
+    for (int t = 0; t < UT; ++t) tr_write(scr + t * TBLK, g, c, in[t]);
+    wave_lds_sync();
+#pragma unroll
+    for (int t = 0; t < UT; ++t) out[t] = tr_read(scr + t * TBLK, g, c);
+}
+
+template <int UT>
+__global__ __launch_bounds__(DEC_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    using I = Img<UT>;
+    fill_images<UT, true>(sm, a);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+    float* __restrict__ scr = sm + I::SCR + wave * UT * TBLK;
+    const unsigned ntiles = (a.R + 15u) / 16u;
+    const unsigned nwaves = gridDim.x * DEC_WAVES;
+    const int L = a.L, Dy = a.Dy, U = a.U;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 aW1[UT][UT], aW2[UT], aWs, aW0[UT], ab0[UT], ab1[UT];
+    float abm[2] = {0.f, 0.f}, abv[2] = {0.f, 0.f}, abs2[2] = {0.f, 0.f};
+    aWs = zero4;
+#pragma unroll
+    for (int i = 0; i < UT; ++i) {
+        aW2[i] = zero4; aW0[i] = zero4; ab0[i] = zero4; ab1[i] = zero4;
+#pragma unroll
+        for (int j = 0; j < UT; ++j) aW1[i][j] = zero4;
+    }
+
+    for (unsigned tile = blockIdx.x * DEC_WAVES + wave; tile < ntiles; tile += nwaves) {
+        const unsigned row = tile * 16u + c;
+        const bool ok = row < a.R;
+        const unsigned rr = ok ? row : a.R - 1u;
+        const float* __restrict__ xr = a.x + (size_t)rr * L;
+        const float xb0 = g < L ? xr[g] : 0.f;
+        const float xb1 = 4 + g < L ? xr[4 + g] : 0.f;
+        // x in operand form for the weight gradients: lane (g,c) <- x[row 4g+kk][dim c]
+        f32x4 xT;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const unsigned r2 = tile * 16u + 4u * g + kk;
+            xT[kk] = (r2 < a.R && c < L) ? a.x[(size_t)r2 * L + c] : 0.f;
+        }
+        f32x4 h0[UT], h1[UT], O;
+        dec_forward_tile<UT>(sm, lane, xb0, xb1, h0, h1, O);
+
+        // ---- reconstruction term: gradients w.r.t. the output slots
+        const unsigned cell = rr / a.S, n = cell / a.K;
+        const float ga = ok ? a.gA[cell] : 0.f;
+        f32x4 dO;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int d = 2 * g + j;
+            const bool dv = d < Dy;
+            const float raw2 = O[2 + j];
+            const float vr = softplus_f(raw2) + sm[I::SP2 + (d & 7)];
+            const float yv = dv ? a.y[(size_t)n * Dy + d] : 0.f;
+            const float df = yv - O[j], iv = 1.0f / vr;
+            const float gm = dv ? ga * (-2.f * df * iv) : 0.f;
+            const float gv = dv ? ga * (1.0f / (vr + 1e-8f) - df * df * iv * iv) : 0.f;
+            const float gr = gv * sigmoid_f(raw2);
+            dO[j] = gm;
+            dO[2 + j] = gr;
+            abm[j] += gm;
+            abv[j] += gr;
+            abs2[j] += gv;
+        }
+
+        // ---- dW2 (and shortcut W): [h1 ; x]^T . dO
+        {
+            f32x4 h1T[UT], dOT;
+            transpose_set<UT>(scr, g, c, h1, h1T);
+            wave_lds_sync();
+            tr_write(scr, g, c, dO);
+            wave_lds_sync();
+            dOT = tr_read(scr, g, c);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int t = 0; t < UT; ++t) aW2[t] = mfma4(h1T[t][kk], dOT[kk], aW2[t]);
+                aWs = mfma4(xT[kk], dOT[kk], aWs);
+            }
+        }
+        // ---- dh1 = W2 . dO, through tanh
+        f32x4 dh1[UT];
+#pragma unroll
+        for (int tp = 0; tp < UT; ++tp) {
+            const f32x4 w = lds4(sm + I::B1 + (tp * 64 + lane) * 4);
+            f32x4 acc = zero4;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc = mfma4(w[v], dO[v], acc);
+            dh1[tp] = acc;
+        }
+#pragma unroll
+        for (int tp = 0; tp < UT; ++tp) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) dh1[tp][v] *= 1.0f - h1[tp][v] * h1[tp][v];
+            ab1[tp] += dh1[tp];
+        }
+        // ---- dW1 = h0^T . dh1pre
+        {
+            f32x4 h0T[UT], dT[UT];
+            transpose_set<UT>(scr, g, c, h0, h0T);
+            transpose_set<UT>(scr, g, c, dh1, dT);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int ti = 0; ti < UT; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < UT; ++tj) aW1[ti][tj] = mfma4(h0T[ti][kk], dT[tj][kk], aW1[ti][tj]);
+        }
+        // ---- dh0 = W1 . dh1pre, through tanh
+        f32x4 dh0[UT];
+#pragma unroll
+        for (int tp = 0; tp < UT; ++tp) dh0[tp] = zero4;
+#pragma unroll
+        for (int t = 0; t < UT; ++t) {
+            f32x4 w[UT];
+#pragma unroll
+            for (int tp = 0; tp < UT; ++tp) w[tp] = lds4(sm + I::B2 + ((tp * UT + t) * 64 + lane) * 4);
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int tp = 0; tp < UT; ++tp) dh0[tp] = mfma4(w[tp][v], dh1[t][v], dh0[tp]);
+        }
+#pragma unroll
+        for (int tp = 0; tp < UT; ++tp) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) dh0[tp][v] *= 1.0f - h0[tp][v] * h0[tp][v];
+            ab0[tp] += dh0[tp];
+        }
+        // ---- dW0 = x^T . dh0pre
+        {
+            f32x4 dT[UT];
+            transpose_set<UT>(scr, g, c, dh0, dT);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int tj = 0; tj < UT; ++tj) aW0[tj] = mfma4(xT[kk], dT[tj][kk], aW0[tj]);
+        }
+        // ---- dx = W0 . dh0pre + Ws . dO(mean)
+        {
+            f32x4 d0 = zero4, d1 = zero4;
+            const f32x4 ws = lds4(sm + I::B3S + lane * 4);
+            d0 = mfma4(ws[0], dO[0], d0);
+            d1 = mfma4(ws[1], dO[1], d1);
+            d0 = mfma4(ws[2], dO[2], d0);
+            d1 = mfma4(ws[3], dO[3], d1);
+#pragma unroll
+            for (int t = 0; t < UT; ++t) {
+                const f32x4 w = lds4(sm + I::B3 + (t * 64 + lane) * 4);
+                d0 = mfma4(w[0], dh0[t][0], d0);
+                d1 = mfma4(w[1], dh0[t][1], d1);
+                d0 = mfma4(w[2], dh0[t][2], d0);
+                d1 = mfma4(w[3], dh0[t][3], d1);
+            }
+            const f32x4 dxv = d0 + d1;                   // [dim 4g+v][row c]
+            if (ok) {
+                if (L == 8) {
+                    if (g < 2) *reinterpret_cast<f32x4*>(a.dx + (size_t)row * 8 + 4 * g) = dxv;
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (4 * g + v < L) a.dx[(size_t)row * L + 4 * g + v] = dxv[v];
+                }
+            }
+        }
+    }
+
+    // ---- reduce the per-wave accumulators: waves of the block in a fixed order through LDS
+    const DecGeo q = dec_geo(L, U, Dy);
+    __syncthreads();                                    // everybody is done with the operand images
+    float* __restrict__ accum = sm;
+    for (int w = 0; w < DEC_WAVES; ++w) {
+        if (wave == w) {
+            if (w == 0) for (int i = lane; i < q.PW; i += WAVE) accum[i] = 0.f;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ti = 0; ti < UT; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < UT; ++tj)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int in = 16 * ti + 4 * g + v, out = 16 * tj + c;
+                        if (in < U && out < U) accum[q.oW1 + in * U + out] += aW1[ti][tj][v];
+                    }
+#pragma unroll
+            for (int t = 0; t < UT; ++t)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int unit = 16 * t + 4 * g + v, d = slot_d(c), ty = slot_ty(c);
+                    if (unit < U && d < Dy) accum[q.oW2 + unit * 2 * Dy + ty * Dy + d] += aW2[t][v];
+                    const int dim = 4 * g + v, u2 = 16 * t + c;
+                    if (dim < L && u2 < U) accum[q.oW0 + dim * U + u2] += aW0[t][v];
+                }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int dim = 4 * g + v, d = slot_d(c), ty = slot_ty(c);
+                if (dim < L && d < Dy && ty == 0) accum[q.oWs + dim * Dy + d] += aWs[v];
+            }
+            // biases: sum over the 16 rows (lanes c of a DPP row), lane c == 0 adds
+#pragma unroll
+            for (int t = 0; t < UT; ++t)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float s0 = row16_sum(ab0[t][v]), s1 = row16_sum(ab1[t][v]);
+                    const int unit = 16 * t + 4 * g + v;
+                    if (c == 0 && unit < U) {
+                        accum[q.ob0 + unit] += s0;
+                        accum[q.ob1 + unit] += s1;
+                    }
+                }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float sm_ = row16_sum(abm[j]), sv_ = row16_sum(abv[j]), s2_ = row16_sum(abs2[j]);
+                const int d = 2 * g + j;
+                if (c == 0 && d < Dy) {
+                    accum[q.ob2 + d] += sm_;
+                    accum[q.ob2 + Dy + d] += sv_;
+                    accum[q.obs1 + d] += sm_;
+                    accum[q.obs2 + d] += s2_;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // sigmoid(bs2) factor of d/d bs2 log1p(exp(bs2)) is applied by the reduce kernel
+    for (int i = threadIdx.x; i < q.PW; i += DEC_THREADS) a.part[(size_t)blockIdx.x * q.PW + i] = accum[i];
+}
+
+struct DecRedArgs {
+    const float* part;
+    const float* bs2;
+    float* out;
+    int blocks, PW, obs2, Dy;
+};
+__global__ __launch_bounds__(256) void dec_reduce_kernel(DecRedArgs r) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= r.PW) return;
+    double s = 0.0;
+    for (int b = 0; b < r.blocks; ++b) s += (double)r.part[(size_t)b * r.PW + i];
+    if (i >= r.obs2) s *= 1.0 / (1.0 + exp(-(double)r.bs2[i - r.obs2]));
+    r.out[i] = (float)s;
+}
+
+int dec_blocks(long long rows) {
+    const long long tiles = (rows + 15) / 16;
+    long long b = (tiles + DEC_WAVES - 1) / DEC_WAVES;
+    if (b > 512) b = 512;                               // 2 resident blocks on each of the 256 CUs
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+int dec_check(const char* what, long long N, int K, int S, int L, int Dy, int U) {
+    if (N < 0 || K < 1 || S < 1 || L < 1 || L > 8 || Dy < 1 || Dy > 8 || U < 1 || U > 64) {
+        set_error("%s: unsupported sizes N=%lld K=%d S=%d L=%d Dy=%d U=%d (L, Dy <= 8, U <= 64)", what, N, K, S, L, Dy, U);
+        return VMP_E_DIM;
+    }
+    if ((double)N * K * S >= 2147483648.0) {
+        set_error("%s: N*K*S = %.0f rows exceed 2^31 - split the batch", what, (double)N * K * S);
+        return VMP_E_DIM;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vmp_decoder_param_words(int L, int U, int Dy) { return dec_geo(L, U, Dy).PW; }
+
+size_t vmp_decoder_workspace_bytes(int64_t N, int K, int S, int L, int U, int Dy) {
+    return (size_t)dec_blocks((long long)N * K * S) * (size_t)dec_geo(L, U, Dy).PW * sizeof(float);
+}
+
+int vmp_decoder_loglike_fwd(const float* x, const float* y, const float* W0, const float* b0, const float* W1,
+                            const float* b1, const float* W2, const float* b2, const float* Ws, const float* bs1,
+                            const float* bs2, int64_t N, int K, int S, int L, int Dy, int U, float* ll, float* mean,
+                            float* var, void* stream) {
+    if (int e = dec_check("vmp_decoder_loglike_fwd", N, K, S, L, Dy, U)) return e;
+    if (!x || (!y && ll) || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !Ws || !bs1 || !bs2 || (!ll && !mean) || (!mean != !var)) {
+        set_error("vmp_decoder_loglike_fwd: NULL argument");
+        return VMP_E_BADARG;
+    }
+    if (N == 0) return 0;
+    DecArgs a{};
+    a.x = x; a.y = y; a.W0 = W0; a.b0 = b0; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Ws = Ws; a.bs1 = bs1; a.bs2 = bs2;
+    a.ll = ll; a.mean = mean; a.var = var;
+    a.R = (unsigned)(N * K * S); a.K = (unsigned)K; a.S = (unsigned)S; a.L = L; a.Dy = Dy; a.U = U;
+    const int blocks = dec_blocks((long long)a.R);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define DEC_FWD(UTV)                                                                                                  \
+    do {                                                                                                              \
+        const int lds = Img<UTV>::FWD_END * (int)sizeof(float);                                                       \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fwd_kernel<UTV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((dec_fwd_kernel<UTV>), dim3(blocks), dim3(DEC_THREADS), lds, s, a);                       \
+    } while (0)
+    switch ((U + 15) / 16) {
+        case 1: DEC_FWD(1); break;
+        case 2: DEC_FWD(2); break;
+        case 3: DEC_FWD(3); break;
+        default: DEC_FWD(4); break;
+    }
+#undef DEC_FWD
+    return check_launch("vmp_decoder_loglike_fwd");
+}
+
+int vmp_decoder_loglike_bwd(const float* x, const float* y, const float* gA, const float* W0, const float* b0,
+                            const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws,
+                            const float* bs1, const float* bs2, int64_t N, int K, int S, int L, int Dy, int U, float* dx,
+                            float* dparams, void* ws, size_t ws_bytes, void* stream) {
+    if (int e = dec_check("vmp_decoder_loglike_bwd", N, K, S, L, Dy, U)) return e;
+    if (!x || !y || !gA || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !Ws || !bs1 || !bs2 || !dx || !dparams || !ws) {
+        set_error("vmp_decoder_loglike_bwd: NULL argument");
+        return VMP_E_BADARG;
+    }
+    const DecGeo q = dec_geo(L, U, Dy);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (N == 0) {
+        (void)hipMemsetAsync(dparams, 0, (size_t)q.PW * sizeof(float), s);
+        return check_launch("vmp_decoder_loglike_bwd");
+    }
+    if (ws_bytes < vmp_decoder_workspace_bytes(N, K, S, L, U, Dy)) {
+        set_error("vmp_decoder_loglike_bwd: workspace too small (%zu < %zu bytes)", ws_bytes,
+                  vmp_decoder_workspace_bytes(N, K, S, L, U, Dy));
+        return VMP_E_WS;
+    }
+    DecArgs a{};
+    a.x = x; a.y = y; a.gA = gA; a.W0 = W0; a.b0 = b0; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Ws = Ws; a.bs1 = bs1; a.bs2 = bs2;
+    a.dx = dx; a.part = static_cast<float*>(ws);
+    a.R = (unsigned)(N * K * S); a.K = (unsigned)K; a.S = (unsigned)S; a.L = L; a.Dy = Dy; a.U = U;
+    const int blocks = dec_blocks((long long)a.R);
+#define DEC_BWD(UTV)                                                                                                  \
+    do {                                                                                                              \
+        const int lds = Img<UTV>::BWD_TOTAL * (int)sizeof(float);                                                     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<UTV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((dec_bwd_kernel<UTV>), dim3(blocks), dim3(DEC_THREADS), lds, s, a);                       \
+    } while (0)
+    switch ((U + 15) / 16) {
+        case 1: DEC_BWD(1); break;
+        case 2: DEC_BWD(2); break;
+        case 3: DEC_BWD(3); break;
+        default: DEC_BWD(4); break;
+    }
+#undef DEC_BWD
+    if (int e = check_launch("vmp_decoder_loglike_bwd")) return e;
+    DecRedArgs r{a.part, bs2, dparams, blocks, q.PW, q.obs2, Dy};
+    hipLaunchKernelGGL(dec_reduce_kernel, dim3((q.PW + 255) / 256), dim3(256), 0, s, r);
+    return check_launch("vmp_decoder_loglike_bwd(reduce)");
+}
+
+}  // extern "C"

@@ -163,3 +163,81 @@ def student_t_logprob(y, mu, sigma, v):
                                           L.ptr(cst.float().contiguous()), L.ptr(_c(v.detach().float(), 'v')), N, K, S, D,
                                           L.ptr(out), L.stream()), 'vmp_student_t_logprob')
     return out
+
+
+DECODER_PARAM_NAMES = ('layer_0/kernel', 'layer_0/bias', 'layer_1/kernel', 'layer_1/bias', 'gaussian_output/kernel',
+                       'gaussian_output/bias', 'shortcut/W', 'shortcut/b1', 'shortcut/b2')
+
+
+def _decoder_dims(x, params):
+    W0, b0, W1, b1, W2, b2, Ws, bs1, bs2 = params
+    Ld, U = W0.shape
+    Dy = Ws.shape[1]
+    shapes = ((Ld, U), (U,), (U, U), (U,), (U, 2 * Dy), (2 * Dy,), (Ld, Dy), (Dy,), (Dy,))
+    for n, p, s in zip(DECODER_PARAM_NAMES, params, shapes):
+        if tuple(p.shape) != s:
+            raise AssertionError('decoder parameter %s has shape %s, expected %s' % (n, tuple(p.shape), s))
+    if x.shape[-1] != Ld:
+        raise AssertionError('decoder input has %d features, layer_0/kernel expects %d' % (x.shape[-1], Ld))
+    return Ld, U, Dy
+
+
+def fused_decoder_supported(Ld, U, Dy):
+    """Compiled range of the fused MFMA decoder kernels (csrc/vmp_decoder.hip)."""
+    return 1 <= Ld <= 8 and 1 <= Dy <= 8 and 1 <= U <= 64
+
+
+class DecoderLoglikeFn(torch.autograd.Function):
+    """(y (N,Dy), x (N,K,S,L), 9 decoder parameters) -> A (N,K) = sum_{s,d} (y - mean)^2 / var + log(var + 1e-8) with
+    (mean, var) = decoder(x) (reference vae.py:75-128 + :233-248), one fused HIP kernel each way: the
+    (N,K,S,U) activations and (N,K,S,Dy) outputs never reach memory.  Gradients to x and the 9 parameters."""
+
+    @staticmethod
+    def forward(ctx, y, x, *params):
+        x = _c(x, 'x_k_samples')
+        if x.dim() != 4:
+            raise L.VmpError('x must have shape (N,K,S,L)')
+        N, K, S, _ = x.shape
+        params = [_c(p, n) for p, n in zip(params, DECODER_PARAM_NAMES)]
+        Ld, U, Dy = _decoder_dims(x, params)
+        y = _c(y, 'y', (N, Dy))
+        ll = torch.empty(N, K, S, dtype=torch.float32, device=x.device)
+        L.check(L.lib().vmp_decoder_loglike_fwd(L.ptr(x), L.ptr(y), *[L.ptr(p) for p in params], N, K, S, Ld, Dy, U,
+                                                L.ptr(ll), None, None, L.stream()), 'vmp_decoder_loglike_fwd')
+        ctx.save_for_backward(y, x, *params)
+        ctx.dims = (N, K, S, Ld, Dy, U)
+        return ll.sum(-1)
+
+    @staticmethod
+    def backward(ctx, gA):
+        sv = ctx.saved_tensors
+        y, x, params = sv[0], sv[1], sv[2:]
+        N, K, S, Ld, Dy, U = ctx.dims
+        gA = gA.contiguous().float()
+        dx = torch.empty_like(x)
+        PW = L.lib().vmp_decoder_param_words(Ld, U, Dy)
+        dp = torch.empty(PW, dtype=torch.float32, device=x.device)
+        nbytes = L.lib().vmp_decoder_workspace_bytes(N, K, S, Ld, U, Dy)
+        ws = L.workspace(x.device, nbytes)
+        L.check(L.lib().vmp_decoder_loglike_bwd(L.ptr(x), L.ptr(y), L.ptr(gA), *[L.ptr(p) for p in params], N, K, S, Ld, Dy,
+                                                U, L.ptr(dx), L.ptr(dp), L.ptr(ws), nbytes, L.stream()),
+                'vmp_decoder_loglike_bwd')
+        grads, o = [], 0
+        for p in params:
+            grads.append(dp[o:o + p.numel()].reshape(p.shape))
+            o += p.numel()
+        return (None, dx) + tuple(grads)
+
+
+def decoder_outputs(x, params):
+    """(mean, var) of the decoder on x (..., L) through the fused forward kernel (no gradient)."""
+    shape = tuple(x.shape)
+    x2 = _c(x.detach().reshape(-1, 1, 1, shape[-1]), 'x')
+    params = [_c(p.detach(), n) for p, n in zip(params, DECODER_PARAM_NAMES)]
+    Ld, U, Dy = _decoder_dims(x2, params)
+    R = x2.shape[0]
+    mean = torch.empty(R, Dy, dtype=torch.float32, device=x2.device)
+    var = torch.empty(R, Dy, dtype=torch.float32, device=x2.device)
+    L.check(L.lib().vmp_decoder_loglike_fwd(L.ptr(x2), None, *[L.ptr(p) for p in params], R, 1, 1, Ld, Dy, U, None,
+                                            L.ptr(mean), L.ptr(var), L.stream()), 'vmp_decoder_loglike_fwd')
+    return mean.reshape(shape[:-1] + (Dy,)), var.reshape(shape[:-1] + (Dy,))

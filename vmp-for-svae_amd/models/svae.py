@@ -201,8 +201,11 @@ def compute_elbo(y, reconstructions, theta, phi_tilde, x_k_samps, log_z_given_y_
         raise L.VmpError('compute_elbo needs the per-cell terms of the fused E-step: call e_step / inference with '
                          'theta=<the same theta> (the stand-alone per-sample density kernels are not built yet)')
     r_nk = torch.exp(log_z_given_y_phi)
-    means, out_2 = reconstructions
-    rec = vae.expected_diagonal_gaussian_loglike(y, means, out_2, weights=r_nk)
+    if isinstance(reconstructions, vae.LazyReconstruction):     # fused decoder + reconstruction term
+        rec = vae.expected_diagonal_gaussian_loglike(y, reconstructions, None, weights=r_nk)
+    else:
+        means, out_2 = reconstructions
+        rec = vae.expected_diagonal_gaussian_loglike(y, means, out_2, weights=r_nk)
     Tp = phi_tilde.T_prime
     reg = (r_nk * (Tp + log_z_given_y_phi)).sum()
     elbo = rec - reg
@@ -275,12 +278,13 @@ def init_recognition_params(theta, nb_components, seed=0, param_device='cuda', v
 
 
 def inference(y, phi_gmm, encoder_layers, decoder_layers, nb_samples=10, stddev_init_nn=0.01, seed=0, name='inference',
-              param_device='cuda', noise=None, z_draws=None, theta=None):
+              param_device='cuda', noise=None, z_draws=None, theta=None, lazy_decoder=False):
     """reference svae.py:499-516.  Returns (y_reconstruction, x_given_y_phi, x_k_samples, x_samples, log_z, phi_gmm,
-    phi_tilde)."""
+    phi_tilde).  lazy_decoder=True: y_reconstruction is a vae.LazyReconstruction (fused decoder kernels)."""
     x_given_y_phi = vae.make_encoder(y, layerspecs=encoder_layers, stddev_init=stddev_init_nn, seed=seed)
     x_k_samples, log_z, phi_tilde, _ = e_step(x_given_y_phi, phi_gmm, nb_samples, seed=seed, noise=noise, theta=theta)
-    y_rec = vae.make_decoder(x_k_samples, layerspecs=decoder_layers, stddev_init=stddev_init_nn, seed=seed)
+    y_rec = vae.make_decoder(x_k_samples, layerspecs=decoder_layers, stddev_init=stddev_init_nn, seed=seed,
+                             lazy=lazy_decoder)
     x_samples = subsample_x(x_k_samples, log_z, seed, z_draws=z_draws, nb_out=1)[:, 0, :]
     return y_rec, x_given_y_phi, x_k_samples, x_samples, log_z, phi_gmm, phi_tilde
 

@@ -38,22 +38,34 @@ def rand_partial_isometry(m, n, stddev, seed=0):
     return np.linalg.qr(g)[0][:m, :n]
 
 
-def make_layer(inputs, units, stddev=1, activation=torch.tanh, name='layer', param_device=None, seed=0, scope=''):
-    """reference vae.py:17-25 (tf.layers.dense with N(0, stddev) kernel and bias)."""
-    dev = inputs.device
+def _layer_variables(in_dim, units, stddev, name, seed, scope, dev):
+    """kernel / bias of one tf.layers.dense (reference vae.py:17-25: N(0, stddev) kernel and bias)."""
     full = scope + '/' + name
 
     def init(shape):
         g = torch.Generator(device='cpu').manual_seed(int(seed))
         return lambda: (torch.randn(shape, generator=g) * stddev).to(dev)
-    w = _get_variable(full + '/kernel', init((inputs.shape[-1], units)))
-    b = _get_variable(full + '/bias', init((units,)))
+    return _get_variable(full + '/kernel', init((in_dim, units))), _get_variable(full + '/bias', init((units,)))
+
+
+def make_layer(inputs, units, stddev=1, activation=torch.tanh, name='layer', param_device=None, seed=0, scope=''):
+    """reference vae.py:17-25 (tf.layers.dense with N(0, stddev) kernel and bias)."""
+    w, b = _layer_variables(inputs.shape[-1], units, stddev, name, seed, scope, inputs.device)
     out = torch.addmm(b, inputs, w)
     return activation(out) if activation is not None else out
 
 
 def _softplus(x):
     return torch.nn.functional.softplus(x, beta=1.0, threshold=30.0)
+
+
+def _shortcut_variables(in_dim, out_dim, name, seed, dev):
+    """reference vae.py:97-116: W = partial isometry (vae.py:58-72), b1 = b2 = 0."""
+    W = _get_variable(name + '/shortcut/W', lambda: torch.as_tensor(rand_partial_isometry(in_dim, out_dim, 1., seed),
+                                                                    dtype=torch.float32).to(dev))
+    b1 = _get_variable(name + '/shortcut/b1', lambda: torch.zeros(out_dim, device=dev))
+    b2 = _get_variable(name + '/shortcut/b2', lambda: torch.zeros(out_dim, device=dev))
+    return W, b1, b2
 
 
 def make_nnet(input, layerspecs, stddev, name, param_device=None, seed=0):
@@ -75,11 +87,7 @@ def make_nnet(input, layerspecs, stddev, name, param_device=None, seed=0):
         o1, o2, a = raw1, -0.5 * _softplus(raw2), -0.5
     else:
         raise Exception("Type '%s' does not exist." % typ)
-    dev = input.device
-    W = _get_variable(name + '/shortcut/W', lambda: torch.as_tensor(rand_partial_isometry(shape[-1], out_dim, 1., seed),
-                                                                    dtype=torch.float32).to(dev))
-    b1 = _get_variable(name + '/shortcut/b1', lambda: torch.zeros(out_dim, device=dev))
-    b2 = _get_variable(name + '/shortcut/b2', lambda: torch.zeros(out_dim, device=dev))
+    W, b1, b2 = _shortcut_variables(shape[-1], out_dim, name, seed, input.device)
     res1 = torch.addmm(b1, x2, W)
     res2 = a * torch.log1p(torch.exp(b2))
     oshape = shape[:-1] + (out_dim,)
@@ -93,10 +101,70 @@ def make_encoder(input, layerspecs=None, stddev_init=1., param_device=None, seed
     return make_nnet(input, layerspecs, stddev_init, 'encoder_net', param_device, seed)
 
 
-def make_decoder(input, layerspecs=None, stddev_init=1., param_device=None, seed=0):
-    """reference vae.py:138-151."""
+def fused_decoder_eligible(in_dim, layerspecs):
+    """The fused MFMA decoder (csrc/vmp_decoder.hip) covers the decoder the SVAE driver builds
+    (experiments.py:140): two tanh layers of equal width U <= 64, 'standard' Gaussian head, L, Dy <= 8."""
+    if len(layerspecs) != 3 or layerspecs[-1][1] != 'standard':
+        return False
+    (u0, a0), (u1, a1), (dy, _) = layerspecs
+    return (a0 is torch.tanh and a1 is torch.tanh and u0 == u1
+            and _svae_ops.fused_decoder_supported(in_dim, u0, dy))
+
+
+def decoder_variables(in_dim, layerspecs, stddev_init=1., seed=0, device='cuda', name='decoder_net'):
+    """The 9 decoder variables in the reference's order, created (as make_nnet would) if they do not exist yet."""
+    ps = []
+    d = in_dim
+    for i, (units, _) in enumerate(layerspecs[:-1]):
+        ps += list(_layer_variables(d, units, stddev_init, 'layer_%d' % i, seed, name, device))
+        d = units
+    out_dim = layerspecs[-1][0]
+    ps += list(_layer_variables(d, 2 * out_dim, stddev_init, 'gaussian_output', seed, name, device))
+    ps += list(_shortcut_variables(in_dim, out_dim, name, seed, device))
+    return ps
+
+
+class LazyReconstruction(object):
+    """Deferred decoder output for the training step: stands where the reference has y_reconstruction =
+    (means, vars) of shape (N,K,S,Dy) (svae.py:511-512) but keeps only the decoder INPUT.  compute_elbo turns it
+    into the reconstruction term with the fused decoder+log-likelihood kernels; iterating / indexing it
+    materialises (means, vars) through the fused forward kernel (no gradient)."""
+
+    def __init__(self, x_k_samples, params):
+        self.x = x_k_samples
+        self.params = list(params)
+        self._out = None
+
+    def loglike_cells(self, y):
+        """A (N,K) = sum_{s,d} (y - mean)^2 / var + log(var + 1e-8), differentiable w.r.t. x and the parameters."""
+        return _svae_ops.DecoderLoglikeFn.apply(y, self.x, *self.params)
+
+    def materialize(self):
+        if self._out is None:
+            self._out = _svae_ops.decoder_outputs(self.x, self.params)
+        return self._out
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    def __getitem__(self, i):
+        return self.materialize()[i]
+
+    def __len__(self):
+        return 2
+
+
+def make_decoder(input, layerspecs=None, stddev_init=1., param_device=None, seed=0, lazy=False):
+    """reference vae.py:138-151.  lazy=True (training step) returns a LazyReconstruction when the fused decoder
+    kernels cover the layerspecs; without gradients the fused forward kernel produces (means, vars) directly."""
     if layerspecs is None:
         layerspecs = [(100, torch.tanh), (100, torch.tanh), (784, 'standard')]
+    if input.is_cuda and fused_decoder_eligible(input.shape[-1], layerspecs):
+        if lazy and input.dim() == 4:
+            return LazyReconstruction(input, decoder_variables(input.shape[-1], layerspecs, stddev_init, seed, input.device))
+        if not torch.is_grad_enabled():
+            ps = decoder_variables(input.shape[-1], layerspecs, stddev_init, seed, input.device)
+            return _svae_ops.decoder_outputs(input, ps)
     return make_nnet(input, layerspecs, stddev_init, 'decoder_net', param_device, seed)
 
 
@@ -109,9 +177,16 @@ def expected_diagonal_gaussian_loglike(y, means, vars, weights=None, name='diag_
         A = _svae_ops.DiagGaussLoglikeFn.apply(y, means.unsqueeze(1), (vars - 1e-8).unsqueeze(1)) \
             if False else None
         raise NotImplementedError('plain-VAE branch (weights=None): SURVEY 8f rank 4')
-    M, K, S, Ld = means.shape
-    if tuple(vars.shape) != tuple(means.shape) or tuple(weights.shape) != (M, K):
-        raise AssertionError('shape mismatch')
-    A = _svae_ops.DiagGaussLoglikeFn.apply(y, means, vars)
+    if isinstance(means, LazyReconstruction):
+        M, K, S, _ = means.x.shape
+        Ld = y.shape[1]
+        if tuple(weights.shape) != (M, K):
+            raise AssertionError('shape mismatch')
+        A = means.loglike_cells(y)
+    else:
+        M, K, S, Ld = means.shape
+        if tuple(vars.shape) != tuple(means.shape) or tuple(weights.shape) != (M, K):
+            raise AssertionError('shape mismatch')
+        A = _svae_ops.DiagGaussLoglikeFn.apply(y, means, vars)
     sample_mean = (A * weights).sum() / S
     return -0.5 * sample_mean - M * Ld / 2. * float(np.log(2. * np.pi))

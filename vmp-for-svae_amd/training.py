@@ -70,7 +70,7 @@ def unpack_after_allreduce(buf, stats_shape, grad_shapes, n_scalars):
 
 class SVAETrainer(object):
     def __init__(self, K, Ld, U, Dy, nb_samples=10, lr=3e-4, lrcvi=0.2, decay_rate=0.95, stddev_init_nn=0.01, seed=0,
-                 device='cuda', m_uniform=None, pi_normal=None, group=None, smm=False, dof=5.0):
+                 device='cuda', m_uniform=None, pi_normal=None, group=None, smm=False, dof=5.0, fused_decoder=True):
         self.K, self.L, self.S = K, Ld, nb_samples
         self.lr, self.lrcvi0, self.decay_rate = lr, lrcvi, decay_rate
         self.group = group
@@ -81,6 +81,7 @@ class SVAETrainer(object):
         self.stddev_init_nn = stddev_init_nn
         self.seed = seed
         self.smm = smm
+        self.fused_decoder = fused_decoder      # decoder + reconstruction term in the fused MFMA kernels when covered
         self.gmm_prior, self.theta = svae.init_mm(K, Ld, seed=seed, param_device=self.device, m_uniform=m_uniform)
         self.phi_gmm = list(svae.init_recognition_params(self.theta, K, seed=seed, param_device=self.device,
                                                          pi_normal=pi_normal))
@@ -110,7 +111,7 @@ class SVAETrainer(object):
     def forward(self, y, noise=None, z_draws=None):
         out = svae.inference(y, self.phi_gmm, self.encoder_layers, self.decoder_layers, self.S,
                              stddev_init_nn=self.stddev_init_nn, seed=self.seed + self.global_step, noise=noise,
-                             z_draws=z_draws, theta=self.theta)
+                             z_draws=z_draws, theta=self.theta, lazy_decoder=self.fused_decoder)
         y_rec, phi_enc, x_k, x_s, log_z, _, phi_tilde = out
         elbo_fn = svae.compute_elbo_smm if self.smm else svae.compute_elbo
         elbo, details = elbo_fn(y, y_rec, self.theta, phi_tilde, x_k, log_z, 'standard')
