@@ -26,8 +26,9 @@ using namespace vmp;
 
 namespace {
 
-constexpr int DEC_THREADS = 256;
-constexpr int DEC_WAVES = DEC_THREADS / WAVE;
+constexpr int FWD_THREADS = 256;       // forward: 2 blocks per CU
+constexpr int BWD_THREADS = 512;       // backward: 1 block per CU (8 waves share one set of operand images)
+constexpr int BWD_WAVES = BWD_THREADS / WAVE;
 constexpr int TS = 20;                 // row stride (floats) of a 16x16 transpose scratch block
 constexpr int TBLK = 16 * TS;
 
@@ -82,8 +83,8 @@ struct Img {
     static constexpr int B3 = B2 + UT * UT * 256;       // [t][lane][v]       dx  = W0 . dh0pre
     static constexpr int B3S = B3 + UT * 256;           // [lane][v]          dx += Ws . dO(mean slots)
     static constexpr int BWD_END = B3S + 256;
-    static constexpr int SCR = BWD_END;                 // per wave: UT transpose blocks
-    static constexpr int BWD_TOTAL = SCR + DEC_WAVES * UT * TBLK;
+    static constexpr int SCR = BWD_END;                 // per wave: two sets of UT transpose blocks
+    static constexpr int BWD_TOTAL = SCR + BWD_WAVES * 2 * UT * TBLK;
 };
 
 // output slot m (0..15) of the last layer: lane group g = m>>2 owns slots 4g..4g+3 = (mean d0, mean d1, var d0, var d1)
@@ -91,39 +92,72 @@ struct Img {
 __device__ __forceinline__ int slot_d(int m) { return 2 * (m >> 2) + (m & 1); }
 __device__ __forceinline__ int slot_ty(int m) { return (m >> 1) & 1; }
 
-__device__ __forceinline__ float softplus_f(float v) { return v > 30.f ? v : log1pf(__expf(v)); }
-__device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float rcp_f(float v) { return __builtin_amdgcn_rcpf(v); }
+// log(1 + exp(v)), absolute error ~1e-7 (v_exp / v_log based); series for tiny exp(-|v|) keeps it relatively accurate
+__device__ __forceinline__ float softplus_f(float v) {
+    const float t = __expf(-fabsf(v));
+    const float l = t < 1e-3f ? t * (1.0f - t * (0.5f - t * 0.33333334f)) : __logf(1.0f + t);
+    return fmaxf(v, 0.f) + l;
+}
+__device__ __forceinline__ float sigmoid_f(float v) { return rcp_f(1.0f + __expf(-v)); }
 
-template <int UT, bool BWD>
+// tanh as the clamped rational x P(x^2) / Q(x^2) of Eigen's generic_fast_tanh_float - the implementation behind
+// tf.tanh in the reference's TensorFlow - max relative error 3.5e-7, |tanh| <= 1; two values per v_pk_* instruction.
+__device__ __forceinline__ v2f tanh2(v2f x) {
+    const float lim = 7.90531110763549805f;
+    x[0] = __builtin_amdgcn_fmed3f(x[0], -lim, lim);
+    x[1] = __builtin_amdgcn_fmed3f(x[1], -lim, lim);
+    const v2f x2 = x * x;
+    v2f p = x2 * -2.76076847742355e-16f + 2.00018790482477e-13f;
+    p = p * x2 + -8.60467152213735e-11f;
+    p = p * x2 + 5.12229709037114e-08f;
+    p = p * x2 + 1.48572235717979e-05f;
+    p = p * x2 + 6.37261928875436e-04f;
+    p = p * x2 + 4.89352455891786e-03f;
+    p = p * x;
+    v2f q = x2 * 1.19825839466702e-06f + 1.18534705686654e-04f;
+    q = q * x2 + 2.26843463243900e-03f;
+    q = q * x2 + 4.89352518554385e-03f;
+    v2f r;
+    r[0] = rcp_f(q[0]);
+    r[1] = rcp_f(q[1]);
+    return p * r;
+}
+__device__ __forceinline__ f32x4 tanh4(f32x4 z) {
+    const v2f a = tanh2(v2f{z[0], z[1]}), b = tanh2(v2f{z[2], z[3]});
+    return f32x4{a[0], a[1], b[0], b[1]};
+}
+
+template <int UT, bool BWD, int THREADS>
 __device__ void fill_images(float* __restrict__ sm, const DecArgs& a) {
     using I = Img<UT>;
     const int L = a.L, U = a.U, Dy = a.Dy;
     const int tid = threadIdx.x;
     // F0: A[i = unit 16t'+c][k = dim 4kk+g] = W0[dim][unit]
-    for (int i = tid; i < UT * 256; i += DEC_THREADS) {
+    for (int i = tid; i < UT * 256; i += THREADS) {
         const int v = i & 3, l = (i >> 2) & 63, tp = i >> 8, g = l >> 4, c = l & 15;
         const int dim = 4 * v + g, unit = 16 * tp + c;
         sm[I::F0 + i] = (v < 2 && dim < L && unit < U) ? a.W0[dim * U + unit] : 0.f;
     }
     // F1: A[i = out 16t'+c][k = in 16t+4g+v] = W1[in][out]
-    for (int i = tid; i < UT * UT * 256; i += DEC_THREADS) {
+    for (int i = tid; i < UT * UT * 256; i += THREADS) {
         const int v = i & 3, l = (i >> 2) & 63, e = i >> 8, t = e % UT, tp = e / UT, g = l >> 4, c = l & 15;
         const int in = 16 * t + 4 * g + v, out = 16 * tp + c;
         sm[I::F1 + i] = (in < U && out < U) ? a.W1[in * U + out] : 0.f;
     }
     // F2: A[i = slot c][k = in 16t+4g+v] = W2[in][ty*Dy + d]
-    for (int i = tid; i < UT * 256; i += DEC_THREADS) {
+    for (int i = tid; i < UT * 256; i += THREADS) {
         const int v = i & 3, l = (i >> 2) & 63, t = i >> 8, g = l >> 4, c = l & 15;
         const int in = 16 * t + 4 * g + v, d = slot_d(c), ty = slot_ty(c);
         sm[I::F2 + i] = (in < U && d < Dy) ? a.W2[in * 2 * Dy + ty * Dy + d] : 0.f;
     }
     // F2S: A[i = slot c][k = dim 4kk+g] = Ws[dim][d] for the mean slots
-    for (int i = tid; i < 256; i += DEC_THREADS) {
+    for (int i = tid; i < 256; i += THREADS) {
         const int v = i & 3, l = i >> 2, g = l >> 4, c = l & 15;
         const int dim = 4 * v + g, d = slot_d(c), ty = slot_ty(c);
         sm[I::F2S + i] = (v < 2 && dim < L && d < Dy && ty == 0) ? a.Ws[dim * Dy + d] : 0.f;
     }
-    for (int i = tid; i < 16 * UT; i += DEC_THREADS) {
+    for (int i = tid; i < 16 * UT; i += THREADS) {
         sm[I::BIAS0 + i] = i < U ? a.b0[i] : 0.f;
         sm[I::BIAS1 + i] = i < U ? a.b1[i] : 0.f;
     }
@@ -134,29 +168,29 @@ __device__ void fill_images(float* __restrict__ sm, const DecArgs& a) {
     if (tid < 8) {
         const float b = tid < Dy ? a.bs2[tid] : 0.f;
         sm[I::SP2 + tid] = log1pf(expf(b));            // the reference's naive form (vae.py:116)
-        sm[I::SG2 + tid] = sigmoid_f(b);
+        sm[I::SG2 + tid] = 1.0f / (1.0f + expf(-b));
     }
     if (BWD) {
         // B1: A[i = unit 16t'+c][k = slot 4g+v] = W2[unit][o(slot)]
-        for (int i = tid; i < UT * 256; i += DEC_THREADS) {
+        for (int i = tid; i < UT * 256; i += THREADS) {
             const int v = i & 3, l = (i >> 2) & 63, tp = i >> 8, g = l >> 4, c = l & 15;
             const int unit = 16 * tp + c, m = 4 * g + v, d = slot_d(m), ty = slot_ty(m);
             sm[I::B1 + i] = (unit < U && d < Dy) ? a.W2[unit * 2 * Dy + ty * Dy + d] : 0.f;
         }
         // B2: A[i = in 16t'+c][k = out 16t+4g+v] = W1[in][out]
-        for (int i = tid; i < UT * UT * 256; i += DEC_THREADS) {
+        for (int i = tid; i < UT * UT * 256; i += THREADS) {
             const int v = i & 3, l = (i >> 2) & 63, e = i >> 8, t = e % UT, tp = e / UT, g = l >> 4, c = l & 15;
             const int in = 16 * tp + c, out = 16 * t + 4 * g + v;
             sm[I::B2 + i] = (in < U && out < U) ? a.W1[in * U + out] : 0.f;
         }
         // B3: A[i = dim c][k = unit 16t+4g+v] = W0[dim][unit]
-        for (int i = tid; i < UT * 256; i += DEC_THREADS) {
+        for (int i = tid; i < UT * 256; i += THREADS) {
             const int v = i & 3, l = (i >> 2) & 63, t = i >> 8, g = l >> 4, c = l & 15;
             const int unit = 16 * t + 4 * g + v;
             sm[I::B3 + i] = (c < L && unit < U) ? a.W0[c * U + unit] : 0.f;
         }
         // B3S: A[i = dim c][k = slot 4g+v] = Ws[dim][d] for the mean slots
-        for (int i = tid; i < 256; i += DEC_THREADS) {
+        for (int i = tid; i < 256; i += THREADS) {
             const int v = i & 3, l = i >> 2, g = l >> 4, c = l & 15;
             const int m = 4 * g + v, d = slot_d(m), ty = slot_ty(m);
             sm[I::B3S + i] = (c < L && d < Dy && ty == 0) ? a.Ws[c * Dy + d] : 0.f;
@@ -169,8 +203,31 @@ __device__ __forceinline__ f32x4 mfma4(float av, float bv, f32x4 cv) {
 }
 __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// k-steps over hidden units are enumerated (t, v) <-> units 16t + 4g + v; in the last unit tile only v < VL reach a
+// unit below U (VL = min(4, U - 16 (UT-1))), the others multiply zero padding and are skipped at compile time.
+template <int UT, int VL>
+__device__ __forceinline__ constexpr bool kstep_on(int t, int v) { return t < UT - 1 || v < VL; }
+
+// row -> (cell, n) for the 16 rows of a tile: the tile's first row is divided on the scalar unit, the lane offset
+// (< 16 + S) by an exact small-integer float division.
+struct RowMap {
+    unsigned cell, n;
+};
+__device__ __forceinline__ RowMap row_map(unsigned tile, int c, unsigned S, unsigned K, float invS, float invK,
+                                          unsigned ncells) {
+    const unsigned row0 = __builtin_amdgcn_readfirstlane(tile) * 16u;
+    const unsigned cell0 = row0 / S, rem0 = row0 - cell0 * S;
+    const unsigned n0 = cell0 / K, crem0 = cell0 - n0 * K;
+    const unsigned q1 = (unsigned)(((float)(rem0 + (unsigned)c) + 0.5f) * invS);
+    const unsigned q2 = (unsigned)(((float)(crem0 + q1) + 0.5f) * invK);
+    RowMap m;
+    m.cell = min(cell0 + q1, ncells - 1u);
+    m.n = min(n0 + q2, (ncells - 1u) / K);
+    return m;
+}
+
 // forward of one 16-row tile; xb0/xb1 = x[row c][g], x[row c][4+g] (B operand of layer 0)
-template <int UT>
+template <int UT, int VL>
 __device__ __forceinline__ void dec_forward_tile(const float* __restrict__ sm, int lane, float xb0, float xb1,
                                                  f32x4 (&h0)[UT], f32x4 (&h1)[UT], f32x4& O) {
     using I = Img<UT>;
@@ -184,9 +241,7 @@ __device__ __forceinline__ void dec_forward_tile(const float* __restrict__ sm, i
         h0[tp] = acc;
     }
 #pragma unroll
-    for (int tp = 0; tp < UT; ++tp)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) h0[tp][v] = tanhf(h0[tp][v]);
+    for (int tp = 0; tp < UT; ++tp) h0[tp] = tanh4(h0[tp]);
 #pragma unroll
     for (int tp = 0; tp < UT; ++tp) h1[tp] = lds4(sm + I::BIAS1 + 16 * tp + 4 * g);
 #pragma unroll
@@ -196,13 +251,13 @@ __device__ __forceinline__ void dec_forward_tile(const float* __restrict__ sm, i
         for (int tp = 0; tp < UT; ++tp) w[tp] = lds4(sm + I::F1 + ((tp * UT + t) * 64 + lane) * 4);
 #pragma unroll
         for (int v = 0; v < 4; ++v)
+            if (kstep_on<UT, VL>(t, v)) {
 #pragma unroll
-            for (int tp = 0; tp < UT; ++tp) h1[tp] = mfma4(w[tp][v], h0[t][v], h1[tp]);
+                for (int tp = 0; tp < UT; ++tp) h1[tp] = mfma4(w[tp][v], h0[t][v], h1[tp]);
+            }
     }
 #pragma unroll
-    for (int tp = 0; tp < UT; ++tp)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) h1[tp][v] = tanhf(h1[tp][v]);
+    for (int tp = 0; tp < UT; ++tp) h1[tp] = tanh4(h1[tp]);
     f32x4 o0 = lds4(sm + I::BIASO + 4 * g), o1 = {0.f, 0.f, 0.f, 0.f};
     {
         const f32x4 w = lds4(sm + I::F2S + lane * 4);
@@ -212,46 +267,51 @@ __device__ __forceinline__ void dec_forward_tile(const float* __restrict__ sm, i
 #pragma unroll
     for (int t = 0; t < UT; ++t) {
         const f32x4 w = lds4(sm + I::F2 + (t * 64 + lane) * 4);
-        o0 = mfma4(w[0], h1[t][0], o0);
-        o1 = mfma4(w[1], h1[t][1], o1);
-        o0 = mfma4(w[2], h1[t][2], o0);
-        o1 = mfma4(w[3], h1[t][3], o1);
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            if (kstep_on<UT, VL>(t, v)) {
+                if (v & 1) o1 = mfma4(w[v], h1[t][v], o1);
+                else o0 = mfma4(w[v], h1[t][v], o0);
+            }
     }
     O = o0 + o1;
 }
 
-template <int UT>
-__global__ __launch_bounds__(DEC_THREADS) void dec_fwd_kernel(DecArgs a) {
+template <int UT, int VL>
+__global__ __launch_bounds__(FWD_THREADS, 2) void dec_fwd_kernel(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     using I = Img<UT>;
-    fill_images<UT, false>(sm, a);
+    fill_images<UT, false, FWD_THREADS>(sm, a);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
     const unsigned ntiles = (a.R + 15u) / 16u;
-    const unsigned nwaves = gridDim.x * DEC_WAVES;
+    const unsigned nwaves = gridDim.x * (FWD_THREADS / WAVE);
     const int L = a.L, Dy = a.Dy;
-    for (unsigned tile = blockIdx.x * DEC_WAVES + wave; tile < ntiles; tile += nwaves) {
+    const float invS = 1.0f / (float)a.S, invK = 1.0f / (float)a.K;
+    const unsigned ncells = a.R / a.S;
+    for (unsigned tile = blockIdx.x * (FWD_THREADS / WAVE) + wave; tile < ntiles; tile += nwaves) {
         const unsigned row = tile * 16u + c;
         const bool ok = row < a.R;
         const unsigned rr = ok ? row : a.R - 1u;
         const float* __restrict__ xr = a.x + (size_t)rr * L;
         const float xb0 = g < L ? xr[g] : 0.f;
         const float xb1 = 4 + g < L ? xr[4 + g] : 0.f;
+        const RowMap rm = row_map(tile, c, a.S, a.K, invS, invK, ncells);
+        float yv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) yv[j] = (2 * g + j < Dy && a.ll) ? a.y[(size_t)rm.n * Dy + 2 * g + j] : 0.f;
         f32x4 h0[UT], h1[UT], O;
-        dec_forward_tile<UT>(sm, lane, xb0, xb1, h0, h1, O);
-        const unsigned cell = rr / a.S, n = cell / a.K;
+        dec_forward_tile<UT, VL>(sm, lane, xb0, xb1, h0, h1, O);
         float acc = 0.f;
         float mu[2], vr[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int d = 2 * g + j;
-            const bool dv = d < Dy;
             mu[j] = O[j];
             vr[j] = softplus_f(O[2 + j]) + sm[I::SP2 + (d & 7)];
-            const float yv = (dv && a.ll) ? a.y[(size_t)n * Dy + d] : 0.f;
-            const float df = yv - mu[j];
-            const float term = df * df / vr[j] + logf(vr[j] + 1e-8f);
-            acc += dv ? term : 0.f;
+            const float df = yv[j] - mu[j];
+            const float term = df * df * rcp_f(vr[j]) + __logf(vr[j] + 1e-8f);
+            acc += d < Dy ? term : 0.f;
         }
         acc += __shfl_xor(acc, 16);
         acc += __shfl_xor(acc, 32);
@@ -269,7 +329,9 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_fwd_kernel(DecArgs a) {
     }
 }
 
-__device__ __forceinline__ void wave_lds_sync() {
+// Lanes of ONE wave exchange data through LDS: the LDS unit executes a wave's instructions in order, so no wait is
+// needed - only the compiler must keep the program order of the accesses.
+__device__ __forceinline__ void wave_lds_order() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -282,40 +344,40 @@ __device__ __forceinline__ void tr_write(float* __restrict__ T, int g, int c, f3
 }
 __device__ __forceinline__ f32x4 tr_read(const float* __restrict__ T, int g, int c) { return lds4(T + c * TS + 4 * g); }
 
-template <int UT>
-__device__ __forceinline__ void transpose_set(float* __restrict__ scr, int g, int c, const f32x4 (&in)[UT], f32x4 (&out)[UT]) {
-    wave_lds_sync();                                    // previous readers of the scratch are done
-#pragma unroll
-    for (int t = 0; t < UT; ++t) tr_write(scr + t * TBLK, g, c, in[t]);
-    wave_lds_sync();
-#pragma unroll
-    for (int t = 0; t < UT; ++t) out[t] = tr_read(scr + t * TBLK, g, c);
-}
-
-template <int UT>
-__global__ __launch_bounds__(DEC_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
+// Bias gradients ride in the zero padding of the weight-gradient products: the x tile (A operand of dW0 and of the
+// shortcut product) has rows L..15 free, so a row of ones at "dim 8" makes row 8 of those accumulators equal to
+// sum_row dh0pre (= db0) and sum_row dO (= db2, dbs1); likewise a ones "unit U" in the transposed h0 block gives
+// db1 as row U of dW1 when U is not a multiple of 16 (FS); otherwise db1 is summed on the VALU.
+template <int UT, int VL, bool FS>
+__global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     using I = Img<UT>;
-    fill_images<UT, true>(sm, a);
+    fill_images<UT, true, BWD_THREADS>(sm, a);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
-    float* __restrict__ scr = sm + I::SCR + wave * UT * TBLK;
+    float* __restrict__ scrA = sm + I::SCR + wave * 2 * UT * TBLK;
+    float* __restrict__ scrB = scrA + UT * TBLK;
     const unsigned ntiles = (a.R + 15u) / 16u;
-    const unsigned nwaves = gridDim.x * DEC_WAVES;
+    const unsigned nwaves = gridDim.x * BWD_WAVES;
     const int L = a.L, Dy = a.Dy, U = a.U;
+    const float invS = 1.0f / (float)a.S, invK = 1.0f / (float)a.K;
+    const unsigned ncells = a.R / a.S;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    f32x4 aW1[UT][UT], aW2[UT], aWs, aW0[UT], ab0[UT], ab1[UT];
-    float abm[2] = {0.f, 0.f}, abv[2] = {0.f, 0.f}, abs2[2] = {0.f, 0.f};
+    f32x4 aW1[UT][UT], aW2[UT], aWs, aW0[UT], ab1[FS ? 1 : UT];
+    float abs2[2] = {0.f, 0.f};
     aWs = zero4;
+    const int fsu = U & 15;                             // FS: the free unit slot of the last tile
+#pragma unroll
+    for (int i = 0; i < (FS ? 1 : UT); ++i) ab1[i] = zero4;
 #pragma unroll
     for (int i = 0; i < UT; ++i) {
-        aW2[i] = zero4; aW0[i] = zero4; ab0[i] = zero4; ab1[i] = zero4;
+        aW2[i] = zero4; aW0[i] = zero4;
 #pragma unroll
         for (int j = 0; j < UT; ++j) aW1[i][j] = zero4;
     }
 
-    for (unsigned tile = blockIdx.x * DEC_WAVES + wave; tile < ntiles; tile += nwaves) {
+    for (unsigned tile = blockIdx.x * BWD_WAVES + wave; tile < ntiles; tile += nwaves) {
         const unsigned row = tile * 16u + c;
         const bool ok = row < a.R;
         const unsigned rr = ok ? row : a.R - 1u;
@@ -327,14 +389,20 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const unsigned r2 = tile * 16u + 4u * g + kk;
-            xT[kk] = (r2 < a.R && c < L) ? a.x[(size_t)r2 * L + c] : 0.f;
+            xT[kk] = (r2 < a.R && c < L) ? a.x[(size_t)r2 * L + c] : (c == 8 ? 1.0f : 0.f);
         }
+        const RowMap rm = row_map(tile, c, a.S, a.K, invS, invK, ncells);
+        const float ga = ok ? a.gA[rm.cell] : 0.f;
+        float yv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) yv[j] = 2 * g + j < Dy ? a.y[(size_t)rm.n * Dy + 2 * g + j] : 0.f;
+
         f32x4 h0[UT], h1[UT], O;
-        dec_forward_tile<UT>(sm, lane, xb0, xb1, h0, h1, O);
+        dec_forward_tile<UT, VL>(sm, lane, xb0, xb1, h0, h1, O);
+#pragma unroll
+        for (int t = 0; t < UT; ++t) tr_write(scrA + t * TBLK, g, c, h1[t]);
 
         // ---- reconstruction term: gradients w.r.t. the output slots
-        const unsigned cell = rr / a.S, n = cell / a.K;
-        const float ga = ok ? a.gA[cell] : 0.f;
         f32x4 dO;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -342,34 +410,16 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             const bool dv = d < Dy;
             const float raw2 = O[2 + j];
             const float vr = softplus_f(raw2) + sm[I::SP2 + (d & 7)];
-            const float yv = dv ? a.y[(size_t)n * Dy + d] : 0.f;
-            const float df = yv - O[j], iv = 1.0f / vr;
+            const float df = yv[j] - O[j], iv = rcp_f(vr);
             const float gm = dv ? ga * (-2.f * df * iv) : 0.f;
-            const float gv = dv ? ga * (1.0f / (vr + 1e-8f) - df * df * iv * iv) : 0.f;
+            const float gv = dv ? ga * (rcp_f(vr + 1e-8f) - df * df * iv * iv) : 0.f;
             const float gr = gv * sigmoid_f(raw2);
             dO[j] = gm;
             dO[2 + j] = gr;
-            abm[j] += gm;
-            abv[j] += gr;
             abs2[j] += gv;
         }
-
-        // ---- dW2 (and shortcut W): [h1 ; x]^T . dO
-        {
-            f32x4 h1T[UT], dOT;
-            transpose_set<UT>(scr, g, c, h1, h1T);
-            wave_lds_sync();
-            tr_write(scr, g, c, dO);
-            wave_lds_sync();
-            dOT = tr_read(scr, g, c);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-                for (int t = 0; t < UT; ++t) aW2[t] = mfma4(h1T[t][kk], dOT[kk], aW2[t]);
-                aWs = mfma4(xT[kk], dOT[kk], aWs);
-            }
-        }
-        // ---- dh1 = W2 . dO, through tanh
+        tr_write(scrB, g, c, dO);
+        // ---- dh1 = W2 . dO
         f32x4 dh1[UT];
 #pragma unroll
         for (int tp = 0; tp < UT; ++tp) {
@@ -379,25 +429,34 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             for (int v = 0; v < 4; ++v) acc = mfma4(w[v], dO[v], acc);
             dh1[tp] = acc;
         }
+        // ---- dW2 (and shortcut W): [h1 ; x]^T . dO
+        wave_lds_order();
+        {
+            f32x4 h1T[UT];
+#pragma unroll
+            for (int t = 0; t < UT; ++t) h1T[t] = tr_read(scrA + t * TBLK, g, c);
+            const f32x4 dOT = tr_read(scrB, g, c);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int t = 0; t < UT; ++t) aW2[t] = mfma4(h1T[t][kk], dOT[kk], aW2[t]);
+                aWs = mfma4(xT[kk], dOT[kk], aWs);
+            }
+        }
+        // ---- through tanh of layer 1
 #pragma unroll
         for (int tp = 0; tp < UT; ++tp) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) dh1[tp][v] *= 1.0f - h1[tp][v] * h1[tp][v];
-            ab1[tp] += dh1[tp];
+            if (!FS) ab1[tp] += dh1[tp];
         }
-        // ---- dW1 = h0^T . dh1pre
-        {
-            f32x4 h0T[UT], dT[UT];
-            transpose_set<UT>(scr, g, c, h0, h0T);
-            transpose_set<UT>(scr, g, c, dh1, dT);
+        wave_lds_order();
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int ti = 0; ti < UT; ++ti)
-#pragma unroll
-                    for (int tj = 0; tj < UT; ++tj) aW1[ti][tj] = mfma4(h0T[ti][kk], dT[tj][kk], aW1[ti][tj]);
+        for (int t = 0; t < UT; ++t) {
+            tr_write(scrA + t * TBLK, g, c, h0[t]);
+            tr_write(scrB + t * TBLK, g, c, dh1[t]);
         }
-        // ---- dh0 = W1 . dh1pre, through tanh
+        // ---- dh0 = W1 . dh1pre
         f32x4 dh0[UT];
 #pragma unroll
         for (int tp = 0; tp < UT; ++tp) dh0[tp] = zero4;
@@ -408,24 +467,37 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             for (int tp = 0; tp < UT; ++tp) w[tp] = lds4(sm + I::B2 + ((tp * UT + t) * 64 + lane) * 4);
 #pragma unroll
             for (int v = 0; v < 4; ++v)
+                if (kstep_on<UT, VL>(t, v)) {
 #pragma unroll
-                for (int tp = 0; tp < UT; ++tp) dh0[tp] = mfma4(w[tp][v], dh1[t][v], dh0[tp]);
+                    for (int tp = 0; tp < UT; ++tp) dh0[tp] = mfma4(w[tp][v], dh1[t][v], dh0[tp]);
+                }
         }
+        // ---- dW1 = h0^T . dh1pre
+        wave_lds_order();
+        {
+            f32x4 h0T[UT], dT[UT];
+#pragma unroll
+            for (int t = 0; t < UT; ++t) {
+                h0T[t] = tr_read(scrA + t * TBLK, g, c);
+                dT[t] = tr_read(scrB + t * TBLK, g, c);
+            }
+            if (FS && c == fsu) h0T[UT - 1] = f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int ti = 0; ti < UT; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < UT; ++tj) aW1[ti][tj] = mfma4(h0T[ti][kk], dT[tj][kk], aW1[ti][tj]);
+        }
+        // ---- through tanh of layer 0
 #pragma unroll
         for (int tp = 0; tp < UT; ++tp) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) dh0[tp][v] *= 1.0f - h0[tp][v] * h0[tp][v];
-            ab0[tp] += dh0[tp];
         }
-        // ---- dW0 = x^T . dh0pre
-        {
-            f32x4 dT[UT];
-            transpose_set<UT>(scr, g, c, dh0, dT);
+        wave_lds_order();
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int tj = 0; tj < UT; ++tj) aW0[tj] = mfma4(xT[kk], dT[tj][kk], aW0[tj]);
-        }
+        for (int t = 0; t < UT; ++t) tr_write(scrA + t * TBLK, g, c, dh0[t]);
         // ---- dx = W0 . dh0pre + Ws . dO(mean)
         {
             f32x4 d0 = zero4, d1 = zero4;
@@ -437,10 +509,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
 #pragma unroll
             for (int t = 0; t < UT; ++t) {
                 const f32x4 w = lds4(sm + I::B3 + (t * 64 + lane) * 4);
-                d0 = mfma4(w[0], dh0[t][0], d0);
-                d1 = mfma4(w[1], dh0[t][1], d1);
-                d0 = mfma4(w[2], dh0[t][2], d0);
-                d1 = mfma4(w[3], dh0[t][3], d1);
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (kstep_on<UT, VL>(t, v)) {
+                        if (v & 1) d1 = mfma4(w[v], dh0[t][v], d1);
+                        else d0 = mfma4(w[v], dh0[t][v], d0);
+                    }
             }
             const f32x4 dxv = d0 + d1;                   // [dim 4g+v][row c]
             if (ok) {
@@ -453,17 +527,28 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
                 }
             }
         }
+        // ---- dW0 = x^T . dh0pre
+        wave_lds_order();
+        {
+            f32x4 dT[UT];
+#pragma unroll
+            for (int t = 0; t < UT; ++t) dT[t] = tr_read(scrA + t * TBLK, g, c);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int tj = 0; tj < UT; ++tj) aW0[tj] = mfma4(xT[kk], dT[tj][kk], aW0[tj]);
+        }
+        wave_lds_order();
     }
 
     // ---- reduce the per-wave accumulators: waves of the block in a fixed order through LDS
     const DecGeo q = dec_geo(L, U, Dy);
     __syncthreads();                                    // everybody is done with the operand images
     float* __restrict__ accum = sm;
-    for (int w = 0; w < DEC_WAVES; ++w) {
+    for (int w = 0; w < BWD_WAVES; ++w) {
         if (wave == w) {
             if (w == 0) for (int i = lane; i < q.PW; i += WAVE) accum[i] = 0.f;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_order();
 #pragma unroll
             for (int ti = 0; ti < UT; ++ti)
 #pragma unroll
@@ -487,34 +572,48 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
                 const int dim = 4 * g + v, d = slot_d(c), ty = slot_ty(c);
                 if (dim < L && d < Dy && ty == 0) accum[q.oWs + dim * Dy + d] += aWs[v];
             }
-            // biases: sum over the 16 rows (lanes c of a DPP row), lane c == 0 adds
+            // biases out of the ones rows: dim 8 <-> lane group g == 2, register 0
+            if (g == 2) {
 #pragma unroll
-            for (int t = 0; t < UT; ++t)
+                for (int t = 0; t < UT; ++t)
+                    if (16 * t + c < U) accum[q.ob0 + 16 * t + c] += aW0[t][0];
+                const int d = slot_d(c), ty = slot_ty(c);
+                if (d < Dy) {
+                    accum[q.ob2 + ty * Dy + d] += aWs[0];
+                    if (ty == 0) accum[q.obs1 + d] += aWs[0];
+                }
+            }
+            if (FS) {
+                if (g == (fsu >> 2)) {
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float s0 = row16_sum(ab0[t][v]), s1 = row16_sum(ab1[t][v]);
-                    const int unit = 16 * t + 4 * g + v;
-                    if (c == 0 && unit < U) {
-                        accum[q.ob0 + unit] += s0;
-                        accum[q.ob1 + unit] += s1;
+                    for (int tj = 0; tj < UT; ++tj) {
+                        const f32x4 z = aW1[UT - 1][tj];
+                        const int v = fsu & 3;
+                        const float val = v == 0 ? z[0] : v == 1 ? z[1] : v == 2 ? z[2] : z[3];
+                        if (16 * tj + c < U) accum[q.ob1 + 16 * tj + c] += val;
                     }
                 }
+            } else {
+#pragma unroll
+                for (int t = 0; t < UT; ++t)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float s1 = row16_sum(ab1[t][v]);
+                        const int unit = 16 * t + 4 * g + v;
+                        if (c == 0 && unit < U) accum[q.ob1 + unit] += s1;
+                    }
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const float sm_ = row16_sum(abm[j]), sv_ = row16_sum(abv[j]), s2_ = row16_sum(abs2[j]);
+                const float s2_ = row16_sum(abs2[j]);
                 const int d = 2 * g + j;
-                if (c == 0 && d < Dy) {
-                    accum[q.ob2 + d] += sm_;
-                    accum[q.ob2 + Dy + d] += sv_;
-                    accum[q.obs1 + d] += sm_;
-                    accum[q.obs2 + d] += s2_;
-                }
+                if (c == 0 && d < Dy) accum[q.obs2 + d] += s2_;
             }
         }
         __syncthreads();
     }
     // sigmoid(bs2) factor of d/d bs2 log1p(exp(bs2)) is applied by the reduce kernel
-    for (int i = threadIdx.x; i < q.PW; i += DEC_THREADS) a.part[(size_t)blockIdx.x * q.PW + i] = accum[i];
+    for (int i = threadIdx.x; i < q.PW; i += BWD_THREADS) a.part[(size_t)blockIdx.x * q.PW + i] = accum[i];
 }
 
 struct DecRedArgs {
@@ -532,13 +631,15 @@ __global__ __launch_bounds__(256) void dec_reduce_kernel(DecRedArgs r) {
     r.out[i] = (float)s;
 }
 
-int dec_blocks(long long rows) {
+int dec_blocks(long long rows, int waves_per_block, int max_blocks) {
     const long long tiles = (rows + 15) / 16;
-    long long b = (tiles + DEC_WAVES - 1) / DEC_WAVES;
-    if (b > 512) b = 512;                               // 2 resident blocks on each of the 256 CUs
+    long long b = (tiles + waves_per_block - 1) / waves_per_block;
+    if (b > max_blocks) b = max_blocks;
     if (b < 1) b = 1;
     return (int)b;
 }
+int dec_fwd_blocks(long long rows) { return dec_blocks(rows, FWD_THREADS / WAVE, 512); }   // 2 blocks on each of 256 CUs
+int dec_bwd_blocks(long long rows) { return dec_blocks(rows, BWD_WAVES, 256); }            // 1 block per CU
 
 int dec_check(const char* what, long long N, int K, int S, int L, int Dy, int U) {
     if (N < 0 || K < 1 || S < 1 || L < 1 || L > 8 || Dy < 1 || Dy > 8 || U < 1 || U > 64) {
@@ -552,6 +653,18 @@ int dec_check(const char* what, long long N, int K, int S, int L, int Dy, int U)
     return 0;
 }
 
+// dispatch on (UT, VL) = (unit tiles, live k-steps of the last tile)
+#define DEC_DISPATCH(U, CALL)                                                                  \
+    do {                                                                                       \
+        const int ut_ = ((U) + 15) / 16, vl_ = ((U) - 16 * (ut_ - 1)) >= 4 ? 4 : ((U) - 16 * (ut_ - 1)); \
+        switch (ut_ * 4 + vl_ - 1) {                                                           \
+            case 4: CALL(1, 1); break;  case 5: CALL(1, 2); break;  case 6: CALL(1, 3); break;  case 7: CALL(1, 4); break;   \
+            case 8: CALL(2, 1); break;  case 9: CALL(2, 2); break;  case 10: CALL(2, 3); break; case 11: CALL(2, 4); break;  \
+            case 12: CALL(3, 1); break; case 13: CALL(3, 2); break; case 14: CALL(3, 3); break; case 15: CALL(3, 4); break;  \
+            case 16: CALL(4, 1); break; case 17: CALL(4, 2); break; case 18: CALL(4, 3); break; default: CALL(4, 4); break;  \
+        }                                                                                      \
+    } while (0)
+
 }  // namespace
 
 extern "C" {
@@ -559,7 +672,7 @@ extern "C" {
 int vmp_decoder_param_words(int L, int U, int Dy) { return dec_geo(L, U, Dy).PW; }
 
 size_t vmp_decoder_workspace_bytes(int64_t N, int K, int S, int L, int U, int Dy) {
-    return (size_t)dec_blocks((long long)N * K * S) * (size_t)dec_geo(L, U, Dy).PW * sizeof(float);
+    return (size_t)dec_bwd_blocks((long long)N * K * S) * (size_t)dec_geo(L, U, Dy).PW * sizeof(float);
 }
 
 int vmp_decoder_loglike_fwd(const float* x, const float* y, const float* W0, const float* b0, const float* W1,
@@ -576,20 +689,15 @@ int vmp_decoder_loglike_fwd(const float* x, const float* y, const float* W0, con
     a.x = x; a.y = y; a.W0 = W0; a.b0 = b0; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Ws = Ws; a.bs1 = bs1; a.bs2 = bs2;
     a.ll = ll; a.mean = mean; a.var = var;
     a.R = (unsigned)(N * K * S); a.K = (unsigned)K; a.S = (unsigned)S; a.L = L; a.Dy = Dy; a.U = U;
-    const int blocks = dec_blocks((long long)a.R);
+    const int blocks = dec_fwd_blocks((long long)a.R);
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define DEC_FWD(UTV)                                                                                                  \
+#define DEC_FWD(UTV, VLV)                                                                                             \
     do {                                                                                                              \
         const int lds = Img<UTV>::FWD_END * (int)sizeof(float);                                                       \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fwd_kernel<UTV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        hipLaunchKernelGGL((dec_fwd_kernel<UTV>), dim3(blocks), dim3(DEC_THREADS), lds, s, a);                       \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fwd_kernel<UTV, VLV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((dec_fwd_kernel<UTV, VLV>), dim3(blocks), dim3(FWD_THREADS), lds, s, a);                   \
     } while (0)
-    switch ((U + 15) / 16) {
-        case 1: DEC_FWD(1); break;
-        case 2: DEC_FWD(2); break;
-        case 3: DEC_FWD(3); break;
-        default: DEC_FWD(4); break;
-    }
+    DEC_DISPATCH(U, DEC_FWD);
 #undef DEC_FWD
     return check_launch("vmp_decoder_loglike_fwd");
 }
@@ -618,19 +726,19 @@ int vmp_decoder_loglike_bwd(const float* x, const float* y, const float* gA, con
     a.x = x; a.y = y; a.gA = gA; a.W0 = W0; a.b0 = b0; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Ws = Ws; a.bs1 = bs1; a.bs2 = bs2;
     a.dx = dx; a.part = static_cast<float*>(ws);
     a.R = (unsigned)(N * K * S); a.K = (unsigned)K; a.S = (unsigned)S; a.L = L; a.Dy = Dy; a.U = U;
-    const int blocks = dec_blocks((long long)a.R);
-#define DEC_BWD(UTV)                                                                                                  \
+    const int blocks = dec_bwd_blocks((long long)a.R);
+#define DEC_BWD(UTV, VLV)                                                                                             \
     do {                                                                                                              \
         const int lds = Img<UTV>::BWD_TOTAL * (int)sizeof(float);                                                     \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<UTV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        hipLaunchKernelGGL((dec_bwd_kernel<UTV>), dim3(blocks), dim3(DEC_THREADS), lds, s, a);                       \
+        if (VLV == 4 && (U & 15) == 0) {                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<UTV, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            hipLaunchKernelGGL((dec_bwd_kernel<UTV, 4, false>), dim3(blocks), dim3(BWD_THREADS), lds, s, a);         \
+        } else {                                                                                                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<UTV, VLV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            hipLaunchKernelGGL((dec_bwd_kernel<UTV, VLV, true>), dim3(blocks), dim3(BWD_THREADS), lds, s, a);        \
+        }                                                                                                             \
     } while (0)
-    switch ((U + 15) / 16) {
-        case 1: DEC_BWD(1); break;
-        case 2: DEC_BWD(2); break;
-        case 3: DEC_BWD(3); break;
-        default: DEC_BWD(4); break;
-    }
+    DEC_DISPATCH(U, DEC_BWD);
 #undef DEC_BWD
     if (int e = check_launch("vmp_decoder_loglike_bwd")) return e;
     DecRedArgs r{a.part, bs2, dparams, blocks, q.PW, q.obs2, Dy};
