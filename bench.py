@@ -155,8 +155,9 @@ def bench_t2(N, Ld, K, S, steps, warmup, dev, dist=None, world=1):
 
 
 def bench_t3(N, Ld, K, S, U, steps, warmup, dev, chunk):
-    """T3: the full training step of experiments.py:196-267 (encoder/decoder MLPs in torch fp32, reconstruction
-    term, all gradients, TF-Adam, CVI) on synthetic y = GMM data with Dy = L."""
+    """T3: the full training step of experiments.py:196-267 (encoder MLP in torch fp32; decoder MLP + reconstruction
+    term in the fused fp32-MFMA kernels; fused E-step kernels; all gradients, TF-Adam, CVI) on synthetic y = GMM data
+    with Dy = L."""
     from vmp_for_svae_amd.models import vae
     from vmp_for_svae_amd.training import SVAETrainer
     vae.reset_variables()
@@ -171,9 +172,13 @@ def bench_t3(N, Ld, K, S, U, steps, warmup, dev, chunk):
         out = tr.step(y, chunk=chunk)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    rows = float(N) * K * S
+    dec_flop = 3 * 2.0 * rows * (Ld * U + U * U + U * 2 * Ld + Ld * Ld)     # fwd + 2x bwd, useful flops of the decoder
     return {'steps_per_sec': steps / dt, 'ms_per_step': dt / steps * 1e3, 'datapoints_per_sec': N * steps / dt,
-            'elbo_per_datapoint': float(out['elbo']) / N,
-            'config': 'T3 svae-train N=%d (chunks of %d), L=Dy=%d, K=%d, S=%d, U=%d' % (N, chunk, Ld, K, S, U)}
+            'elbo_per_datapoint': float(out['elbo']) / N, 'decoder_rows_per_step': rows,
+            'decoder_useful_TFLOPs_over_whole_step': dec_flop / (dt / steps) / 1e12,
+            'config': 'T3 svae-train N=%d (%s), L=Dy=%d, K=%d, S=%d, U=%d' % (
+                N, 'one pass' if chunk is None else 'chunks of %d' % chunk, Ld, K, S, U)}
 
 
 def main():
@@ -249,7 +254,7 @@ def main():
         extra['t2_svae_vmp'] = bench_t2(N, D, K, args.s, 5, 2, dev, dist, world)
         torch.cuda.empty_cache()
         if world == 1:
-            extra['t3_svae_train'] = bench_t3(1 << 16, D, K, args.s, args.u, 3, 1, dev, 1 << 14)
+            extra['t3_svae_train'] = bench_t3(N, D, K, args.s, args.u, 3, 1, dev, None)
             torch.cuda.empty_cache()
 
     if rank == 0:

@@ -233,9 +233,11 @@ int    vmp_student_t_logprob(const float* y, const float* mu, const float* W, co
  * ------------------------------------------------------------------------------------------------
  *   mse (N,K) = mean_s sum_d (y - mean)^2                                             (may be NULL)
  *   lse (N,K) = log 1/S sum_s exp( logw_nk(s) - 1/2 sum_d mask_nd [(y-mean)^2/var + log var + log 2pi] )   (may be NULL)
- * logw: (N,K), or (N,K,S) when logw_per_sample, or NULL; mask (N,Dy) uint8 or NULL (losses.py:118-124).       */
+ * logw: (N,K), or (N,K,S) when logw_per_sample, or NULL; mask (N,Dy) uint8 or NULL (losses.py:118-124).
+ * mask_mse != 0: the squared error also counts masked entries only,
+ *   mse = mean_s sum_d mask_nd (y - mean)^2   = the per-cell part of losses.imputation_mse (losses.py:148-170).   */
 int    vmp_eval_cell_metrics(const float* y, const float* mean, const float* var, const float* logw,
-                             int logw_per_sample, const uint8_t* mask, int64_t N, int K, int S, int Dy,
+                             int logw_per_sample, const uint8_t* mask, int mask_mse, int64_t N, int K, int S, int Dy,
                              float* mse, float* lse, void* stream);
 
 #ifdef __cplusplus

@@ -1,4 +1,4 @@
-"""Oracle: evaluation metrics (reference losses.py:9-38, 83-145, 313-349).  TEST INFRASTRUCTURE (oracle/__init__.py)."""
+"""Oracle: evaluation metrics (reference losses.py:9-38, 83-145, 148-310, 313-349).  TEST INFRASTRUCTURE (oracle/__init__.py)."""
 import math
 
 import torch
@@ -44,3 +44,37 @@ def purity(r_nk, labels, eps=1e-10):
     entropy = (N_k / N * cluster_entropy).sum()
     pur = (N_k / N * p_kc.max(dim=1).values).sum()
     return entropy, pur
+
+
+def imputation_mse(y_true, y_pred, r_nk, mask):
+    """losses.py:148-170."""
+    N, K, S, D = y_pred.shape
+    m = mask.to(y_pred.dtype)
+    yt = y_true * m
+    yp = m.unsqueeze(1).unsqueeze(2) * y_pred
+    se = ((yt.unsqueeze(1).unsqueeze(2) - yp) ** 2).mean(2)              # (N,K,D)
+    return (se * r_nk.unsqueeze(2)).sum() / N
+
+
+def perturb_data(y, mask, noise):
+    """losses.py:288-310 with the tf.random_normal draw injected."""
+    m = mask.to(y.dtype)
+    return (1.0 - m) * y + m * noise
+
+
+def imputation_losses(y_true, mask, imputation_method, noise, nb_samples_rec):
+    """losses.py:173-246 ('standard' decoder): literal restatement - masked predictions, per-perturbation MSE, then ONE
+    diagonal_gaussian_logprob over the imputations concatenated along the sample axis."""
+    P = noise.shape[0]
+    mse = 0.0
+    means, vars_, lws = [], [], []
+    for s in range(P):
+        y_pert = perturb_data(y_true, mask, noise[s])
+        mean, var, log_r = imputation_method(y_pert)
+        pred = mask.to(mean.dtype).unsqueeze(1).unsqueeze(2) * mean
+        mse = mse + imputation_mse(y_true, pred, torch.exp(log_r), mask)
+        means.append(mean)
+        vars_.append(var)
+        lws.append(log_r.unsqueeze(2).repeat(1, 1, nb_samples_rec))
+    ll = diagonal_gaussian_logprob(y_true, torch.cat(means, 2), torch.cat(vars_, 2), torch.cat(lws, 2), mask=mask)
+    return mse / P, ll

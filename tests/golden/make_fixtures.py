@@ -409,6 +409,50 @@ def case_metrics(seed, N, K, S, D, C):
     out.update({'in_' + k: v for k, v in inputs.items()})
     return out
 
+# ============================================================================ missing-data imputation (losses.py:148-310)
+def imputation_toy_method(y_pert, K, S, D, a_ks, b_ksd, Wr, lib):
+    """A deterministic stand-in for the `impute` closure of experiments.py:365-372 (which runs svae.inference on the
+    perturbed data): (mean (N,K,S,D), var (N,K,S,D), log_r_nk (N,K)) as smooth functions of y_perturbed.  `lib` is the
+    tensor namespace (the tf shim here, torch in the tests) - only +,*,exp,log, sum are used."""
+    mean = y_pert[:, None, None, :] * a_ks[None, :, :, None] + b_ksd[None]
+    var = 0.3 + 0.5 * (y_pert[:, None, None, :] * a_ks[None, :, :, None]) ** 2
+    logits = y_pert @ Wr
+    log_r = logits - lib.log(lib.exp(logits).sum(1, keepdim=True))
+    return mean, var, log_r
+
+
+def case_imputation(seed, N, K, S, D, P):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    y = f32(rng.standard_normal((N, D)) * 1.5)
+    noise = f32(rng.standard_normal((P, N, D)))
+    a_ks = f32(0.6 + 0.4 * rng.random((K, S)))
+    b_ksd = f32(0.3 * rng.standard_normal((K, S, D)))
+    Wr = f32(0.5 * rng.standard_normal((D, K)))
+    y_pred = f32(y[:, None, None, :] + 0.7 * rng.standard_normal((N, K, S, D)))
+    lw = rng.standard_normal((N, K))
+    r = f32(np.exp(lw) / np.exp(lw).sum(1, keepdims=True))
+    inputs = dict(y=y, noise=noise, a_ks=a_ks, b_ksd=b_ksd, Wr=Wr, y_pred=y_pred, r=r, dims=np.array([N, K, S, D, P]),
+                  mask_seed=np.array(seed), mask_ratio=np.array(0.3))
+
+    def run():
+        o = {}
+        mask = R.losses.generate_missing_data_mask(T(y), 0.3, seed=seed)
+        o['mask'] = npy(mask)
+        o['mask_quarter'] = npy(R.losses.generate_missing_data_mask(T(np.zeros((3, 16))), mask_type='quarter'))
+        o['mask_left_half'] = npy(R.losses.generate_missing_data_mask(T(np.zeros((2, 16))), mask_type='left_half'))
+        tf.INJECT['random_normal'] += [T(noise[0])]
+        o['perturbed0'] = npy(R.losses.perturb_data(T(y), mask, seed))
+        o['imputation_mse'] = npy(R.losses.imputation_mse(T(y), T(y_pred), T(r), mask))
+        tf.INJECT['random_normal'] += [T(noise[p]) for p in range(P)]
+        method = lambda yp: imputation_toy_method(yp, K, S, D, T(a_ks), T(b_ksd), T(Wr), torch)
+        mse, ll = R.losses.imputation_losses(T(y), mask, method, nb_samples_pert=P, nb_samples_rec=S, seed=seed)
+        o['imp_mse'], o['imp_loglike'] = npy(mse), npy(ll)
+        return o
+
+    out = both(run)
+    out.update({'in_' + k: v for k, v in inputs.items()})
+    return out
+
 
 def main():
     cases = {
@@ -424,6 +468,7 @@ def main():
         'svae_smm_tiny': lambda: case_svae(10, N=7, K=4, L=3, S=5, Dy=2, U=5, smm=True),
         'metrics': lambda: case_metrics(12, N=50, K=5, S=7, D=3, C=4),
         'metrics_s100': lambda: case_metrics(13, N=12, K=10, S=100, D=6, C=3),
+        'imputation': lambda: case_imputation(14, N=40, K=5, S=6, D=6, P=4),
         'svae_smm_l8': lambda: case_svae(11, N=10, K=16, L=8, S=10, Dy=8, U=50, smm=True, steps=2),
     }
     only = sys.argv[1:]

@@ -196,3 +196,29 @@ def test_metrics(golden, case, dtype, suf, rtol):
     close(metrics.diagonal_gaussian_logprob(y, mean, var, lw, mask=T(g['in_mask'])), g['loli_mask' + suf], rtol)
     e, p_ = metrics.purity(r, T(g['in_labels'], dtype))
     close(e, g['entropy' + suf], rtol), close(p_, g['purity' + suf], rtol)
+
+
+def _toy_impute(g, dtype):
+    """The deterministic imputation method of tests/golden/make_fixtures.py::imputation_toy_method (data only)."""
+    a_ks, b_ksd, Wr = [T(g['in_' + k], dtype) for k in ('a_ks', 'b_ksd', 'Wr')]
+
+    def method(y_pert):
+        mean = y_pert[:, None, None, :] * a_ks[None, :, :, None] + b_ksd[None]
+        var = 0.3 + 0.5 * (y_pert[:, None, None, :] * a_ks[None, :, :, None]) ** 2
+        logits = y_pert @ Wr
+        return mean, var, logits - torch.logsumexp(logits, dim=1, keepdim=True)
+    return method
+
+
+@pytest.mark.parametrize('dtype,suf,rtol', [(torch.float64, '', 1e-12), (torch.float32, '__f32', 1e-4)])
+def test_imputation(golden, dtype, suf, rtol):
+    """SURVEY 8f rank 2 (losses.py:148-310) vs the reference run."""
+    g = golden('imputation')
+    N, K, S, D, P = [int(v) for v in g['in_dims']]
+    y, noise = T(g['in_y'], dtype), T(g['in_noise'], dtype)
+    mask = torch.as_tensor(g['mask'].astype(bool))
+    assert int(mask.sum()) == int(N * D * 0.3)
+    close(metrics.perturb_data(y, mask, noise[0]), g['perturbed0' + suf], rtol)
+    close(metrics.imputation_mse(y, T(g['in_y_pred'], dtype), T(g['in_r'], dtype), mask), g['imputation_mse' + suf], rtol)
+    mse, ll = metrics.imputation_losses(y, mask, _toy_impute(g, dtype), noise, S)
+    close(mse, g['imp_mse' + suf], rtol), close(ll, g['imp_loglike' + suf], rtol)

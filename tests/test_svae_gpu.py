@@ -225,6 +225,69 @@ def test_eval_metrics_golden(golden, case):
     assert rel(e, g['entropy']) < 1e-5 and rel(p_, g['purity']) < 1e-5
 
 
+def test_imputation_golden(golden):
+    """generate_missing_data_mask, perturb_data, imputation_mse, imputation_losses
+    (reference losses.py:148-310) vs the reference run; the (N,K,S,D)-sized parts in the eval HIP kernel."""
+    from vmp_for_svae_amd import losses
+    g = golden('imputation')
+    N, K, S, D, P = [int(v) for v in g['in_dims']]
+    y, noise = dev(g['in_y']), dev(g['in_noise'])
+    mask = losses.generate_missing_data_mask(y, float(g['in_mask_ratio']), seed=int(g['in_mask_seed']))
+    assert mask.dtype == torch.bool and np.array_equal(mask.cpu().numpy(), g['mask'].astype(bool))
+    for typ, n_, key in (('quarter', 3, 'mask_quarter'), ('left_half', 2, 'mask_left_half')):
+        m2 = losses.generate_missing_data_mask(torch.zeros(n_, 16, device='cuda'), mask_type=typ)
+        assert np.array_equal(m2.cpu().numpy(), g[key].astype(bool))
+    assert rel(losses.perturb_data(y, mask, 0, noise=noise[0]), g['perturbed0']) < 1e-6
+    assert rel(losses.imputation_mse(y, dev(g['in_y_pred']), dev(g['in_r']), mask), g['imputation_mse']) < 1e-5
+    a_ks, b_ksd, Wr = [dev(g['in_' + k]) for k in ('a_ks', 'b_ksd', 'Wr')]
+
+    def method(y_pert):
+        mean = (y_pert[:, None, None, :] * a_ks[None, :, :, None] + b_ksd[None]).contiguous()
+        var = (0.3 + 0.5 * (y_pert[:, None, None, :] * a_ks[None, :, :, None]) ** 2).contiguous()
+        logits = y_pert @ Wr
+        return mean, var, logits - torch.logsumexp(logits, dim=1, keepdim=True)
+    mse, ll = losses.imputation_losses(y, mask, method, nb_samples_pert=P, nb_samples_rec=S, noise=noise)
+    assert rel(mse, g['imp_mse']) < 1e-5 and rel(ll, g['imp_loglike']) < 1e-5
+    # default noise path: different perturbations, finite results
+    mse2, ll2 = losses.imputation_losses(y, mask, method, nb_samples_pert=3, nb_samples_rec=S, seed=1)
+    assert torch.isfinite(mse2) and torch.isfinite(ll2)
+
+
+def test_checkpoint_resume_and_imputation_eval(tmp_path):
+    """8f rank 3/2: a run restored from save_checkpoint continues bit-for-bit (parameters, theta, Adam slots, step
+    counters); the imputation measurement of experiments.py:361-377 runs on the trained model."""
+    from vmp_for_svae_amd import experiments, losses
+    from vmp_for_svae_amd.models import vae
+    from vmp_for_svae_amd.training import SVAETrainer
+    K, Ld, U, Dy, S, N = 6, 3, 20, 4, 5, 96
+    g = torch.Generator(device='cuda').manual_seed(11)
+    y = torch.randn(N, Dy, device='cuda', generator=g) * 2
+    noises = [torch.randn(N, K, Ld, S, device='cuda', generator=g) for _ in range(5)]
+    zd = [torch.randint(0, K, (N, S), device='cuda', generator=g) for _ in range(5)]
+
+    def fresh():
+        vae.reset_variables()
+        return SVAETrainer(K, Ld, U, Dy, nb_samples=S, lr=1e-2, lrcvi=0.3, decay_rate=0.95, stddev_init_nn=0.1)
+    tr = fresh()
+    for i in range(3):
+        tr.step(y, noise=noises[i], z_draws=zd[i])
+    path = experiments.save_checkpoint(tr, str(tmp_path / 'ck.npz'))
+    for i in range(3, 5):
+        tr.step(y, noise=noises[i], z_draws=zd[i])
+    want = {k: v.copy() for k, v in experiments.checkpoint_state(tr).items()}
+    tr2 = experiments.load_checkpoint(fresh(), path)
+    assert tr2.global_step == 3
+    for i in range(3, 5):
+        tr2.step(y, noise=noises[i], z_draws=zd[i])
+    got = experiments.checkpoint_state(tr2)
+    assert set(got) == set(want)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    mask = losses.generate_missing_data_mask(y, 0.25, seed=0)
+    m = experiments.evaluate_imputation(tr2, y, mask, nb_samples_pert=3, nb_samples_te=7, seed=0)
+    assert np.isfinite(m['imp_mse']) and np.isfinite(m['imp_logprob']) and m['imp_mse'] > 0
+
+
 def test_driver_pinwheel_converges():
     """End-to-end (8f rank 3): the experiments driver on pinwheel (reference config: K=10, L=2, U=50, minibatch 100,
     lr 0.01, lrcvi 0.1).  The negative normalised ELBO must fall and the held-out log-likelihood must rise."""

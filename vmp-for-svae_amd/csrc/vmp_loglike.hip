@@ -108,7 +108,7 @@ struct EvArgs {
     float* mse;             // (N,K) or NULL
     float* lse;             // (N,K) or NULL
     long long cells;
-    int K, S, Dy, logw_per_sample;
+    int K, S, Dy, logw_per_sample, mask_mse;
 };
 
 __global__ __launch_bounds__(256) void eval_kernel(EvArgs a) {
@@ -134,11 +134,11 @@ __global__ __launch_bounds__(256) void eval_kernel(EvArgs a) {
                 float q = 0.f, lp = 0.f;
                 for (int d = 0; d < Dy; ++d) {
                     const float df = yr[d] - a.mean[base + d];
-                    q = fmaf(df, df, q);
+                    const float m = a.mask ? (a.mask[n * Dy + d] ? 1.f : 0.f) : 1.f;
+                    q = fmaf(a.mask_mse ? m * df : df, df, q);
                     if (a.var) {
                         const float v = a.var[base + d];
                         const float term = df * df / v + logf(v) + LOG2PI;
-                        const float m = a.mask ? (a.mask[n * Dy + d] ? 1.f : 0.f) : 1.f;
                         lp = fmaf(-0.5f * m, term, lp);
                     }
                 }
@@ -203,12 +203,13 @@ int vmp_diag_gauss_loglike_bwd(const float* y, const float* mean, const float* v
 }
 
 int vmp_eval_cell_metrics(const float* y, const float* mean, const float* var, const float* logw, int logw_per_sample,
-                          const uint8_t* mask, int64_t N, int K, int S, int Dy, float* mse, float* lse, void* stream) {
+                          const uint8_t* mask, int mask_mse, int64_t N, int K, int S, int Dy, float* mse, float* lse,
+                          void* stream) {
     if (!y || !mean || N <= 0 || K <= 0 || S <= 0 || Dy <= 0 || (!mse && !lse) || (lse && !var)) {
         set_error("vmp_eval_cell_metrics: bad argument");
         return VMP_E_BADARG;
     }
-    EvArgs a{y, mean, var, logw, mask, mse, lse, (long long)N * K, K, S, Dy, logw_per_sample};
+    EvArgs a{y, mean, var, logw, mask, mse, lse, (long long)N * K, K, S, Dy, logw_per_sample, (mask && mask_mse) ? 1 : 0};
     const int SL = S < WAVE ? S : WAVE, CPT = WAVE / SL;
     long long blocks = (((long long)N * K + CPT - 1) / CPT + 3) / 4;
     if (blocks > 4096) blocks = 4096;

@@ -29,8 +29,82 @@ def evaluate(tr, y, labels, nb_samples, seed=0):
     return out
 
 
+def evaluate_imputation(tr, y, missing_data_mask, nb_samples_pert=20, nb_samples_te=100, seed=0):
+    """experiments.py:361-377: missing entries are replaced by noise nb_samples_pert times, each perturbed set is pushed
+    through svae.inference with nb_samples_te samples, and the imputations are scored on the missing entries."""
+    def impute(y_perturbed):                                          # experiments.py:365-372
+        (y_k_mean, out2), _, _, _, log_r_nk, _, _ = svae.inference(
+            y_perturbed.contiguous(), tr.phi_gmm, tr.encoder_layers, tr.decoder_layers, nb_samples_te,
+            stddev_init_nn=tr.stddev_init_nn, seed=seed)
+        return y_k_mean, out2, log_r_nk
+    with torch.no_grad():
+        mse, lopr = losses.imputation_losses(y, missing_data_mask, impute, nb_samples_pert, nb_samples_te, seed=seed)
+    return {'imp_mse': float(mse), 'imp_logprob': float(lopr)}
+
+
+THETA_NAMES = ('alpha_k', 'A', 'b', 'beta_k', 'v_hat')               # natural parameters, svae.py:433-458
+
+
+def checkpoint_state(tr):
+    """Everything a run needs to resume (the reference's tf.train.Saver covers the same variables, experiments.py:357,
+    433-440): MLP weights, phi_gmm, theta, Adam slots, step counters - keyed by the reference's variable names."""
+    st = {}
+    names, params = tr.trainables()
+    for n, p in zip(names, params):
+        st[n] = p.detach().cpu().numpy()
+    if tr.smm:
+        st['theta/alpha_k'] = tr.theta[0].detach().cpu().numpy()
+        st['theta/DoF'] = tr.theta[3].detach().cpu().numpy()
+    else:
+        for n, t in zip(THETA_NAMES, tr.theta):
+            st['theta/' + n] = t.detach().cpu().numpy()
+    st['global_step'] = np.array(tr.global_step)
+    if tr.opt is not None:
+        st['adam/t'] = np.array(tr.opt.t)
+        for n, m, v in zip(names, tr.opt.m, tr.opt.v):
+            st['adam/m/' + n] = m.cpu().numpy()
+            st['adam/v/' + n] = v.cpu().numpy()
+    return st
+
+
+def save_checkpoint(tr, path):
+    np.savez(path, **checkpoint_state(tr))
+    return path
+
+
+def load_checkpoint(tr, path):
+    """Restore a trainer created with the same configuration from save_checkpoint's .npz."""
+    from .training import TFAdam
+    z = np.load(path)
+    # make sure the MLP variables exist (they are created lazily by the first forward pass)
+    dev = tr.device
+    if not vae.net_variables('decoder_net'):
+        Dy = tr.decoder_layers[-1][0]
+        vae.make_encoder(torch.zeros(1, Dy, device=dev), tr.encoder_layers, tr.stddev_init_nn, seed=tr.seed)
+        vae.decoder_variables(tr.L, tr.decoder_layers, tr.stddev_init_nn, tr.seed, dev)
+    names, params = tr.trainables()
+    with torch.no_grad():
+        for n, p in zip(names, params):
+            p.copy_(torch.as_tensor(z[n]).to(dev))
+        if tr.smm:
+            tr.theta[0].copy_(torch.as_tensor(z['theta/alpha_k']).to(dev))
+            tr.theta[3].copy_(torch.as_tensor(z['theta/DoF']).to(dev))
+        else:
+            for n, t in zip(THETA_NAMES, tr.theta):
+                t.copy_(torch.as_tensor(z['theta/' + n]).to(dev))
+    tr.global_step = int(z['global_step'])
+    if 'adam/t' in z.files:
+        tr.opt = TFAdam(params, tr.lr)
+        tr.opt.t = int(z['adam/t'])
+        for n, m, v in zip(names, tr.opt.m, tr.opt.v):
+            m.copy_(torch.as_tensor(z['adam/m/' + n]).to(dev))
+            v.copy_(torch.as_tensor(z['adam/v/' + n]).to(dev))
+    return tr
+
+
 def run(config, nb_iters=2000, size_minibatch=100, nb_samples=10, nb_samples_te=100, measurement_freq=500,
-        path_dataset=None, device='cuda', verbose=True, ratio_tr=0.7):
+        path_dataset=None, device='cuda', verbose=True, ratio_tr=0.7, imputation_freq=None, nb_samples_pert=20,
+        ratio_missing_data=0.1, checkpoint_freq=None, checkpoint_dir=None):
     torch.manual_seed(config.get('seed', 0))
     vae.reset_variables()
     X, lab = data_mod.load_dataset(config['dataset'], path_dataset)
@@ -44,6 +118,7 @@ def run(config, nb_iters=2000, size_minibatch=100, nb_samples=10, nb_samples_te=
                      device=dev, smm=smm, dof=config.get('DoF', 5))
     batches = data_mod.minibatches(X_tr, size_minibatch, seed=config.get('seed', 0))
     log_id = generate_log_id(config)
+    missing_data_mask = losses.generate_missing_data_mask(Xte, ratio_missing_data, seed=config.get('seed', 0))
     history = []
     t0 = time.time()
     for i in range(nb_iters):
@@ -52,10 +127,17 @@ def run(config, nb_iters=2000, size_minibatch=100, nb_samples=10, nb_samples_te=
         if i % measurement_freq == 0 or i == nb_iters - 1:
             m = evaluate(tr, Xte, Lte, nb_samples_te, seed=config.get('seed', 0))
             m['iter'], m['neg_normed_elbo'] = i, -float(out['elbo']) / size_minibatch      # experiments.py:318-320
+            if imputation_freq and (i % imputation_freq == 0 or i == nb_iters - 1):       # experiments.py:446-452
+                m.update(evaluate_imputation(tr, Xte, missing_data_mask, nb_samples_pert, nb_samples_te,
+                                             seed=config.get('seed', 0)))
             history.append(m)
             if verbose:
                 print('Iteration %5d\t\t%.4fsec\t\t%.4f   %s' % (i, time.time() - t0, m['neg_normed_elbo'],
                                                                  {k: round(v, 4) for k, v in m.items() if k not in ('iter', 'neg_normed_elbo')}))
+        if checkpoint_freq and checkpoint_dir and (i % checkpoint_freq == 0 or i == nb_iters - 1):
+            import os
+            os.makedirs(checkpoint_dir, exist_ok=True)
+            save_checkpoint(tr, os.path.join(checkpoint_dir, '%s_iter%d.npz' % (log_id, i)))   # experiments.py:433-440
     return tr, history, log_id
 
 
