@@ -197,7 +197,9 @@ int    vmp_diag_gauss_loglike_bwd(const float* y, const float* mean, const float
  *   fwd: ll (N,K,S) and/or (mean, var) (N,K,S,Dy) - either may be NULL (K = S = 1 gives the plain decoder);
  *        y may be NULL when ll is.
  *   bwd: given gA (N,K) = dLoss/dA_nk writes dx (N,K,S,L) and the flat parameter gradient
- *        dparams [W0|b0|W1|b1|W2|b2|Ws|bs1|bs2] (vmp_decoder_param_words floats); deterministic.            */
+ *        dparams [W0|b0|W1|b1|W2|b2|Ws|bs1|bs2] (vmp_decoder_param_words floats); deterministic.  With ll != NULL
+ *        the same pass also writes ll (N,K,S) - value and gradient from one launch, for callers that know gA
+ *        beforehand (the ELBO's dLoss/dA_nk = r_nk / 2S does not depend on the decoder).                     */
 int    vmp_decoder_param_words(int L, int U, int Dy);
 size_t vmp_decoder_workspace_bytes(int64_t N, int K, int S, int L, int U, int Dy);
 int    vmp_decoder_loglike_fwd(const float* x, const float* y, const float* W0, const float* b0, const float* W1,
@@ -207,7 +209,7 @@ int    vmp_decoder_loglike_fwd(const float* x, const float* y, const float* W0, 
 int    vmp_decoder_loglike_bwd(const float* x, const float* y, const float* gA, const float* W0, const float* b0,
                                const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws,
                                const float* bs1, const float* bs2, int64_t N, int K, int S, int L, int Dy, int U,
-                               float* dx, float* dparams, void* ws, size_t ws_bytes, void* stream);
+                               float* dx, float* dparams, float* ll, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stand-alone per-cell log-densities (forward only; the training step uses the fused kernels above)

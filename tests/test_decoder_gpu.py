@@ -126,3 +126,27 @@ def test_fused_decoder_full_size_properties():
     assert torch.equal(torch.cat([g1[0], g2[0]]), gr[0])
     for a, b, c in zip(gr[1:], g1[1:], g2[1:]):
         assert relerr(b + c, a) < 2e-5
+
+
+@pytest.mark.parametrize('scale', [1.0, -0.37])
+def test_weighted_loglike_single_launch(scale):
+    """DecoderWeightedLoglikeFn (value + all gradients from one launch of the backward kernel) == the two-launch
+    DecoderLoglikeFn contracted with the weights, including the gradient w.r.t. the weights and a non-unit upstream."""
+    from vmp_for_svae_amd.models import _svae_ops
+    N, K, S, Ld, Dy, U = 37, 10, 10, 6, 6, 50
+    x, y, r, w = make_case(N, K, S, Ld, Dy, U, seed=21)
+    f32 = lambda a: torch.tensor(a, dtype=torch.float32, device='cuda')
+    res = []
+    for fused in (True, False):
+        xg, rg = f32(x).requires_grad_(True), f32(r).requires_grad_(True)
+        wg = [f32(a).requires_grad_(True) for a in w]
+        if fused:
+            out = _svae_ops.DecoderWeightedLoglikeFn.apply(f32(y), xg, rg, *wg)
+        else:
+            out = (_svae_ops.DecoderLoglikeFn.apply(f32(y), xg, *wg) * rg).sum()
+        res.append([out.detach()] + list(torch.autograd.grad(out * scale, [xg, rg] + wg)))
+    for n_, a, b in zip(('value', 'x', 'weights') + NET_VARS, *res):
+        assert relerr(a, b) < 3e-6, (n_, relerr(a, b))
+    with torch.no_grad():
+        out = _svae_ops.DecoderWeightedLoglikeFn.apply(f32(y), f32(x), f32(r), *[f32(a) for a in w])
+    assert relerr(out, res[0][0]) < 1e-6

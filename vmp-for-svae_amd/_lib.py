@@ -46,7 +46,7 @@ _SIGNATURES = {
     'vmp_decoder_param_words': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int]),
     'vmp_decoder_workspace_bytes': (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     'vmp_decoder_loglike_fwd': (_c.c_int, [_P] * 11 + [_c.c_int64] + [_c.c_int] * 5 + [_P] * 4),
-    'vmp_decoder_loglike_bwd': (_c.c_int, [_P] * 12 + [_c.c_int64] + [_c.c_int] * 5 + [_P, _P, _P, _c.c_size_t, _P]),
+    'vmp_decoder_loglike_bwd': (_c.c_int, [_P] * 12 + [_c.c_int64] + [_c.c_int] * 5 + [_P, _P, _P, _P, _c.c_size_t, _P]),
     'vmp_mix_finalize_ws': (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int] + [_P] * 6 + [_P] * 9 + [_P, _P]),
 }
 

@@ -404,6 +404,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
 
         // ---- reconstruction term: gradients w.r.t. the output slots
         f32x4 dO;
+        float llacc = 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int d = 2 * g + j;
@@ -417,6 +418,12 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             dO[j] = gm;
             dO[2 + j] = gr;
             abs2[j] += gv;
+            if (a.ll) llacc += dv ? df * df * iv + __logf(vr + 1e-8f) : 0.f;
+        }
+        if (a.ll) {                                      // value and gradient in one pass (wave-uniform branch)
+            llacc += __shfl_xor(llacc, 16);
+            llacc += __shfl_xor(llacc, 32);
+            if (ok && g == 0) a.ll[row] = llacc;
         }
         tr_write(scrB, g, c, dO);
         // ---- dh1 = W2 . dO
@@ -705,7 +712,7 @@ int vmp_decoder_loglike_fwd(const float* x, const float* y, const float* W0, con
 int vmp_decoder_loglike_bwd(const float* x, const float* y, const float* gA, const float* W0, const float* b0,
                             const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws,
                             const float* bs1, const float* bs2, int64_t N, int K, int S, int L, int Dy, int U, float* dx,
-                            float* dparams, void* ws, size_t ws_bytes, void* stream) {
+                            float* dparams, float* ll, void* ws, size_t ws_bytes, void* stream) {
     if (int e = dec_check("vmp_decoder_loglike_bwd", N, K, S, L, Dy, U)) return e;
     if (!x || !y || !gA || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !Ws || !bs1 || !bs2 || !dx || !dparams || !ws) {
         set_error("vmp_decoder_loglike_bwd: NULL argument");
@@ -724,7 +731,7 @@ int vmp_decoder_loglike_bwd(const float* x, const float* y, const float* gA, con
     }
     DecArgs a{};
     a.x = x; a.y = y; a.gA = gA; a.W0 = W0; a.b0 = b0; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Ws = Ws; a.bs1 = bs1; a.bs2 = bs2;
-    a.dx = dx; a.part = static_cast<float*>(ws);
+    a.dx = dx; a.part = static_cast<float*>(ws); a.ll = ll;
     a.R = (unsigned)(N * K * S); a.K = (unsigned)K; a.S = (unsigned)S; a.L = L; a.Dy = Dy; a.U = U;
     const int blocks = dec_bwd_blocks((long long)a.R);
 #define DEC_BWD(UTV, VLV)                                                                                             \

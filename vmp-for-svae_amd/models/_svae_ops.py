@@ -220,13 +220,70 @@ class DecoderLoglikeFn(torch.autograd.Function):
         nbytes = L.lib().vmp_decoder_workspace_bytes(N, K, S, Ld, U, Dy)
         ws = L.workspace(x.device, nbytes)
         L.check(L.lib().vmp_decoder_loglike_bwd(L.ptr(x), L.ptr(y), L.ptr(gA), *[L.ptr(p) for p in params], N, K, S, Ld, Dy,
-                                                U, L.ptr(dx), L.ptr(dp), L.ptr(ws), nbytes, L.stream()),
+                                                U, L.ptr(dx), L.ptr(dp), None, L.ptr(ws), nbytes, L.stream()),
                 'vmp_decoder_loglike_bwd')
+        return (None, dx) + tuple(_split_flat(dp, params))
+
+
+def _split_flat(dp, params):
+    grads, o = [], 0
+    for p in params:
+        grads.append(dp[o:o + p.numel()].reshape(p.shape))
+        o += p.numel()
+    return grads
+
+
+class DecoderWeightedLoglikeFn(torch.autograd.Function):
+    """(y, x (N,K,S,L), w (N,K), 9 decoder parameters) -> scalar  sum_nk w_nk A_nk  with A as in DecoderLoglikeFn -
+    the contraction einsum('nksd,nk->') of reference vae.py:240.  Because dLoss/dA_nk = w_nk is an INPUT, the value
+    and every gradient come out of ONE launch of the backward kernel (which recomputes the forward anyway): the
+    separate forward launch of DecoderLoglikeFn is saved.  Gradients: x, w (= A) and the 9 parameters."""
+
+    @staticmethod
+    def forward(ctx, y, x, w, *params):
+        x = _c(x, 'x_k_samples')
+        if x.dim() != 4:
+            raise L.VmpError('x must have shape (N,K,S,L)')
+        N, K, S, _ = x.shape
+        params = [_c(p, n) for p, n in zip(params, DECODER_PARAM_NAMES)]
+        Ld, U, Dy = _decoder_dims(x, params)
+        y = _c(y, 'y', (N, Dy))
+        w = _c(w, 'weights', (N, K))
+        ll = torch.empty(N, K, S, dtype=torch.float32, device=x.device)
+        args = [L.ptr(p) for p in params]
+        if not any(ctx.needs_input_grad):
+            L.check(L.lib().vmp_decoder_loglike_fwd(L.ptr(x), L.ptr(y), *args, N, K, S, Ld, Dy, U, L.ptr(ll), None, None,
+                                                    L.stream()), 'vmp_decoder_loglike_fwd')
+            return (ll.sum(-1) * w).sum()
+        dx = torch.empty_like(x)
+        dp = torch.empty(L.lib().vmp_decoder_param_words(Ld, U, Dy), dtype=torch.float32, device=x.device)
+        nbytes = L.lib().vmp_decoder_workspace_bytes(N, K, S, Ld, U, Dy)
+        ws = L.workspace(x.device, nbytes)
+        L.check(L.lib().vmp_decoder_loglike_bwd(L.ptr(x), L.ptr(y), L.ptr(w), *args, N, K, S, Ld, Dy, U, L.ptr(dx),
+                                                L.ptr(dp), L.ptr(ll), L.ptr(ws), nbytes, L.stream()),
+                'vmp_decoder_loglike_bwd')
+        A = ll.sum(-1)
+        ctx.save_for_backward(A, dx, dp)
+        ctx.pshapes = [tuple(p.shape) for p in params]
+        return (A * w).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        A, dx, dp = ctx.saved_tensors
+        # dx is (N,K,S,L)-sized: rescaling it costs a full pass over HBM, so the (usual) upstream gradient of exactly
+        # 1 - compute_elbo folds its -1/2S into the weights - is detected with one scalar read-back instead
+        gs = float(g)
+        if gs != 1.0:
+            dx = dx * gs
+            dp = dp * gs
         grads, o = [], 0
-        for p in params:
-            grads.append(dp[o:o + p.numel()].reshape(p.shape))
-            o += p.numel()
-        return (None, dx) + tuple(grads)
+        for shp in ctx.pshapes:
+            n = 1
+            for v in shp:
+                n *= v
+            grads.append(dp[o:o + n].reshape(shp))
+            o += n
+        return (None, dx, A * g) + tuple(grads)
 
 
 def decoder_outputs(x, params):

@@ -139,6 +139,10 @@ class LazyReconstruction(object):
         """A (N,K) = sum_{s,d} (y - mean)^2 / var + log(var + 1e-8), differentiable w.r.t. x and the parameters."""
         return _svae_ops.DecoderLoglikeFn.apply(y, self.x, *self.params)
 
+    def weighted_loglike(self, y, weights):
+        """sum_nk weights_nk A_nk (the einsum of vae.py:240) - value and all gradients from one kernel launch."""
+        return _svae_ops.DecoderWeightedLoglikeFn.apply(y, self.x, weights, *self.params)
+
     def materialize(self):
         if self._out is None:
             self._out = _svae_ops.decoder_outputs(self.x, self.params)
@@ -182,7 +186,9 @@ def expected_diagonal_gaussian_loglike(y, means, vars, weights=None, name='diag_
         Ld = y.shape[1]
         if tuple(weights.shape) != (M, K):
             raise AssertionError('shape mismatch')
-        A = means.loglike_cells(y)
+        # -1/2 * (sum_nk w A) / S with the constant folded into the weights: the fused kernel then sees the final
+        # dLoss/dA and the upstream gradient of this term is exactly 1 for loss = -elbo
+        return -means.weighted_loglike(y, weights * (0.5 / S)) - M * Ld / 2. * float(np.log(2. * np.pi))
     else:
         M, K, S, Ld = means.shape
         if tuple(vars.shape) != tuple(means.shape) or tuple(weights.shape) != (M, K):
