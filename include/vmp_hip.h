@@ -172,6 +172,33 @@ int    vmp_svae_subsample(const float* x, const float* lz, const float* u, const
                           int L, int S_out, float* out, int64_t* z_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K-sized parameter maps of the training step, one launch each (one thread per component, fp64 inside)
+ * ------------------------------------------------------------------------------------------------
+ * vmp_svae_phi_prep_fwd : svae.unpack_recognition_gmm (svae.py:342-358) + the k-only part of compute_log_z_given_y
+ *   (svae.py:70-92):  L_k = tril(L_raw), softplus on the diagonal;  P_k = L_k L_k^T (= -2 eta2);
+ *   bias_k = -1/2 |L_k^-1 mu_k|^2 + sum_i log (L_k)_ii + log softmax(pi_raw)_k  - the inputs of vmp_svae_estep_fwd.
+ * vmp_svae_phi_prep_bwd : its adjoint: (g_hk, g_P (w.r.t. the full matrix), g_bias) -> gradients w.r.t. the three
+ *   'phi_gmm' variables (what TF's autodiff does through tril / softplus / matmul / matrix_solve / softmax).
+ * vmp_svae_theta_pack   : theta side of compute_elbo (svae.py:205-214): niw.natural_to_standard + expected_values
+ *   (niw.py:8-43), dirichlet.expected_log_pi (dirichlet.py:8-22) -> m_k, W_k = chol(E[Sigma_k])^-1 (lower),
+ *   kappa_k = sum_i log W_ii - L/2 log 2pi + E log pi_k   (no gradient: stop_gradient in the reference).
+ * vmp_svae_cvi_update   : svae.m_step in natural parameters (svae.py:154-176 = prior + raw moments, +1 on v_hat,
+ *   SURVEY appendix A.6) and update_gmm_params (svae.py:376-403): theta <- (1-rho) theta + rho theta*, in place;
+ *   theta* is also written when the s_* pointers are given.  stats = vmp_mix_stats layout (fp64).
+ *   rho_dev != NULL reads the step size from device memory (graph-captured steps).                            */
+int    vmp_svae_phi_prep_fwd(const float* mu_k, const float* L_raw, const float* pi_raw, int K, int L, float* Lk,
+                             float* P, float* bias, void* stream);
+int    vmp_svae_phi_prep_bwd(const float* mu_k, const float* L_raw, const float* pi_raw, const float* g_hk,
+                             const float* g_P, const float* g_bias, int K, int L, float* g_mu, float* g_Lraw,
+                             float* g_piraw, void* stream);
+int    vmp_svae_theta_pack(const float* alpha, const float* A, const float* b, const float* beta, const float* v_hat,
+                           int K, int L, float* m, float* W, float* kappa, void* stream);
+int    vmp_svae_cvi_update(const double* stats, const float* p_alpha, const float* p_A, const float* p_b,
+                           const float* p_beta, const float* p_vhat, float* t_alpha, float* t_A, float* t_b,
+                           float* t_beta, float* t_vhat, float* s_alpha, float* s_A, float* s_b, float* s_beta,
+                           float* s_vhat, const float* rho_dev, float rho, int K, int L, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Reconstruction term (models/vae.py:201-250, weights branch :233-248)
  * ------------------------------------------------------------------------------------------------
  * A_nk = sum_{s,d} [ (y_nd - mean_nksd)^2 / var_nksd + log(var_nksd + 1e-8) ]   -- the tensor the reference

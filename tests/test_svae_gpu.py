@@ -288,6 +288,48 @@ def test_checkpoint_resume_and_imputation_eval(tmp_path):
     assert np.isfinite(m['imp_mse']) and np.isfinite(m['imp_logprob']) and m['imp_mse'] > 0
 
 
+def test_graphed_step_matches_eager():
+    """The HIP-graph replay of the training step (training.GraphedSVAEStep) follows the eager step: same noise and
+    uniforms in, same parameters / theta / ELBO out (Adam's update is algebraically the same, rounded differently)."""
+    from vmp_for_svae_amd.models import vae
+    from vmp_for_svae_amd.training import SVAETrainer, GraphedSVAEStep
+    K, Ld, U, Dy, S, N = 10, 6, 50, 6, 10, 64
+    g = torch.Generator(device='cuda').manual_seed(5)
+    ys = [torch.randn(N, Dy, device='cuda', generator=g) * 2 for _ in range(4)]
+
+    def fresh():
+        vae.reset_variables()
+        return SVAETrainer(K, Ld, U, Dy, nb_samples=S, lr=3e-3, lrcvi=0.2, decay_rate=0.95, stddev_init_nn=0.1, seed=3)
+    # eager reference run with the generator protocol of GraphedSVAEStep (3 warm-up steps, one discarded refresh)
+    tr = fresh()
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    noise, u = torch.empty(N, K, Ld, S, device='cuda'), torch.empty(N, 1, device='cuda')
+    elbos = []
+    for i in range(3 + 1 + 4):
+        noise.normal_(generator=gen)
+        u.uniform_(generator=gen)
+        if i == 3:
+            continue
+        y = ys[0] if i < 3 else ys[i - 4]
+        elbos.append(tr.step(y, noise=noise, u=u)['elbo'].item())
+    _, want = tr.trainables()
+    want = [p.detach().clone() for p in want] + [t.clone() for t in tr.theta]
+    # graphed run
+    tr2 = fresh()
+    gs = GraphedSVAEStep(tr2, ys[0], warmup=3)
+    got_elbo = []
+    for i in range(4):
+        out = gs(ys[i])
+        got_elbo.append(out['elbo'].item())
+    assert tr2.global_step == 7 and tr2.opt.t == 7
+    _, got = tr2.trainables()
+    got = list(got) + list(tr2.theta)
+    for a, b in zip(got_elbo, elbos[3:]):
+        assert abs(a - b) <= 2e-5 * abs(b), (a, b)
+    for a, b in zip(got, want):
+        assert rel(a, b.double().cpu().numpy()) < 2e-5
+
+
 def test_driver_pinwheel_converges():
     """End-to-end (8f rank 3): the experiments driver on pinwheel (reference config: K=10, L=2, U=50, minibatch 100,
     lr 0.01, lrcvi 0.1).  The negative normalised ELBO must fall and the held-out log-likelihood must rise."""

@@ -1,0 +1,269 @@
+// K-sized parameter maps of the SVAE training step (reference models/svae.py:342-358 unpack_recognition_gmm,
+// :205-214 the theta side of compute_elbo via distributions/niw.py:8-43 + dirichlet.py:8-22, :154-176 m_step and
+// :376-403 update_gmm_params) as single-launch kernels: one thread per mixture component, fp64 inside, fp32 in/out.
+// At the reference's real operating point (minibatches of 64-100 rows) the step is bound by the NUMBER of launches:
+// these maps were ~120 tiny torch kernels (batched Cholesky / triangular solves with host-side error checks, tril,
+// softplus, digamma ...) and their autograd; here they are 4 launches.
+#include "vmp_common.h"
+
+using namespace vmp;
+
+namespace {
+
+constexpr int PREP_THREADS = 64;     // K <= VMP_MAX_K = 64
+constexpr int ML = VMP_MAX_D;        // L <= 8
+
+__device__ __forceinline__ double softplus_d(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
+
+__device__ double digamma_dd(double x) {
+    double r = 0.0;
+    while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
+    const double f = 1.0 / (x * x);
+    return r + log(x) - 0.5 / x
+           - f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f * (1.0 / 132 - f * (691.0 / 32760))))));
+}
+
+// L_k = tril(raw) with softplus on the diagonal (svae.py:347-352), rounded to fp32 as the tensors the reference holds
+__device__ __forceinline__ void load_Lk(const float* __restrict__ raw, int L, double (&Lm)[ML][ML]) {
+    for (int i = 0; i < L; ++i)
+        for (int j = 0; j < L; ++j) {
+            double v = 0.0;
+            if (j < i) v = (double)raw[i * L + j];
+            else if (j == i) v = (double)(float)softplus_d((double)raw[i * L + i]);
+            Lm[i][j] = v;
+        }
+}
+
+struct PhiArgs {
+    const float* mu;      // (K,L)  'phi_gmm/mu_k' (used as eta1, svae.py:345)
+    const float* Lraw;    // (K,L,L)
+    const float* piraw;   // (K)
+    const float* g_hk;    // bwd: (K,L)
+    const float* g_P;     // bwd: (K,L,L) gradient w.r.t. the full matrix P = L L^T
+    const float* g_bias;  // bwd: (K)
+    float* Lk;            // fwd out (K,L,L)
+    float* P;             // fwd out (K,L,L)
+    float* bias;          // fwd out (K): B_k + log softmax(piraw)_k
+    float* g_mu;          // bwd out
+    float* g_Lraw;        // bwd out
+    float* g_piraw;       // bwd out
+    int K, L;
+};
+
+__device__ __forceinline__ void log_softmax_stats(const float* __restrict__ piraw, int K, double& mx, double& lse) {
+    mx = -1e300;
+    for (int j = 0; j < K; ++j) mx = fmax(mx, (double)piraw[j]);
+    double s = 0.0;
+    for (int j = 0; j < K; ++j) s += exp((double)piraw[j] - mx);
+    lse = mx + log(s);
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(PREP_THREADS) void phi_prep_kernel(PhiArgs a) {
+    const int k = threadIdx.x, K = a.K, L = a.L;
+    __shared__ double s_gb;
+    if (BWD && k == 0) {
+        double t = 0.0;
+        for (int j = 0; j < K; ++j) t += (double)a.g_bias[j];
+        s_gb = t;
+    }
+    __syncthreads();
+    if (k >= K) return;
+    double Lm[ML][ML];
+    load_Lk(a.Lraw + (size_t)k * L * L, L, Lm);
+    double h[ML], s[ML];
+    for (int i = 0; i < L; ++i) h[i] = (double)a.mu[k * L + i];
+    double B = 0.0;
+    for (int i = 0; i < L; ++i) {                       // s = L^-1 h
+        double t = h[i];
+        for (int j = 0; j < i; ++j) t -= Lm[i][j] * s[j];
+        s[i] = t / Lm[i][i];
+        B += -0.5 * s[i] * s[i] + log(Lm[i][i]);
+    }
+    double mx, lse;
+    log_softmax_stats(a.piraw, K, mx, lse);
+    const double logpi = (double)a.piraw[k] - lse;
+    if (!BWD) {
+        for (int i = 0; i < L; ++i)
+            for (int j = 0; j < L; ++j) {
+                a.Lk[((size_t)k * L + i) * L + j] = (float)Lm[i][j];
+                double p = 0.0;
+                const int m = i < j ? i : j;
+                for (int q = 0; q <= m; ++q) p += Lm[i][q] * Lm[j][q];
+                a.P[((size_t)k * L + i) * L + j] = (float)p;
+            }
+        a.bias[k] = (float)(B + logpi);
+        return;
+    }
+    // ---- backward
+    double u[ML];                                       // u = L^-T s = P^-1 h
+    for (int i = L - 1; i >= 0; --i) {
+        double t = s[i];
+        for (int j = i + 1; j < L; ++j) t -= Lm[j][i] * u[j];
+        u[i] = t / Lm[i][i];
+    }
+    const double gb = (double)a.g_bias[k];
+    for (int i = 0; i < L; ++i) a.g_mu[k * L + i] = (float)((double)a.g_hk[k * L + i] - gb * u[i]);
+    a.g_piraw[k] = (float)(gb - exp(logpi) * s_gb);
+    const float* __restrict__ G = a.g_P + (size_t)k * L * L;
+    for (int i = 0; i < L; ++i)
+        for (int j = 0; j < L; ++j) {
+            double g = 0.0;
+            if (j <= i) {
+                for (int q = j; q < L; ++q) g += ((double)G[i * L + q] + (double)G[q * L + i]) * Lm[q][j];   // (G + G^T) L
+                g += gb * u[i] * s[j];
+                if (i == j) {
+                    g += gb / Lm[i][i];
+                    const double r = (double)a.Lraw[((size_t)k * L + i) * L + i];
+                    g *= 1.0 / (1.0 + exp(-r));         // softplus'
+                }
+            }
+            a.g_Lraw[((size_t)k * L + i) * L + j] = (float)g;
+        }
+}
+
+struct ThetaArgs {
+    const float *alpha, *A, *b, *beta, *vhat;     // natural NIW / Dirichlet parameters
+    float* m;        // (K,L)
+    float* W;        // (K,L,L) lower, W^T W = E[Sigma]^-1
+    float* kappa;    // (K)
+    int K, L;
+};
+
+__global__ __launch_bounds__(PREP_THREADS) void theta_pack_kernel(ThetaArgs a) {
+    const int k = threadIdx.x, K = a.K, L = a.L;
+    if (k >= K) return;
+    double asum = 0.0;
+    for (int j = 0; j < K; ++j) asum += (double)a.alpha[j] + 1.0;            // dirichlet.natural_to_standard
+    const double elp = digamma_dd((double)a.alpha[k] + 1.0) - digamma_dd(asum);
+    const double beta = (double)a.beta[k], nu = (double)a.vhat[k] - (double)(L + 2);   // niw.natural_to_standard
+    double mv[ML], C[ML][ML];
+    for (int i = 0; i < L; ++i) mv[i] = (double)a.b[k * L + i] / beta;
+    for (int i = 0; i < L; ++i)
+        for (int j = 0; j < L; ++j) C[i][j] = (double)a.A[((size_t)k * L + i) * L + j] - (double)a.b[k * L + i] * mv[j];
+    // E[Sigma] = (nu sym(C)^-1)^-1 = sym(C) / nu  (niw.expected_values); Cholesky, then W = Lc^-1
+    double Lc[ML][ML];
+    for (int j = 0; j < L; ++j) {
+        for (int i = j; i < L; ++i) {
+            double t = 0.5 * (C[i][j] + C[j][i]) / nu;
+            for (int q = 0; q < j; ++q) t -= Lc[i][q] * Lc[j][q];
+            Lc[i][j] = (i == j) ? sqrt(t) : t / Lc[j][j];
+        }
+    }
+    double kap = -0.5 * L * 1.8378770664093454836 + elp;
+    for (int j = 0; j < L; ++j) {                       // column j of Lc^-1
+        double w[ML];
+        for (int i = 0; i < L; ++i) {
+            double t = (i == j) ? 1.0 : 0.0;
+            for (int q = j; q < i; ++q) t -= Lc[i][q] * w[q];
+            w[i] = (i < j) ? 0.0 : t / Lc[i][i];
+            a.W[((size_t)k * L + i) * L + j] = (float)w[i];
+        }
+        kap += log(w[j]);
+    }
+    for (int i = 0; i < L; ++i) a.m[k * L + i] = (float)mv[i];
+    a.kappa[k] = (float)kap;
+}
+
+struct CviArgs {
+    const double* stats;                           // (K, 2+L+L*L): [Nk | Wk | sx | sxx]
+    const float *p_alpha, *p_A, *p_b, *p_beta, *p_vhat;   // prior (natural)
+    float *t_alpha, *t_A, *t_b, *t_beta, *t_vhat;         // theta (natural), updated in place
+    float *s_alpha, *s_A, *s_b, *s_beta, *s_vhat;         // theta* out (may be NULL)
+    const float* rho_dev;                          // step size on the device (NULL: use rho)
+    float rho;
+    int K, L;
+};
+
+__device__ __forceinline__ void cvi_one(float* __restrict__ t, float* __restrict__ s, float star, float rho, size_t i) {
+    if (s) s[i] = star;
+    t[i] = t[i] * (1.0f - rho) + rho * star;       // update_gmm_params: theta <- (1-rho) theta + rho theta*
+}
+
+__global__ __launch_bounds__(256) void cvi_kernel(CviArgs a) {
+    const int K = a.K, L = a.L, SW = 2 + L + L * L;
+    const float rho = a.rho_dev ? *a.rho_dev : a.rho;
+    const int per = L * L + L + 3;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < K * per; e += gridDim.x * blockDim.x) {
+        const int k = e / per, f = e - k * per;
+        const double* __restrict__ st = a.stats + (size_t)k * SW;
+        const float Nk = (float)st[0];
+        if (f < L * L) {
+            const size_t i = (size_t)k * L * L + f;
+            cvi_one(a.t_A, a.s_A, a.p_A[i] + (float)st[2 + L + f], rho, i);
+        } else if (f < L * L + L) {
+            const int d = f - L * L;
+            const size_t i = (size_t)k * L + d;
+            cvi_one(a.t_b, a.s_b, a.p_b[i] + (float)st[2 + d], rho, i);
+        } else if (f == L * L + L) {
+            cvi_one(a.t_alpha, a.s_alpha, a.p_alpha[k] + Nk, rho, k);
+        } else if (f == L * L + L + 1) {
+            cvi_one(a.t_beta, a.s_beta, a.p_beta[k] + Nk, rho, k);
+        } else {
+            cvi_one(a.t_vhat, a.s_vhat, a.p_vhat[k] + Nk + 1.0f, rho, k);   // the +1 of gmm.update_vk (gmm.py:81)
+        }
+    }
+}
+
+int prep_check(const char* what, int K, int L) {
+    if (K < 1 || K > VMP_MAX_K || L < 1 || L > VMP_MAX_D) {
+        set_error("%s: K=%d, L=%d outside the compiled range (K <= %d, L <= %d)", what, K, L, VMP_MAX_K, VMP_MAX_D);
+        return VMP_E_DIM;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vmp_svae_phi_prep_fwd(const float* mu_k, const float* L_raw, const float* pi_raw, int K, int L, float* Lk, float* P,
+                          float* bias, void* stream) {
+    if (int e = prep_check("vmp_svae_phi_prep_fwd", K, L)) return e;
+    if (!mu_k || !L_raw || !pi_raw || !Lk || !P || !bias) { set_error("vmp_svae_phi_prep_fwd: NULL argument"); return VMP_E_BADARG; }
+    PhiArgs a{};
+    a.mu = mu_k; a.Lraw = L_raw; a.piraw = pi_raw; a.Lk = Lk; a.P = P; a.bias = bias; a.K = K; a.L = L;
+    hipLaunchKernelGGL((phi_prep_kernel<false>), dim3(1), dim3(PREP_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch("vmp_svae_phi_prep_fwd");
+}
+
+int vmp_svae_phi_prep_bwd(const float* mu_k, const float* L_raw, const float* pi_raw, const float* g_hk, const float* g_P,
+                          const float* g_bias, int K, int L, float* g_mu, float* g_Lraw, float* g_piraw, void* stream) {
+    if (int e = prep_check("vmp_svae_phi_prep_bwd", K, L)) return e;
+    if (!mu_k || !L_raw || !pi_raw || !g_hk || !g_P || !g_bias || !g_mu || !g_Lraw || !g_piraw) {
+        set_error("vmp_svae_phi_prep_bwd: NULL argument");
+        return VMP_E_BADARG;
+    }
+    PhiArgs a{};
+    a.mu = mu_k; a.Lraw = L_raw; a.piraw = pi_raw; a.g_hk = g_hk; a.g_P = g_P; a.g_bias = g_bias;
+    a.g_mu = g_mu; a.g_Lraw = g_Lraw; a.g_piraw = g_piraw; a.K = K; a.L = L;
+    hipLaunchKernelGGL((phi_prep_kernel<true>), dim3(1), dim3(PREP_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch("vmp_svae_phi_prep_bwd");
+}
+
+int vmp_svae_theta_pack(const float* alpha, const float* A, const float* b, const float* beta, const float* v_hat, int K,
+                        int L, float* m, float* W, float* kappa, void* stream) {
+    if (int e = prep_check("vmp_svae_theta_pack", K, L)) return e;
+    if (!alpha || !A || !b || !beta || !v_hat || !m || !W || !kappa) { set_error("vmp_svae_theta_pack: NULL argument"); return VMP_E_BADARG; }
+    ThetaArgs a{alpha, A, b, beta, v_hat, m, W, kappa, K, L};
+    hipLaunchKernelGGL(theta_pack_kernel, dim3(1), dim3(PREP_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch("vmp_svae_theta_pack");
+}
+
+int vmp_svae_cvi_update(const double* stats, const float* p_alpha, const float* p_A, const float* p_b, const float* p_beta,
+                        const float* p_vhat, float* t_alpha, float* t_A, float* t_b, float* t_beta, float* t_vhat,
+                        float* s_alpha, float* s_A, float* s_b, float* s_beta, float* s_vhat, const float* rho_dev,
+                        float rho, int K, int L, void* stream) {
+    if (int e = prep_check("vmp_svae_cvi_update", K, L)) return e;
+    if (!stats || !p_alpha || !p_A || !p_b || !p_beta || !p_vhat || !t_alpha || !t_A || !t_b || !t_beta || !t_vhat) {
+        set_error("vmp_svae_cvi_update: NULL argument");
+        return VMP_E_BADARG;
+    }
+    CviArgs a{stats, p_alpha, p_A, p_b, p_beta, p_vhat, t_alpha, t_A, t_b, t_beta, t_vhat,
+              s_alpha, s_A, s_b, s_beta, s_vhat, rho_dev, rho, K, L};
+    const int n = K * (L * L + L + 3);
+    hipLaunchKernelGGL(cvi_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch("vmp_svae_cvi_update");
+}
+
+}  // extern "C"

@@ -272,10 +272,13 @@ class DecoderWeightedLoglikeFn(torch.autograd.Function):
         A, dx, dp = ctx.saved_tensors
         # dx is (N,K,S,L)-sized: rescaling it costs a full pass over HBM, so the (usual) upstream gradient of exactly
         # 1 - compute_elbo folds its -1/2S into the weights - is detected with one scalar read-back instead
-        gs = float(g)
-        if gs != 1.0:
-            dx = dx * gs
-            dp = dp * gs
+        if torch.cuda.is_current_stream_capturing():     # no host read-back inside a graph capture
+            dx, dp = dx * g, dp * g
+        else:
+            gs = float(g)
+            if gs != 1.0:
+                dx = dx * gs
+                dp = dp * gs
         grads, o = [], 0
         for shp in ctx.pshapes:
             n = 1
@@ -298,3 +301,66 @@ def decoder_outputs(x, params):
     L.check(L.lib().vmp_decoder_loglike_fwd(L.ptr(x2), None, *[L.ptr(p) for p in params], R, 1, 1, Ld, Dy, U, None,
                                             L.ptr(mean), L.ptr(var), L.stream()), 'vmp_decoder_loglike_fwd')
     return mean.reshape(shape[:-1] + (Dy,)), var.reshape(shape[:-1] + (Dy,))
+
+
+class PhiPrepFn(torch.autograd.Function):
+    """(mu_k, L_k_raw, pi_k_raw) -> (h_k = mu_k, P_k = L L^T, bias_k) - the K-sized inputs of the fused E-step -
+    one launch forward, one backward (reference svae.py:342-358 and :70-92; csrc/vmp_prep.hip)."""
+
+    @staticmethod
+    def forward(ctx, mu_k, L_raw, pi_raw):
+        mu_k = _c(mu_k, 'phi_gmm/mu_k')
+        K, Ld = mu_k.shape
+        L_raw = _c(L_raw, 'phi_gmm/L_k', (K, Ld, Ld))
+        pi_raw = _c(pi_raw, 'phi_gmm/log_pi_k', (K,))
+        f32 = dict(dtype=torch.float32, device=mu_k.device)
+        Lk, P, bias = torch.empty(K, Ld, Ld, **f32), torch.empty(K, Ld, Ld, **f32), torch.empty(K, **f32)
+        L.check(L.lib().vmp_svae_phi_prep_fwd(L.ptr(mu_k), L.ptr(L_raw), L.ptr(pi_raw), K, Ld, L.ptr(Lk), L.ptr(P),
+                                              L.ptr(bias), L.stream()), 'vmp_svae_phi_prep_fwd')
+        ctx.save_for_backward(mu_k, L_raw, pi_raw)
+        return mu_k.detach().clone(), P, bias
+
+    @staticmethod
+    def backward(ctx, g_hk, g_P, g_bias):
+        mu_k, L_raw, pi_raw = ctx.saved_tensors
+        K, Ld = mu_k.shape
+        z = lambda g, ref: torch.zeros_like(ref) if g is None else g.contiguous().float()
+        g_hk = z(g_hk, mu_k)
+        g_P = z(g_P, L_raw)
+        g_bias = z(g_bias, pi_raw)
+        g_mu, g_L, g_pi = torch.empty_like(mu_k), torch.empty_like(L_raw), torch.empty_like(pi_raw)
+        L.check(L.lib().vmp_svae_phi_prep_bwd(L.ptr(mu_k), L.ptr(L_raw), L.ptr(pi_raw), L.ptr(g_hk), L.ptr(g_P),
+                                              L.ptr(g_bias), K, Ld, L.ptr(g_mu), L.ptr(g_L), L.ptr(g_pi), L.stream()),
+                'vmp_svae_phi_prep_bwd')
+        return g_mu, g_L, g_pi
+
+
+def theta_pack_gmm(theta):
+    """(m_k, W_k, kappa_k) of a natural NIW / Dirichlet theta (no gradient, as the reference's stop_gradient)."""
+    alpha, A, b, beta, v_hat = [_c(t.detach(), n) for t, n in zip(theta, ('alpha', 'A', 'b', 'beta', 'v_hat'))]
+    K, Ld = b.shape
+    f32 = dict(dtype=torch.float32, device=b.device)
+    m, W, kappa = torch.empty(K, Ld, **f32), torch.empty(K, Ld, Ld, **f32), torch.empty(K, **f32)
+    L.check(L.lib().vmp_svae_theta_pack(L.ptr(alpha), L.ptr(A), L.ptr(b), L.ptr(beta), L.ptr(v_hat), K, Ld, L.ptr(m),
+                                        L.ptr(W), L.ptr(kappa), L.stream()), 'vmp_svae_theta_pack')
+    return m, W, kappa
+
+
+def cvi_update(gmm_prior, theta, stats, rho, want_star=True, rho_dev=None):
+    """theta <- (1 - rho) theta + rho theta*, theta* = prior + raw moments (+1 on v_hat), in place, one launch.
+    Returns theta* (5 tensors) when want_star."""
+    pri = [_c(t.detach(), 'prior') for t in gmm_prior]
+    K, Ld = pri[2].shape
+    for t in theta:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise L.VmpError('theta must be contiguous fp32 GPU tensors')
+    stats = stats.contiguous()
+    if stats.dtype != torch.float64 or tuple(stats.shape) != (K, 2 + Ld + Ld * Ld):
+        raise L.VmpError('stats must be fp64 (K, 2+L+L*L)')
+    star = [torch.empty_like(t) for t in theta] if want_star else [None] * 5
+    L.check(L.lib().vmp_svae_cvi_update(L.ptr(stats), *[L.ptr(t) for t in pri], *[L.ptr(t) for t in theta],
+                                        *[L.ptr(t) for t in star], L.ptr(rho_dev), float(rho), K, Ld, L.stream()),
+            'vmp_svae_cvi_update')
+    for t in theta:
+        torch.autograd.graph.increment_version(t)
+    return star if want_star else None

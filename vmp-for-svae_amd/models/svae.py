@@ -62,17 +62,8 @@ def _theta_pack(theta):
         kappa = (torch.lgamma(0.5 * (nu + Ld)) - torch.lgamma(0.5 * nu) - 0.5 * Ld * torch.log(math.pi * nu)
                  - torch.log(torch.diagonal(Lk, dim1=-2, dim2=-1)).sum(-1) + elp)
         return mu_k, W, kappa, nu.contiguous()
-    with torch.no_grad():
-        beta_k, m_k, C_k, v_k = niw.natural_to_standard(*theta[1:])
-        mu, sigma = niw.expected_values((beta_k, m_k, C_k, v_k))
-        sig = sigma.double()
-        Lc = torch.linalg.cholesky(0.5 * (sig + sig.transpose(-1, -2)))
-        Ld = mu.shape[-1]
-        eye = torch.eye(Ld, dtype=Lc.dtype, device=Lc.device).expand_as(Lc)
-        W = torch.linalg.solve_triangular(Lc, eye, upper=False)
-        elp = dirichlet.expected_log_pi(dirichlet.natural_to_standard(theta[0]).double())
-        kappa = torch.log(torch.diagonal(W, dim1=-2, dim2=-1)).sum(-1) - 0.5 * Ld * math.log(2 * math.pi) + elp
-        return mu.float().contiguous(), W.float().contiguous(), kappa.float().contiguous(), None
+    m, W, kappa = _svae_ops.theta_pack_gmm(theta)           # one launch (csrc/vmp_prep.hip)
+    return m, W, kappa, None
 
 
 def _neutral_theta(K, Ld, device):
@@ -84,8 +75,8 @@ class PhiTilde(object):
     """What e_step returns as `phi_tilde`: behaves like the reference's tuple (eta1 (N,K,L,1), eta2 (N,K,L,L))
     - materialised only if indexed - and carries the fused per-cell ELBO terms for compute_elbo."""
 
-    def __init__(self, eta1_phi1, eta2_diag, eta1_phi2, eta2_phi2, T_prime, theta_key):
-        self._p = (eta1_phi1, eta2_diag, eta1_phi2, eta2_phi2)
+    def __init__(self, eta1_phi1, eta2_diag, eta1_phi2, P_phi2, T_prime, theta_key):
+        self._p = (eta1_phi1, eta2_diag, eta1_phi2, P_phi2)
         self.T_prime = T_prime
         self.theta_key = theta_key
 
@@ -93,7 +84,8 @@ class PhiTilde(object):
         return 2
 
     def __getitem__(self, i):
-        e1, e2d, e1k, e2k = self._p
+        e1, e2d, e1k, Pk = self._p
+        e2k = -0.5 * Pk
         if i == 0:
             return (e1.unsqueeze(1) + e1k.unsqueeze(0)).unsqueeze(-1)
         if i == 1:
@@ -127,16 +119,15 @@ def e_step(phi_enc, phi_gmm, nb_samples, seed=0, name="e_step", noise=None, thet
     Dirichlet parameters) is given, the per-sample densities compute_elbo needs are evaluated in the same pass."""
     eta1_phi1, eta2_diag = phi_enc
     N, Ld = eta1_phi1.shape
-    eta1_phi2, eta2_phi2, pi_phi2 = unpack_recognition_gmm(phi_gmm)
+    # unpack_recognition_gmm + the k-only part of compute_log_z_given_y in one launch (autograd: one more)
+    eta1_phi2, P, bias = _svae_ops.PhiPrepFn.apply(*phi_gmm)
     K = eta1_phi2.shape[0]
-    P, bias = _recognition_bias(eta1_phi2, eta2_phi2, pi_phi2)
     if noise is None:
         g = torch.Generator(device=eta1_phi1.device).manual_seed(int(seed))
         noise = torch.randn(N, K, Ld, nb_samples, generator=g, device=eta1_phi1.device)
     mk, Wk, kap, nu = _theta_pack(theta) if theta is not None else _neutral_theta(K, Ld, eta1_phi1.device)
-    x, lz, Tp = _svae_ops.SvaeEStepFn.apply(eta1_phi1, eta2_diag, eta1_phi2.contiguous(), P.contiguous(), bias, noise,
-                                            mk, Wk, kap, nu)
-    phi_tilde = PhiTilde(eta1_phi1, eta2_diag, eta1_phi2, eta2_phi2, Tp if theta is not None else None, _theta_key(theta))
+    x, lz, Tp = _svae_ops.SvaeEStepFn.apply(eta1_phi1, eta2_diag, eta1_phi2, P, bias, noise, mk, Wk, kap, nu)
+    phi_tilde = PhiTilde(eta1_phi1, eta2_diag, eta1_phi2, P, Tp if theta is not None else None, _theta_key(theta))
     return x, lz, phi_tilde, (None, None)
 
 
@@ -144,7 +135,7 @@ def sample_x_per_comp(eta1, eta2, nb_samples, seed=0):
     raise NotImplementedError('fused into vmp_svae_estep_fwd; use e_step')
 
 
-def subsample_x(x_k_samples, log_q_z_given_y, seed=0, z_draws=None, nb_out=None):
+def subsample_x(x_k_samples, log_q_z_given_y, seed=0, z_draws=None, nb_out=None, u=None):
     """reference svae.py:122-151: z_ns ~ Cat(exp log_q), gather x[n, z_ns, s].  HIP kernel vmp_svae_subsample;
     `z_draws` (N,S) replaces tf.multinomial (default: inverse CDF of torch.rand with `seed`).  `nb_out` < S only
     produces the first nb_out sample columns (the reference's caller keeps s = 0, svae.py:514)."""
@@ -152,9 +143,12 @@ def subsample_x(x_k_samples, log_q_z_given_y, seed=0, z_draws=None, nb_out=None)
     N, K, S, Ld = x.shape
     lz = L.dev_f32(log_q_z_given_y.detach(), 'log_q_z_given_y', (N, K))
     So = S if nb_out is None else int(nb_out)
-    u = z = None
+    z = None
     if z_draws is not None:
+        u = None
         z = z_draws[:, :So].to(torch.int64).contiguous()
+    elif u is not None:                                  # supplied uniforms (N,So) - e.g. a static graph input
+        u = L.dev_f32(u, 'u', (N, So))
     else:
         g = torch.Generator(device=x.device).manual_seed(int(seed))
         u = torch.rand(N, So, generator=g, device=x.device)
@@ -184,6 +178,11 @@ def m_step_from_stats(gmm_prior, stats):
     sxx = stats[:, 2 + Ld:].reshape(K, Ld, Ld).float()
     alpha, A, b, beta, v_hat = gmm_prior
     return [alpha + Nk, A + sxx, b + sx, beta + Nk, v_hat + Nk + 1.0]
+
+
+def cvi_update_from_stats(gmm_prior, theta, stats, step_size, want_star=True, step_size_dev=None):
+    """m_step_from_stats + update_gmm_params (reference svae.py:154-176, 376-403) in one launch; theta in place."""
+    return _svae_ops.cvi_update(gmm_prior, theta, stats, step_size, want_star, step_size_dev)
 
 
 def m_step_smm(smm_prior, r_nk):
@@ -278,14 +277,14 @@ def init_recognition_params(theta, nb_components, seed=0, param_device='cuda', v
 
 
 def inference(y, phi_gmm, encoder_layers, decoder_layers, nb_samples=10, stddev_init_nn=0.01, seed=0, name='inference',
-              param_device='cuda', noise=None, z_draws=None, theta=None, lazy_decoder=False):
+              param_device='cuda', noise=None, z_draws=None, theta=None, lazy_decoder=False, u=None):
     """reference svae.py:499-516.  Returns (y_reconstruction, x_given_y_phi, x_k_samples, x_samples, log_z, phi_gmm,
     phi_tilde).  lazy_decoder=True: y_reconstruction is a vae.LazyReconstruction (fused decoder kernels)."""
     x_given_y_phi = vae.make_encoder(y, layerspecs=encoder_layers, stddev_init=stddev_init_nn, seed=seed)
     x_k_samples, log_z, phi_tilde, _ = e_step(x_given_y_phi, phi_gmm, nb_samples, seed=seed, noise=noise, theta=theta)
     y_rec = vae.make_decoder(x_k_samples, layerspecs=decoder_layers, stddev_init=stddev_init_nn, seed=seed,
                              lazy=lazy_decoder)
-    x_samples = subsample_x(x_k_samples, log_z, seed, z_draws=z_draws, nb_out=1)[:, 0, :]
+    x_samples = subsample_x(x_k_samples, log_z, seed, z_draws=z_draws, nb_out=1, u=u)[:, 0, :]
     return y_rec, x_given_y_phi, x_k_samples, x_samples, log_z, phi_gmm, phi_tilde
 
 

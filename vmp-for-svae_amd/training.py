@@ -26,7 +26,8 @@ def exponential_decay(lr0, global_step, decay_steps, decay_rate):
 
 
 class TFAdam(object):
-    """tf.train.AdamOptimizer (TF 1.3): lr_t = lr sqrt(1-b2^t)/(1-b1^t); var -= lr_t m / (sqrt(v) + eps)."""
+    """tf.train.AdamOptimizer (TF 1.3): lr_t = lr sqrt(1-b2^t)/(1-b1^t); var -= lr_t m / (sqrt(v) + eps).
+    Multi-tensor (torch._foreach_*) updates: a handful of launches for all 21 tensors instead of 7 per tensor."""
 
     def __init__(self, params, lr, beta1=0.9, beta2=0.999, eps=1e-8):
         self.params = list(params)
@@ -35,14 +36,29 @@ class TFAdam(object):
         self.v = [torch.zeros_like(p) for p in self.params]
         self.t = 0
 
+    def lr_t(self, t):
+        return self.lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
+
     @torch.no_grad()
-    def apply_gradients(self, grads):
-        self.t += 1
-        lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
-        for p, g, m, v in zip(self.params, grads, self.m, self.v):
-            m.mul_(self.b1).add_(g, alpha=1.0 - self.b1)
-            v.mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
-            p.addcdiv_(m, v.sqrt().add_(self.eps), value=-lr_t)
+    def apply_gradients(self, grads, lr_t_dev=None):
+        """lr_t_dev: the bias-corrected step size as a 0-dim device tensor (graph-captured steps: the caller advances
+        self.t and refreshes the tensor before every replay); default: computed here from the step count."""
+        # contiguous gradients with the parameters' strides keep torch on the multi-tensor fast path
+        grads = [g.to(p.dtype).contiguous() for g, p in zip(grads, self.params)]
+        torch._foreach_mul_(self.m, self.b1)
+        torch._foreach_add_(self.m, grads, alpha=1.0 - self.b1)
+        torch._foreach_mul_(self.v, self.b2)
+        torch._foreach_addcmul_(self.v, grads, grads, value=1.0 - self.b2)
+        denom = torch._foreach_sqrt(self.v)
+        torch._foreach_add_(denom, self.eps)
+        data = [p.data for p in self.params]
+        if lr_t_dev is None:
+            self.t += 1
+            torch._foreach_addcdiv_(data, self.m, denom, value=-self.lr_t(self.t))
+        else:
+            upd = torch._foreach_div(self.m, denom)
+            torch._foreach_mul_(upd, lr_t_dev)
+            torch._foreach_sub_(data, upd)
 
 
 def pack_for_allreduce(stats, grads, scalars):
@@ -108,18 +124,20 @@ class SVAETrainer(object):
                 ts.append(p)
         return names, ts
 
-    def forward(self, y, noise=None, z_draws=None):
+    def forward(self, y, noise=None, z_draws=None, u=None):
         out = svae.inference(y, self.phi_gmm, self.encoder_layers, self.decoder_layers, self.S,
                              stddev_init_nn=self.stddev_init_nn, seed=self.seed + self.global_step, noise=noise,
-                             z_draws=z_draws, theta=self.theta, lazy_decoder=self.fused_decoder)
+                             z_draws=z_draws, theta=self.theta, lazy_decoder=self.fused_decoder, u=u)
         y_rec, phi_enc, x_k, x_s, log_z, _, phi_tilde = out
         elbo_fn = svae.compute_elbo_smm if self.smm else svae.compute_elbo
         elbo, details = elbo_fn(y, y_rec, self.theta, phi_tilde, x_k, log_z, 'standard')
         return elbo, details, x_k, x_s, log_z
 
-    def step(self, y, noise=None, z_draws=None, chunk=None):
+    def step(self, y, noise=None, z_draws=None, chunk=None, u=None, _dev_scalars=None):
         """One training step.  `chunk` rows at a time (the ELBO is a sum over datapoints, so gradients and
-        moments simply accumulate over chunks) - needed when N*K*S decoder rows do not fit at once."""
+        moments simply accumulate over chunks) - needed when N*K*S decoder rows do not fit at once.
+        `u` (N,1) supplies the uniforms of the categorical sub-sampling; `_dev_scalars` = (lrcvi, lr_t) as 0-dim
+        device tensors is what GraphedSVAEStep captures with (step counters are then advanced by the caller)."""
         import torch.distributed as dist
         world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
         rows = y.shape[0]
@@ -132,7 +150,8 @@ class SVAETrainer(object):
             ys = y[i:i + chunk]
             ns = None if noise is None else noise[i:i + chunk]
             zs = None if z_draws is None else z_draws[i:i + chunk]
-            elbo, details, x_k, x_s, log_z = self.forward(ys, ns, zs)
+            us = None if u is None else u[i:i + chunk]
+            elbo, details, x_k, x_s, log_z = self.forward(ys, ns, zs, us)
             if params is None:
                 names, params = self.trainables()
             g = torch.autograd.grad(-elbo, params, allow_unused=True)
@@ -157,16 +176,73 @@ class SVAETrainer(object):
             grads = [(g / world).to(torch.float32) for g in g64]                    # average_gradients (tf_utils.py:79)
             elbo_t, rec_t, reg_t = sc[0], sc[1], sc[2]
         lrcvi = exponential_decay(self.lrcvi0, self.global_step, 1000, self.decay_rate)
-        if self.smm:                                                                # experiments.py:252-256
-            theta_star = [self.gmm_prior + stats[:, 0].float()]
-        else:
-            theta_star = svae.m_step_from_stats(self.gmm_prior, stats)
         if self.opt is None:
             self.opt = TFAdam(params, self.lr)
-        svae.update_gmm_params(self.theta[:1] if self.smm else self.theta, theta_star, lrcvi)   # experiments.py:258-260
-        self.opt.apply_gradients(grads)                                             # experiments.py:264-265
-        self.global_step += 1
+        if self.smm:                                                                # experiments.py:252-256
+            theta_star = [self.gmm_prior + stats[:, 0].float()]
+            svae.update_gmm_params(self.theta[:1], theta_star, lrcvi)
+        elif _dev_scalars is not None:
+            theta_star = svae.cvi_update_from_stats(self.gmm_prior, self.theta, stats.double(), 0.0,
+                                                    step_size_dev=_dev_scalars[0])
+        else:                                                                       # experiments.py:258-260
+            theta_star = svae.cvi_update_from_stats(self.gmm_prior, self.theta, stats.double(), lrcvi)
+        if _dev_scalars is not None:
+            self.opt.apply_gradients(grads, lr_t_dev=_dev_scalars[1])
+        else:
+            self.opt.apply_gradients(grads)                                         # experiments.py:264-265
+            self.global_step += 1
         out = dict(elbo=elbo_t, neg_rec_err=rec_t, regulariser=reg_t, grads=dict(zip(names, grads)),
                    theta_star=theta_star, lrcvi=lrcvi)
         out.update(keep)
         return out
+
+
+
+class GraphedSVAEStep(object):
+    """The whole training step of a fixed minibatch size captured ONCE as a HIP graph and replayed: at the reference's
+    operating point (minibatches of 64-100 rows, experiments.py:26) the step is ~150 launches of microsecond kernels
+    and is bound by launch overhead, not by the GPU.  Per call: copy the minibatch into the static input, refresh the
+    noise / uniforms in place, write the two step-dependent scalars (CVI step size, bias-corrected Adam step size) to
+    device memory, replay.  GMM-SVAE, one process (the data-parallel step has a collective in the middle)."""
+
+    def __init__(self, trainer, y_example, warmup=3):
+        tr = self.tr = trainer
+        if tr.smm:
+            raise NotImplementedError('graph capture covers the GMM-SVAE step')
+        dev = tr.device
+        N = y_example.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.y = y_example.to(**f32).clone()
+        self.noise = torch.empty(N, tr.K, tr.L, tr.S, **f32)
+        self.u = torch.empty(N, 1, **f32)
+        self.rho = torch.zeros((), **f32)
+        self.lr_t = torch.zeros((), **f32)
+        self.gen = torch.Generator(device=dev).manual_seed(int(tr.seed))
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                      # creates the variables / Adam slots, sizes the workspaces
+                self._refresh()
+                tr.step(self.y, noise=self.noise, u=self.u)
+        torch.cuda.current_stream().wait_stream(side)
+        self._refresh()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = tr.step(self.y, noise=self.noise, u=self.u, _dev_scalars=(self.rho, self.lr_t))
+
+    def _refresh(self):
+        tr = self.tr
+        self.noise.normal_(generator=self.gen)
+        self.u.uniform_(generator=self.gen)
+        self.rho.fill_(exponential_decay(tr.lrcvi0, tr.global_step, 1000, tr.decay_rate))
+        if tr.opt is not None:
+            self.lr_t.fill_(tr.opt.lr_t(tr.opt.t + 1))
+
+    def __call__(self, y):
+        tr = self.tr
+        self.y.copy_(y)
+        self._refresh()
+        self.graph.replay()
+        tr.opt.t += 1
+        tr.global_step += 1
+        return self.out
