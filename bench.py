@@ -181,6 +181,68 @@ def bench_t3(N, Ld, K, S, U, steps, warmup, dev, chunk):
                 N, 'one pass' if chunk is None else 'chunks of %d' % chunk, Ld, K, S, U)}
 
 
+def bench_minibatch(N, K, Ld, Dy, S, U, dev, steps=200, cpu=True):
+    """The reference's own operating point (experiments.py:26,56-66: minibatches of 64 rows, Auto-sized model): the full
+    training step eager, the same step replayed from one HIP graph, and the oracle's literal restatement of
+    experiments.py:196-267 on the host cores (fp32)."""
+    from vmp_for_svae_amd.models import vae
+    from vmp_for_svae_amd.training import SVAETrainer, GraphedSVAEStep
+    vae.reset_variables()
+    g = torch.Generator(device=dev).manual_seed(99)
+    y = torch.randn(N, Dy, device=dev, generator=g) * 2
+    tr = SVAETrainer(K, Ld, U, Dy, nb_samples=S, device=dev)
+    for _ in range(10):
+        tr.step(y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(y)
+    torch.cuda.synchronize()
+    eager = (time.perf_counter() - t0) / steps
+    gs = GraphedSVAEStep(tr, y)
+    for _ in range(10):
+        gs(y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = gs(y)
+    torch.cuda.synchronize()
+    graphed = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(out['elbo'])
+    res = {'config': 'T3 svae-train minibatch N=%d, K=%d, L=%d, Dy=%d, S=%d, U=%d' % (N, K, Ld, Dy, S, U),
+           'eager_steps_per_sec': 1.0 / eager, 'eager_ms_per_step': eager * 1e3,
+           'graphed_steps_per_sec': 1.0 / graphed, 'graphed_ms_per_step': graphed * 1e3}
+    if cpu:
+        from oracle import nets, svae_ref, train_ref
+        # tiny tensors: more than a few threads only adds synchronisation (256 threads: ~30 s per step)
+        torch.set_num_threads(min(8, os.cpu_count() or 1))
+        rng = np.random.Generator(np.random.PCG64(1))
+        w = {}
+        for scope, din, dout in (('encoder_net', Dy, Ld), ('decoder_net', Ld, Dy)):
+            shapes = {'layer_0/kernel': (din, U), 'layer_0/bias': (U,), 'layer_1/kernel': (U, U), 'layer_1/bias': (U,),
+                      'gaussian_output/kernel': (U, 2 * dout), 'gaussian_output/bias': (2 * dout,), 'shortcut/b1': (dout,),
+                      'shortcut/b2': (dout,)}
+            for n_, shp in shapes.items():
+                w[scope + '/' + n_] = torch.as_tensor((rng.standard_normal(shp) * 0.01).astype(np.float32))
+            w[scope + '/shortcut/W'] = torch.as_tensor(nets.rand_partial_isometry(din, dout, 1., 0).astype(np.float32))
+        prior, theta = svae_ref.init_mm(K, Ld, torch.as_tensor(rng.random((K, Ld)).astype(np.float32)), torch.float32)
+        phi = svae_ref.init_recognition_params(theta, torch.as_tensor(rng.standard_normal(K).astype(np.float32)))
+        st = train_ref.State(phi, {n_: w['encoder_net/' + n_] for n_ in nets.NET_VARS},
+                             {n_: w['decoder_net/' + n_] for n_ in nets.NET_VARS}, theta, prior)
+        yc = y.cpu()
+        noise = torch.as_tensor(rng.standard_normal((N, K, Ld, S)).astype(np.float32))
+        zd = torch.as_tensor(rng.integers(0, K, size=(N, S)))
+        train_ref.train_step(st, yc, noise, zd, 3e-4, 0.2, 0.95)
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            train_ref.train_step(st, yc, noise, zd, 3e-4, 0.2, 0.95)
+        cpu_t = (time.perf_counter() - t0) / reps
+        res['cpu_oracle_steps_per_sec'] = 1.0 / cpu_t
+        res['cpu_oracle_cores'] = torch.get_num_threads()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -255,6 +317,9 @@ def main():
         torch.cuda.empty_cache()
         if world == 1:
             extra['t3_svae_train'] = bench_t3(N, D, K, args.s, args.u, 3, 1, dev, None)
+            torch.cuda.empty_cache()
+            # BASELINE configs[3]-sized model at the reference's minibatch size (Auto: Dy=6, L=8, K=10, U=50)
+            extra['t3_minibatch64'] = bench_minibatch(64, 10, 8, 6, args.s, args.u, dev, cpu=not args.no_cpu_baseline)
             torch.cuda.empty_cache()
 
     if rank == 0:

@@ -104,7 +104,7 @@ def load_checkpoint(tr, path):
 
 def run(config, nb_iters=2000, size_minibatch=100, nb_samples=10, nb_samples_te=100, measurement_freq=500,
         path_dataset=None, device='cuda', verbose=True, ratio_tr=0.7, imputation_freq=None, nb_samples_pert=20,
-        ratio_missing_data=0.1, checkpoint_freq=None, checkpoint_dir=None):
+        ratio_missing_data=0.1, checkpoint_freq=None, checkpoint_dir=None, graph=True):
     torch.manual_seed(config.get('seed', 0))
     vae.reset_variables()
     X, lab = data_mod.load_dataset(config['dataset'], path_dataset)
@@ -121,9 +121,18 @@ def run(config, nb_iters=2000, size_minibatch=100, nb_samples=10, nb_samples_te=
     missing_data_mask = losses.generate_missing_data_mask(Xte, ratio_missing_data, seed=config.get('seed', 0))
     history = []
     t0 = time.time()
+    # fixed-size minibatches: capture the training step once as a HIP graph and replay it (training.GraphedSVAEStep)
+    stepper = None
     for i in range(nb_iters):
         idx = torch.as_tensor(next(batches)).to(dev)
-        out = tr.step(Xtr[idx].contiguous())
+        yb = Xtr[idx].contiguous()
+        if graph and not smm and dev.type == 'cuda':
+            if stepper is None:
+                from .training import GraphedSVAEStep
+                stepper = GraphedSVAEStep(tr, yb)
+            out = stepper(yb) if yb.shape[0] == stepper.y.shape[0] else tr.step(yb)
+        else:
+            out = tr.step(yb)
         if i % measurement_freq == 0 or i == nb_iters - 1:
             m = evaluate(tr, Xte, Lte, nb_samples_te, seed=config.get('seed', 0))
             m['iter'], m['neg_normed_elbo'] = i, -float(out['elbo']) / size_minibatch      # experiments.py:318-320

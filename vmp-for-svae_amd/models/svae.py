@@ -263,7 +263,10 @@ def make_loc_scale_variables(theta, param_device='cuda', name='copy_m_v'):
     """reference svae.py:474-485."""
     std = niw.natural_to_standard(theta[1], theta[2], theta[3], theta[4])
     mu, sigma = niw.expected_values(std)
-    return (torch.nn.Parameter(mu.detach().clone()), torch.nn.Parameter(torch.linalg.cholesky(sigma).detach().clone()))
+    # contiguous copies: cholesky returns a column-major batch, and one oddly-strided parameter drops the optimiser's
+    # multi-tensor updates onto the per-tensor slow path
+    return (torch.nn.Parameter(mu.detach().clone(memory_format=torch.contiguous_format)),
+            torch.nn.Parameter(torch.linalg.cholesky(sigma).detach().clone(memory_format=torch.contiguous_format)))
 
 
 def init_recognition_params(theta, nb_components, seed=0, param_device='cuda', var_scope='phi_gmm', pi_normal=None):
