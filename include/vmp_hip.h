@@ -233,6 +233,13 @@ int    vmp_decoder_loglike_fwd(const float* x, const float* y, const float* W0, 
                                const float* b1, const float* W2, const float* b2, const float* Ws, const float* bs1,
                                const float* bs2, int64_t N, int K, int S, int L, int Dy, int U, float* ll, float* mean,
                                float* var, void* stream);
+/* Backward pass of the same network as a stand-alone Gaussian-head MLP (the encoder, vae.make_encoder
+ * models/vae.py:131-135; forward = vmp_decoder_loglike_fwd with ll == NULL, K = S = 1): the upstream gradients of the two
+ * head outputs (mean, var) are inputs.  x (R,L); gmean, gvar (R,Dy); dx (R,L) may be NULL (x is data).        */
+int    vmp_mlp_gauss_bwd(const float* x, const float* gmean, const float* gvar, const float* W0, const float* b0,
+                         const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws,
+                         const float* bs1, const float* bs2, int64_t R, int L, int Dy, int U, float* dx, float* dparams,
+                         void* ws, size_t ws_bytes, void* stream);
 int    vmp_decoder_loglike_bwd(const float* x, const float* y, const float* gA, const float* W0, const float* b0,
                                const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws,
                                const float* bs1, const float* bs2, int64_t N, int K, int S, int L, int Dy, int U,

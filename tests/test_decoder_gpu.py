@@ -150,3 +150,34 @@ def test_weighted_loglike_single_launch(scale):
     with torch.no_grad():
         out = _svae_ops.DecoderWeightedLoglikeFn.apply(f32(y), f32(x), f32(r), *[f32(a) for a in w])
     assert relerr(out, res[0][0]) < 1e-6
+
+
+@pytest.mark.parametrize('dims', [(64, 6, 8, 50), (700, 2, 2, 20), (33, 8, 8, 64), (5, 3, 7, 33)])
+@pytest.mark.parametrize('head', ['natparam', 'standard'])
+def test_fused_encoder_vs_oracle(dims, head):
+    """vae.make_encoder through the fused MLP kernels (GaussMLPFn: forward + gradient-input backward) against the
+    oracle's fp64 make_nnet (vae.py:75-128) with torch autograd, for both Gaussian heads, incl. the input gradient."""
+    from oracle import nets
+    from vmp_for_svae_amd.models import vae
+    R, Din, Dout, U = dims
+    rng = np.random.Generator(np.random.PCG64(R + U))
+    shapes = ((Din, U), (U,), (U, U), (U,), (U, 2 * Dout), (2 * Dout,), (Din, Dout), (Dout,), (Dout,))
+    w = [rng.standard_normal(s) * 0.3 for s in shapes]
+    x = rng.standard_normal((R, Din)) * 1.5
+    g1, g2 = rng.standard_normal((R, Dout)), rng.standard_normal((R, Dout))
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in w]
+    o1, o2 = nets.mlp(xt, dict(zip(NET_VARS, wt)), head)
+    gt = torch.autograd.grad((o1 * torch.tensor(g1)).sum() + (o2 * torch.tensor(g2)).sum(), [xt] + wt)
+    f32 = lambda a: torch.tensor(a, dtype=torch.float32, device='cuda')
+    vae.reset_variables()
+    for n_, a in zip(NET_VARS, w):
+        vae.VARIABLES['encoder_net/' + n_] = torch.nn.Parameter(f32(a))
+    xg = f32(x).requires_grad_(True)
+    e1, e2 = vae.make_encoder(xg, [(U, torch.tanh), (U, torch.tanh), (Dout, head)])
+    assert relerr(e1, o1) < 1e-5 and relerr(e2, o2) < 1e-5
+    ps = [vae.VARIABLES['encoder_net/' + n_] for n_ in NET_VARS]
+    gd = torch.autograd.grad((e1 * f32(g1)).sum() + (e2 * f32(g2)).sum(), [xg] + ps)
+    for n_, a, b in zip(('x',) + NET_VARS, gd, gt):
+        assert relerr(a, b) < 1e-5, (n_, relerr(a, b))
+    vae.reset_variables()

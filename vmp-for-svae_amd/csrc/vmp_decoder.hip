@@ -36,6 +36,8 @@ struct DecArgs {
     const float* x;        // (R, L)  rows = N*K*S
     const float* y;        // (N, Dy)
     const float* gA;       // (N, K)  backward: upstream gradient of A_nk = sum_s ll_row
+    const float* gmean;    // (R, Dy) backward, gradient-input mode: upstream gradients of the two head outputs
+    const float* gvar;     // (R, Dy)
     const float *W0, *b0, *W1, *b1, *W2, *b2, *Ws, *bs1, *bs2;
     float* ll;             // (R)      forward (nullable)
     float* mean;           // (R, Dy)  forward (nullable)
@@ -348,7 +350,9 @@ __device__ __forceinline__ f32x4 tr_read(const float* __restrict__ T, int g, int
 // shortcut product) has rows L..15 free, so a row of ones at "dim 8" makes row 8 of those accumulators equal to
 // sum_row dh0pre (= db0) and sum_row dO (= db2, dbs1); likewise a ones "unit U" in the transposed h0 block gives
 // db1 as row U of dW1 when U is not a multiple of 16 (FS); otherwise db1 is summed on the VALU.
-template <int UT, int VL, bool FS>
+// GIN (gradient-input mode): the upstream gradients of (mean, var) are given per row instead of being derived from
+// the log-likelihood - the same kernel then is the backward pass of a stand-alone Gaussian-head MLP (the encoder).
+template <int UT, int VL, bool FS, bool GIN>
 __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     using I = Img<UT>;
@@ -391,11 +395,21 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             const unsigned r2 = tile * 16u + 4u * g + kk;
             xT[kk] = (r2 < a.R && c < L) ? a.x[(size_t)r2 * L + c] : (c == 8 ? 1.0f : 0.f);
         }
-        const RowMap rm = row_map(tile, c, a.S, a.K, invS, invK, ncells);
-        const float ga = ok ? a.gA[rm.cell] : 0.f;
-        float yv[2];
+        float ga = 0.f, yv[2] = {0.f, 0.f}, gin_m[2] = {0.f, 0.f}, gin_v[2] = {0.f, 0.f};
+        if (GIN) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) yv[j] = 2 * g + j < Dy ? a.y[(size_t)rm.n * Dy + 2 * g + j] : 0.f;
+            for (int j = 0; j < 2; ++j) {
+                const bool dv = ok && 2 * g + j < Dy;
+                const float m_ = a.gmean[(size_t)rr * Dy + (dv ? 2 * g + j : 0)], v_ = a.gvar[(size_t)rr * Dy + (dv ? 2 * g + j : 0)];
+                gin_m[j] = dv ? m_ : 0.f;
+                gin_v[j] = dv ? v_ : 0.f;
+            }
+        } else {
+            const RowMap rm = row_map(tile, c, a.S, a.K, invS, invK, ncells);
+            ga = ok ? a.gA[rm.cell] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) yv[j] = 2 * g + j < Dy ? a.y[(size_t)rm.n * Dy + 2 * g + j] : 0.f;
+        }
 
         f32x4 h0[UT], h1[UT], O;
         dec_forward_tile<UT, VL>(sm, lane, xb0, xb1, h0, h1, O);
@@ -412,15 +426,15 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             const float raw2 = O[2 + j];
             const float vr = softplus_f(raw2) + sm[I::SP2 + (d & 7)];
             const float df = yv[j] - O[j], iv = rcp_f(vr);
-            const float gm = dv ? ga * (-2.f * df * iv) : 0.f;
-            const float gv = dv ? ga * (rcp_f(vr + 1e-8f) - df * df * iv * iv) : 0.f;
+            const float gm = GIN ? gin_m[j] : (dv ? ga * (-2.f * df * iv) : 0.f);
+            const float gv = GIN ? gin_v[j] : (dv ? ga * (rcp_f(vr + 1e-8f) - df * df * iv * iv) : 0.f);
             const float gr = gv * sigmoid_f(raw2);
             dO[j] = gm;
             dO[2 + j] = gr;
             abs2[j] += gv;
-            if (a.ll) llacc += dv ? df * df * iv + __logf(vr + 1e-8f) : 0.f;
+            if (!GIN && a.ll) llacc += dv ? df * df * iv + __logf(vr + 1e-8f) : 0.f;
         }
-        if (a.ll) {                                      // value and gradient in one pass (wave-uniform branch)
+        if (!GIN && a.ll) {                                      // value and gradient in one pass (wave-uniform branch)
             llacc += __shfl_xor(llacc, 16);
             llacc += __shfl_xor(llacc, 32);
             if (ok && g == 0) a.ll[row] = llacc;
@@ -524,7 +538,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
                     }
             }
             const f32x4 dxv = d0 + d1;                   // [dim 4g+v][row c]
-            if (ok) {
+            if (ok && a.dx) {
                 if (L == 8) {
                     if (g < 2) *reinterpret_cast<f32x4*>(a.dx + (size_t)row * 8 + 4 * g) = dxv;
                 } else {
@@ -672,6 +686,25 @@ int dec_check(const char* what, long long N, int K, int S, int L, int Dy, int U)
         }                                                                                      \
     } while (0)
 
+template <bool GIN>
+int dec_bwd_launch(const DecArgs& a, int blocks, hipStream_t s) {
+    const int U = a.U;
+#define DEC_BWD(UTV, VLV)                                                                                             \
+    do {                                                                                                              \
+        const int lds = Img<UTV>::BWD_TOTAL * (int)sizeof(float);                                                     \
+        if (VLV == 4 && (U & 15) == 0) {                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<UTV, 4, false, GIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            hipLaunchKernelGGL((dec_bwd_kernel<UTV, 4, false, GIN>), dim3(blocks), dim3(BWD_THREADS), lds, s, a);    \
+        } else {                                                                                                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<UTV, VLV, true, GIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            hipLaunchKernelGGL((dec_bwd_kernel<UTV, VLV, true, GIN>), dim3(blocks), dim3(BWD_THREADS), lds, s, a);   \
+        }                                                                                                             \
+    } while (0)
+    DEC_DISPATCH(U, DEC_BWD);
+#undef DEC_BWD
+    return check_launch(GIN ? "vmp_mlp_gauss_bwd" : "vmp_decoder_loglike_bwd");
+}
+
 }  // namespace
 
 extern "C" {
@@ -734,23 +767,40 @@ int vmp_decoder_loglike_bwd(const float* x, const float* y, const float* gA, con
     a.dx = dx; a.part = static_cast<float*>(ws); a.ll = ll;
     a.R = (unsigned)(N * K * S); a.K = (unsigned)K; a.S = (unsigned)S; a.L = L; a.Dy = Dy; a.U = U;
     const int blocks = dec_bwd_blocks((long long)a.R);
-#define DEC_BWD(UTV, VLV)                                                                                             \
-    do {                                                                                                              \
-        const int lds = Img<UTV>::BWD_TOTAL * (int)sizeof(float);                                                     \
-        if (VLV == 4 && (U & 15) == 0) {                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<UTV, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-            hipLaunchKernelGGL((dec_bwd_kernel<UTV, 4, false>), dim3(blocks), dim3(BWD_THREADS), lds, s, a);         \
-        } else {                                                                                                      \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<UTV, VLV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-            hipLaunchKernelGGL((dec_bwd_kernel<UTV, VLV, true>), dim3(blocks), dim3(BWD_THREADS), lds, s, a);        \
-        }                                                                                                             \
-    } while (0)
-    DEC_DISPATCH(U, DEC_BWD);
-#undef DEC_BWD
-    if (int e = check_launch("vmp_decoder_loglike_bwd")) return e;
+    if (int e = dec_bwd_launch<false>(a, blocks, s)) return e;
     DecRedArgs r{a.part, bs2, dparams, blocks, q.PW, q.obs2, Dy};
     hipLaunchKernelGGL(dec_reduce_kernel, dim3((q.PW + 255) / 256), dim3(256), 0, s, r);
     return check_launch("vmp_decoder_loglike_bwd(reduce)");
+}
+
+int vmp_mlp_gauss_bwd(const float* x, const float* gmean, const float* gvar, const float* W0, const float* b0,
+                      const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws, const float* bs1,
+                      const float* bs2, int64_t R, int L, int Dy, int U, float* dx, float* dparams, void* ws,
+                      size_t ws_bytes, void* stream) {
+    if (int e = dec_check("vmp_mlp_gauss_bwd", R, 1, 1, L, Dy, U)) return e;
+    if (!x || !gmean || !gvar || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !Ws || !bs1 || !bs2 || !dparams || !ws) {
+        set_error("vmp_mlp_gauss_bwd: NULL argument");
+        return VMP_E_BADARG;
+    }
+    const DecGeo q = dec_geo(L, U, Dy);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (R == 0) {
+        (void)hipMemsetAsync(dparams, 0, (size_t)q.PW * sizeof(float), s);
+        return check_launch("vmp_mlp_gauss_bwd");
+    }
+    if (ws_bytes < vmp_decoder_workspace_bytes(R, 1, 1, L, U, Dy)) {
+        set_error("vmp_mlp_gauss_bwd: workspace too small");
+        return VMP_E_WS;
+    }
+    DecArgs a{};
+    a.x = x; a.gmean = gmean; a.gvar = gvar; a.W0 = W0; a.b0 = b0; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Ws = Ws;
+    a.bs1 = bs1; a.bs2 = bs2; a.dx = dx; a.part = static_cast<float*>(ws);
+    a.R = (unsigned)R; a.K = 1; a.S = 1; a.L = L; a.Dy = Dy; a.U = U;
+    const int blocks = dec_bwd_blocks((long long)a.R);
+    if (int e = dec_bwd_launch<true>(a, blocks, s)) return e;
+    DecRedArgs r{a.part, bs2, dparams, blocks, q.PW, q.obs2, Dy};
+    hipLaunchKernelGGL(dec_reduce_kernel, dim3((q.PW + 255) / 256), dim3(256), 0, s, r);
+    return check_launch("vmp_mlp_gauss_bwd(reduce)");
 }
 
 }  // extern "C"

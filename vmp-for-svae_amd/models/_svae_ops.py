@@ -364,3 +364,40 @@ def cvi_update(gmm_prior, theta, stats, rho, want_star=True, rho_dev=None):
     for t in theta:
         torch.autograd.graph.increment_version(t)
     return star if want_star else None
+
+
+class GaussMLPFn(torch.autograd.Function):
+    """(x (R,L), 9 parameters) -> (mean, var) (R,Dy) of the two-tanh-layer Gaussian-head MLP with shortcut (reference
+    vae.py:75-128, 'standard' head) through the fused MFMA kernels, differentiable: one launch forward, one (+ the
+    partial reduce) backward.  The encoder's 'natparam' head is (mean, -1/2 var) (vae.py:38-42,108-111)."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        x = _c(x, 'mlp input')
+        if x.dim() != 2:
+            raise L.VmpError('input must have shape (R, L)')
+        params = [_c(p, n) for p, n in zip(params, DECODER_PARAM_NAMES)]
+        Ld, U, Dy = _decoder_dims(x, params)
+        R = x.shape[0]
+        mean = torch.empty(R, Dy, dtype=torch.float32, device=x.device)
+        var = torch.empty(R, Dy, dtype=torch.float32, device=x.device)
+        L.check(L.lib().vmp_decoder_loglike_fwd(L.ptr(x), None, *[L.ptr(p) for p in params], R, 1, 1, Ld, Dy, U, None,
+                                                L.ptr(mean), L.ptr(var), L.stream()), 'vmp_decoder_loglike_fwd')
+        ctx.save_for_backward(x, *params)
+        ctx.dims = (R, Ld, Dy, U)
+        return mean, var
+
+    @staticmethod
+    def backward(ctx, g_mean, g_var):
+        sv = ctx.saved_tensors
+        x, params = sv[0], sv[1:]
+        R, Ld, Dy, U = ctx.dims
+        g_mean = torch.zeros(R, Dy, dtype=torch.float32, device=x.device) if g_mean is None else g_mean.contiguous().float()
+        g_var = torch.zeros(R, Dy, dtype=torch.float32, device=x.device) if g_var is None else g_var.contiguous().float()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dp = torch.empty(L.lib().vmp_decoder_param_words(Ld, U, Dy), dtype=torch.float32, device=x.device)
+        nbytes = L.lib().vmp_decoder_workspace_bytes(R, 1, 1, Ld, U, Dy)
+        ws = L.workspace(x.device, nbytes)
+        L.check(L.lib().vmp_mlp_gauss_bwd(L.ptr(x), L.ptr(g_mean), L.ptr(g_var), *[L.ptr(p) for p in params], R, Ld, Dy, U,
+                                          L.ptr(dx), L.ptr(dp), L.ptr(ws), nbytes, L.stream()), 'vmp_mlp_gauss_bwd')
+        return (dx,) + tuple(_split_flat(dp, params))

@@ -95,10 +95,22 @@ def make_nnet(input, layerspecs, stddev, name, param_device=None, seed=0):
 
 
 def make_encoder(input, layerspecs=None, stddev_init=1., param_device=None, seed=0):
-    """reference vae.py:131-135."""
+    """reference vae.py:131-135.  The encoder the SVAE driver builds (experiments.py:139: two tanh layers of width
+    U <= 64, Gaussian head, in/out <= 8) runs in the fused MFMA MLP kernels (one launch each way)."""
     if layerspecs is None:
         layerspecs = [(100, torch.tanh), (100, torch.tanh), (10, 'standard')]
+    if input.is_cuda and input.dim() == 2 and _fused_mlp_eligible(input.shape[-1], layerspecs):
+        ps = decoder_variables(input.shape[-1], layerspecs, stddev_init, seed, input.device, name='encoder_net')
+        mean, var = _svae_ops.GaussMLPFn.apply(input, *ps)
+        return (mean, var) if layerspecs[-1][1] == 'standard' else (mean, -0.5 * var)
     return make_nnet(input, layerspecs, stddev_init, 'encoder_net', param_device, seed)
+
+
+def _fused_mlp_eligible(in_dim, layerspecs):
+    if len(layerspecs) != 3 or layerspecs[-1][1] not in ('standard', 'natparam'):
+        return False
+    (u0, a0), (u1, a1), (dy, _) = layerspecs
+    return (a0 is torch.tanh and a1 is torch.tanh and u0 == u1 and _svae_ops.fused_decoder_supported(in_dim, u0, dy))
 
 
 def fused_decoder_eligible(in_dim, layerspecs):
