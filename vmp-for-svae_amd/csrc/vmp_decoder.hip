@@ -562,14 +562,17 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
         wave_lds_order();
     }
 
-    // ---- reduce the per-wave accumulators: waves of the block in a fixed order through LDS
+    // ---- reduce the per-wave accumulators through LDS.  Every parameter index is owned by exactly one (lane,
+    // register) of a wave, so each wave drops its accumulators into a slab of its own with plain stores (a turn-taking
+    // read-modify-write over 8 waves cost ~50 us per launch - most of the kernel at minibatch sizes); then all threads
+    // sum the slabs in wave order (deterministic).  Two rounds of BWD_WAVES/2 slabs stay inside the LDS allocation.
     const DecGeo q = dec_geo(L, U, Dy);
     __syncthreads();                                    // everybody is done with the operand images
+    constexpr int HALF = BWD_WAVES / 2;
     float* __restrict__ accum = sm;
-    for (int w = 0; w < BWD_WAVES; ++w) {
-        if (wave == w) {
-            if (w == 0) for (int i = lane; i < q.PW; i += WAVE) accum[i] = 0.f;
-            wave_lds_order();
+    for (int round = 0; round < 2; ++round) {
+        if (wave / HALF == round) {
+            float* __restrict__ slab = sm + (1 + wave % HALF) * q.PW;
 #pragma unroll
             for (int ti = 0; ti < UT; ++ti)
 #pragma unroll
@@ -577,31 +580,31 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const int in = 16 * ti + 4 * g + v, out = 16 * tj + c;
-                        if (in < U && out < U) accum[q.oW1 + in * U + out] += aW1[ti][tj][v];
+                        if (in < U && out < U) slab[q.oW1 + in * U + out] = aW1[ti][tj][v];
                     }
 #pragma unroll
             for (int t = 0; t < UT; ++t)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int unit = 16 * t + 4 * g + v, d = slot_d(c), ty = slot_ty(c);
-                    if (unit < U && d < Dy) accum[q.oW2 + unit * 2 * Dy + ty * Dy + d] += aW2[t][v];
+                    if (unit < U && d < Dy) slab[q.oW2 + unit * 2 * Dy + ty * Dy + d] = aW2[t][v];
                     const int dim = 4 * g + v, u2 = 16 * t + c;
-                    if (dim < L && u2 < U) accum[q.oW0 + dim * U + u2] += aW0[t][v];
+                    if (dim < L && u2 < U) slab[q.oW0 + dim * U + u2] = aW0[t][v];
                 }
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int dim = 4 * g + v, d = slot_d(c), ty = slot_ty(c);
-                if (dim < L && d < Dy && ty == 0) accum[q.oWs + dim * Dy + d] += aWs[v];
+                if (dim < L && d < Dy && ty == 0) slab[q.oWs + dim * Dy + d] = aWs[v];
             }
             // biases out of the ones rows: dim 8 <-> lane group g == 2, register 0
             if (g == 2) {
 #pragma unroll
                 for (int t = 0; t < UT; ++t)
-                    if (16 * t + c < U) accum[q.ob0 + 16 * t + c] += aW0[t][0];
+                    if (16 * t + c < U) slab[q.ob0 + 16 * t + c] = aW0[t][0];
                 const int d = slot_d(c), ty = slot_ty(c);
                 if (d < Dy) {
-                    accum[q.ob2 + ty * Dy + d] += aWs[0];
-                    if (ty == 0) accum[q.obs1 + d] += aWs[0];
+                    slab[q.ob2 + ty * Dy + d] = aWs[0];
+                    if (ty == 0) slab[q.obs1 + d] = aWs[0];
                 }
             }
             if (FS) {
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
                         const f32x4 z = aW1[UT - 1][tj];
                         const int v = fsu & 3;
                         const float val = v == 0 ? z[0] : v == 1 ? z[1] : v == 2 ? z[2] : z[3];
-                        if (16 * tj + c < U) accum[q.ob1 + 16 * tj + c] += val;
+                        if (16 * tj + c < U) slab[q.ob1 + 16 * tj + c] = val;
                     }
                 }
             } else {
@@ -621,15 +624,22 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
                     for (int v = 0; v < 4; ++v) {
                         const float s1 = row16_sum(ab1[t][v]);
                         const int unit = 16 * t + 4 * g + v;
-                        if (c == 0 && unit < U) accum[q.ob1 + unit] += s1;
+                        if (c == 0 && unit < U) slab[q.ob1 + unit] = s1;
                     }
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float s2_ = row16_sum(abs2[j]);
                 const int d = 2 * g + j;
-                if (c == 0 && d < Dy) accum[q.obs2 + d] += s2_;
+                if (c == 0 && d < Dy) slab[q.obs2 + d] = s2_;
             }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < q.PW; i += BWD_THREADS) {
+            float t = round ? accum[i] : 0.f;
+#pragma unroll
+            for (int w = 0; w < HALF; ++w) t += sm[(1 + w) * q.PW + i];
+            accum[i] = t;
         }
         __syncthreads();
     }
@@ -689,9 +699,10 @@ int dec_check(const char* what, long long N, int K, int S, int L, int Dy, int U)
 template <bool GIN>
 int dec_bwd_launch(const DecArgs& a, int blocks, hipStream_t s) {
     const int U = a.U;
+    const int red_floats = (1 + BWD_WAVES / 2) * dec_geo(a.L, a.U, a.Dy).PW;     // epilogue: accumulator + 4 slabs
 #define DEC_BWD(UTV, VLV)                                                                                             \
     do {                                                                                                              \
-        const int lds = Img<UTV>::BWD_TOTAL * (int)sizeof(float);                                                     \
+        const int lds = (Img<UTV>::BWD_TOTAL > red_floats ? Img<UTV>::BWD_TOTAL : red_floats) * (int)sizeof(float);   \
         if (VLV == 4 && (U & 15) == 0) {                                                                              \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<UTV, 4, false, GIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
             hipLaunchKernelGGL((dec_bwd_kernel<UTV, 4, false, GIN>), dim3(blocks), dim3(BWD_THREADS), lds, s, a);    \

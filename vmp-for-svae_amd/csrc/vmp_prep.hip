@@ -11,7 +11,13 @@ using namespace vmp;
 namespace {
 
 constexpr int PREP_THREADS = 64;     // K <= VMP_MAX_K = 64
-constexpr int ML = VMP_MAX_D;        // L <= 8
+// L is a template parameter everywhere: with run-time loop bounds the per-thread matrices live in scratch memory and
+// every element access is a dependent round trip (measured: 50 us per launch instead of a few).
+#define PREP_DISPATCH_L(L, CALL)                                                     \
+    switch (L) {                                                                     \
+        case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; \
+        case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break; default: CALL(8); break; \
+    }
 
 __device__ __forceinline__ double softplus_d(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 
@@ -24,8 +30,11 @@ __device__ double digamma_dd(double x) {
 }
 
 // L_k = tril(raw) with softplus on the diagonal (svae.py:347-352), rounded to fp32 as the tensors the reference holds
-__device__ __forceinline__ void load_Lk(const float* __restrict__ raw, int L, double (&Lm)[ML][ML]) {
+template <int L>
+__device__ __forceinline__ void load_Lk(const float* __restrict__ raw, double (&Lm)[L][L]) {
+#pragma unroll
     for (int i = 0; i < L; ++i)
+#pragma unroll
         for (int j = 0; j < L; ++j) {
             double v = 0.0;
             if (j < i) v = (double)raw[i * L + j];
@@ -58,9 +67,9 @@ __device__ __forceinline__ void log_softmax_stats(const float* __restrict__ pira
     lse = mx + log(s);
 }
 
-template <bool BWD>
+template <int L, bool BWD>
 __global__ __launch_bounds__(PREP_THREADS) void phi_prep_kernel(PhiArgs a) {
-    const int k = threadIdx.x, K = a.K, L = a.L;
+    const int k = threadIdx.x, K = a.K;
     __shared__ double s_gb;
     if (BWD && k == 0) {
         double t = 0.0;
@@ -69,13 +78,16 @@ __global__ __launch_bounds__(PREP_THREADS) void phi_prep_kernel(PhiArgs a) {
     }
     __syncthreads();
     if (k >= K) return;
-    double Lm[ML][ML];
-    load_Lk(a.Lraw + (size_t)k * L * L, L, Lm);
-    double h[ML], s[ML];
+    double Lm[L][L];
+    load_Lk<L>(a.Lraw + (size_t)k * L * L, Lm);
+    double h[L], s[L];
+#pragma unroll
     for (int i = 0; i < L; ++i) h[i] = (double)a.mu[k * L + i];
     double B = 0.0;
+#pragma unroll
     for (int i = 0; i < L; ++i) {                       // s = L^-1 h
         double t = h[i];
+#pragma unroll
         for (int j = 0; j < i; ++j) t -= Lm[i][j] * s[j];
         s[i] = t / Lm[i][i];
         B += -0.5 * s[i] * s[i] + log(Lm[i][i]);
@@ -84,11 +96,14 @@ __global__ __launch_bounds__(PREP_THREADS) void phi_prep_kernel(PhiArgs a) {
     log_softmax_stats(a.piraw, K, mx, lse);
     const double logpi = (double)a.piraw[k] - lse;
     if (!BWD) {
+#pragma unroll
         for (int i = 0; i < L; ++i)
+#pragma unroll
             for (int j = 0; j < L; ++j) {
                 a.Lk[((size_t)k * L + i) * L + j] = (float)Lm[i][j];
                 double p = 0.0;
                 const int m = i < j ? i : j;
+#pragma unroll
                 for (int q = 0; q <= m; ++q) p += Lm[i][q] * Lm[j][q];
                 a.P[((size_t)k * L + i) * L + j] = (float)p;
             }
@@ -96,21 +111,32 @@ __global__ __launch_bounds__(PREP_THREADS) void phi_prep_kernel(PhiArgs a) {
         return;
     }
     // ---- backward
-    double u[ML];                                       // u = L^-T s = P^-1 h
+    double u[L];                                        // u = L^-T s = P^-1 h
+#pragma unroll
     for (int i = L - 1; i >= 0; --i) {
         double t = s[i];
+#pragma unroll
         for (int j = i + 1; j < L; ++j) t -= Lm[j][i] * u[j];
         u[i] = t / Lm[i][i];
     }
     const double gb = (double)a.g_bias[k];
+#pragma unroll
     for (int i = 0; i < L; ++i) a.g_mu[k * L + i] = (float)((double)a.g_hk[k * L + i] - gb * u[i]);
     a.g_piraw[k] = (float)(gb - exp(logpi) * s_gb);
     const float* __restrict__ G = a.g_P + (size_t)k * L * L;
+    double Gs[L][L];                                    // G + G^T
+#pragma unroll
     for (int i = 0; i < L; ++i)
+#pragma unroll
+        for (int j = 0; j < L; ++j) Gs[i][j] = (double)G[i * L + j] + (double)G[j * L + i];
+#pragma unroll
+    for (int i = 0; i < L; ++i)
+#pragma unroll
         for (int j = 0; j < L; ++j) {
             double g = 0.0;
             if (j <= i) {
-                for (int q = j; q < L; ++q) g += ((double)G[i * L + q] + (double)G[q * L + i]) * Lm[q][j];   // (G + G^T) L
+#pragma unroll
+                for (int q = j; q < L; ++q) g += Gs[i][q] * Lm[q][j];        // (G + G^T) L
                 g += gb * u[i] * s[j];
                 if (i == j) {
                     g += gb / Lm[i][i];
@@ -130,37 +156,49 @@ struct ThetaArgs {
     int K, L;
 };
 
+template <int L>
 __global__ __launch_bounds__(PREP_THREADS) void theta_pack_kernel(ThetaArgs a) {
-    const int k = threadIdx.x, K = a.K, L = a.L;
+    const int k = threadIdx.x, K = a.K;
     if (k >= K) return;
     double asum = 0.0;
     for (int j = 0; j < K; ++j) asum += (double)a.alpha[j] + 1.0;            // dirichlet.natural_to_standard
     const double elp = digamma_dd((double)a.alpha[k] + 1.0) - digamma_dd(asum);
     const double beta = (double)a.beta[k], nu = (double)a.vhat[k] - (double)(L + 2);   // niw.natural_to_standard
-    double mv[ML], C[ML][ML];
+    double mv[L], C[L][L];
+#pragma unroll
     for (int i = 0; i < L; ++i) mv[i] = (double)a.b[k * L + i] / beta;
+#pragma unroll
     for (int i = 0; i < L; ++i)
+#pragma unroll
         for (int j = 0; j < L; ++j) C[i][j] = (double)a.A[((size_t)k * L + i) * L + j] - (double)a.b[k * L + i] * mv[j];
     // E[Sigma] = (nu sym(C)^-1)^-1 = sym(C) / nu  (niw.expected_values); Cholesky, then W = Lc^-1
-    double Lc[ML][ML];
+    double Lc[L][L];
+    const double inv_nu = 1.0 / nu;
+#pragma unroll
     for (int j = 0; j < L; ++j) {
+#pragma unroll
         for (int i = j; i < L; ++i) {
-            double t = 0.5 * (C[i][j] + C[j][i]) / nu;
+            double t = 0.5 * (C[i][j] + C[j][i]) * inv_nu;
+#pragma unroll
             for (int q = 0; q < j; ++q) t -= Lc[i][q] * Lc[j][q];
             Lc[i][j] = (i == j) ? sqrt(t) : t / Lc[j][j];
         }
     }
     double kap = -0.5 * L * 1.8378770664093454836 + elp;
+#pragma unroll
     for (int j = 0; j < L; ++j) {                       // column j of Lc^-1
-        double w[ML];
+        double w[L];
+#pragma unroll
         for (int i = 0; i < L; ++i) {
             double t = (i == j) ? 1.0 : 0.0;
+#pragma unroll
             for (int q = j; q < i; ++q) t -= Lc[i][q] * w[q];
             w[i] = (i < j) ? 0.0 : t / Lc[i][i];
             a.W[((size_t)k * L + i) * L + j] = (float)w[i];
         }
         kap += log(w[j]);
     }
+#pragma unroll
     for (int i = 0; i < L; ++i) a.m[k * L + i] = (float)mv[i];
     a.kappa[k] = (float)kap;
 }
@@ -223,7 +261,9 @@ int vmp_svae_phi_prep_fwd(const float* mu_k, const float* L_raw, const float* pi
     if (!mu_k || !L_raw || !pi_raw || !Lk || !P || !bias) { set_error("vmp_svae_phi_prep_fwd: NULL argument"); return VMP_E_BADARG; }
     PhiArgs a{};
     a.mu = mu_k; a.Lraw = L_raw; a.piraw = pi_raw; a.Lk = Lk; a.P = P; a.bias = bias; a.K = K; a.L = L;
-    hipLaunchKernelGGL((phi_prep_kernel<false>), dim3(1), dim3(PREP_THREADS), 0, static_cast<hipStream_t>(stream), a);
+#define PREP_CALL(LL) hipLaunchKernelGGL((phi_prep_kernel<LL, false>), dim3(1), dim3(PREP_THREADS), 0, static_cast<hipStream_t>(stream), a)
+    PREP_DISPATCH_L(L, PREP_CALL)
+#undef PREP_CALL
     return check_launch("vmp_svae_phi_prep_fwd");
 }
 
@@ -237,7 +277,9 @@ int vmp_svae_phi_prep_bwd(const float* mu_k, const float* L_raw, const float* pi
     PhiArgs a{};
     a.mu = mu_k; a.Lraw = L_raw; a.piraw = pi_raw; a.g_hk = g_hk; a.g_P = g_P; a.g_bias = g_bias;
     a.g_mu = g_mu; a.g_Lraw = g_Lraw; a.g_piraw = g_piraw; a.K = K; a.L = L;
-    hipLaunchKernelGGL((phi_prep_kernel<true>), dim3(1), dim3(PREP_THREADS), 0, static_cast<hipStream_t>(stream), a);
+#define PREP_CALL(LL) hipLaunchKernelGGL((phi_prep_kernel<LL, true>), dim3(1), dim3(PREP_THREADS), 0, static_cast<hipStream_t>(stream), a)
+    PREP_DISPATCH_L(L, PREP_CALL)
+#undef PREP_CALL
     return check_launch("vmp_svae_phi_prep_bwd");
 }
 
@@ -246,7 +288,9 @@ int vmp_svae_theta_pack(const float* alpha, const float* A, const float* b, cons
     if (int e = prep_check("vmp_svae_theta_pack", K, L)) return e;
     if (!alpha || !A || !b || !beta || !v_hat || !m || !W || !kappa) { set_error("vmp_svae_theta_pack: NULL argument"); return VMP_E_BADARG; }
     ThetaArgs a{alpha, A, b, beta, v_hat, m, W, kappa, K, L};
-    hipLaunchKernelGGL(theta_pack_kernel, dim3(1), dim3(PREP_THREADS), 0, static_cast<hipStream_t>(stream), a);
+#define PREP_CALL(LL) hipLaunchKernelGGL((theta_pack_kernel<LL>), dim3(1), dim3(PREP_THREADS), 0, static_cast<hipStream_t>(stream), a)
+    PREP_DISPATCH_L(L, PREP_CALL)
+#undef PREP_CALL
     return check_launch("vmp_svae_theta_pack");
 }
 
