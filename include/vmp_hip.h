@@ -204,10 +204,20 @@ int    vmp_svae_cvi_update(const double* stats, const float* p_alpha, const floa
  * A_nk = sum_{s,d} [ (y_nd - mean_nksd)^2 / var_nksd + log(var_nksd + 1e-8) ]   -- the tensor the reference
  * contracts with the responsibilities in einsum('nksd,nk->') (vae.py:240).  y (N,Dy); mean, var (N,K,S,Dy).
  * Backward: gmean = gA_nk * d/dmean, gvar = gA_nk * d/dvar (same shapes as mean / var).                        */
+/* eps: the reference adds 1e-8 inside the log in the weights branch (vae.py:240) and nothing in the plain-VAE branch
+ * (weights=None, vae.py:225; call with K = 1, means (M,1,S,L)).                                                    */
 int    vmp_diag_gauss_loglike_fwd(const float* y, const float* mean, const float* var, int64_t N, int K, int S,
-                                  int Dy, float* A, void* stream);
+                                  int Dy, float eps, float* A, void* stream);
 int    vmp_diag_gauss_loglike_bwd(const float* y, const float* mean, const float* var, const float* gA,
-                                  int64_t N, int K, int S, int Dy, float* gmean, float* gvar, void* stream);
+                                  int64_t N, int K, int S, int Dy, float eps, float* gmean, float* gvar, void* stream);
+
+/* Bernoulli decoder: rows_nks = sum_d m_nd * ( -log(1 + exp(-logit_nksd * y_nd)) ), y in {-1,+1},
+ * m = 1 or the missing-data mask (N,D) - the per-sample-row part of vae.expected_bernoulli_loglike
+ * (models/vae.py:175-198) and losses.bernoulli_logprob (losses.py:41-80).  logits (N,K,S,D); rows, g_rows (N,K,S).   */
+int    vmp_bernoulli_rows_fwd(const float* y, const float* logits, const uint8_t* mask, int64_t N, int K, int S, int D,
+                              float* rows, void* stream);
+int    vmp_bernoulli_rows_bwd(const float* y, const float* logits, const uint8_t* mask, const float* g_rows, int64_t N,
+                              int K, int S, int D, float* g_logits, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused decoder MLP + reconstruction term (models/vae.py:75-128 make_nnet, :138-151 make_decoder, :233-248)

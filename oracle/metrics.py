@@ -78,3 +78,23 @@ def imputation_losses(y_true, mask, imputation_method, noise, nb_samples_rec):
         lws.append(log_r.unsqueeze(2).repeat(1, 1, nb_samples_rec))
     ll = diagonal_gaussian_logprob(y_true, torch.cat(means, 2), torch.cat(vars_, 2), torch.cat(lws, 2), mask=mask)
     return mse / P, ll
+
+
+def bernoulli_logprob(y_true_bin, logits, log_weights=None, mask=None):
+    """losses.py:41-80 (note: subtracts S, not log S, :76-78)."""
+    S = logits.shape[-2]
+    yb = y_true_bin.unsqueeze(1)
+    if log_weights is not None:
+        if log_weights.dim() == 2:
+            log_weights = log_weights.unsqueeze(2)
+        yb = yb.unsqueeze(1)
+    px = -torch.log(1. + torch.exp(-logits * yb))
+    if mask is not None:
+        m = mask.to(px.dtype).unsqueeze(1)
+        if log_weights is not None:
+            m = m.unsqueeze(1)
+        px = px * m
+    lp = px.sum(-1)
+    if log_weights is not None:
+        lp = torch.logsumexp(lp + log_weights, dim=1)
+    return (torch.logsumexp(lp, dim=-1) - float(S)).mean()

@@ -35,6 +35,9 @@ def mlp(inp, w, out_type):
     n_hidden = sum(1 for k in w if k.endswith('/kernel') and k.startswith('layer_'))
     for i in range(n_hidden):
         h = torch.tanh(h @ w['layer_%d/kernel' % i] + w['layer_%d/bias' % i])
+    if out_type == 'bernoulli':                                       # vae.py:53-55,89-90,97-104,122
+        logits = h @ w['bernoulli_output/kernel'] + w['bernoulli_output/bias'] + x2d @ w['shortcut/W'] + w['shortcut/b1']
+        return logits.reshape(tuple(shape[:-1]) + (logits.shape[-1],))
     u = h @ w['gaussian_output/kernel'] + w['gaussian_output/bias']
     raw1, raw2 = torch.chunk(u, 2, dim=-1)
     if out_type == 'standard':
@@ -72,3 +75,40 @@ def expected_diagonal_gaussian_loglike(y, means, vars_, weights=None):
         yy = y.unsqueeze(1).unsqueeze(1)
         sm = torch.einsum('nksd,nk->', (yy - means) ** 2 / vars_ + torch.log(vars_ + 1e-8), weights)
     return -0.5 * (sm / S) - M * L / 2. * math.log(2. * math.pi)
+
+
+def decoder_bernoulli(x, w):
+    """vae.py:138-151 with a 'bernoulli' head: (probas, logits)."""
+    logits = mlp(x, w, 'bernoulli')
+    return torch.sigmoid(logits), logits
+
+
+def kl_divergence(enc_mean, enc_var):
+    """vae.py:154-172."""
+    return -(1 + torch.log(enc_var) - enc_mean ** 2 - enc_var).sum(1).mean() / 2.
+
+
+def expected_bernoulli_loglike(y_binary, logits, r_nk=None):
+    """vae.py:175-198 (the reference's naive -log(1 + exp(-logit*y)))."""
+    yb = y_binary.unsqueeze(1)
+    if r_nk is not None:
+        yb = yb.unsqueeze(1)
+    img = (-torch.log(1. + torch.exp(-logits * yb))).sum(-1).mean(-1)
+    if r_nk is not None:
+        img = (r_nk * img).sum(1)
+    return img.sum()
+
+
+def reparam_trick_sampling(mean, var, noise):
+    """vae.py:282-296 with the Normal draw injected: (M,S,L)."""
+    return mean.unsqueeze(1) + torch.sqrt(var).unsqueeze(1) * noise
+
+
+def vae_compute_elbo(y, enc_mu, enc_var, dec_output, decoder_type):
+    """vae.py:253-279."""
+    M = y.shape[0]
+    if decoder_type == 'bernoulli':
+        rec = expected_bernoulli_loglike(y, dec_output[1])
+    else:
+        rec = expected_diagonal_gaussian_loglike(y, dec_output[0], dec_output[1])
+    return rec / M - kl_divergence(enc_mu, enc_var)

@@ -453,6 +453,96 @@ def case_imputation(seed, N, K, S, D, P):
     out.update({'in_' + k: v for k, v in inputs.items()})
     return out
 
+# ============================================================================ Bernoulli decoder + plain VAE (8f rank 4)
+def case_vae_bernoulli(seed, N, K, S, L, D, U):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    y_bin = f32(np.where(rng.random((N, D)) < 0.5, -1.0, 1.0))
+    y_real = f32(rng.standard_normal((N, D)) * 1.5)
+    x4 = f32(rng.standard_normal((N, K, S, L)))
+    lw = rng.standard_normal((N, K))
+    lw = f32(lw - np.log(np.exp(lw).sum(1, keepdims=True)))
+    lws = f32(lw[:, :, None] + 0.1 * rng.standard_normal((N, K, S)))
+    mask = rng.random((N, D)) < 0.3
+    noise_rep = f32(rng.standard_normal((N, S, L)))
+    unif_pert = f32(rng.random((N, D)))
+    std = 0.4
+    w = {}
+    for head, dout, key in (('bernoulli', D, 'bernoulli_output'), ('standard', 2 * D, 'gaussian_output')):
+        pre = 'dec_%s/' % head
+        w[pre + 'layer_0/kernel'] = f32(rng.standard_normal((L, U)) * std)
+        w[pre + 'layer_0/bias'] = f32(rng.standard_normal((U,)) * std)
+        w[pre + 'layer_1/kernel'] = f32(rng.standard_normal((U, U)) * std)
+        w[pre + 'layer_1/bias'] = f32(rng.standard_normal((U,)) * std)
+        w[pre + key + '/kernel'] = f32(rng.standard_normal((U, dout)) * std)
+        w[pre + key + '/bias'] = f32(rng.standard_normal((dout,)) * std)
+        w[pre + 'shortcut/W'] = f32(R.vae.rand_partial_isometry(L, D, 1., seed=0))
+        w[pre + 'shortcut/b1'] = f32(rng.standard_normal((D,)) * 0.1)
+        if head == 'standard':
+            w[pre + 'shortcut/b2'] = f32(rng.standard_normal((D,)) * 0.1)
+    pre = 'enc/'
+    w[pre + 'layer_0/kernel'] = f32(rng.standard_normal((D, U)) * std)
+    w[pre + 'layer_0/bias'] = f32(rng.standard_normal((U,)) * std)
+    w[pre + 'layer_1/kernel'] = f32(rng.standard_normal((U, U)) * std)
+    w[pre + 'layer_1/bias'] = f32(rng.standard_normal((U,)) * std)
+    w[pre + 'gaussian_output/kernel'] = f32(rng.standard_normal((U, 2 * L)) * std)
+    w[pre + 'gaussian_output/bias'] = f32(rng.standard_normal((2 * L,)) * std)
+    w[pre + 'shortcut/W'] = f32(R.vae.rand_partial_isometry(D, L, 1., seed=0))
+    w[pre + 'shortcut/b1'] = f32(rng.standard_normal((L,)) * 0.1)
+    w[pre + 'shortcut/b2'] = f32(rng.standard_normal((L,)) * 0.1)
+    inputs = dict(y_bin=y_bin, y_real=y_real, x4=x4, lw=lw, lws=lws, mask=mask, noise_rep=noise_rep, unif_pert=unif_pert,
+                  dims=np.array([N, K, S, L, D, U]))
+    inputs.update({'w_' + k: v for k, v in w.items()})
+
+    def load(net, prefix):
+        names = []
+        for k, v in w.items():
+            if k.startswith(prefix):
+                full = net + '/' + k[len(prefix):]
+                t = T(v, grad=True)
+                t._tf_name = full + ':0'
+                tf.VARIABLES[full] = t
+                names.append(full)
+        return names
+
+    def run():
+        o = {}
+        tanh = tf.tanh
+        # ---- Bernoulli decoder on the SVAE sample tensor (svae.py:511, vae.py:138-151)
+        load('decoder_net', 'dec_bernoulli/')
+        probas, logits = R.vae.make_decoder(T(x4), [(U, tanh), (U, tanh), (D, 'bernoulli')], stddev_init=0.3)
+        o['probas'], o['logits'] = npy(probas), npy(logits)
+        r = tf.exp(T(lw))
+        o['ebl_weighted'] = npy(R.vae.expected_bernoulli_loglike(T(y_bin), logits, r))
+        o['ebl_plain'] = npy(R.vae.expected_bernoulli_loglike(T(y_bin), logits[:, 0]))
+        o['blp_plain'] = npy(R.losses.bernoulli_logprob(T(y_bin), logits[:, 0]))
+        o['blp_w'] = npy(R.losses.bernoulli_logprob(T(y_bin), logits, T(lw)))
+        o['blp_ws_mask'] = npy(R.losses.bernoulli_logprob(T(y_bin), logits, T(lws), tf._T(torch.as_tensor(mask))))
+        tf.INJECT['random_uniform'] += [T(unif_pert)]
+        o['perturbed_bern'] = npy(R.losses.perturb_data(T(y_bin), tf._T(torch.as_tensor(mask)), 0, decoder_type='bernoulli'))
+        # ---- plain VAE (vae.py:131-135, 282-296, 253-279), Bernoulli and Gaussian decoders, with gradients
+        for head, yv in (('bernoulli', y_bin), ('standard', y_real)):
+            tf.reset()
+            enc_names = load('encoder_net', 'enc/')
+            dec_names = load('decoder_net', 'dec_%s/' % head)
+            mu, var = R.vae.make_encoder(T(yv), [(U, tanh), (U, tanh), (L, 'standard')], stddev_init=0.3)
+            tf.INJECT['random_normal'] += [T(noise_rep)]
+            xs = R.vae.reparam_trick_sampling(mu, var, S, seed=0)
+            dec = R.vae.make_decoder(xs, [(U, tanh), (U, tanh), (D, head)], stddev_init=0.3)
+            elbo = R.vae.compute_elbo(T(yv), mu, var, dec, decoder_type=head)
+            o['vae_%s_enc_mu' % head], o['vae_%s_enc_var' % head] = npy(mu), npy(var)
+            o['vae_%s_x' % head] = npy(xs)
+            o['vae_%s_kl' % head] = npy(R.vae.build_kl_divergence(mu, var))
+            o['vae_%s_elbo' % head] = npy(elbo)
+            names = enc_names + dec_names
+            gr = torch.autograd.grad(-elbo, [tf.VARIABLES[n] for n in names])
+            for n, g_ in zip(names, gr):
+                o['vae_%s_grad_%s' % (head, n)] = npy(g_)
+        return o
+
+    out = both(run)
+    out.update({'in_' + k: v for k, v in inputs.items()})
+    return out
+
 
 def main():
     cases = {
@@ -468,6 +558,7 @@ def main():
         'svae_smm_tiny': lambda: case_svae(10, N=7, K=4, L=3, S=5, Dy=2, U=5, smm=True),
         'metrics': lambda: case_metrics(12, N=50, K=5, S=7, D=3, C=4),
         'metrics_s100': lambda: case_metrics(13, N=12, K=10, S=100, D=6, C=3),
+        'vae_bernoulli': lambda: case_vae_bernoulli(15, N=12, K=4, S=5, L=3, D=40, U=16),
         'imputation': lambda: case_imputation(14, N=40, K=5, S=6, D=6, P=4),
         'svae_smm_l8': lambda: case_svae(11, N=10, K=16, L=8, S=10, Dy=8, U=50, smm=True, steps=2),
     }

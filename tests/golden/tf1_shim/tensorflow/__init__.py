@@ -474,11 +474,33 @@ class _Dirichlet(object):
         return _wrap(v.to(_dt('float')))
 
 
+class _Normal(object):
+    """tf.contrib.distributions.Normal(loc, scale).sample(seed=...): one draw of the parameters' shape (vae.py:292-293)."""
+    def __init__(self, loc, scale):
+        self.loc, self.scale = loc, scale
+
+    def sample(self, seed=None):
+        return random_normal(_b.tuple(self.loc.shape)) * self.scale + self.loc
+
+
+class _BernoulliDist(object):
+    """tf.distributions.Bernoulli(probs=...).sample(seed=...) in {0,1} (losses.py:302-303); draws = injected uniforms."""
+    def __init__(self, probs=None, logits=None):
+        self.probs = probs
+
+    def sample(self, seed=None):
+        u = random_uniform(_b.tuple(self.probs.shape))
+        return _wrap((u < self.probs).to(self.probs.dtype))
+
+
 contrib = _NS()
 contrib.linalg = _NS()
 contrib.linalg.LinearOperatorTriL = _TriL
 contrib.distributions = _NS()
 contrib.distributions.Dirichlet = _Dirichlet
+contrib.distributions.Normal = _Normal
+distributions = _NS()
+distributions.Bernoulli = _BernoulliDist
 
 summary = _NS()
 for _n in ('scalar', 'histogram', 'tensor_summary', 'image', 'merge_all', 'merge', 'FileWriter'):

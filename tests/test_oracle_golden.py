@@ -222,3 +222,40 @@ def test_imputation(golden, dtype, suf, rtol):
     close(metrics.imputation_mse(y, T(g['in_y_pred'], dtype), T(g['in_r'], dtype), mask), g['imputation_mse' + suf], rtol)
     mse, ll = metrics.imputation_losses(y, mask, _toy_impute(g, dtype), noise, S)
     close(mse, g['imp_mse' + suf], rtol), close(ll, g['imp_loglike' + suf], rtol)
+
+
+def _vb_weights(g, prefix, dtype):
+    return {k[len('in_w_' + prefix):]: T(g[k], dtype) for k in g.files if k.startswith('in_w_' + prefix)}
+
+
+@pytest.mark.parametrize('dtype,suf,rtol', [(torch.float64, '', 1e-10), (torch.float32, '__f32', 2e-4)])
+def test_bernoulli_and_plain_vae(golden, dtype, suf, rtol):
+    """SURVEY 8f rank 4 (vae.py:53-55,138-198,253-296; losses.py:41-80) vs the reference run."""
+    g = golden('vae_bernoulli')
+    N, K, S, Ld, D, U = [int(v) for v in g['in_dims']]
+    yb, yr, x4, lw, lws = [T(g['in_' + k], dtype) for k in ('y_bin', 'y_real', 'x4', 'lw', 'lws')]
+    mask = torch.as_tensor(g['in_mask'])
+    probas, logits = nets.decoder_bernoulli(x4, _vb_weights(g, 'dec_bernoulli/', dtype))
+    close(probas, g['probas' + suf], rtol), close(logits, g['logits' + suf], rtol)
+    close(nets.expected_bernoulli_loglike(yb, logits, torch.exp(lw)), g['ebl_weighted' + suf], rtol)
+    close(nets.expected_bernoulli_loglike(yb, logits[:, 0]), g['ebl_plain' + suf], rtol)
+    close(metrics.bernoulli_logprob(yb, logits[:, 0]), g['blp_plain' + suf], rtol)
+    close(metrics.bernoulli_logprob(yb, logits, lw), g['blp_w' + suf], rtol)
+    close(metrics.bernoulli_logprob(yb, logits, lws, mask), g['blp_ws_mask' + suf], rtol)
+    pert = torch.where(mask, torch.where(T(g['in_unif_pert'], dtype) < 0.5, 1.0, -1.0).to(dtype) * 0 +
+                       torch.where(T(g['in_unif_pert'], dtype) < 0.5, torch.ones_like(yb), -torch.ones_like(yb)), yb)
+    close(pert, g['perturbed_bern' + suf], rtol)
+    for head, y in (('bernoulli', yb), ('standard', yr)):
+        ew = {k: v.clone().requires_grad_(True) for k, v in _vb_weights(g, 'enc/', dtype).items()}
+        dw = {k: v.clone().requires_grad_(True) for k, v in _vb_weights(g, 'dec_%s/' % head, dtype).items()}
+        mu, var = nets.mlp(y, ew, 'standard')
+        xs = nets.reparam_trick_sampling(mu, var, T(g['in_noise_rep'], dtype))
+        dec = nets.decoder_bernoulli(xs, dw) if head == 'bernoulli' else nets.decoder(xs, dw)
+        elbo = nets.vae_compute_elbo(y, mu, var, dec, head)
+        close(xs, g['vae_%s_x%s' % (head, suf)], rtol)
+        close(nets.kl_divergence(mu, var), g['vae_%s_kl%s' % (head, suf)], rtol)
+        close(elbo, g['vae_%s_elbo%s' % (head, suf)], rtol)
+        names = [('encoder_net/' + k, v) for k, v in ew.items()] + [('decoder_net/' + k, v) for k, v in dw.items()]
+        grads = torch.autograd.grad(-elbo, [v for _, v in names])
+        for (n_, _), gr in zip(names, grads):
+            close(gr, g['vae_%s_grad_%s%s' % (head, n_, suf)], 5 * rtol, what=n_)

@@ -41,8 +41,10 @@ _SIGNATURES = {
     'vmp_gauss_logprob_nat': (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _P, _P]),
     'vmp_student_t_logprob': (_c.c_int, [_P, _P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
     'vmp_eval_cell_metrics': (_c.c_int, [_P, _P, _P, _P, _c.c_int, _P, _c.c_int, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
-    'vmp_diag_gauss_loglike_fwd': (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
-    'vmp_diag_gauss_loglike_bwd': (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
+    'vmp_diag_gauss_loglike_fwd': (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _P, _P]),
+    'vmp_diag_gauss_loglike_bwd': (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _P, _P, _P]),
+    'vmp_bernoulli_rows_fwd': (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
+    'vmp_bernoulli_rows_bwd': (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
     'vmp_decoder_param_words': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int]),
     'vmp_decoder_workspace_bytes': (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     'vmp_decoder_loglike_fwd': (_c.c_int, [_P] * 11 + [_c.c_int64] + [_c.c_int] * 5 + [_P] * 4),

@@ -20,6 +20,7 @@ struct LLArgs {
     float* gvar;           // (N,K,S,Dy)
     long long cells;       // N*K
     int K, S, Dy, vec_ok;
+    float eps;             // log(var + eps): 1e-8 in the weights branch (vae.py:240), 0 in the plain-VAE branch (vae.py:225)
 };
 
 template <bool BWD>
@@ -54,9 +55,9 @@ __global__ __launch_bounds__(256) void loglike_kernel(LLArgs a) {
                             const float df = y4[q] - mm[q], iv = 1.0f / vv[q];
                             if (BWD) {
                                 gm[q] = g * (-2.f * df * iv);
-                                gv[q] = g * (1.0f / (vv[q] + 1e-8f) - df * df * iv * iv);
+                                gv[q] = g * (1.0f / (vv[q] + a.eps) - df * df * iv * iv);
                             } else {
-                                acc += df * df * iv + logf(vv[q] + 1e-8f);
+                                acc += df * df * iv + logf(vv[q] + a.eps);
                             }
                         }
                         if (BWD) {
@@ -70,9 +71,9 @@ __global__ __launch_bounds__(256) void loglike_kernel(LLArgs a) {
                         const float df = yr[d] - m, iv = 1.0f / v;
                         if (BWD) {
                             a.gmean[base + d] = g * (-2.f * df * iv);
-                            a.gvar[base + d] = g * (1.0f / (v + 1e-8f) - df * df * iv * iv);
+                            a.gvar[base + d] = g * (1.0f / (v + a.eps) - df * df * iv * iv);
                         } else {
-                            acc += df * df * iv + logf(v + 1e-8f);
+                            acc += df * df * iv + logf(v + a.eps);
                         }
                     }
                 }
@@ -170,6 +171,77 @@ __global__ __launch_bounds__(256) void eval_kernel(EvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Bernoulli decoder (reference models/vae.py:175-198 expected_bernoulli_loglike, losses.py:41-80
+// bernoulli_logprob): per sample row (n,k,s)   rows_nks = sum_d m_nd * ( -log(1 + exp(-logit_nksd * y_nd)) ),
+// y in {-1,+1}, m = 1 or the missing-data mask; evaluated as -softplus(-logit*y) (the reference's naive form
+// overflows for logit*y << 0).  One wave per row when D >= 32 (lanes stride over d, coalesced), else one lane per row.
+// ---------------------------------------------------------------------------------------------------------
+struct BernArgs {
+    const float* y;          // (N,D)
+    const float* logits;     // (R,D), R = N*K*S
+    const uint8_t* mask;     // (N,D) or NULL
+    const float* grow;       // (R) backward
+    float* rows;             // (R) forward
+    float* glogits;          // (R,D) backward
+    long long R;
+    int KS, D;
+};
+
+__device__ __forceinline__ float neg_softplus(float z) {           // -log(1 + exp(z))
+    return -(fmaxf(z, 0.f) + log1pf(__expf(-fabsf(z))));
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void bern_kernel(BernArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int D = a.D;
+    if (D >= 32) {
+        for (long long r = (long long)blockIdx.x * nw + wave; r < a.R; r += (long long)gridDim.x * nw) {
+            const long long n = r / a.KS;
+            const float* __restrict__ lg = a.logits + r * D;
+            const float* __restrict__ yr = a.y + n * D;
+            const float g = BWD ? a.grow[r] : 0.f;
+            float acc = 0.f;
+            for (int d = lane; d < D; d += WAVE) {
+                const float m = a.mask ? (a.mask[n * D + d] ? 1.f : 0.f) : 1.f;
+                const float z = -lg[d] * yr[d];
+                if (BWD) a.glogits[r * D + d] = g * m * yr[d] / (1.0f + __expf(-z));     // y * sigmoid(-logit*y)
+                else acc += m * neg_softplus(z);
+            }
+            if (!BWD) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+                if (lane == 0) a.rows[r] = acc;
+            }
+        }
+    } else {
+        for (long long r = ((long long)blockIdx.x * nw + wave) * WAVE + lane; r < a.R; r += (long long)gridDim.x * nw * WAVE) {
+            const long long n = r / a.KS;
+            const float g = BWD ? a.grow[r] : 0.f;
+            float acc = 0.f;
+            for (int d = 0; d < D; ++d) {
+                const float m = a.mask ? (a.mask[n * D + d] ? 1.f : 0.f) : 1.f;
+                const float yv = a.y[n * D + d];
+                const float z = -a.logits[r * D + d] * yv;
+                if (BWD) a.glogits[r * D + d] = g * m * yv / (1.0f + __expf(-z));
+                else acc += m * neg_softplus(z);
+            }
+            if (!BWD) a.rows[r] = acc;
+        }
+    }
+}
+
+int bern_launch(BernArgs a, bool bwd, hipStream_t s) {
+    long long units = a.D >= 32 ? a.R : (a.R + WAVE - 1) / WAVE;
+    long long blocks = (units + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    if (bwd) hipLaunchKernelGGL((bern_kernel<true>), dim3((int)blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((bern_kernel<false>), dim3((int)blocks), dim3(256), 0, s, a);
+    return check_launch("bern_kernel");
+}
+
 bool al16b(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int ll_launch(LLArgs a, bool bwd, hipStream_t s) {
@@ -187,17 +259,17 @@ int ll_launch(LLArgs a, bool bwd, hipStream_t s) {
 extern "C" {
 
 int vmp_diag_gauss_loglike_fwd(const float* y, const float* mean, const float* var, int64_t N, int K, int S, int Dy,
-                               float* A, void* stream) {
+                               float eps, float* A, void* stream) {
     if (!y || !mean || !var || !A || N <= 0 || K <= 0 || S <= 0 || Dy <= 0) { set_error("vmp_diag_gauss_loglike_fwd: bad argument"); return VMP_E_BADARG; }
-    LLArgs a{y, mean, var, nullptr, A, nullptr, nullptr, (long long)N * K, K, S, Dy, 0};
+    LLArgs a{y, mean, var, nullptr, A, nullptr, nullptr, (long long)N * K, K, S, Dy, 0, eps};
     a.vec_ok = al16b(y) && al16b(mean) && al16b(var);
     return ll_launch(a, false, static_cast<hipStream_t>(stream));
 }
 
 int vmp_diag_gauss_loglike_bwd(const float* y, const float* mean, const float* var, const float* gA, int64_t N, int K,
-                               int S, int Dy, float* gmean, float* gvar, void* stream) {
+                               int S, int Dy, float eps, float* gmean, float* gvar, void* stream) {
     if (!y || !mean || !var || !gA || !gmean || !gvar || N <= 0 || K <= 0 || S <= 0 || Dy <= 0) { set_error("vmp_diag_gauss_loglike_bwd: bad argument"); return VMP_E_BADARG; }
-    LLArgs a{y, mean, var, gA, nullptr, gmean, gvar, (long long)N * K, K, S, Dy, 0};
+    LLArgs a{y, mean, var, gA, nullptr, gmean, gvar, (long long)N * K, K, S, Dy, 0, eps};
     a.vec_ok = al16b(y) && al16b(mean) && al16b(var) && al16b(gmean) && al16b(gvar);
     return ll_launch(a, true, static_cast<hipStream_t>(stream));
 }
@@ -215,6 +287,20 @@ int vmp_eval_cell_metrics(const float* y, const float* mean, const float* var, c
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(eval_kernel, dim3((int)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return check_launch("eval_kernel");
+}
+
+int vmp_bernoulli_rows_fwd(const float* y, const float* logits, const uint8_t* mask, int64_t N, int K, int S, int D,
+                           float* rows, void* stream) {
+    if (!y || !logits || !rows || N <= 0 || K <= 0 || S <= 0 || D <= 0) { set_error("vmp_bernoulli_rows_fwd: bad argument"); return VMP_E_BADARG; }
+    BernArgs a{y, logits, mask, nullptr, rows, nullptr, (long long)N * K * S, K * S, D};
+    return bern_launch(a, false, static_cast<hipStream_t>(stream));
+}
+
+int vmp_bernoulli_rows_bwd(const float* y, const float* logits, const uint8_t* mask, const float* g_rows, int64_t N, int K,
+                           int S, int D, float* g_logits, void* stream) {
+    if (!y || !logits || !g_rows || !g_logits || N <= 0 || K <= 0 || S <= 0 || D <= 0) { set_error("vmp_bernoulli_rows_bwd: bad argument"); return VMP_E_BADARG; }
+    BernArgs a{y, logits, mask, g_rows, nullptr, g_logits, (long long)N * K * S, K * S, D};
+    return bern_launch(a, true, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

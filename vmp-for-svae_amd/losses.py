@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .models import _mix
+from .models import _mix, _svae_ops
 
 
 def _cell_metrics(y, mean, var, logw, mask, want_mse, want_lse, mask_mse=False):
@@ -52,6 +52,29 @@ def diagonal_gaussian_logprob(y_true, mean, var, log_weights, mask=None, name='g
     """reference losses.py:83-145: mean_n log sum_k exp(log_weights) 1/S sum_s N(y_n | mean_nks, diag var_nks)."""
     _, lse = _cell_metrics(y_true, mean, var, log_weights, mask, False, True)
     return torch.logsumexp(lse, dim=1).mean()
+
+
+def bernoulli_logprob(y_true_bin, logits, log_weights=None, missing_data_mask=None, name='bernoulli_logprob'):
+    """reference losses.py:41-80.  logits (N,S,D) or, with log_weights (N,K) / (N,K,S), (N,K,S,D); y in {-1,+1}.
+    Kept as written: the sample average subtracts S, not log S (losses.py:76-78)."""
+    if log_weights is None:
+        N, S, D = logits.shape
+        lg4 = logits.unsqueeze(1)
+    else:
+        N, K, S, D = logits.shape
+        if tuple(log_weights.shape) not in ((N, K), (N, K, S)):
+            raise AssertionError('log_weights must have shape (N,K) or (N,K,S)')
+        if log_weights.dim() == 2:
+            log_weights = log_weights.unsqueeze(2)
+        lg4 = logits
+    if tuple(y_true_bin.shape) != (N, D):
+        raise AssertionError('y_true_bin must have shape (N,D)')
+    rows = _svae_ops.BernoulliRowsFn.apply(y_true_bin, lg4.contiguous(), missing_data_mask)      # (N,K|1,S)
+    if log_weights is not None:
+        logprobs = torch.logsumexp(rows + log_weights, dim=1)                                   # (N,S)
+    else:
+        logprobs = rows[:, 0, :]
+    return (torch.logsumexp(logprobs, dim=-1) - float(S)).mean()
 
 
 def purity(r_nk, labels, eps=1e-10, name='purity'):
@@ -111,12 +134,15 @@ def generate_missing_data_mask(y, noise_ratio=0.3, mask_type='random', seed=0, n
 def perturb_data(y, missing_data_mask, seed, decoder_type='standard', name='perturb_data', noise=None):
     """reference losses.py:288-310: masked entries are replaced by N(0,1) noise (`noise` (N,D) injects the draw that
     tf.random_normal makes in the reference)."""
-    if decoder_type != 'standard':
-        raise NotImplementedError("decoder_type '%s': SURVEY 8f rank 4" % decoder_type)
     m = missing_data_mask.to(y.dtype)
     if noise is None:
         g = torch.Generator(device=y.device).manual_seed(int(seed))
-        noise = torch.randn(y.shape, generator=g, device=y.device, dtype=y.dtype)
+        if decoder_type == 'standard':
+            noise = torch.randn(y.shape, generator=g, device=y.device, dtype=y.dtype)
+        elif decoder_type == 'bernoulli':                 # fair coin in {-1,+1} (losses.py:301-306)
+            noise = (torch.rand(y.shape, generator=g, device=y.device) < 0.5).to(y.dtype) * 2.0 - 1.0
+        else:
+            raise NotImplementedError
     return (1.0 - m) * y + m * noise
 
 
@@ -129,17 +155,33 @@ def imputation_losses(y_true, missing_data_mask, imputation_method, nb_samples_p
     log 1/(P S) sum_{p,s} e^{..} = logsumexp_p(lse_p) - log P with lse_p the per-cell value of one perturbation.
     `noise` (P,N,D) injects the perturbation draws; by default perturbation p uses seed + p (the reference passes the
     SAME op seed to every tf.random_normal, losses.py:207)."""
-    if decoder_type != 'standard':
-        raise NotImplementedError("decoder_type '%s': SURVEY 8f rank 4" % decoder_type)
+    if decoder_type not in ('standard', 'bernoulli'):
+        raise NotImplementedError
+    bern = decoder_type == 'bernoulli'
+    # for the MSE the binary data in {-1,1} is compared as {0,1} (losses.py:193-198)
+    y_cmp = torch.where(y_true == -1, torch.zeros_like(y_true), torch.ones_like(y_true)) if bern else y_true
     mse = 0.0
     lse_acc = None
+    rows_all, lw_all = [], []
     for p in range(nb_samples_pert):
-        y_pert = perturb_data(y_true, missing_data_mask, seed + p, noise=None if noise is None else noise[p])
+        y_pert = perturb_data(y_true, missing_data_mask, seed + p, decoder_type=decoder_type,
+                              noise=None if noise is None else noise[p])
         with torch.no_grad():
-            mean, var, log_r_nk = imputation_method(y_pert)
-        m_p, lse_p = _cell_metrics(y_true, mean, var, log_r_nk, missing_data_mask, True, True, mask_mse=True)
+            mean, out2, log_r_nk = imputation_method(y_pert)
+        if bern:
+            m_p, _ = _cell_metrics(y_cmp, mean, None, None, missing_data_mask, True, False, mask_mse=True)
+            rows_all.append(_svae_ops.BernoulliRowsFn.apply(y_true, out2.contiguous(), missing_data_mask))
+            lw_all.append(log_r_nk.unsqueeze(2).expand(-1, -1, out2.shape[2]))
+        else:
+            m_p, lse_p = _cell_metrics(y_true, mean, out2, log_r_nk, missing_data_mask, True, True, mask_mse=True)
+            lse_acc = lse_p if lse_acc is None else torch.logaddexp(lse_acc, lse_p)
         mse = mse + (m_p * torch.exp(log_r_nk)).sum() / y_true.shape[0]
-        lse_acc = lse_p if lse_acc is None else torch.logaddexp(lse_acc, lse_p)
     expected_mse = mse / nb_samples_pert
-    loglike = torch.logsumexp(lse_acc - math.log(nb_samples_pert), dim=1).mean()
+    if bern:
+        # bernoulli_logprob on the imputations concatenated along S (losses.py:231-241): only (N,K,S)-sized tensors
+        rows, lw = torch.cat(rows_all, dim=2), torch.cat(lw_all, dim=2)
+        logprobs = torch.logsumexp(rows + lw, dim=1)
+        loglike = (torch.logsumexp(logprobs, dim=-1) - float(rows.shape[2])).mean()
+    else:
+        loglike = torch.logsumexp(lse_acc - math.log(nb_samples_pert), dim=1).mean()
     return expected_mse, loglike

@@ -87,10 +87,11 @@ class SvaeEStepFn(torch.autograd.Function):
 
 
 class DiagGaussLoglikeFn(torch.autograd.Function):
-    """A_nk = sum_{s,d} (y - mean)^2 / var + log(var + 1e-8)   (reference vae.py:240), with gradients to mean, var."""
+    """A_nk = sum_{s,d} (y - mean)^2 / var + log(var + eps), eps = 1e-8 in the weights branch (reference vae.py:240),
+    0 in the plain-VAE branch (vae.py:225); gradients to mean, var."""
 
     @staticmethod
-    def forward(ctx, y, mean, var):
+    def forward(ctx, y, mean, var, eps=1e-8):
         y = _c(y, 'y')
         mean = _c(mean, 'means')
         var = _c(var, 'vars', tuple(mean.shape))
@@ -98,9 +99,10 @@ class DiagGaussLoglikeFn(torch.autograd.Function):
         if tuple(y.shape) != (N, Dy):
             raise L.VmpError('y must have shape (N,Dy)')
         A = torch.empty(N, K, dtype=torch.float32, device=y.device)
-        L.check(L.lib().vmp_diag_gauss_loglike_fwd(L.ptr(y), L.ptr(mean), L.ptr(var), N, K, S, Dy, L.ptr(A), L.stream()),
-                'vmp_diag_gauss_loglike_fwd')
+        L.check(L.lib().vmp_diag_gauss_loglike_fwd(L.ptr(y), L.ptr(mean), L.ptr(var), N, K, S, Dy, float(eps), L.ptr(A),
+                                                   L.stream()), 'vmp_diag_gauss_loglike_fwd')
         ctx.save_for_backward(y, mean, var)
+        ctx.eps = float(eps)
         return A
 
     @staticmethod
@@ -109,9 +111,43 @@ class DiagGaussLoglikeFn(torch.autograd.Function):
         N, K, S, Dy = mean.shape
         gA = gA.contiguous()
         gm, gv = torch.empty_like(mean), torch.empty_like(var)
-        L.check(L.lib().vmp_diag_gauss_loglike_bwd(L.ptr(y), L.ptr(mean), L.ptr(var), L.ptr(gA), N, K, S, Dy, L.ptr(gm),
-                                                   L.ptr(gv), L.stream()), 'vmp_diag_gauss_loglike_bwd')
-        return None, gm, gv
+        L.check(L.lib().vmp_diag_gauss_loglike_bwd(L.ptr(y), L.ptr(mean), L.ptr(var), L.ptr(gA), N, K, S, Dy, ctx.eps,
+                                                   L.ptr(gm), L.ptr(gv), L.stream()), 'vmp_diag_gauss_loglike_bwd')
+        return None, gm, gv, None
+
+
+class BernoulliRowsFn(torch.autograd.Function):
+    """rows_nks = sum_d m_nd (-log(1 + exp(-logit_nksd y_nd)))  (reference vae.py:190-192, losses.py:61-69);
+    y in {-1,+1} (N,D), logits (N,K,S,D), mask (N,D) bool or None.  Gradient to the logits."""
+
+    @staticmethod
+    def forward(ctx, y, logits, mask=None):
+        y = _c(y, 'y_binary')
+        logits = _c(logits, 'logits')
+        N, K, S, D = logits.shape
+        if tuple(y.shape) != (N, D):
+            raise AssertionError('y_binary must have shape (N,D)')
+        m8 = None
+        if mask is not None:
+            if tuple(mask.shape) != (N, D):
+                raise AssertionError('mask must have shape (N,D)')
+            m8 = mask.to(torch.uint8).contiguous()
+        rows = torch.empty(N, K, S, dtype=torch.float32, device=y.device)
+        L.check(L.lib().vmp_bernoulli_rows_fwd(L.ptr(y), L.ptr(logits), L.ptr(m8), N, K, S, D, L.ptr(rows), L.stream()),
+                'vmp_bernoulli_rows_fwd')
+        ctx.save_for_backward(y, logits)
+        ctx.m8 = m8
+        return rows
+
+    @staticmethod
+    def backward(ctx, g_rows):
+        y, logits = ctx.saved_tensors
+        N, K, S, D = logits.shape
+        g_rows = g_rows.contiguous().float()
+        gl = torch.empty_like(logits)
+        L.check(L.lib().vmp_bernoulli_rows_bwd(L.ptr(y), L.ptr(logits), L.ptr(ctx.m8), L.ptr(g_rows), N, K, S, D, L.ptr(gl),
+                                               L.stream()), 'vmp_bernoulli_rows_bwd')
+        return None, gl, None
 
 
 def gauss_logprob_nat(x, eta1, eta2, weights=None):

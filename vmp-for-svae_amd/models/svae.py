@@ -194,13 +194,15 @@ def m_step_smm(smm_prior, r_nk):
 
 def compute_elbo(y, reconstructions, theta, phi_tilde, x_k_samps, log_z_given_y_phi, decoder_type):
     """reference svae.py:199-262.  Returns (elbo, (neg_rec_err, numerator, denominator, regulariser))."""
-    if decoder_type != 'standard':
-        raise NotImplementedError("decoder_type '%s': SURVEY 8f rank 4" % decoder_type)
+    if decoder_type not in ('standard', 'bernoulli'):
+        raise NotImplementedError("decoder_type '%s'" % decoder_type)
     if not isinstance(phi_tilde, PhiTilde) or phi_tilde.T_prime is None or phi_tilde.theta_key != _theta_key(theta):
         raise L.VmpError('compute_elbo needs the per-cell terms of the fused E-step: call e_step / inference with '
                          'theta=<the same theta> (the stand-alone per-sample density kernels are not built yet)')
     r_nk = torch.exp(log_z_given_y_phi)
-    if isinstance(reconstructions, vae.LazyReconstruction):     # fused decoder + reconstruction term
+    if decoder_type == 'bernoulli':                               # svae.py:222-223: out_2 = logits
+        rec = vae.expected_bernoulli_loglike(y, reconstructions[1], r_nk=r_nk)
+    elif isinstance(reconstructions, vae.LazyReconstruction):   # fused decoder + reconstruction term
         rec = vae.expected_diagonal_gaussian_loglike(y, reconstructions, None, weights=r_nk)
     else:
         means, out_2 = reconstructions

@@ -78,7 +78,12 @@ def make_nnet(input, layerspecs, stddev, name, param_device=None, seed=0):
         h = make_layer(h, units, stddev, act, 'layer_%d' % i, seed=seed, scope=name)
     out_dim, typ = layerspecs[-1]
     if typ == 'bernoulli':
-        raise NotImplementedError("bernoulli decoder: SURVEY 8f rank 4 (not on the hot path of BASELINE's configs)")
+        # reference vae.py:53-55,89-90,122: logits = dense(h) + x W + b1 (no second shortcut output)
+        logits = make_layer(h, out_dim, stddev, None, 'bernoulli_output', seed=seed, scope=name)
+        W = _get_variable(name + '/shortcut/W', lambda: torch.as_tensor(rand_partial_isometry(shape[-1], out_dim, 1., seed),
+                                                                        dtype=torch.float32).to(input.device))
+        b1 = _get_variable(name + '/shortcut/b1', lambda: torch.zeros(out_dim, device=input.device))
+        return (logits + torch.addmm(b1, x2, W)).reshape(shape[:-1] + (out_dim,))
     u = make_layer(h, 2 * out_dim, stddev, None, 'gaussian_output', seed=seed, scope=name)
     raw1, raw2 = u[:, :out_dim], u[:, out_dim:]
     if typ == 'standard':
@@ -181,18 +186,73 @@ def make_decoder(input, layerspecs=None, stddev_init=1., param_device=None, seed
         if not torch.is_grad_enabled():
             ps = decoder_variables(input.shape[-1], layerspecs, stddev_init, seed, input.device)
             return _svae_ops.decoder_outputs(input, ps)
-    return make_nnet(input, layerspecs, stddev_init, 'decoder_net', param_device, seed)
+    output = make_nnet(input, layerspecs, stddev_init, 'decoder_net', param_device, seed)
+    if layerspecs[-1][1] == 'bernoulli':                      # vae.py:147-149: (probas, logits)
+        output = torch.sigmoid(output), output
+    return output
+
+
+def make_bernoulli_layer(input, output_dim, stddev=1, name='bernoulli_output', param_device=None, seed=0, scope=''):
+    """reference vae.py:53-55."""
+    return make_layer(input, output_dim, stddev, None, name, param_device, seed, scope)
+
+
+def build_kl_divergence(enc_mean, enc_var, name='kl_divergence'):
+    """reference vae.py:154-172: KL(N(mean, diag var) || N(0, I)) averaged over the minibatch ((M,L)-sized: torch)."""
+    return -(1 + torch.log(enc_var) - enc_mean ** 2 - enc_var).sum(dim=1).mean() / 2.
+
+
+def expected_bernoulli_loglike(y_binary, logits, r_nk=None, name='bernoulli_expct_loglike'):
+    """reference vae.py:175-198: sum_n [sum_k r_nk] mean_s sum_d -log(1 + exp(-logit y)); the (.., S, D)-sized part
+    runs in the HIP kernel vmp_bernoulli_rows."""
+    if r_nk is None:
+        N, S, D = logits.shape
+        if tuple(y_binary.shape) != (N, D):
+            raise AssertionError('y_binary must have shape (N,D)')
+        rows = _svae_ops.BernoulliRowsFn.apply(y_binary, logits.unsqueeze(1))         # (N,1,S)
+        return rows.mean(-1).sum()
+    N, K, S, D = logits.shape
+    if tuple(y_binary.shape) != (N, D) or tuple(r_nk.shape) != (N, K):
+        raise AssertionError('shape mismatch')
+    rows = _svae_ops.BernoulliRowsFn.apply(y_binary, logits)                          # (N,K,S)
+    return (r_nk * rows.mean(-1)).sum()
+
+
+def compute_elbo(y_true, enc_mu, enc_var, dec_output, decoder_type='standard', name='elbo'):
+    """reference vae.py:253-279: the plain-VAE ELBO (Kingma & Welling, eq. 8), per datapoint."""
+    M, D = y_true.shape
+    d_kl = build_kl_divergence(enc_mu, enc_var)
+    if decoder_type == 'bernoulli':
+        _, dec_logits = dec_output
+        neg_rec_err = expected_bernoulli_loglike(y_true, dec_logits)
+    elif decoder_type == 'standard':
+        dec_mu, dec_var = dec_output
+        neg_rec_err = expected_diagonal_gaussian_loglike(y_true, dec_mu, dec_var)
+    else:
+        raise NotImplementedError
+    return neg_rec_err / M - d_kl
+
+
+def reparam_trick_sampling(mean, var_diag, nb_samples, seed, noise=None):
+    """reference vae.py:282-296: mean + sqrt(var) * eps, eps (M,S,L) ~ N(0,1) (`noise` injects the draw)."""
+    M, Ld = mean.shape
+    if noise is None:
+        g = torch.Generator(device=mean.device).manual_seed(int(seed))
+        noise = torch.randn(M, nb_samples, Ld, generator=g, device=mean.device, dtype=mean.dtype)
+    return mean.unsqueeze(1) + torch.sqrt(var_diag).unsqueeze(1) * noise
 
 
 def expected_diagonal_gaussian_loglike(y, means, vars, weights=None, name='diag_gauss_expct'):
     """reference vae.py:201-250.  weights (N,K) branch: HIP reduction over (s,d) + K-cheap contraction."""
     if weights is None:
+        # plain-VAE branch (vae.py:217-230): sum (y - mean)^2 / var + sum log var (no epsilon), K = 1
         if means.dim() != 3:
             means, vars = means.unsqueeze(1), vars.unsqueeze(1)
         M, S, Ld = means.shape
-        A = _svae_ops.DiagGaussLoglikeFn.apply(y, means.unsqueeze(1), (vars - 1e-8).unsqueeze(1)) \
-            if False else None
-        raise NotImplementedError('plain-VAE branch (weights=None): SURVEY 8f rank 4')
+        if tuple(y.shape) != (M, Ld):
+            raise AssertionError('y must have shape (M,L)')
+        A = _svae_ops.DiagGaussLoglikeFn.apply(y, means.unsqueeze(1).contiguous(), vars.unsqueeze(1).contiguous(), 0.0)
+        return -0.5 * A.sum() / S - M * Ld / 2. * float(np.log(2. * np.pi))
     if isinstance(means, LazyReconstruction):
         M, K, S, _ = means.x.shape
         Ld = y.shape[1]

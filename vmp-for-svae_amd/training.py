@@ -246,3 +246,35 @@ class GraphedSVAEStep(object):
         tr.opt.t += 1
         tr.global_step += 1
         return self.out
+
+
+class VAETrainer(object):
+    """The plain-VAE baseline of the reference (the training loop of models/vae.py:298-end): encoder with a 'standard'
+    Gaussian head, reparameterised samples, Gaussian or Bernoulli decoder, ELBO of vae.compute_elbo, TF-Adam."""
+
+    def __init__(self, Ld, U, Dy, nb_samples=10, lr=3e-4, stddev_init_nn=0.01, seed=0, decoder_type='standard',
+                 device='cuda'):
+        tanh = torch.tanh
+        self.encoder_layers = [(U, tanh), (U, tanh), (Ld, 'standard')]
+        self.decoder_layers = [(U, tanh), (U, tanh), (Dy, decoder_type)]
+        self.decoder_type, self.S, self.lr = decoder_type, nb_samples, lr
+        self.stddev_init_nn, self.seed, self.device = stddev_init_nn, seed, torch.device(device)
+        self.global_step = 0
+        self.opt = None
+
+    def forward(self, y, noise=None):
+        mu, var = vae.make_encoder(y, self.encoder_layers, self.stddev_init_nn, seed=self.seed)
+        x = vae.reparam_trick_sampling(mu, var, self.S, self.seed + self.global_step, noise=noise)
+        dec = vae.make_decoder(x, self.decoder_layers, self.stddev_init_nn, seed=self.seed)
+        return vae.compute_elbo(y, mu, var, dec, self.decoder_type), (mu, var, x, dec)
+
+    def step(self, y, noise=None):
+        elbo, _ = self.forward(y, noise)
+        names = [n for scope in ('encoder_net', 'decoder_net') for n in sorted(vae.VARIABLES) if n.startswith(scope + '/')]
+        params = [vae.VARIABLES[n] for n in names]
+        grads = torch.autograd.grad(-elbo, params)
+        if self.opt is None:
+            self.opt = TFAdam(params, self.lr)
+        self.opt.apply_gradients(grads)
+        self.global_step += 1
+        return dict(elbo=elbo.detach(), grads=dict(zip(names, grads)))
