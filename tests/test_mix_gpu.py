@@ -248,3 +248,35 @@ def test_distributed_loop_single_rank_rccl():
                 assert relerr(tb, ta.double().cpu().numpy()) < 1e-6
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('flav', ['gmm', 'smm'])
+def test_far_outliers_stay_finite(flav):
+    """Rows hundreds of standard deviations from every component (log rho ~ -1e5) must still give finite, normalised
+    responsibilities equal to the oracle's: the softmax is shifted by the exact row maximum as in the reference
+    (gmm.py:141-151).  (A cheaper kernel-wide bound was tried and rejected: it costs the small responsibilities their
+    dynamic range, log r = -inf where the reference is finite, for a 4% gain.)"""
+    from oracle import mixtures
+    from vmp_for_svae_amd.models import gmm, smm, _mix
+    rng = np.random.Generator(np.random.PCG64(77))
+    N, D, K = 4096, 8, 16
+    c = rng.standard_normal((K, D)) * 5
+    x = (c[rng.integers(0, K, N)] + rng.standard_normal((N, D))).astype(np.float32)
+    far = rng.choice(N, size=37, replace=False)
+    x[far] += (rng.standard_normal((37, D)) * 300).astype(np.float32)          # q ~ 1e5..1e6 >> the fp32 exp range
+    r0 = np.exp(3 * rng.standard_normal((N, K)))
+    r0 = (r0 / r0.sum(1, keepdims=True)).astype(np.float32)
+    xd, rd = dev(x), dev(r0)
+    xo, ro = torch.as_tensor(x).double(), torch.as_tensor(r0).double()
+    if flav == 'gmm':
+        step, _, _, _ = gmm.inference(xd, K, 0, r_init=rd)
+        r = step()
+        r_ref = mixtures.gmm_inference_step(xo, ro)[0]
+    else:
+        step, _, _, _ = smm.inference(xd, K, 5.0, 0, r_init=rd)
+        r = step()
+        r_ref = mixtures.smm_inference_step(xo, ro, torch.ones_like(ro), 5.0)[0]
+    assert torch.isfinite(r).all()
+    assert (r.sum(1) - 1).abs().max().item() < 1e-5
+    assert abserr(r, r_ref.numpy()) < 2e-5
+    assert abserr(r[torch.as_tensor(far).cuda()], r_ref[torch.as_tensor(far)].numpy()) < 2e-5
