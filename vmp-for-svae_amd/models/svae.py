@@ -1,8 +1,10 @@
 """SVAE assembly - mirror of reference models/svae.py:14-516 (GMM-structured latent space).
 
 N-sized arithmetic (per-(n,k) Cholesky, log-dets, triangular solves, responsibilities, reparameterised
-samples, per-sample log-densities of the ELBO, and all of their gradients) runs in csrc/vmp_svae.hip; the
-K-sized parameter maps (unpack_recognition_gmm, NIW conversions ...) are torch with autograd.
+samples, per-sample log-densities of the ELBO, and all of their gradients) runs in csrc/vmp_svae.hip; on the
+training path the K-sized parameter maps (unpack_recognition_gmm + bias terms and their adjoint, the theta side of
+compute_elbo, m_step + update_gmm_params) are the single-launch kernels of csrc/vmp_prep.hip; the stand-alone API
+functions (unpack_recognition_gmm, compute_log_z_given_y, m_step, the SMM theta) remain torch with autograd.
 """
 import math
 

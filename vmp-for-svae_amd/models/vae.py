@@ -1,7 +1,10 @@
-"""Encoder / decoder MLPs and expected log-likelihoods - mirror of reference models/vae.py:17-151,175-250.
+"""Encoder / decoder MLPs, expected log-likelihoods and the plain-VAE pieces - mirror of reference models/vae.py.
 
-The dense layers are plain torch (ROCm: hipBLASLt GEMMs) as BASELINE.json's north_star prescribes; the
-(N,K,S,Dy)-sized reduction of the reconstruction term runs in the HIP kernels of csrc/vmp_loglike.hip.
+The networks the SVAE driver builds (experiments.py:139-140: two tanh layers of equal width U <= 64, Gaussian head,
+in/out dimension <= 8) run in the fused fp32-MFMA kernels of csrc/vmp_decoder.hip: the decoder fused with the
+reconstruction term (LazyReconstruction -> one launch for the value and every gradient), the encoder as a
+stand-alone MLP (GaussMLPFn).  Any other layerspecs (e.g. the 784-wide Bernoulli decoder) use torch / hipBLASLt for
+the dense layers and the streaming kernels of csrc/vmp_loglike.hip for the (N,K,S,D)-sized reductions.
 Variables live in a name-keyed store that mimics tf.get_variable + variable_scope reuse.
 """
 import numpy as np

@@ -11,6 +11,10 @@ lrcvi = lrcvi0 * decay_rate ** (global_step / 1000) (experiments.py:146); Adam i
 parameter device + stack/mean becomes ONE all-reduce (RCCL) of a packed fp64 buffer
     [ raw moments (K, 2+L+L*L) | flat gradients | elbo, neg_rec_err, regulariser ]
 after which every rank applies the identical theta update and Adam step.
+
+GraphedSVAEStep captures the whole single-process step of a fixed minibatch size as one HIP graph (the reference's
+operating point - minibatches of 64-100 rows - is bound by launch count, not by the GPU); VAETrainer is the plain-VAE
+baseline of models/vae.py.
 """
 import math
 
