@@ -191,6 +191,10 @@ int    vmp_svae_phi_prep_fwd(const float* mu_k, const float* L_raw, const float*
 int    vmp_svae_phi_prep_bwd(const float* mu_k, const float* L_raw, const float* pi_raw, const float* g_hk,
                              const float* g_P, const float* g_bias, int K, int L, float* g_mu, float* g_Lraw,
                              float* g_piraw, void* stream);
+/* Fixed-order fp64 reduction of vmp_svae_estep_bwd's per-block partials into the K-sized gradients: g_hk (K,L),
+ * g_P (K,L,L, symmetric), g_bias (K) and - Student-t theta only, else NULL - g_mk (K,L), g_W (K,L,L, lower), g_kappa (K). */
+int    vmp_svae_bwd_reduce(const float* partials, int nblk, int K, int L, float* g_hk, float* g_P, float* g_bias,
+                           float* g_mk, float* g_W, float* g_kappa, void* stream);
 int    vmp_svae_theta_pack(const float* alpha, const float* A, const float* b, const float* beta, const float* v_hat,
                            int K, int L, float* m, float* W, float* kappa, void* stream);
 int    vmp_svae_cvi_update(const double* stats, const float* p_alpha, const float* p_A, const float* p_b,

@@ -51,6 +51,7 @@ _SIGNATURES = {
     'vmp_decoder_loglike_bwd': (_c.c_int, [_P] * 12 + [_c.c_int64] + [_c.c_int] * 5 + [_P, _P, _P, _P, _c.c_size_t, _P]),
     'vmp_svae_phi_prep_fwd': (_c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _P, _P, _P, _P]),
     'vmp_svae_phi_prep_bwd': (_c.c_int, [_P] * 6 + [_c.c_int, _c.c_int] + [_P] * 4),
+    'vmp_svae_bwd_reduce': (_c.c_int, [_P, _c.c_int, _c.c_int, _c.c_int] + [_P] * 7),
     'vmp_svae_theta_pack': (_c.c_int, [_P] * 5 + [_c.c_int, _c.c_int] + [_P] * 4),
     'vmp_svae_cvi_update': (_c.c_int, [_P] * 17 + [_c.c_float, _c.c_int, _c.c_int, _P]),
     'vmp_mlp_gauss_bwd': (_c.c_int, [_P] * 12 + [_c.c_int64] + [_c.c_int] * 3 + [_P, _P, _P, _c.c_size_t, _P]),

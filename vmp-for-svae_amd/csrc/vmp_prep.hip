@@ -243,6 +243,40 @@ __global__ __launch_bounds__(256) void cvi_kernel(CviArgs a) {
     }
 }
 
+// Reduction of the fused E-step backward kernel's per-block partial sums (vmp_svae_estep_bwd: (nblk, K, PW) with
+// PW = 2 (L + TRI + 1): [g_hk | g_Pk lower | g_bias | g_mk | g_Wk lower | g_kappa]) in a fixed order in fp64, unpacked
+// into the K-sized gradient tensors: g_P symmetric (both triangles carry the packed lower value), g_W lower.
+struct RedArgs {
+    const float* partials;
+    float *g_hk, *g_P, *g_bias, *g_mk, *g_W, *g_kappa;     // theta-side outputs may be NULL
+    int nblk, K, L;
+};
+
+__global__ __launch_bounds__(256) void svae_bwd_reduce_kernel(RedArgs a) {
+    const int L = a.L, TRI = L * (L + 1) / 2, TH = L + TRI + 1, PW = 2 * TH;
+    const int half = a.g_mk ? PW : TH;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < a.K * half; e += gridDim.x * blockDim.x) {
+        const int k = e / half, f = e - k * half;
+        double s = 0.0;
+        for (int b = 0; b < a.nblk; ++b) s += (double)a.partials[((size_t)b * a.K + k) * PW + f];
+        const float v = (float)s;
+        const int g = f < TH ? f : f - TH;                  // position inside the phi-side / theta-side group
+        const bool th = f >= TH;
+        if (g < L) {
+            (th ? a.g_mk : a.g_hk)[k * L + g] = v;
+        } else if (g < L + TRI) {
+            int idx = g - L, i = 0;
+            while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+            const int j = idx - i * (i + 1) / 2;
+            float* M = (th ? a.g_W : a.g_P) + (size_t)k * L * L;
+            M[i * L + j] = v;
+            if (i != j) M[j * L + i] = th ? 0.f : v;
+        } else {
+            (th ? a.g_kappa : a.g_bias)[k] = v;
+        }
+    }
+}
+
 int prep_check(const char* what, int K, int L) {
     if (K < 1 || K > VMP_MAX_K || L < 1 || L > VMP_MAX_D) {
         set_error("%s: K=%d, L=%d outside the compiled range (K <= %d, L <= %d)", what, K, L, VMP_MAX_K, VMP_MAX_D);
@@ -281,6 +315,19 @@ int vmp_svae_phi_prep_bwd(const float* mu_k, const float* L_raw, const float* pi
     PREP_DISPATCH_L(L, PREP_CALL)
 #undef PREP_CALL
     return check_launch("vmp_svae_phi_prep_bwd");
+}
+
+int vmp_svae_bwd_reduce(const float* partials, int nblk, int K, int L, float* g_hk, float* g_P, float* g_bias, float* g_mk,
+                        float* g_W, float* g_kappa, void* stream) {
+    if (int e = prep_check("vmp_svae_bwd_reduce", K, L)) return e;
+    if (!partials || nblk < 1 || !g_hk || !g_P || !g_bias || ((!g_mk) != (!g_W)) || ((!g_mk) != (!g_kappa))) {
+        set_error("vmp_svae_bwd_reduce: bad argument");
+        return VMP_E_BADARG;
+    }
+    RedArgs a{partials, g_hk, g_P, g_bias, g_mk, g_W, g_kappa, nblk, K, L};
+    const int n = K * 2 * (L + L * (L + 1) / 2 + 1);
+    hipLaunchKernelGGL(svae_bwd_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch("vmp_svae_bwd_reduce");
 }
 
 int vmp_svae_theta_pack(const float* alpha, const float* A, const float* b, const float* beta, const float* v_hat, int K,

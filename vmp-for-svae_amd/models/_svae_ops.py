@@ -9,27 +9,6 @@ def _c(t, name, shape=None):
     return L.dev_f32(t, name, shape)
 
 
-def _unpack_partials(red, Ld, device):
-    """(K, 2(L+TRI+1)) fp64 sums -> g_hk, g_Pk (symmetric), g_bias, g_mk, g_Wk (lower), g_kappa."""
-    K = red.shape[0]
-    T = Ld * (Ld + 1) // 2
-    il = torch.tril_indices(Ld, Ld, device=device)
-
-    def lower(tri):
-        M = torch.zeros(K, Ld, Ld, dtype=torch.float64, device=device)
-        M[:, il[0], il[1]] = tri
-        return M
-    g_hk = red[:, :Ld]
-    gp = lower(red[:, Ld:Ld + T])
-    g_P = gp + gp.transpose(1, 2) - torch.diag_embed(torch.diagonal(gp, dim1=1, dim2=2))
-    g_bias = red[:, Ld + T]
-    o = Ld + T + 1
-    g_mk = red[:, o:o + Ld]
-    g_W = lower(red[:, o + Ld:o + Ld + T])
-    g_kappa = red[:, o + Ld + T]
-    return [t.float() for t in (g_hk, g_P, g_bias, g_mk, g_W, g_kappa)]
-
-
 class SvaeEStepFn(torch.autograd.Function):
     """(eta1, eta2d, hk, Pk, bias, noise, mk, Wk, kappa, nu) -> (x (N,K,S,L), log_z (N,K), T' (N,K)).
     Gradients flow to eta1, eta2d (N,L), to hk, Pk, bias (K-sized, summed over n) and - for the Student-t theta of the
@@ -79,10 +58,13 @@ class SvaeEStepFn(torch.autograd.Function):
                                            L.ptr(Wk), L.ptr(nu), L.ptr(x), L.ptr(lz), L.ptr(g_x), L.ptr(g_lz), L.ptr(g_T),
                                            N, K, Ld, S, L.ptr(g_eta1), L.ptr(g_eta2d), L.ptr(partials),
                                            partials.numel() * 4, L.stream()), 'vmp_svae_estep_bwd')
-        red = partials.double().sum(0)                       # (K, PW): K-sized, fixed order
-        g_hk, g_P, g_bias, g_mk, g_W, g_kappa = _unpack_partials(red, Ld, eta1.device)
-        if nu is None:
-            g_mk = g_W = g_kappa = None
+        # fixed-order fp64 reduction of the per-block partials + unpacking into the K-sized gradients: one launch
+        g_hk, g_P, g_bias = torch.empty(K, Ld, **f32), torch.empty(K, Ld, Ld, **f32), torch.empty(K, **f32)
+        g_mk = g_W = g_kappa = None
+        if nu is not None:
+            g_mk, g_W, g_kappa = torch.empty(K, Ld, **f32), torch.empty(K, Ld, Ld, **f32), torch.empty(K, **f32)
+        L.check(L.lib().vmp_svae_bwd_reduce(L.ptr(partials), nblk, K, Ld, L.ptr(g_hk), L.ptr(g_P), L.ptr(g_bias),
+                                            L.ptr(g_mk), L.ptr(g_W), L.ptr(g_kappa), L.stream()), 'vmp_svae_bwd_reduce')
         return g_eta1, g_eta2d, g_hk, g_P, g_bias, None, g_mk, g_W, g_kappa, None
 
 
