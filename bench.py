@@ -39,8 +39,7 @@ def cpu_baseline(x, r0, workload, chunk=1 << 15, reps=3):
     models/smm.py, pinned by tests/golden), timed on this host in N-chunks (the literal graph materialises
     (N,K,D,D) temporaries).  One VMP step over a bounded sample of the workload; best of `reps`."""
     from oracle import mixtures, dists
-    torch.set_num_threads(os.cpu_count() or 1)
-    Ns = min(x.shape[0], 1 << 18)                      # bounded sample: 262144 rows (about 10-20 s total)
+    Ns = min(x.shape[0], 1 << 18)                      # bounded sample: 262144 rows
     xs, rs = torch.as_tensor(x[:Ns]), torch.as_tensor(r0[:Ns])
     K, D = rs.shape[1], xs.shape[1]
     prior = mixtures.vmp_prior(K, D, torch.float32)
@@ -76,16 +75,27 @@ def cpu_baseline(x, r0, workload, chunk=1 << 15, reps=3):
                 out.append(mixtures.gmm_e_step(xs[i:i + chunk], alpha_k, beta_k, m_k, P_k, v_k)[0])
         return torch.cat(out)
 
-    one_step()
-    best = float('inf')
-    for _ in range(reps):
-        t0 = time.perf_counter()
+    # The thread count is part of the baseline: on the 256-hardware-thread host of the GPU box torch's intra-op pool
+    # collapses when every thread is used (measured: 1.5e4 datapoints/s at 256 threads vs 7.3e5 at 32), so a few
+    # pool sizes are tried and the FASTEST is reported, with its thread count in `cores`.
+    ncpu = os.cpu_count() or 1
+    cands = sorted({t for t in (8, 16, 32, 64) if t <= ncpu} | ({ncpu} if ncpu <= 64 else set())) or [ncpu]
+    best, best_t = float('inf'), cands[0]
+    for th in cands:
+        torch.set_num_threads(th)
         one_step()
-        best = min(best, time.perf_counter() - t0)
-    return {'value': Ns / best, 'unit': 'datapoints/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'steps_per_sec_at_sample': 1.0 / best,
-            'sample': 'one %s VMP step (oracle, fp32, torch-CPU %d threads, N-chunks of %d) on the first %d rows of the '
-                      'workload; best of %d after warm-up' % (workload, torch.get_num_threads(), chunk, Ns, reps)}
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            one_step()
+            dt = time.perf_counter() - t0
+            if dt < best:
+                best, best_t = dt, th
+    torch.set_num_threads(best_t)
+    return {'value': Ns / best, 'unit': 'datapoints/s', 'cores': best_t, 'kind': 'port',
+            'steps_per_sec_at_sample': 1.0 / best, 'host_hw_threads': ncpu, 'thread_counts_tried': cands,
+            'sample': 'one %s VMP step (oracle, fp32, torch-CPU, N-chunks of %d) on the first %d rows of the workload; '
+                      'fastest of %d timed runs at each of %s threads (best: %d threads)'
+                      % (workload, chunk, Ns, reps, cands, best_t)}
 
 
 
@@ -214,8 +224,8 @@ def bench_minibatch(N, K, Ld, Dy, S, U, dev, steps=200, cpu=True):
            'graphed_steps_per_sec': 1.0 / graphed, 'graphed_ms_per_step': graphed * 1e3}
     if cpu:
         from oracle import nets, svae_ref, train_ref
-        # tiny tensors: more than a few threads only adds synchronisation (256 threads: ~30 s per step)
-        torch.set_num_threads(min(8, os.cpu_count() or 1))
+        # tiny tensors: more than a few threads only adds synchronisation (256 threads: ~30 s per step); the fastest
+        # of a few pool sizes is reported
         rng = np.random.Generator(np.random.PCG64(1))
         w = {}
         for scope, din, dout in (('encoder_net', Dy, Ld), ('decoder_net', Ld, Dy)):
@@ -232,14 +242,20 @@ def bench_minibatch(N, K, Ld, Dy, S, U, dev, steps=200, cpu=True):
         yc = y.cpu()
         noise = torch.as_tensor(rng.standard_normal((N, K, Ld, S)).astype(np.float32))
         zd = torch.as_tensor(rng.integers(0, K, size=(N, S)))
-        train_ref.train_step(st, yc, noise, zd, 3e-4, 0.2, 0.95)
-        reps = 3
-        t0 = time.perf_counter()
-        for _ in range(reps):
+        ncpu = os.cpu_count() or 1
+        cpu_t, cpu_th = float('inf'), 1
+        for th in sorted({t for t in (1, 8, 32) if t <= ncpu}):
+            torch.set_num_threads(th)
             train_ref.train_step(st, yc, noise, zd, 3e-4, 0.2, 0.95)
-        cpu_t = (time.perf_counter() - t0) / reps
+            reps = 3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                train_ref.train_step(st, yc, noise, zd, 3e-4, 0.2, 0.95)
+            dt = (time.perf_counter() - t0) / reps
+            if dt < cpu_t:
+                cpu_t, cpu_th = dt, th
         res['cpu_oracle_steps_per_sec'] = 1.0 / cpu_t
-        res['cpu_oracle_cores'] = torch.get_num_threads()
+        res['cpu_oracle_cores'] = cpu_th
     return res
 
 
