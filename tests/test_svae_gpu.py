@@ -328,6 +328,15 @@ def test_graphed_step_matches_eager():
         assert abs(a - b) <= 2e-5 * abs(b), (a, b)
     for a, b in zip(got, want):
         assert rel(a, b.double().cpu().numpy()) < 2e-5
+    # a later, larger eager step re-allocates the shared scratch buffer; the graph keeps its own buffers alive
+    import vmp_for_svae_amd as V
+    before = dict(V._lib._WS)
+    big = torch.randn(4096, Dy, device='cuda', generator=g)
+    tr2.step(big)
+    assert any(V._lib._WS[k] is not before[k] for k in before), 'expected the workspace to grow'
+    assert all(gs._ws_refs[k] is before[k] for k in before)
+    out = gs(ys[0])
+    assert torch.isfinite(out['elbo']) and all(torch.isfinite(p).all() for p in tr2.trainables()[1])
 
 
 def test_driver_pinwheel_converges():

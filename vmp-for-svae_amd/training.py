@@ -233,6 +233,9 @@ class GraphedSVAEStep(object):
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = tr.step(self.y, noise=self.noise, u=self.u, _dev_scalars=(self.rho, self.lr_t))
+        # the captured kernels hold raw pointers into the shared scratch buffers: keep those buffers alive even if a later,
+        # larger eager call makes _lib.workspace() replace them
+        self._ws_refs = dict(L._WS)
 
     def _refresh(self):
         tr = self.tr
