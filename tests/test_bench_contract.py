@@ -1,0 +1,30 @@
+"""The committed bench line (profiles/r01_bench.json, produced by `python bench.py` on an MI355X) carries every field of
+the driver's contract, with the roofline arithmetic consistent with DESIGN.md's algorithmic bytes."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_schema():
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_bench.json')))
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert d['dtype'] == 'f32' and d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    N, D, K = d['config']['N_per_gpu'], d['config']['D'], d['config']['K']
+    alg = 4.0 * N * (2 * D + 2 * K)                              # T1 GMM algorithmic bytes per step
+    assert abs(r['algorithmic_bytes_per_launch'] - alg) < 1
+    assert abs(r['achieved'] - alg / (r['kernel_ms'] * 1e-3) / 1e9) < 1e-3 * r['achieved']
+    assert r['traffic'] is None or 0.4 * alg < r['traffic'] < 2 * alg      # PMC bytes: no wasted re-reads
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] in ('reference', 'port') and c['unit'] == d['unit']
+    assert abs(d['value'] - N * d['n_gpus'] / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
