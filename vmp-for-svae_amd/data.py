@@ -72,3 +72,15 @@ def minibatches(X, size_minibatch, seed=0):
         perm = rng.permutation(N)
         for i in range(0, N - size_minibatch + 1, size_minibatch):
             yield perm[i:i + size_minibatch]
+
+
+def minibatches_device(X_dev, size_minibatch, seed=0):
+    """As `minibatches`, but yields the minibatch ROWS gathered on the device: one host-to-device copy of the epoch's
+    permutation instead of one (synchronising) index copy per iteration.  Same permutation stream as `minibatches`."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(seed))
+    N = X_dev.shape[0]
+    while True:
+        perm = torch.as_tensor(rng.permutation(N)).to(X_dev.device)
+        for i in range(0, N - size_minibatch + 1, size_minibatch):
+            yield X_dev.index_select(0, perm[i:i + size_minibatch])

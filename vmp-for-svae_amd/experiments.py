@@ -116,7 +116,7 @@ def run(config, nb_iters=2000, size_minibatch=100, nb_samples=10, nb_samples_te=
     tr = SVAETrainer(config['K'], config['L'], config['U'], X_tr.shape[1], nb_samples=nb_samples, lr=config['lr'],
                      lrcvi=config['lrcvi'], decay_rate=config.get('decay_rate', 1), seed=config.get('seed', 0),
                      device=dev, smm=smm, dof=config.get('DoF', 5))
-    batches = data_mod.minibatches(X_tr, size_minibatch, seed=config.get('seed', 0))
+    batches = data_mod.minibatches_device(Xtr, size_minibatch, seed=config.get('seed', 0))
     log_id = generate_log_id(config)
     missing_data_mask = losses.generate_missing_data_mask(Xte, ratio_missing_data, seed=config.get('seed', 0))
     history = []
@@ -124,8 +124,7 @@ def run(config, nb_iters=2000, size_minibatch=100, nb_samples=10, nb_samples_te=
     # fixed-size minibatches: capture the training step once as a HIP graph and replay it (training.GraphedSVAEStep)
     stepper = None
     for i in range(nb_iters):
-        idx = torch.as_tensor(next(batches)).to(dev)
-        yb = Xtr[idx].contiguous()
+        yb = next(batches)
         if graph and not smm and dev.type == 'cuda':
             if stepper is None:
                 from .training import GraphedSVAEStep
