@@ -331,12 +331,46 @@ def test_graphed_step_matches_eager():
     # a later, larger eager step re-allocates the shared scratch buffer; the graph keeps its own buffers alive
     import vmp_for_svae_amd as V
     before = dict(V._lib._WS)
-    big = torch.randn(4096, Dy, device='cuda', generator=g)
-    tr2.step(big)
-    assert any(V._lib._WS[k] is not before[k] for k in before), 'expected the workspace to grow'
+    for k, buf in before.items():                       # force the growth a larger eager call would cause
+        V._lib.workspace(buf.device, buf.numel() + 1)
+    assert all(V._lib._WS[k] is not before[k] for k in before)
     assert all(gs._ws_refs[k] is before[k] for k in before)
+    tr2.step(torch.randn(512, Dy, device='cuda', generator=g))          # eager step on the new buffer
     out = gs(ys[0])
     assert torch.isfinite(out['elbo']) and all(torch.isfinite(p).all() for p in tr2.trainables()[1])
+
+
+def test_sample_x_per_comp_standalone_matches_fused(golden):
+    """svae.sample_x_per_comp (svae.py:95-119) on the materialised phi_tilde reproduces the samples of the fused E-step
+    kernel and the reference's x_k."""
+    from vmp_for_svae_amd.models import svae
+    g = golden('svae_tiny')
+    tr, (N, K, Ld, S, Dy, U, steps) = make_trainer(g)
+    from vmp_for_svae_amd.models import vae
+    y, noise = dev(g['in_y']), dev(g['in_noise'][0])
+    with torch.no_grad():
+        phi_enc = vae.make_encoder(y, tr.encoder_layers, tr.stddev_init_nn)
+        x_k, log_z, phi_tilde, _ = svae.e_step(phi_enc, tr.phi_gmm, S, noise=noise)
+        x2 = svae.sample_x_per_comp(phi_tilde[0], phi_tilde[1], S, noise=noise)
+    assert tuple(x2.shape) == (N, K, S, Ld)
+    assert rel(x2, x_k.double().cpu().numpy()) < 1e-5
+    assert rel(x2, g['step0_x_k']) < 1e-4
+
+
+def test_elbo_debug_details_on_demand(golden):
+    """details[1], details[2] of svae.compute_elbo (svae.py:256-260: sum r mean_s log-numerator / log-denominator),
+    computed on access through the stand-alone density kernel, vs the reference run."""
+    from vmp_for_svae_amd.models import svae
+    g = golden('svae_paper')
+    tr, (N, K, Ld, S, Dy, U, steps) = make_trainer(g)
+    y, noise, zd = dev(g['in_y']), dev(g['in_noise'][0]), dev(g['in_zdraw'][0], torch.int64)
+    elbo, details, x_k, x_s, log_z = tr.forward(y, noise, zd)
+    det = g['step0_details']
+    assert len(details) == 4
+    rec, num, den, reg = details
+    for got, want in ((rec, det[0]), (num, det[1]), (den, det[2]), (reg, det[3])):
+        got = float(got.detach())
+        assert abs(got - want) <= 3e-5 * max(abs(want), abs(det[0]) * 0.1), (got, want)
 
 
 def test_driver_pinwheel_converges():

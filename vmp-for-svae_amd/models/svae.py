@@ -133,8 +133,19 @@ def e_step(phi_enc, phi_gmm, nb_samples, seed=0, name="e_step", noise=None, thet
     return x, lz, phi_tilde, (None, None)
 
 
-def sample_x_per_comp(eta1, eta2, nb_samples, seed=0):
-    raise NotImplementedError('fused into vmp_svae_estep_fwd; use e_step')
+def sample_x_per_comp(eta1, eta2, nb_samples, seed=0, noise=None):
+    """reference svae.py:95-119 as a stand-alone function for GENERAL (N,K,L,L) eta2 (API parity; torch batched
+    factorisations): x = Sigma eta1 + L^-T eps, L = chol(-2 eta2), eps (N,K,L,S); returns (N,K,S,L).  The training path
+    never calls it: e_step's fused kernel does this per cell with the structured eta2 = diag(encoder) + P_k."""
+    N, K, Ld, _ = eta2.shape
+    inv_sigma = -2.0 * eta2
+    Lc = torch.linalg.cholesky(inv_sigma)
+    if noise is None:
+        g = torch.Generator(device=eta2.device).manual_seed(int(seed))
+        noise = torch.randn(N, K, Ld, nb_samples, generator=g, device=eta2.device, dtype=eta2.dtype)
+    nz = torch.linalg.solve_triangular(Lc.transpose(-1, -2), noise, upper=True)
+    mu = torch.cholesky_solve(eta1, Lc)
+    return (mu + nz).transpose(-1, -2)
 
 
 def subsample_x(x_k_samples, log_q_z_given_y, seed=0, z_draws=None, nb_out=None, u=None):
@@ -212,12 +223,47 @@ def compute_elbo(y, reconstructions, theta, phi_tilde, x_k_samps, log_z_given_y_
     Tp = phi_tilde.T_prime
     reg = (r_nk * (Tp + log_z_given_y_phi)).sum()
     elbo = rec - reg
-    with torch.no_grad():
-        # debug scalars of svae.py:256-260: sum r * mean_s(numerator), sum r * mean_s(denominator).  The fused kernel
-        # only keeps their difference; the split is recovered from the closed form of the numerator.
-        num = None
-        den = None
-    return elbo, (rec, num, den, reg)
+    return elbo, ElboDetails(rec, reg, phi_tilde, x_k_samps, log_z_given_y_phi)
+
+
+class ElboDetails(object):
+    """The `details` 4-tuple of reference svae.py:256-260 (neg_rec_err, sum r mean_s numerator, sum r mean_s denominator,
+    regulariser).  In the reference these are graph nodes evaluated only when fetched; here the two middle debug scalars
+    - which the fused kernel does not keep apart (it returns mean_s[numerator - denominator]) - are computed on first
+    access: numerator from the stand-alone density kernel on the materialised phi_tilde (gaussian.py:74-105),
+    denominator = numerator - regulariser."""
+
+    def __init__(self, rec, reg, phi_tilde, x_k, log_z):
+        self._rec, self._reg = rec, reg
+        self._lazy = (phi_tilde, x_k, log_z)
+        self._nd = None
+
+    def _split(self):
+        if self._nd is None:
+            phi_tilde, x_k, log_z = self._lazy
+            with torch.no_grad():
+                lp = gaussian.log_probability_nat_per_samp(x_k.detach().contiguous(), phi_tilde[0].squeeze(-1).detach().contiguous(),
+                                                           phi_tilde[1].detach().contiguous())
+                num = (torch.exp(log_z) * (lp.mean(-1) + log_z)).sum().detach()
+                self._nd = (num, num - self._reg.detach())
+        return self._nd
+
+    def __len__(self):
+        return 4
+
+    def __getitem__(self, i):
+        if i in (0, -4):
+            return self._rec
+        if i in (3, -1):
+            return self._reg
+        if i in (1, -3):
+            return self._split()[0]
+        if i in (2, -2):
+            return self._split()[1]
+        raise IndexError(i)
+
+    def __iter__(self):
+        return iter((self[0], self[1], self[2], self[3]))
 
 
 def compute_elbo_smm(y, reconstructions, theta, phi_tilde, x_k_samps, log_z_given_y_phi, decoder_type):

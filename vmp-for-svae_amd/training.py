@@ -168,7 +168,7 @@ class SVAETrainer(object):
                 st = _mix.raw_stats(x_s.detach().contiguous(), r_nk.contiguous())  # HIP: (K, 2+L+L*L) fp64
             grads = g if grads is None else [a + b for a, b in zip(grads, g)]
             stats = st if stats is None else stats + st
-            rec, _, _, reg = details
+            rec, reg = details[0], details[3]                # the two debug scalars in between are computed on access only
             elbo_t, rec_t, reg_t = elbo_t + elbo.detach(), rec_t + rec.detach(), reg_t + reg.detach()
             if rows <= chunk:
                 keep = dict(log_z=log_z.detach(), x_samples=x_s.detach(), x_k=x_k.detach())
