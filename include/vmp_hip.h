@@ -274,6 +274,11 @@ int    vmp_gauss_logprob_nat_per_samp(const float* x, const float* eta1, const f
                                       int D, float* out, void* stream);
 int    vmp_gauss_logprob_nat(const float* x, const float* eta1, const float* eta2, const float* log_weights,
                              int64_t N, int K, int D, float* out, void* stream);
+/* Stand-alone expected Mahalanobis distance (gmm.compute_expct_mahalanobis_dist models/gmm.py:84-94,
+ * compute_dev_missing_data :97-114, smm.expct_mahalanobis_dist models/smm.py:88-96):
+ * out (N,K) = v_k (x_n - m_k)^T P_k (x_n - m_k) + D / beta_k, entries with miss_mask (N,D) != 0 dropped.          */
+int    vmp_mix_mahalanobis(const float* x, const float* m, const float* P, const float* v, const float* beta,
+                           const uint8_t* miss_mask, int64_t N, int D, int K, float* out, void* stream);
 int    vmp_student_t_logprob(const float* y, const float* mu, const float* W, const float* cst, const float* nu,
                              int64_t N, int K, int S, int D, float* out, void* stream);
 

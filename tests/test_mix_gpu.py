@@ -280,3 +280,71 @@ def test_far_outliers_stay_finite(flav):
     assert (r.sum(1) - 1).abs().max().item() < 1e-5
     assert abserr(r, r_ref.numpy()) < 2e-5
     assert abserr(r[torch.as_tensor(far).cuda()], r_ref[torch.as_tensor(far)].numpy()) < 2e-5
+
+
+def test_individual_update_functions_compose_to_the_steps():
+    """The reference's individual functions (gmm.py:25-151, smm.py:25-137, student_t.py:42-56) under their own names:
+    each against the oracle's restatement in fp64, and composed by hand they reproduce the fused e_step."""
+    from oracle import dists, mixtures
+    from vmp_for_svae_amd.distributions import student_t
+    from vmp_for_svae_amd.models import gmm, smm
+    rng = np.random.Generator(np.random.PCG64(31))
+    N, D, K = 777, 6, 10
+    c = rng.standard_normal((K, D)) * 4
+    x = (c[rng.integers(0, K, N)] + rng.standard_normal((N, D))).astype(np.float32)
+    r0 = np.exp(2 * rng.standard_normal((N, K)))
+    r0 = (r0 / r0.sum(1, keepdims=True)).astype(np.float32)
+    u0 = (0.5 + rng.random((N, K))).astype(np.float32)
+    mask = rng.random((N, D)) < 0.2
+    xd, rd, ud = dev(x), dev(r0), dev(u0)
+    xo, ro, uo = [torch.as_tensor(a).double() for a in (x, r0, u0)]
+    # ---- GMM M-step pieces
+    Nk = gmm.update_Nk(rd)
+    xk = gmm.update_xk(xd, rd, Nk)
+    Sk = gmm.update_Sk(xd, rd, Nk, xk)
+    Nk_o = mixtures.gmm_update_Nk(ro)
+    xk_o = mixtures.gmm_update_xk(xo, ro, Nk_o)
+    assert relerr(Nk, Nk_o.numpy()) < 1e-6 and relerr(xk, xk_o.numpy()) < 1e-5
+    assert relerr(Sk, mixtures.gmm_update_Sk(xo, ro, Nk_o, xk_o).numpy()) < 2e-5
+    prior = mixtures.vmp_prior(K, D, torch.float64)
+    al, be, m, C, v, _, _ = mixtures.gmm_m_step(xo, ro, *prior)
+    P = dists.inv(C)
+    f = lambda t: t.float().cuda()
+    # ---- E-step pieces, stand-alone and composed
+    dev_o = mixtures.gmm_expct_mahalanobis(xo, be, m, P, v)
+    dev_d = gmm.compute_expct_mahalanobis_dist(xd, f(be), f(m), f(P), f(v))
+    assert relerr(dev_d, dev_o.numpy()) < 1e-5
+    dev_m = gmm.compute_dev_missing_data(xd, f(be), f(m), f(P), f(v), dev(mask, torch.bool))
+    assert relerr(dev_m, mixtures.gmm_expct_mahalanobis(xo, be, m, P, v, torch.as_tensor(mask)).numpy()) < 1e-5
+    r_comp = gmm.compute_rnk(gmm.compute_log_pi(f(al)), gmm.compute_expct_log_det_prec(f(v), f(P)), dev_d)
+    r_fused, _ = gmm.e_step(xd, f(al), f(be), f(m), f(P), f(v))
+    assert abserr(r_comp, r_fused.double().cpu().numpy()) < 2e-5
+    assert abserr(r_comp, mixtures.gmm_e_step(xo, al, be, m, P, v)[0].numpy()) < 2e-5
+    # ---- SMM pieces
+    ru = rd * ud
+    Wk = smm.update_Wk(ru)
+    xk_s = smm.update_xk(xd, ru, Wk)
+    Sk_s = smm.update_Sk(xd, ru, Wk, xk_s)
+    al2, be2, m2, C2, v2, xk2, Sk2 = mixtures.smm_m_step(xo, ro, uo, *prior)
+    assert relerr(xk_s, xk2.numpy()) < 1e-5 and relerr(Sk_s, Sk2.numpy()) < 2e-5
+    a0, b0, m0, C0, v0 = [f(t) for t in prior]
+    Nk_s = smm.update_Nk(rd)
+    be_s = smm.update_betak(b0, Wk)
+    assert relerr(smm.update_alphak(a0, Nk_s), al2.numpy()) < 1e-6 and relerr(be_s, be2.numpy()) < 1e-6
+    assert relerr(smm.update_mk(b0, m0, Wk, xk_s, be_s), m2.numpy()) < 1e-5
+    assert relerr(smm.update_Ck(C0, xk_s, Wk, m0, b0, be_s, Sk_s), C2.numpy()) < 2e-5
+    assert relerr(smm.update_vk(v0, Nk_s), v2.numpy()) < 1e-6
+    P2 = dists.inv(C2)
+    kap = torch.full((K,), 5.0, device='cuda')
+    md = smm.expct_mahalanobis_dist(xd, f(be2), f(m2), f(P2), f(v2))
+    r_s = smm.compute_rnk(smm.expct_log_pi(f(al2)), smm.expct_log_det_prec(f(v2), f(P2)), md, kap, D)
+    u_s = smm.compute_expct_unk(md, kap, D)
+    r_f, u_f, _ = smm.e_step(xd, f(al2), f(be2), f(m2), f(P2), f(v2), kap)
+    assert abserr(r_s, r_f.double().cpu().numpy()) < 2e-5 and relerr(u_s, u_f.double().cpu().numpy()) < 1e-5
+    # ---- Student-t mixture log-probability (student_t.py:42-56) vs scipy
+    from scipy.stats import multivariate_t
+    mu = rng.standard_normal((3, D)); A = rng.standard_normal((3, D, D)); sig = A @ A.transpose(0, 2, 1) + D * np.eye(D)
+    nu = np.array([3.0, 5.5, 9.0]); lpi = np.log(np.array([0.2, 0.3, 0.5]))
+    lp = student_t.logprob_smm_mixture(xd[:50].contiguous(), dev(mu), dev(sig), dev(nu), dev(lpi))
+    want = np.stack([multivariate_t(mu[k], sig[k], df=nu[k]).logpdf(x[:50].astype(np.float64)) + lpi[k] for k in range(3)], 1)
+    assert abserr(lp, want) < 2e-4

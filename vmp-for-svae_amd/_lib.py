@@ -39,6 +39,7 @@ _SIGNATURES = {
     'vmp_svae_subsample': (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
     'vmp_gauss_logprob_nat_per_samp': (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
     'vmp_gauss_logprob_nat': (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _P, _P]),
+    'vmp_mix_mahalanobis': (_c.c_int, [_P] * 6 + [_c.c_int64, _c.c_int, _c.c_int, _P, _P]),
     'vmp_student_t_logprob': (_c.c_int, [_P, _P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
     'vmp_eval_cell_metrics': (_c.c_int, [_P, _P, _P, _P, _c.c_int, _P, _c.c_int, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
     'vmp_diag_gauss_loglike_fwd': (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _P, _P]),

@@ -176,6 +176,37 @@ int chk(long long N, int K, int D, int S) {
     return 0;
 }
 
+// Stand-alone expected Mahalanobis distance of the mixture E-step (reference gmm.py:84-94, its missing-data variant
+// gmm.py:97-114, smm.py:88-96): out_nk = v_k (x_n - m_k)^T P_k (x_n - m_k) + D / beta_k, masked entries of (x - m) zeroed.
+// One (n,k) cell per lane.  (The VMP iteration never calls this: the distance lives inside the fused pass kernel.)
+struct MArgs {
+    const float *x, *m, *P, *v, *beta;
+    const uint8_t* mask;
+    float* out;
+    long long cells;
+    int K, D;
+};
+
+__global__ __launch_bounds__(256) void maha_kernel(MArgs a) {
+    const int D = a.D;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < a.cells; c += (long long)gridDim.x * blockDim.x) {
+        const long long n = c / a.K;
+        const int k = (int)(c - n * a.K);
+        float d[VMP_MAX_D];
+        for (int i = 0; i < D; ++i) {
+            const bool miss = a.mask && a.mask[n * D + i] != 0;
+            d[i] = miss ? 0.f : a.x[n * D + i] - a.m[k * D + i];
+        }
+        float q = 0.f;
+        for (int i = 0; i < D; ++i) {
+            float t = 0.f;
+            for (int j = 0; j < D; ++j) t = fmaf(a.P[((long long)k * D + i) * D + j], d[j], t);
+            q = fmaf(d[i], t, q);
+        }
+        a.out[c] = a.v[k] * q + (float)D / a.beta[k];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -228,6 +259,18 @@ int vmp_student_t_logprob(const float* y, const float* mu, const float* W, const
         rc = check_launch("student_t_kernel");
     });
     return rc;
+}
+
+int vmp_mix_mahalanobis(const float* x, const float* m, const float* P, const float* v, const float* beta,
+                        const uint8_t* miss_mask, int64_t N, int D, int K, float* out, void* stream) {
+    int rc = chk(N, K, D, 1);
+    if (rc) return rc;
+    if (!x || !m || !P || !v || !beta || !out) { set_error("vmp_mix_mahalanobis: null pointer"); return VMP_E_BADARG; }
+    MArgs a{x, m, P, v, beta, miss_mask, out, (long long)N * K, K, D};
+    long long blocks = ((long long)N * K + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(maha_kernel, dim3((int)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch("maha_kernel");
 }
 
 }  // extern "C"

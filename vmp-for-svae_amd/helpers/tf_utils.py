@@ -17,3 +17,13 @@ def average_gradients(tower_grads):
         g = torch.stack([g_ for g_, _ in gv], dim=0).mean(dim=0)
         out.append((g, gv[0][1]))
     return out
+
+
+def variable_on_device(name, shape, initializer, trainable=True, dtype=torch.float32, device='cuda'):
+    """reference tf_utils.py:8-22: a named variable living on `device` (get-or-create in the vae variable store)."""
+    from ..models import vae
+
+    def init():
+        v = initializer(shape) if callable(initializer) else torch.as_tensor(initializer)
+        return v.to(device=device, dtype=dtype)
+    return vae._get_variable(name, init, trainable)

@@ -17,6 +17,31 @@ def update_Nk(r_nk):
     return _mix.raw_stats(ones, r_nk)[:, 0].to(r_nk.dtype)
 
 
+def _centred_moments(x, w, W_k, a_k, eps):
+    """sum_n w_nk x_n / (W_k + eps) and sum_n w_nk (x_n - a_k)(x_n - a_k)^T / (W_k + eps) from the raw moments of the HIP stats
+    kernel (fp64: sxx - sx a^T - a sx^T + (sum w) a a^T); returns the un-normalised sums too."""
+    st = _mix.raw_stats(x, w)                                   # (K, 2+D+D*D) fp64: [sum w | . | sum w x | sum w x x^T]
+    D = x.shape[1]
+    sw, sx, sxx = st[:, 0], st[:, 2:2 + D], st[:, 2 + D:].reshape(-1, D, D)
+    return sw, sx, sxx
+
+
+def update_xk(x, r_nk, N_k):
+    """reference gmm.py:30-36 (Bishop 10.52): sum_n r_nk x_n / N_k, un-normalised where N_k == 0 (NaN fallback)."""
+    _, sx, _ = _centred_moments(x, r_nk, N_k, None, 0.0)
+    normed = sx / N_k.double()[:, None]
+    return torch.where(torch.isnan(normed), sx, normed).to(x.dtype)
+
+
+def update_Sk(x, r_nk, N_k, x_k):
+    """reference gmm.py:39-46 (Bishop 10.53): sum_n r_nk (x_n - x_k)(x_n - x_k)^T / N_k with the same NaN fallback."""
+    sw, sx, sxx = _centred_moments(x, r_nk, N_k, x_k, 0.0)
+    a = x_k.double()
+    S = sxx - sx[:, :, None] * a[:, None, :] - a[:, :, None] * sx[:, None, :] + sw[:, None, None] * a[:, :, None] * a[:, None, :]
+    normed = S / N_k.double()[:, None, None]
+    return torch.where(torch.isnan(normed), S, normed).to(x.dtype)
+
+
 def update_alphak(alpha_0, N_k):
     return alpha_0 + N_k                       # Bishop 10.58, reference gmm.py:49-51
 
@@ -79,10 +104,33 @@ def e_step_missing_data(x, alpha_k, beta_k, m_k, P_k, v_k, missing_data_mask, na
     return r, pi
 
 
+def _mahalanobis(x, beta_k, m_k, P_k, v_k, mask=None):
+    x = L.dev_f32(x, 'x')
+    N, D = x.shape
+    K = m_k.shape[0]
+    m, P, v, b = (L.dev_f32(m_k.detach().float(), 'm_k', (K, D)), L.dev_f32(P_k.detach().float(), 'P_k', (K, D, D)),
+                  L.dev_f32(v_k.detach().float(), 'v_k', (K,)), L.dev_f32(beta_k.detach().float(), 'beta_k', (K,)))
+    m8 = None if mask is None else mask.to(torch.uint8).contiguous()
+    out = torch.empty(N, K, dtype=torch.float32, device=x.device)
+    L.check(L.lib().vmp_mix_mahalanobis(L.ptr(x), L.ptr(m), L.ptr(P), L.ptr(v), L.ptr(b), L.ptr(m8), N, D, K, L.ptr(out),
+                                        L.stream()), 'vmp_mix_mahalanobis')
+    return out
+
+
 def compute_expct_mahalanobis_dist(x, beta_k, m_k, P_k, v_k):
-    """reference gmm.py:84-94 is fused into the E-pass kernel; this stand-alone form recovers it from the
-    kernel's un-normalised log-responsibilities is not offered - use e_step."""
-    raise NotImplementedError('fused into vmp_mix_estep; use e_step / e_step_missing_data')
+    """reference gmm.py:84-94 (Bishop 10.64), stand-alone: (N,K).  Inside e_step / inference the distance never leaves
+    the fused pass kernel."""
+    return _mahalanobis(x, beta_k, m_k, P_k, v_k)
+
+
+def compute_dev_missing_data(x, beta_k, m_k, P_k, v_k, missing_data_mask):
+    """reference gmm.py:97-114: as above with the missing entries of (x - m_k) zeroed."""
+    return _mahalanobis(x, beta_k, m_k, P_k, v_k, missing_data_mask)
+
+
+def compute_rnk(expct_log_pi, expct_log_det_cov, expct_dev):
+    """reference gmm.py:141-151 (Bishop 10.49): max-shifted softmax over k of E log pi + 1/2 E log det - 1/2 E dev."""
+    return torch.softmax(expct_log_pi + 0.5 * expct_log_det_cov - 0.5 * expct_dev, dim=1)
 
 
 class _Handle(object):

@@ -348,3 +348,17 @@ def predict(y, phi_gmm, encoder_layers, decoder_layers, seed=0):
     x_samples = subsample_x(x_k_samples, log_r_nk, seed)[:, 0, :]
     y_mean, _ = vae.make_decoder(x_samples, layerspecs=decoder_layers)
     return y_mean, torch.argmax(log_r_nk, dim=1)
+
+
+def identity_transform(input, nb_components, nb_samples, type='standard', name='debug_nn'):
+    """reference svae.py:519-535 (debug helper that freezes the network): mu_n = x_n, Sigma_n = 0.1 I (2-D data)."""
+    nn_var = 1e-1
+    mu = input
+    sigma = nn_var * torch.eye(2, dtype=input.dtype, device=input.device).expand(mu.shape[0], 2, 2)
+    if type == 'natparam':
+        eta1, eta2 = gaussian.standard_to_natural(mu, sigma)
+        return eta1, torch.diagonal(eta2, dim1=-2, dim2=-1)
+    sig = torch.full_like(mu[:, :2], nn_var)              # diagonal of sigma, (N,2)
+    if tuple(sig.shape) != tuple(input.shape):            # svae.py:532-533
+        sig = sig[:, None, None, :].expand(-1, nb_components, nb_samples, -1)
+    return mu, sig

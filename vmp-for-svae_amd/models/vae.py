@@ -195,6 +195,19 @@ def make_decoder(input, layerspecs=None, stddev_init=1., param_device=None, seed
     return output
 
 
+def make_gaussian_layer(inputs, output_dim, stddev=1, type='standard', name='gaussian_output', param_device=None, seed=0,
+                        scope=''):
+    """reference vae.py:28-50: dense layer of width 2*output_dim whose halves are (mean, softplus) ('standard') or
+    (eta1, -1/2 softplus) ('natparam')."""
+    u = make_layer(inputs, 2 * output_dim, stddev, None, name, param_device, seed, scope)
+    raw1, raw2 = u[..., :output_dim], u[..., output_dim:]
+    if type == 'standard':
+        return raw1, _softplus(raw2)
+    if type == 'natparam':
+        return raw1, -0.5 * _softplus(raw2)
+    raise Exception("Type '%s' does not exist." % type)
+
+
 def make_bernoulli_layer(input, output_dim, stddev=1, name='bernoulli_output', param_device=None, seed=0, scope=''):
     """reference vae.py:53-55."""
     return make_layer(input, output_dim, stddev, None, name, param_device, seed, scope)
