@@ -84,3 +84,38 @@ def minibatches_device(X_dev, size_minibatch, seed=0):
         perm = torch.as_tensor(rng.permutation(N)).to(X_dev.device)
         for i in range(0, N - size_minibatch + 1, size_minibatch):
             yield X_dev.index_select(0, perm[i:i + size_minibatch])
+
+
+def perturb_data(x, noise_ratio=0.1, noise_mean=0, noise_stddev=10, seed=0):
+    """reference data.py:238-259: a random `noise_ratio` of the rows is REPLACED by N(mean, stddev) noise (in place,
+    same numpy RandomState stream)."""
+    np.random.seed(seed)
+    N, D = x.shape
+    N_noise = int(N * noise_ratio)
+    noise_indices = np.random.permutation(np.arange(N))[:N_noise]
+    x[noise_indices, :] = np.random.normal(loc=noise_mean, scale=noise_stddev, size=(N_noise, D))
+    return x
+
+
+def make_minibatch(dataset, ratio_tr=None, ratio_val=None, binarise=False, path_datadir='../datasets', size_minibatch=128,
+                   size_testbatch=-1, nb_towers=1, nb_threads=2, seed_split=0, seed_minibatch=0, dtype=None,
+                   name='data_prep', noise_level=0.1, device='cuda'):
+    """reference data.py:9-176 for the table datasets (pinwheel, noisy-pinwheel, auto, aggregation, geyser):
+    returns (y_tr, lbl_tr, y_te, lbl_te) like the reference, where y_tr is an endless generator of shuffled minibatches
+    gathered on the device (the reference's tf.train.shuffle_batch queue; split over `nb_towers` = ranks is done by the
+    launcher) and y_te / labels are device tensors.  The MNIST-style TFRecord inputs (data.py:13-33,179-213) are not
+    built: there are no such files in this image."""
+    import torch
+    if dataset in ('mnist', 'mnist-small', 'fashion') or binarise:
+        raise NotImplementedError('TFRecord image datasets are not built')
+    data, labels = load_dataset(dataset, path_datadir)
+    if dataset == 'noisy-pinwheel':
+        data = perturb_data(np.array(data, dtype=np.float64), noise_ratio=noise_level)
+    X_tr, l_tr, X_te, l_te = split_and_scale(dataset, data, labels, ratio_tr=0.7 if ratio_tr is None else ratio_tr,
+                                             seed_split=seed_split)
+    dev = torch.device(device)
+    Xtr, Xte = torch.as_tensor(X_tr).to(dev), torch.as_tensor(X_te).to(dev)
+    if size_testbatch and size_testbatch > 0:
+        Xte, l_te = Xte[:size_testbatch], (None if l_te is None else l_te[:size_testbatch])
+    to_t = lambda a: None if a is None else torch.as_tensor(a, dtype=torch.float32).to(dev)
+    return minibatches_device(Xtr, size_minibatch, seed=seed_minibatch), to_t(l_tr), Xte, to_t(l_te)
