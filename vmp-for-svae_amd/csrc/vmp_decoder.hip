@@ -19,7 +19,9 @@
 //     contraction index; the two operands of those products need (unit,row) -> (row,unit) transposes, done 16x16 at
 //     a time through a per-wave LDS scratch.  Per-wave accumulators are reduced in a fixed order: waves of a block
 //     through LDS, blocks through a workspace and a second tiny kernel in fp64 (deterministic, no atomics).
-// MFMA work per 16 rows at U=50: 90 (fwd) / 290 (bwd incl. recompute) instructions of 32 cycles.
+// MFMA work per 16 rows at U=50: 80 (fwd) / 270 (bwd incl. recompute) instructions of 32 cycles (k-steps that would only
+// multiply zero padding are skipped at compile time).  On gfx950 the fp32 MFMA runs at the fp32 vector rate and its time
+// ADDS to the VALU time of the SIMD (tools/ubench/mfma_cover.hip), so the bound of both kernels is MFMA + VALU issue.
 #include "vmp_common.h"
 
 using namespace vmp;
