@@ -1,5 +1,4 @@
-"""Profiling target: T2 (SVAE E-step fwd + bwd + sub-sampling + M-step moments) at BASELINE config 3 size.
-K-sized inputs are prepared on the CPU (torch's rocsolver-based linalg misbehaves under rocprofv3 --pmc)."""
+"""Profiling target: T2 (SVAE E-step fwd + bwd + sub-sampling + M-step moments) at BASELINE config 3 size."""
 import os
 import sys
 import torch
@@ -8,12 +7,13 @@ import vmp_for_svae_amd as V
 from vmp_for_svae_amd.models import svae, _svae_ops, _mix
 N = int(os.environ.get('N', 1000000)); Ld = int(os.environ.get('L', 8)); K = int(os.environ.get('K', 16)); S = int(os.environ.get('S', 10))
 dev = 'cuda'
+# initial parameters on the CPU (torch's rocsolver-based linalg misbehaves under rocprofv3 --pmc), then moved
 prior, theta = svae.init_mm(K, Ld, seed=0, param_device='cpu')
-phi = list(svae.init_recognition_params(theta, K, seed=0, param_device='cpu'))
-e1k, e2k, pik = svae.unpack_recognition_gmm(phi)
-P, bias = svae._recognition_bias(e1k, e2k, pik)
+phi = [p.detach().to(dev).contiguous() for p in svae.init_recognition_params(theta, K, seed=0, param_device='cpu')]
+theta = [t.to(dev).contiguous() for t in theta]
+with torch.no_grad():
+    hk, P, bias = _svae_ops.PhiPrepFn.apply(*[p.detach() for p in phi])        # K-sized inputs from the prep kernels
 mk, Wk, kap, nu = svae._theta_pack(theta)
-hk, P, bias, mk, Wk, kap = [t.detach().float().to(dev).contiguous() for t in (e1k, P, bias, mk, Wk, kap)]
 g = torch.Generator(device=dev).manual_seed(0)
 eta1 = torch.randn(N, Ld, device=dev, generator=g).requires_grad_(True)
 eta2d = (-0.5 * torch.log1p(torch.exp(torch.randn(N, Ld, device=dev, generator=g)))).requires_grad_(True)
