@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+FP32_PEAK_FLOPS = 157.3e12     # fp32 vector = fp32 MFMA peak (same guide)
 
 
 def synth(N, D, K, seed):
@@ -259,27 +260,96 @@ def bench_minibatch(N, K, Ld, Dy, S, U, dev, steps=200, cpu=True):
     return res
 
 
+def time_t1(loop, steps, warmup, reps, barrier, dist, dev):
+    """`reps` repetitions of the contract's timed region (barrier + synchronize, EXACTLY `steps` steps, barrier +
+    synchronize; MAX over ranks), each preceded by nothing but the previous region.  Returns the per-region wall times (s)
+    and the mean duration (ms) of the dominant kernel, bracketed by HIP events on the launch stream on every EV_EVERY-th
+    step (an event record between two dependent launches costs a few microseconds of gap: bracketing every step inflates
+    the step)."""
+    EV_EVERY = 4
+    for _ in range(warmup):
+        loop.step()
+    walls, kern = [], []
+    for _ in range(reps):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range((steps + EV_EVERY - 1) // EV_EVERY)]
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loop.finalize_phase()
+            if i % EV_EVERY == 0:
+                ev[i // EV_EVERY][0].record()
+                loop.estep()                             # exactly one launch: the fused streaming pass
+                ev[i // EV_EVERY][1].record()
+            else:
+                loop.estep()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = tt.item()
+        walls.append(dt)
+        kern.append(float(np.mean([a.elapsed_time(b) for a, b in ev])))
+    return walls, kern
+
+
+def t1_flops(N, D, K):
+    """F ~ N K [(2 D^2 + 3 D) + 2 (D + D^2) + 12] (Mahalanobis form + moments + softmax)."""
+    return float(N) * K * ((2 * D * D + 3 * D) + 2 * (D + D * D) + 12)
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh worker processes of this script (one rank per GPU,
+    RCCL rendezvous on 127.0.0.1) BEFORE anything here has touched the GPU, wait for them and pass rank 0's JSON line
+    through.  (Under torchrun the ranks already exist and this is not used.)"""
+    import socket
+    import subprocess
+    s_ = socket.socket()
+    s_.bind(('127.0.0.1', 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--reps', type=int, default=31, help='repetitions of the timed region; the median is reported')
     ap.add_argument('--workload', default='gmm', choices=['gmm', 'smm'])
     ap.add_argument('--n', type=int, default=1_000_000)
     ap.add_argument('--d', type=int, default=8)
     ap.add_argument('--k', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-extra', action='store_true', help='skip the T2 / T3 side measurements')
+    ap.add_argument('--no-extra', action='store_true', help='skip the side measurements (T2 / T3 / N=1e7 / forced-dist)')
     ap.add_argument('--s', type=int, default=10)
     ap.add_argument('--u', type=int, default=50)
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        ndev = torch.cuda.device_count()                 # does not initialise the GPU on this image
+        if ndev < args.gpus:
+            sys.exit('bench.py: --gpus %d but only %d GPU(s) visible' % (args.gpus, ndev))
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        sys.exit('bench.py: --gpus %d does not match WORLD_SIZE=%d' % (args.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
-    force_dist = os.environ.get('VMP_FORCE_DIST') == '1'        # exercise the RCCL path with a single rank
-    if world > 1 or force_dist:
+    if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
@@ -297,45 +367,55 @@ def main():
     x_h, r0_h = synth(N, D, K, seed=rank)                # every rank: its own shard of the (virtual) N*world rows
     x, r0 = torch.as_tensor(x_h).to(dev), torch.as_tensor(r0_h).to(dev)
     kappa = torch.full((K,), 5.0, device=dev) if flav == L.VMP_SMM else None
-    if world > 1 or force_dist:
-        loop = DistributedVMPLoop(x, r0, flav, kappa=kappa)
-    else:
-        loop = _mix.VMPLoop(x, r0, flav, kappa=kappa)
+    loop = DistributedVMPLoop(x, r0, flav, kappa=kappa) if world > 1 else _mix.VMPLoop(x, r0, flav, kappa=kappa)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        loop.step()
-    # HIP events bracket the dominant kernel on every EV_EVERY-th step of the timed region (an event record between two
-    # dependent launches costs a few microseconds of gap: bracketing every step inflates a 66 us step to 74 us)
-    EV_EVERY = 4
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range((args.steps + EV_EVERY - 1) // EV_EVERY)]
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loop.finalize_phase()
-        if i % EV_EVERY == 0:
-            ev[i // EV_EVERY][0].record()
-            loop.estep()                                 # exactly one launch: the fused streaming pass
-            ev[i // EV_EVERY][1].record()
-        else:
-            loop.estep()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    walls, kerns = time_t1(loop, args.steps, args.warmup, max(1, args.reps), barrier, dist, dev)
+    dt = float(np.median(walls))
+    kern_ms = float(np.median(kerns))
     assert torch.isfinite(loop.r).all()
     extra = {}
     if not args.no_extra:
-        del loop, x, r0
+        del loop
         torch.cuda.empty_cache()
+        if world == 1:
+            # (a) what the data-parallel iteration costs on top of the plain one, with ONE rank (local reduction ->
+            #     RCCL all-reduce of the fp64 moments -> posterior + pack -> streaming pass)
+            import torch.distributed as dist1
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            dist1.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+            dloop = DistributedVMPLoop(x, r0, flav, kappa=kappa)
+            dw, _ = time_t1(dloop, args.steps, args.warmup, 7, lambda: torch.cuda.synchronize(), None, dev)
+            dist1.destroy_process_group()
+            d_us = float(np.median(dw)) / args.steps * 1e6
+            extra['t1_forced_dist_1rank'] = {'us_per_step': d_us, 'plain_us_per_step': dt / args.steps * 1e6,
+                                             'dist_overhead_us': d_us - dt / args.steps * 1e6}
+            del dloop
+        del x, r0
+        torch.cuda.empty_cache()
+        if world == 1 and (N, D, K) == (1_000_000, 8, 16):
+            # (b) the cache-defeating size of SURVEY 8d: N=1e7 (x + r = 960 MB >> the 256 MiB Infinity Cache)
+            Nb = 10_000_000
+            g = torch.Generator(device=dev).manual_seed(5)
+            cb = torch.randn(K, D, device=dev, generator=g) * 5
+            xb = cb[torch.randint(0, K, (Nb,), device=dev, generator=g)] + torch.randn(Nb, D, device=dev, generator=g)
+            rb = torch.softmax(3 * torch.randn(Nb, K, device=dev, generator=g), dim=1)
+            bloop = _mix.VMPLoop(xb, rb, flav, kappa=kappa)
+            bw, bk = time_t1(bloop, 20, 5, 7, lambda: torch.cuda.synchronize(), None, dev)
+            b_ms, bk_ms = float(np.median(bw)) / 20 * 1e3, float(np.median(bk))
+            wordsb = (2 * D + 2 * K) if flav == L.VMP_GMM else (2 * D + 4 * K)
+            extra['t1_n1e7'] = {'ms_per_step': b_ms, 'datapoints_per_sec': Nb / (b_ms * 1e-3), 'kernel_ms': bk_ms,
+                                'algorithmic_GBps': 4.0 * Nb * wordsb / (bk_ms * 1e-3) / 1e9,
+                                'frac_hbm': 4.0 * Nb * wordsb / (bk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                'moved_GBps': 2.0 * Nb * wordsb / (bk_ms * 1e-3) / 1e9,
+                                'valu_frac': t1_flops(Nb, D, K) / (bk_ms * 1e-3) / FP32_PEAK_FLOPS}
+            del bloop, xb, rb
+            torch.cuda.empty_cache()
         extra['t2_svae_vmp'] = bench_t2(N, D, K, args.s, 5, 2, dev, dist, world)
         torch.cuda.empty_cache()
         if world == 1:
@@ -351,25 +431,34 @@ def main():
         alg_bytes = 4.0 * N * words                      # T1 algorithmic bytes per step (per GPU)
         min_bytes = alg_bytes / 2                        # what the fused pass has to move: read x, write r (u)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         tf = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % args.workload)
         if os.path.exists(tf) and (N, D, K) == (1_000_000, 8, 16):
-            traffic = json.load(open(tf)).get('hbm_bytes_per_launch')
+            tj = json.load(open(tf))
+            traffic = tj.get('hbm_bytes_per_launch')
+            traffic_src = 'committed rocprofv3 PMC summary (%s), not re-measured by this run' % tj.get('source', tf)
         out = {
             'metric': 'vmp_step_datapoints_per_sec', 'value': N * world / (dt / args.steps), 'unit': 'datapoints/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'reps': len(walls), 'ms_per_step': ms,
+            'ms_per_step_min': min(walls) / args.steps * 1e3, 'ms_per_step_max': max(walls) / args.steps * 1e3,
             'steps_per_sec': args.steps / dt, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'T1 %s VMP step (M-step + E-step), synthetic GMM N=%d per GPU, D=%d, K=%d'
                                    % (args.workload, N, D, K), 'N_per_gpu': N, 'D': D, 'K': K,
-                       'parallelism': 'dp%d (rows sharded, 1 all-reduce of K-sized stats per step)' % world},
+                       'parallelism': 'dp%d (rows sharded, 1 all-reduce of K-sized stats per step)' % world,
+                       'timing': 'median over `reps` timed regions of `steps` steps each'},
+            # `achieved`/`frac` follow the contract: ALGORITHMIC bytes (4N(2D+2K), the un-fused M-pass +
+            # E-pass) / kernel time.  The fused pass MOVES half of that (x read once, r written once): `moved_*` is the
+            # physical HBM rate, `valu_frac` the fp32 arithmetic rate - the kernel is instruction-issue bound.
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': 'pass_kernel<E-step + fused moments>', 'kernel_ms': kern_ms,
                          'algorithmic_bytes_per_launch': alg_bytes,
                          'moved_bytes_min_per_launch': min_bytes,
                          'moved_GBps': min_bytes / (kern_ms * 1e-3) / 1e9,
-                         'moved_frac': min_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         'moved_frac': min_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         'flops_per_launch': t1_flops(N, D, K),
+                         'valu_frac': t1_flops(N, D, K) / (kern_ms * 1e-3) / FP32_PEAK_FLOPS},
         }
         if extra:
             out['extra'] = extra

@@ -295,6 +295,21 @@ int    vmp_eval_cell_metrics(const float* y, const float* mean, const float* var
                              int logw_per_sample, const uint8_t* mask, int mask_mse, int64_t N, int K, int S, int Dy,
                              float* mse, float* lse, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU exchange (replaces the in-graph tower gather + mean of experiments.py:247-260 and
+ * helpers/tf_utils.py:52-87): ONE in-place all-reduce(sum) over RCCL / xGMI of the packed fp64 buffer
+ *   T1: raw moments (K, 2+D+D*D);   T3: [ raw moments | flat gradients | elbo, neg_rec_err, regulariser ]
+ * after which every rank applies the identical K-sized update.  `comm` is an RCCL communicator (ncclComm_t); a host
+ * that has none (the torch host uses torch.distributed's) builds one with the three helpers: rank 0 calls
+ * vmp_comm_unique_id and ships the 128-byte id to the other ranks out of band, every rank calls vmp_comm_init_rank
+ * with its device current.  RCCL is resolved at run time (the copy the process has already loaded, else librccl.so.1):
+ * the library has no link-time dependency on it and single-GPU hosts never load it.                              */
+#define VMP_COMM_ID_BYTES 128
+int    vmp_comm_unique_id(void* id_out /* VMP_COMM_ID_BYTES */);
+int    vmp_comm_init_rank(void** comm_out, int nranks, const void* id, int rank);
+int    vmp_comm_destroy(void* comm);
+int    vmp_pack_allreduce(void* comm, double* buf, size_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -177,3 +177,80 @@ def smm_inference_step(x, r, u, kappa):
     kap = torch.full((K,), float(kappa), dtype=x.dtype) if not torch.is_tensor(kappa) else kappa
     r_new, u_new, pi = smm_e_step(x, alpha_k, beta_k, m_k, P_k, v_k, kap)
     return r_new, u_new, (alpha_k, beta_k, m_k, C_k, v_k, kap), (x_k, S_k, pi)
+
+
+# =============================================================================== N-chunked evaluation (large N)
+# The literal formulation above materialises (N,K,D,D) temporaries, which is fine for the golden-vector sizes but not
+# for N = 1e6.  The functions below evaluate THE SAME two-pass update (gmm.py:25-46 / smm.py:25-50: N_k and x_k first,
+# then the centred S_k around that x_k; E-step row by row) over row chunks with the partial sums accumulated in the
+# working dtype - no algebraic shortcut (no raw-moment trick), so in fp64 they are the same truth the goldens pin.
+# tests/test_oracle_golden.py checks chunked == un-chunked.
+def _chunks(N, chunk):
+    return [(i, min(N, i + chunk)) for i in range(0, N, chunk)]
+
+
+def _m_step_sums_chunked(x, w, chunk):
+    """(sum_n w, x_k (NaN/eps handling left to the caller: returns the raw sum too), centred scatter sum)."""
+    K, D = w.shape[1], x.shape[1]
+    W_k = torch.zeros(K, dtype=x.dtype)
+    sx = torch.zeros(K, D, dtype=x.dtype)
+    for a, b in _chunks(x.shape[0], chunk):
+        W_k += w[a:b].sum(0)
+        sx += torch.einsum('nk,nd->kd', w[a:b], x[a:b])
+    return W_k, sx
+
+
+def _scatter_chunked(x, w, x_k, chunk):
+    K, D = w.shape[1], x.shape[1]
+    S = torch.zeros(K, D, D, dtype=x.dtype)
+    for a, b in _chunks(x.shape[0], chunk):
+        d = x[a:b].unsqueeze(1) - x_k.unsqueeze(0)
+        S += torch.einsum('nk,nkd,nke->kde', w[a:b], d, d)
+    return S
+
+
+def gmm_inference_step_chunked(x, r, chunk=1 << 15):
+    """gmm_inference_step (gmm.py:258-269) over row chunks.  Same return value."""
+    K, D = r.shape[1], x.shape[1]
+    prior = vmp_prior(K, D, x.dtype)
+    alpha_0, beta_0, m_0, C_0, v_0 = prior
+    N_k, sx = _m_step_sums_chunked(x, r, chunk)
+    xn = sx / N_k.unsqueeze(1)
+    x_k = torch.where(torch.isnan(xn), sx, xn)                                   # gmm.py:34-36
+    S = _scatter_chunked(x, r, x_k, chunk)
+    Sn = S / N_k.view(-1, 1, 1)
+    S_k = torch.where(torch.isnan(Sn), S, Sn)                                    # gmm.py:44-46
+    alpha_k, beta_k = alpha_0 + N_k, beta_0 + N_k
+    m_k = (beta_0.reshape(-1, 1) * m_0 + N_k.unsqueeze(1) * x_k) / beta_k.unsqueeze(1)
+    q0 = x_k - m_0
+    C_k = C_0 + N_k.view(-1, 1, 1) * S_k + torch.einsum('k,kd,ke->kde', beta_0 * N_k / beta_k, q0, q0)
+    v_k = v_0 + N_k + 1
+    P_k = dists.inv(C_k)
+    r_new = torch.cat([gmm_e_step(x[a:b], alpha_k, beta_k, m_k, P_k, v_k)[0] for a, b in _chunks(x.shape[0], chunk)])
+    return r_new, torch.log(r_new), (alpha_k, beta_k, m_k, C_k, v_k), (x_k, S_k, torch.exp(gmm_log_pi(alpha_k)))
+
+
+def smm_inference_step_chunked(x, r, u, kappa, chunk=1 << 15, eps=1e-20):
+    """smm_inference_step (smm.py:232-245) over row chunks.  Same return value."""
+    K, D = r.shape[1], x.shape[1]
+    alpha_0, beta_0, m_0, C_0, v_0 = vmp_prior(K, D, x.dtype)
+    ru = r * u
+    N_k = torch.zeros(K, dtype=x.dtype)
+    for a, b in _chunks(x.shape[0], chunk):
+        N_k += r[a:b].sum(0)
+    W_k, sx = _m_step_sums_chunked(x, ru, chunk)
+    x_k = sx / (W_k.unsqueeze(1) + eps)
+    S_k = _scatter_chunked(x, ru, x_k, chunk) / (W_k.view(-1, 1, 1) + eps)
+    alpha_k, beta_k = alpha_0 + N_k, beta_0 + W_k
+    m_k = (beta_0.reshape(-1, 1) * m_0 + W_k.unsqueeze(1) * x_k) / beta_k.unsqueeze(1)
+    e0 = x_k - m_0
+    C_k = C_0 + W_k.view(-1, 1, 1) * S_k + torch.einsum('k,kd,ke->kde', beta_0 * W_k / beta_k, e0, e0)
+    v_k = v_0 + N_k
+    P_k = dists.inv(C_k)
+    kap = torch.full((K,), float(kappa), dtype=x.dtype) if not torch.is_tensor(kappa) else kappa
+    rs, us = [], []
+    for a, b in _chunks(x.shape[0], chunk):
+        r_c, u_c, pi = smm_e_step(x[a:b], alpha_k, beta_k, m_k, P_k, v_k, kap)
+        rs.append(r_c)
+        us.append(u_c)
+    return torch.cat(rs), torch.cat(us), (alpha_k, beta_k, m_k, C_k, v_k, kap), (x_k, S_k, pi)

@@ -246,10 +246,14 @@ def load_weights(w):
         tf.VARIABLES[k] = t
 
 
-def case_svae(seed, N, K, L, S, Dy, U, smm=False, steps=3, lr=3e-4, lrcvi=0.2, decay=0.95):
+def case_svae(seed, N, K, L, S, Dy, U, smm=False, steps=3, lr=3e-4, lrcvi=0.2, decay=0.95, y=None, slim=False):
+    """`y` (N,Dy): data rows to train on (default: a synthetic mixture).  `slim`: keep the large per-sample outputs
+    (reconstructions, phi_tilde) out of the fixture and store x_k in fp64 only."""
     rng = np.random.Generator(np.random.PCG64(seed))
     c = rng.standard_normal((K, Dy)) * 2.0
-    y = f32(c[rng.integers(0, K, size=N)] + 0.5 * rng.standard_normal((N, Dy)))
+    y_syn = f32(c[rng.integers(0, K, size=N)] + 0.5 * rng.standard_normal((N, Dy)))
+    y = y_syn if y is None else f32(y)
+    assert y.shape == (N, Dy)
     weights = make_weights(rng, Dy, L, U)
     m_unif = f32(rng.random((K, L)))                      # tf.random_uniform draw of svae.py:440 (pre-scaling)
     pi_norm = f32(rng.standard_normal((K,)))              # tf.random_normal draw of svae.py:491
@@ -335,8 +339,9 @@ def case_svae(seed, N, K, L, S, Dy, U, smm=False, steps=3, lr=3e-4, lrcvi=0.2, d
             grads = torch.autograd.grad(-elbo, params, allow_unused=True)
             o[pre + 'enc_eta1'], o[pre + 'enc_eta2'] = npy(y_enc[0]), npy(y_enc[1])
             o[pre + 'x_k'], o[pre + 'x_s'], o[pre + 'log_z'] = npy(x_k), npy(x_s), npy(log_z)
-            o[pre + 'rec_mean'], o[pre + 'rec_var'] = npy(y_rec[0]), npy(y_rec[1])
-            o[pre + 'phi_tilde_eta1'], o[pre + 'phi_tilde_eta2'] = npy(phi_tilde[0]), npy(phi_tilde[1])
+            if not slim:
+                o[pre + 'rec_mean'], o[pre + 'rec_var'] = npy(y_rec[0]), npy(y_rec[1])
+                o[pre + 'phi_tilde_eta1'], o[pre + 'phi_tilde_eta2'] = npy(phi_tilde[0]), npy(phi_tilde[1])
             o[pre + 'elbo'] = npy(elbo)
             o[pre + 'details'] = np.stack([npy(d) for d in details])
             for n_, g in zip(names, grads):
@@ -376,9 +381,42 @@ def case_svae(seed, N, K, L, S, Dy, U, smm=False, steps=3, lr=3e-4, lrcvi=0.2, d
         return o
 
     out = both(run)
+    if slim:
+        for k in [k for k in out if k.endswith('__f32') and (k.endswith('x_k__f32') or k.endswith('x_s__f32'))]:
+            del out[k]
     out.update({'in_' + k: v for k, v in inputs.items()})
     out['in_dims'] = np.array([N, K, L, S, Dy, U, steps, int(smm)])
     return out
+
+
+# ============================================================================ data.py: loaders, split, scaling, perturbation
+def case_datasets():
+    """Outputs of the reference's own data.py (make_pinwheel_data :216-235, make_minibatch :9-176 with
+    size_minibatch=-1 i.e. the full split tensors, perturb_data :238-259) on the dataset files that ship with the
+    reference (datasets/Auto/auto-mpg.csv, Aggregation.txt, geyser).  Only the processed arrays are stored."""
+    import data as rdata
+    tf.reset()
+    o = {}
+    X, lab = rdata.make_pinwheel_data(0.3, 0.05, 5, 200, 0.25)
+    o['pinwheel_data'], o['pinwheel_labels'] = X, lab
+    for ds in ('auto', 'aggregation', 'geyser', 'pinwheel', 'noisy-pinwheel'):
+        X_tr, y_tr, X_te, y_te = rdata.make_minibatch(ds, ratio_tr=0.7, path_datadir=os.path.join(REF, 'datasets'),
+                                                      size_minibatch=-1, size_testbatch=-1, seed_split=0,
+                                                      noise_level=0.1)
+        key = ds.replace('-', '_')
+        o[key + '_X_tr'], o[key + '_X_te'] = npy(X_tr), npy(X_te)
+        o[key + '_y_tr'], o[key + '_y_te'] = npy(y_tr), npy(y_te)
+    z = np.arange(60, dtype=np.float64).reshape(20, 3)
+    o['perturb_in'] = z.copy()
+    o['perturb_out'] = rdata.perturb_data(z.copy(), noise_ratio=0.25, noise_mean=1.0, noise_stddev=3.0, seed=7)
+    return o
+
+
+def auto_minibatch(n=64, seed=0):
+    """The first minibatch of the Auto training set (reference loader, standardised x5) under the build's PCG64 shuffle."""
+    d = np.load(os.path.join(HERE, 'datasets.npz'))
+    X = d['auto_X_tr']
+    return X[np.random.Generator(np.random.PCG64(seed)).permutation(X.shape[0])[:n]]
 
 
 # ============================================================================ evaluation metrics (losses.py)
@@ -546,6 +584,8 @@ def case_vae_bernoulli(seed, N, K, S, L, D, U):
 
 def main():
     cases = {
+        'datasets': case_datasets,
+        'svae_auto': lambda: case_svae(16, N=64, K=10, L=8, S=10, Dy=6, U=50, steps=3, y=auto_minibatch(), slim=True),
         'dist_tiny': lambda: case_distributions(1, N=6, K=4, L=3, S=5),
         'dist_l8': lambda: case_distributions(2, N=9, K=5, L=8, S=4),
         'gmm_tiny': lambda: case_gmm(3, N=60, D=2, K=3),

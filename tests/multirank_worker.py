@@ -1,0 +1,83 @@
+"""One rank of the multi-rank GPU tests (tests/test_multirank_gpu.py starts WORLD_SIZE of these as child processes).
+Every rank runs the product's data-parallel step functions on ITS shard of the rows - HIP kernels on the (shared) GPU,
+the one packed all-reduce of a step through torch.distributed (gloo rendezvous: RCCL refuses two ranks on one device) -
+and writes what it ends up with to <out>/rank<r>.npz.  Not a test module itself (no test_ prefix)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    payload, out_dir = sys.argv[1], sys.argv[2]
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import vmp_for_svae_amd as V
+    from vmp_for_svae_amd import data as data_mod, experiments
+    from vmp_for_svae_amd.models import vae
+    from vmp_for_svae_amd.models.parallel_mix import DistributedVMPLoop
+    from vmp_for_svae_amd.training import SVAETrainer
+    L = V._lib
+    p = np.load(payload)
+    dev = lambda a, dt=torch.float32: torch.as_tensor(np.asarray(a)).to('cuda', dt)
+    res = {}
+
+    # ---- T1: DistributedVMPLoop.step on a contiguous row shard (uneven split on purpose)
+    x, r0 = p['t1_x'], p['t1_r0']
+    N = x.shape[0]
+    cut = [0, int(N * 0.37), N] if world == 2 else [N * i // world for i in range(world + 1)]
+    sl = slice(cut[rank], cut[rank + 1])
+    for name, flav in (('gmm', L.VMP_GMM), ('smm', L.VMP_SMM)):
+        kap = torch.full((r0.shape[1],), 5.0, device='cuda') if flav == L.VMP_SMM else None
+        loop = DistributedVMPLoop(dev(x[sl]), dev(r0[sl]), flav, kappa=kap)
+        for _ in range(3):
+            r = loop.step()
+        res['t1_%s_r' % name] = r.cpu().numpy()
+        for n_, t in zip(('alpha', 'beta', 'm', 'C', 'v'), loop.theta()):
+            res['t1_%s_%s' % (name, n_)] = t.cpu().numpy()
+
+    # ---- T3: SVAETrainer.step on this tower's rows of the minibatch (tf.split semantics, data.py:174-175)
+    Nb, K, Ld, S, Dy, U = [int(v) for v in p['t3_dims']]
+    tsl = data_mod.tower_slice(Nb, rank, world)
+    vae.reset_variables()
+    for k in p.files:
+        if k.startswith('w_'):
+            vae.VARIABLES[k[2:]] = torch.nn.Parameter(dev(p[k]))
+    tr = SVAETrainer(K, Ld, U, Dy, nb_samples=S, m_uniform=dev(p['t3_m_unif']), pi_normal=dev(p['t3_pi_norm']))
+    with torch.no_grad():
+        tr.phi_gmm[1].add_(dev(p['t3_Lk_low']))
+    for it in range(2):
+        out = tr.step(dev(p['t3_y'][tsl]), noise=dev(p['t3_noise'][it][tsl]), z_draws=dev(p['t3_zd'][it][tsl], torch.int64))
+        res['t3_elbo%d' % it] = np.float64(out['elbo'].item())
+        for n_, g in out['grads'].items():
+            res['t3_grad%d_%s' % (it, n_)] = g.cpu().numpy()
+        for n_, t in zip(('alpha', 'A', 'b', 'beta', 'vhat'), out['theta_star']):
+            res['t3_theta_star%d_%s' % (it, n_)] = t.cpu().numpy()
+    names, params = tr.trainables()
+    for n_, t in zip(names, params):
+        res['t3_param_' + n_] = t.detach().cpu().numpy()
+    for n_, t in zip(('alpha', 'A', 'b', 'beta', 'vhat'), tr.theta):
+        res['t3_theta_' + n_] = t.cpu().numpy()
+
+    # ---- the driver: experiments.run shards every minibatch by rank and ends with identical parameters everywhere
+    vae.reset_variables()
+    cfg = {'dataset': 'pinwheel', 'method': 'svae-cvi', 'lr': 0.003, 'lrcvi': 0.2, 'K': 5, 'L': 2, 'U': 20, 'seed': 0}
+    tr2, hist, _ = experiments.run(cfg, nb_iters=6, size_minibatch=64, nb_samples=4, nb_samples_te=4, measurement_freq=100,
+                                   verbose=False)
+    _, params2 = tr2.trainables()
+    res['run_params'] = np.concatenate([t.detach().cpu().numpy().reshape(-1) for t in params2])
+    res['run_theta'] = np.concatenate([t.cpu().numpy().reshape(-1) for t in tr2.theta])
+    res['run_elbo'] = np.float64(hist[-1]['neg_normed_elbo'])
+    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

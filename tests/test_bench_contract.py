@@ -28,3 +28,17 @@ def test_committed_bench_line_schema():
         assert k in c, k
     assert c['kind'] in ('reference', 'port') and c['unit'] == d['unit']
     assert abs(d['value'] - N * d['n_gpus'] / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+
+
+def test_gpus_flag_is_not_ignored():
+    """`--gpus N` either launches N ranks or refuses: asking for more GPUs than are visible, or for a count that
+    disagrees with the launcher's WORLD_SIZE, exits non-zero instead of silently reporting a 1-GPU number."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['HIP_VISIBLE_DEVICES'] = ''
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8'], env=env, capture_output=True, text=True)
+    assert p.returncode != 0 and 'GPU' in (p.stderr + p.stdout)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=dict(env, WORLD_SIZE='4', RANK='0'),
+                       capture_output=True, text=True)
+    assert p.returncode != 0 and 'WORLD_SIZE' in (p.stderr + p.stdout)

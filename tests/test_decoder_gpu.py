@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+import parity_log
+
 pytestmark = pytest.mark.gpu
 NET_VARS = ('layer_0/kernel', 'layer_0/bias', 'layer_1/kernel', 'layer_1/bias', 'gaussian_output/kernel',
             'gaussian_output/bias', 'shortcut/W', 'shortcut/b1', 'shortcut/b2')
@@ -36,7 +38,7 @@ def truth(x, y, r, w):
 
 def relerr(got, want):
     want = want.detach().double().cpu()
-    return ((got.detach().double().cpu() - want).abs().max() / want.abs().max().clamp_min(1e-300)).item()
+    return parity_log.record('rel', ((got.detach().double().cpu() - want).abs().max() / want.abs().max().clamp_min(1e-300)).item())
 
 
 CASES = [  # N, K, S, L, Dy, U

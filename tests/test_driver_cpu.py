@@ -12,10 +12,36 @@ from vmp_for_svae_amd.helpers.scheduling import create_schedule
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
 
 
+DATADIR = os.path.join(GOLD, 'datasets')                     # the reference's dataset files (data, not source)
+
+
 def test_pinwheel_matches_reference_output():
-    g = np.load(os.path.join(GOLD, 'pinwheel.npz'))          # generated by reference data.make_pinwheel_data
+    g = np.load(os.path.join(GOLD, 'datasets.npz'))          # make_fixtures.py case_datasets: reference data.py outputs
     X, lab = data.make_pinwheel_data(0.3, 0.05, 5, 200, 0.25)
-    assert np.array_equal(X, g['data']) and np.array_equal(lab, g['labels'])
+    assert np.array_equal(X, g['pinwheel_data']) and np.array_equal(lab, g['pinwheel_labels'])
+
+
+def test_loaders_split_scaling_match_reference_make_minibatch():
+    """load_dataset + split_and_scale (and make_minibatch(size_minibatch=-1), the form gmm.py:316 / smm.py:285 /
+    vae.py:363 call) reproduce what the reference's data.make_minibatch returned for every table dataset, incl. the
+    Auto set of BASELINE configs[3] (392 rows x 6 features, standardised x5) and noisy-pinwheel, whose perturbation
+    touches the TRAINING rows only (data.py:108-109)."""
+    g = np.load(os.path.join(GOLD, 'datasets.npz'))
+    for ds in ('auto', 'aggregation', 'geyser', 'pinwheel', 'noisy-pinwheel'):
+        key = ds.replace('-', '_')
+        X, lab = data.load_dataset(ds, DATADIR)
+        X_tr, y_tr, X_te, y_te = data.split_and_scale(ds, X, lab, ratio_tr=0.7, seed_split=0)
+        for got, name in ((X_tr, 'X_tr'), (X_te, 'X_te'), (y_tr, 'y_tr'), (y_te, 'y_te')):
+            want = g[key + '_' + name]
+            assert got.shape == want.shape, (ds, name)
+            assert np.allclose(got, want.astype(np.float32), rtol=1e-6, atol=1e-6), (ds, name)
+        full = data.make_minibatch(ds, ratio_tr=0.7, path_datadir=DATADIR, size_minibatch=-1, device='cpu')
+        assert np.allclose(full[0].numpy(), g[key + '_X_tr'], rtol=1e-6, atol=1e-6)
+        assert np.allclose(full[1].numpy(), g[key + '_y_tr']) and np.allclose(full[3].numpy(), g[key + '_y_te'])
+    assert g['auto_X_tr'].shape == (274, 6) and g['auto_X_te'].shape == (118, 6)
+    assert np.array_equal(g['noisy_pinwheel_X_te'], g['pinwheel_X_te'])            # the test split stays clean
+    assert (np.abs(g['noisy_pinwheel_X_tr'] - g['pinwheel_X_tr']).sum(1) > 0).sum() == 69
+    assert np.array_equal(data.perturb_data(g['perturb_in'].copy(), 0.25, 1.0, 3.0, seed=7), g['perturb_out'])
 
 
 def test_split_and_minibatches():
@@ -45,9 +71,39 @@ def test_device_minibatches_follow_the_same_stream():
 
 
 def test_make_minibatch_and_perturb_data():
+    import pytest
+    import torch
     y_tr, lbl_tr, y_te, lbl_te = data.make_minibatch('noisy-pinwheel', size_minibatch=50, device='cpu')
-    b = next(y_tr)
-    assert tuple(b.shape) == (50, 2) and tuple(y_te.shape) == (301, 2) and tuple(lbl_te.shape) == (301, 5)
+    b, lb = next(y_tr), next(lbl_tr)
+    assert tuple(b.shape) == (50, 2) and tuple(lb.shape) == (50, 5)
+    assert tuple(y_te.shape) == (301, 2) and tuple(lbl_te.shape) == (301, 5)
+    # rows and labels come off the same shuffled stream: each batch row sits in the training set next to its label
+    full_x, full_l, _, _ = data.make_minibatch('noisy-pinwheel', size_minibatch=-1, device='cpu')
+    for row, l in zip(b, lb):
+        i = int((full_x == row).all(1).nonzero()[0, 0])
+        assert torch.equal(full_l[i], l)
     x = np.zeros((100, 3))
     xp = data.perturb_data(x, noise_ratio=0.2, seed=4)
     assert (np.abs(xp).sum(1) > 0).sum() == 20
+    with pytest.raises(ValueError):
+        next(data.make_minibatch('pinwheel', size_minibatch=700, device='cpu')[0])      # more than the 699 rows
+    # towers (data.py:174-175): contiguous equal splits of every minibatch; one process per GPU keeps its own
+    towers = next(data.make_minibatch('pinwheel', size_minibatch=48, nb_towers=4, device='cpu')[0])
+    whole = next(data.make_minibatch('pinwheel', size_minibatch=48, device='cpu')[0])
+    assert len(towers) == 4 and torch.equal(torch.cat(towers), whole)
+    mine = next(data.make_minibatch('pinwheel', size_minibatch=48, nb_towers=4, rank=2, device='cpu')[0])
+    assert torch.equal(mine, whole[24:36])
+    X = torch.arange(80, dtype=torch.float32).reshape(40, 2)
+    parts = [next(data.minibatches_device(X, 12, seed=5, rank=r, world=3)) for r in range(3)]
+    assert torch.equal(torch.cat(parts), next(data.minibatches_device(X, 12, seed=5)))
+
+
+def test_average_gradients_mirror():
+    """helpers/tf_utils.average_gradients (reference tf_utils.py:52-87): mean over towers, variable of the first."""
+    import torch
+    from vmp_for_svae_amd.helpers import tf_utils
+    v1, v2 = torch.zeros(2, 3), torch.zeros(4)
+    towers = [[(torch.full((2, 3), float(t + 1)), v1), (torch.arange(4.) * (t + 1), v2)] for t in range(3)]
+    out = tf_utils.average_gradients(towers)
+    assert out[0][1] is v1 and out[1][1] is v2
+    assert torch.equal(out[0][0], torch.full((2, 3), 2.0)) and torch.equal(out[1][0], torch.arange(4.) * 2)

@@ -1,0 +1,134 @@
+"""Parity AT THE SIZES THE NORTH-STAR QUOTES (BASELINE.json configs[2] / configs[4]: N=1e6, D=8, K=16), not only through
+size-independent properties: the HIP path against the fp64 oracle evaluated in row chunks (oracle/mixtures.py
+*_chunked: the same two-pass update as the golden-pinned literal functions; tests/test_oracle_golden.py checks that).
+
+    T1  3 free-running VMP iterations, GMM and SMM:  |r - r*| <= 1e-5 absolute, theta <= 1e-5 relative
+    T3  one SVAE training step at N=65536, L=8, K=16, S=10, U=50: ELBO <= 1e-5 relative, r <= 1e-5 absolute, theta*,
+        and all 21 gradients against the oracle's chunked autograd (experiments.py:196-267 with 32 towers)
+
+The achieved errors are written to gpurun_out/r02_parity_errors.json (tests/parity_log.py)."""
+import numpy as np
+import pytest
+import torch
+
+import parity_log
+
+pytestmark = pytest.mark.gpu
+
+N1, D1, K1 = 1_000_000, 8, 16
+
+
+def _synth(N, D, K, seed):
+    """bench.py's generator: centres ~ N(0, 25 I), uniform labels, unit covariance, r0 = softmax(3 N(0,1))."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    c = rng.standard_normal((K, D)) * 5.0
+    z = rng.integers(0, K, size=N)
+    x = (c[z] + rng.standard_normal((N, D), dtype=np.float32)).astype(np.float32)
+    r0 = np.exp(3.0 * rng.standard_normal((N, K), dtype=np.float32))
+    r0 = (r0 / r0.sum(1, keepdims=True)).astype(np.float32)
+    return x, r0
+
+
+def _abs(got, want, tol, what):
+    e = (got.detach().double().cpu() - want).abs().max().item()
+    parity_log.record('abs', e, tol, what)
+    return e
+
+
+def _rel(got, want, tol, what):
+    e = ((got.detach().double().cpu() - want).abs().max() / want.abs().max().clamp_min(1e-300)).item()
+    parity_log.record('rel', e, tol, what)
+    return e
+
+
+@pytest.mark.parametrize('flavour', ['gmm', 'smm'])
+def test_t1_three_iterations_at_1e6_vs_chunked_oracle(flavour):
+    from oracle import mixtures
+    from vmp_for_svae_amd import _lib as L
+    from vmp_for_svae_amd.models import _mix
+    x, r0 = _synth(N1, D1, K1, seed=0)
+    xo, ro = torch.as_tensor(x).double(), torch.as_tensor(r0).double()
+    uo = torch.ones_like(ro)
+    xd, rd = torch.as_tensor(x).cuda(), torch.as_tensor(r0).cuda()
+    if flavour == 'gmm':
+        loop = _mix.VMPLoop(xd, rd, L.VMP_GMM)
+    else:
+        loop = _mix.VMPLoop(xd, rd, L.VMP_SMM, kappa=torch.full((K1,), 5.0, device='cuda'))
+    for it in range(3):
+        r = loop.step()
+        if flavour == 'gmm':
+            ro, _, th_o, _ = mixtures.gmm_inference_step_chunked(xo, ro)
+        else:
+            ro, uo, th_o, _ = mixtures.smm_inference_step_chunked(xo, ro, uo, 5.0)
+        e_r = _abs(r, ro, 1e-5, 'r_nk it%d' % it)
+        assert e_r <= 1e-5, (flavour, it, 'r', e_r)
+        if flavour == 'smm':
+            e_u = _rel(loop.u, uo, 1e-5, 'u_nk it%d' % it)
+            assert e_u <= 1e-5, (flavour, it, 'u', e_u)
+        for n_, t, o in zip(('alpha', 'beta', 'm', 'C', 'v'), loop.theta(), th_o):
+            e = _rel(t, o, 1e-5, '%s it%d' % (n_, it))
+            assert e <= 1e-5, (flavour, it, n_, e)
+
+
+def _svae_problem(N, K, Ld, S, Dy, U, seed, wstd=0.1):
+    from oracle import nets
+    rng = np.random.Generator(np.random.PCG64(seed))
+    c = rng.standard_normal((K, Dy)) * 2.0
+    y = (c[rng.integers(0, K, size=N)] + 0.5 * rng.standard_normal((N, Dy))).astype(np.float32)
+    w = {}
+    for scope, din, dout in (('encoder_net', Dy, Ld), ('decoder_net', Ld, Dy)):
+        shapes = {'layer_0/kernel': (din, U), 'layer_0/bias': (U,), 'layer_1/kernel': (U, U), 'layer_1/bias': (U,),
+                  'gaussian_output/kernel': (U, 2 * dout), 'gaussian_output/bias': (2 * dout,), 'shortcut/b1': (dout,),
+                  'shortcut/b2': (dout,)}
+        for n_, shp in shapes.items():
+            w[scope + '/' + n_] = (rng.standard_normal(shp) * wstd).astype(np.float32)
+        w[scope + '/shortcut/W'] = nets.rand_partial_isometry(din, dout, 1., 0).astype(np.float32)
+    m_unif = rng.random((K, Ld)).astype(np.float32)
+    pi_norm = rng.standard_normal(K).astype(np.float32)
+    Lk_low = np.tril(rng.standard_normal((K, Ld, Ld)) * 0.2, -1).astype(np.float32)
+    return y, w, m_unif, pi_norm, Lk_low
+
+
+def test_t3_training_step_at_65536_vs_chunked_oracle():
+    from oracle import nets, svae_ref, train_ref
+    from vmp_for_svae_amd.models import vae
+    from vmp_for_svae_amd.training import SVAETrainer
+    N, K, Ld, S, Dy, U = 65536, 16, 8, 10, 8, 50
+    towers = 32                                                      # oracle: 2048-row chunks
+    y, w, m_unif, pi_norm, Lk_low = _svae_problem(N, K, Ld, S, Dy, U, seed=3)
+    g = torch.Generator(device='cuda').manual_seed(11)
+    noise = torch.randn(N, K, Ld, S, device='cuda', generator=g)
+    zd = torch.randint(0, K, (N, S), device='cuda', generator=g)
+    vae.reset_variables()
+    for n_, v in w.items():
+        vae.VARIABLES[n_] = torch.nn.Parameter(torch.as_tensor(v).cuda())
+    tr = SVAETrainer(K, Ld, U, Dy, nb_samples=S, m_uniform=torch.as_tensor(m_unif).cuda(), pi_normal=torch.as_tensor(pi_norm).cuda())
+    with torch.no_grad():
+        tr.phi_gmm[1].add_(torch.as_tensor(Lk_low).cuda())
+    out = tr.step(torch.as_tensor(y).cuda(), noise=noise, z_draws=zd)
+    torch.cuda.synchronize()
+
+    T = lambda a: torch.as_tensor(a).double()
+    prior, theta = svae_ref.init_mm(K, Ld, T(m_unif), torch.float64)
+    phi = list(svae_ref.init_recognition_params(theta, T(pi_norm)))
+    phi[1] = phi[1] + T(Lk_low)
+    st = train_ref.State(phi, {n_: T(w['encoder_net/' + n_]) for n_ in nets.NET_VARS},
+                         {n_: T(w['decoder_net/' + n_]) for n_ in nets.NET_VARS}, theta, prior)
+    ref = train_ref.train_step(st, T(y), noise.cpu().double(), zd.cpu(), 3e-4, 0.2, 0.95, towers=towers)
+    e = abs(out['elbo'].item() - ref['elbo'].item()) / abs(ref['elbo'].item())
+    parity_log.record('rel', e, 1e-5, 'elbo')
+    assert e <= 1e-5, ('elbo', e, out['elbo'].item(), ref['elbo'].item())
+    e_r = _abs(torch.exp(out['log_z']), torch.exp(ref['log_z']), 1e-5, 'r_nk')
+    assert e_r <= 1e-5, ('r', e_r)
+    det = ref['details']
+    for i, key in ((0, 'neg_rec_err'), (3, 'regulariser')):
+        e = abs(out[key].item() - det[i].item()) / abs(det[i].item())
+        parity_log.record('rel', e, 2e-5, key)
+        assert e <= 2e-5, (key, e)
+    assert _rel(out['x_samples'], ref['x_samples'], 1e-5, 'x_samples') <= 1e-5
+    for n_, ts, o in zip(('alpha', 'A', 'b', 'beta', 'vhat'), out['theta_star'], ref['theta_star']):
+        e = _rel(ts, o, 1e-5, 'theta_star ' + n_)
+        assert e <= 1e-5, (n_, e)
+    for n_, gr in ref['grads'].items():                           # the oracle AVERAGES over towers (tf_utils.py:79)
+        e = _rel(out['grads'][n_], gr * towers, 1e-4, 'grad ' + n_)
+        assert e <= 1e-4, (n_, e)

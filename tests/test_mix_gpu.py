@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+import parity_log
+
 pytestmark = pytest.mark.gpu
 
 RTOL, ATOL_R = 1e-5, 1e-5
@@ -19,11 +21,11 @@ def dev(a, dtype=torch.float32):
 def relerr(got, want):
     want = np.asarray(want, dtype=np.float64)
     got = got.detach().double().cpu().numpy()
-    return np.abs(got - want).max() / max(np.abs(want).max(), 1e-300)
+    return parity_log.record('rel', np.abs(got - want).max() / max(np.abs(want).max(), 1e-300))
 
 
 def abserr(got, want):
-    return np.abs(got.detach().double().cpu().numpy() - np.asarray(want, dtype=np.float64)).max()
+    return parity_log.record('abs', np.abs(got.detach().double().cpu().numpy() - np.asarray(want, dtype=np.float64)).max())
 
 
 def bar(g, key, base, rel=True):

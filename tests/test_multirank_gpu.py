@@ -1,0 +1,200 @@
+"""The multi-rank step functions EXECUTED with more than one rank: two child processes share the GPU,
+each runs the HIP kernels on its row shard through DistributedVMPLoop.step / SVAETrainer.step / experiments.run, the
+single packed all-reduce of a step goes through torch.distributed (gloo rendezvous; the buffer is staged through the
+host) - and the outcome must equal the single-process result on the concatenated rows (T1) resp. the reference's
+tower semantics (T3: ELBO summed, gradients AVERAGED over towers - helpers/tf_utils.py:52-87, experiments.py:247-260;
+oracle: train_ref.train_step(towers=2), fp64).  Also: the C ABI's own RCCL communicator (vmp_pack_allreduce)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import parity_log
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NET_VARS = ('layer_0/kernel', 'layer_0/bias', 'layer_1/kernel', 'layer_1/bias', 'gaussian_output/kernel',
+            'gaussian_output/bias', 'shortcut/W', 'shortcut/b1', 'shortcut/b2')
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _payload(path):
+    from oracle import nets
+    rng = np.random.Generator(np.random.PCG64(42))
+    N, D, K = 30011, 8, 16
+    c = rng.standard_normal((K, D)) * 5
+    x = (c[rng.integers(0, K, N)] + rng.standard_normal((N, D))).astype(np.float32)
+    r0 = np.exp(3 * rng.standard_normal((N, K)))
+    r0 = (r0 / r0.sum(1, keepdims=True)).astype(np.float32)
+    Nb, K3, Ld, S, Dy, U = 64, 10, 6, 10, 6, 50
+    cy = rng.standard_normal((K3, Dy)) * 2
+    y = (cy[rng.integers(0, K3, Nb)] + 0.5 * rng.standard_normal((Nb, Dy))).astype(np.float32)
+    p = dict(t1_x=x, t1_r0=r0, t3_dims=np.array([Nb, K3, Ld, S, Dy, U]), t3_y=y,
+             t3_m_unif=rng.random((K3, Ld)).astype(np.float32), t3_pi_norm=rng.standard_normal(K3).astype(np.float32),
+             t3_Lk_low=np.tril(rng.standard_normal((K3, Ld, Ld)) * 0.3, -1).astype(np.float32),
+             t3_noise=rng.standard_normal((2, Nb, K3, Ld, S)).astype(np.float32),
+             t3_zd=rng.integers(0, K3, size=(2, Nb, S)))
+    for scope, din, dout in (('encoder_net', Dy, Ld), ('decoder_net', Ld, Dy)):
+        shapes = {'layer_0/kernel': (din, U), 'layer_0/bias': (U,), 'layer_1/kernel': (U, U), 'layer_1/bias': (U,),
+                  'gaussian_output/kernel': (U, 2 * dout), 'gaussian_output/bias': (2 * dout,), 'shortcut/b1': (dout,),
+                  'shortcut/b2': (dout,)}
+        for n_, shp in shapes.items():
+            p['w_%s/%s' % (scope, n_)] = (rng.standard_normal(shp) * 0.3).astype(np.float32)
+        p['w_%s/shortcut/W' % scope] = nets.rand_partial_isometry(din, dout, 1., 0).astype(np.float32)
+    np.savez(path, **p)
+    return p
+
+
+@pytest.fixture(scope='module')
+def two_ranks(tmp_path_factory):
+    d = tmp_path_factory.mktemp('multirank')
+    payload = str(d / 'payload.npz')
+    p = _payload(payload)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'multirank_worker.py'), payload, str(d)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for pr in procs:
+        try:
+            o, _ = pr.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            o, _ = pr.communicate()
+        outs.append(o.decode(errors='replace'))
+    assert all(pr.returncode == 0 for pr in procs), '\n'.join(o[-3000:] for o in outs)
+    return p, [np.load(str(d / ('rank%d.npz' % r))) for r in range(2)]
+
+
+def _rel(got, want, what, tol):
+    want = np.asarray(want, dtype=np.float64)
+    e = np.abs(np.asarray(got, dtype=np.float64) - want).max() / max(np.abs(want).max(), 1e-300)
+    parity_log.record('rel', e, tol, what)
+    return e
+
+
+def test_distributed_vmp_loop_two_ranks_equals_single_process(two_ranks):
+    from vmp_for_svae_amd import _lib as L
+    from vmp_for_svae_amd.models import _mix
+    p, ranks = two_ranks
+    x, r0 = torch.as_tensor(p['t1_x']).cuda(), torch.as_tensor(p['t1_r0']).cuda()
+    for name, flav in (('gmm', L.VMP_GMM), ('smm', L.VMP_SMM)):
+        kap = torch.full((r0.shape[1],), 5.0, device='cuda') if flav == L.VMP_SMM else None
+        loop = _mix.VMPLoop(x, r0, flav, kappa=kap)
+        for _ in range(3):
+            r = loop.step()
+        r_dist = np.concatenate([ranks[0]['t1_%s_r' % name], ranks[1]['t1_%s_r' % name]])
+        assert r_dist.shape == tuple(r.shape)
+        e = np.abs(r_dist - r.cpu().numpy()).max()
+        parity_log.record('abs', e, 2e-6, name + ' r')
+        assert e <= 2e-6, (name, e)
+        for n_, t in zip(('alpha', 'beta', 'm', 'C', 'v'), loop.theta()):
+            for rk in ranks:
+                assert _rel(rk['t1_%s_%s' % (name, n_)], t.cpu().numpy(), '%s %s' % (name, n_), 2e-6) <= 2e-6, (name, n_)
+            assert np.array_equal(ranks[0]['t1_%s_%s' % (name, n_)], ranks[1]['t1_%s_%s' % (name, n_)])   # replicas agree bitwise
+
+
+def test_svae_trainer_two_ranks_follows_tower_semantics(two_ranks):
+    from oracle import nets, svae_ref, train_ref
+    p, ranks = two_ranks
+    Nb, K, Ld, S, Dy, U = [int(v) for v in p['t3_dims']]
+    T = lambda a: torch.as_tensor(np.asarray(a)).double()
+    prior, theta = svae_ref.init_mm(K, Ld, T(p['t3_m_unif']), torch.float64)
+    phi = list(svae_ref.init_recognition_params(theta, T(p['t3_pi_norm'])))
+    phi[1] = phi[1] + T(p['t3_Lk_low'])
+    st = train_ref.State(phi, {n_: T(p['w_encoder_net/' + n_]) for n_ in NET_VARS},
+                         {n_: T(p['w_decoder_net/' + n_]) for n_ in NET_VARS}, theta, prior)
+    for it in range(2):
+        ref = train_ref.train_step(st, T(p['t3_y']), T(p['t3_noise'][it]), torch.as_tensor(p['t3_zd'][it]), 3e-4, 0.2, 0.95,
+                                   towers=2)
+        slack = 1 + 2 * it
+        for rk in ranks:
+            e = abs(float(rk['t3_elbo%d' % it]) - ref['elbo'].item()) / abs(ref['elbo'].item())
+            parity_log.record('rel', e, slack * 2e-5, 'elbo')
+            assert e <= slack * 2e-5, (it, e)
+            for n_, g in ref['grads'].items():                       # averaged over the two towers on both sides
+                assert _rel(rk['t3_grad%d_%s' % (it, n_)], g.numpy(), 'grad ' + n_, slack * 1e-4) <= slack * 1e-4, (it, n_)
+            for n_, ts in zip(('alpha', 'A', 'b', 'beta', 'vhat'), ref['theta_star']):
+                assert _rel(rk['t3_theta_star%d_%s' % (it, n_)], ts.numpy(), 'theta* ' + n_, slack * 2e-5) <= slack * 2e-5
+    names, params = st.trainables()
+    for rk in ranks:
+        for n_, t in zip(names, params):
+            assert _rel(rk['t3_param_' + n_], t.detach().numpy(), 'param ' + n_, 1e-4) <= 1e-4, n_
+        for n_, t in zip(('alpha', 'A', 'b', 'beta', 'vhat'), st.theta):
+            assert _rel(rk['t3_theta_' + n_], t.numpy(), 'theta ' + n_, 1e-4) <= 1e-4, n_
+    for k in ranks[0].files:
+        if k.startswith('t3_param_') or k.startswith('t3_theta_'):
+            assert np.array_equal(ranks[0][k], ranks[1][k]), k              # every rank applied the identical update
+
+
+def test_two_rank_step_equals_single_process_step_on_the_whole_minibatch(two_ranks):
+    """ELBO and moments are SUMS over towers, gradients MEANS: 2 x the 2-rank gradient = the 1-process gradient."""
+    from vmp_for_svae_amd.models import vae
+    from vmp_for_svae_amd.training import SVAETrainer
+    p, ranks = two_ranks
+    Nb, K, Ld, S, Dy, U = [int(v) for v in p['t3_dims']]
+    dev = lambda a, dt=torch.float32: torch.as_tensor(np.asarray(a)).to('cuda', dt)
+    vae.reset_variables()
+    for k in p:
+        if k.startswith('w_'):
+            vae.VARIABLES[k[2:]] = torch.nn.Parameter(dev(p[k]))
+    tr = SVAETrainer(K, Ld, U, Dy, nb_samples=S, m_uniform=dev(p['t3_m_unif']), pi_normal=dev(p['t3_pi_norm']))
+    with torch.no_grad():
+        tr.phi_gmm[1].add_(dev(p['t3_Lk_low']))
+    out = tr.step(dev(p['t3_y']), noise=dev(p['t3_noise'][0]), z_draws=dev(p['t3_zd'][0], torch.int64))
+    rk = ranks[0]
+    assert abs(float(rk['t3_elbo0']) - out['elbo'].item()) <= 2e-6 * abs(out['elbo'].item())
+    for n_, g in out['grads'].items():
+        assert _rel(2.0 * rk['t3_grad0_' + n_], g.cpu().numpy(), 'grad x2 ' + n_, 2e-5) <= 2e-5, n_
+    for n_, ts in zip(('alpha', 'A', 'b', 'beta', 'vhat'), out['theta_star']):
+        assert _rel(rk['t3_theta_star0_' + n_], ts.cpu().numpy(), 'theta* ' + n_, 2e-6) <= 2e-6, n_
+
+
+def test_driver_run_shards_minibatches_and_keeps_replicas_identical(two_ranks):
+    _, ranks = two_ranks
+    assert np.array_equal(ranks[0]['run_params'], ranks[1]['run_params'])
+    assert np.array_equal(ranks[0]['run_theta'], ranks[1]['run_theta'])
+    assert np.isfinite(ranks[0]['run_params']).all() and np.isfinite(float(ranks[0]['run_elbo']))
+    assert float(ranks[0]['run_elbo']) == float(ranks[1]['run_elbo'])          # the all-reduced ELBO, not a per-shard one
+
+
+def test_c_abi_rccl_communicator_single_rank():
+    """vmp_comm_* + vmp_pack_allreduce (the exchange a non-torch host binds): a 1-rank RCCL communicator leaves the packed
+    buffer unchanged, and DistributedVMPLoop driven through it reproduces the plain loop."""
+    from vmp_for_svae_amd import _lib as L
+    from vmp_for_svae_amd.models import _mix
+    from vmp_for_svae_amd.models.parallel_mix import DistributedVMPLoop, PackComm
+    uid = PackComm.unique_id()
+    assert len(uid) == 128
+    comm = PackComm(1, 0, uid)
+    try:
+        buf = torch.arange(1000, dtype=torch.float64, device='cuda') * 0.5
+        want = buf.clone()
+        comm.allreduce_(buf)
+        torch.cuda.synchronize()
+        assert torch.equal(buf, want)
+        rng = np.random.Generator(np.random.PCG64(8))
+        x = torch.as_tensor((rng.standard_normal((20000, 8)) * 3).astype(np.float32)).cuda()
+        r0 = torch.softmax(torch.as_tensor(rng.standard_normal((20000, 16)).astype(np.float32)).cuda(), 1)
+        a, b = _mix.VMPLoop(x, r0, L.VMP_GMM), DistributedVMPLoop(x, r0, L.VMP_GMM, comm=comm)
+        for _ in range(3):
+            ra, rb = a.step(), b.step()
+        assert (ra - rb).abs().max().item() < 1e-6
+        with pytest.raises(L.VmpError):
+            comm.allreduce_(torch.zeros(4, device='cuda'))              # fp32: refused
+    finally:
+        comm.close()

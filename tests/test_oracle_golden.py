@@ -1,5 +1,7 @@
 """The oracle (oracle/*.py) against the golden vectors produced by executing the reference's own
 functions (tests/golden/make_fixtures.py), plus independent known-answer checks.  CPU only."""
+import os
+
 import numpy as np
 import pytest
 import scipy.special
@@ -9,6 +11,7 @@ import torch
 from oracle import dists, metrics, mixtures, nets, svae_ref, train_ref
 
 F64_RTOL = 1e-9
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
 def T(a, dtype=torch.float64):
@@ -118,7 +121,7 @@ def _svae_state(g, dtype, suf=''):
     return train_ref.State(phi, enc, dec, theta, prior, smm=bool(smm)), (N, K, L, S, Dy, U, steps, smm)
 
 
-@pytest.mark.parametrize('case', ['svae_tiny', 'svae_paper', 'svae_c1', 'svae_l8', 'svae_smm_tiny', 'svae_smm_l8'])
+@pytest.mark.parametrize('case', ['svae_tiny', 'svae_paper', 'svae_c1', 'svae_l8', 'svae_smm_tiny', 'svae_smm_l8', 'svae_auto'])
 def test_svae_init_matches_reference(golden, case):
     g = golden(case)
     st, dims = _svae_state(g, torch.float64)
@@ -133,7 +136,7 @@ def test_svae_init_matches_reference(golden, case):
             close(p_, g['prior_' + n_]), close(t_, g['theta_init_' + n_])
 
 
-@pytest.mark.parametrize('case', ['svae_tiny', 'svae_paper', 'svae_c1', 'svae_l8', 'svae_smm_tiny', 'svae_smm_l8'])
+@pytest.mark.parametrize('case', ['svae_tiny', 'svae_paper', 'svae_c1', 'svae_l8', 'svae_smm_tiny', 'svae_smm_l8', 'svae_auto'])
 @pytest.mark.parametrize('dtype,suf,rtol', [(torch.float64, '', 1e-8), (torch.float32, '__f32', 2e-3)])
 def test_svae_training_steps(golden, case, dtype, suf, rtol):
     """Full training steps (inference, ELBO, 21/23 gradients, CVI update, TF-Adam) vs the reference run."""
@@ -146,10 +149,12 @@ def test_svae_training_steps(golden, case, dtype, suf, rtol):
         # forward pieces first (before the step mutates the state)
         y_rec, phi_enc, x_k, x_s, log_z, _, phi_tilde = svae_ref.inference(y, st.phi_gmm, st.enc_w, st.dec_w, noise, zd)
         close(phi_enc[0], g[pre + 'enc_eta1' + suf], rtol), close(phi_enc[1], g[pre + 'enc_eta2' + suf], rtol)
-        close(x_k, g[pre + 'x_k' + suf], rtol), close(x_s, g[pre + 'x_s' + suf], rtol)
+        if pre + 'x_k' + suf in g.files:                      # slim fixtures (svae_auto) hold x_k / x_s in fp64 only
+            close(x_k, g[pre + 'x_k' + suf], rtol), close(x_s, g[pre + 'x_s' + suf], rtol)
         close(torch.exp(log_z), np.exp(g[pre + 'log_z' + suf]), atol=max(rtol * 0.1, 1e-10), what='r_nk')
-        close(y_rec[0], g[pre + 'rec_mean' + suf], rtol), close(y_rec[1], g[pre + 'rec_var' + suf], rtol)
-        close(phi_tilde[0], g[pre + 'phi_tilde_eta1' + suf], rtol), close(phi_tilde[1], g[pre + 'phi_tilde_eta2' + suf], rtol)
+        if pre + 'rec_mean' + suf in g.files:
+            close(y_rec[0], g[pre + 'rec_mean' + suf], rtol), close(y_rec[1], g[pre + 'rec_var' + suf], rtol)
+            close(phi_tilde[0], g[pre + 'phi_tilde_eta1' + suf], rtol), close(phi_tilde[1], g[pre + 'phi_tilde_eta2' + suf], rtol)
         out = train_ref.train_step(st, y, noise, zd, float(g['in_lr']), float(g['in_lrcvi']), float(g['in_decay']))
         close(out['elbo'], g[pre + 'elbo' + suf], rtol, what='elbo')
         close(out['details'], g[pre + 'details' + suf], rtol, what='details')
@@ -166,6 +171,35 @@ def test_svae_training_steps(golden, case, dtype, suf, rtol):
             for n_, ts, t_ in zip(('alpha', 'A', 'b', 'beta', 'vhat'), out['theta_star'], st.theta):
                 close(ts, g[pre + 'theta_star_' + n_ + suf], rtol, what='theta* ' + n_)
                 close(t_, g[pre + 'theta_' + n_ + suf], rtol, what='theta ' + n_)
+
+
+def test_auto_fixture_is_the_auto_minibatch():
+    """BASELINE configs[3]: svae_auto trains on 64 rows of the Auto training split the reference's loader produced."""
+    g, d = np.load(os.path.join(GOLDEN_DIR, 'svae_auto.npz')), np.load(os.path.join(GOLDEN_DIR, 'datasets.npz'))
+    assert [int(v) for v in g['in_dims'][:6]] == [64, 10, 8, 10, 6, 50]
+    X = d['auto_X_tr'].astype(np.float32)
+    assert all((X == row.astype(np.float32)).all(1).any() for row in g['in_y'])
+
+
+@pytest.mark.parametrize('chunk', [100, 257])
+def test_chunked_mixture_steps_equal_the_literal_ones(golden, chunk):
+    """The N-chunked evaluation used for the N=1e6 GPU parity tests is the same two-pass update."""
+    g = golden('gmm_d8k16')
+    x, r = T(g['in_x'], torch.float64), T(g['in_r0'], torch.float64)
+    u = torch.ones_like(r)
+    for it in range(3):
+        a, b = mixtures.gmm_inference_step(x, r), mixtures.gmm_inference_step_chunked(x, r, chunk)
+        close(b[0], a[0].numpy(), atol=1e-11)
+        for p, q in zip(a[2], b[2]):
+            close(q, p.numpy(), 1e-12)
+        close(b[0], g['gmm%d_r' % it], atol=1e-10)
+        r = a[0]
+    r = T(g['in_r0'], torch.float64)
+    for it in range(3):
+        a, b = mixtures.smm_inference_step(x, r, u, 5.0), mixtures.smm_inference_step_chunked(x, r, u, 5.0, chunk)
+        close(b[0], a[0].numpy(), atol=1e-11), close(b[1], a[1].numpy(), 1e-12)
+        close(b[0], g['smm%d_r' % it], atol=1e-10)
+        r, u = a[0], a[1]
 
 
 def test_towers_average_gradients(golden):

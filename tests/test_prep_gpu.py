@@ -8,12 +8,14 @@ import numpy as np
 import pytest
 import torch
 
+import parity_log
+
 pytestmark = pytest.mark.gpu
 
 
 def relerr(got, want):
     want = want.detach().double().cpu()
-    return ((got.detach().double().cpu() - want).abs().max() / want.abs().max().clamp_min(1e-300)).item()
+    return parity_log.record('rel', ((got.detach().double().cpu() - want).abs().max() / want.abs().max().clamp_min(1e-300)).item())
 
 
 @pytest.mark.parametrize('K,Ld', [(5, 2), (10, 6), (16, 8), (1, 1), (64, 3)])

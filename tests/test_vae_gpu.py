@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+import parity_log
+
 pytestmark = pytest.mark.gpu
 
 
@@ -15,7 +17,7 @@ def dev(a, dtype=torch.float32):
 def rel(got, want):
     want = np.asarray(want, dtype=np.float64)
     got = got.detach().double().cpu().numpy()
-    return np.abs(got - want).max() / max(np.abs(want).max(), 1e-300)
+    return parity_log.record('rel', np.abs(got - want).max() / max(np.abs(want).max(), 1e-300))
 
 
 def load_net(g, scope, prefix):

@@ -56,6 +56,10 @@ _SIGNATURES = {
     'vmp_svae_theta_pack': (_c.c_int, [_P] * 5 + [_c.c_int, _c.c_int] + [_P] * 4),
     'vmp_svae_cvi_update': (_c.c_int, [_P] * 17 + [_c.c_float, _c.c_int, _c.c_int, _P]),
     'vmp_mlp_gauss_bwd': (_c.c_int, [_P] * 12 + [_c.c_int64] + [_c.c_int] * 3 + [_P, _P, _P, _c.c_size_t, _P]),
+    'vmp_comm_unique_id': (_c.c_int, [_P]),
+    'vmp_comm_init_rank': (_c.c_int, [_c.POINTER(_c.c_void_p), _c.c_int, _P, _c.c_int]),
+    'vmp_comm_destroy': (_c.c_int, [_P]),
+    'vmp_pack_allreduce': (_c.c_int, [_P, _P, _c.c_size_t, _P]),
     'vmp_mix_finalize_ws': (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int] + [_P] * 6 + [_P] * 9 + [_P, _P]),
 }
 
@@ -119,8 +123,13 @@ _WS = {}
 
 
 def workspace(device, nbytes):
-    """Per-device scratch buffer owned by the host side (the library never allocates)."""
-    key = (device.type, device.index)
+    """Scratch buffer owned by the host side (the library never allocates), private to the calling (device, stream,
+    host thread): kernels of one stream serialise on it, calls on other streams / from other threads get their own, so
+    the C ABI's "callable concurrently from any host thread" holds through this layer as well.  A buffer that has to grow
+    is replaced; the old one is released to torch's stream-ordered caching allocator (same stream: safe)."""
+    import threading
+    sid = torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0
+    key = (device.type, device.index, sid, threading.get_ident())
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

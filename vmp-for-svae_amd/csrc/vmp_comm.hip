@@ -1,0 +1,92 @@
+// Multi-GPU exchange of the C ABI: one in-place all-reduce(sum) of the packed fp64 buffer over RCCL (xGMI inside a
+// node).  Reference: the tower gather + M-step on the parameter device (experiments.py:247-260) and the gradient
+// mean (helpers/tf_utils.py:52-87) - here every rank sums the same packed buffer and applies the identical update.
+// RCCL is bound at run time with dlopen/dlsym: a torch process already carries an RCCL (soname librccl.so.1) and a
+// second, link-time copy must not be pulled in next to it; single-GPU hosts never load it at all.
+#include "vmp_common.h"
+#include <dlfcn.h>
+#include <string.h>
+#include <rccl/rccl.h>
+#include <mutex>
+
+using namespace vmp;
+
+namespace {
+
+struct Rccl {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+Rccl g_rccl;
+std::once_flag g_once;
+
+void load_rccl() {
+    void* h = nullptr;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return;
+    g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllReduce;
+}
+
+int need_rccl(const char* who) {
+    std::call_once(g_once, load_rccl);
+    if (!g_rccl.ok) { set_error("%s: RCCL (librccl.so.1) could not be loaded: %s", who, dlerror() ? dlerror() : "missing symbols"); return VMP_E_BADARG; }
+    return 0;
+}
+
+int rccl_status(ncclResult_t r, const char* who) {
+    if (r == ncclSuccess) return 0;
+    set_error("%s: RCCL error %d (%s)", who, (int)r, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    return (int)r > 0 ? (int)r : 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vmp_comm_unique_id(void* id_out) {
+    static_assert(sizeof(ncclUniqueId) == VMP_COMM_ID_BYTES, "RCCL unique id size");
+    if (!id_out) { set_error("vmp_comm_unique_id: null pointer"); return VMP_E_BADARG; }
+    if (int rc = need_rccl("vmp_comm_unique_id")) return rc;
+    return rccl_status(g_rccl.GetUniqueId(static_cast<ncclUniqueId*>(id_out)), "vmp_comm_unique_id");
+}
+
+int vmp_comm_init_rank(void** comm_out, int nranks, const void* id, int rank) {
+    if (!comm_out || !id || nranks < 1 || rank < 0 || rank >= nranks) { set_error("vmp_comm_init_rank: bad argument"); return VMP_E_BADARG; }
+    if (int rc = need_rccl("vmp_comm_init_rank")) return rc;
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    ncclComm_t c = nullptr;
+    int rc = rccl_status(g_rccl.CommInitRank(&c, nranks, uid, rank), "vmp_comm_init_rank");
+    *comm_out = c;
+    return rc;
+}
+
+int vmp_comm_destroy(void* comm) {
+    if (!comm) return 0;
+    if (int rc = need_rccl("vmp_comm_destroy")) return rc;
+    return rccl_status(g_rccl.CommDestroy(static_cast<ncclComm_t>(comm)), "vmp_comm_destroy");
+}
+
+int vmp_pack_allreduce(void* comm, double* buf, size_t n, void* stream) {
+    if (!comm || (!buf && n)) { set_error("vmp_pack_allreduce: null pointer"); return VMP_E_BADARG; }
+    if (n == 0) return 0;
+    if (int rc = need_rccl("vmp_pack_allreduce")) return rc;
+    return rccl_status(g_rccl.AllReduce(buf, buf, n, ncclFloat64, ncclSum, static_cast<ncclComm_t>(comm),
+                                        static_cast<hipStream_t>(stream)), "vmp_pack_allreduce");
+}
+
+}  // extern "C"

@@ -44,9 +44,10 @@ def load_dataset(dataset, path_datadir=None):
     raise Exception("Dataset '%s' does not exist." % dataset)
 
 
-def split_and_scale(dataset, data, labels, ratio_tr=0.7, seed_split=0):
-    """data.py:82-120: sklearn train_test_split; 'auto' is standardised and scaled by 5, pinwheel is left as is,
-    everything else is standardised.  Returns (X_tr, y_tr, X_te, y_te) with one-hot labels (or None)."""
+def split_and_scale(dataset, data, labels, ratio_tr=0.7, seed_split=0, noise_level=0.1):
+    """data.py:82-120: sklearn train_test_split; 'noisy-pinwheel' perturbs the TRAINING rows only, after the split, with
+    seed=seed_split (data.py:108-109); 'auto' is standardised and scaled by 5, pinwheel is left as is, everything else is
+    standardised.  Returns (X_tr, y_tr, X_te, y_te) with one-hot labels (or None)."""
     from sklearn.model_selection import train_test_split
     from sklearn.preprocessing import StandardScaler
     onehot = None
@@ -57,6 +58,9 @@ def split_and_scale(dataset, data, labels, ratio_tr=0.7, seed_split=0):
     else:
         X_tr, X_te = train_test_split(data, test_size=1 - ratio_tr, random_state=seed_split)
         y_tr = y_te = None
+    if dataset == 'noisy-pinwheel':
+        X_tr = perturb_data(np.array(X_tr, dtype=np.float64), noise_ratio=noise_level, noise_mean=0, noise_stddev=10,
+                            seed=seed_split)
     if dataset not in ('pinwheel', 'noisy-pinwheel'):
         sc = StandardScaler().fit(X_tr)
         mult = 5.0 if dataset == 'auto' else 1.0
@@ -64,58 +68,101 @@ def split_and_scale(dataset, data, labels, ratio_tr=0.7, seed_split=0):
     return X_tr.astype(np.float32), y_tr, X_te.astype(np.float32), y_te
 
 
-def minibatches(X, size_minibatch, seed=0):
-    """Endless generator of shuffled minibatches (index arrays)."""
+def _epochs(N, size_minibatch, seed):
+    """Endless stream of index arrays: a fresh permutation per epoch, cut into whole minibatches."""
+    if not 0 < size_minibatch <= N:
+        raise ValueError('size_minibatch=%d must be in 1..N=%d' % (size_minibatch, N))
     rng = np.random.Generator(np.random.PCG64(seed))
-    N = X.shape[0]
     while True:
         perm = rng.permutation(N)
         for i in range(0, N - size_minibatch + 1, size_minibatch):
             yield perm[i:i + size_minibatch]
 
 
-def minibatches_device(X_dev, size_minibatch, seed=0):
+def tower_slice(size_minibatch, rank, world):
+    """Rows of a minibatch that tower / rank `rank` of `world` owns: the contiguous equal split of
+    tf.split(m_batch, nb_towers, axis=0) (data.py:174-175)."""
+    if size_minibatch % world:
+        raise ValueError('size_minibatch=%d is not divisible by the %d towers' % (size_minibatch, world))
+    per = size_minibatch // world
+    return slice(rank * per, (rank + 1) * per)
+
+
+def minibatches(X, size_minibatch, seed=0):
+    """Endless generator of shuffled minibatches (index arrays)."""
+    return _epochs(X.shape[0], size_minibatch, seed)
+
+
+def minibatches_device(X_dev, size_minibatch, seed=0, rank=0, world=1):
     """As `minibatches`, but yields the minibatch ROWS gathered on the device: one host-to-device copy of the epoch's
-    permutation instead of one (synchronising) index copy per iteration.  Same permutation stream as `minibatches`."""
+    permutation instead of one (synchronising) index copy per iteration.  Same permutation stream as `minibatches`.
+    With world > 1 every rank draws the SAME stream and keeps its tower_slice of each minibatch."""
     import torch
-    rng = np.random.Generator(np.random.PCG64(seed))
     N = X_dev.shape[0]
+    if not 0 < size_minibatch <= N:
+        raise ValueError('size_minibatch=%d must be in 1..N=%d' % (size_minibatch, N))
+    sl = tower_slice(size_minibatch, rank, world)
+    rng = np.random.Generator(np.random.PCG64(seed))
     while True:
         perm = torch.as_tensor(rng.permutation(N)).to(X_dev.device)
         for i in range(0, N - size_minibatch + 1, size_minibatch):
-            yield X_dev.index_select(0, perm[i:i + size_minibatch])
+            yield X_dev.index_select(0, perm[i:i + size_minibatch][sl])
 
 
 def perturb_data(x, noise_ratio=0.1, noise_mean=0, noise_stddev=10, seed=0):
-    """reference data.py:238-259: a random `noise_ratio` of the rows is REPLACED by N(mean, stddev) noise (in place,
-    same numpy RandomState stream)."""
+    """reference data.py:238-259: int(N * noise_ratio) randomly chosen rows of `x` are overwritten, in place, by
+    N(noise_mean, noise_stddev) draws.  The draws come from numpy's legacy global stream seeded with `seed` (one
+    permutation of the row indices, then one normal block), which is what makes the perturbed set identical to the
+    reference's."""
+    n_rows, n_cols = x.shape
+    n_replaced = int(n_rows * noise_ratio)
     np.random.seed(seed)
-    N, D = x.shape
-    N_noise = int(N * noise_ratio)
-    noise_indices = np.random.permutation(np.arange(N))[:N_noise]
-    x[noise_indices, :] = np.random.normal(loc=noise_mean, scale=noise_stddev, size=(N_noise, D))
+    victims = np.random.permutation(np.arange(n_rows))[:n_replaced]
+    x[victims] = np.random.normal(noise_mean, noise_stddev, (n_replaced, n_cols))
     return x
 
 
 def make_minibatch(dataset, ratio_tr=None, ratio_val=None, binarise=False, path_datadir='../datasets', size_minibatch=128,
                    size_testbatch=-1, nb_towers=1, nb_threads=2, seed_split=0, seed_minibatch=0, dtype=None,
-                   name='data_prep', noise_level=0.1, device='cuda'):
+                   name='data_prep', noise_level=0.1, device='cuda', rank=None):
     """reference data.py:9-176 for the table datasets (pinwheel, noisy-pinwheel, auto, aggregation, geyser):
-    returns (y_tr, lbl_tr, y_te, lbl_te) like the reference, where y_tr is an endless generator of shuffled minibatches
-    gathered on the device (the reference's tf.train.shuffle_batch queue; split over `nb_towers` = ranks is done by the
-    launcher) and y_te / labels are device tensors.  The MNIST-style TFRecord inputs (data.py:13-33,179-213) are not
-    built: there are no such files in this image."""
+    returns (y_tr, lbl_tr, y_te, lbl_te) like the reference.
+      size_minibatch > 0: y_tr and lbl_tr are endless generators over the SAME shuffled stream (the reference's
+        tf.train.shuffle_batch([X_tr, y_tr]) queue, data.py:130-150): the i-th next(lbl_tr) holds the labels of the rows of
+        the i-th next(y_tr);
+      size_minibatch <= 0: the full training tensors (data.py:151-153), as gmm.py:316 / smm.py:285 / vae.py:363 use it.
+    nb_towers > 1 (data.py:174-175): each minibatch is the list of its nb_towers contiguous splits; with `rank` given
+    (one process per GPU) only that tower's split is produced.
+    The MNIST-style TFRecord inputs (data.py:13-33,179-213) are not built: there are no such files in this image."""
     import torch
     if dataset in ('mnist', 'mnist-small', 'fashion') or binarise:
         raise NotImplementedError('TFRecord image datasets are not built')
+    if ratio_val is not None:
+        raise NotImplementedError('validation split (data.py:91-105) is not built')
     data, labels = load_dataset(dataset, path_datadir)
-    if dataset == 'noisy-pinwheel':
-        data = perturb_data(np.array(data, dtype=np.float64), noise_ratio=noise_level)
     X_tr, l_tr, X_te, l_te = split_and_scale(dataset, data, labels, ratio_tr=0.7 if ratio_tr is None else ratio_tr,
-                                             seed_split=seed_split)
+                                             seed_split=seed_split, noise_level=noise_level)
     dev = torch.device(device)
-    Xtr, Xte = torch.as_tensor(X_tr).to(dev), torch.as_tensor(X_te).to(dev)
-    if size_testbatch and size_testbatch > 0:
-        Xte, l_te = Xte[:size_testbatch], (None if l_te is None else l_te[:size_testbatch])
     to_t = lambda a: None if a is None else torch.as_tensor(a, dtype=torch.float32).to(dev)
-    return minibatches_device(Xtr, size_minibatch, seed=seed_minibatch), to_t(l_tr), Xte, to_t(l_te)
+    Xtr, Xte, Ltr, Lte = to_t(X_tr), to_t(X_te), to_t(l_tr), to_t(l_te)
+
+    def stream(T, size, seed):
+        def pick(rows):
+            if nb_towers <= 1:
+                return rows
+            parts = [rows[tower_slice(size, t, nb_towers)] for t in range(nb_towers)]
+            return parts if rank is None else parts[rank]
+        for idx in _epochs(T.shape[0], size, seed):
+            yield pick(T.index_select(0, torch.as_tensor(idx).to(dev)))
+
+    if size_minibatch > 0:
+        y_tr = stream(Xtr, size_minibatch, seed_minibatch)
+        lbl_tr = None if Ltr is None else stream(Ltr, size_minibatch, seed_minibatch)
+    else:
+        y_tr, lbl_tr = Xtr, Ltr
+    if size_testbatch and size_testbatch > 0:
+        y_te = stream(Xte, size_testbatch, seed_minibatch)
+        lbl_te = None if Lte is None else stream(Lte, size_testbatch, seed_minibatch)
+    else:
+        y_te, lbl_te = Xte, Lte
+    return y_tr, lbl_tr, y_te, lbl_te

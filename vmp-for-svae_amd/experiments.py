@@ -104,19 +104,29 @@ def load_checkpoint(tr, path):
 
 def run(config, nb_iters=2000, size_minibatch=100, nb_samples=10, nb_samples_te=100, measurement_freq=500,
         path_dataset=None, device='cuda', verbose=True, ratio_tr=0.7, imputation_freq=None, nb_samples_pert=20,
-        ratio_missing_data=0.1, checkpoint_freq=None, checkpoint_dir=None, graph=True):
+        ratio_missing_data=0.1, checkpoint_freq=None, checkpoint_dir=None, graph=True, group=None):
+    """One run of the reference driver (experiments.py:86-457).  Under torch.distributed (one process per GPU) every
+    rank draws the same shuffled minibatch stream and trains on its tower_slice of each minibatch - the reference's
+    tf.split over towers (data.py:174-175, experiments.py:196-244); SVAETrainer.step sums moments / ELBO and averages
+    gradients over ranks, so the run equals the single-process run on the whole minibatch."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
     torch.manual_seed(config.get('seed', 0))
     vae.reset_variables()
     X, lab = data_mod.load_dataset(config['dataset'], path_dataset)
-    X_tr, y_tr, X_te, y_te = data_mod.split_and_scale(config['dataset'], X, lab, ratio_tr=ratio_tr, seed_split=0)
+    X_tr, y_tr, X_te, y_te = data_mod.split_and_scale(config['dataset'], X, lab, ratio_tr=ratio_tr, seed_split=0,
+                                                      noise_level=config.get('noise_level', 0.1))
     dev = torch.device(device)
     Xtr, Xte = torch.as_tensor(X_tr).to(dev), torch.as_tensor(X_te).to(dev)
     Lte = None if y_te is None else torch.as_tensor(y_te, dtype=torch.float32).to(dev)
     smm = 'smm' in config['method']
     tr = SVAETrainer(config['K'], config['L'], config['U'], X_tr.shape[1], nb_samples=nb_samples, lr=config['lr'],
                      lrcvi=config['lrcvi'], decay_rate=config.get('decay_rate', 1), seed=config.get('seed', 0),
-                     device=dev, smm=smm, dof=config.get('DoF', 5))
-    batches = data_mod.minibatches_device(Xtr, size_minibatch, seed=config.get('seed', 0))
+                     device=dev, smm=smm, dof=config.get('DoF', 5), group=group)
+    batches = data_mod.minibatches_device(Xtr, size_minibatch, seed=config.get('seed', 0), rank=rank, world=world)
+    if world > 1:
+        graph = False                      # the data-parallel step has a collective in the middle: not captured
     log_id = generate_log_id(config)
     missing_data_mask = losses.generate_missing_data_mask(Xte, ratio_missing_data, seed=config.get('seed', 0))
     history = []

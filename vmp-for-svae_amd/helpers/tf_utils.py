@@ -11,7 +11,7 @@ def logdet(A, name='logdet'):
 def average_gradients(tower_grads):
     """reference tf_utils.py:52-87: list over towers of [(grad, var), ...] -> [(mean grad, var), ...].
     In the one-process-per-GPU design the towers are ranks and this mean is one packed RCCL all-reduce
-    (see vmp_for_svae_amd.models.driver); this in-process form is kept for API parity and tests."""
+    (vmp_for_svae_amd.training.SVAETrainer.step); this in-process form is kept for API parity and tests."""
     out = []
     for gv in zip(*tower_grads):
         g = torch.stack([g_ for g_, _ in gv], dim=0).mean(dim=0)

@@ -13,20 +13,64 @@ from .. import _lib as L
 from . import _mix
 
 
-def allreduce_sum_(t, group=None):
-    """In-place sum over ranks (no-op when torch.distributed is not initialised)."""
+def allreduce_sum_(t, group=None, comm=None):
+    """In-place sum over ranks of the packed buffer `t`.
+    comm (PackComm): the C ABI's own RCCL communicator (vmp_pack_allreduce) - the path a non-torch host binds;
+    otherwise torch.distributed (backend nccl = RCCL; no-op when it is not initialised).  With the gloo backend (CPU
+    rendezvous: tests, or several ranks sharing one GPU, which RCCL refuses) a device buffer is staged through the
+    host - it is 10-80 KB."""
+    if comm is not None:
+        return comm.allreduce_(t)
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if t.is_cuda and dist.get_backend(group) == 'gloo':
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+class PackComm(object):
+    """RCCL communicator owned through the C ABI (vmp_comm_* / vmp_pack_allreduce, include/vmp_hip.h): what a host
+    without torch.distributed uses for the one collective of a step.  Rank 0 creates the id with PackComm.unique_id()
+    and ships the 128 bytes to the other ranks out of band; every rank constructs PackComm(nranks, rank, id) with its
+    device current."""
+
+    @staticmethod
+    def unique_id():
+        import ctypes
+        buf = ctypes.create_string_buffer(128)
+        L.check(L.lib().vmp_comm_unique_id(buf), 'vmp_comm_unique_id')
+        return buf.raw
+
+    def __init__(self, nranks, rank, uid):
+        import ctypes
+        self.nranks, self.rank = int(nranks), int(rank)
+        h = ctypes.c_void_p()
+        L.check(L.lib().vmp_comm_init_rank(ctypes.byref(h), self.nranks, ctypes.create_string_buffer(uid, 128), self.rank),
+                'vmp_comm_init_rank')
+        self._h = h
+
+    def allreduce_(self, t):
+        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+            raise L.VmpError('PackComm.allreduce_ needs a contiguous fp64 GPU buffer')
+        L.check(L.lib().vmp_pack_allreduce(self._h, L.ptr(t), t.numel(), L.stream()), 'vmp_pack_allreduce')
+        return t
+
+    def close(self):
+        if self._h is not None:
+            L.check(L.lib().vmp_comm_destroy(self._h), 'vmp_comm_destroy')
+            self._h = None
 
 
 class DistributedVMPLoop(_mix.VMPLoop):
     """VMPLoop whose posterior update sees the statistics of ALL ranks' rows."""
 
-    def __init__(self, x, r_init, flavour, kappa=None, u_init=None, prior=None, group=None):
+    def __init__(self, x, r_init, flavour, kappa=None, u_init=None, prior=None, group=None, comm=None):
         super().__init__(x, r_init, flavour, kappa=kappa, u_init=u_init, prior=prior)
-        self.group = group
+        self.group, self.comm = group, comm
         self._stats = torch.empty((self.K, L.lib().vmp_mix_stats_words(self.D)), dtype=torch.float64,
                                   device=self.x.device)
 
@@ -37,7 +81,7 @@ class DistributedVMPLoop(_mix.VMPLoop):
                                             L.ptr(pr[0]), L.ptr(pr[1]), L.ptr(pr[2]), L.ptr(pr[3]), L.ptr(pr[4]),
                                             L.ptr(self.kappa), *([None] * 9), L.ptr(self._stats), L.stream()),
                 'vmp_mix_finalize_ws')                   # all outputs NULL: fixed-order reduction of the partials only
-        allreduce_sum_(self._stats, self.group)
+        allreduce_sum_(self._stats, self.group, self.comm)
         p, pr = self.post, self.prior
         L.check(L.lib().vmp_mix_finalize(L.ptr(self._stats), self.D, self.K, self.flavour, L.ptr(pr[0]), L.ptr(pr[1]),
                                          L.ptr(pr[2]), L.ptr(pr[3]), L.ptr(pr[4]), L.ptr(self.kappa),

@@ -28,7 +28,10 @@ def unpack_recognition_gmm(phi_gmm, name='unpack_phi2'):
     return eta1, -0.5 * (Lk @ Lk.transpose(-1, -2)), torch.softmax(pi_k_raw, dim=-1)
 
 
-unpack_recognition_gmm_debug = unpack_recognition_gmm
+def unpack_recognition_gmm_debug(phi_gmm, name='unpack_phi2'):
+    """reference svae.py:325-339 (used by experiments.py:424): as unpack_recognition_gmm, plus the raw factor."""
+    eta1, eta2, pi_k = unpack_recognition_gmm(phi_gmm, name)
+    return eta1, eta2, pi_k, phi_gmm[1]
 
 
 def unpack_smm(theta_smm, name='unpack_theta_smm'):

@@ -175,7 +175,8 @@ class SVAETrainer(object):
             del elbo, details, x_k, x_s, log_z
         if world > 1:
             buf = pack_for_allreduce(stats, grads, [elbo_t, rec_t, reg_t])
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            from .models.parallel_mix import allreduce_sum_
+            allreduce_sum_(buf, self.group)
             stats, g64, sc = unpack_after_allreduce(buf, tuple(stats.shape), [tuple(g.shape) for g in grads], 3)
             grads = [(g / world).to(torch.float32) for g in g64]                    # average_gradients (tf_utils.py:79)
             elbo_t, rec_t, reg_t = sc[0], sc[1], sc[2]
@@ -222,19 +223,43 @@ class GraphedSVAEStep(object):
         self.rho = torch.zeros((), **f32)
         self.lr_t = torch.zeros((), **f32)
         self.gen = torch.Generator(device=dev).manual_seed(int(tr.seed))
+        # Warm-up steps (they create the variables / Adam slots and size the workspaces) must not train: everything a
+        # step mutates is snapshotted first and put back before the capture, so that call number i of this object
+        # is training step number i of the eager trainer (and of the reference).
+        if not vae.net_variables('decoder_net'):
+            Dy = tr.decoder_layers[-1][0]
+            vae.make_encoder(torch.zeros(1, Dy, **f32), tr.encoder_layers, tr.stddev_init_nn, seed=tr.seed)
+            vae.decoder_variables(tr.L, tr.decoder_layers, tr.stddev_init_nn, tr.seed, dev)
+        _, params = tr.trainables()
+        had_opt = tr.opt is not None
+        snap = dict(params=[p.detach().clone() for p in params], theta=[t.detach().clone() for t in tr.theta],
+                    step=tr.global_step, t=tr.opt.t if had_opt else 0,
+                    m=[m.clone() for m in tr.opt.m] if had_opt else None,
+                    v=[v.clone() for v in tr.opt.v] if had_opt else None,
+                    gen=self.gen.get_state())
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(warmup):                      # creates the variables / Adam slots, sizes the workspaces
+            for _ in range(max(1, warmup)):
                 self._refresh()
                 tr.step(self.y, noise=self.noise, u=self.u)
+            with torch.no_grad():
+                for p, q in zip(params, snap['params']):
+                    p.copy_(q)
+                for t, q in zip(tr.theta, snap['theta']):
+                    t.copy_(q)
+                for i in range(len(params)):
+                    tr.opt.m[i].copy_(snap['m'][i]) if had_opt else tr.opt.m[i].zero_()
+                    tr.opt.v[i].copy_(snap['v'][i]) if had_opt else tr.opt.v[i].zero_()
         torch.cuda.current_stream().wait_stream(side)
+        tr.global_step, tr.opt.t = snap['step'], snap['t']
+        self.gen.set_state(snap['gen'])
         self._refresh()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = tr.step(self.y, noise=self.noise, u=self.u, _dev_scalars=(self.rho, self.lr_t))
-        # the captured kernels hold raw pointers into the shared scratch buffers: keep those buffers alive even if a later,
-        # larger eager call makes _lib.workspace() replace them
+        self.gen.set_state(snap['gen'])     # the capture-time refresh drew nothing that a replay uses
+        # the captured kernels hold raw pointers into scratch buffers of the capture stream: keep them alive
         self._ws_refs = dict(L._WS)
 
     def _refresh(self):
@@ -249,6 +274,7 @@ class GraphedSVAEStep(object):
         tr = self.tr
         self.y.copy_(y)
         self._refresh()
+        self.out['lrcvi'] = exponential_decay(tr.lrcvi0, tr.global_step, 1000, tr.decay_rate)
         self.graph.replay()
         tr.opt.t += 1
         tr.global_step += 1
