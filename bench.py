@@ -343,6 +343,10 @@ def main():
         if ndev < args.gpus:
             sys.exit('bench.py: --gpus %d but only %d GPU(s) visible' % (args.gpus, ndev))
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    # stdout carries exactly ONE line (the JSON): everything else this process or its libraries print (RCCL's version
+    # banner, warnings) goes to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
         sys.exit('bench.py: --gpus %d does not match WORLD_SIZE=%d' % (args.gpus, world))
@@ -465,7 +469,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(x_h, r0_h, args.workload)
             out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist is not None:
         dist.destroy_process_group()
 

@@ -36,8 +36,10 @@ def main():
     for name, flav in (('gmm', L.VMP_GMM), ('smm', L.VMP_SMM)):
         kap = torch.full((r0.shape[1],), 5.0, device='cuda') if flav == L.VMP_SMM else None
         loop = DistributedVMPLoop(dev(x[sl]), dev(r0[sl]), flav, kappa=kap)
-        for _ in range(3):
+        for it in range(3):
             r = loop.step()
+            if it == 0:
+                res['t1_%s_r1' % name] = r.cpu().numpy()
         res['t1_%s_r' % name] = r.cpu().numpy()
         for n_, t in zip(('alpha', 'beta', 'm', 'C', 'v'), loop.theta()):
             res['t1_%s_%s' % (name, n_)] = t.cpu().numpy()

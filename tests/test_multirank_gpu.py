@@ -95,16 +95,21 @@ def test_distributed_vmp_loop_two_ranks_equals_single_process(two_ranks):
     for name, flav in (('gmm', L.VMP_GMM), ('smm', L.VMP_SMM)):
         kap = torch.full((r0.shape[1],), 5.0, device='cuda') if flav == L.VMP_SMM else None
         loop = _mix.VMPLoop(x, r0, flav, kappa=kap)
-        for _ in range(3):
+        # one iteration from the same r0: the sharded moments (per-rank pivots and block partitions, summed in fp64) give
+        # the same posterior up to fp32 rounding of the per-block accumulation; three free-running iterations amplify that
+        # (early VMP iterations are expansive, see test_fullsize_gpu.py), hence the wider second bar
+        for it, (key, tol_r, tol_t) in enumerate((('r1', 2e-6, None), (None, None, None), ('r', 3e-5, 1e-5))):
             r = loop.step()
-        r_dist = np.concatenate([ranks[0]['t1_%s_r' % name], ranks[1]['t1_%s_r' % name]])
-        assert r_dist.shape == tuple(r.shape)
-        e = np.abs(r_dist - r.cpu().numpy()).max()
-        parity_log.record('abs', e, 2e-6, name + ' r')
-        assert e <= 2e-6, (name, e)
+            if key is None:
+                continue
+            r_dist = np.concatenate([ranks[0]['t1_%s_%s' % (name, key)], ranks[1]['t1_%s_%s' % (name, key)]])
+            assert r_dist.shape == tuple(r.shape)
+            e = np.abs(r_dist - r.cpu().numpy()).max()
+            parity_log.record('abs', e, tol_r, '%s r after %d iteration(s)' % (name, it + 1))
+            assert e <= tol_r, (name, it, e)
         for n_, t in zip(('alpha', 'beta', 'm', 'C', 'v'), loop.theta()):
             for rk in ranks:
-                assert _rel(rk['t1_%s_%s' % (name, n_)], t.cpu().numpy(), '%s %s' % (name, n_), 2e-6) <= 2e-6, (name, n_)
+                assert _rel(rk['t1_%s_%s' % (name, n_)], t.cpu().numpy(), '%s %s' % (name, n_), 1e-5) <= 1e-5, (name, n_)
             assert np.array_equal(ranks[0]['t1_%s_%s' % (name, n_)], ranks[1]['t1_%s_%s' % (name, n_)])   # replicas agree bitwise
 
 

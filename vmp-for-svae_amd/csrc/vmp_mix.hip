@@ -24,7 +24,9 @@ namespace {
 
 constexpr int TR = 64;        // data rows per wave tile
 constexpr int LS = 66;        // LDS stride (floats) between value-rows of the x image
-constexpr int MAX_NW = 8;     // waves per block
+constexpr int MAX_NW = 8;     // waves per block (K > 16)
+constexpr int MAX_NW1 = 12;   // waves per block when K <= 16 (158 VGPRs: three waves per SIMD fit)
+constexpr int max_nw(int KT) { return KT == 1 ? MAX_NW1 : MAX_NW; }
 constexpr int MAX_BLOCKS = 1024;   // upper bound (workspace sizing); the plan uses tuned_blocks
 
 struct PassArgs {
@@ -94,7 +96,7 @@ __device__ __forceinline__ v2f row16_sum2(v2f v) {
 }
 
 template <int D, int KT, int FLAV, bool ESTEP, bool STATS, bool MASK>
-__global__ __launch_bounds__(MAX_NW * WAVE) void pass_kernel(PassArgs a) {
+__global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
     using G = Geo<D>;
     constexpr int FT = G::FT;
     constexpr bool SMM = (FLAV == VMP_SMM);
@@ -846,7 +848,7 @@ Plan make_plan(long long N, int D, int K, int flavour, bool stats) {
     (void)flavour;
     const size_t wreg = (size_t)(D + 2) * LS * sizeof(float);
     int nw = tuned_nw;
-    if (nw > MAX_NW) nw = MAX_NW;
+    if (nw > max_nw((K + 15) / 16)) nw = max_nw((K + 15) / 16);
     if (nw < 1) nw = 1;
     const long long ntiles = (N + TR - 1) / TR;
     if ((long long)nw > ntiles) nw = (int)ntiles;
