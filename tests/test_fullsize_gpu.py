@@ -44,7 +44,8 @@ def _rel(got, want, tol, what):
 @pytest.mark.parametrize('flavour', ['gmm', 'smm'])
 def test_t1_three_iterations_at_1e6_vs_chunked_oracle(flavour):
     """(a) every iteration on identical inputs: the oracle's step from the very (r, u) the GPU iteration started from
-           must agree to 1e-5 (r absolute; theta, u relative);
+           must agree to 1e-5 (theta, u relative; r absolute, or 3 x what the reference's own fp32 arithmetic loses on that
+           step where that is more - the SMM's log rho is (D + kappa) / 2 = 6.5 x the Mahalanobis term);
        (b) free-running, 3 iterations from r0 on both sides: early VMP iterations from a random r0 amplify ANY
            perturbation (measured here: ~7x per iteration for the GMM, ~13x for the SMM, whose log rho carries the factor
            (D + kappa)/2), so the per-iteration fp32 rounding compounds.  SURVEY section 7's policy applies: the bar is
@@ -74,10 +75,14 @@ def test_t1_three_iterations_at_1e6_vs_chunked_oracle(flavour):
     r_prev, u_prev = r_free.clone(), u_free.clone()        # what the GPU iteration starts from
     for it in range(3):
         r = loop.step()
-        # (a) same inputs
+        # (a) same inputs: fp64 truth, and the same step in the reference's own dtype for the bar
         ro, uo, th_o = oracle_step(r_prev, u_prev)
-        e_r = _abs(r, ro, 1e-5, 'same-input r_nk it%d' % it)
-        assert e_r <= 1e-5, (flavour, it, 'r', e_r)
+        ro32, _, _ = oracle_step(r_prev.float(), u_prev.float(), x32)
+        ref32 = (ro32.double() - ro).abs().max().item()
+        parity_log.record('abs', ref32, None, 'same-input fp32 oracle (reference dtype) vs fp64 truth, r_nk it%d' % it)
+        bar_r = max(1e-5, 3 * ref32)
+        e_r = _abs(r, ro, bar_r, 'same-input r_nk it%d' % it)
+        assert e_r <= bar_r, (flavour, it, 'r', e_r, ref32)
         if smm:
             e_u = _rel(loop.u, uo, 1e-5, 'same-input u_nk it%d' % it)
             assert e_u <= 1e-5, (flavour, it, 'u', e_u)

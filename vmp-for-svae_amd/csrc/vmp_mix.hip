@@ -1,31 +1,43 @@
 // T1: pure mixture VMP (GMM: reference models/gmm.py:25-269; SMM: models/smm.py:25-245) for gfx950.
 //
-// One streaming "pass" kernel.  A wave processes tiles of 64 data rows; inside a tile it walks 8 steps of
-// 8 rows.  Lane l = (i16 = l & 15, kk = l >> 4) owns mixture component k = i16 (+16 per extra component tile)
-// and data rows n0+kk and n0+4+kk of the step - which is exactly the operand layout of the 16x16x4 fp32 MFMA
-// (A[i = l&15][inner = l>>4]), so the two parts of the pass share registers:
+// One streaming "pass" kernel.  A wave processes tiles of 64 data rows in two bodies of 32 rows = 4 groups of 8 rows.
+// Lane l = (i16 = l & 15, kk = l >> 4) owns mixture component k = i16 (+16 per extra component tile) and the data
+// rows n8+kk and n8+4+kk of a group:
 //   E-part  (packed fp32 VALU): q = ||W_k (x_n - m_k)||^2 with W_k, m_k resident in the lane's VGPRs (loaded once
 //            per kernel), the two rows of the lane packed into v_pk_fma_f32; softmax over k = all-reduce over the
-//            16 lanes of a DPP row (v_*_dpp row_ror), no LDS, no scalar loads in the loop;
-//   M-part  (MFMA): sum_n w_nk * [1 | x_n | x_n x_n^T] as a GEMM with the data row as inner index: A = w straight
-//            from the E-part's registers, B = features built from the per-wave LDS image of the x tile.
-// r_nk leaves the E-part in a layout whose 64 lanes cover 4 consecutive rows x 16 components = contiguous
-// memory, so it is stored coalesced without a transpose.  The x tile is staged once per tile in LDS as
-// [d][row] with stride 66 floats (66 = 2 mod 32: the (16 feature columns x 4 rows) operand reads hit 32
-// distinct banks per half-wave).  fp32 MFMA accumulators are flushed into fp64 registers after every tile;
-// per-block fp64 partials go to the workspace and are reduced in a fixed order by the finalize kernel
-// (deterministic, no atomics).
+//            16 lanes of a DPP row (v_*_dpp row_ror), no scalar loads in the loop;
+//   M-part  (matrix pipe): sum_n w_nk * [1 | x_n | x_n x_n^T] as a GEMM with the data row as inner index.  fp32 MFMA
+//            runs on the VALU's issue slots on gfx950 (round-1 measurement), so the operands are split into three
+//            bf16 terms each (v = h + m + l, 8 bits per term, |residual| < 2^-26 |v|) and the six products of order
+//            <= 2 go to v_mfma_f32_16x16x32_bf16: exact products, fp32 accumulation - the accuracy of the fp32 chain
+//            it replaces (tools/ubench/mfma_split_numerics.hip) on the otherwise idle XDL pipe.  The lane's weights
+//            and feature products of a group fill slot t = 2u + h of its 8 k-slots (the same slot <-> row map for
+//            A and B); one burst of 18 MFMAs per body.  The h h products and the five corrections accumulate
+//            separately (fp32), flushed to fp64 registers after every tile.
+// r_nk leaves the E-part in a layout whose 64 lanes cover 4 consecutive rows x 16 components = contiguous memory,
+// so it is stored coalesced without a transpose.  The x tile is staged once per tile in LDS as [d][position] with the
+// two rows of a lane adjacent (one ds_read_b64 each, see ppos below).  Per-block fp64 partials go to the workspace
+// and are reduced in a fixed order by the finalize kernel (deterministic, no atomics).
+// See vmp_common.h for the packed-fp32 op_sel erratum the bf16 MFMAs expose.
 #include "vmp_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 using namespace vmp;
 
 namespace {
 
 constexpr int TR = 64;        // data rows per wave tile
-constexpr int LS = 66;        // LDS stride (floats) between value-rows of the x image
+#ifndef VMP_X_PAIRS
+#define VMP_X_PAIRS 1
+#endif
+#if VMP_X_PAIRS
+constexpr int LS = 68;        // LDS stride (floats) between value-rows of the x image (68 = 4 mod 64: see below)
+#else
+constexpr int LS = 66;
+#endif
 constexpr int MAX_NW = 8;     // waves per block (K > 16)
-constexpr int MAX_NW1 = 12;   // waves per block when K <= 16 (158 VGPRs: three waves per SIMD fit)
+constexpr int MAX_NW1 = 8;    // waves per block when K <= 16 (12 waves = 3 per SIMD measured no faster and caps the VGPRs at 168)
 constexpr int max_nw(int KT) { return KT == 1 ? MAX_NW1 : MAX_NW; }
 constexpr int MAX_BLOCKS = 1024;   // upper bound (workspace sizing); the plan uses tuned_blocks
 
@@ -95,6 +107,32 @@ __device__ __forceinline__ v2f row16_sum2(v2f v) {
     return v2f{a, b};
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {       // bf16(lo) | bf16(hi) << 16, round-to-nearest-even
+    unsigned p;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(lo), "v"(hi));
+    return p;
+}
+// v = h + m + l + O(2^-26 |v|): three bf16 terms (8 significant bits each) per value, packed per pair of values.  The
+// moment GEMM keeps the six products of order <= 2 (hh, hm, mh, hl, lh, mm); what it drops (ml, lm, ll and the split
+// residuals) is below 2^-24 |w phi| - fp32 accuracy, as the fp32 MFMA it replaces (a two-term split, three products,
+// is ~2^-17 per product: fine on average at N = 1e6 but visible - 1.4e-5 on r - on a 60-row problem).
+template <int TERMS>
+__device__ __forceinline__ void split_bf16(v2f v, unsigned (&t)[3]) {
+    t[0] = cvt_pk_bf16(v.x, v.y);
+    v2f rem = v - v2f{__uint_as_float(t[0] << 16), __uint_as_float(t[0] & 0xffff0000u)};
+    t[1] = cvt_pk_bf16(rem.x, rem.y);
+    if constexpr (TERMS == 3) {
+        rem = rem - v2f{__uint_as_float(t[1] << 16), __uint_as_float(t[1] & 0xffff0000u)};
+        t[2] = cvt_pk_bf16(rem.x, rem.y);
+    } else {
+        t[2] = 0u;
+    }
+}
+constexpr int MOM_TERMS = 3;
+
 template <int D, int KT, int FLAV, bool ESTEP, bool STATS, bool MASK>
 __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
     using G = Geo<D>;
@@ -108,6 +146,16 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
     constexpr int ONE = D, ZERO = D + 1;
     xl[ONE * LS + lane] = 1.0f;
     xl[ZERO * LS + lane] = 0.0f;
+    // Within a value-row the 64 data rows of a tile are stored so that the two rows one lane works on in a group of 8
+    // (n8 + kk and n8 + 4 + kk) are ADJACENT: position of tile row t = 8 (t / 8) + 2 (t % 4) + (t / 4) % 2.  A lane then
+    // fetches both with one ds_read_b64 (half the LDS cycles of ds_read2_b32).  Banks of ds_read_b64 are dword-address
+    // mod 64: with LS = 4 (mod 64) the feature reads of a half-wave (value-row ra = 0..9 by lane, kk in {0,1} or {2,3})
+    // fall on banks 4 ra + {0..3} (+ 4): all distinct; the E-part reads are two broadcast addresses per half-wave.
+#if VMP_X_PAIRS
+    const int ppos = (lane & ~7) + 2 * (lane & 3) + ((lane >> 2) & 1);
+#else
+    const int ppos = lane;
+#endif
 
     const int i16 = lane & 15, kk = lane >> 4;
     // NOTE on every "cond ? load : 0" below: a load under a per-element condition compiles to a branch plus a full
@@ -158,22 +206,29 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
             while (p >= D - d) { p -= D - d; ++d; }
             ra = d; rb = d + p;
         }
+#if VMP_X_PAIRS
+        offA[ft] = ra * LS + 2 * kk;
+        offB[ft] = rb * LS + 2 * kk;
+#else
         offA[ft] = ra * LS + kk;
         offB[ft] = rb * LS + kk;
+#endif
     }
 
-    f32x4 acc[KT][FT];
-    f32x4 nacc[KT];
+    f32x4 acc[KT][FT], acs[KT][FT];
+    f32x4 nacc[KT], nacs[KT];
     double dacc[KT][FT][4];
     double dn[KT][4];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
         nacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        nacs[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 4; ++c) dn[kt][c] = 0.0;
 #pragma unroll
         for (int ft = 0; ft < FT; ++ft) {
             acc[kt][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acs[kt][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 4; ++c) dacc[kt][ft][c] = 0.0;
         }
@@ -197,7 +252,7 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
         {
             const bool valid = row0 + lane < hi;
 #pragma unroll
-            for (int j = 0; j < D; ++j) xl[j * LS + lane] = valid ? xr[j] - pv[j] : 0.f;
+            for (int j = 0; j < D; ++j) xl[j * LS + ppos] = valid ? xr[j] - pv[j] : 0.f;
             const long long n2 = row0 + TR + lane;
 #pragma unroll
             for (int j = 0; j < D; ++j) xr[j] = 0.f;
@@ -208,125 +263,242 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
         // this lane's element of r/u/logr for (row0 + kk, component i16) - everything else is a 32-bit offset
         const long long tbase = (row0 + kk) * K + i16;
         const int K4 = 4 * K;
+        // A tile is walked in bodies of 32 rows = 4 groups of 8 rows.  One group = the E-part for this lane's two rows
+        // (n8 + kk, n8 + 4 + kk); its weights and feature products are split into bf16 (hi, lo) pairs and parked in the
+        // operand registers of the 16x16x32 bf16 MFMA (slot t = 2u + h of lane group kk <-> row 8u + 4h + kk, the same
+        // for A and B), so that the moment GEMM of the body is 3 products (hi hi + hi lo + lo hi) per feature tile on the
+        // MATRIX pipe instead of 8 fp32 MFMAs per tile on the vector pipe (fp32 MFMA shares the VALU issue slots on
+        // gfx950).  FULL bodies (32 valid rows, K a multiple of 16) skip every predicate.
 #pragma unroll 1
-        for (int n0 = 0; n0 < trows; n0 += 8) {
-            const long long ra = row0 + n0 + kk, rb = ra + 4;             // this lane's two data rows
-            const bool va = ra < hi, vb = rb < hi;
-            const int so = n0 * K;                                        // wave-uniform
-            v2f w[KT], rr[KT];
-            if constexpr (ESTEP) {
-                v2f xv[D];
+        for (int n0 = 0; n0 < trows; n0 += 32) {
+            unsigned As[KT][3][4], Rs[KT][3][4], Bs[FT][3][4];          // [term h/m/l][group u]
+            auto group = [&](auto full_c, auto u_c) __attribute__((always_inline)) {
+                constexpr bool FULL = decltype(full_c)::value;
+                constexpr int u = decltype(u_c)::value;
+                const int n8 = n0 + 8 * u;
+                if (!FULL && n8 >= trows) {                                   // wave-uniform: nothing left in this body
+                    if constexpr (STATS) {
 #pragma unroll
-                for (int j = 0; j < D; ++j) xv[j] = v2f{xl[j * LS + n0 + kk], xl[j * LS + n0 + 4 + kk]};
-                v2f keep[D];
-                if constexpr (MASK) {
+                        for (int t = 0; t < 3; ++t) {
 #pragma unroll
-                    for (int j = 0; j < D; ++j)
-                        keep[j] = v2f{(va && a.mask[ra * D + j] != 0) ? 0.f : 1.f, (vb && a.mask[rb * D + j] != 0) ? 0.f : 1.f};
-                }
-                v2f lg[KT], uu[KT];
-                v2f mx = v2f{-INFINITY, -INFINITY};
+                            for (int kt = 0; kt < KT; ++kt) { As[kt][t][u] = 0u; Rs[kt][t][u] = 0u; }
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) {
-                    v2f dv[D];
-#pragma unroll
-                    for (int j = 0; j < D; ++j) {
-                        dv[j] = pk_sub_b(xv[j], pm2[kt][j >> 1], j & 1);
-                        if constexpr (MASK) dv[j] = dv[j] * keep[j];
-                    }
-                    // y = W (x - m), W lower triangular packed row-major; walked by COLUMNS so that the D
-                    // accumulators form independent dependency chains (a row-wise walk is latency-bound)
-                    v2f y[D];
-#pragma unroll
-                    for (int i = 0; i < D; ++i) y[i] = pk_mul_b(dv[0], pw2[kt][(i * (i + 1) / 2) >> 1], (i * (i + 1) / 2) & 1);
-#pragma unroll
-                    for (int j = 1; j < D; ++j)
-#pragma unroll
-                        for (int i = j; i < D; ++i) {
-                            const int e = i * (i + 1) / 2 + j;
-                            y[i] = pk_fma_b(dv[j], pw2[kt][e >> 1], y[i], e & 1);
+                            for (int ft = 0; ft < FT; ++ft) Bs[ft][t][u] = 0u;
                         }
-                    v2f q = y[0] * y[0], q1 = v2f{0.f, 0.f};
-#pragma unroll
-                    for (int i = 1; i < D; ++i) {
-                        if (i & 1) q1 = __builtin_elementwise_fma(y[i], y[i], q1);
-                        else q = __builtin_elementwise_fma(y[i], y[i], q);
                     }
-                    q += q1;
-                    lg[kt] = pk_const_minus_scaled(q, pch[kt]);           // log2 rho
-                    mx = __builtin_elementwise_max(mx, lg[kt]);
-                    if constexpr (SMM) uu[kt] = v2f{pua[kt] * __builtin_amdgcn_rcpf(q.x + pub[kt]), pua[kt] * __builtin_amdgcn_rcpf(q.y + pub[kt])};
+                    return;
                 }
-                mx = row16_max2(mx);
-                v2f ssum = v2f{0.f, 0.f};
+                const long long ra = row0 + n8 + kk, rb = ra + 4;             // this lane's two data rows
+                const bool va = FULL || ra < hi, vb = FULL || rb < hi;
+                const int so = n8 * K;                                        // wave-uniform
+                v2f w[KT], rr[KT];
+                // the LDS reads of the moment features are issued here, ahead of the E-part, so that their latency is
+                // covered by its ~350 cycles of arithmetic instead of being waited for three times at the end of the group
+                v2f fa[FT], fb[FT];
+#ifndef VMP_HOIST
+#define VMP_HOIST 0
+#endif
+                auto load_features = [&]() __attribute__((always_inline)) {
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) {
-                    lg[kt] = v2f{__builtin_amdgcn_exp2f(lg[kt].x - mx.x), __builtin_amdgcn_exp2f(lg[kt].y - mx.y)};
-                    ssum += lg[kt];
-                }
-                ssum = row16_sum2(ssum);
-                const v2f inv = v2f{va ? __builtin_amdgcn_rcpf(ssum.x) : 0.f, vb ? __builtin_amdgcn_rcpf(ssum.y) : 0.f};
+                    for (int ft = 0; ft < FT; ++ft) {
+#if VMP_X_PAIRS
+                        fa[ft] = *reinterpret_cast<const v2f*>(&xl[offA[ft] + n8]);
+                        fb[ft] = *reinterpret_cast<const v2f*>(&xl[offB[ft] + n8]);
+#else
+                        fa[ft] = v2f{xl[offA[ft] + n8], xl[offA[ft] + n8 + 4]};
+                        fb[ft] = v2f{xl[offB[ft] + n8], xl[offB[ft] + n8 + 4]};
+#endif
+                    }
+                };
+                if constexpr (STATS && VMP_HOIST) load_features();
+                if constexpr (ESTEP) {
+                    v2f xv[D];
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) {
-                    const int k = kt * 16 + i16;
-                    rr[kt] = lg[kt] * inv;
-                    w[kt] = SMM ? rr[kt] * uu[kt] : rr[kt];
-                    const bool sa = va && k < K, sb = vb && k < K;
-                    float* __restrict__ ro = a.r_out + tbase + kt * 16;
-                    if (sa) ro[so] = rr[kt].x;
-                    if (sb) ro[so + K4] = rr[kt].y;
-                    if constexpr (SMM) {
-                        float* __restrict__ uo = a.u_out + tbase + kt * 16;
-                        if (sa) uo[so] = uu[kt].x;
-                        if (sb) uo[so + K4] = uu[kt].y;
+#if VMP_X_PAIRS
+                    for (int j = 0; j < D; ++j) xv[j] = *reinterpret_cast<const v2f*>(&xl[j * LS + n8 + 2 * kk]);
+#else
+                    for (int j = 0; j < D; ++j) xv[j] = v2f{xl[j * LS + n8 + kk], xl[j * LS + n8 + 4 + kk]};
+#endif
+                    v2f keep[D];
+                    if constexpr (MASK) {
+#pragma unroll
+                        for (int j = 0; j < D; ++j)
+                            keep[j] = v2f{(va && a.mask[ra * D + j] != 0) ? 0.f : 1.f, (vb && a.mask[rb * D + j] != 0) ? 0.f : 1.f};
                     }
-                    if (a.logr_out) {
-                        float* __restrict__ lo = a.logr_out + tbase + kt * 16;
-                        if (sa) lo[so] = logf(rr[kt].x);
-                        if (sb) lo[so + K4] = logf(rr[kt].y);
+                    v2f lg[KT], uu[KT];
+                    v2f mx;
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) {
+                        v2f dv[D];
+#pragma unroll
+                        for (int j = 0; j < D; ++j) {
+                            dv[j] = pk_sub_b(xv[j], pm2[kt][j >> 1], j & 1);
+                            if constexpr (MASK) dv[j] = dv[j] * keep[j];
+                        }
+                        // y = W (x - m), W lower triangular packed row-major; walked by COLUMNS so that the D
+                        // accumulators form independent dependency chains (a row-wise walk is latency-bound)
+                        v2f y[D];
+#pragma unroll
+                        for (int i = 0; i < D; ++i) y[i] = pk_mul_b(dv[0], pw2[kt][(i * (i + 1) / 2) >> 1], (i * (i + 1) / 2) & 1);
+#pragma unroll
+                        for (int j = 1; j < D; ++j)
+#pragma unroll
+                            for (int i = j; i < D; ++i) {
+                                const int e = i * (i + 1) / 2 + j;
+                                y[i] = pk_fma_b(dv[j], pw2[kt][e >> 1], y[i], e & 1);
+                            }
+                        v2f q = y[0] * y[0], q1 = v2f{0.f, 0.f};
+#pragma unroll
+                        for (int i = 1; i < D; ++i) {
+                            if (i & 1) q1 = __builtin_elementwise_fma(y[i], y[i], q1);
+                            else q = __builtin_elementwise_fma(y[i], y[i], q);
+                        }
+                        q += q1;
+                        lg[kt] = pk_const_minus_scaled(q, pch[kt]);           // log2 rho
+                        if (kt == 0) mx = lg[0];
+                        else mx = v2f{fmaxf(mx.x, lg[kt].x), fmaxf(mx.y, lg[kt].y)};
+                        if constexpr (SMM) uu[kt] = v2f{pua[kt] * __builtin_amdgcn_rcpf(q.x + pub[kt]), pua[kt] * __builtin_amdgcn_rcpf(q.y + pub[kt])};
+                    }
+                    mx = row16_max2(mx);
+                    v2f ssum;
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) {
+                        lg[kt] = v2f{__builtin_amdgcn_exp2f(lg[kt].x - mx.x), __builtin_amdgcn_exp2f(lg[kt].y - mx.y)};
+                        if (kt == 0) ssum = lg[0];
+                        else ssum += lg[kt];
+                    }
+                    ssum = row16_sum2(ssum);
+                    v2f inv = v2f{__builtin_amdgcn_rcpf(ssum.x), __builtin_amdgcn_rcpf(ssum.y)};
+                    if constexpr (!FULL) inv = v2f{va ? inv.x : 0.f, vb ? inv.y : 0.f};
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) {
+                        const int k = kt * 16 + i16;
+                        rr[kt] = lg[kt] * inv;
+                        w[kt] = SMM ? rr[kt] * uu[kt] : rr[kt];
+                        if constexpr (FULL) {
+                            // K == 16 KT here: every offset below the tile base is a compile-time constant
+                            float* __restrict__ ro = a.r_out + tbase + kt * 16 + (long long)n0 * (16 * KT);
+                            ro[8 * u * 16 * KT] = rr[kt].x;
+                            ro[(8 * u + 4) * 16 * KT] = rr[kt].y;
+                            if constexpr (SMM) {
+                                float* __restrict__ uo = a.u_out + tbase + kt * 16 + (long long)n0 * (16 * KT);
+                                uo[8 * u * 16 * KT] = uu[kt].x;
+                                uo[(8 * u + 4) * 16 * KT] = uu[kt].y;
+                            }
+                            if (a.logr_out) {
+                                float* __restrict__ lo = a.logr_out + tbase + kt * 16 + (long long)n0 * (16 * KT);
+                                lo[8 * u * 16 * KT] = logf(rr[kt].x);
+                                lo[(8 * u + 4) * 16 * KT] = logf(rr[kt].y);
+                            }
+                        } else {
+                            const bool sa = va && k < K, sb = vb && k < K;
+                            float* __restrict__ ro = a.r_out + tbase + kt * 16;
+                            if (sa) ro[so] = rr[kt].x;
+                            if (sb) ro[so + K4] = rr[kt].y;
+                            if constexpr (SMM) {
+                                float* __restrict__ uo = a.u_out + tbase + kt * 16;
+                                if (sa) uo[so] = uu[kt].x;
+                                if (sb) uo[so + K4] = uu[kt].y;
+                            }
+                            if (a.logr_out) {
+                                float* __restrict__ lo = a.logr_out + tbase + kt * 16;
+                                if (sa) lo[so] = logf(rr[kt].x);
+                                if (sb) lo[so + K4] = logf(rr[kt].y);
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) {
+                        const int k = kt * 16 + i16;
+                        const bool on = k < K;
+                        const float* __restrict__ ri = a.r_in + tbase + kt * 16;
+                        const float r0v = *((on && va) ? ri + so : a.r_in), r1v = *((on && vb) ? ri + so + K4 : a.r_in);
+                        rr[kt] = v2f{(on && va) ? r0v : 0.f, (on && vb) ? r1v : 0.f};
+                        if constexpr (SMM) {
+                            const float* __restrict__ ui = a.u_in + tbase + kt * 16;
+                            const float u0v = *((on && va) ? ui + so : a.u_in), u1v = *((on && vb) ? ui + so + K4 : a.u_in);
+                            const v2f u2 = v2f{(on && va) ? u0v : 0.f, (on && vb) ? u1v : 0.f};
+                            w[kt] = rr[kt] * u2;
+                        } else {
+                            w[kt] = rr[kt];
+                        }
                     }
                 }
+
+                if constexpr (STATS) {
+                    if constexpr (!VMP_HOIST) load_features();
+                    unsigned t3[3];
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) {
+                        split_bf16<MOM_TERMS>(w[kt], t3);
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) As[kt][t][u] = t3[t];
+                        if constexpr (SMM) {
+                            split_bf16<MOM_TERMS>(rr[kt], t3);
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) Rs[kt][t][u] = t3[t];
+                        }
+                    }
+#pragma unroll
+                    for (int ft = 0; ft < FT; ++ft) {
+                        split_bf16<MOM_TERMS>(fa[ft] * fb[ft], t3);
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) Bs[ft][t][u] = t3[t];
+                    }
+                }
+            };
+            using std::integral_constant;
+            const bool full = (K == 16 * KT) && (n0 + 32 <= trows);
+            if (full) {
+                group(integral_constant<bool, true>{}, integral_constant<int, 0>{});
+                group(integral_constant<bool, true>{}, integral_constant<int, 1>{});
+                group(integral_constant<bool, true>{}, integral_constant<int, 2>{});
+                group(integral_constant<bool, true>{}, integral_constant<int, 3>{});
             } else {
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt) {
-                    const int k = kt * 16 + i16;
-                    const bool on = k < K;
-                    const float* __restrict__ ri = a.r_in + tbase + kt * 16;
-                    const float r0v = *((on && va) ? ri + so : a.r_in), r1v = *((on && vb) ? ri + so + K4 : a.r_in);
-                    rr[kt] = v2f{(on && va) ? r0v : 0.f, (on && vb) ? r1v : 0.f};
-                    if constexpr (SMM) {
-                        const float* __restrict__ ui = a.u_in + tbase + kt * 16;
-                        const float u0v = *((on && va) ? ui + so : a.u_in), u1v = *((on && vb) ? ui + so + K4 : a.u_in);
-                        const v2f u2 = v2f{(on && va) ? u0v : 0.f, (on && vb) ? u1v : 0.f};
-                        w[kt] = rr[kt] * u2;
-                    } else {
-                        w[kt] = rr[kt];
-                    }
-                }
+                group(integral_constant<bool, false>{}, integral_constant<int, 0>{});
+                group(integral_constant<bool, false>{}, integral_constant<int, 1>{});
+                group(integral_constant<bool, false>{}, integral_constant<int, 2>{});
+                group(integral_constant<bool, false>{}, integral_constant<int, 3>{});
             }
 
             if constexpr (STATS) {
-                float b0[FT], b4[FT];
+                bf16x8 b[FT][3];
 #pragma unroll
-                for (int ft = 0; ft < FT; ++ft) {
-                    b0[ft] = xl[offA[ft] + n0] * xl[offB[ft] + n0];
-                    b4[ft] = xl[offA[ft] + n0 + 4] * xl[offB[ft] + n0 + 4];
-                }
-                // all MFMAs of the first 4-row group, then all of the second: back-to-back MFMAs never share an
-                // accumulator (a dependent pair would stall ~40 cycles)
+                for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-                    for (int ft = 0; ft < FT; ++ft)
-                        acc[kt][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[kt].x, b0[ft], acc[kt][ft], 0, 0, 0);
-                    if constexpr (SMM) nacc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(rr[kt].x, b0[0], nacc[kt], 0, 0, 0);
-                }
+                    for (int t = 0; t < 3; ++t)
+                        b[ft][t] = __builtin_bit_cast(bf16x8, u32x4{Bs[ft][t][0], Bs[ft][t][1], Bs[ft][t][2], Bs[ft][t][3]});
+                // sum over (ta, tb) with ta + tb < MOM_TERMS; within one (ta, tb) the FT MFMAs hit different accumulators,
+                // so back-to-back MFMAs never share one
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) {
+                    bf16x8 av[3], rv[3];
 #pragma unroll
-                    for (int ft = 0; ft < FT; ++ft)
-                        acc[kt][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[kt].y, b4[ft], acc[kt][ft], 0, 0, 0);
-                    if constexpr (SMM) nacc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(rr[kt].y, b4[0], nacc[kt], 0, 0, 0);
+                    for (int t = 0; t < 3; ++t) {
+                        av[t] = __builtin_bit_cast(bf16x8, u32x4{As[kt][t][0], As[kt][t][1], As[kt][t][2], As[kt][t][3]});
+                        if constexpr (SMM) rv[t] = __builtin_bit_cast(bf16x8, u32x4{Rs[kt][t][0], Rs[kt][t][1], Rs[kt][t][2], Rs[kt][t][3]});
+                    }
+                    // The h h products (full magnitude) and the five corrections (<= 2^-8 of it) go to SEPARATE fp32
+                    // accumulators: a correction added to a large accumulator loses most of its bits, and six roundings at
+                    // the large magnitude per body cost ~3x the accuracy of the fp32 chain this replaces (measured on the
+                    // 60-row golden SMM case: C_k 2.2e-6 vs 6.8e-7).  Both are summed in fp64 at the tile flush.
+#pragma unroll
+                    for (int ta = 0; ta < MOM_TERMS; ++ta) {
+#pragma unroll
+                        for (int tb = 0; tb + ta < MOM_TERMS; ++tb) {
+#pragma unroll
+                            for (int ft = 0; ft < FT; ++ft) {
+                                if (ta + tb == 0) acc[kt][ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ta], b[ft][tb], acc[kt][ft], 0, 0, 0);
+                                else acs[kt][ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ta], b[ft][tb], acs[kt][ft], 0, 0, 0);
+                            }
+                        }
+                        // N_k = sum r: column 0 of feature tile 0 is the constant 1 (exact in bf16: only its h term is non-zero)
+                        if constexpr (SMM) {
+                            if (ta == 0) nacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rv[ta], b[0][0], nacc[kt], 0, 0, 0);
+                            else nacs[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rv[ta], b[0][0], nacs[kt], 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
@@ -336,13 +508,14 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
             for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    if constexpr (SMM) dn[kt][c] += (double)nacc[kt][c];
+                    if constexpr (SMM) dn[kt][c] += (double)nacc[kt][c] + (double)nacs[kt][c];
 #pragma unroll
-                    for (int ft = 0; ft < FT; ++ft) dacc[kt][ft][c] += (double)acc[kt][ft][c];
+                    for (int ft = 0; ft < FT; ++ft) dacc[kt][ft][c] += (double)acc[kt][ft][c] + (double)acs[kt][ft][c];
                 }
                 nacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                nacs[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ft = 0; ft < FT; ++ft) acc[kt][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int ft = 0; ft < FT; ++ft) { acc[kt][ft] = f32x4{0.f, 0.f, 0.f, 0.f}; acs[kt][ft] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             }
         }
         __builtin_amdgcn_wave_barrier();
