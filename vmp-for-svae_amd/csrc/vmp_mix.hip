@@ -564,18 +564,29 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
                 __syncthreads();
             }
         }
-        double* out = a.partials + (long long)blockIdx.x * K * G::PF;
+        // partials[k][block][PX]: one component's rows of all blocks are contiguous (what a finalize block streams);
+        // slot PF of every row = this block's sum_k N_k (the Dirichlet normaliser needs the total count)
+        constexpr int PX = G::PF + 1;
+        double* out = a.partials;
         for (int e = threadIdx.x; e < KT * (FT + 1) * 4 * WAVE; e += blockDim.x) {
             const int l = e & 63, c = (e >> 6) & 3, tf = (e >> 8) % (FT + 1), kt = (e >> 8) / (FT + 1);
             const int k = kt * 16 + (l >> 4) * 4 + c;
             if (k >= K) continue;
+            double* row = out + ((long long)k * MAX_BLOCKS + blockIdx.x) * PX;
             if (tf < FT) {
                 const int f = tf * 16 + (l & 15);
-                if (f < G::F) out[k * G::PF + f] = sc[e];
+                if (f < G::F) row[f] = sc[e];
             } else if ((l & 15) == 0) {
-                out[k * G::PF + G::F] = sc[e];                 // Nk = sum_n r_nk
-                a.partials[(long long)MAX_BLOCKS * K * G::PF + (long long)blockIdx.x * K + k] = sc[e];   // compact copy (all k)
+                row[G::F] = sc[e];                             // Nk = sum_n r_nk
             }
+        }
+        if (threadIdx.x == 0) {
+            double ntot = 0.0;
+            for (int k = 0; k < K; ++k) {
+                const int kt = k >> 4, l = ((k & 15) >> 2) * 16, c = k & 3;
+                ntot += sc[((kt * (FT + 1) + FT) * 4 + c) * WAVE + l];
+            }
+            for (int k = 0; k < K; ++k) out[((long long)k * MAX_BLOCKS + blockIdx.x) * PX + G::PF] = ntot;
         }
     }
 }
@@ -592,7 +603,7 @@ __device__ double digamma_d(double x) {
 }
 
 struct FinArgs {
-    const double* partials;    // [nblk][K][PF]   (src == 0)
+    const double* partials;    // [K][MAX_BLOCKS][PF + 1]   (src == 0)
     const double* stats_in;    // [K][SW]         (src == 1)
     int nblk, K, flavour, src, do_post;
     const float *alpha0, *beta0, *m0, *C0, *v0, *kappa;
@@ -740,9 +751,8 @@ template <int D>
 __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
     using G = Geo<D>;
     __shared__ double part[FIN_GROUPS][64];
-    __shared__ double npart[FIN_GROUPS][64];
     __shared__ double st[G::SW];           // canonical: Nk, Wk, sx[D], sxx[D*D]
-    __shared__ double nall[VMP_MAX_K];
+    __shared__ double ntot;                // sum_j N_j over all components
     __shared__ double Ck[D * D], mk[D], sp[D + 4], scal[8];
     __shared__ double alpha0s[VMP_MAX_K];
     const int k = blockIdx.x, tid = threadIdx.x, K = a.K;
@@ -763,42 +773,41 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
 
     if (a.dbg_t && blockIdx.x == 0 && tid == 0) a.dbg_t[0] = clock64();
     if (a.src == 0) {
+        constexpr int PX = G::PF + 1;
         const int f = tid & 63, g = tid >> 6;
-        double s = 0.0, s2 = 0.0;
-        // all loads of a chunk are issued before the first add (fixed summation order: b ascending)
+        double s = 0.0;
+        // all loads of a chunk are issued before the first add (fixed summation order: b ascending).  The rows of this
+        // component are contiguous: partials[k][b][PX].
+        const double* __restrict__ mine = a.partials + (long long)k * MAX_BLOCKS * PX;
         for (int b0 = g; b0 < a.nblk; b0 += FIN_GROUPS * 16) {
-            double v1[16], v2[16];
+            double v1[16];
             // unconditional loads from clamped (always valid) addresses, masked afterwards: a load under a
             // per-element condition becomes a branch + full wait per element (32 serialised round trips)
-            const int fc = f < G::PF ? f : G::PF - 1, kc = f < K ? f : K - 1;
+            const int fc = f < PX ? f : PX - 1;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int b = b0 + i * FIN_GROUPS;
                 const int bc = b < a.nblk ? b : a.nblk - 1;
-                v1[i] = a.partials[((long long)bc * K + k) * G::PF + fc];
-                v2[i] = a.partials[(long long)MAX_BLOCKS * K * G::PF + (long long)bc * K + kc];      // compact N_j of block bc
+                v1[i] = mine[(long long)bc * PX + fc];
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const bool in = b0 + i * FIN_GROUPS < a.nblk;
-                v1[i] = (in && f < G::PF) ? v1[i] : 0.0;
-                v2[i] = (in && f < K) ? v2[i] : 0.0;
+                v1[i] = (in && f < PX) ? v1[i] : 0.0;
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { s += v1[i]; s2 += v2[i]; }
+            for (int i = 0; i < 16; ++i) s += v1[i];
         }
         part[g][f] = s;
-        npart[g][f] = s2;
         __syncthreads();
         if (a.dbg_t && blockIdx.x == 0 && tid == 0) a.dbg_t[1] = clock64();
         if (tid < 64) {
-            double t1 = 0.0, t2 = 0.0;
-            for (int gg = 0; gg < FIN_GROUPS; ++gg) { t1 += part[gg][tid]; t2 += npart[gg][tid]; }
+            double t1 = 0.0;
+            for (int gg = 0; gg < FIN_GROUPS; ++gg) t1 += part[gg][tid];
             part[0][tid] = t1;
-            if (tid < K) nall[tid] = t2;
         }
         __syncthreads();
-        if (tid == 0) { st[0] = part[0][G::F]; st[1] = part[0][0]; }
+        if (tid == 0) { st[0] = part[0][G::F]; st[1] = part[0][0]; ntot = part[0][G::PF]; }
         if (tid < D) st[2 + tid] = part[0][1 + tid];
         if (tid < D * D) {
             const int d = tid / D, e = tid % D;
@@ -807,7 +816,11 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
         }
     } else {
         for (int i = tid; i < G::SW; i += FIN_THREADS) st[i] = a.stats_in[(long long)k * G::SW + i];
-        for (int j = tid; j < K; j += FIN_THREADS) nall[j] = a.stats_in[(long long)j * G::SW];
+        if (tid == 0) {
+            double t = 0.0;
+            for (int j = 0; j < K; ++j) t += a.stats_in[(long long)j * G::SW];
+            ntot = t;
+        }
     }
     __syncthreads();
     // st holds the moments of the SHIFTED data x - c (c = pivot, 0 if none); the public layout is un-shifted:
@@ -890,7 +903,8 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
         sp[D] = digamma_d(alpha_k);
     } else if (tid == 64 + D + 1) {
         double asum = 0.0;
-        for (int j = 0; j < K; ++j) asum += alpha0s[j] + nall[j];
+        for (int j = 0; j < K; ++j) asum += alpha0s[j];
+        asum += ntot;
         sp[D + 1] = digamma_d(asum);
     } else if (tid == 64 + D + 2 && smm) {
         sp[D + 2] = lgamma(0.5 * (D + kap)) - lgamma(0.5 * kap);
@@ -1134,7 +1148,7 @@ int vmp_mix_stats_words(int D) { return stats_words(D); }
 
 size_t vmp_mix_workspace_bytes(int64_t N, int D, int K) {
     (void)N;
-    return (size_t)MAX_BLOCKS * K * (partial_words(D) + 1) * sizeof(double);   // per-block partials + compact N_k table
+    return (size_t)MAX_BLOCKS * K * (partial_words(D) + 1) * sizeof(double);   // [K][MAX_BLOCKS][PF + 1] per-block partials
 }
 
 int vmp_mix_pivot(const float* x, int64_t N, int D, float* pivot_out, void* stream) {
