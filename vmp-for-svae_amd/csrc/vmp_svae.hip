@@ -105,6 +105,7 @@ __device__ __forceinline__ void solve_lower_t(const float (&Lm)[SvGeo<L>::TRI], 
 
 // sum / max over the K lanes of this lane's row, through a 64-float LDS scratch
 __device__ __forceinline__ float row_sum(float v, float* scr, int lane, int rbase, int K) {
+    if (K == 16) return row16_sum(v);            // a row = one 16-lane DPP row: 4 rotations instead of 17 LDS accesses + 16 adds
     scr[lane] = v;
     __builtin_amdgcn_wave_barrier();
     float s = 0.f;
@@ -113,6 +114,7 @@ __device__ __forceinline__ float row_sum(float v, float* scr, int lane, int rbas
     return s;
 }
 __device__ __forceinline__ float row_max(float v, float* scr, int lane, int rbase, int K) {
+    if (K == 16) return row16_max(v);
     scr[lane] = v;
     __builtin_amdgcn_wave_barrier();
     float m = -INFINITY;
