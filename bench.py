@@ -152,6 +152,21 @@ def bench_t2(N, Ld, K, S, steps, warmup, dev, dist=None, world=1):
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
+    # the same forward with eps drawn inside the kernel (Philox4x32-10), and what the noise tensor costs to produce
+    evp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
+    evr = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
+    with torch.no_grad():
+        for i in range(4):
+            evp[i][0].record()
+            xp, lzp, ptp, _ = svae.e_step((eta1, eta2d), phi, S, seed=i, noise='philox', theta=theta)
+            evp[i][1].record()
+            del xp, lzp, ptp
+            evr[i][0].record()
+            noise.normal_(generator=g)
+            evr[i][1].record()
+    torch.cuda.synchronize()
+    p_ms = float(np.median([a.elapsed_time(b) for a, b in evp[1:]]))
+    r_ms = float(np.median([a.elapsed_time(b) for a, b in evr[1:]]))
     f_ms = float(np.mean([a.elapsed_time(b) for a, b in evf]))
     b_ms = float(np.mean([a.elapsed_time(b) for a, b in evb]))
     alg = 4.0 * N * (4.0 * K * S * Ld + 2 * K + 4 * Ld)         # SURVEY 8d T2 bytes per step, injected noise
@@ -159,7 +174,7 @@ def bench_t2(N, Ld, K, S, steps, warmup, dev, dist=None, world=1):
     bwd_bytes = 4.0 * N * (2.0 * K * S * Ld + 4 * Ld + 3 * K)   # reads x + dx + (lz, dlz, dT'), writes d eta
     return {'steps_per_sec': steps / dt, 'ms_per_step': dt / steps * 1e3, 'datapoints_per_sec': N * world * steps / dt,
             'algorithmic_bytes_per_step': alg, 'algorithmic_GBps_whole_step': alg / (dt / steps) / 1e9,
-            'fwd_kernel_ms': f_ms, 'bwd_kernel_ms': b_ms,
+            'fwd_kernel_ms': f_ms, 'bwd_kernel_ms': b_ms, 'fwd_in_kernel_philox_ms': p_ms, 'noise_tensor_randn_ms': r_ms,
             'fwd_GBps': fwd_bytes / (f_ms * 1e-3) / 1e9, 'bwd_GBps': bwd_bytes / (b_ms * 1e-3) / 1e9,
             'fwd_frac_hbm': fwd_bytes / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'bwd_frac_hbm': bwd_bytes / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             'config': 'T2 svae-vmp N=%d per GPU, L=%d, K=%d, S=%d (fwd+bwd of the fused E-step, sub-sampling, M-step, CVI)' % (N, Ld, K, S)}

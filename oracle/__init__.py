@@ -22,4 +22,4 @@ How it is pinned  (parity PINNED by reference execution, not by reference tests 
     /root/reference; they are replaced by LAPACK (torch.linalg) and torch.special here, i.e. the
     published algorithms (partial-pivot LU, Cholesky), and the fp64 evaluation is the adopted truth.
 """
-from . import dists, metrics, mixtures, nets, svae_ref, train_ref  # noqa: F401
+from . import dists, metrics, mixtures, nets, philox, svae_ref, train_ref  # noqa: F401

@@ -1,0 +1,68 @@
+"""Oracle: Philox4x32-10 (Salmon, Moraes, Dror, Shaw - "Parallel random numbers: as easy as 1, 2, 3", SC'11; the
+counter-based generator behind tf.random_normal / cuRAND / torch on GPUs) and the Box-Muller map, in numpy.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  The reference draws its noise inside the step with TF's own Philox
+stream (models/svae.py:113-114); TF 1.3's exact counter layout is a TensorFlow internal that is absent from the reference
+tree, so the product's in-kernel generator defines its own layout (csrc/vmp_svae.hip: counter = (cell_lo, cell_hi,
+block, 0), key = seed) and parity is distributional.  This file pins the generator itself: the known-answer vectors of
+the Random123 distribution (kat_vectors: philox4x32 10 rounds) and the element layout of a cell's noise block."""
+import numpy as np
+
+M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+W0, W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
+
+
+def philox4x32_10(ctr, key):
+    """ctr (..., 4) uint32, key (..., 2) uint32 -> (..., 4) uint32."""
+    c = [np.asarray(ctr[..., i], dtype=np.uint32).copy() for i in range(4)]
+    k0 = np.asarray(key[..., 0], dtype=np.uint32).copy()
+    k1 = np.asarray(key[..., 1], dtype=np.uint32).copy()
+    with np.errstate(over='ignore'):
+        for r in range(10):
+            if r:
+                k0 = (k0 + W0).astype(np.uint32)
+                k1 = (k1 + W1).astype(np.uint32)
+            p0 = M0 * c[0].astype(np.uint64)
+            p1 = M1 * c[2].astype(np.uint64)
+            hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), p0.astype(np.uint32)
+            hi1, lo1 = (p1 >> np.uint64(32)).astype(np.uint32), p1.astype(np.uint32)
+            c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
+    return np.stack(c, axis=-1)
+
+
+def box_muller4(u):
+    """(..., 4) uint32 -> (..., 4) float64 standard normals: pairs (u0,u1) and (u2,u3);
+    radius from the top 24 bits of the first word, angle (in revolutions) from the top 24 bits of the second."""
+    u = np.asarray(u, dtype=np.uint32)
+    out = []
+    for a, b in ((0, 1), (2, 3)):
+        u1 = ((u[..., a] >> np.uint32(8)).astype(np.float64) + 0.5) * 2.0 ** -24
+        ang = (u[..., b] >> np.uint32(8)).astype(np.float64) * 2.0 ** -24
+        r = np.sqrt(-2.0 * np.log(u1))
+        out += [r * np.cos(2 * np.pi * ang), r * np.sin(2 * np.pi * ang)]
+    return np.stack(out, axis=-1)
+
+
+def cell_noise(seed, cells, L, S):
+    """The (len(cells), L, S) noise blocks of the given cell ids (n*K + k) under `seed`.
+    Block b = (i >> 1) * ceil(S/2) + (s >> 1) of a cell holds elements (i, s), (i, s+1), (i+1, s), (i+1, s+1)."""
+    cells = np.asarray(cells, dtype=np.uint64)
+    SP, LP = (S + 1) // 2, (L + 1) // 2
+    blk = np.arange(LP * SP, dtype=np.uint32)
+    ctr = np.zeros((cells.size, blk.size, 4), dtype=np.uint32)
+    ctr[..., 0] = (cells & np.uint64(0xFFFFFFFF)).astype(np.uint32)[:, None]
+    ctr[..., 1] = (cells >> np.uint64(32)).astype(np.uint32)[:, None]
+    ctr[..., 2] = blk[None, :]
+    key = np.zeros((cells.size, blk.size, 2), dtype=np.uint32)
+    key[..., 0] = np.uint32(seed & 0xFFFFFFFF)
+    key[..., 1] = np.uint32((seed >> 32) & 0xFFFFFFFF)
+    z = box_muller4(philox4x32_10(ctr, key))                 # (cells, blocks, 4)
+    out = np.zeros((cells.size, L, S))
+    for ip in range(LP):
+        for sp in range(SP):
+            b = ip * SP + sp
+            for j, (di, ds) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+                i, s = 2 * ip + di, 2 * sp + ds
+                if i < L and s < S:
+                    out[:, i, s] = z[:, b, j]
+    return out

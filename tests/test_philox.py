@@ -1,0 +1,94 @@
+"""In-kernel noise (reference models/svae.py:113-114: tf.random_normal inside the step = TensorFlow's Philox stream).
+CPU: the oracle's Philox4x32-10 against the Random123 known-answer vectors.  GPU: the kernels' stream equals the
+oracle's element for element; the in-kernel E-step equals the E-step fed with the materialised stream; statistics of
+1e7 draws (moments, Kolmogorov-Smirnov); the ELBO of a training step under both noise sources agrees in distribution."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox
+
+# Random123 kat_vectors, philox4x32 10 rounds: (counter, key) -> output
+KAT = [
+    ((0x00000000, 0x00000000, 0x00000000, 0x00000000), (0x00000000, 0x00000000),
+     (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    ((0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff), (0xffffffff, 0xffffffff),
+     (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+     (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+]
+
+
+def test_oracle_philox_known_answers():
+    for ctr, key, want in KAT:
+        got = philox.philox4x32_10(np.array([ctr], dtype=np.uint32), np.array([key], dtype=np.uint32))[0]
+        assert tuple(int(v) for v in got) == want
+
+
+def test_oracle_box_muller_is_standard_normal():
+    from scipy import stats
+    z = philox.cell_noise(123, np.arange(4000), 8, 10).reshape(-1)
+    assert abs(z.mean()) < 5e-3 and abs(z.var() - 1) < 1e-2
+    assert stats.kstest(z, 'norm').pvalue > 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,K,Ld,S', [(37, 16, 8, 10), (9, 5, 3, 7), (130, 10, 6, 10), (11, 7, 8, 3)])
+def test_kernel_stream_equals_oracle(N, K, Ld, S):
+    from vmp_for_svae_amd.models import _svae_ops
+    seed = 0x1234567890ABCDEF
+    got = _svae_ops.PhiloxNoise(seed, S).materialise(N, K, Ld, 'cuda').double().cpu().numpy()
+    want = philox.cell_noise(seed, np.arange(N * K), Ld, S).reshape(N, K, Ld, S)
+    assert np.abs(got - want).max() < 2e-5            # v_log / v_sqrt / v_sin / v_cos vs libm
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,K,Ld,S', [(1000, 16, 8, 10), (77, 10, 6, 10), (50, 5, 2, 10), (40, 4, 3, 5), (33, 16, 8, 6)])
+def test_in_kernel_noise_equals_materialised_stream(N, K, Ld, S):
+    """E-step with eps drawn in the kernel == E-step fed with the same stream as a tensor (value AND gradients)."""
+    from vmp_for_svae_amd.models import svae, _svae_ops
+    g = torch.Generator(device='cuda').manual_seed(1)
+    prior, theta = svae.init_mm(K, Ld, seed=0, param_device='cuda')
+    outs = []
+    for mode in ('philox', 'tensor'):
+        eta1 = torch.randn(N, Ld, device='cuda', generator=torch.Generator(device='cuda').manual_seed(2)).requires_grad_(True)
+        eta2d = (-0.5 * torch.nn.functional.softplus(torch.randn(N, Ld, device='cuda', generator=torch.Generator(device='cuda').manual_seed(3)))).requires_grad_(True)
+        phi = [p.detach().requires_grad_(True) for p in svae.init_recognition_params(theta, K, seed=0, param_device='cuda')]
+        noise = 'philox' if mode == 'philox' else _svae_ops.PhiloxNoise(99, S).materialise(N, K, Ld, 'cuda')
+        x, lz, pt, _ = svae.e_step((eta1, eta2d), phi, S, seed=99, noise=noise, theta=theta)
+        loss = (x * 0.01).sum() + (torch.exp(lz) * (pt.T_prime + lz)).sum()
+        gr = torch.autograd.grad(loss, [eta1, eta2d] + phi)
+        outs.append([x, lz, pt.T_prime] + list(gr))
+    for a, b in zip(*outs):
+        scale = b.abs().max().clamp_min(1e-30)
+        assert ((a - b).abs().max() / scale).item() < 2e-6
+
+
+@pytest.mark.gpu
+def test_in_kernel_noise_statistics_and_elbo():
+    from scipy import stats
+    from vmp_for_svae_amd.models import svae, _svae_ops
+    z = _svae_ops.PhiloxNoise(7, 10).materialise(8000, 16, 8, 'cuda').reshape(-1)        # 1.02e7 draws
+    m, v = z.double().mean().item(), z.double().var().item()
+    sk = ((z.double() - m) ** 3).mean().item() / v ** 1.5
+    ku = ((z.double() - m) ** 4).mean().item() / v ** 2
+    assert abs(m) < 1.5e-3 and abs(v - 1) < 2e-3 and abs(sk) < 3e-3 and abs(ku - 3) < 1e-2
+    assert stats.kstest(z[:2_000_000].cpu().numpy(), 'norm').pvalue > 1e-3
+    z2 = _svae_ops.PhiloxNoise(8, 10).materialise(8000, 16, 8, 'cuda').reshape(-1)       # another key: uncorrelated
+    assert abs((z * z2).double().mean().item()) < 1.5e-3
+    # the regulariser of the ELBO under in-kernel noise vs torch.randn noise: same distribution (means within 4 sigma)
+    N, K, Ld, S = 20000, 16, 8, 10
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    eta1 = torch.randn(N, Ld, device='cuda', generator=gen)
+    eta2d = -0.5 * torch.nn.functional.softplus(torch.randn(N, Ld, device='cuda', generator=gen))
+    prior, theta = svae.init_mm(K, Ld, seed=0, param_device='cuda')
+    phi = list(svae.init_recognition_params(theta, K, seed=0, param_device='cuda'))
+    vals = {'philox': [], 'torch': []}
+    with torch.no_grad():
+        for rep in range(6):
+            for mode in vals:
+                x, lz, pt, _ = svae.e_step((eta1, eta2d), phi, S, seed=100 + rep, noise='philox' if mode == 'philox' else None, theta=theta)
+                vals[mode].append((torch.exp(lz) * (pt.T_prime + lz)).sum().item() / N)
+    a, b = np.array(vals['philox']), np.array(vals['torch'])
+    sig = np.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b))
+    assert abs(a.mean() - b.mean()) < 4 * sig + 1e-6 * abs(b.mean()), (a, b)

@@ -13,7 +13,7 @@ eta2d = (-0.5 * torch.nn.functional.softplus(torch.randn(N, Ld, device=dev, gene
 noise = torch.randn(N, K, Ld, S, device=dev, generator=g)
 Gx = torch.randn(N, K, S, Ld, device=dev, generator=g) * 0.01
 Glz = torch.randn(N, K, device=dev, generator=g) * 0.1
-tf, tb = [], []
+tf, tb, tp = [], [], []
 for it in range(8):
     a, b, c = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     a.record()
@@ -27,4 +27,14 @@ for it in range(8):
     if it >= 2:
         tf.append(a.elapsed_time(b)); tb.append(b2.elapsed_time(c))
     del x, lz, pt, grads
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    with torch.no_grad():
+        x, lz, pt, _ = svae.e_step((eta1, eta2d), phi, S, seed=it, noise='philox', theta=theta)
+    b.record()
+    torch.cuda.synchronize()
+    if it >= 2:
+        tp.append(a.elapsed_time(b))
+    del x, lz, pt
+print('T2 forward with in-kernel Philox noise: %.3f ms' % np.median(tp))
 print('T2 N=%d K=%d: fwd %.3f ms  bwd %.3f ms   (bwd 10.4 GB -> %.0f GB/s = %.2f of 8 TB/s)' % (N, K, np.median(tf), np.median(tb), 4.0 * N * (2.0 * K * S * Ld + 4 * Ld + 3 * K) / (np.median(tb) * 1e-3) / 1e9, 4.0 * N * (2.0 * K * S * Ld + 4 * Ld + 3 * K) / (np.median(tb) * 1e-3) / 8e12))

@@ -45,6 +45,7 @@ struct EFwdArgs {
     float* Tp;              // (N,K)
     long long N;
     int K, S, vec_ok;
+    unsigned long long seed;   // in-kernel noise (noise == NULL): Philox4x32-10 key
 };
 
 template <int L>
@@ -1020,6 +1021,59 @@ __global__ __launch_bounds__(SV_FWD_MAX_NW * WAVE) void svae_estep_fwd3_kernel(E
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// In-kernel noise (reference models/svae.py:113-114 draws eps inside the step with TensorFlow's Philox stream).
+// Philox4x32-10 (Salmon et al., SC'11; Random123 known-answer vectors in tests/test_philox.py) keyed by the seed, counter
+// = (cell id low, cell id high, block, 0) with cell = n K + k; block b = (i >> 1) ceil(S/2) + (s >> 1) yields the four
+// standard normals of elements (i, s), (i, s+1), (i+1, s), (i+1, s+1) by Box-Muller (radius from the top 24 bits of one
+// word, angle from the top 24 bits of the next; v_log / v_sqrt / v_sin / v_cos).  Stateless: any kernel (or the host
+// oracle, oracle/philox.py) can regenerate the same element from (seed, n, k, i, s).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        if (r) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+        c[1] = (unsigned)p1; c[3] = (unsigned)p0; c[0] = n0; c[2] = n2;
+    }
+}
+__device__ __forceinline__ v2f box_muller(unsigned a, unsigned b) {
+    const float u1 = ((float)(a >> 8) + 0.5f) * 5.9604644775390625e-08f;         // (0, 1)
+    const float ang = (float)(b >> 8) * 5.9604644775390625e-08f;                  // revolutions, [0, 1)
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1), v_log_f32 = log2
+    return v2f{rad * __builtin_amdgcn_cosf(ang), rad * __builtin_amdgcn_sinf(ang)};
+}
+// the four normals of block `blk` of cell `cell`: (i,s), (i,s+1), (i+1,s), (i+1,s+1)
+__device__ __forceinline__ void philox_normal4(unsigned long long cell, unsigned blk, unsigned long long seed, v2f& lo, v2f& hi) {
+    unsigned c[4] = {(unsigned)cell, (unsigned)(cell >> 32), blk, 0u};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+    lo = box_muller(c[0], c[1]);
+    hi = box_muller(c[2], c[3]);
+}
+
+struct NoiseArgs { float* out; long long cells; int L, S; unsigned long long seed; };
+// Materialises the same stream as a (cells, L, S) tensor: for shapes the in-kernel path does not cover, and for tests.
+__global__ __launch_bounds__(256) void philox_noise_kernel(NoiseArgs a) {
+    const int SP = (a.S + 1) >> 1, LP = (a.L + 1) >> 1, NB = SP * LP;
+    const long long total = a.cells * NB;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long cell = e / NB;
+        const int b = (int)(e - cell * NB), ip = b / SP, sp = b - ip * SP;
+        v2f lo, hi;
+        philox_normal4((unsigned long long)cell, (unsigned)b, a.seed, lo, hi);
+        float* o = a.out + cell * a.L * a.S;
+        const int i = 2 * ip, s2 = 2 * sp;
+        o[i * a.S + s2] = lo.x;
+        if (s2 + 1 < a.S) o[i * a.S + s2 + 1] = lo.y;
+        if (i + 1 < a.L) {
+            o[(i + 1) * a.S + s2] = hi.x;
+            if (s2 + 1 < a.S) o[(i + 1) * a.S + s2 + 1] = hi.y;
+        }
+    }
+}
+
 // Forward kernel, LDS-DMA form.  Measured on the single-buffered kernels above (C3): loads+compute 1.3 ms,
 // compute+stores 1.4 ms, everything 2.8 ms - a wave's load phase and store phase do not overlap, and 7 waves per CU
 // with <=10 KB each in flight cannot hide it.  Here every wave owns TWO noise buffers: the next tile streams in with
@@ -1030,7 +1084,9 @@ __global__ __launch_bounds__(SV_FWD_MAX_NW * WAVE) void svae_estep_fwd3_kernel(E
 // cell's last float4.  One s_waitcnt vmcnt(0) per tile retires the tile's DMA (issued a whole tile earlier) and
 // the previous tile's stores; the row loads of the tile are consumed BEFORE the next DMA is issued, so no
 // compiler-generated wait ever covers a DMA in flight.
-template <int L, int ST>
+// RNG = true: no noise tensor at all - eps is generated in registers (Philox4x32-10, above) right where it is consumed;
+// the LDS tile then only serves the (cell, S, L) output transposition.
+template <int L, int ST, bool RNG>
 __global__ __launch_bounds__(4 * WAVE) void svae_estep_fwd4_kernel(EFwdArgs a, int CS_rt) {
     constexpr int TRI = SvGeo<L>::TRI;
     constexpr int TP = (TRI + 1) / 2, LP = (L + 1) / 2;
@@ -1149,7 +1205,7 @@ __global__ __launch_bounds__(4 * WAVE) void svae_estep_fwd4_kernel(EFwdArgs a, i
     };
 
     long long t = (long long)blockIdx.x * nw + wave;
-    if (t < ntiles) issue_dma(t, buf0);
+    if constexpr (!RNG) { if (t < ntiles) issue_dma(t, buf0); }
     int cur = 0;
     // the encoder rows of a tile are fetched one tile ahead as well (plain loads, consumed before the next DMA is issued)
     float e1r[L], e2r[L];
@@ -1209,7 +1265,7 @@ __global__ __launch_bounds__(4 * WAVE) void svae_estep_fwd4_kernel(EFwdArgs a, i
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < L; ++i) asm volatile("" : "+v"(e1r[i]), "+v"(e2r[i]));
-        if (t + tstride < ntiles) issue_dma(t + tstride, buf0 + (cur ^ 1) * (WAVE * CS));
+        if constexpr (!RNG) { if (t + tstride < ntiles) issue_dma(t + tstride, buf0 + (cur ^ 1) * (WAVE * CS)); }
 
         v2f Lm2[TP], av2[LP];
 #pragma unroll
@@ -1220,7 +1276,19 @@ __global__ __launch_bounds__(4 * WAVE) void svae_estep_fwd4_kernel(EFwdArgs a, i
         // ---- samples (two at a time) and the per-cell regulariser term
         v2f eps2 = v2f{0.f, 0.f}, qth = v2f{0.f, 0.f};
         float* cell = et + lane * CS;
+        const unsigned long long cellid = (unsigned long long)(on ? row : 0) * (unsigned long long)K + (unsigned long long)kc;
         auto read_pair = [&](int s2, v2f (&eo)[L]) {
+            if constexpr (RNG) {
+                const unsigned SPn = (unsigned)(S + 1) >> 1;
+#pragma unroll
+                for (int ip = 0; ip < LP; ++ip) {
+                    v2f lo, hi;
+                    philox_normal4(cellid, (unsigned)ip * SPn + ((unsigned)s2 >> 1), a.seed, lo, hi);
+                    eo[2 * ip] = lo;
+                    if (2 * ip + 1 < L) eo[2 * ip + 1] = hi;
+                }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < L; ++i) {
                 if constexpr (ST != 0 && (ST & 1) == 0) eo[i] = *reinterpret_cast<const v2f*>(cell + i * S + s2);   // 8-byte aligned: CS, S, s even
@@ -1235,7 +1303,7 @@ __global__ __launch_bounds__(4 * WAVE) void svae_estep_fwd4_kernel(EFwdArgs a, i
             v2f z[L], ec[L];
 #pragma unroll
             for (int i = 0; i < L; ++i) ec[i] = en[i];
-            read_pair((s + 2 < S) ? s + 2 : s, en);
+            if (!RNG || s + 2 < S) read_pair((s + 2 < S) ? s + 2 : s, en);
 #pragma unroll
             for (int i = 0; i < L; ++i) {
                 v2f e = ec[i];
@@ -1544,17 +1612,47 @@ size_t vmp_svae_workspace_bytes(int64_t N, int K, int L) {
 
 int vmp_svae_bwd_blocks(int64_t N, int K) { return sv_blocks(N, K); }
 
-int vmp_svae_estep_fwd(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
-                       const float* noise, const float* mk, const float* Wk, const float* kappa, const float* nu,
-                       int64_t N, int K, int L, int S, float* x, float* lz, float* Tp, void* stream) {
-    int rc = check_sv(N, K, L, S);
-    if (rc) return rc;
-    if (!eta1 || !eta2d || !hk || !Pk || !bias || !noise || !mk || !Wk || !kappa || !x || !lz || !Tp) {
-        set_error("vmp_svae_estep_fwd: null pointer");
-        return VMP_E_BADARG;
+// LDS-DMA / in-kernel-noise forward kernel: launch geometry, or 0 waves when the shape is not covered
+static int fwd4_plan(int K, int L, int S, int& CS, size_t& lds4) {
+    if ((L * S) % 4 != 0) return 0;
+    if ((size_t)(L * S | 1) * WAVE * sizeof(float) > 36 * 1024) return 0;
+    CS = L * S;
+    if (((CS >> 2) & 1) == 0) CS += 4;
+    const size_t table = (size_t)((K * ((L * (L + 1) / 2) | 1) + 3) & ~3) * sizeof(float);
+    const size_t pw = (size_t)(2 * WAVE * CS + WAVE) * sizeof(float);
+    int nw4 = (int)((158 * 1024 - table) / pw);
+    if (nw4 > 4) nw4 = 4;
+    if (nw4 < 1) return 0;
+    lds4 = table + pw * nw4;
+    return nw4;
+}
+
+static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
+    const long long N = a.N;
+    const int K = a.K, S = a.S;
+    const float* noise = a.noise;
+    int rc;
+    if (rng) {
+        int CS = 0;
+        size_t lds4 = 0;
+        const int nw4 = fwd4_plan(K, L, S, CS, lds4);
+        if (nw4 < 1) { set_error("in-kernel noise covers L*S %% 4 == 0 tiles that fit the LDS only (L=%d, S=%d)", L, S); return VMP_E_DIM; }
+        const int RPT4 = WAVE / K;
+        long long bl = ((N + RPT4 - 1) / RPT4 + nw4 - 1) / nw4;
+        if (bl > 256) bl = 256;
+        rc = -1;
+        VMP_DISPATCH_L(L, {
+            if (S == 10) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<LL, 10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                hipLaunchKernelGGL((svae_estep_fwd4_kernel<LL, 10, true>), dim3((int)bl), dim3(nw4 * WAVE), lds4, static_cast<hipStream_t>(stream), a, CS);
+            } else {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<LL, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                hipLaunchKernelGGL((svae_estep_fwd4_kernel<LL, 0, true>), dim3((int)bl), dim3(nw4 * WAVE), lds4, static_cast<hipStream_t>(stream), a, CS);
+            }
+            rc = check_launch("svae_estep_fwd4_kernel<rng>");
+        });
+        return rc;
     }
-    EFwdArgs a{eta1, eta2d, hk, Pk, bias, noise, mk, Wk, kappa, nu, x, lz, Tp, N, K, S, 0};
-    a.vec_ok = al16(noise) && al16(x);
     {
         const int SP = (S + 1) / 2;
         static const int use_v2 = getenv("VMP_SV_FWD_V2") ? 1 : 0;   // measured slower than the staged form at C3 (4.1 vs 3.6 ms)
@@ -1608,11 +1706,11 @@ int vmp_svae_estep_fwd(const float* eta1, const float* eta2d, const float* hk, c
             rc = -1;
             VMP_DISPATCH_L(L, {
                 if (S == 10) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<LL, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
-                    hipLaunchKernelGGL((svae_estep_fwd4_kernel<LL, 10>), dim3((int)bl), dim3(nw4 * WAVE), lds4, static_cast<hipStream_t>(stream), a, CS);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<LL, 10, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                    hipLaunchKernelGGL((svae_estep_fwd4_kernel<LL, 10, false>), dim3((int)bl), dim3(nw4 * WAVE), lds4, static_cast<hipStream_t>(stream), a, CS);
                 } else {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<LL, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
-                    hipLaunchKernelGGL((svae_estep_fwd4_kernel<LL, 0>), dim3((int)bl), dim3(nw4 * WAVE), lds4, static_cast<hipStream_t>(stream), a, CS);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<LL, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                    hipLaunchKernelGGL((svae_estep_fwd4_kernel<LL, 0, false>), dim3((int)bl), dim3(nw4 * WAVE), lds4, static_cast<hipStream_t>(stream), a, CS);
                 }
                 rc = check_launch("svae_estep_fwd4_kernel");
             });
@@ -1660,6 +1758,60 @@ int vmp_svae_estep_fwd(const float* eta1, const float* eta2d, const float* hk, c
         rc = check_launch("svae_estep_fwd_kernel");
     });
     return rc;
+}
+
+int vmp_svae_estep_fwd(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
+                       const float* noise, const float* mk, const float* Wk, const float* kappa, const float* nu,
+                       int64_t N, int K, int L, int S, float* x, float* lz, float* Tp, void* stream) {
+    int rc = check_sv(N, K, L, S);
+    if (rc) return rc;
+    if (!eta1 || !eta2d || !hk || !Pk || !bias || !noise || !mk || !Wk || !kappa || !x || !lz || !Tp) {
+        set_error("vmp_svae_estep_fwd: null pointer");
+        return VMP_E_BADARG;
+    }
+    EFwdArgs a{eta1, eta2d, hk, Pk, bias, noise, mk, Wk, kappa, nu, x, lz, Tp, N, K, S, 0, 0ull};
+    a.vec_ok = al16(noise) && al16(x);
+    return run_fwd(a, L, stream, false);
+}
+
+int vmp_svae_rng_in_kernel(int K, int L, int S) {
+    int CS = 0;
+    size_t lds4 = 0;
+    return (K >= 1 && K <= 64 && L >= 1 && L <= 8 && fwd4_plan(K, L, S, CS, lds4) >= 1) ? 1 : 0;
+}
+
+int vmp_svae_philox_noise(uint64_t seed, int64_t N, int K, int L, int S, float* noise, void* stream) {
+    int rc = check_sv(N, K, L, S);
+    if (rc) return rc;
+    if (!noise) { set_error("vmp_svae_philox_noise: null pointer"); return VMP_E_BADARG; }
+    NoiseArgs na{noise, (long long)N * K, L, S, (unsigned long long)seed};
+    const long long total = na.cells * ((S + 1) / 2) * ((L + 1) / 2);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(philox_noise_kernel, dim3((int)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), na);
+    return check_launch("philox_noise_kernel");
+}
+
+int vmp_svae_estep_fwd_rng(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
+                           uint64_t seed, const float* mk, const float* Wk, const float* kappa, const float* nu,
+                           int64_t N, int K, int L, int S, float* x, float* lz, float* Tp, float* noise_ws, void* stream) {
+    int rc = check_sv(N, K, L, S);
+    if (rc) return rc;
+    if (!eta1 || !eta2d || !hk || !Pk || !bias || !mk || !Wk || !kappa || !x || !lz || !Tp) {
+        set_error("vmp_svae_estep_fwd_rng: null pointer");
+        return VMP_E_BADARG;
+    }
+    EFwdArgs a{eta1, eta2d, hk, Pk, bias, nullptr, mk, Wk, kappa, nu, x, lz, Tp, N, K, S, 0, (unsigned long long)seed};
+    if (vmp_svae_rng_in_kernel(K, L, S)) {
+        a.vec_ok = al16(x);
+        return run_fwd(a, L, stream, true);
+    }
+    if (!noise_ws) { set_error("vmp_svae_estep_fwd_rng: this shape needs the (N,K,L,S) noise workspace"); return VMP_E_WS; }
+    rc = vmp_svae_philox_noise(seed, N, K, L, S, noise_ws, stream);
+    if (rc) return rc;
+    a.noise = noise_ws;
+    a.vec_ok = al16(noise_ws) && al16(x);
+    return run_fwd(a, L, stream, false);
 }
 
 int vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,

@@ -9,6 +9,20 @@ def _c(t, name, shape=None):
     return L.dev_f32(t, name, shape)
 
 
+class PhiloxNoise(object):
+    """Stand-in for the (N,K,L,S) noise tensor: "generate it in the kernel" (csrc/vmp_svae.hip, Philox4x32-10 keyed by
+    `seed`; include/vmp_hip.h vmp_svae_estep_fwd_rng).  The reference draws eps inside the step the same way
+    (models/svae.py:113-114).  materialise() returns the identical stream as a tensor."""
+
+    def __init__(self, seed, nb_samples):
+        self.seed, self.S = int(seed) & 0xFFFFFFFFFFFFFFFF, int(nb_samples)
+
+    def materialise(self, N, K, Ld, device):
+        out = torch.empty(N, K, Ld, self.S, dtype=torch.float32, device=device)
+        L.check(L.lib().vmp_svae_philox_noise(self.seed, N, K, Ld, self.S, L.ptr(out), L.stream()), 'vmp_svae_philox_noise')
+        return out
+
+
 class SvaeEStepFn(torch.autograd.Function):
     """(eta1, eta2d, hk, Pk, bias, noise, mk, Wk, kappa, nu) -> (x (N,K,S,L), log_z (N,K), T' (N,K)).
     Gradients flow to eta1, eta2d (N,L), to hk, Pk, bias (K-sized, summed over n) and - for the Student-t theta of the
@@ -22,19 +36,31 @@ class SvaeEStepFn(torch.autograd.Function):
         eta2d = _c(eta2d, 'eta2_diag', (N, Ld))
         K = hk.shape[0]
         hk, Pk, bias = _c(hk, 'eta1_phi2', (K, Ld)), _c(Pk, 'P_k', (K, Ld, Ld)), _c(bias, 'bias_k', (K,))
-        noise = _c(noise, 'noise')
-        if noise.dim() != 4 or tuple(noise.shape[:3]) != (N, K, Ld):
-            raise L.VmpError('noise must have shape (N,K,L,S), got %s' % (tuple(noise.shape),))
-        S = noise.shape[3]
+        rng = noise if isinstance(noise, PhiloxNoise) else None
+        if rng is None:
+            noise = _c(noise, 'noise')
+            if noise.dim() != 4 or tuple(noise.shape[:3]) != (N, K, Ld):
+                raise L.VmpError('noise must have shape (N,K,L,S), got %s' % (tuple(noise.shape),))
+            S = noise.shape[3]
+        else:
+            S = rng.S
         mk, Wk, kappa = _c(mk, 'm_k', (K, Ld)), _c(Wk, 'W_k', (K, Ld, Ld)), _c(kappa, 'kappa_k', (K,))
         nu = None if nu is None else _c(nu, 'nu_k', (K,))
         f32 = dict(dtype=torch.float32, device=eta1.device)
         x = torch.empty(N, K, S, Ld, **f32)
         lz = torch.empty(N, K, **f32)
         Tp = torch.empty(N, K, **f32)
-        L.check(L.lib().vmp_svae_estep_fwd(L.ptr(eta1), L.ptr(eta2d), L.ptr(hk), L.ptr(Pk), L.ptr(bias), L.ptr(noise),
-                                           L.ptr(mk), L.ptr(Wk), L.ptr(kappa), L.ptr(nu), N, K, Ld, S, L.ptr(x),
-                                           L.ptr(lz), L.ptr(Tp), L.stream()), 'vmp_svae_estep_fwd')
+        if rng is not None:
+            ws = None
+            if not L.lib().vmp_svae_rng_in_kernel(K, Ld, S):     # shape outside the in-kernel path: same stream via a scratch tensor
+                ws = torch.empty(N, K, Ld, S, **f32)
+            L.check(L.lib().vmp_svae_estep_fwd_rng(L.ptr(eta1), L.ptr(eta2d), L.ptr(hk), L.ptr(Pk), L.ptr(bias), rng.seed,
+                                                   L.ptr(mk), L.ptr(Wk), L.ptr(kappa), L.ptr(nu), N, K, Ld, S, L.ptr(x),
+                                                   L.ptr(lz), L.ptr(Tp), L.ptr(ws), L.stream()), 'vmp_svae_estep_fwd_rng')
+        else:
+            L.check(L.lib().vmp_svae_estep_fwd(L.ptr(eta1), L.ptr(eta2d), L.ptr(hk), L.ptr(Pk), L.ptr(bias), L.ptr(noise),
+                                               L.ptr(mk), L.ptr(Wk), L.ptr(kappa), L.ptr(nu), N, K, Ld, S, L.ptr(x),
+                                               L.ptr(lz), L.ptr(Tp), L.stream()), 'vmp_svae_estep_fwd')
         ctx.save_for_backward(eta1, eta2d, hk, Pk, bias, mk, Wk, x, lz, *([nu] if nu is not None else []))
         ctx.dims = (N, K, Ld, S)
         return x, lz, Tp

@@ -120,14 +120,20 @@ def compute_log_z_given_y(eta1_phi1, eta2_phi1, eta1_phi2, eta2_phi2, pi_phi2, n
 
 def e_step(phi_enc, phi_gmm, nb_samples, seed=0, name="e_step", noise=None, theta=None):
     """reference svae.py:14-47.  Returns (x_k_samples (N,K,S,L), log_z (N,K), phi_tilde, dbg).
-    `noise` (N,K,L,S) replaces tf.random_normal (default: torch.randn with `seed`); when `theta` (natural NIW /
-    Dirichlet parameters) is given, the per-sample densities compute_elbo needs are evaluated in the same pass."""
+    `noise` (N,K,L,S) replaces tf.random_normal (default: torch.randn with `seed`); noise='philox' draws eps INSIDE the
+    kernel (Philox4x32-10 keyed by `seed`, as the reference's tf.random_normal does inside its step, svae.py:113-114):
+    no (N,K,L,S) tensor is written or read.  When `theta` (natural NIW / Dirichlet parameters) is given, the per-sample
+    densities compute_elbo needs are evaluated in the same pass."""
     eta1_phi1, eta2_diag = phi_enc
     N, Ld = eta1_phi1.shape
     # unpack_recognition_gmm + the k-only part of compute_log_z_given_y in one launch (autograd: one more)
     eta1_phi2, P, bias = _svae_ops.PhiPrepFn.apply(*phi_gmm)
     K = eta1_phi2.shape[0]
-    if noise is None:
+    if isinstance(noise, str):
+        if noise != 'philox':
+            raise ValueError("noise must be a tensor, None or 'philox'")
+        noise = _svae_ops.PhiloxNoise(seed, nb_samples)
+    elif noise is None:
         g = torch.Generator(device=eta1_phi1.device).manual_seed(int(seed))
         noise = torch.randn(N, K, Ld, nb_samples, generator=g, device=eta1_phi1.device)
     mk, Wk, kap, nu = _theta_pack(theta) if theta is not None else _neutral_theta(K, Ld, eta1_phi1.device)

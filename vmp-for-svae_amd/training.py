@@ -90,7 +90,8 @@ def unpack_after_allreduce(buf, stats_shape, grad_shapes, n_scalars):
 
 class SVAETrainer(object):
     def __init__(self, K, Ld, U, Dy, nb_samples=10, lr=3e-4, lrcvi=0.2, decay_rate=0.95, stddev_init_nn=0.01, seed=0,
-                 device='cuda', m_uniform=None, pi_normal=None, group=None, smm=False, dof=5.0, fused_decoder=True):
+                 device='cuda', m_uniform=None, pi_normal=None, group=None, smm=False, dof=5.0, fused_decoder=True,
+                 rng='torch'):
         self.K, self.L, self.S = K, Ld, nb_samples
         self.lr, self.lrcvi0, self.decay_rate = lr, lrcvi, decay_rate
         self.group = group
@@ -102,6 +103,9 @@ class SVAETrainer(object):
         self.seed = seed
         self.smm = smm
         self.fused_decoder = fused_decoder      # decoder + reconstruction term in the fused MFMA kernels when covered
+        if rng not in ('torch', 'philox'):
+            raise ValueError("rng must be 'torch' (noise tensor from torch.randn) or 'philox' (drawn inside the E-step kernel)")
+        self.rng = rng                          # where eps comes from when the caller injects none
         self.gmm_prior, self.theta = svae.init_mm(K, Ld, seed=seed, param_device=self.device, m_uniform=m_uniform)
         self.phi_gmm = list(svae.init_recognition_params(self.theta, K, seed=seed, param_device=self.device,
                                                          pi_normal=pi_normal))
@@ -129,6 +133,8 @@ class SVAETrainer(object):
         return names, ts
 
     def forward(self, y, noise=None, z_draws=None, u=None):
+        if noise is None and self.rng == 'philox':
+            noise = 'philox'
         out = svae.inference(y, self.phi_gmm, self.encoder_layers, self.decoder_layers, self.S,
                              stddev_init_nn=self.stddev_init_nn, seed=self.seed + self.global_step, noise=noise,
                              z_draws=z_draws, theta=self.theta, lazy_decoder=self.fused_decoder, u=u)
