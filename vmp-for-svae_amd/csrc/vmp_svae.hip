@@ -58,49 +58,50 @@ __host__ __device__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j
 
 // Cholesky of the cell matrix (lower, packed).  On return Lm holds the factor with the DIAGONAL REPLACED BY ITS
 // RECIPROCAL rd_j = 1/Lt_jj (every later use multiplies by it), and half_logdet = sum_j log Lt_jj.
+// Right-looking form: once column j is final, every remaining entry takes its update -L_ij L_qj at once.  Each entry still
+// receives its terms in the order p = 0, 1, 2, ... (bitwise the same result as the left-looking loop), but the updates
+// of one column are mutually independent, so the dependency chain is L steps deep instead of ~L^2/2 - with two waves
+// per SIMD that is what the VALU waits on (SQ_WAIT_INST_ANY 30 % of the backward kernel in round 1).
 template <int L>
 __device__ __forceinline__ void cell_cholesky(float (&Lm)[SvGeo<L>::TRI], float& half_logdet) {
     float prod_log = 0.f;
 #pragma unroll
     for (int j = 0; j < L; ++j) {
-        float s = Lm[tri(j, j)];
-#pragma unroll
-        for (int p = 0; p < j; ++p) s = fmaf(-Lm[tri(j, p)], Lm[tri(j, p)], s);
+        const float s = Lm[tri(j, j)];
         const float rd = __builtin_amdgcn_rsqf(s);
         prod_log += __logf(s);
 #pragma unroll
-        for (int i = j + 1; i < L; ++i) {
-            float t = Lm[tri(i, j)];
-#pragma unroll
-            for (int p = 0; p < j; ++p) t = fmaf(-Lm[tri(i, p)], Lm[tri(j, p)], t);
-            Lm[tri(i, j)] = t * rd;
-        }
+        for (int i = j + 1; i < L; ++i) Lm[tri(i, j)] *= rd;
         Lm[tri(j, j)] = rd;
+#pragma unroll
+        for (int i = j + 1; i < L; ++i)
+#pragma unroll
+            for (int q = j + 1; q <= i; ++q) Lm[tri(i, q)] = fmaf(-Lm[tri(i, j)], Lm[tri(q, j)], Lm[tri(i, q)]);
     }
     half_logdet = 0.5f * prod_log;
 }
 
-// v <- Lt^-1 v   (forward substitution; diagonal of Lm holds reciprocals)
+// v <- Lt^-1 v   (forward substitution, column-oriented: v_j final -> all v_i, i > j, updated independently; the terms
+// reach every v_i in the same order p = 0, 1, ... as in the row-oriented loop; diagonal of Lm holds reciprocals)
 template <int L>
 __device__ __forceinline__ void solve_lower(const float (&Lm)[SvGeo<L>::TRI], float (&v)[L]) {
 #pragma unroll
-    for (int i = 0; i < L; ++i) {
-        float t = v[i];
+    for (int j = 0; j < L; ++j) {
+        v[j] *= Lm[tri(j, j)];
 #pragma unroll
-        for (int p = 0; p < i; ++p) t = fmaf(-Lm[tri(i, p)], v[p], t);
-        v[i] = t * Lm[tri(i, i)];
+        for (int i = j + 1; i < L; ++i) v[i] = fmaf(-Lm[tri(i, j)], v[j], v[i]);
     }
 }
 
-// v <- Lt^-T v   (back substitution)
+// v <- Lt^-T v   (back substitution, column-oriented; terms reach v_i in the order p = L-1, L-2, ...: the row-oriented
+// loop summed p = i+1, ..., L-1, so the rounding differs in the last bits)
 template <int L>
 __device__ __forceinline__ void solve_lower_t(const float (&Lm)[SvGeo<L>::TRI], float (&v)[L]) {
 #pragma unroll
-    for (int i = L - 1; i >= 0; --i) {
-        float t = v[i];
+    for (int j = L - 1; j >= 0; --j) {
+        v[j] *= Lm[tri(j, j)];
 #pragma unroll
-        for (int p = i + 1; p < L; ++p) t = fmaf(-Lm[tri(p, i)], v[p], t);
-        v[i] = t * Lm[tri(i, i)];
+        for (int i = 0; i < j; ++i) v[i] = fmaf(-Lm[tri(j, i)], v[j], v[i]);
     }
 }
 
@@ -504,6 +505,8 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
 
     const long long ntiles = (a.N + RPT - 1) / RPT;
     const float invS = 1.0f / (float)S;
+    float nxs[2 * L], ngx[2 * L];
+    bool first_tile = true;
     for (long long t = (long long)blockIdx.x * nw + wave; t < ntiles; t += (long long)gridDim.x * nw) {
         const long long row = t * RPT + r;
         const bool on = lane_on && row < a.N;
@@ -550,7 +553,8 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
         // of ~31 B per launch at C3 (TCP_TCC_READ_REQ), i.e. the kernel was bound by L1<->L2 requests, not by HBM.
         // (one branch around the whole group of loads: skipping the tail prefetches matters - an unconditional
         //  clamped version measured 27% slower)
-        auto load_pair = [&](int s2, float (&xo)[2 * L], float (&go)[2 * L]) {
+        auto load_pair = [&](const float* __restrict__ xc, const float* __restrict__ gc, bool on, int s2,
+                             float (&xo)[2 * L], float (&go)[2 * L]) {
             const bool live = on && s2 < S;
             const bool both = s2 + 1 < S;
             if (live) {
@@ -586,13 +590,15 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
                 xo[L + i] = (live && both) ? xo[L + i] : 0.f; go[L + i] = (live && both) ? go[L + i] : 0.f;
             }
         };
-        float nxs[2 * L], ngx[2 * L];                       // next pair, in flight while this one is used
-        load_pair(0, nxs, ngx);
+        // nxs / ngx: the next pair, in flight while this one is used.  The FIRST pair of a tile was requested before the
+        // previous tile's assembly phase (below), so its latency is covered by ~4 k cycles of arithmetic instead of being
+        // exposed behind the Cholesky of every tile.
+        if (first_tile) { load_pair(xc, gc, on, 0, nxs, ngx); first_tile = false; }
         for (int s0 = 0; s0 < S; s0 += 2) {
             float xp[2 * L], gp[2 * L];
 #pragma unroll
             for (int i = 0; i < 2 * L; ++i) { xp[i] = nxs[i]; gp[i] = ngx[i]; }
-            load_pair(s0 + 2, nxs, ngx);
+            if (s0 + 2 < S) load_pair(xc, gc, on, s0 + 2, nxs, ngx);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
             if (h == 1 && s0 + 1 >= S) break;
@@ -645,6 +651,13 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
                 for (int j = 0; j <= i; ++j) M[tri(i, j)] = fmaf(e, gx[j], M[tri(i, j)]);
             }
             }
+        }
+        {   // first sample pair of this wave's NEXT tile
+            const long long tn = t + (long long)gridDim.x * nw;
+            const long long rown = tn * RPT + r;
+            const bool onn = lane_on && tn < ntiles && rown < a.N;
+            const long long celln = (onn ? rown : 0) * K + kc;
+            load_pair(a.x + celln * LSn, a.Gx + celln * LSn, onn, 0, nxs, ngx);
         }
         // ---- assemble dLoss/dht and dLoss/dPt (symmetric, lower triangle)
         float V[L];
