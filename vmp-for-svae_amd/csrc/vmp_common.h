@@ -15,6 +15,35 @@ constexpr int WAVE = 64;
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// ---- bf16 operand splitting for the XDL matrix pipe (v_mfma_f32_16x16x32_bf16) ------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// bf16(lo) | bf16(hi) << 16, round-to-nearest-even: one v_cvt_pk_bf16_f32.  Deliberately NOT inline assembly: the
+// compiler's hazard recogniser does not see register writes inside an asm block, and a cvt that overwrites a register an
+// in-flight MFMA still reads as its C operand (write-after-read, needs wait states) corrupted one instantiation of the
+// decoder kernel.
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v2f{lo, hi}, bf16x2));
+}
+// v = h + m + l + O(2^-26 |v|): three bf16 terms (8 significant bits each) per value, packed per pair of values.  The
+// moment GEMM keeps the six products of order <= 2 (hh, hm, mh, hl, lh, mm); what it drops (ml, lm, ll and the split
+// residuals) is below 2^-24 |w phi| - fp32 accuracy, as the fp32 MFMA it replaces (a two-term split, three products,
+// is ~2^-17 per product: fine on average at N = 1e6 but visible - 1.4e-5 on r - on a 60-row problem).
+template <int TERMS>
+__device__ __forceinline__ void split_bf16(v2f v, unsigned (&t)[3]) {
+    t[0] = cvt_pk_bf16(v.x, v.y);
+    v2f rem = v - v2f{__uint_as_float(t[0] << 16), __uint_as_float(t[0] & 0xffff0000u)};
+    t[1] = cvt_pk_bf16(rem.x, rem.y);
+    if constexpr (TERMS == 3) {
+        rem = rem - v2f{__uint_as_float(t[1] << 16), __uint_as_float(t[1] & 0xffff0000u)};
+        t[2] = cvt_pk_bf16(rem.x, rem.y);
+    } else {
+        t[2] = 0u;
+    }
+}
+
 // ---- packed fp32 (v_pk_*_f32) against a broadcast parameter -------------------------------------------
 // x holds two independent values (two data rows, or two samples of one cell); the parameter is ONE float,
 // stored two to a 64-bit register pair and broadcast to both halves with op_sel.  A {p, p} splat written in

@@ -69,12 +69,17 @@ __host__ __device__ inline DecGeo dec_geo(int L, int U, int Dy) {
     return q;
 }
 
-// LDS layout (floats).  Operand image entry for MFMA operand `e`, lane l, sub-step v:  (e*64 + l)*4 + v.
+// LDS layout (floats / dwords).  fp32 operand image entry for MFMA operand `e`, lane l, sub-step v:  (e*64 + l)*4 + v.
+// The two U x U products of a tile (layer 1 forward, dh0 backward) run on the XDL pipe as 3-term bf16 splits
+// (vmp_common.h): their images hold, per (output tile t', k-block kb, term), one 16x32 bf16 A operand = 4 dwords per lane,
+// k-slot j of lane group g  <->  hidden unit 16 (2 kb + (j >> 2)) + 4 g + (j & 3) - the two accumulator tiles 2kb, 2kb+1
+// of the producing layer, so the layers still chain in registers.
 template <int UT>
 struct Img {
+    static constexpr int KB = (UT + 1) / 2;             // k-blocks of 32 hidden units
     static constexpr int F0 = 0;                        // [t'][lane][kk<2 (pad 4)]      layer 0
-    static constexpr int F1 = F0 + UT * 256;            // [t'][t][lane][v]               layer 1
-    static constexpr int F2 = F1 + UT * UT * 256;       // [t][lane][v]                   output layer
+    static constexpr int F1 = F0 + UT * 256;            // [t'][kb][term][lane][4]        layer 1 (bf16 x 3)
+    static constexpr int F2 = F1 + UT * KB * 3 * 256;   // [t][lane][v]                   output layer
     static constexpr int F2S = F2 + UT * 256;           // [lane][kk<2 (pad 4)]           shortcut into the output layer
     static constexpr int BIAS0 = F2S + 256;             // 16*UT   b0 zero-padded
     static constexpr int BIAS1 = BIAS0 + 16 * UT;       // 16*UT   b1
@@ -83,12 +88,18 @@ struct Img {
     static constexpr int SG2 = SP2 + 8;                 // 8       sigmoid(bs2_d)
     static constexpr int FWD_END = SG2 + 8;
     static constexpr int B1 = FWD_END;                  // [t'][lane][v]      dh1 = W2 . dO
-    static constexpr int B2 = B1 + UT * 256;            // [t'][t][lane][v]   dh0 = W1 . dh1pre
-    static constexpr int B3 = B2 + UT * UT * 256;       // [t][lane][v]       dx  = W0 . dh0pre
+    static constexpr int B2 = B1 + UT * 256;            // [t'][kb][term][lane][4]   dh0 = W1 . dh1pre (bf16 x 3)
+    static constexpr int B3 = B2 + UT * KB * 3 * 256;   // [t][lane][v]       dx  = W0 . dh0pre
     static constexpr int B3S = B3 + UT * 256;           // [lane][v]          dx += Ws . dO(mean slots)
     static constexpr int BWD_END = B3S + 256;
-    static constexpr int SCR = BWD_END;                 // per wave: two sets of UT transpose blocks
-    static constexpr int BWD_TOTAL = SCR + BWD_WAVES * 2 * UT * TBLK;
+    // per-wave transpose scratch, two regions that are re-used through the tile:
+    //   P: (h, m) bf16 terms of h0 [term][t][half][unit][8 rows] (UT*256 dwords), later dh0pre as fp32 blocks (UT*TBLK)
+    //   Q: h1 and dO as fp32 blocks ((UT+1)*TBLK), later the (h, m) bf16 terms of dh1pre (UT*256 dwords)
+    static constexpr int TW = UT * 256;
+    static constexpr int PSZ = TW > UT * TBLK ? TW : UT * TBLK;
+    static constexpr int QSZ = TW > (UT + 1) * TBLK ? TW : (UT + 1) * TBLK;
+    static constexpr int SCR = BWD_END;
+    static constexpr int BWD_TOTAL = SCR + BWD_WAVES * (PSZ + QSZ);
 };
 
 // output slot m (0..15) of the last layer: lane group g = m>>2 owns slots 4g..4g+3 = (mean d0, mean d1, var d0, var d1)
@@ -143,11 +154,21 @@ __device__ void fill_images(float* __restrict__ sm, const DecArgs& a) {
         const int dim = 4 * v + g, unit = 16 * tp + c;
         sm[I::F0 + i] = (v < 2 && dim < L && unit < U) ? a.W0[dim * U + unit] : 0.f;
     }
-    // F1: A[i = out 16t'+c][k = in 16t+4g+v] = W1[in][out]
-    for (int i = tid; i < UT * UT * 256; i += THREADS) {
-        const int v = i & 3, l = (i >> 2) & 63, e = i >> 8, t = e % UT, tp = e / UT, g = l >> 4, c = l & 15;
-        const int in = 16 * t + 4 * g + v, out = 16 * tp + c;
-        sm[I::F1 + i] = (in < U && out < U) ? a.W1[in * U + out] : 0.f;
+    // F1 (bf16 x 3): A[i = out 16t'+c][k-slot 8g+j of block kb = in 16(2kb + (j>>2)) + 4g + (j&3)] = W1[in][out]
+    unsigned* __restrict__ smu = reinterpret_cast<unsigned*>(sm);
+    constexpr int KB = I::KB;
+    for (int i = tid; i < UT * KB * 256; i += THREADS) {
+        const int dw = i & 3, l = (i >> 2) & 63, e = i >> 8, kb = e % KB, tp = e / KB, g = l >> 4, c = l & 15;
+        v2f w;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = 2 * dw + h, t = 2 * kb + (j >> 2), in = 16 * t + 4 * g + (j & 3), out = 16 * tp + c;
+            w[h] = (t < UT && in < U && out < U) ? a.W1[in * U + out] : 0.f;
+        }
+        unsigned t3[3];
+        split_bf16<3>(w, t3);
+#pragma unroll
+        for (int term = 0; term < 3; ++term) smu[I::F1 + ((e * 3 + term) * 64 + l) * 4 + dw] = t3[term];
     }
     // F2: A[i = slot c][k = in 16t+4g+v] = W2[in][ty*Dy + d]
     for (int i = tid; i < UT * 256; i += THREADS) {
@@ -181,11 +202,19 @@ __device__ void fill_images(float* __restrict__ sm, const DecArgs& a) {
             const int unit = 16 * tp + c, m = 4 * g + v, d = slot_d(m), ty = slot_ty(m);
             sm[I::B1 + i] = (unit < U && d < Dy) ? a.W2[unit * 2 * Dy + ty * Dy + d] : 0.f;
         }
-        // B2: A[i = in 16t'+c][k = out 16t+4g+v] = W1[in][out]
-        for (int i = tid; i < UT * UT * 256; i += THREADS) {
-            const int v = i & 3, l = (i >> 2) & 63, e = i >> 8, t = e % UT, tp = e / UT, g = l >> 4, c = l & 15;
-            const int in = 16 * tp + c, out = 16 * t + 4 * g + v;
-            sm[I::B2 + i] = (in < U && out < U) ? a.W1[in * U + out] : 0.f;
+        // B2 (bf16 x 3): A[i = in 16t'+c][k-slot 8g+j of block kb = out 16(2kb + (j>>2)) + 4g + (j&3)] = W1[in][out]
+        for (int i = tid; i < UT * KB * 256; i += THREADS) {
+            const int dw = i & 3, l = (i >> 2) & 63, e = i >> 8, kb = e % KB, tp = e / KB, g = l >> 4, c = l & 15;
+            v2f w;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = 2 * dw + h, t = 2 * kb + (j >> 2), out = 16 * t + 4 * g + (j & 3), in = 16 * tp + c;
+                w[h] = (t < UT && in < U && out < U) ? a.W1[in * U + out] : 0.f;
+            }
+            unsigned t3[3];
+            split_bf16<3>(w, t3);
+#pragma unroll
+            for (int term = 0; term < 3; ++term) smu[I::B2 + ((e * 3 + term) * 64 + l) * 4 + dw] = t3[term];
         }
         // B3: A[i = dim c][k = unit 16t+4g+v] = W0[dim][unit]
         for (int i = tid; i < UT * 256; i += THREADS) {
@@ -206,6 +235,10 @@ __device__ __forceinline__ f32x4 mfma4(float av, float bv, f32x4 cv) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, cv, 0, 0, 0);
 }
 __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ u32x4 ldsu4(const float* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ f32x4 mfma_bf(u32x4 av, u32x4 bv, f32x4 cv) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), cv, 0, 0, 0);
+}
 
 // k-steps over hidden units are enumerated (t, v) <-> units 16t + 4g + v; in the last unit tile only v < VL reach a
 // unit below U (VL = min(4, U - 16 (UT-1))), the others multiply zero padding and are skipped at compile time.
@@ -230,10 +263,51 @@ __device__ __forceinline__ RowMap row_map(unsigned tile, int c, unsigned S, unsi
     return m;
 }
 
-// forward of one 16-row tile; xb0/xb1 = x[row c][g], x[row c][4+g] (B operand of layer 0)
-template <int UT, int VL>
-__device__ __forceinline__ void dec_forward_tile(const float* __restrict__ sm, int lane, float xb0, float xb1,
-                                                 f32x4 (&h0)[UT], f32x4 (&h1)[UT], f32x4& O) {
+// (unit 16t+4g+v, row c) activations of one layer -> the three bf16 terms of every value, packed per (v, v+1) pair:
+// ts[term][2t + p] = values v = 2p, 2p+1 of tile t.  Registers 4kb .. 4kb+3 of a term ARE the B operand of k-block kb.
+template <int UT>
+__device__ __forceinline__ void split_tiles(const f32x4 (&h)[UT], unsigned (&ts)[3][4 * Img<UT>::KB]) {
+#pragma unroll
+    for (int i = 0; i < 4 * Img<UT>::KB; ++i) {
+        if (i < 2 * UT) {
+            unsigned t3[3];
+            split_bf16<3>(v2f{h[i >> 1][2 * (i & 1)], h[i >> 1][2 * (i & 1) + 1]}, t3);
+            ts[0][i] = t3[0]; ts[1][i] = t3[1]; ts[2][i] = t3[2];
+        } else {
+            ts[0][i] = 0u; ts[1][i] = 0u; ts[2][i] = 0u;
+        }
+    }
+}
+
+// out[t'] += W . act for a U x U weight image `img` (F1 or B2) on the XDL pipe: the six products of order <= 2 of the
+// 3-term splits (hh, hm, hl, mh, mm, lh) - what is dropped is below 2^-24 of the product, as in the fp32 MFMA chain.
+template <int UT>
+__device__ __forceinline__ void gemm_uu_bf16(const float* __restrict__ img, int lane, const unsigned (&ts)[3][4 * Img<UT>::KB],
+                                             f32x4 (&out)[UT]) {
+    constexpr int KB = Img<UT>::KB;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+        for (int ta = 0; ta < 3; ++ta) {
+            u32x4 w[UT];
+#pragma unroll
+            for (int tp = 0; tp < UT; ++tp) w[tp] = ldsu4(img + (((tp * KB + kb) * 3 + ta) * 64 + lane) * 4);
+#pragma unroll
+            for (int tb = 0; tb + ta < 3; ++tb) {
+                const u32x4 bv = {ts[tb][4 * kb], ts[tb][4 * kb + 1], ts[tb][4 * kb + 2], ts[tb][4 * kb + 3]};
+#pragma unroll
+                for (int tp = 0; tp < UT; ++tp) out[tp] = mfma_bf(w[tp], bv, out[tp]);
+            }
+        }
+    }
+}
+
+// forward of one 16-row tile; xb0/xb1 = x[row c][g], x[row c][4+g] (B operand of layer 0).  onev >= 0 on the lanes that
+// own the free padding unit of the last tile: that unit's activation is forced to 1 (its weights are zero everywhere),
+// see the bias-gradient note at dec_bwd_kernel.  h0s = bf16 terms of h0 (the backward pass transposes them for dW1).
+template <int UT, int VL, bool ONES>
+__device__ __forceinline__ void dec_forward_tile(const float* __restrict__ sm, int lane, float xb0, float xb1, int onev,
+                                                 f32x4 (&h0)[UT], unsigned (&h0s)[3][4 * Img<UT>::KB], f32x4 (&h1)[UT], f32x4& O) {
     using I = Img<UT>;
     const int g = lane >> 4;
 #pragma unroll
@@ -246,20 +320,14 @@ __device__ __forceinline__ void dec_forward_tile(const float* __restrict__ sm, i
     }
 #pragma unroll
     for (int tp = 0; tp < UT; ++tp) h0[tp] = tanh4(h0[tp]);
+    if (ONES) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) h0[UT - 1][v] = onev == v ? 1.0f : h0[UT - 1][v];
+    }
+    split_tiles<UT>(h0, h0s);
 #pragma unroll
     for (int tp = 0; tp < UT; ++tp) h1[tp] = lds4(sm + I::BIAS1 + 16 * tp + 4 * g);
-#pragma unroll
-    for (int t = 0; t < UT; ++t) {
-        f32x4 w[UT];
-#pragma unroll
-        for (int tp = 0; tp < UT; ++tp) w[tp] = lds4(sm + I::F1 + ((tp * UT + t) * 64 + lane) * 4);
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-            if (kstep_on<UT, VL>(t, v)) {
-#pragma unroll
-                for (int tp = 0; tp < UT; ++tp) h1[tp] = mfma4(w[tp][v], h0[t][v], h1[tp]);
-            }
-    }
+    gemm_uu_bf16<UT>(sm + I::F1, lane, h0s, h1);
 #pragma unroll
     for (int tp = 0; tp < UT; ++tp) h1[tp] = tanh4(h1[tp]);
     f32x4 o0 = lds4(sm + I::BIASO + 4 * g), o1 = {0.f, 0.f, 0.f, 0.f};
@@ -305,7 +373,8 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void dec_fwd_kernel(DecArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) yv[j] = (2 * g + j < Dy && a.ll) ? a.y[(size_t)rm.n * Dy + 2 * g + j] : 0.f;
         f32x4 h0[UT], h1[UT], O;
-        dec_forward_tile<UT, VL>(sm, lane, xb0, xb1, h0, h1, O);
+        unsigned h0s[3][4 * I::KB];
+        dec_forward_tile<UT, VL, false>(sm, lane, xb0, xb1, -1, h0, h0s, h1, O);
         float acc = 0.f;
         float mu[2], vr[2];
 #pragma unroll
@@ -348,6 +417,31 @@ __device__ __forceinline__ void tr_write(float* __restrict__ T, int g, int c, f3
 }
 __device__ __forceinline__ f32x4 tr_read(const float* __restrict__ T, int g, int c) { return lds4(T + c * TS + 4 * g); }
 
+// The same transposition for the (h, m) bf16 terms of a layer's activations, for the weight-gradient product on the XDL
+// pipe (data row = contraction index, 16 rows per tile).  Layout [term][tile][half = row>>3][unit][8 rows] of bf16:
+// an operand read is one conflict-free ds_read_b128 per lane.  The 32 k-slots of the MFMA carry two terms of the 16
+// rows: lanes g < 2 read rows 8g.. of the first term, lanes g >= 2 rows 8(g-2).. of the second, so
+//   (h|m) x (h|h) = hh + mh   and   (h|m) x (m|m) = hm + mm
+// - four products in two instructions, relative error <= 2^-17 per product (both factors carry 16+ bits).  That is
+// below the fp32 rounding of a sum over >= 16 rows and far below that of the tens of thousands of rows a wave
+// accumulates; the activations themselves (gemm_uu_bf16) keep all six products.
+template <int UT>
+__device__ __forceinline__ void trb_write(unsigned char* __restrict__ T, int g, int c, const unsigned (&ts)[3][4 * Img<UT>::KB]) {
+    unsigned char* __restrict__ base = T + (c >> 3) * 256 + (4 * g) * 16 + 2 * (c & 7);
+#pragma unroll
+    for (int term = 0; term < 2; ++term)
+#pragma unroll
+        for (int t = 0; t < UT; ++t)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const unsigned pk = ts[term][2 * t + p];
+                unsigned char* q = base + (term * UT + t) * 512 + (2 * p) * 16;
+                *reinterpret_cast<unsigned short*>(q) = (unsigned short)pk;
+                *reinterpret_cast<unsigned short*>(q + 16) = (unsigned short)(pk >> 16);
+            }
+}
+__device__ __forceinline__ u32x4 trb_read(const unsigned char* __restrict__ p) { return *reinterpret_cast<const u32x4*>(p); }
+
 // Bias gradients ride in the zero padding of the weight-gradient products: the x tile (A operand of dW0 and of the
 // shortcut product) has rows L..15 free, so a row of ones at "dim 8" makes row 8 of those accumulators equal to
 // sum_row dh0pre (= db0) and sum_row dO (= db2, dbs1); likewise a ones "unit U" in the transposed h0 block gives
@@ -361,8 +455,12 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
     fill_images<UT, true, BWD_THREADS>(sm, a);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
-    float* __restrict__ scrA = sm + I::SCR + wave * 2 * UT * TBLK;
-    float* __restrict__ scrB = scrA + UT * TBLK;
+    float* __restrict__ scrP = sm + I::SCR + wave * (I::PSZ + I::QSZ);
+    float* __restrict__ scrQ = scrP + I::PSZ;
+    unsigned char* __restrict__ scrPb = reinterpret_cast<unsigned char*>(scrP);
+    unsigned char* __restrict__ scrQb = reinterpret_cast<unsigned char*>(scrQ);
+    const int rd_hm = (((g >> 1) * UT) * 2 + (g & 1)) * 256 + c * 16;      // operand (h|m): + tile * 512
+    const int rd_xx = (g & 1) * 256 + c * 16;                             // operand (h|h): + tile * 512; (m|m): + (UT + tile) * 512
     const unsigned ntiles = (a.R + 15u) / 16u;
     const unsigned nwaves = gridDim.x * BWD_WAVES;
     const int L = a.L, Dy = a.Dy, U = a.U;
@@ -374,6 +472,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
     float abs2[2] = {0.f, 0.f};
     aWs = zero4;
     const int fsu = U & 15;                             // FS: the free unit slot of the last tile
+    const int onev = (FS && g == (fsu >> 2)) ? (fsu & 3) : -1;
 #pragma unroll
     for (int i = 0; i < (FS ? 1 : UT); ++i) ab1[i] = zero4;
 #pragma unroll
@@ -414,9 +513,13 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
         }
 
         f32x4 h0[UT], h1[UT], O;
-        dec_forward_tile<UT, VL>(sm, lane, xb0, xb1, h0, h1, O);
+        {
+            unsigned h0s[3][4 * I::KB];
+            dec_forward_tile<UT, VL, FS>(sm, lane, xb0, xb1, onev, h0, h0s, h1, O);
+            trb_write<UT>(scrPb, g, c, h0s);
+        }
 #pragma unroll
-        for (int t = 0; t < UT; ++t) tr_write(scrA + t * TBLK, g, c, h1[t]);
+        for (int t = 0; t < UT; ++t) tr_write(scrQ + t * TBLK, g, c, h1[t]);
 
         // ---- reconstruction term: gradients w.r.t. the output slots
         f32x4 dO;
@@ -441,7 +544,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             llacc += __shfl_xor(llacc, 32);
             if (ok && g == 0) a.ll[row] = llacc;
         }
-        tr_write(scrB, g, c, dO);
+        tr_write(scrQ + UT * TBLK, g, c, dO);
         // ---- dh1 = W2 . dO
         f32x4 dh1[UT];
 #pragma unroll
@@ -457,8 +560,8 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
         {
             f32x4 h1T[UT];
 #pragma unroll
-            for (int t = 0; t < UT; ++t) h1T[t] = tr_read(scrA + t * TBLK, g, c);
-            const f32x4 dOT = tr_read(scrB, g, c);
+            for (int t = 0; t < UT; ++t) h1T[t] = tr_read(scrQ + t * TBLK, g, c);
+            const f32x4 dOT = tr_read(scrQ + UT * TBLK, g, c);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -474,43 +577,33 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             if (!FS) ab1[tp] += dh1[tp];
         }
         wave_lds_order();
-#pragma unroll
-        for (int t = 0; t < UT; ++t) {
-            tr_write(scrA + t * TBLK, g, c, h0[t]);
-            tr_write(scrB + t * TBLK, g, c, dh1[t]);
-        }
-        // ---- dh0 = W1 . dh1pre
+        // ---- dh0 = W1 . dh1pre (XDL pipe), and the terms of dh1pre transposed for dW1
         f32x4 dh0[UT];
 #pragma unroll
         for (int tp = 0; tp < UT; ++tp) dh0[tp] = zero4;
-#pragma unroll
-        for (int t = 0; t < UT; ++t) {
-            f32x4 w[UT];
-#pragma unroll
-            for (int tp = 0; tp < UT; ++tp) w[tp] = lds4(sm + I::B2 + ((tp * UT + t) * 64 + lane) * 4);
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-                if (kstep_on<UT, VL>(t, v)) {
-#pragma unroll
-                    for (int tp = 0; tp < UT; ++tp) dh0[tp] = mfma4(w[tp][v], dh1[t][v], dh0[tp]);
-                }
+        {
+            unsigned d1s[3][4 * I::KB];
+            split_tiles<UT>(dh1, d1s);
+            trb_write<UT>(scrQb, g, c, d1s);
+            gemm_uu_bf16<UT>(sm + I::B2, lane, d1s, dh0);
         }
         // ---- dW1 = h0^T . dh1pre
         wave_lds_order();
         {
-            f32x4 h0T[UT], dT[UT];
+            u32x4 dTh[UT], dTm[UT];
 #pragma unroll
             for (int t = 0; t < UT; ++t) {
-                h0T[t] = tr_read(scrA + t * TBLK, g, c);
-                dT[t] = tr_read(scrB + t * TBLK, g, c);
+                dTh[t] = trb_read(scrQb + rd_xx + t * 512);
+                dTm[t] = trb_read(scrQb + rd_xx + (UT + t) * 512);
             }
-            if (FS && c == fsu) h0T[UT - 1] = f32x4{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+            for (int ti = 0; ti < UT; ++ti) {
+                const u32x4 h0T = trb_read(scrPb + rd_hm + ti * 512);
 #pragma unroll
-                for (int ti = 0; ti < UT; ++ti)
+                for (int tj = 0; tj < UT; ++tj) aW1[ti][tj] = mfma_bf(h0T, dTh[tj], aW1[ti][tj]);
 #pragma unroll
-                    for (int tj = 0; tj < UT; ++tj) aW1[ti][tj] = mfma4(h0T[ti][kk], dT[tj][kk], aW1[ti][tj]);
+                for (int tj = 0; tj < UT; ++tj) aW1[ti][tj] = mfma_bf(h0T, dTm[tj], aW1[ti][tj]);
+            }
         }
         // ---- through tanh of layer 0
 #pragma unroll
@@ -520,7 +613,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
         }
         wave_lds_order();
 #pragma unroll
-        for (int t = 0; t < UT; ++t) tr_write(scrA + t * TBLK, g, c, dh0[t]);
+        for (int t = 0; t < UT; ++t) tr_write(scrP + t * TBLK, g, c, dh0[t]);
         // ---- dx = W0 . dh0pre + Ws . dO(mean)
         {
             f32x4 d0 = zero4, d1 = zero4;
@@ -555,7 +648,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
         {
             f32x4 dT[UT];
 #pragma unroll
-            for (int t = 0; t < UT; ++t) dT[t] = tr_read(scrA + t * TBLK, g, c);
+            for (int t = 0; t < UT; ++t) dT[t] = tr_read(scrP + t * TBLK, g, c);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll

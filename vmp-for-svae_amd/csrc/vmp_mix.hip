@@ -107,30 +107,6 @@ __device__ __forceinline__ v2f row16_sum2(v2f v) {
     return v2f{a, b};
 }
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {       // bf16(lo) | bf16(hi) << 16, round-to-nearest-even
-    unsigned p;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(lo), "v"(hi));
-    return p;
-}
-// v = h + m + l + O(2^-26 |v|): three bf16 terms (8 significant bits each) per value, packed per pair of values.  The
-// moment GEMM keeps the six products of order <= 2 (hh, hm, mh, hl, lh, mm); what it drops (ml, lm, ll and the split
-// residuals) is below 2^-24 |w phi| - fp32 accuracy, as the fp32 MFMA it replaces (a two-term split, three products,
-// is ~2^-17 per product: fine on average at N = 1e6 but visible - 1.4e-5 on r - on a 60-row problem).
-template <int TERMS>
-__device__ __forceinline__ void split_bf16(v2f v, unsigned (&t)[3]) {
-    t[0] = cvt_pk_bf16(v.x, v.y);
-    v2f rem = v - v2f{__uint_as_float(t[0] << 16), __uint_as_float(t[0] & 0xffff0000u)};
-    t[1] = cvt_pk_bf16(rem.x, rem.y);
-    if constexpr (TERMS == 3) {
-        rem = rem - v2f{__uint_as_float(t[1] << 16), __uint_as_float(t[1] & 0xffff0000u)};
-        t[2] = cvt_pk_bf16(rem.x, rem.y);
-    } else {
-        t[2] = 0u;
-    }
-}
 constexpr int MOM_TERMS = 3;
 
 template <int D, int KT, int FLAV, bool ESTEP, bool STATS, bool MASK>
