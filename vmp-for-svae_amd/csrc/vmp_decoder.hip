@@ -9,30 +9,37 @@
 // The reference evaluates this on N*K*S rows with three tiny GEMMs whose (rows x U) activations go through memory
 // five times forward and as often backward.  Here one wave owns 16 rows at a time and the activations never leave
 // its registers:
-//   * every layer is a chain of v_mfma_f32_16x16x4_f32 (exact fp32) with M = output unit, N = data row,
+//   * every product runs on the XDL matrix pipe as v_mfma_f32_16x16x32_bf16 over 3-term bf16 splits of BOTH operands
+//     (v = h + m + l, vmp_common.h): the six products of order <= 2 reproduce the fp32 product to 2^-24 - the accuracy of
+//     the fp32 chain they replace (round 1 used v_mfma_f32_16x16x4_f32, which on gfx950 runs at the fp32 VECTOR rate in
+//     the VALU issue slots: 32 cycles per K = 4 against 16 cycles per K = 32 here).  M = output unit, N = data row,
 //     K = input unit.  The accumulator layout of layer l (lane (g,c), register v  <->  unit 16t+4g+v, row c) IS the
-//     B-operand layout of layer l+1 when its k-steps are enumerated as (t, v) - the contraction order is free - so
-//     the layers chain without any transpose or LDS round trip; the weights are pre-permuted into that order once
-//     per block ("operand images" in LDS, read as conflict-free ds_read_b128).
+//     B-operand layout of layer l+1 when its 32 k-slots are enumerated as (tile pair, v) - the contraction order is
+//     free - so the layers chain without any transpose or LDS round trip; the weights are split and pre-permuted into
+//     that order once per block ("operand images" in LDS, conflict-free ds_read_b128).
+//   * contractions shorter than 32 (K = L <= 8 input dims, K = 16 output slots) put SEVERAL TERMS of the same values
+//     into the 32 k-slots, so one instruction yields two to four of the six products:
+//         K = 16:  (h|m) x (h|h),  (h|m) x (m|m),  (l|h) x (h|l)                           3 instructions
+//         K =  8:  (h|m|l|h) x (h|h|h|m),  (m|h|0|0) x (m|l|0|0)                            2 instructions
 //   * the backward pass recomputes the forward (cheaper than storing 2 x rows x U floats), back-propagates with the
 //     transposed operand images, and accumulates ALL weight gradients in MFMA accumulators with the data row as the
-//     contraction index; the two operands of those products need (unit,row) -> (row,unit) transposes, done 16x16 at
-//     a time through a per-wave LDS scratch.  Per-wave accumulators are reduced in a fixed order: waves of a block
-//     through LDS, blocks through a workspace and a second tiny kernel in fp64 (deterministic, no atomics).
-// MFMA work per 16 rows at U=50: 80 (fwd) / 270 (bwd incl. recompute) instructions of 32 cycles (k-steps that would only
-// multiply zero padding are skipped at compile time).  On gfx950 the fp32 MFMA runs at the fp32 vector rate and its time
-// ADDS to the VALU time of the SIMD (tools/ubench/mfma_cover.hip), so the bound of both kernels is MFMA + VALU issue.
+//     contraction index (16 rows: the (h|m) x (h|h), (h|m) x (m|m) pair gives hh + mh + hm + mm, relative error
+//     <= 2^-17 per product - below the fp32 rounding of the row sums they feed).  The operands of those products need
+//     (unit,row) -> (row,unit) transposes of the bf16 terms, done through a per-wave LDS scratch.  Per-wave
+//     accumulators are reduced in a fixed order: waves of a block through LDS, blocks through a workspace and a second
+//     tiny kernel in fp64 (deterministic, no atomics).
+// MFMA work per 16 rows at U=50: 70 (fwd) / 195 (bwd incl. recompute) instructions of 16 cycles.  Measured on MI355X
+// (tools/ubench/xdl_overlap.hip): beside enough VALU work a bf16 MFMA costs ~10-12 issue cycles of its SIMD, i.e. the
+// XDL pipe overlaps the VALU only partially; the kernels are bound by VALU + MFMA issue.
 #include "vmp_common.h"
 
 using namespace vmp;
 
 namespace {
 
-constexpr int FWD_THREADS = 256;       // forward: 2 blocks per CU
+constexpr int FWD_THREADS = 256;       // forward: 2+ blocks per CU
 constexpr int BWD_THREADS = 512;       // backward: 1 block per CU (8 waves share one set of operand images)
 constexpr int BWD_WAVES = BWD_THREADS / WAVE;
-constexpr int TS = 20;                 // row stride (floats) of a 16x16 transpose scratch block
-constexpr int TBLK = 16 * TS;
 
 struct DecArgs {
     const float* x;        // (R, L)  rows = N*K*S
@@ -69,37 +76,40 @@ __host__ __device__ inline DecGeo dec_geo(int L, int U, int Dy) {
     return q;
 }
 
-// LDS layout (floats / dwords).  fp32 operand image entry for MFMA operand `e`, lane l, sub-step v:  (e*64 + l)*4 + v.
-// The two U x U products of a tile (layer 1 forward, dh0 backward) run on the XDL pipe as 3-term bf16 splits
-// (vmp_common.h): their images hold, per (output tile t', k-block kb, term), one 16x32 bf16 A operand = 4 dwords per lane,
-// k-slot j of lane group g  <->  hidden unit 16 (2 kb + (j >> 2)) + 4 g + (j & 3) - the two accumulator tiles 2kb, 2kb+1
-// of the producing layer, so the layers still chain in registers.
+// LDS layout (dwords).  A bf16 operand image entry = 4 dwords (8 bf16 k-slots) per lane: (e*64 + lane)*4.
+//   K = 32 hidden units per k-block kb: k-slot j of lane group g  <->  unit 16 (2 kb + (j >> 2)) + 4 g + (j & 3), i.e. the
+//     accumulator tiles 2kb, 2kb+1 of the producing layer; one image per (output tile, kb, term).
+//   K = 16 output slots: k-slots 0-3 of lane group g <-> slots 4g..4g+3 of one term, k-slots 4-7 the same slots of another
+//     term; two images per output tile: form 0 = (h|m), form 1 = (l|h).
+//   K = 8 input dims (lane group g holds dims g and 4+g): k-slot 2q+d <-> dim g+4d in term combination q; form a =
+//     (h,m,l,h) 4 dwords per lane, form b = (m,h) 2 dwords per lane.
 template <int UT>
 struct Img {
     static constexpr int KB = (UT + 1) / 2;             // k-blocks of 32 hidden units
-    static constexpr int F0 = 0;                        // [t'][lane][kk<2 (pad 4)]      layer 0
-    static constexpr int F1 = F0 + UT * 256;            // [t'][kb][term][lane][4]        layer 1 (bf16 x 3)
-    static constexpr int F2 = F1 + UT * KB * 3 * 256;   // [t][lane][v]                   output layer
-    static constexpr int F2S = F2 + UT * 256;           // [lane][kk<2 (pad 4)]           shortcut into the output layer
-    static constexpr int BIAS0 = F2S + 256;             // 16*UT   b0 zero-padded
+    static constexpr int F0A = 0;                       // [t'][lane][4]                  layer 0, form a
+    static constexpr int F0B = F0A + UT * 256;          // [t'][lane][2]                  layer 0, form b
+    static constexpr int F1 = F0B + UT * 128;           // [t'][kb][term][lane][4]        layer 1
+    static constexpr int F2 = F1 + UT * KB * 3 * 256;   // [kb][term][lane][4]            output layer
+    static constexpr int F2SA = F2 + KB * 3 * 256;      // [lane][4]                      shortcut into the output layer, form a
+    static constexpr int F2SB = F2SA + 256;             // [lane][2]                      form b
+    static constexpr int BIAS0 = F2SB + 128;            // 16*UT   b0 zero-padded (fp32)
     static constexpr int BIAS1 = BIAS0 + 16 * UT;       // 16*UT   b1
     static constexpr int BIASO = BIAS1 + 16 * UT;       // 16      output bias in slot order
     static constexpr int SP2 = BIASO + 16;              // 8       log1p(exp(bs2_d))
     static constexpr int SG2 = SP2 + 8;                 // 8       sigmoid(bs2_d)
     static constexpr int FWD_END = SG2 + 8;
-    static constexpr int B1 = FWD_END;                  // [t'][lane][v]      dh1 = W2 . dO
-    static constexpr int B2 = B1 + UT * 256;            // [t'][kb][term][lane][4]   dh0 = W1 . dh1pre (bf16 x 3)
-    static constexpr int B3 = B2 + UT * KB * 3 * 256;   // [t][lane][v]       dx  = W0 . dh0pre
-    static constexpr int B3S = B3 + UT * 256;           // [lane][v]          dx += Ws . dO(mean slots)
-    static constexpr int BWD_END = B3S + 256;
-    // per-wave transpose scratch, two regions that are re-used through the tile:
-    //   P: (h, m) bf16 terms of h0 [term][t][half][unit][8 rows] (UT*256 dwords), later dh0pre as fp32 blocks (UT*TBLK)
-    //   Q: h1 and dO as fp32 blocks ((UT+1)*TBLK), later the (h, m) bf16 terms of dh1pre (UT*256 dwords)
-    static constexpr int TW = UT * 256;
-    static constexpr int PSZ = TW > UT * TBLK ? TW : UT * TBLK;
-    static constexpr int QSZ = TW > (UT + 1) * TBLK ? TW : (UT + 1) * TBLK;
+    static constexpr int B1 = FWD_END;                  // [t'][form][lane][4]            dh1 = W2 . dO          (K = 16 slots)
+    static constexpr int B2 = B1 + UT * 2 * 256;        // [t'][kb][term][lane][4]        dh0 = W1 . dh1pre
+    static constexpr int B3 = B2 + UT * KB * 3 * 256;   // [kb][term][lane][4]            dx  = W0 . dh0pre
+    static constexpr int B3S = B3 + KB * 3 * 256;       // [form][lane][4]                dx += Ws . dO(mean slots) (K = 16 slots)
+    static constexpr int BWD_END = B3S + 2 * 256;
+    // per-wave transpose scratch for the weight-gradient products, bf16 (h, m) terms, [term][tile][half][unit][8 rows]:
+    //   X: the x tile (dims 0..7; row "dim 8" = ones, see dec_bwd_kernel)                       256 dwords
+    //   P: h0, later dh0pre                                                                      UT * 256
+    //   Q: h1 and dO, later dh1pre                                                               (UT + 1) * 256
+    static constexpr int XSZ = 256, PSZ = UT * 256, QSZ = (UT + 1) * 256;
     static constexpr int SCR = BWD_END;
-    static constexpr int BWD_TOTAL = SCR + BWD_WAVES * (PSZ + QSZ);
+    static constexpr int BWD_TOTAL = SCR + BWD_WAVES * (XSZ + PSZ + QSZ);
 };
 
 // output slot m (0..15) of the last layer: lane group g = m>>2 owns slots 4g..4g+3 = (mean d0, mean d1, var d0, var d1)
@@ -143,44 +153,67 @@ __device__ __forceinline__ f32x4 tanh4(f32x4 z) {
     return f32x4{a[0], a[1], b[0], b[1]};
 }
 
+// hidden unit behind k-slot j of lane group g in k-block kb
+__device__ __forceinline__ int kslot_unit(int g, int j, int kb) { return 16 * (2 * kb + (j >> 2)) + 4 * g + (j & 3); }
+
 template <int UT, bool BWD, int THREADS>
 __device__ void fill_images(float* __restrict__ sm, const DecArgs& a) {
     using I = Img<UT>;
+    constexpr int KB = I::KB;
+    unsigned* __restrict__ smu = reinterpret_cast<unsigned*>(sm);
     const int L = a.L, U = a.U, Dy = a.Dy;
     const int tid = threadIdx.x;
-    // F0: A[i = unit 16t'+c][k = dim 4kk+g] = W0[dim][unit]
-    for (int i = tid; i < UT * 256; i += THREADS) {
-        const int v = i & 3, l = (i >> 2) & 63, tp = i >> 8, g = l >> 4, c = l & 15;
-        const int dim = 4 * v + g, unit = 16 * tp + c;
-        sm[I::F0 + i] = (v < 2 && dim < L && unit < U) ? a.W0[dim * U + unit] : 0.f;
+    // F0: A[i = unit 16t'+c][dims g, 4+g] = W0[dim][unit]; F2S: A[i = slot c][dims g, 4+g] = Ws[dim][d] for the mean slots
+    for (int i = tid; i < (UT + 1) * 64; i += THREADS) {
+        const int l = i & 63, tp = i >> 6, g = l >> 4, c = l & 15;
+        v2f w;
+        if (tp < UT) {
+            const int unit = 16 * tp + c;
+            w[0] = (g < L && unit < U) ? a.W0[g * U + unit] : 0.f;
+            w[1] = (4 + g < L && unit < U) ? a.W0[(4 + g) * U + unit] : 0.f;
+        } else {
+            const int d = slot_d(c), ty = slot_ty(c);
+            w[0] = (g < L && d < Dy && ty == 0) ? a.Ws[g * Dy + d] : 0.f;
+            w[1] = (4 + g < L && d < Dy && ty == 0) ? a.Ws[(4 + g) * Dy + d] : 0.f;
+        }
+        unsigned t3[3];
+        split_bf16<3>(w, t3);
+        unsigned* __restrict__ pa = smu + (tp < UT ? I::F0A + (tp * 64 + l) * 4 : I::F2SA + l * 4);
+        unsigned* __restrict__ pb = smu + (tp < UT ? I::F0B + (tp * 64 + l) * 2 : I::F2SB + l * 2);
+        pa[0] = t3[0]; pa[1] = t3[1]; pa[2] = t3[2]; pa[3] = t3[0];
+        pb[0] = t3[1]; pb[1] = t3[0];
     }
-    // F1 (bf16 x 3): A[i = out 16t'+c][k-slot 8g+j of block kb = in 16(2kb + (j>>2)) + 4g + (j&3)] = W1[in][out]
-    unsigned* __restrict__ smu = reinterpret_cast<unsigned*>(sm);
-    constexpr int KB = I::KB;
-    for (int i = tid; i < UT * KB * 256; i += THREADS) {
-        const int dw = i & 3, l = (i >> 2) & 63, e = i >> 8, kb = e % KB, tp = e / KB, g = l >> 4, c = l & 15;
+    // F1: A[i = out 16t'+c][k-slot -> in] = W1[in][out];  B2: A[i = in 16t'+c][k-slot -> out] = W1[in][out]
+    for (int i = tid; i < (BWD ? 2 : 1) * UT * KB * 256; i += THREADS) {
+        const int dw = i & 3, l = (i >> 2) & 63, e0 = i >> 8, bw = e0 >= UT * KB, e = bw ? e0 - UT * KB : e0;
+        const int kb = e % KB, tp = e / KB, g = l >> 4, c = l & 15;
         v2f w;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int j = 2 * dw + h, t = 2 * kb + (j >> 2), in = 16 * t + 4 * g + (j & 3), out = 16 * tp + c;
-            w[h] = (t < UT && in < U && out < U) ? a.W1[in * U + out] : 0.f;
+            const int j = 2 * dw + h, ku = kslot_unit(g, j, kb), mu = 16 * tp + c;
+            const int in = bw ? mu : ku, out = bw ? ku : mu;
+            w[h] = (ku < 16 * UT && in < U && out < U) ? a.W1[in * U + out] : 0.f;
         }
         unsigned t3[3];
         split_bf16<3>(w, t3);
 #pragma unroll
-        for (int term = 0; term < 3; ++term) smu[I::F1 + ((e * 3 + term) * 64 + l) * 4 + dw] = t3[term];
+        for (int term = 0; term < 3; ++term) smu[(bw ? I::B2 : I::F1) + ((e * 3 + term) * 64 + l) * 4 + dw] = t3[term];
     }
-    // F2: A[i = slot c][k = in 16t+4g+v] = W2[in][ty*Dy + d]
-    for (int i = tid; i < UT * 256; i += THREADS) {
-        const int v = i & 3, l = (i >> 2) & 63, t = i >> 8, g = l >> 4, c = l & 15;
-        const int in = 16 * t + 4 * g + v, d = slot_d(c), ty = slot_ty(c);
-        sm[I::F2 + i] = (in < U && d < Dy) ? a.W2[in * 2 * Dy + ty * Dy + d] : 0.f;
-    }
-    // F2S: A[i = slot c][k = dim 4kk+g] = Ws[dim][d] for the mean slots
-    for (int i = tid; i < 256; i += THREADS) {
-        const int v = i & 3, l = i >> 2, g = l >> 4, c = l & 15;
-        const int dim = 4 * v + g, d = slot_d(c), ty = slot_ty(c);
-        sm[I::F2S + i] = (v < 2 && dim < L && d < Dy && ty == 0) ? a.Ws[dim * Dy + d] : 0.f;
+    // F2: A[i = slot c][k-slot -> unit] = W2[unit][ty*Dy + d];  B3: A[i = dim c][k-slot -> unit] = W0[dim][unit]
+    for (int i = tid; i < (BWD ? 2 : 1) * KB * 256; i += THREADS) {
+        const int dw = i & 3, l = (i >> 2) & 63, e0 = i >> 8, bw = e0 >= KB, kb = bw ? e0 - KB : e0, g = l >> 4, c = l & 15;
+        const int d = slot_d(c), ty = slot_ty(c);
+        v2f w;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int unit = kslot_unit(g, 2 * dw + h, kb);
+            if (bw) w[h] = (unit < U && c < L) ? a.W0[c * U + unit] : 0.f;
+            else w[h] = (unit < U && d < Dy) ? a.W2[unit * 2 * Dy + ty * Dy + d] : 0.f;
+        }
+        unsigned t3[3];
+        split_bf16<3>(w, t3);
+#pragma unroll
+        for (int term = 0; term < 3; ++term) smu[(bw ? I::B3 : I::F2) + ((kb * 3 + term) * 64 + l) * 4 + dw] = t3[term];
     }
     for (int i = tid; i < 16 * UT; i += THREADS) {
         sm[I::BIAS0 + i] = i < U ? a.b0[i] : 0.f;
@@ -196,54 +229,37 @@ __device__ void fill_images(float* __restrict__ sm, const DecArgs& a) {
         sm[I::SG2 + tid] = 1.0f / (1.0f + expf(-b));
     }
     if (BWD) {
-        // B1: A[i = unit 16t'+c][k = slot 4g+v] = W2[unit][o(slot)]
-        for (int i = tid; i < UT * 256; i += THREADS) {
-            const int v = i & 3, l = (i >> 2) & 63, tp = i >> 8, g = l >> 4, c = l & 15;
-            const int unit = 16 * tp + c, m = 4 * g + v, d = slot_d(m), ty = slot_ty(m);
-            sm[I::B1 + i] = (unit < U && d < Dy) ? a.W2[unit * 2 * Dy + ty * Dy + d] : 0.f;
-        }
-        // B2 (bf16 x 3): A[i = in 16t'+c][k-slot 8g+j of block kb = out 16(2kb + (j>>2)) + 4g + (j&3)] = W1[in][out]
-        for (int i = tid; i < UT * KB * 256; i += THREADS) {
-            const int dw = i & 3, l = (i >> 2) & 63, e = i >> 8, kb = e % KB, tp = e / KB, g = l >> 4, c = l & 15;
-            v2f w;
+        // B1: A[i = unit 16t'+c][slots 4g..4g+3] = W2[unit][o(slot)];  B3S: A[i = dim c][slots 4g..4g+3] = Ws[dim][d], mean slots
+        for (int i = tid; i < (UT + 1) * 64; i += THREADS) {
+            const int l = i & 63, tp = i >> 6, g = l >> 4, c = l & 15;
+            unsigned th[2], tm[2], tl[2];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int j = 2 * dw + h, t = 2 * kb + (j >> 2), out = 16 * t + 4 * g + (j & 3), in = 16 * tp + c;
-                w[h] = (t < UT && in < U && out < U) ? a.W1[in * U + out] : 0.f;
+            for (int p = 0; p < 2; ++p) {
+                v2f w;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int m = 4 * g + 2 * p + h, d = slot_d(m), ty = slot_ty(m);
+                    if (tp < UT) w[h] = (16 * tp + c < U && d < Dy) ? a.W2[(16 * tp + c) * 2 * Dy + ty * Dy + d] : 0.f;
+                    else w[h] = (c < L && d < Dy && ty == 0) ? a.Ws[c * Dy + d] : 0.f;
+                }
+                unsigned t3[3];
+                split_bf16<3>(w, t3);
+                th[p] = t3[0]; tm[p] = t3[1]; tl[p] = t3[2];
             }
-            unsigned t3[3];
-            split_bf16<3>(w, t3);
-#pragma unroll
-            for (int term = 0; term < 3; ++term) smu[I::B2 + ((e * 3 + term) * 64 + l) * 4 + dw] = t3[term];
-        }
-        // B3: A[i = dim c][k = unit 16t+4g+v] = W0[dim][unit]
-        for (int i = tid; i < UT * 256; i += THREADS) {
-            const int v = i & 3, l = (i >> 2) & 63, t = i >> 8, g = l >> 4, c = l & 15;
-            const int unit = 16 * t + 4 * g + v;
-            sm[I::B3 + i] = (c < L && unit < U) ? a.W0[c * U + unit] : 0.f;
-        }
-        // B3S: A[i = dim c][k = slot 4g+v] = Ws[dim][d] for the mean slots
-        for (int i = tid; i < 256; i += THREADS) {
-            const int v = i & 3, l = i >> 2, g = l >> 4, c = l & 15;
-            const int m = 4 * g + v, d = slot_d(m), ty = slot_ty(m);
-            sm[I::B3S + i] = (c < L && d < Dy && ty == 0) ? a.Ws[c * Dy + d] : 0.f;
+            unsigned* __restrict__ q = smu + (tp < UT ? I::B1 + (tp * 2 * 64 + l) * 4 : I::B3S + l * 4);
+            q[0] = th[0]; q[1] = th[1]; q[2] = tm[0]; q[3] = tm[1];                 // form 0 = (h|m)
+            q[256] = tl[0]; q[257] = tl[1]; q[258] = th[0]; q[259] = th[1];         // form 1 = (l|h)
         }
     }
 }
 
-__device__ __forceinline__ f32x4 mfma4(float av, float bv, f32x4 cv) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, cv, 0, 0, 0);
-}
 __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ u32x4 ldsu4(const float* p) { return *reinterpret_cast<const u32x4*>(p); }
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 ldsu2(const float* p) { return *reinterpret_cast<const u32x2*>(p); }
 __device__ __forceinline__ f32x4 mfma_bf(u32x4 av, u32x4 bv, f32x4 cv) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), cv, 0, 0, 0);
 }
-
-// k-steps over hidden units are enumerated (t, v) <-> units 16t + 4g + v; in the last unit tile only v < VL reach a
-// unit below U (VL = min(4, U - 16 (UT-1))), the others multiply zero padding and are skipped at compile time.
-template <int UT, int VL>
-__device__ __forceinline__ constexpr bool kstep_on(int t, int v) { return t < UT - 1 || v < VL; }
 
 // row -> (cell, n) for the 16 rows of a tile: the tile's first row is divided on the scalar unit, the lane offset
 // (< 16 + S) by an exact small-integer float division.
@@ -279,44 +295,106 @@ __device__ __forceinline__ void split_tiles(const f32x4 (&h)[UT], unsigned (&ts)
     }
 }
 
-// out[t'] += W . act for a U x U weight image `img` (F1 or B2) on the XDL pipe: the six products of order <= 2 of the
-// 3-term splits (hh, hm, hl, mh, mm, lh) - what is dropped is below 2^-24 of the product, as in the fp32 MFMA chain.
-template <int UT>
-__device__ __forceinline__ void gemm_uu_bf16(const float* __restrict__ img, int lane, const unsigned (&ts)[3][4 * Img<UT>::KB],
-                                             f32x4 (&out)[UT]) {
+// out[t'] += W . act over the hidden units (K = 16 UT, k-blocks of 32), W = weight image `img` with OT output tiles:
+// the six products of order <= 2 of the 3-term splits (hh, hm, hl, mh, mm, lh).
+template <int UT, int OT>
+__device__ __forceinline__ void gemm_units(const float* __restrict__ img, int lane, const unsigned (&ts)[3][4 * Img<UT>::KB],
+                                           f32x4 (&out)[OT]) {
     constexpr int KB = Img<UT>::KB;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
         for (int ta = 0; ta < 3; ++ta) {
-            u32x4 w[UT];
+            u32x4 w[OT];
 #pragma unroll
-            for (int tp = 0; tp < UT; ++tp) w[tp] = ldsu4(img + (((tp * KB + kb) * 3 + ta) * 64 + lane) * 4);
+            for (int tp = 0; tp < OT; ++tp) w[tp] = ldsu4(img + (((tp * KB + kb) * 3 + ta) * 64 + lane) * 4);
 #pragma unroll
             for (int tb = 0; tb + ta < 3; ++tb) {
                 const u32x4 bv = {ts[tb][4 * kb], ts[tb][4 * kb + 1], ts[tb][4 * kb + 2], ts[tb][4 * kb + 3]};
 #pragma unroll
-                for (int tp = 0; tp < UT; ++tp) out[tp] = mfma_bf(w[tp], bv, out[tp]);
+                for (int tp = 0; tp < OT; ++tp) out[tp] = mfma_bf(w[tp], bv, out[tp]);
             }
         }
     }
 }
+// the same with ONE output tile: one accumulator chain per k-block (a single chain would be 6 KB dependent instructions)
+template <int UT>
+__device__ __forceinline__ f32x4 gemm_units_1(const float* __restrict__ img, int lane, const unsigned (&ts)[3][4 * Img<UT>::KB],
+                                              f32x4 init) {
+    constexpr int KB = Img<UT>::KB;
+    f32x4 acc[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) acc[kb] = kb == 0 ? init : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ta = 0; ta < 3; ++ta) {
+        u32x4 w[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) w[kb] = ldsu4(img + ((kb * 3 + ta) * 64 + lane) * 4);
+#pragma unroll
+        for (int tb = 0; tb + ta < 3; ++tb)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const u32x4 bv = {ts[tb][4 * kb], ts[tb][4 * kb + 1], ts[tb][4 * kb + 2], ts[tb][4 * kb + 3]};
+                acc[kb] = mfma_bf(w[kb], bv, acc[kb]);
+            }
+    }
+    f32x4 r = acc[0];
+#pragma unroll
+    for (int kb = 1; kb < KB; ++kb) r += acc[kb];
+    return r;
+}
 
-// forward of one 16-row tile; xb0/xb1 = x[row c][g], x[row c][4+g] (B operand of layer 0).  onev >= 0 on the lanes that
-// own the free padding unit of the last tile: that unit's activation is forced to 1 (its weights are zero everywhere),
-// see the bias-gradient note at dec_bwd_kernel.  h0s = bf16 terms of h0 (the backward pass transposes them for dW1).
-template <int UT, int VL, bool ONES>
-__device__ __forceinline__ void dec_forward_tile(const float* __restrict__ sm, int lane, float xb0, float xb1, int onev,
-                                                 f32x4 (&h0)[UT], unsigned (&h0s)[3][4 * Img<UT>::KB], f32x4 (&h1)[UT], f32x4& O) {
+// K = 8 input dims: xs = the three terms of the lane's (x[row c][g], x[row c][4+g]) pair
+struct XOps {
+    u32x4 b1, b2;
+};
+__device__ __forceinline__ XOps x_operands(const unsigned (&xs)[3]) {
+    return XOps{u32x4{xs[0], xs[0], xs[0], xs[1]}, u32x4{xs[1], xs[2], 0u, 0u}};
+}
+__device__ __forceinline__ f32x4 gemm_dims(const float* __restrict__ img_a, const float* __restrict__ img_b, int lane, const XOps& xo, f32x4 acc) {
+    const u32x4 a1 = ldsu4(img_a + lane * 4);
+    const u32x2 a2 = ldsu2(img_b + lane * 2);
+    acc = mfma_bf(a1, xo.b1, acc);
+    return mfma_bf(u32x4{a2[0], a2[1], 0u, 0u}, xo.b2, acc);
+}
+
+// K = 16 output slots: ds = the three terms of the lane's slot pairs (4g, 4g+1), (4g+2, 4g+3); img = [form][lane][4]
+struct SOps {
+    u32x4 hh, mm, hl;
+};
+__device__ __forceinline__ SOps slot_operands(const unsigned (&ds)[3][2]) {
+    return SOps{u32x4{ds[0][0], ds[0][1], ds[0][0], ds[0][1]}, u32x4{ds[1][0], ds[1][1], ds[1][0], ds[1][1]},
+                u32x4{ds[0][0], ds[0][1], ds[2][0], ds[2][1]}};
+}
+__device__ __forceinline__ f32x4 gemm_slots(const float* __restrict__ img, int lane, const SOps& so, f32x4 acc) {
+    const u32x4 a0 = ldsu4(img + lane * 4), a1 = ldsu4(img + 256 + lane * 4);
+    acc = mfma_bf(a0, so.hh, acc);
+    acc = mfma_bf(a0, so.mm, acc);
+    return mfma_bf(a1, so.hl, acc);
+}
+
+// forward of one 16-row tile.  onev >= 0 on the lanes that own the free padding unit of the last tile: that unit's
+// activation is forced to 1 (its weights are zero everywhere), see the bias-gradient note at dec_bwd_kernel.
+// h0s / h1s = bf16 terms of the activations (the backward pass transposes them for the weight gradients).
+template <int UT, bool ONES>
+__device__ __forceinline__ void dec_forward_tile(const float* __restrict__ sm, int lane, const XOps& xo, int onev,
+                                                 f32x4 (&h0)[UT], unsigned (&h0s)[3][4 * Img<UT>::KB], f32x4 (&h1)[UT],
+                                                 unsigned (&h1s)[3][4 * Img<UT>::KB], f32x4& O) {
     using I = Img<UT>;
     const int g = lane >> 4;
+    {
+        u32x4 a1[UT];
+        u32x2 a2[UT];
 #pragma unroll
-    for (int tp = 0; tp < UT; ++tp) {
-        f32x4 acc = lds4(sm + I::BIAS0 + 16 * tp + 4 * g);
-        const f32x4 w = lds4(sm + I::F0 + (tp * 64 + lane) * 4);
-        acc = mfma4(w[0], xb0, acc);
-        acc = mfma4(w[1], xb1, acc);
-        h0[tp] = acc;
+        for (int tp = 0; tp < UT; ++tp) {
+            h0[tp] = lds4(sm + I::BIAS0 + 16 * tp + 4 * g);
+            a1[tp] = ldsu4(sm + I::F0A + (tp * 64 + lane) * 4);
+            a2[tp] = ldsu2(sm + I::F0B + (tp * 64 + lane) * 2);
+        }
+#pragma unroll
+        for (int tp = 0; tp < UT; ++tp) h0[tp] = mfma_bf(a1[tp], xo.b1, h0[tp]);
+#pragma unroll
+        for (int tp = 0; tp < UT; ++tp) h0[tp] = mfma_bf(u32x4{a2[tp][0], a2[tp][1], 0u, 0u}, xo.b2, h0[tp]);
     }
 #pragma unroll
     for (int tp = 0; tp < UT; ++tp) h0[tp] = tanh4(h0[tp]);
@@ -327,29 +405,15 @@ __device__ __forceinline__ void dec_forward_tile(const float* __restrict__ sm, i
     split_tiles<UT>(h0, h0s);
 #pragma unroll
     for (int tp = 0; tp < UT; ++tp) h1[tp] = lds4(sm + I::BIAS1 + 16 * tp + 4 * g);
-    gemm_uu_bf16<UT>(sm + I::F1, lane, h0s, h1);
+    gemm_units<UT, UT>(sm + I::F1, lane, h0s, h1);
 #pragma unroll
     for (int tp = 0; tp < UT; ++tp) h1[tp] = tanh4(h1[tp]);
-    f32x4 o0 = lds4(sm + I::BIASO + 4 * g), o1 = {0.f, 0.f, 0.f, 0.f};
-    {
-        const f32x4 w = lds4(sm + I::F2S + lane * 4);
-        o0 = mfma4(w[0], xb0, o0);
-        o1 = mfma4(w[1], xb1, o1);
-    }
-#pragma unroll
-    for (int t = 0; t < UT; ++t) {
-        const f32x4 w = lds4(sm + I::F2 + (t * 64 + lane) * 4);
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-            if (kstep_on<UT, VL>(t, v)) {
-                if (v & 1) o1 = mfma4(w[v], h1[t][v], o1);
-                else o0 = mfma4(w[v], h1[t][v], o0);
-            }
-    }
-    O = o0 + o1;
+    split_tiles<UT>(h1, h1s);
+    const f32x4 os = gemm_dims(sm + I::F2SA, sm + I::F2SB, lane, xo, f32x4{0.f, 0.f, 0.f, 0.f});
+    O = gemm_units_1<UT>(sm + I::F2, lane, h1s, lds4(sm + I::BIASO + 4 * g)) + os;
 }
 
-template <int UT, int VL>
+template <int UT>
 __global__ __launch_bounds__(FWD_THREADS, 2) void dec_fwd_kernel(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     using I = Img<UT>;
@@ -362,6 +426,7 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void dec_fwd_kernel(DecArgs a) {
     const float invS = 1.0f / (float)a.S, invK = 1.0f / (float)a.K;
     const unsigned ncells = a.R / a.S;
     for (unsigned tile = blockIdx.x * (FWD_THREADS / WAVE) + wave; tile < ntiles; tile += nwaves) {
+        asm volatile("" ::: "memory");                  // keep the (loop-invariant) operand-image reads inside the loop: hoisted, they spill
         const unsigned row = tile * 16u + c;
         const bool ok = row < a.R;
         const unsigned rr = ok ? row : a.R - 1u;
@@ -372,9 +437,12 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void dec_fwd_kernel(DecArgs a) {
         float yv[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) yv[j] = (2 * g + j < Dy && a.ll) ? a.y[(size_t)rm.n * Dy + 2 * g + j] : 0.f;
+        unsigned xs[3];
+        split_bf16<3>(v2f{xb0, xb1}, xs);
+        const XOps xo = x_operands(xs);
         f32x4 h0[UT], h1[UT], O;
-        unsigned h0s[3][4 * I::KB];
-        dec_forward_tile<UT, VL, false>(sm, lane, xb0, xb1, -1, h0, h0s, h1, O);
+        unsigned h0s[3][4 * I::KB], h1s[3][4 * I::KB];
+        dec_forward_tile<UT, false>(sm, lane, xo, -1, h0, h0s, h1, h1s, O);
         float acc = 0.f;
         float mu[2], vr[2];
 #pragma unroll
@@ -410,57 +478,68 @@ __device__ __forceinline__ void wave_lds_order() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// (unit 4g+v, row c) accumulator block  ->  operand form: lane (g,c) gets block[unit c][rows 4g..4g+3]
-__device__ __forceinline__ void tr_write(float* __restrict__ T, int g, int c, f32x4 z) {
-#pragma unroll
-    for (int v = 0; v < 4; ++v) T[(4 * g + v) * TS + c] = z[v];
-}
-__device__ __forceinline__ f32x4 tr_read(const float* __restrict__ T, int g, int c) { return lds4(T + c * TS + 4 * g); }
-
-// The same transposition for the (h, m) bf16 terms of a layer's activations, for the weight-gradient product on the XDL
-// pipe (data row = contraction index, 16 rows per tile).  Layout [term][tile][half = row>>3][unit][8 rows] of bf16:
-// an operand read is one conflict-free ds_read_b128 per lane.  The 32 k-slots of the MFMA carry two terms of the 16
-// rows: lanes g < 2 read rows 8g.. of the first term, lanes g >= 2 rows 8(g-2).. of the second, so
+// Transposition of the (h, m) bf16 terms of a (unit 4g+v, row c) accumulator block set for the weight-gradient products
+// (data row = contraction index, 16 rows per tile).  Layout [term][tile][half = row>>3][unit][8 rows] of bf16: an operand
+// read is one conflict-free ds_read_b128 per lane.  The 32 k-slots of the MFMA carry two terms of the 16 rows: lanes
+// g < 2 read rows 8g.. of the first term, lanes g >= 2 rows 8(g-2).. of the second, so
 //   (h|m) x (h|h) = hh + mh   and   (h|m) x (m|m) = hm + mm
-// - four products in two instructions, relative error <= 2^-17 per product (both factors carry 16+ bits).  That is
-// below the fp32 rounding of a sum over >= 16 rows and far below that of the tens of thousands of rows a wave
-// accumulates; the activations themselves (gemm_uu_bf16) keep all six products.
-template <int UT>
-__device__ __forceinline__ void trb_write(unsigned char* __restrict__ T, int g, int c, const unsigned (&ts)[3][4 * Img<UT>::KB]) {
-    unsigned char* __restrict__ base = T + (c >> 3) * 256 + (4 * g) * 16 + 2 * (c & 7);
+// - four products in two instructions, relative error <= 2^-17 per product (both factors carry 16+ bits).
+// NT tiles; ts[term][2t + p] = packed values (v = 2p, 2p+1) of tile t (split_tiles).
+// Swizzle: in the second half (rows 8..15) a unit's 16-byte slot is rotated by two within its group of four, so that
+// the two half-rows of a write instruction (lanes c < 8 and c >= 8, 256 bytes apart = the same banks) land on different
+// banks; a read still covers each half's 256 bytes exactly once.
+__device__ __forceinline__ int trb_slot(int unit, int half) { return (unit & ~3) | ((unit + 2 * half) & 3); }
+template <int NT, int NTS>
+__device__ __forceinline__ void trb_write(unsigned char* __restrict__ T, int g, int c, const unsigned (&ts)[3][NTS]) {
+    const int half = c >> 3;
+    unsigned char* __restrict__ base = T + half * 256 + 2 * (c & 7);
+    int off[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) off[v] = trb_slot(4 * g + v, half) * 16;
 #pragma unroll
     for (int term = 0; term < 2; ++term)
 #pragma unroll
-        for (int t = 0; t < UT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const unsigned pk = ts[term][2 * t + p];
-                unsigned char* q = base + (term * UT + t) * 512 + (2 * p) * 16;
-                *reinterpret_cast<unsigned short*>(q) = (unsigned short)pk;
-                *reinterpret_cast<unsigned short*>(q + 16) = (unsigned short)(pk >> 16);
+                unsigned char* q = base + (term * NT + t) * 512;
+                *reinterpret_cast<unsigned short*>(q + off[2 * p]) = (unsigned short)pk;
+                *reinterpret_cast<unsigned short*>(q + off[2 * p + 1]) = (unsigned short)(pk >> 16);
             }
 }
 __device__ __forceinline__ u32x4 trb_read(const unsigned char* __restrict__ p) { return *reinterpret_cast<const u32x4*>(p); }
 
 // Bias gradients ride in the zero padding of the weight-gradient products: the x tile (A operand of dW0 and of the
 // shortcut product) has rows L..15 free, so a row of ones at "dim 8" makes row 8 of those accumulators equal to
-// sum_row dh0pre (= db0) and sum_row dO (= db2, dbs1); likewise a ones "unit U" in the transposed h0 block gives
-// db1 as row U of dW1 when U is not a multiple of 16 (FS); otherwise db1 is summed on the VALU.
+// sum_row dh0pre (= db0) and sum_row dO (= db2, dbs1); likewise a ones "unit U" in h0 gives db1 as row U of dW1 when U
+// is not a multiple of 16 (FS); otherwise db1 is summed on the VALU.
 // GIN (gradient-input mode): the upstream gradients of (mean, var) are given per row instead of being derived from
 // the log-likelihood - the same kernel then is the backward pass of a stand-alone Gaussian-head MLP (the encoder).
-template <int UT, int VL, bool FS, bool GIN>
+template <int UT, bool FS, bool GIN>
 __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     using I = Img<UT>;
+    constexpr int KB = I::KB;
     fill_images<UT, true, BWD_THREADS>(sm, a);
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
-    float* __restrict__ scrP = sm + I::SCR + wave * (I::PSZ + I::QSZ);
-    float* __restrict__ scrQ = scrP + I::PSZ;
-    unsigned char* __restrict__ scrPb = reinterpret_cast<unsigned char*>(scrP);
-    unsigned char* __restrict__ scrQb = reinterpret_cast<unsigned char*>(scrQ);
-    const int rd_hm = (((g >> 1) * UT) * 2 + (g & 1)) * 256 + c * 16;      // operand (h|m): + tile * 512
-    const int rd_xx = (g & 1) * 256 + c * 16;                             // operand (h|h): + tile * 512; (m|m): + (UT + tile) * 512
+    float* __restrict__ scr = sm + I::SCR + wave * (I::XSZ + I::PSZ + I::QSZ);
+    unsigned char* __restrict__ scrXb = reinterpret_cast<unsigned char*>(scr);
+    unsigned char* __restrict__ scrPb = reinterpret_cast<unsigned char*>(scr + I::XSZ);
+    unsigned char* __restrict__ scrQb = reinterpret_cast<unsigned char*>(scr + I::XSZ + I::PSZ);
+    unsigned char* __restrict__ scrOb = scrQb + 2 * UT * 512;                  // dO terms behind the h1 terms
+    {   // x tile: dims 8..15 are constants - "dim 8" = ones (h term 1.0, m term 0), the rest zero
+        unsigned* __restrict__ xz = reinterpret_cast<unsigned*>(scr);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xz[lane + 64 * i] = 0u;
+        wave_lds_order();
+        if (lane < 8) xz[(lane >> 2) * 64 + trb_slot(8, lane >> 2) * 4 + (lane & 3)] = 0x3F803F80u;
+    }
+    __syncthreads();
+    const int rd_c = trb_slot(c, g & 1) * 16;
+    const int rd_hm = (((g >> 1) * UT) * 2 + (g & 1)) * 256 + rd_c;        // operand (h|m) of a UT-tile set: + tile * 512
+    const int rd_hm1 = ((g >> 1) * 2 + (g & 1)) * 256 + rd_c;              // operand (h|m) of a 1-tile set
+    const int rd_xx = (g & 1) * 256 + rd_c;                               // operand (h|h): + tile * 512; (m|m): + (NT + tile) * 512
     const unsigned ntiles = (a.R + 15u) / 16u;
     const unsigned nwaves = gridDim.x * BWD_WAVES;
     const int L = a.L, Dy = a.Dy, U = a.U;
@@ -482,44 +561,61 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
         for (int j = 0; j < UT; ++j) aW1[i][j] = zero4;
     }
 
-    for (unsigned tile = blockIdx.x * BWD_WAVES + wave; tile < ntiles; tile += nwaves) {
+    // per-tile inputs of a lane: x[row c][g], x[row c][4+g] and either (gA, y) or the two upstream gradient pairs; the
+    // NEXT tile's are fetched while the current tile is processed
+    struct TileIn {
+        float xb0, xb1, ga, p0, p1, q0, q1;
+    };
+    auto fetch = [&](unsigned tile) -> TileIn {
+        TileIn t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (tile >= ntiles) return t;
         const unsigned row = tile * 16u + c;
         const bool ok = row < a.R;
         const unsigned rr = ok ? row : a.R - 1u;
         const float* __restrict__ xr = a.x + (size_t)rr * L;
-        const float xb0 = g < L ? xr[g] : 0.f;
-        const float xb1 = 4 + g < L ? xr[4 + g] : 0.f;
-        // x in operand form for the weight gradients: lane (g,c) <- x[row 4g+kk][dim c]
-        f32x4 xT;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const unsigned r2 = tile * 16u + 4u * g + kk;
-            xT[kk] = (r2 < a.R && c < L) ? a.x[(size_t)r2 * L + c] : (c == 8 ? 1.0f : 0.f);
-        }
-        float ga = 0.f, yv[2] = {0.f, 0.f}, gin_m[2] = {0.f, 0.f}, gin_v[2] = {0.f, 0.f};
+        t.xb0 = (ok && g < L) ? xr[g] : 0.f;
+        t.xb1 = (ok && 4 + g < L) ? xr[4 + g] : 0.f;
         if (GIN) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const bool dv = ok && 2 * g + j < Dy;
-                const float m_ = a.gmean[(size_t)rr * Dy + (dv ? 2 * g + j : 0)], v_ = a.gvar[(size_t)rr * Dy + (dv ? 2 * g + j : 0)];
-                gin_m[j] = dv ? m_ : 0.f;
-                gin_v[j] = dv ? v_ : 0.f;
-            }
+            const bool d0 = ok && 2 * g < Dy, d1 = ok && 2 * g + 1 < Dy;
+            const float m0 = a.gmean[(size_t)rr * Dy + (d0 ? 2 * g : 0)], v0 = a.gvar[(size_t)rr * Dy + (d0 ? 2 * g : 0)];
+            const float m1 = a.gmean[(size_t)rr * Dy + (d1 ? 2 * g + 1 : 0)], v1 = a.gvar[(size_t)rr * Dy + (d1 ? 2 * g + 1 : 0)];
+            t.p0 = d0 ? m0 : 0.f; t.p1 = d1 ? m1 : 0.f; t.q0 = d0 ? v0 : 0.f; t.q1 = d1 ? v1 : 0.f;
         } else {
             const RowMap rm = row_map(tile, c, a.S, a.K, invS, invK, ncells);
-            ga = ok ? a.gA[rm.cell] : 0.f;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) yv[j] = 2 * g + j < Dy ? a.y[(size_t)rm.n * Dy + 2 * g + j] : 0.f;
+            t.ga = ok ? a.gA[rm.cell] : 0.f;
+            t.p0 = 2 * g < Dy ? a.y[(size_t)rm.n * Dy + 2 * g] : 0.f;
+            t.p1 = 2 * g + 1 < Dy ? a.y[(size_t)rm.n * Dy + 2 * g + 1] : 0.f;
         }
+        return t;
+    };
+    TileIn nxt = fetch(blockIdx.x * BWD_WAVES + wave);
+    for (unsigned tile = blockIdx.x * BWD_WAVES + wave; tile < ntiles; tile += nwaves) {
+        const unsigned row = tile * 16u + c;
+        const bool ok = row < a.R;
+        const TileIn cur = nxt;
+        nxt = fetch(tile + nwaves);
+        const float xb0 = cur.xb0, xb1 = cur.xb1, ga = cur.ga;
+        const float yv[2] = {cur.p0, cur.p1}, gin_m[2] = {cur.p0, cur.p1}, gin_v[2] = {cur.q0, cur.q1};
 
+        unsigned xs[3];
+        split_bf16<3>(v2f{xb0, xb1}, xs);
+        const XOps xo = x_operands(xs);
+        {   // x (h, m) terms transposed: lo half = dim g, hi half = dim 4+g of row c
+            unsigned char* __restrict__ q = scrXb + (c >> 3) * 256 + 2 * (c & 7);
+            const int o0 = trb_slot(g, c >> 3) * 16, o1 = trb_slot(4 + g, c >> 3) * 16;
+#pragma unroll
+            for (int term = 0; term < 2; ++term) {
+                *reinterpret_cast<unsigned short*>(q + term * 512 + o0) = (unsigned short)xs[term];
+                *reinterpret_cast<unsigned short*>(q + term * 512 + o1) = (unsigned short)(xs[term] >> 16);
+            }
+        }
         f32x4 h0[UT], h1[UT], O;
         {
-            unsigned h0s[3][4 * I::KB];
-            dec_forward_tile<UT, VL, FS>(sm, lane, xb0, xb1, onev, h0, h0s, h1, O);
+            unsigned h0s[3][4 * KB], h1s[3][4 * KB];
+            dec_forward_tile<UT, FS>(sm, lane, xo, onev, h0, h0s, h1, h1s, O);
             trb_write<UT>(scrPb, g, c, h0s);
+            trb_write<UT>(scrQb, g, c, h1s);
         }
-#pragma unroll
-        for (int t = 0; t < UT; ++t) tr_write(scrQ + t * TBLK, g, c, h1[t]);
 
         // ---- reconstruction term: gradients w.r.t. the output slots
         f32x4 dO;
@@ -544,30 +640,45 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             llacc += __shfl_xor(llacc, 32);
             if (ok && g == 0) a.ll[row] = llacc;
         }
-        tr_write(scrQ + UT * TBLK, g, c, dO);
+        unsigned dOs[3][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            unsigned t3[3];
+            split_bf16<3>(v2f{dO[2 * p], dO[2 * p + 1]}, t3);
+            dOs[0][p] = t3[0]; dOs[1][p] = t3[1]; dOs[2][p] = t3[2];
+        }
+        trb_write<1>(scrOb, g, c, dOs);
+        const SOps so = slot_operands(dOs);
         // ---- dh1 = W2 . dO
         f32x4 dh1[UT];
+        {
+            u32x4 a0[UT], a1[UT];
 #pragma unroll
-        for (int tp = 0; tp < UT; ++tp) {
-            const f32x4 w = lds4(sm + I::B1 + (tp * 64 + lane) * 4);
-            f32x4 acc = zero4;
+            for (int tp = 0; tp < UT; ++tp) {
+                a0[tp] = ldsu4(sm + I::B1 + tp * 512 + lane * 4);
+                a1[tp] = ldsu4(sm + I::B1 + tp * 512 + 256 + lane * 4);
+            }
 #pragma unroll
-            for (int v = 0; v < 4; ++v) acc = mfma4(w[v], dO[v], acc);
-            dh1[tp] = acc;
+            for (int tp = 0; tp < UT; ++tp) dh1[tp] = mfma_bf(a0[tp], so.hh, zero4);
+#pragma unroll
+            for (int tp = 0; tp < UT; ++tp) dh1[tp] = mfma_bf(a0[tp], so.mm, dh1[tp]);
+#pragma unroll
+            for (int tp = 0; tp < UT; ++tp) dh1[tp] = mfma_bf(a1[tp], so.hl, dh1[tp]);
         }
         // ---- dW2 (and shortcut W): [h1 ; x]^T . dO
         wave_lds_order();
+        u32x4 xT;
         {
-            f32x4 h1T[UT];
+            const u32x4 dTh = trb_read(scrOb + rd_xx), dTm = trb_read(scrOb + rd_xx + 512);
+            xT = trb_read(scrXb + rd_hm1);
 #pragma unroll
-            for (int t = 0; t < UT; ++t) h1T[t] = tr_read(scrQ + t * TBLK, g, c);
-            const f32x4 dOT = tr_read(scrQ + UT * TBLK, g, c);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-                for (int t = 0; t < UT; ++t) aW2[t] = mfma4(h1T[t][kk], dOT[kk], aW2[t]);
-                aWs = mfma4(xT[kk], dOT[kk], aWs);
+            for (int t = 0; t < UT; ++t) {
+                const u32x4 h1T = trb_read(scrQb + rd_hm + t * 512);
+                aW2[t] = mfma_bf(h1T, dTh, aW2[t]);
+                aW2[t] = mfma_bf(h1T, dTm, aW2[t]);
             }
+            aWs = mfma_bf(xT, dTh, aWs);
+            aWs = mfma_bf(xT, dTm, aWs);
         }
         // ---- through tanh of layer 1
 #pragma unroll
@@ -577,15 +688,15 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             if (!FS) ab1[tp] += dh1[tp];
         }
         wave_lds_order();
-        // ---- dh0 = W1 . dh1pre (XDL pipe), and the terms of dh1pre transposed for dW1
+        // ---- dh0 = W1 . dh1pre, and the terms of dh1pre transposed for dW1
         f32x4 dh0[UT];
 #pragma unroll
         for (int tp = 0; tp < UT; ++tp) dh0[tp] = zero4;
         {
-            unsigned d1s[3][4 * I::KB];
+            unsigned d1s[3][4 * KB];
             split_tiles<UT>(dh1, d1s);
             trb_write<UT>(scrQb, g, c, d1s);
-            gemm_uu_bf16<UT>(sm + I::B2, lane, d1s, dh0);
+            gemm_units<UT, UT>(sm + I::B2, lane, d1s, dh0);
         }
         // ---- dW1 = h0^T . dh1pre
         wave_lds_order();
@@ -612,27 +723,13 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             for (int v = 0; v < 4; ++v) dh0[tp][v] *= 1.0f - h0[tp][v] * h0[tp][v];
         }
         wave_lds_order();
-#pragma unroll
-        for (int t = 0; t < UT; ++t) tr_write(scrP + t * TBLK, g, c, dh0[t]);
         // ---- dx = W0 . dh0pre + Ws . dO(mean)
         {
-            f32x4 d0 = zero4, d1 = zero4;
-            const f32x4 ws = lds4(sm + I::B3S + lane * 4);
-            d0 = mfma4(ws[0], dO[0], d0);
-            d1 = mfma4(ws[1], dO[1], d1);
-            d0 = mfma4(ws[2], dO[2], d0);
-            d1 = mfma4(ws[3], dO[3], d1);
-#pragma unroll
-            for (int t = 0; t < UT; ++t) {
-                const f32x4 w = lds4(sm + I::B3 + (t * 64 + lane) * 4);
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    if (kstep_on<UT, VL>(t, v)) {
-                        if (v & 1) d1 = mfma4(w[v], dh0[t][v], d1);
-                        else d0 = mfma4(w[v], dh0[t][v], d0);
-                    }
-            }
-            const f32x4 dxv = d0 + d1;                   // [dim 4g+v][row c]
+            unsigned d0s[3][4 * KB];
+            split_tiles<UT>(dh0, d0s);
+            trb_write<UT>(scrPb, g, c, d0s);
+            const f32x4 ds_ = gemm_slots(sm + I::B3S, lane, so, zero4);
+            const f32x4 dxv = gemm_units_1<UT>(sm + I::B3, lane, d0s, zero4) + ds_;        // [dim 4g+v][row c]
             if (ok && a.dx) {
                 if (L == 8) {
                     if (g < 2) *reinterpret_cast<f32x4*>(a.dx + (size_t)row * 8 + 4 * g) = dxv;
@@ -645,14 +742,11 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
         }
         // ---- dW0 = x^T . dh0pre
         wave_lds_order();
-        {
-            f32x4 dT[UT];
 #pragma unroll
-            for (int t = 0; t < UT; ++t) dT[t] = tr_read(scrP + t * TBLK, g, c);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int tj = 0; tj < UT; ++tj) aW0[tj] = mfma4(xT[kk], dT[tj][kk], aW0[tj]);
+        for (int tj = 0; tj < UT; ++tj) {
+            const u32x4 dTh = trb_read(scrPb + rd_xx + tj * 512), dTm = trb_read(scrPb + rd_xx + (UT + tj) * 512);
+            aW0[tj] = mfma_bf(xT, dTh, aW0[tj]);
+            aW0[tj] = mfma_bf(xT, dTm, aW0[tj]);
         }
         wave_lds_order();
     }
@@ -764,7 +858,10 @@ int dec_blocks(long long rows, int waves_per_block, int max_blocks) {
     if (b < 1) b = 1;
     return (int)b;
 }
-int dec_fwd_blocks(long long rows) { return dec_blocks(rows, FWD_THREADS / WAVE, 512); }   // 2 blocks on each of 256 CUs
+int dec_fwd_blocks(long long rows) {
+    static const int bpc = getenv("VMP_DEC_FWD_BPC") ? atoi(getenv("VMP_DEC_FWD_BPC")) : 4;    // blocks per CU: 82 VGPRs and 39 KB of LDS leave room for 4 (1.42 -> 1.29 ms per 1.05e7 rows)
+    return dec_blocks(rows, FWD_THREADS / WAVE, 256 * bpc);
+}
 int dec_bwd_blocks(long long rows) { return dec_blocks(rows, BWD_WAVES, 256); }            // 1 block per CU
 
 int dec_check(const char* what, long long N, int K, int S, int L, int Dy, int U) {
@@ -779,31 +876,30 @@ int dec_check(const char* what, long long N, int K, int S, int L, int Dy, int U)
     return 0;
 }
 
-// dispatch on (UT, VL) = (unit tiles, live k-steps of the last tile)
-#define DEC_DISPATCH(U, CALL)                                                                  \
-    do {                                                                                       \
-        const int ut_ = ((U) + 15) / 16, vl_ = ((U) - 16 * (ut_ - 1)) >= 4 ? 4 : ((U) - 16 * (ut_ - 1)); \
-        switch (ut_ * 4 + vl_ - 1) {                                                           \
-            case 4: CALL(1, 1); break;  case 5: CALL(1, 2); break;  case 6: CALL(1, 3); break;  case 7: CALL(1, 4); break;   \
-            case 8: CALL(2, 1); break;  case 9: CALL(2, 2); break;  case 10: CALL(2, 3); break; case 11: CALL(2, 4); break;  \
-            case 12: CALL(3, 1); break; case 13: CALL(3, 2); break; case 14: CALL(3, 3); break; case 15: CALL(3, 4); break;  \
-            case 16: CALL(4, 1); break; case 17: CALL(4, 2); break; case 18: CALL(4, 3); break; default: CALL(4, 4); break;  \
-        }                                                                                      \
+// dispatch on UT = unit tiles of 16
+#define DEC_DISPATCH(U, CALL)                          \
+    do {                                               \
+        switch (((U) + 15) / 16) {                     \
+            case 1: CALL(1); break;                    \
+            case 2: CALL(2); break;                    \
+            case 3: CALL(3); break;                    \
+            default: CALL(4); break;                   \
+        }                                              \
     } while (0)
 
 template <bool GIN>
 int dec_bwd_launch(const DecArgs& a, int blocks, hipStream_t s) {
     const int U = a.U;
     const int red_floats = (1 + BWD_WAVES / 2) * dec_geo(a.L, a.U, a.Dy).PW;     // epilogue: accumulator + 4 slabs
-#define DEC_BWD(UTV, VLV)                                                                                             \
+#define DEC_BWD(UTV)                                                                                                  \
     do {                                                                                                              \
         const int lds = (Img<UTV>::BWD_TOTAL > red_floats ? Img<UTV>::BWD_TOTAL : red_floats) * (int)sizeof(float);   \
-        if (VLV == 4 && (U & 15) == 0) {                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<UTV, 4, false, GIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-            hipLaunchKernelGGL((dec_bwd_kernel<UTV, 4, false, GIN>), dim3(blocks), dim3(BWD_THREADS), lds, s, a);    \
+        if ((U & 15) == 0) {                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<UTV, false, GIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            hipLaunchKernelGGL((dec_bwd_kernel<UTV, false, GIN>), dim3(blocks), dim3(BWD_THREADS), lds, s, a);        \
         } else {                                                                                                      \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<UTV, VLV, true, GIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-            hipLaunchKernelGGL((dec_bwd_kernel<UTV, VLV, true, GIN>), dim3(blocks), dim3(BWD_THREADS), lds, s, a);   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<UTV, true, GIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            hipLaunchKernelGGL((dec_bwd_kernel<UTV, true, GIN>), dim3(blocks), dim3(BWD_THREADS), lds, s, a);         \
         }                                                                                                             \
     } while (0)
     DEC_DISPATCH(U, DEC_BWD);
@@ -837,11 +933,11 @@ int vmp_decoder_loglike_fwd(const float* x, const float* y, const float* W0, con
     a.R = (unsigned)(N * K * S); a.K = (unsigned)K; a.S = (unsigned)S; a.L = L; a.Dy = Dy; a.U = U;
     const int blocks = dec_fwd_blocks((long long)a.R);
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define DEC_FWD(UTV, VLV)                                                                                             \
+#define DEC_FWD(UTV)                                                                                                  \
     do {                                                                                                              \
         const int lds = Img<UTV>::FWD_END * (int)sizeof(float);                                                       \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fwd_kernel<UTV, VLV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        hipLaunchKernelGGL((dec_fwd_kernel<UTV, VLV>), dim3(blocks), dim3(FWD_THREADS), lds, s, a);                   \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fwd_kernel<UTV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((dec_fwd_kernel<UTV>), dim3(blocks), dim3(FWD_THREADS), lds, s, a);                        \
     } while (0)
     DEC_DISPATCH(U, DEC_FWD);
 #undef DEC_FWD
