@@ -54,10 +54,13 @@ struct PassArgs {
     double* partials;
     long long N;
     long long rpw;        // rows per wave (multiple of 8): wave g owns rows [g*rpw, min(N, (g+1)*rpw))
+    long long rpw_b;      // != rpw: the first half of a block's waves own rpw rows each, the second half rpw_b (see make_plan)
     int K;
     int vec_ok;       // x pointer 16-byte aligned (vector row loads allowed)
     int par_reduce;   // LDS holds one fp64 slab per wave: reduce the waves in one parallel step
+    long long* dbg_t; // exploration only: timestamps of block 0 / wave 0 (vmp_debug_set_pass_timestamps)
 };
+#define PASS_TS(i) do { if (a.dbg_t && (blockIdx.x == 0 || blockIdx.x == 100) && (threadIdx.x & 63) == 0) a.dbg_t[(blockIdx.x ? 64 : 0) + (threadIdx.x >> 6) * 8 + (i)] = clock64(); } while (0)
 
 template <int D>
 __device__ __forceinline__ void load_row(const float* __restrict__ p, float (&o)[D], bool vec) {
@@ -118,6 +121,9 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int K = a.K;
+    PASS_TS(0);
+    if (a.dbg_t && (blockIdx.x == 0 || blockIdx.x == 100) && (threadIdx.x & 63) == 0)
+        a.dbg_t[(blockIdx.x ? 64 : 0) + (threadIdx.x >> 6) * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
     float* xl = smem + wave * (G::XROWS * LS);     // [XROWS][LS]: (x - pivot) columns, ones, zeros
     constexpr int ONE = D, ZERO = D + 1;
     xl[ONE * LS + lane] = 1.0f;
@@ -213,14 +219,29 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
     // Each wave owns a CONTIGUOUS row range of the same length (a multiple of 8 rows): with whole 64-row tiles dealt
     // round-robin the waves of a full chip get 5 or 6 tiles each at N=1e6 and everyone waits for the 6s.
     const bool vec = a.vec_ok != 0;
-    const long long lo = ((long long)blockIdx.x * nw + wave) * a.rpw;
-    const long long hi = (lo + a.rpw < a.N) ? lo + a.rpw : a.N;
+    long long lo, hi;
+    if (a.rpw_b == a.rpw) {
+        lo = ((long long)blockIdx.x * nw + wave) * a.rpw;
+        hi = lo + a.rpw;
+    } else {
+        const int hw = nw >> 1;
+        const long long base = (long long)blockIdx.x * hw * (a.rpw + a.rpw_b);
+        lo = wave < hw ? base + wave * a.rpw : base + hw * a.rpw + (wave - hw) * a.rpw_b;
+        hi = lo + (wave < hw ? a.rpw : a.rpw_b);
+    }
+    if (hi > a.N) hi = a.N;
     float xr[D];
     {
         const long long n = lo + lane;
 #pragma unroll
         for (int j = 0; j < D; ++j) xr[j] = 0.f;
         if (n < hi) load_row<D>(a.x + n * D, xr, vec);
+    }
+    if (a.dbg_t) {                                                        // parameters and first rows have arrived
+        float chk = xr[0] + pv[0];
+        if constexpr (ESTEP) chk += pm2[0][0][0] + pch[0].x;
+        asm volatile("" :: "v"(chk));
+        PASS_TS(1);
     }
     for (long long row0 = lo; row0 < hi; row0 += TR) {
         const int trows = (hi - row0 < TR) ? (int)(hi - row0) : TR;      // rows of this (possibly partial) tile
@@ -497,9 +518,11 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
         __builtin_amdgcn_wave_barrier();
     }
 
+    PASS_TS(2);
     if constexpr (STATS) {
         // ---- block reduction in fp64 (waves summed in a fixed order), then one partial per block
         __syncthreads();
+        PASS_TS(3);
         double* sc = reinterpret_cast<double*>(smem);          // [KT][FT+1][4][64]
         constexpr int SLAB = KT * (FT + 1) * 4 * WAVE;
         if (a.par_reduce) {
@@ -540,6 +563,7 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
                 __syncthreads();
             }
         }
+        PASS_TS(4);
         // partials[k][block][PX]: one component's rows of all blocks are contiguous (what a finalize block streams);
         // slot PF of every row = this block's sum_k N_k (the Dirichlet normaliser needs the total count)
         constexpr int PX = G::PF + 1;
@@ -564,6 +588,7 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
             }
             for (int k = 0; k < K; ++k) out[((long long)k * MAX_BLOCKS + blockIdx.x) * PX + G::PF] = ntot;
         }
+        PASS_TS(5);
     }
 }
 
@@ -996,7 +1021,7 @@ __global__ __launch_bounds__(1024) void pivot_kernel(PivotArgs a) {
 struct Plan {
     int nw, blocks, par_reduce;
     size_t lds;
-    long long rpw;
+    long long rpw, rpw_b;
 };
 
 int env_int(const char* name, int dflt) {
@@ -1023,6 +1048,21 @@ Plan make_plan(long long N, int D, int K, int flavour, bool stats) {
     rpw = (rpw + 7) / 8 * 8;
     if (rpw < TR) rpw = TR;
     blocks = ((N + rpw - 1) / rpw + nw - 1) / nw;
+    p.rpw_b = rpw;
+    // Two waves share a SIMD (w and w + 4 of an 8-wave block) and the sequencer serves the OLDER one first: with equal
+    // shares, clock64 stamps (tools/pass_ts.py) show waves 0-3 done at 76 k cycles and waves 4-7 at 107 k - the last 30 %
+    // of the kernel runs one wave per SIMD with nothing to hide its latencies behind (s_setprio does not change it).  The
+    // older waves therefore get the larger share, so that both mates finish together.  Ranges stay contiguous and fixed:
+    // results remain deterministic.
+    static const int split = env_int("VMP_MIX_SPLIT", 64);        // % of a pair's rows for the older wave; measured optimum (GMM, SMM, N = 1e6, 1e7)
+    if (nw == 8 && split != 50 && rpw >= 2 * TR) {
+        long long ra = (2 * rpw * split / 100 + 7) / 8 * 8, rb = 2 * rpw - ra;
+        if (rb >= TR) {
+            rpw = ra;
+            p.rpw_b = rb;
+            blocks = (N + 4 * (ra + rb) - 1) / (4 * (ra + rb));
+        }
+    }
     p.rpw = rpw;
     p.nw = nw;
     p.blocks = (int)blocks;
@@ -1088,10 +1128,13 @@ int check_dims(int64_t N, int D, int K) {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+static long long* g_dbg_pass = nullptr;
 int run_pass(PassArgs a, int D, int flavour, bool estep, bool stats, bool mask, hipStream_t s) {
     Plan p = make_plan(a.N, D, a.K, flavour, stats);
     a.rpw = p.rpw;
+    a.rpw_b = p.rpw_b;
     a.par_reduce = p.par_reduce;
+    a.dbg_t = g_dbg_pass;
 
     int rc = -1;
     VMP_DISPATCH_D(D, rc = launch_pass_d<DD>(a, p, flavour, estep, stats, mask, s));
@@ -1118,6 +1161,7 @@ int run_finalize(FinArgs f, int D, hipStream_t s) {
 extern "C" {
 
 void vmp_debug_set_finalize_timestamps(long long* p) { g_dbg_t = p; }
+void vmp_debug_set_pass_timestamps(long long* p) { g_dbg_pass = p; }
 
 int vmp_mix_pack_words(int D) { return pack_words(D); }
 int vmp_mix_stats_words(int D) { return stats_words(D); }
