@@ -139,6 +139,28 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
     const int ppos = lane;
 #endif
 
+    // (The first rows are requested before the parameters, so that both are in flight together.)
+    // Each wave owns a CONTIGUOUS row range of the same length (a multiple of 8 rows): with whole 64-row tiles dealt
+    // round-robin the waves of a full chip get 5 or 6 tiles each at N=1e6 and everyone waits for the 6s.
+    const bool vec = a.vec_ok != 0;
+    long long lo, hi;
+    if (a.rpw_b == a.rpw) {
+        lo = ((long long)blockIdx.x * nw + wave) * a.rpw;
+        hi = lo + a.rpw;
+    } else {
+        const int hw = nw >> 1;
+        const long long base = (long long)blockIdx.x * hw * (a.rpw + a.rpw_b);
+        lo = wave < hw ? base + wave * a.rpw : base + hw * a.rpw + (wave - hw) * a.rpw_b;
+        hi = lo + (wave < hw ? a.rpw : a.rpw_b);
+    }
+    if (hi > a.N) hi = a.N;
+    float xr[D];
+    {
+        const long long n = lo + lane;
+#pragma unroll
+        for (int j = 0; j < D; ++j) xr[j] = 0.f;
+        if (n < hi) load_row<D>(a.x + n * D, xr, vec);
+    }
     const int i16 = lane & 15, kk = lane >> 4;
     // NOTE on every "cond ? load : 0" below: a load under a per-element condition compiles to a branch plus a full
     // s_waitcnt per element (serialised round trips).  Loads are therefore issued unconditionally from an address
@@ -162,8 +184,18 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
             const bool on = k < K;
             const float* __restrict__ p = a.pack + (on ? k : 0) * G::PACK;
             float raw[G::PACK];
+            if (G::PACK % 4 == 0 && (reinterpret_cast<uintptr_t>(a.pack) & 15) == 0) {
+                // 16-byte loads: a quarter of the requests.  (The ~5 k cycles a wave spends before its first row is processed -
+                // tools/pass_ts.py - did not move with this nor with the order of the requests: first-touch latency.)
 #pragma unroll
-            for (int j = 0; j < G::PACK; ++j) raw[j] = p[j];                  // all loads in flight together
+                for (int j = 0; j < G::PACK / 4; ++j) {
+                    const float4 q = reinterpret_cast<const float4*>(p)[j];
+                    raw[4 * j] = q.x; raw[4 * j + 1] = q.y; raw[4 * j + 2] = q.z; raw[4 * j + 3] = q.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < G::PACK; ++j) raw[j] = p[j];              // all loads in flight together
+            }
 #pragma unroll
             for (int j = 0; j < 2 * MP; ++j) pm2[kt][j >> 1][j & 1] = (on && j < D) ? raw[j < D ? j : 0] - pv[j < D ? j : 0] : 0.f;
 #pragma unroll
@@ -216,27 +248,6 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
         }
     }
 
-    // Each wave owns a CONTIGUOUS row range of the same length (a multiple of 8 rows): with whole 64-row tiles dealt
-    // round-robin the waves of a full chip get 5 or 6 tiles each at N=1e6 and everyone waits for the 6s.
-    const bool vec = a.vec_ok != 0;
-    long long lo, hi;
-    if (a.rpw_b == a.rpw) {
-        lo = ((long long)blockIdx.x * nw + wave) * a.rpw;
-        hi = lo + a.rpw;
-    } else {
-        const int hw = nw >> 1;
-        const long long base = (long long)blockIdx.x * hw * (a.rpw + a.rpw_b);
-        lo = wave < hw ? base + wave * a.rpw : base + hw * a.rpw + (wave - hw) * a.rpw_b;
-        hi = lo + (wave < hw ? a.rpw : a.rpw_b);
-    }
-    if (hi > a.N) hi = a.N;
-    float xr[D];
-    {
-        const long long n = lo + lane;
-#pragma unroll
-        for (int j = 0; j < D; ++j) xr[j] = 0.f;
-        if (n < hi) load_row<D>(a.x + n * D, xr, vec);
-    }
     if (a.dbg_t) {                                                        // parameters and first rows have arrived
         float chk = xr[0] + pv[0];
         if constexpr (ESTEP) chk += pm2[0][0][0] + pch[0].x;
@@ -897,17 +908,19 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
                 if (i >= tid) p[i * (i + 1) / 2 + tid] = (float)(X[i] * sv);      // W = sqrt(v) L^{-1}, lower
         }
         if (tid == 0) { scal[0] = -2.0 * sumlog; scal[1] = ok ? 1.0 : 0.0; }
-    } else if (tid >= 64 && tid < 64 + D) {
+    } else if (tid >= 64 && tid < 64 + D + 2) {
+        // all digammas in ONE wave and ONE code path (different branches of a wave run one after the other: four
+        // special-function evaluations in sequence were most of this phase)
         const int i = tid - 64;
-        sp[i] = digamma_d(0.5 * (v_k + (smm ? 0.0 : 1.0) + i));     // gmm.py:128-129 / smm.py:107-108
-    } else if (tid == 64 + D) {
-        sp[D] = digamma_d(alpha_k);
-    } else if (tid == 64 + D + 1) {
-        double asum = 0.0;
-        for (int j = 0; j < K; ++j) asum += alpha0s[j];
-        asum += ntot;
-        sp[D + 1] = digamma_d(asum);
-    } else if (tid == 64 + D + 2 && smm) {
+        double arg = 0.5 * (v_k + (smm ? 0.0 : 1.0) + i);             // gmm.py:128-129 / smm.py:107-108
+        if (i == D) arg = alpha_k;
+        if (i == D + 1) {
+            double asum = 0.0;
+            for (int j = 0; j < K; ++j) asum += alpha0s[j];
+            arg = asum + ntot;
+        }
+        sp[i] = digamma_d(arg);
+    } else if (tid == 128 && smm) {
         sp[D + 2] = lgamma(0.5 * (D + kap)) - lgamma(0.5 * kap);
     }
     __syncthreads();
