@@ -56,6 +56,7 @@ struct DecArgs {
     unsigned R;            // rows
     unsigned K, S;
     int L, Dy, U;
+    int split;             // backward: % of a SIMD pair's tiles that go to the older wave (see dec_bwd_kernel)
 };
 
 struct DecGeo {
@@ -541,7 +542,6 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
     const int rd_hm1 = ((g >> 1) * 2 + (g & 1)) * 256 + rd_c;              // operand (h|m) of a 1-tile set
     const int rd_xx = (g & 1) * 256 + rd_c;                               // operand (h|h): + tile * 512; (m|m): + (NT + tile) * 512
     const unsigned ntiles = (a.R + 15u) / 16u;
-    const unsigned nwaves = gridDim.x * BWD_WAVES;
     const int L = a.L, Dy = a.Dy, U = a.U;
     const float invS = 1.0f / (float)a.S, invK = 1.0f / (float)a.K;
     const unsigned ncells = a.R / a.S;
@@ -561,6 +561,16 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
         for (int j = 0; j < UT; ++j) aW1[i][j] = zero4;
     }
 
+    // Tile ranges.  A block owns a contiguous run of tiles, each SIMD pair of waves (w, w + 4) a quarter of it.  The sequencer
+    // serves the OLDER wave of a pair first, so with equal shares the younger one would run the last third of the kernel
+    // alone, with nothing to hide its latencies behind (measured on the T1 pass kernel, tools/pass_ts.py): the older wave
+    // gets a.split % of the pair's tiles.  Static ranges: the summation order, hence every bit of the result, is fixed.
+    const unsigned tpb = (ntiles + gridDim.x - 1) / gridDim.x;
+    const unsigned b0 = min(blockIdx.x * tpb, ntiles), b1 = min(b0 + tpb, ntiles);
+    const unsigned tpp = (tpb + 3) / 4;
+    const unsigned p0 = min(b0 + (wave & 3) * tpp, b1), p1 = min(p0 + tpp, b1);
+    const unsigned pm = min(p0 + (tpp >= 8u ? (tpp * (unsigned)a.split + 50u) / 100u : (tpp + 1u) / 2u), p1);   // few tiles: even shares
+    const unsigned t0 = wave < 4 ? p0 : pm, t1 = wave < 4 ? pm : p1;
     // per-tile inputs of a lane: x[row c][g], x[row c][4+g] and either (gA, y) or the two upstream gradient pairs; the
     // NEXT tile's are fetched while the current tile is processed
     struct TileIn {
@@ -568,7 +578,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
     };
     auto fetch = [&](unsigned tile) -> TileIn {
         TileIn t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (tile >= ntiles) return t;
+        if (tile >= t1) return t;
         const unsigned row = tile * 16u + c;
         const bool ok = row < a.R;
         const unsigned rr = ok ? row : a.R - 1u;
@@ -588,12 +598,12 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
         }
         return t;
     };
-    TileIn nxt = fetch(blockIdx.x * BWD_WAVES + wave);
-    for (unsigned tile = blockIdx.x * BWD_WAVES + wave; tile < ntiles; tile += nwaves) {
+    TileIn nxt = fetch(t0);
+    for (unsigned tile = t0; tile < t1; ++tile) {
         const unsigned row = tile * 16u + c;
         const bool ok = row < a.R;
         const TileIn cur = nxt;
-        nxt = fetch(tile + nwaves);
+        nxt = fetch(tile + 1);
         const float xb0 = cur.xb0, xb1 = cur.xb1, ga = cur.ga;
         const float yv[2] = {cur.p0, cur.p1}, gin_m[2] = {cur.p0, cur.p1}, gin_v[2] = {cur.q0, cur.q1};
 
@@ -888,7 +898,11 @@ int dec_check(const char* what, long long N, int K, int S, int L, int Dy, int U)
     } while (0)
 
 template <bool GIN>
-int dec_bwd_launch(const DecArgs& a, int blocks, hipStream_t s) {
+int dec_bwd_launch(const DecArgs& a0, int blocks, hipStream_t s) {
+    // measured optimum at 4.2e7 rows: 58 % for U = 50 (10.0 -> 9.3 ms), 54 % for U = 64 (11.8 -> 11.3 ms)
+    static const int split = getenv("VMP_DEC_SPLIT") ? atoi(getenv("VMP_DEC_SPLIT")) : 0;
+    DecArgs a = a0;
+    a.split = split ? split : ((a0.U & 15) ? 58 : 54);
     const int U = a.U;
     const int red_floats = (1 + BWD_WAVES / 2) * dec_geo(a.L, a.U, a.Dy).PW;     // epilogue: accumulator + 4 slabs
 #define DEC_BWD(UTV)                                                                                                  \
