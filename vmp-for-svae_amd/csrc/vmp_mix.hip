@@ -112,6 +112,13 @@ __device__ __forceinline__ v2f row16_sum2(v2f v) {
 
 constexpr int MOM_TERMS = 3;
 
+__device__ __forceinline__ double readlane_d(double v, int src_lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src_lane);
+    hi = __builtin_amdgcn_readlane(hi, src_lane);
+    return __hiloint2double(hi, lo);
+}
+
 template <int D, int KT, int FLAV, bool ESTEP, bool STATS, bool MASK>
 __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
     using G = Geo<D>;
@@ -591,13 +598,16 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
                 row[G::F] = sc[e];                             // Nk = sum_n r_nk
             }
         }
-        if (threadIdx.x == 0) {
+        if (wave == 0) {                                       // lane k holds N_k; fixed-order sum; lane k writes row k's slot
             double ntot = 0.0;
-            for (int k = 0; k < K; ++k) {
-                const int kt = k >> 4, l = ((k & 15) >> 2) * 16, c = k & 3;
-                ntot += sc[((kt * (FT + 1) + FT) * 4 + c) * WAVE + l];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const int k = kt * 16 + (lane & 15), l = ((k & 15) >> 2) * 16, c = k & 3;
+                const double nk = (lane < 16 && k < K) ? sc[((kt * (FT + 1) + FT) * 4 + c) * WAVE + l] : 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) ntot += readlane_d(nk, j);
             }
-            for (int k = 0; k < K; ++k) out[((long long)k * MAX_BLOCKS + blockIdx.x) * PX + G::PF] = ntot;
+            for (int k = lane; k < K; k += WAVE) out[((long long)k * MAX_BLOCKS + blockIdx.x) * PX + G::PF] = ntot;
         }
         PASS_TS(5);
     }
@@ -684,12 +694,6 @@ __device__ __forceinline__ void tri_inv_lower(const double (&L)[D * D], double (
 }
 
 
-__device__ __forceinline__ double readlane_d(double v, int src_lane) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, src_lane);
-    hi = __builtin_amdgcn_readlane(hi, src_lane);
-    return __hiloint2double(hi, lo);
-}
 
 // Wave-parallel factorisation of the SPD matrix A (DxD in LDS): lane i owns row i.  Cholesky A = L L^T by
 // columns (finished entries are broadcast with v_readlane, so the code is uniform across lanes), then lane c
