@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r01_bench.json, produced by `python bench.py` on an MI355X) carries every field of
+"""The committed bench line (profiles/r02_bench.json, produced by `python bench.py` on an MI355X) carries every field of
 the driver's contract, with the roofline arithmetic consistent with DESIGN.md's algorithmic bytes."""
 import json
 import os
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_schema():
-    d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_bench.json')))
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r02_bench.json')))
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
