@@ -383,3 +383,34 @@ def test_fused_pass_equals_estep_only_repeatedly(N, D, K):
         tol = 1e-6 if flav == L.VMP_GMM else 2e-5
         parity_log.record('abs', worst, tol, 'fused vs E-only, flavour %d' % flav)
         assert worst <= tol, (flav, worst)
+
+
+@pytest.mark.parametrize('flavour', ['gmm', 'smm'])
+def test_uneven_wave_shares_cover_every_row_once(flavour):
+    """At this size the pass kernel gives the two waves of a SIMD uneven contiguous row ranges (csrc/vmp_mix.hip make_plan:
+    64 % / 36 %); N is odd, so the last range is ragged.  Every row must be written exactly once and counted exactly once:
+    r (pre-filled with NaN) against the chunked fp64 oracle, and the moments against a direct fp64 evaluation."""
+    from oracle import mixtures
+    from vmp_for_svae_amd import _lib as L
+    from vmp_for_svae_amd.models import _mix
+    N, D, K = 300_007, 8, 16
+    x, r0 = _synth(N, D, K, seed=5)
+    smm = flavour == 'smm'
+    xd, rd = dev(x), dev(r0)
+    loop = _mix.VMPLoop(xd, rd.clone(), L.VMP_SMM if smm else L.VMP_GMM, kappa=torch.full((K,), 5.0, device='cuda') if smm else None)
+    r = loop.step()
+    assert torch.isfinite(r).all()
+    xo, ro = torch.as_tensor(x).double(), torch.as_tensor(r0).double()
+    if smm:
+        want, _, _, _ = mixtures.smm_inference_step_chunked(xo, ro, torch.ones_like(ro), 5.0)
+    else:
+        want, _, _, _ = mixtures.gmm_inference_step_chunked(xo, ro)
+    assert abserr(r, want.numpy()) <= (2e-4 if smm else 2e-5)
+    r2 = loop.step()                                                 # its M-part used the moments the fused pass accumulated
+    st = loop.stats
+    rs = r2.double().sum(1)
+    assert (rs - 1).abs().max().item() < 1e-5
+    w = (r2.double() * loop.u.double()) if smm else r2.double()
+    sx = w.t() @ xd.double()
+    assert ((st[:, 2:2 + D] - sx).abs().max() / sx.abs().max()).item() < 1e-6
+    assert abs(st[:, 0].sum().item() - rs.sum().item()) < 1e-6 * N
