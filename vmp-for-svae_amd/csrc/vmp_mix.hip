@@ -95,18 +95,23 @@ __device__ __forceinline__ void load_row(const float* __restrict__ p, float (&o)
     "v_" OP "_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"  \
     "s_nop 0\n\t"
 // two independent reductions interleaved: the partner's instruction is one of the two wait states
+// (the first step reads the inputs and writes fresh registers: no copies to keep the un-reduced values alive)
+#define VMP_DPP2_FIRST(OP, CTRL)                                             \
+    "v_" OP "_f32_dpp %0, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"  \
+    "v_" OP "_f32_dpp %1, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"  \
+    "s_nop 0\n\t"
 __device__ __forceinline__ v2f row16_max2(v2f v) {
-    float a = v.x, b = v.y;
-    asm("s_nop 1\n\t" VMP_DPP2("max", "row_ror:8") VMP_DPP2("max", "row_ror:4") VMP_DPP2("max", "row_ror:2")
+    float a, b;
+    asm("s_nop 1\n\t" VMP_DPP2_FIRST("max", "row_ror:8") VMP_DPP2("max", "row_ror:4") VMP_DPP2("max", "row_ror:2")
         VMP_DPP2("max", "row_ror:1")
-        : "+v"(a), "+v"(b));
+        : "=&v"(a), "=&v"(b) : "v"(v.x), "v"(v.y));
     return v2f{a, b};
 }
 __device__ __forceinline__ v2f row16_sum2(v2f v) {
-    float a = v.x, b = v.y;
-    asm("s_nop 1\n\t" VMP_DPP2("add", "row_ror:8") VMP_DPP2("add", "row_ror:4") VMP_DPP2("add", "row_ror:2")
+    float a, b;
+    asm("s_nop 1\n\t" VMP_DPP2_FIRST("add", "row_ror:8") VMP_DPP2("add", "row_ror:4") VMP_DPP2("add", "row_ror:2")
         VMP_DPP2("add", "row_ror:1")
-        : "+v"(a), "+v"(b));
+        : "=&v"(a), "=&v"(b) : "v"(v.x), "v"(v.y));
     return v2f{a, b};
 }
 
