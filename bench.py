@@ -181,9 +181,9 @@ def bench_t2(N, Ld, K, S, steps, warmup, dev, dist=None, world=1):
 
 
 def bench_t3(N, Ld, K, S, U, steps, warmup, dev, chunk):
-    """T3: the full training step of experiments.py:196-267 (encoder MLP in torch fp32; decoder MLP + reconstruction
-    term in the fused fp32-MFMA kernels; fused E-step kernels; all gradients, TF-Adam, CVI) on synthetic y = GMM data
-    with Dy = L."""
+    """T3: the full training step of experiments.py:196-267 (encoder / decoder MLP + reconstruction term in the fused
+    MFMA kernels; fused E-step kernels; all gradients, TF-Adam, CVI) on synthetic y = GMM data with Dy = L.  Timed with
+    eps from torch.randn (the default) and, next to it, drawn inside the E-step kernel (rng='philox')."""
     from vmp_for_svae_amd.models import vae
     from vmp_for_svae_amd.training import SVAETrainer
     vae.reset_variables()
@@ -200,7 +200,20 @@ def bench_t3(N, Ld, K, S, U, steps, warmup, dev, chunk):
     dt = time.perf_counter() - t0
     rows = float(N) * K * S
     dec_flop = 3 * 2.0 * rows * (Ld * U + U * U + U * 2 * Ld + Ld * Ld)     # fwd + 2x bwd, useful flops of the decoder
+    del tr
+    torch.cuda.empty_cache()
+    vae.reset_variables()
+    tr = SVAETrainer(K, Ld, U, Ld, nb_samples=S, device=dev, rng='philox')
+    for _ in range(warmup):
+        tr.step(y, chunk=chunk)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(y, chunk=chunk)
+    torch.cuda.synchronize()
+    dt_p = time.perf_counter() - t0
     return {'steps_per_sec': steps / dt, 'ms_per_step': dt / steps * 1e3, 'datapoints_per_sec': N * steps / dt,
+            'ms_per_step_in_kernel_philox': dt_p / steps * 1e3,
             'elbo_per_datapoint': float(out['elbo']) / N, 'decoder_rows_per_step': rows,
             'decoder_useful_TFLOPs_over_whole_step': dec_flop / (dt / steps) / 1e12,
             'config': 'T3 svae-train N=%d (%s), L=Dy=%d, K=%d, S=%d, U=%d' % (
