@@ -852,11 +852,20 @@ struct DecRedArgs {
     float* out;
     int blocks, PW, obs2, Dy;
 };
-__global__ __launch_bounds__(256) void dec_reduce_kernel(DecRedArgs r) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= r.PW) return;
+// 64 consecutive parameters per block; lane group bg = tid / 64 sums the block rows b = bg, bg + 16, .. (independent coalesced
+// loads instead of one chain of `blocks` dependent ones), the 16 group sums are added in a fixed order.
+constexpr int DEC_RED_GROUPS = 16;
+__global__ __launch_bounds__(64 * DEC_RED_GROUPS) void dec_reduce_kernel(DecRedArgs r) {
+    __shared__ double part[DEC_RED_GROUPS][64];
+    const int eg = threadIdx.x & 63, bg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + eg;
     double s = 0.0;
-    for (int b = 0; b < r.blocks; ++b) s += (double)r.part[(size_t)b * r.PW + i];
+    if (i < r.PW)
+        for (int b = bg; b < r.blocks; b += DEC_RED_GROUPS) s += (double)r.part[(size_t)b * r.PW + i];
+    part[bg][eg] = s;
+    __syncthreads();
+    if (bg != 0 || i >= r.PW) return;
+    for (int g2 = 1; g2 < DEC_RED_GROUPS; ++g2) s += part[g2][eg];
     if (i >= r.obs2) s *= 1.0 / (1.0 + exp(-(double)r.bs2[i - r.obs2]));
     r.out[i] = (float)s;
 }
@@ -985,7 +994,7 @@ int vmp_decoder_loglike_bwd(const float* x, const float* y, const float* gA, con
     const int blocks = dec_bwd_blocks((long long)a.R);
     if (int e = dec_bwd_launch<false>(a, blocks, s)) return e;
     DecRedArgs r{a.part, bs2, dparams, blocks, q.PW, q.obs2, Dy};
-    hipLaunchKernelGGL(dec_reduce_kernel, dim3((q.PW + 255) / 256), dim3(256), 0, s, r);
+    hipLaunchKernelGGL(dec_reduce_kernel, dim3((q.PW + 63) / 64), dim3(64 * DEC_RED_GROUPS), 0, s, r);
     return check_launch("vmp_decoder_loglike_bwd(reduce)");
 }
 
@@ -1015,7 +1024,7 @@ int vmp_mlp_gauss_bwd(const float* x, const float* gmean, const float* gvar, con
     const int blocks = dec_bwd_blocks((long long)a.R);
     if (int e = dec_bwd_launch<true>(a, blocks, s)) return e;
     DecRedArgs r{a.part, bs2, dparams, blocks, q.PW, q.obs2, Dy};
-    hipLaunchKernelGGL(dec_reduce_kernel, dim3((q.PW + 255) / 256), dim3(256), 0, s, r);
+    hipLaunchKernelGGL(dec_reduce_kernel, dim3((q.PW + 63) / 64), dim3(64 * DEC_RED_GROUPS), 0, s, r);
     return check_launch("vmp_mlp_gauss_bwd(reduce)");
 }
 

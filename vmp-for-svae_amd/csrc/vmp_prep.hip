@@ -252,13 +252,25 @@ struct RedArgs {
     int nblk, K, L;
 };
 
-__global__ __launch_bounds__(256) void svae_bwd_reduce_kernel(RedArgs a) {
+// A block sums 64 consecutive (k, f) elements: lane group bg = tid / 64 takes the rows b = bg, bg + 16, .. of the partials
+// (64 consecutive floats per row: coalesced, independent loads), the 16 group sums are then added in a fixed order.
+// (One thread per element walking all rows was a chain of nblk dependent strided loads: 390 us at nblk = 1024.)
+constexpr int RED_GROUPS = 16;
+__global__ __launch_bounds__(64 * RED_GROUPS) void svae_bwd_reduce_kernel(RedArgs a) {
     const int L = a.L, TRI = L * (L + 1) / 2, TH = L + TRI + 1, PW = 2 * TH;
     const int half = a.g_mk ? PW : TH;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < a.K * half; e += gridDim.x * blockDim.x) {
-        const int k = e / half, f = e - k * half;
-        double s = 0.0;
-        for (int b = 0; b < a.nblk; ++b) s += (double)a.partials[((size_t)b * a.K + k) * PW + f];
+    __shared__ double part[RED_GROUPS][64];
+    const int eg = threadIdx.x & 63, bg = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + eg;
+    const bool live = e < a.K * half;
+    const int k = live ? e / half : 0, f = live ? e - k * half : 0;
+    double s = 0.0;
+    if (live)
+        for (int b = bg; b < a.nblk; b += RED_GROUPS) s += (double)a.partials[((size_t)b * a.K + k) * PW + f];
+    part[bg][eg] = s;
+    __syncthreads();
+    if (bg == 0 && live) {
+        for (int g2 = 1; g2 < RED_GROUPS; ++g2) s += part[g2][eg];
         const float v = (float)s;
         const int g = f < TH ? f : f - TH;                  // position inside the phi-side / theta-side group
         const bool th = f >= TH;
@@ -326,7 +338,7 @@ int vmp_svae_bwd_reduce(const float* partials, int nblk, int K, int L, float* g_
     }
     RedArgs a{partials, g_hk, g_P, g_bias, g_mk, g_W, g_kappa, nblk, K, L};
     const int n = K * 2 * (L + L * (L + 1) / 2 + 1);
-    hipLaunchKernelGGL(svae_bwd_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(svae_bwd_reduce_kernel, dim3((n + 63) / 64), dim3(64 * RED_GROUPS), 0, static_cast<hipStream_t>(stream), a);
     return check_launch("vmp_svae_bwd_reduce");
 }
 
