@@ -561,10 +561,25 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
                     mine[((kt * (FT + 1) + FT) * 4 + c) * WAVE + lane] = SMM ? dn[kt][c] : dacc[kt][0][c];
                 }
             __syncthreads();
-            for (int e = threadIdx.x; e < SLAB; e += blockDim.x) {
-                double t2 = sc[e];
-                for (int w = 1; w < nw; ++w) t2 += sc[w * SLAB + e];
-                sc[e] = t2;
+            // all slab values of a thread's elements are requested before the first addition (a rolled loop of dependent
+            // read-add steps cost ~1.6 k cycles here); the additions keep the wave order
+            constexpr int EPT = 2, NWB = max_nw(KT);               // elements per thread and round; bound on nw
+            for (int e0 = threadIdx.x; e0 < SLAB; e0 += EPT * blockDim.x) {
+                double vals[EPT][NWB];
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    const int e = e0 + q * blockDim.x;
+#pragma unroll
+                    for (int w = 0; w < NWB; ++w) vals[q][w] = (e < SLAB && w < nw) ? sc[w * SLAB + e] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    const int e = e0 + q * blockDim.x;
+                    double t2 = vals[q][0];
+#pragma unroll
+                    for (int w = 1; w < NWB; ++w) t2 += vals[q][w];
+                    if (e < SLAB) sc[e] = t2;
+                }
             }
             __syncthreads();
         } else {
