@@ -715,6 +715,15 @@ __device__ __forceinline__ void tri_inv_lower(const double (&L)[D * D], double (
 
 
 
+// 1/sqrt(x) for a positive, normal x: the hardware estimate (v_rsq_f64, ~2^-26) and two Newton steps - 8 dependent
+// operations on the serial chain of the factorisation instead of the library routine's range handling.
+__device__ __forceinline__ double fast_rsqrt_d(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
+
 // Wave-parallel factorisation of the SPD matrix A (DxD in LDS): lane i owns row i.  Cholesky A = L L^T by
 // columns (finished entries are broadcast with v_readlane, so the code is uniform across lanes), then lane c
 // solves L X = e_c, i.e. holds column c of L^{-1}.  Returns X (column `lane`), sum_i log L_ii and SPD-ness.
@@ -733,7 +742,7 @@ __device__ __forceinline__ void wave_chol_inverse(const double* A, int lane, dou
         for (int p = 0; p < j; ++p) t -= row[p] * readlane_d(row[p], j);
         const double sj = readlane_d(t, j);              // A_jj - sum_p L_jp^2   (the serial chain: keep it short)
         ok = ok && (sj > 0.0);
-        rd[j] = rsqrt(sj);                               // 1 / L_jj
+        rd[j] = fast_rsqrt_d(sj);                        // 1 / L_jj
         if (lane == j) mydiag = sj;
         row[j] = lane >= j ? t * rd[j] : 0.0;            // lane j: sj / sqrt(sj) = L_jj
     }
@@ -1093,11 +1102,14 @@ Plan make_plan(long long N, int D, int K, int flavour, bool stats) {
     // results remain deterministic.
     static const int split = env_int("VMP_MIX_SPLIT", 64);        // % of a pair's rows for the older wave; measured optimum (GMM, SMM, N = 1e6, 1e7)
     if (nw == 8 && split != 50 && rpw >= 2 * TR) {
-        long long ra = (2 * rpw * split / 100 + 7) / 8 * 8, rb = 2 * rpw - ra;
+        long long cap = tuned_blocks < MAX_BLOCKS ? tuned_blocks : MAX_BLOCKS;
+        long long pr = ((N + 4 * cap - 1) / (4 * cap) + 7) / 8 * 8;           // rows of a SIMD pair, all blocks in use
+        if (pr < 2 * TR) pr = 2 * TR;
+        const long long ra = (pr * split / 100 + 4) / 8 * 8, rb = pr - ra;
         if (rb >= TR) {
             rpw = ra;
             p.rpw_b = rb;
-            blocks = (N + 4 * (ra + rb) - 1) / (4 * (ra + rb));
+            blocks = (N + 4 * pr - 1) / (4 * pr);
         }
     }
     p.rpw = rpw;
