@@ -398,12 +398,13 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
                         if constexpr (FULL) {
                             // K == 16 KT here: every offset below the tile base is a compile-time constant
                             float* __restrict__ ro = a.r_out + tbase + kt * 16 + (long long)n0 * (16 * KT);
-                            ro[8 * u * 16 * KT] = rr[kt].x;
-                            ro[(8 * u + 4) * 16 * KT] = rr[kt].y;
+                            // streaming stores: r (and u) are written once per iteration and never read by these kernels
+                            __builtin_nontemporal_store(rr[kt].x, ro + 8 * u * 16 * KT);
+                            __builtin_nontemporal_store(rr[kt].y, ro + (8 * u + 4) * 16 * KT);
                             if constexpr (SMM) {
                                 float* __restrict__ uo = a.u_out + tbase + kt * 16 + (long long)n0 * (16 * KT);
-                                uo[8 * u * 16 * KT] = uu[kt].x;
-                                uo[(8 * u + 4) * 16 * KT] = uu[kt].y;
+                                __builtin_nontemporal_store(uu[kt].x, uo + 8 * u * 16 * KT);
+                                __builtin_nontemporal_store(uu[kt].y, uo + (8 * u + 4) * 16 * KT);
                             }
                             if (a.logr_out) {
                                 float* __restrict__ lo = a.logr_out + tbase + kt * 16 + (long long)n0 * (16 * KT);
