@@ -1080,7 +1080,6 @@ Plan make_plan(long long N, int D, int K, int flavour, bool stats) {
     Plan p;
     static const int tuned_blocks = env_int("VMP_MIX_BLOCKS", 256);   // one 12-wave block per CU
     static const int tuned_nw = env_int("VMP_MIX_NW", MAX_NW);
-    (void)flavour;
     const size_t wreg = (size_t)(D + 2) * LS * sizeof(float);
     int nw = tuned_nw;
     if (nw > max_nw((K + 15) / 16)) nw = max_nw((K + 15) / 16);
@@ -1101,7 +1100,8 @@ Plan make_plan(long long N, int D, int K, int flavour, bool stats) {
     // of the kernel runs one wave per SIMD with nothing to hide its latencies behind (s_setprio does not change it).  The
     // older waves therefore get the larger share, so that both mates finish together.  Ranges stay contiguous and fixed:
     // results remain deterministic.
-    static const int split = env_int("VMP_MIX_SPLIT", 64);        // % of a pair's rows for the older wave; measured optimum (GMM, SMM, N = 1e6, 1e7)
+    static const int split_env = env_int("VMP_MIX_SPLIT", 0);     // % of a pair's rows for the older wave
+    const int split = split_env ? split_env : (flavour == VMP_SMM ? 62 : 64);   // measured optima (N = 3e5 .. 1e7)
     if (nw == 8 && split != 50 && rpw >= 2 * TR) {
         long long cap = tuned_blocks < MAX_BLOCKS ? tuned_blocks : MAX_BLOCKS;
         long long pr = ((N + 4 * cap - 1) / (4 * cap) + 7) / 8 * 8;           // rows of a SIMD pair, all blocks in use
