@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q 2>&1 | tail -3
+python -m pytest tests -m gpu -q > gpurun_out/r02_pytest_gpu.log 2>&1; grep -a 'passed\|failed' gpurun_out/r02_pytest_gpu.log | tail -2
 python bench.py > gpurun_out/r02_bench.json 2> gpurun_out/r02_bench.err; tail -c 300 gpurun_out/r02_bench.err
 mkdir -p gpurun_out/r02_ks_bench; (cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r02_ks_bench -o k -- python3 $GRAFT_REPO_ROOT/bench.py > $GRAFT_REPO_ROOT/gpurun_out/r02_bench_prof.json 2>/dev/null)
 bash tools/pmc.sh r02_pmc_t1 tools/t1_prof_target.py > /dev/null 2>&1
