@@ -411,7 +411,9 @@ def main():
     kern_ms = float(np.median(kerns))
     assert torch.isfinite(loop.r).all()
     extra = {}
-    if not args.no_extra:
+    # the side measurements are single-GPU experiments: under a multi-rank launch only the headline is measured (nothing
+    # after the timed region may be able to take the JSON line down with it)
+    if not args.no_extra and world == 1:
         del loop
         torch.cuda.empty_cache()
         if world == 1:
