@@ -385,15 +385,15 @@ def test_fused_pass_equals_estep_only_repeatedly(N, D, K):
         assert worst <= tol, (flav, worst)
 
 
-@pytest.mark.parametrize('flavour', ['gmm', 'smm'])
-def test_uneven_wave_shares_cover_every_row_once(flavour):
+@pytest.mark.parametrize('flavour,N,D,K', [('gmm', 300_007, 8, 16), ('smm', 300_007, 8, 16), ('gmm', 150_001, 5, 33)])
+def test_uneven_wave_shares_cover_every_row_once(flavour, N, D, K):
     """At this size the pass kernel gives the two waves of a SIMD uneven contiguous row ranges (csrc/vmp_mix.hip make_plan:
-    64 % / 36 %); N is odd, so the last range is ragged.  Every row must be written exactly once and counted exactly once:
-    r (pre-filled with NaN) against the chunked fp64 oracle, and the moments against a direct fp64 evaluation."""
+    64 % / 36 %, also with K > 16 = several component tiles per lane); N is odd, so the last range is ragged.  Every row
+    must be written exactly once and counted exactly once: r against the chunked fp64 oracle, the moments against a
+    direct fp64 evaluation."""
     from oracle import mixtures
     from vmp_for_svae_amd import _lib as L
     from vmp_for_svae_amd.models import _mix
-    N, D, K = 300_007, 8, 16
     x, r0 = _synth(N, D, K, seed=5)
     smm = flavour == 'smm'
     xd, rd = dev(x), dev(r0)
