@@ -127,8 +127,15 @@ __device__ __forceinline__ float softplus_f(float v) {
 }
 __device__ __forceinline__ float sigmoid_f(float v) { return rcp_f(1.0f + __expf(-v)); }
 
-// tanh as the clamped rational x P(x^2) / Q(x^2) of Eigen's generic_fast_tanh_float - the implementation behind
-// tf.tanh in the reference's TensorFlow - max relative error 3.5e-7, |tanh| <= 1; two values per v_pk_* instruction.
+// tanh(x) = 1 - 2 / (1 + 2^(2 log2(e) x)): v_exp_f32 and v_rcp_f32 (1 ulp each) plus three plain operations per value -
+// about half the issue time of the clamped rational P(x^2)/Q(x^2) of Eigen's generic_fast_tanh_float behind tf.tanh
+// (13 packed operations + 2 v_med3 + 2 v_rcp per PAIR; measured cost table in DESIGN.md section 6).  Absolute error
+// <= 1.5e-7 over the whole range (the rational: 3.5e-7 relative), saturates to +-1 exactly through exp overflow /
+// underflow, |tanh| <= 1.  VMP_TANH_RATIONAL=1 builds the rational form.
+#ifndef VMP_TANH_RATIONAL
+#define VMP_TANH_RATIONAL 0
+#endif
+#if VMP_TANH_RATIONAL
 __device__ __forceinline__ v2f tanh2(v2f x) {
     const float lim = 7.90531110763549805f;
     x[0] = __builtin_amdgcn_fmed3f(x[0], -lim, lim);
@@ -153,6 +160,13 @@ __device__ __forceinline__ f32x4 tanh4(f32x4 z) {
     const v2f a = tanh2(v2f{z[0], z[1]}), b = tanh2(v2f{z[2], z[3]});
     return f32x4{a[0], a[1], b[0], b[1]};
 }
+#else
+__device__ __forceinline__ float tanh1(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);      // e^(2x)
+    return fmaf(-2.0f, rcp_f(e + 1.0f), 1.0f);
+}
+__device__ __forceinline__ f32x4 tanh4(f32x4 z) { return f32x4{tanh1(z[0]), tanh1(z[1]), tanh1(z[2]), tanh1(z[3])}; }
+#endif
 
 // hidden unit behind k-slot j of lane group g in k-block kb
 __device__ __forceinline__ int kslot_unit(int g, int j, int kb) { return 16 * (2 * kb + (j >> 2)) + 4 * g + (j & 3); }
