@@ -892,7 +892,7 @@ int dec_blocks(long long rows, int waves_per_block, int max_blocks) {
     return (int)b;
 }
 int dec_fwd_blocks(long long rows) {
-    static const int bpc = getenv("VMP_DEC_FWD_BPC") ? atoi(getenv("VMP_DEC_FWD_BPC")) : 4;    // blocks per CU: 82 VGPRs and 39 KB of LDS leave room for 4 (1.42 -> 1.29 ms per 1.05e7 rows)
+    static const int bpc = getenv("VMP_DEC_FWD_BPC") ? atoi(getenv("VMP_DEC_FWD_BPC")) : 16;   // blocks per CU: 4 are resident (82 VGPRs, 39 KB LDS), the rest back-fill as the older blocks - which the sequencer favours - finish (2 -> 4 -> 16: 4.5 -> 3.9 -> 3.5 ms per 4.2e7 rows)
     return dec_blocks(rows, FWD_THREADS / WAVE, 256 * bpc);
 }
 int dec_bwd_blocks(long long rows) { return dec_blocks(rows, BWD_WAVES, 256); }            // 1 block per CU
