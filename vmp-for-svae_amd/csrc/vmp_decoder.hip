@@ -504,13 +504,17 @@ __device__ __forceinline__ void wave_lds_order() {
 // the two half-rows of a write instruction (lanes c < 8 and c >= 8, 256 bytes apart = the same banks) land on different
 // banks; a read still covers each half's 256 bytes exactly once.
 __device__ __forceinline__ int trb_slot(int unit, int half) { return (unit & ~3) | ((unit + 2 * half) & 3); }
+// One ds_write_b32 per packed register instead of two ds_write_b16 (a 16-bit LDS write costs ~8 LDS cycles, a 32-bit one
+// ~4; with the b16 form the LDS pipe was 83 % busy, profiles/r02_decoder_pmc_summary.txt): neighbouring lanes (rows c, c^1)
+// first swap halves, so that the even lane holds (unit 2p: rows c, c+1) and the odd lane (unit 2p+1: rows c-1, c).
 template <int NT, int NTS>
 __device__ __forceinline__ void trb_write(unsigned char* __restrict__ T, int g, int c, const unsigned (&ts)[3][NTS]) {
-    const int half = c >> 3;
-    unsigned char* __restrict__ base = T + half * 256 + 2 * (c & 7);
-    int off[4];
+    const int half = c >> 3, odd = c & 1;
+    unsigned char* __restrict__ base = T + half * 256 + 2 * ((c & 7) - odd);
+    const unsigned sel = odd ? 0x03020706u : 0x05040100u;
+    int off[2];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) off[v] = trb_slot(4 * g + v, half) * 16;
+    for (int p = 0; p < 2; ++p) off[p] = trb_slot(4 * g + 2 * p + odd, half) * 16;
 #pragma unroll
     for (int term = 0; term < 2; ++term)
 #pragma unroll
@@ -518,9 +522,8 @@ __device__ __forceinline__ void trb_write(unsigned char* __restrict__ T, int g, 
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const unsigned pk = ts[term][2 * t + p];
-                unsigned char* q = base + (term * NT + t) * 512;
-                *reinterpret_cast<unsigned short*>(q + off[2 * p]) = (unsigned short)pk;
-                *reinterpret_cast<unsigned short*>(q + off[2 * p + 1]) = (unsigned short)(pk >> 16);
+                const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0xB1, 0xF, 0xF, true);   // quad_perm:[1,0,3,2]
+                *reinterpret_cast<unsigned*>(base + (term * NT + t) * 512 + off[p]) = __builtin_amdgcn_perm(nb, pk, sel);
             }
 }
 __device__ __forceinline__ u32x4 trb_read(const unsigned char* __restrict__ p) { return *reinterpret_cast<const u32x4*>(p); }
@@ -625,12 +628,13 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
         split_bf16<3>(v2f{xb0, xb1}, xs);
         const XOps xo = x_operands(xs);
         {   // x (h, m) terms transposed: lo half = dim g, hi half = dim 4+g of row c
-            unsigned char* __restrict__ q = scrXb + (c >> 3) * 256 + 2 * (c & 7);
-            const int o0 = trb_slot(g, c >> 3) * 16, o1 = trb_slot(4 + g, c >> 3) * 16;
+            const int odd = c & 1;
+            unsigned char* __restrict__ q = scrXb + (c >> 3) * 256 + 2 * ((c & 7) - odd) + trb_slot(odd ? 4 + g : g, c >> 3) * 16;
+            const unsigned sel = odd ? 0x03020706u : 0x05040100u;
 #pragma unroll
             for (int term = 0; term < 2; ++term) {
-                *reinterpret_cast<unsigned short*>(q + term * 512 + o0) = (unsigned short)xs[term];
-                *reinterpret_cast<unsigned short*>(q + term * 512 + o1) = (unsigned short)(xs[term] >> 16);
+                const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)xs[term], 0xB1, 0xF, 0xF, true);
+                *reinterpret_cast<unsigned*>(q + term * 512) = __builtin_amdgcn_perm(nb, xs[term], sel);
             }
         }
         f32x4 h0[UT], h1[UT], O;
