@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(256) void philox_noise_kernel(NoiseArgs a) {
 // RNG = true: no noise tensor at all - eps is generated in registers (Philox4x32-10, above) right where it is consumed;
 // the LDS tile then only serves the (cell, S, L) output transposition.
 template <int L, int ST, bool RNG>
-__global__ __launch_bounds__(4 * WAVE) void svae_estep_fwd4_kernel(EFwdArgs a, int CS_rt) {
+__global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(EFwdArgs a, int CS_rt) {
     constexpr int TRI = SvGeo<L>::TRI;
     constexpr int TP = (TRI + 1) / 2, LP = (L + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1116,8 +1116,11 @@ __global__ __launch_bounds__(4 * WAVE) void svae_estep_fwd4_kernel(EFwdArgs a, i
     constexpr int PSTR = TRI | 1;
     const int tab = (K * PSTR + 3) & ~3;
     float* pk_lds = smem;
-    float* buf0 = smem + tab + wave * (2 * WAVE * CS + WAVE);
-    float* scr = buf0 + 2 * WAVE * CS;
+    // two tile buffers per wave (the noise of the next tile arrives by DMA while this one is processed); with in-kernel noise
+    // nothing is prefetched: ONE buffer, which lets 7 waves instead of 4 share the LDS of a CU
+    constexpr int NBUF = RNG ? 1 : 2;
+    float* buf0 = smem + tab + wave * (NBUF * WAVE * CS + WAVE);
+    float* scr = buf0 + NBUF * WAVE * CS;
     const bool lane_on = lane < CT;
     const int r = lane / K, k = lane - r * K, rbase = lane_on ? r * K : 0;
     const bool k16 = (K == 16);
@@ -1229,7 +1232,7 @@ __global__ __launch_bounds__(4 * WAVE) void svae_estep_fwd4_kernel(EFwdArgs a, i
         for (int i = 0; i < L; ++i) { e1r[i] = a.eta1[rc0 * L + i]; e2r[i] = a.eta2d[rc0 * L + i]; }
     }
     for (; t < ntiles; t += tstride) {
-        float* et = buf0 + cur * (WAVE * CS);
+        float* et = buf0 + (RNG ? 0 : cur) * (WAVE * CS);
         const long long row = t * RPT + r;
         const bool on = lane_on && row < a.N;
         const long long rows_here = (a.N - t * RPT) < RPT ? (a.N - t * RPT) : RPT;
@@ -1628,15 +1631,15 @@ size_t vmp_svae_workspace_bytes(int64_t N, int K, int L) {
 int vmp_svae_bwd_blocks(int64_t N, int K) { return sv_blocks(N, K); }
 
 // LDS-DMA / in-kernel-noise forward kernel: launch geometry, or 0 waves when the shape is not covered
-static int fwd4_plan(int K, int L, int S, int& CS, size_t& lds4) {
+static int fwd4_plan(int K, int L, int S, int& CS, size_t& lds4, bool rng = false) {
     if ((L * S) % 4 != 0) return 0;
     if ((size_t)(L * S | 1) * WAVE * sizeof(float) > 36 * 1024) return 0;
     CS = L * S;
     if (((CS >> 2) & 1) == 0) CS += 4;
     const size_t table = (size_t)((K * ((L * (L + 1) / 2) | 1) + 3) & ~3) * sizeof(float);
-    const size_t pw = (size_t)(2 * WAVE * CS + WAVE) * sizeof(float);
+    const size_t pw = (size_t)((rng ? 1 : 2) * WAVE * CS + WAVE) * sizeof(float);
     int nw4 = (int)((158 * 1024 - table) / pw);
-    if (nw4 > 4) nw4 = 4;
+    if (nw4 > (rng ? 8 : 4)) nw4 = rng ? 8 : 4;
     if (nw4 < 1) return 0;
     lds4 = table + pw * nw4;
     return nw4;
@@ -1650,7 +1653,7 @@ static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
     if (rng) {
         int CS = 0;
         size_t lds4 = 0;
-        const int nw4 = fwd4_plan(K, L, S, CS, lds4);
+        const int nw4 = fwd4_plan(K, L, S, CS, lds4, true);
         if (nw4 < 1) { set_error("in-kernel noise covers L*S %% 4 == 0 tiles that fit the LDS only (L=%d, S=%d)", L, S); return VMP_E_DIM; }
         const int RPT4 = WAVE / K;
         long long bl = ((N + RPT4 - 1) / RPT4 + nw4 - 1) / nw4;
@@ -1792,7 +1795,7 @@ int vmp_svae_estep_fwd(const float* eta1, const float* eta2d, const float* hk, c
 int vmp_svae_rng_in_kernel(int K, int L, int S) {
     int CS = 0;
     size_t lds4 = 0;
-    return (K >= 1 && K <= 64 && L >= 1 && L <= 8 && fwd4_plan(K, L, S, CS, lds4) >= 1) ? 1 : 0;
+    return (K >= 1 && K <= 64 && L >= 1 && L <= 8 && fwd4_plan(K, L, S, CS, lds4, true) >= 1) ? 1 : 0;
 }
 
 int vmp_svae_philox_noise(uint64_t seed, int64_t N, int K, int L, int S, float* noise, void* stream) {
