@@ -91,7 +91,7 @@ def unpack_after_allreduce(buf, stats_shape, grad_shapes, n_scalars):
 class SVAETrainer(object):
     def __init__(self, K, Ld, U, Dy, nb_samples=10, lr=3e-4, lrcvi=0.2, decay_rate=0.95, stddev_init_nn=0.01, seed=0,
                  device='cuda', m_uniform=None, pi_normal=None, group=None, smm=False, dof=5.0, fused_decoder=True,
-                 rng='torch'):
+                 rng='philox'):
         self.K, self.L, self.S = K, Ld, nb_samples
         self.lr, self.lrcvi0, self.decay_rate = lr, lrcvi, decay_rate
         self.group = group
@@ -105,7 +105,11 @@ class SVAETrainer(object):
         self.fused_decoder = fused_decoder      # decoder + reconstruction term in the fused MFMA kernels when covered
         if rng not in ('torch', 'philox'):
             raise ValueError("rng must be 'torch' (noise tensor from torch.randn) or 'philox' (drawn inside the E-step kernel)")
-        self.rng = rng                          # where eps comes from when the caller injects none
+        # where eps comes from when the caller injects none.  'philox' (default): drawn inside the fused E-step kernel, as
+        # the reference's tf.random_normal is drawn inside its step (svae.py:113-114) - no (N,K,L,S) tensor exists, and at
+        # C3 the kernel is faster than the one that reads a noise tensor (1.85 vs 2.0 ms + 1.45 ms of randn).  Shapes the
+        # in-kernel generator does not cover fall back to the same Philox stream materialised by its stand-alone kernel.
+        self.rng = rng
         self.gmm_prior, self.theta = svae.init_mm(K, Ld, seed=seed, param_device=self.device, m_uniform=m_uniform)
         self.phi_gmm = list(svae.init_recognition_params(self.theta, K, seed=seed, param_device=self.device,
                                                          pi_normal=pi_normal))
@@ -118,6 +122,13 @@ class SVAETrainer(object):
             self.gmm_prior = self.gmm_prior[0]
         self.global_step = 0
         self.opt = None
+        # the MLP variables are created HERE from `seed` (not lazily by the first forward pass, whose seed also carries the
+        # step number and the rank): every replica starts from the same weights
+        if not vae.net_variables('encoder_net'):
+            vae.make_encoder(torch.zeros(1, Dy, dtype=torch.float32, device=self.device), self.encoder_layers,
+                             self.stddev_init_nn, seed=seed)
+        if not vae.net_variables('decoder_net'):
+            vae.decoder_variables(Ld, self.decoder_layers, self.stddev_init_nn, seed, self.device)
 
     def trainables(self):
         """21 tensors in the reference's order: phi_gmm (3), encoder_net (9), decoder_net (9)."""
@@ -132,11 +143,17 @@ class SVAETrainer(object):
                 ts.append(p)
         return names, ts
 
+    def _step_seed(self):
+        """Seed of this step's draws: every tower (rank) draws its own noise, as the reference's per-tower ops do."""
+        import torch.distributed as dist
+        rank = dist.get_rank(self.group) if (dist.is_available() and dist.is_initialized()) else 0
+        return self.seed + self.global_step + 1000003 * rank
+
     def forward(self, y, noise=None, z_draws=None, u=None):
         if noise is None and self.rng == 'philox':
             noise = 'philox'
         out = svae.inference(y, self.phi_gmm, self.encoder_layers, self.decoder_layers, self.S,
-                             stddev_init_nn=self.stddev_init_nn, seed=self.seed + self.global_step, noise=noise,
+                             stddev_init_nn=self.stddev_init_nn, seed=self._step_seed(), noise=noise,
                              z_draws=z_draws, theta=self.theta, lazy_decoder=self.fused_decoder, u=u)
         y_rec, phi_enc, x_k, x_s, log_z, _, phi_tilde = out
         elbo_fn = svae.compute_elbo_smm if self.smm else svae.compute_elbo
