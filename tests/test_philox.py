@@ -92,3 +92,30 @@ def test_in_kernel_noise_statistics_and_elbo():
     a, b = np.array(vals['philox']), np.array(vals['torch'])
     sig = np.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b))
     assert abs(a.mean() - b.mean()) < 4 * sig + 1e-6 * abs(b.mean()), (a, b)
+
+
+@pytest.mark.gpu
+def test_trainer_default_noise_is_reproducible_and_seed_dependent():
+    """SVAETrainer draws eps inside the kernel by default (seed = model seed + step number + rank offset): two trainers
+    built from the same seed take bit-identical steps, another seed takes different ones, and the MLP variables are
+    created at construction from the model seed alone."""
+    from vmp_for_svae_amd.models import vae
+    from vmp_for_svae_amd.training import SVAETrainer
+    N, K, Ld, S, Dy, U = 96, 5, 4, 10, 3, 20
+    g = torch.Generator(device='cuda').manual_seed(2)
+    y = torch.randn(N, Dy, device='cuda', generator=g)
+
+    def run(seed):
+        vae.reset_variables()
+        tr = SVAETrainer(K, Ld, U, Dy, nb_samples=S, seed=seed)
+        assert tr.rng == 'philox' and len(vae.net_variables('encoder_net')) == 9 and len(vae.net_variables('decoder_net')) == 9
+        w0 = [p.detach().clone() for _, p in vae.net_variables('decoder_net')]
+        outs = [tr.step(y) for _ in range(3)]
+        return w0, [o['elbo'].item() for o in outs], [p.detach().clone() for p in tr.trainables()[1]]
+
+    wa, ea, pa = run(0)
+    wb, eb, pb = run(0)
+    wc, ec, pc = run(1)
+    assert all(torch.equal(a, b) for a, b in zip(wa, wb)) and ea == eb and all(torch.equal(a, b) for a, b in zip(pa, pb))
+    assert ea != ec and not all(torch.equal(a, c) for a, c in zip(wa, wc))
+    assert all(np.isfinite(ea)) and ea[0] != ea[1]                           # a new draw every step
