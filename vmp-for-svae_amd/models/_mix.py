@@ -28,12 +28,15 @@ def pivot_of(x):
     return pv
 
 
+SMALL_STATS_MAX_N = 512        # csrc/vmp_mix.hip: small_stats_kernel
+
+
 def raw_stats(x, r, u=None, pivot=None):
     """(K, 2+D+D*D) fp64 raw moments [Nk | Wk | sum w x | sum w x x^T] (vmp_mix_stats)."""
     x = L.dev_f32(x, 'x')
-    if pivot is None:
-        pivot = pivot_of(x)
     N, K = r.shape
+    if pivot is None and N > SMALL_STATS_MAX_N:          # small batches: the library sums them directly in fp64 (one launch)
+        pivot = pivot_of(x)
     _, D = _dims(x, K)
     r = L.dev_f32(r, 'r_nk', (N, K))
     if u is not None:
