@@ -1,6 +1,6 @@
 """Achieved-error log of the GPU parity tests.  Every relerr()/abserr() evaluation of the `-m gpu` test modules is
 recorded here under the id of the running test; at session end the maxima are written to
-gpurun_out/r02_parity_errors.json (merged back from the GPU box; the copy to be judged is committed under profiles/)."""
+gpurun_out/r03_parity_errors.json (merged back from the GPU box; the copy to be judged is committed under profiles/)."""
 import json
 import os
 
@@ -26,7 +26,7 @@ def dump(root):
         return None
     out_dir = os.path.join(root, 'gpurun_out')
     os.makedirs(out_dir, exist_ok=True)
-    path = os.path.join(out_dir, 'r02_parity_errors.json')
+    path = os.path.join(out_dir, 'r03_parity_errors.json')
     old = {}
     if os.path.exists(path):
         try:

@@ -6,7 +6,7 @@ size-independent properties: the HIP path against the fp64 oracle evaluated in r
     T3  one SVAE training step at N=65536, L=8, K=16, S=10, U=50: ELBO <= 1e-5 relative, r <= 1e-5 absolute, theta*,
         and all 21 gradients against the oracle's chunked autograd (experiments.py:196-267 with 32 towers)
 
-The achieved errors are written to gpurun_out/r02_parity_errors.json (tests/parity_log.py)."""
+The achieved errors are written to gpurun_out/r03_parity_errors.json (tests/parity_log.py)."""
 import numpy as np
 import pytest
 import torch
@@ -41,8 +41,9 @@ def _rel(got, want, tol, what):
     return e
 
 
-@pytest.mark.parametrize('flavour', ['gmm', 'smm'])
-def test_t1_three_iterations_at_1e6_vs_chunked_oracle(flavour):
+@pytest.mark.parametrize('flavour,shape', [('gmm', (N1, D1, K1)), ('smm', (N1, D1, K1)), ('gmm', (100_000, 2, 10))],
+                         ids=['gmm-c3', 'smm-c5', 'gmm-c2'])
+def test_t1_three_iterations_at_1e6_vs_chunked_oracle(flavour, shape):
     """(a) every iteration on identical inputs: the oracle's step from the very (r, u) the GPU iteration started from
            must agree to 1e-5 (theta, u relative; r absolute, or 3 x what the reference's own fp32 arithmetic loses on that
            step where that is more - the SMM's log rho is (D + kappa) / 2 = 6.5 x the Mahalanobis term);
@@ -54,6 +55,7 @@ def test_t1_three_iterations_at_1e6_vs_chunked_oracle(flavour):
     from oracle import mixtures
     from vmp_for_svae_amd import _lib as L
     from vmp_for_svae_amd.models import _mix
+    N1, D1, K1 = shape                      # c3 / c5: BASELINE configs[2] / [4];  c2: the T1 leg of configs[1]
     x, r0 = _synth(N1, D1, K1, seed=0)
     xo = torch.as_tensor(x).double()
     xd, rd = torch.as_tensor(x).cuda(), torch.as_tensor(r0).cuda()
@@ -123,12 +125,15 @@ def _svae_problem(N, K, Ld, S, Dy, U, seed, wstd=0.1):
     return y, w, m_unif, pi_norm, Lk_low
 
 
-def test_t3_training_step_at_65536_vs_chunked_oracle():
+@pytest.mark.parametrize('dims,towers', [((65536, 16, 8, 10, 8, 50), 32), ((100_000, 10, 2, 10, 2, 50), 50)], ids=['c3-65536', 'c2-1e5'])
+def test_t3_training_step_at_65536_vs_chunked_oracle(dims, towers):
+    """c3-65536: the C3 model shape (K=16, L=8, U=50, S=10) at N=65536; c2-1e5: BASELINE configs[1]'s SVAE leg AT ITS FULL
+    SIZE (N=1e5, L=Dy=2, K=10, encoder/decoder [50,50] tanh, S=10) - one training step against the oracle's literal
+    restatement of experiments.py:196-267 evaluated in `towers` row chunks (fp64 autograd)."""
     from oracle import nets, svae_ref, train_ref
     from vmp_for_svae_amd.models import vae
     from vmp_for_svae_amd.training import SVAETrainer
-    N, K, Ld, S, Dy, U = 65536, 16, 8, 10, 8, 50
-    towers = 32                                                      # oracle: 2048-row chunks
+    N, K, Ld, S, Dy, U = dims
     y, w, m_unif, pi_norm, Lk_low = _svae_problem(N, K, Ld, S, Dy, U, seed=3)
     g = torch.Generator(device='cuda').manual_seed(11)
     noise = torch.randn(N, K, Ld, S, device='cuda', generator=g)

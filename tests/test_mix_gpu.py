@@ -18,14 +18,15 @@ def dev(a, dtype=torch.float32):
     return torch.as_tensor(np.asarray(a)).to('cuda', dtype)
 
 
-def relerr(got, want):
+def relerr(got, want, what=None, tol=None):
     want = np.asarray(want, dtype=np.float64)
     got = got.detach().double().cpu().numpy()
-    return parity_log.record('rel', np.abs(got - want).max() / max(np.abs(want).max(), 1e-300))
+    return parity_log.record('rel', np.abs(got - want).max() / max(np.abs(want).max(), 1e-300), tol, what)
 
 
-def abserr(got, want):
-    return parity_log.record('abs', np.abs(got.detach().double().cpu().numpy() - np.asarray(want, dtype=np.float64)).max())
+def abserr(got, want, what=None, tol=None):
+    return parity_log.record('abs', np.abs(got.detach().double().cpu().numpy() - np.asarray(want, dtype=np.float64)).max(),
+                             tol, what)
 
 
 def bar(g, key, base, rel=True):
@@ -127,18 +128,19 @@ def test_vmp_steps_vs_oracle(N, D, K):
     for it in range(2):
         ro, _, th_o, aux_o = mixtures.gmm_inference_step(xo, ro)
         r = step()
-        assert abserr(r, ro.numpy()) <= 2e-5, ('gmm r', it)
-        for t, o in zip(theta(), th_o):
-            assert relerr(t, o.numpy()) <= 2e-5
-        assert abserr(aux()[1], aux_o[1].numpy()) <= 2e-5 * max(1.0, float((xo ** 2).max()))   # S_k
+        assert abserr(r, ro.numpy(), 'gmm r_nk', 2e-5) <= 2e-5, ('gmm r', it)
+        for n_, t, o in zip(('alpha', 'beta', 'm', 'C', 'v'), theta(), th_o):
+            assert relerr(t, o.numpy(), 'gmm ' + n_, 2e-5) <= 2e-5
+        tol_S = 2e-5 * max(1.0, float((xo ** 2).max()))
+        assert abserr(aux()[1], aux_o[1].numpy(), 'gmm S_k', tol_S) <= tol_S
     ro, uo = torch.as_tensor(r0).double(), torch.ones(N, K, dtype=torch.float64)
     step, _, theta, aux = smm.inference(dev(x), K, 5.0, 0, r_init=dev(r0))
     for it in range(2):
         ro, uo, th_o, aux_o = mixtures.smm_inference_step(xo, ro, uo, 5.0)
         r = step()
-        assert abserr(r, ro.numpy()) <= 5e-5, ('smm r', it)
-        for t, o in zip(theta()[:5], th_o[:5]):
-            assert relerr(t, o.numpy()) <= 5e-5
+        assert abserr(r, ro.numpy(), 'smm r_nk', 5e-5) <= 5e-5, ('smm r', it)
+        for n_, t, o in zip(('alpha', 'beta', 'm', 'C', 'v'), theta()[:5], th_o[:5]):
+            assert relerr(t, o.numpy(), 'smm ' + n_, 5e-5) <= 5e-5
 
 
 def test_empty_component_and_far_offsets():

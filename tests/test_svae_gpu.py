@@ -30,7 +30,7 @@ def bar(g, key, base):
     return max(base, 3 * np.abs(a - b).max() / max(np.abs(a).max(), 1e-300))
 
 
-def make_trainer(g):
+def make_trainer(g, **kw):
     from vmp_for_svae_amd.models import vae
     from vmp_for_svae_amd.training import SVAETrainer
     N, K, Ld, S, Dy, U, steps, smm = [int(v) for v in g['in_dims']]
@@ -40,7 +40,7 @@ def make_trainer(g):
             vae.VARIABLES[scope + '/' + v] = torch.nn.Parameter(dev(g['in_w_%s/%s' % (scope, v)]))
     tr = SVAETrainer(K, Ld, U, Dy, nb_samples=S, lr=float(g['in_lr']), lrcvi=float(g['in_lrcvi']),
                      decay_rate=float(g['in_decay']), m_uniform=dev(g['in_m_unif']), pi_normal=dev(g['in_pi_norm']),
-                     smm=bool(smm), dof=float(g['in_dof0']))
+                     smm=bool(smm), dof=float(g['in_dof0']), **kw)
     with torch.no_grad():
         tr.phi_gmm[1].add_(dev(g['in_Lk_low']))
     return tr, (N, K, Ld, S, Dy, U, steps)
@@ -56,10 +56,13 @@ def test_init_matches_reference(golden, case):
         assert rel(p, g['prior_' + n_]) < 1e-6 and rel(t, g['theta_init_' + n_]) < 1e-6, n_
 
 
-@pytest.mark.parametrize('case', ['svae_tiny', 'svae_paper', 'svae_c1', 'svae_l8', 'svae_auto'])
-def test_training_steps_vs_reference(golden, case):
+@pytest.mark.parametrize('case,literal', [('svae_tiny', False), ('svae_paper', False), ('svae_c1', False), ('svae_l8', False),
+                                          ('svae_auto', False), ('svae_paper', True), ('svae_auto', True)])
+def test_training_steps_vs_reference(golden, case, literal):
+    """literal=True: the reference's own call order (experiments.py:209-229): svae.inference(y, phi_gmm, enc, dec, S)
+    WITHOUT theta, then svae.compute_elbo(_smm)(y, y_k_rec, theta, phi_tilde, x_k_samples, log_z, ...) - same bars."""
     g = golden(case)
-    tr, (N, K, Ld, S, Dy, U, steps) = make_trainer(g)
+    tr, (N, K, Ld, S, Dy, U, steps) = make_trainer(g, reference_call_order=literal)
     y = dev(g['in_y'])
     for it in range(steps):
         pre = 'step%d_' % it
@@ -139,12 +142,13 @@ def test_estep_vs_oracle_shapes():
             assert rel(a_, b_.numpy()) < 2e-4 * max(1.0, S / 10.0) ** 0.5, (tag, n_, rel(a_, b_.numpy()))
 
 
-@pytest.mark.parametrize('case', ['svae_smm_tiny', 'svae_smm_l8'])
-def test_smm_training_steps_vs_reference(golden, case):
+@pytest.mark.parametrize('case,literal', [('svae_smm_tiny', False), ('svae_smm_l8', False), ('svae_smm_l8', True)])
+def test_smm_training_steps_vs_reference(golden, case, literal):
     """Student-t mixture SVAE (BASELINE config 5 model): compute_elbo_smm, trainable theta/mu_k, theta/L_k,
-    Dirichlet-only CVI update (experiments.py:154-176, 252-256; svae.py:265-322; student_t.py:7-39)."""
+    Dirichlet-only CVI update (experiments.py:154-176, 252-256; svae.py:265-322; student_t.py:7-39).
+    literal=True: inference(...) without theta, then compute_elbo_smm(..., theta, phi_tilde, ...) as experiments.py:209-224."""
     g = golden(case)
-    tr, (N, K, Ld, S, Dy, U, steps) = make_trainer(g)
+    tr, (N, K, Ld, S, Dy, U, steps) = make_trainer(g, reference_call_order=literal)
     assert rel(tr.gmm_prior, g['prior_alpha']) < 1e-6
     for n_, t in zip(('alpha', 'mu', 'L', 'dof'), tr.theta):
         assert rel(t, g['theta_init_' + n_]) < 1e-6, n_
@@ -395,3 +399,42 @@ def test_driver_pinwheel_converges():
     assert last['loli'] > first['loli'] + 1.0
     assert last['mse'] < 0.5 * first['mse']
     assert 0.2 <= last['purity'] <= 1.0
+
+
+def test_predict_vs_oracle(golden):
+    """svae.predict (reference svae.py:406-430) against the oracle's literal restatement with the same injected draws:
+    reconstruction mean of the sub-sampled latent and the arg-max component; plus the seeded default path."""
+    from oracle import nets, svae_ref
+    from vmp_for_svae_amd.models import svae
+    g = golden('svae_paper')
+    tr, (N, K, Ld, S, Dy, U, steps) = make_trainer(g)
+    y = dev(g['in_y'])
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    noise = torch.randn(N, K, Ld, 1, device='cuda', generator=gen)
+    zd = torch.randint(0, K, (N, 1), device='cuda', generator=gen)
+    with torch.no_grad():
+        y_mean, z_hat = svae.predict(y, tr.phi_gmm, tr.encoder_layers, tr.decoder_layers, seed=3, noise=noise, z_draws=zd)
+    T = lambda a: torch.as_tensor(np.asarray(a)).double()
+    enc_w = {v: T(g['in_w_encoder_net/' + v]) for v in NET_VARS}
+    dec_w = {v: T(g['in_w_decoder_net/' + v]) for v in NET_VARS}
+    phi = [p.detach().double().cpu() for p in tr.phi_gmm]
+    phi_enc = nets.encoder(T(g['in_y']), enc_w)
+    x_k, log_r, _, _ = svae_ref.e_step(phi_enc, phi, noise.double().cpu())
+    x_s = svae_ref.subsample_x(x_k, zd.cpu())[:, 0, :]
+    y_o, _ = nets.decoder(x_s, dec_w)
+    e = rel(y_mean, y_o.numpy())
+    parity_log.record('rel', e, 1e-5, 'predict y_mean')
+    assert e <= 1e-5, e
+    # arg-max: equal wherever the oracle's top two responsibilities are not within fp32 noise of each other
+    top2 = torch.topk(log_r, 2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+    assert clear.sum().item() > 0.9 * N
+    assert (z_hat.cpu()[clear] == torch.argmax(log_r, dim=1)[clear]).all()
+    # default draws: seeded, so two calls agree bit for bit and another seed gives another sample
+    with torch.no_grad():
+        a1, k1 = svae.predict(y, tr.phi_gmm, tr.encoder_layers, tr.decoder_layers, seed=7)
+        a2, k2 = svae.predict(y, tr.phi_gmm, tr.encoder_layers, tr.decoder_layers, seed=7)
+        a3, _ = svae.predict(y, tr.phi_gmm, tr.encoder_layers, tr.decoder_layers, seed=8)
+    assert torch.equal(a1, a2) and torch.equal(k1, k2) and torch.equal(k1, z_hat)
+    assert not torch.equal(a1, a3)
+    assert tuple(a1.shape) == (N, Dy) and k1.dtype == torch.int64

@@ -1,4 +1,5 @@
 """Where the fixed cost of the T1 pass kernel goes: clock64 stamps of every wave of blocks 0 and 100 (debug hook)."""
+# needs a library built with: make -C vmp-for-svae_amd/csrc EXTRA=-DVMP_DEBUG_TS
 import os, sys, ctypes, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vmp_for_svae_amd as V

@@ -123,6 +123,15 @@ def stream():
 
 
 _WS = {}
+_WS_MAX = 16          # scratch buffers kept at most (least recently used beyond that are released to torch's allocator)
+
+
+def release_workspaces(stream=None):
+    """Forget the scratch buffers of `stream` (all streams if None); the memory returns to torch's caching allocator once
+    the kernels queued on it have run (stream-ordered)."""
+    sid = None if stream is None else stream.cuda_stream
+    for k in [k for k in _WS if sid is None or k[2] == sid]:
+        del _WS[k]
 
 
 def workspace(device, nbytes):
@@ -133,8 +142,10 @@ def workspace(device, nbytes):
     import threading
     sid = torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0
     key = (device.type, device.index, sid, threading.get_ident())
-    buf = _WS.get(key)
+    buf = _WS.pop(key, None)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _WS[key] = buf
+    _WS[key] = buf                                   # (re-)inserted last: dict order = recency
+    while len(_WS) > _WS_MAX:                        # streams / threads that went away do not pin memory for ever
+        del _WS[next(iter(_WS))]
     return buf

@@ -24,6 +24,7 @@ struct Rccl {
 
 Rccl g_rccl;
 std::once_flag g_once;
+char g_load_err[256] = "missing symbols";     // why the one-time load failed (written once, inside the call_once)
 
 void load_rccl() {
     void* h = nullptr;
@@ -31,6 +32,8 @@ void load_rccl() {
     for (const char* n : names) {
         h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (h) break;
+        const char* e = dlerror();               // read ONCE: dlerror() clears the state it returns
+        if (e) snprintf(g_load_err, sizeof(g_load_err), "%s", e);
     }
     if (!h) return;
     g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
@@ -43,7 +46,7 @@ void load_rccl() {
 
 int need_rccl(const char* who) {
     std::call_once(g_once, load_rccl);
-    if (!g_rccl.ok) { set_error("%s: RCCL (librccl.so.1) could not be loaded: %s", who, dlerror() ? dlerror() : "missing symbols"); return VMP_E_BADARG; }
+    if (!g_rccl.ok) { set_error("%s: RCCL (librccl.so.1) could not be loaded: %s", who, g_load_err); return VMP_E_BADARG; }
     return 0;
 }
 
@@ -71,7 +74,7 @@ int vmp_comm_init_rank(void** comm_out, int nranks, const void* id, int rank) {
     memcpy(&uid, id, sizeof(uid));
     ncclComm_t c = nullptr;
     int rc = rccl_status(g_rccl.CommInitRank(&c, nranks, uid, rank), "vmp_comm_init_rank");
-    *comm_out = c;
+    if (rc == 0) *comm_out = c;               // untouched on failure
     return rc;
 }
 

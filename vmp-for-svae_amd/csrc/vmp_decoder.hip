@@ -240,7 +240,7 @@ __device__ void fill_images(float* __restrict__ sm, const DecArgs& a) {
     }
     if (tid < 8) {
         const float b = tid < Dy ? a.bs2[tid] : 0.f;
-        sm[I::SP2 + tid] = log1pf(expf(b));            // the reference's naive form (vae.py:116)
+        sm[I::SP2 + tid] = log1p_f(expf(b));            // the reference's naive form (vae.py:116)
         sm[I::SG2 + tid] = 1.0f / (1.0f + expf(-b));
     }
     if (BWD) {
@@ -896,7 +896,7 @@ int dec_blocks(long long rows, int waves_per_block, int max_blocks) {
     return (int)b;
 }
 int dec_fwd_blocks(long long rows) {
-    static const int bpc = getenv("VMP_DEC_FWD_BPC") ? atoi(getenv("VMP_DEC_FWD_BPC")) : 16;   // blocks per CU: 4 are resident (82 VGPRs, 39 KB LDS), the rest back-fill as the older blocks - which the sequencer favours - finish (2 -> 4 -> 16: 4.5 -> 3.9 -> 3.5 ms per 4.2e7 rows)
+    constexpr int bpc = 16;   // blocks per CU: 4 are resident (82 VGPRs, 39 KB LDS), the rest back-fill as the older blocks - which the sequencer favours - finish (2 -> 4 -> 16: 4.5 -> 3.9 -> 3.5 ms per 4.2e7 rows)
     return dec_blocks(rows, FWD_THREADS / WAVE, 256 * bpc);
 }
 int dec_bwd_blocks(long long rows) { return dec_blocks(rows, BWD_WAVES, 256); }            // 1 block per CU
@@ -927,9 +927,8 @@ int dec_check(const char* what, long long N, int K, int S, int L, int Dy, int U)
 template <bool GIN>
 int dec_bwd_launch(const DecArgs& a0, int blocks, hipStream_t s) {
     // measured optimum at 4.2e7 rows: 58 % for U = 50 (10.0 -> 9.3 ms), 54 % for U = 64 (11.8 -> 11.3 ms)
-    static const int split = getenv("VMP_DEC_SPLIT") ? atoi(getenv("VMP_DEC_SPLIT")) : 0;
     DecArgs a = a0;
-    a.split = split ? split : ((a0.U & 15) ? 58 : 54);
+    a.split = (a0.U & 15) ? 58 : 54;
     const int U = a.U;
     const int red_floats = (1 + BWD_WAVES / 2) * dec_geo(a.L, a.U, a.Dy).PW;     // epilogue: accumulator + 4 slabs
 #define DEC_BWD(UTV)                                                                                                  \

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void student_t_kernel(TArgs a) {
             del2 = fmaf(yv, yv, del2);
         }
         const float v = a.nu[k];
-        a.out[g] = a.cst[k] - 0.5f * (v + (float)D) * log1pf(del2 / v);      // student_t.py:34-37
+        a.out[g] = a.cst[k] - 0.5f * (v + (float)D) * log1p_f(del2 / v);      // student_t.py:34-37
     }
 }
 

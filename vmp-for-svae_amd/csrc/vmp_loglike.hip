@@ -189,7 +189,7 @@ struct BernArgs {
 };
 
 __device__ __forceinline__ float neg_softplus(float z) {           // -log(1 + exp(z))
-    return -(fmaxf(z, 0.f) + log1pf(__expf(-fabsf(z))));
+    return -(fmaxf(z, 0.f) + log1p_f(__expf(-fabsf(z))));
 }
 
 template <bool BWD>

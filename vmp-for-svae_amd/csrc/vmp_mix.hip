@@ -28,14 +28,7 @@ using namespace vmp;
 namespace {
 
 constexpr int TR = 64;        // data rows per wave tile
-#ifndef VMP_X_PAIRS
-#define VMP_X_PAIRS 1
-#endif
-#if VMP_X_PAIRS
 constexpr int LS = 68;        // LDS stride (floats) between value-rows of the x image (68 = 4 mod 64: see below)
-#else
-constexpr int LS = 66;
-#endif
 constexpr int MAX_NW = 8;     // waves per block (K > 16)
 constexpr int MAX_NW1 = 8;    // waves per block when K <= 16 (12 waves = 3 per SIMD measured no faster and caps the VGPRs at 168)
 constexpr int max_nw(int KT) { return KT == 1 ? MAX_NW1 : MAX_NW; }
@@ -58,9 +51,17 @@ struct PassArgs {
     int K;
     int vec_ok;       // x pointer 16-byte aligned (vector row loads allowed)
     int par_reduce;   // LDS holds one fp64 slab per wave: reduce the waves in one parallel step
-    long long* dbg_t; // exploration only: timestamps of block 0 / wave 0 (vmp_debug_set_pass_timestamps)
+#ifdef VMP_DEBUG_TS
+    long long* dbg_t; // exploration builds only (make EXTRA=-DVMP_DEBUG_TS): timestamps of blocks 0 and 100
+#endif
 };
+// In-kernel time stamps (tools/pass_ts.py) exist only in -DVMP_DEBUG_TS builds: the shipped library has no debug
+// exports and no process-global state.
+#ifdef VMP_DEBUG_TS
 #define PASS_TS(i) do { if (a.dbg_t && (blockIdx.x == 0 || blockIdx.x == 100) && (threadIdx.x & 63) == 0) a.dbg_t[(blockIdx.x ? 64 : 0) + (threadIdx.x >> 6) * 8 + (i)] = clock64(); } while (0)
+#else
+#define PASS_TS(i) do { } while (0)
+#endif
 
 template <int D>
 __device__ __forceinline__ void load_row(const float* __restrict__ p, float (&o)[D], bool vec) {
@@ -134,8 +135,10 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int K = a.K;
     PASS_TS(0);
+#ifdef VMP_DEBUG_TS
     if (a.dbg_t && (blockIdx.x == 0 || blockIdx.x == 100) && (threadIdx.x & 63) == 0)
         a.dbg_t[(blockIdx.x ? 64 : 0) + (threadIdx.x >> 6) * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+#endif
     float* xl = smem + wave * (G::XROWS * LS);     // [XROWS][LS]: (x - pivot) columns, ones, zeros
     constexpr int ONE = D, ZERO = D + 1;
     xl[ONE * LS + lane] = 1.0f;
@@ -145,11 +148,7 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
     // fetches both with one ds_read_b64 (half the LDS cycles of ds_read2_b32).  Banks of ds_read_b64 are dword-address
     // mod 64: with LS = 4 (mod 64) the feature reads of a half-wave (value-row ra = 0..9 by lane, kk in {0,1} or {2,3})
     // fall on banks 4 ra + {0..3} (+ 4): all distinct; the E-part reads are two broadcast addresses per half-wave.
-#if VMP_X_PAIRS
     const int ppos = (lane & ~7) + 2 * (lane & 3) + ((lane >> 2) & 1);
-#else
-    const int ppos = lane;
-#endif
 
     // (The first rows are requested before the parameters, so that both are in flight together.)
     // Each wave owns a CONTIGUOUS row range of the same length (a multiple of 8 rows): with whole 64-row tiles dealt
@@ -232,13 +231,8 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
             while (p >= D - d) { p -= D - d; ++d; }
             ra = d; rb = d + p;
         }
-#if VMP_X_PAIRS
         offA[ft] = ra * LS + 2 * kk;
         offB[ft] = rb * LS + 2 * kk;
-#else
-        offA[ft] = ra * LS + kk;
-        offB[ft] = rb * LS + kk;
-#endif
     }
 
     f32x4 acc[KT][FT], acs[KT][FT];
@@ -260,12 +254,14 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
         }
     }
 
+#ifdef VMP_DEBUG_TS
     if (a.dbg_t) {                                                        // parameters and first rows have arrived
         float chk = xr[0] + pv[0];
         if constexpr (ESTEP) chk += pm2[0][0][0] + pch[0].x;
         asm volatile("" :: "v"(chk));
         PASS_TS(1);
     }
+#endif
     for (long long row0 = lo; row0 < hi; row0 += TR) {
         const int trows = (hi - row0 < TR) ? (int)(hi - row0) : TR;      // rows of this (possibly partial) tile
         // stage this tile's rows (transposed, pivot-shifted), then prefetch the next tile's row
@@ -315,30 +311,17 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
                 // the LDS reads of the moment features are issued here, ahead of the E-part, so that their latency is
                 // covered by its ~350 cycles of arithmetic instead of being waited for three times at the end of the group
                 v2f fa[FT], fb[FT];
-#ifndef VMP_HOIST
-#define VMP_HOIST 0
-#endif
                 auto load_features = [&]() __attribute__((always_inline)) {
 #pragma unroll
                     for (int ft = 0; ft < FT; ++ft) {
-#if VMP_X_PAIRS
                         fa[ft] = *reinterpret_cast<const v2f*>(&xl[offA[ft] + n8]);
                         fb[ft] = *reinterpret_cast<const v2f*>(&xl[offB[ft] + n8]);
-#else
-                        fa[ft] = v2f{xl[offA[ft] + n8], xl[offA[ft] + n8 + 4]};
-                        fb[ft] = v2f{xl[offB[ft] + n8], xl[offB[ft] + n8 + 4]};
-#endif
                     }
                 };
-                if constexpr (STATS && VMP_HOIST) load_features();
                 if constexpr (ESTEP) {
                     v2f xv[D];
 #pragma unroll
-#if VMP_X_PAIRS
                     for (int j = 0; j < D; ++j) xv[j] = *reinterpret_cast<const v2f*>(&xl[j * LS + n8 + 2 * kk]);
-#else
-                    for (int j = 0; j < D; ++j) xv[j] = v2f{xl[j * LS + n8 + kk], xl[j * LS + n8 + 4 + kk]};
-#endif
                     v2f keep[D];
                     if constexpr (MASK) {
 #pragma unroll
@@ -448,7 +431,7 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
                 }
 
                 if constexpr (STATS) {
-                    if constexpr (!VMP_HOIST) load_features();
+                    load_features();
                     unsigned t3[3];
 #pragma unroll
                     for (int kt = 0; kt < KT; ++kt) {
@@ -653,8 +636,16 @@ struct FinArgs {
     const float* pivot;        // the shift the pass kernel applied to x (src == 0 only; NULL: none)
     float *alpha, *beta, *m, *C, *v, *xbar, *S, *pi, *pack;
     double* stats_out;
-    long long* dbg_t;          // exploration only: 8 timestamps of block 0 / thread 0
+#ifdef VMP_DEBUG_TS
+    long long* dbg_t;          // exploration builds only: 8 timestamps of block 0 / thread 0
+#endif
 };
+
+#ifdef VMP_DEBUG_TS
+#define FIN_TS(i) do { if (a.dbg_t && blockIdx.x == 0 && tid == 0) a.dbg_t[i] = clock64(); } while (0)
+#else
+#define FIN_TS(i) do { } while (0)
+#endif
 
 template <int D>
 __device__ void write_pack(float* pack, int k, const double* m, const double* W /*lower, row-major full DxD*/,
@@ -817,7 +808,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
     }
     if (post && tid < K) alpha0s[tid] = a.alpha0[tid];
 
-    if (a.dbg_t && blockIdx.x == 0 && tid == 0) a.dbg_t[0] = clock64();
+    FIN_TS(0);
     if (a.src == 0) {
         constexpr int PX = G::PF + 1;
         const int f = tid & 63, g = tid >> 6;
@@ -846,7 +837,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
         }
         part[g][f] = s;
         __syncthreads();
-        if (a.dbg_t && blockIdx.x == 0 && tid == 0) a.dbg_t[1] = clock64();
+        FIN_TS(1);
         if (tid < 64) {
             double t1 = 0.0;
             for (int gg = 0; gg < FIN_GROUPS; ++gg) t1 += part[gg][tid];
@@ -898,7 +889,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
     const double alpha_k = alpha0 + Nk;                              // gmm.py:49-51 / smm.py:53-55
     const double beta_k = beta0 + Wk;                                // gmm.py:54-56 / smm.py:58-60
     const double v_k = smm ? (v0 + Nk) : (v0 + Nk + 1.0);            // smm.py:73-76 / gmm.py:79-81 (+1 quirk)
-    if (a.dbg_t && blockIdx.x == 0 && tid == 0) a.dbg_t[2] = clock64();
+    FIN_TS(2);
     // ---- phase B: element (d,e) per lane
     if (tid < D * D) {
         const int d = tid / D, e = tid % D;
@@ -926,7 +917,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
         if (a.v) a.v[k] = (float)v_k;
     }
     __syncthreads();
-    if (a.dbg_t && blockIdx.x == 0 && tid == 0) a.dbg_t[3] = clock64();
+    FIN_TS(3);
     // ---- phase C: factorisation (thread 0)  ||  special functions (threads 64..)
     // P_k = inv(C_k) (gmm.py:260) is never formed: with C = Lc Lc^T,
     //   v (x-m)^T P (x-m) = || sqrt(v) Lc^{-1} (x-m) ||^2   and   log det P = -2 sum log diag Lc.
@@ -958,7 +949,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
         sp[D + 2] = lgamma(0.5 * (D + kap)) - lgamma(0.5 * kap);
     }
     __syncthreads();
-    if (a.dbg_t && blockIdx.x == 0 && tid == 0) a.dbg_t[4] = clock64();
+    FIN_TS(4);
     // ---- phase D
     if (tid == 0) {
         const double LOG2 = 0.69314718055994530942, PI = 3.14159265358979323846;
@@ -990,7 +981,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
         float* p = a.pack + k * G::PACK;
         if (tid < D) p[tid] = (float)mk[tid];
     }
-    if (a.dbg_t && blockIdx.x == 0 && tid == 0) a.dbg_t[5] = clock64();
+    FIN_TS(5);
 }
 
 // E-step pack from explicit (alpha, beta, m, P, v): gmm.e_step / smm.e_step signature.
@@ -1100,15 +1091,10 @@ struct Plan {
     long long rpw, rpw_b;
 };
 
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 Plan make_plan(long long N, int D, int K, int flavour, bool stats) {
     Plan p;
-    static const int tuned_blocks = env_int("VMP_MIX_BLOCKS", 256);   // one 12-wave block per CU
-    static const int tuned_nw = env_int("VMP_MIX_NW", MAX_NW);
+    constexpr int tuned_blocks = 256;      // one 8-wave block per CU
+    constexpr int tuned_nw = MAX_NW;
     const size_t wreg = (size_t)(D + 2) * LS * sizeof(float);
     int nw = tuned_nw;
     if (nw > max_nw((K + 15) / 16)) nw = max_nw((K + 15) / 16);
@@ -1129,8 +1115,7 @@ Plan make_plan(long long N, int D, int K, int flavour, bool stats) {
     // of the kernel runs one wave per SIMD with nothing to hide its latencies behind (s_setprio does not change it).  The
     // older waves therefore get the larger share, so that both mates finish together.  Ranges stay contiguous and fixed:
     // results remain deterministic.
-    static const int split_env = env_int("VMP_MIX_SPLIT", 0);     // % of a pair's rows for the older wave
-    const int split = split_env ? split_env : (flavour == VMP_SMM ? 62 : 64);   // measured optima (N = 3e5 .. 1e7)
+    const int split = flavour == VMP_SMM ? 62 : 64;   // % of a pair's rows for the older wave: measured optima (N = 3e5 .. 1e7)
     if (nw == 8 && split != 50 && rpw >= 2 * TR) {
         long long cap = tuned_blocks < MAX_BLOCKS ? tuned_blocks : MAX_BLOCKS;
         long long pr = ((N + 4 * cap - 1) / (4 * cap) + 7) / 8 * 8;           // rows of a SIMD pair, all blocks in use
@@ -1207,23 +1192,29 @@ int check_dims(int64_t N, int D, int K) {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+#ifdef VMP_DEBUG_TS
 static long long* g_dbg_pass = nullptr;
+static long long* g_dbg_t = nullptr;
+#endif
 int run_pass(PassArgs a, int D, int flavour, bool estep, bool stats, bool mask, hipStream_t s) {
     Plan p = make_plan(a.N, D, a.K, flavour, stats);
     a.rpw = p.rpw;
     a.rpw_b = p.rpw_b;
     a.par_reduce = p.par_reduce;
+#ifdef VMP_DEBUG_TS
     a.dbg_t = g_dbg_pass;
+#endif
 
     int rc = -1;
     VMP_DISPATCH_D(D, rc = launch_pass_d<DD>(a, p, flavour, estep, stats, mask, s));
     return rc;
 }
 
-static long long* g_dbg_t = nullptr;
 int run_finalize(FinArgs f, int D, hipStream_t s) {
     int rc = -1;
+#ifdef VMP_DEBUG_TS
     f.dbg_t = g_dbg_t;
+#endif
 
     VMP_DISPATCH_D(D, {
         hipLaunchKernelGGL((finalize_kernel<DD>), dim3(f.K), dim3(FIN_THREADS), 0, s, f);
@@ -1239,8 +1230,10 @@ int run_finalize(FinArgs f, int D, hipStream_t s) {
 // =========================================================================================================
 extern "C" {
 
-void vmp_debug_set_finalize_timestamps(long long* p) { g_dbg_t = p; }
+#ifdef VMP_DEBUG_TS
+void vmp_debug_set_finalize_timestamps(long long* p) { g_dbg_t = p; }     // exploration builds only (tools/pass_ts.py)
 void vmp_debug_set_pass_timestamps(long long* p) { g_dbg_pass = p; }
+#endif
 
 int vmp_mix_pack_words(int D) { return pack_words(D); }
 int vmp_mix_stats_words(int D) { return stats_words(D); }

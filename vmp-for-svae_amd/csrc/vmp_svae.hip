@@ -125,317 +125,6 @@ __device__ __forceinline__ float row_max(float v, float* scr, int lane, int rbas
     return m;
 }
 
-template <int L>
-__global__ __launch_bounds__(SV_FWD_MAX_NW * WAVE) void svae_estep_fwd_kernel(EFwdArgs a) {
-    constexpr int TRI = SvGeo<L>::TRI;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int K = a.K, S = a.S;
-    const int LSn = L * S, CSTR = LSn | 1;                 // odd LDS stride per cell
-    const int RPT = WAVE / K, CT = RPT * K;                // rows / cells per wave tile
-    float* et = smem + wave * (WAVE * CSTR + WAVE);        // noise tile, later the samples
-    float* scr = et + WAVE * CSTR;
-    const bool lane_on = lane < CT;
-    const int r = lane / K, k = lane - r * K, rbase = lane_on ? r * K : 0;
-
-    // resident component parameters
-    float Pl[TRI], hkk[L], mkk[L], Wt[TRI];                // Wt: lower triangle of W_k, packed
-    float biask = 0.f, kappak = 0.f, nuk = 0.f;
-    const bool student = a.nu != nullptr;
-    // unconditional loads from clamped indices + value selects (a load under a per-element condition costs a
-    // branch and a full wait per element)
-    const int kc = lane_on ? k : 0;
-#pragma unroll
-    for (int i = 0; i < L; ++i) {
-        const float hv = a.hk[kc * L + i], mv = a.mk[kc * L + i];
-        hkk[i] = lane_on ? hv : 0.f;
-        mkk[i] = lane_on ? mv : 0.f;
-#pragma unroll
-        for (int j = 0; j <= i; ++j) {
-            const float pvv = a.Pk[(kc * L + i) * L + j], wv = a.Wk[(kc * L + i) * L + j];
-            Pl[tri(i, j)] = lane_on ? pvv : (i == j ? 1.f : 0.f);
-            Wt[tri(i, j)] = lane_on ? wv : 0.f;
-        }
-    }
-    {
-        const float bv = a.bias[kc], kv = a.kappa[kc], nv = *(student ? a.nu + kc : a.bias);
-        biask = lane_on ? bv : 0.f; kappak = lane_on ? kv : 0.f; nuk = (student && lane_on) ? nv : 1.f;
-    }
-    const float inv_nu = 1.0f / nuk;
-
-    const long long ntiles = (a.N + RPT - 1) / RPT;
-    const float invLS = 1.0f / (float)LSn, invS = 1.0f / (float)S;
-    for (long long t = (long long)blockIdx.x * nw + wave; t < ntiles; t += (long long)gridDim.x * nw) {
-        const long long row = t * RPT + r;
-        const bool on = lane_on && row < a.N;
-        const long long rows_here = (a.N - t * RPT) < RPT ? (a.N - t * RPT) : RPT;
-        const int tot = (int)rows_here * K * LSn;          // floats of noise / samples in this tile
-        // ---- stage the noise tile: coalesced global reads, padded per-cell layout in LDS
-        {
-            const float* __restrict__ g = a.noise + t * CT * LSn;
-            if (a.vec_ok && (LSn & 3) == 0) {
-                // 5 vector loads in flight per lane before the first LDS write (a one-load-at-a-time copy loop
-                // exposes the full memory latency 20 times per tile)
-                constexpr int UN = 10;
-                for (int e0 = 4 * lane; e0 < tot; e0 += UN * 4 * WAVE) {
-                    float4 v[UN];
-#pragma unroll
-                    for (int u = 0; u < UN; ++u) {
-                        const int e = e0 + u * 4 * WAVE;
-                        v[u] = (e < tot) ? *reinterpret_cast<const float4*>(g + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-#pragma unroll
-                    for (int u = 0; u < UN; ++u) {
-                        const int e = e0 + u * 4 * WAVE;
-                        if (e < tot) {
-                            const int c = (int)(((float)e + 0.5f) * invLS);
-                            const int j = e - c * LSn;
-                            float* d = et + c * CSTR + j;
-                            d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
-                        }
-                    }
-                }
-            } else {
-                for (int e = lane; e < tot; e += WAVE) {
-                    const int c = (int)(((float)e + 0.5f) * invLS);
-                    et[c * CSTR + (e - c * LSn)] = g[e];
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- cell factorisation
-        float Lm[TRI], av[L];
-#pragma unroll
-        for (int i = 0; i < TRI; ++i) Lm[i] = Pl[i];
-        const long long rowc = on ? row : 0;
-#pragma unroll
-        for (int i = 0; i < L; ++i) {
-            const float e1v = a.eta1[rowc * L + i], e2v = a.eta2d[rowc * L + i];
-            const float e1 = on ? e1v : 0.f;
-            const float e2 = on ? e2v : -0.5f;
-            Lm[tri(i, i)] = fmaf(-2.f, e2, Lm[tri(i, i)]);
-            av[i] = e1 + hkk[i];
-        }
-        float ld;
-        cell_cholesky<L>(Lm, ld);
-        solve_lower<L>(Lm, av);
-        float aa = 0.f;
-#pragma unroll
-        for (int i = 0; i < L; ++i) aa = fmaf(av[i], av[i], aa);
-        const float c = on ? (biask + 0.5f * aa - ld) : -INFINITY;
-        const float mx = row_max(c, scr, lane, rbase, K);
-        const float ex = on ? __expf(c - mx) : 0.f;
-        const float se = row_sum(ex, scr, lane, rbase, K);
-        const float lz = c - mx - __logf(se);
-
-        // ---- samples and the per-cell regulariser term
-        float eps2 = 0.f, qth = 0.f;
-        float* cell = et + lane * CSTR;
-        for (int s = 0; s < S; ++s) {
-            float z[L];
-#pragma unroll
-            for (int i = 0; i < L; ++i) {
-                const float e = lane_on ? cell[i * S + s] : 0.f;
-                eps2 = fmaf(e, e, eps2);
-                z[i] = av[i] + e;
-            }
-            solve_lower_t<L>(Lm, z);                       // z is now x_s
-            float d[L];
-#pragma unroll
-            for (int i = 0; i < L; ++i) d[i] = z[i] - mkk[i];
-            float del2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < L; ++i) {
-                float y = 0.f;
-#pragma unroll
-                for (int j = 0; j <= i; ++j) y = fmaf(Wt[tri(i, j)], d[j], y);
-                del2 = fmaf(y, y, del2);
-            }
-            qth += student ? (nuk + (float)L) * log1pf(del2 * inv_nu) : del2;
-            if (lane_on) {
-#pragma unroll
-                for (int i = 0; i < L; ++i) cell[i * S + s] = z[i];
-            }
-        }
-        if (on) {
-            a.lz[row * K + k] = lz;
-            a.Tp[row * K + k] = -0.5f * L * LOG_2PI + ld - 0.5f * invS * eps2 + 0.5f * invS * qth - kappak;
-        }
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- samples out: (cell, S, L) layout, coalesced
-        {
-            float* __restrict__ g = a.x + t * CT * LSn;
-            if (a.vec_ok && (L & 3) == 0) {
-                for (int o = 4 * lane; o < tot; o += 4 * WAVE) {
-                    const int c2 = (int)(((float)o + 0.5f) * invLS);
-                    const int rem = o - c2 * LSn;
-                    const int s = rem / L, l = rem - s * L;
-                    const float* src = et + c2 * CSTR + l * S + s;
-                    float4 v;
-                    v.x = src[0]; v.y = src[S]; v.z = src[2 * S]; v.w = src[3 * S];
-                    *reinterpret_cast<float4*>(g + o) = v;
-                }
-            } else {
-                for (int o = lane; o < tot; o += WAVE) {
-                    const int c2 = (int)(((float)o + 0.5f) * invLS);
-                    const int rem = o - c2 * LSn;
-                    const int s = rem / L, l = rem - s * L;
-                    g[o] = et[c2 * CSTR + l * S + s];
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------
-// Forward, sample-parallel form (the fast path): lane = (cell, pair of samples).  The SP = ceil(S/2) lanes of a
-// cell each repeat the cell's small factorisation (cheap, and it keeps every lane busy) and then own two samples,
-// so that a lane's dependent chain is one Cholesky + two back-substitutions instead of one Cholesky + S of them,
-// and there are SP times more independent chains in flight.  A block covers RPB whole rows (RPB*K cells): the
-// softmax over k and the per-cell sums of the regulariser go through LDS.  Noise is read straight from global
-// memory (issued before the factorisation, so its latency hides behind it); a cell's SP lanes write its S samples
-// as one contiguous (S x L) block, i.e. the wave's stores are fully coalesced without staging.
-// ---------------------------------------------------------------------------------------------------------
-template <int L>
-__global__ __launch_bounds__(512) void svae_estep_fwd2_kernel(EFwdArgs a, int RPB, int SP) {
-    constexpr int TRI = SvGeo<L>::TRI;
-    constexpr int PSTR = TRI | 1;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int K = a.K, S = a.S;
-    const int CB = RPB * K;                                 // cells per block tile
-    float* pk_lds = smem;                                   // [K][PSTR]
-    float* c_lds = smem + K * PSTR;                         // [CB]   c_nk of the tile
-    float* e_lds = c_lds + CB;                              // [CB*SP] eps^2 partial sums
-    float* q_lds = e_lds + CB * SP;                         // [CB*SP] theta-term partial sums
-    const int tid = threadIdx.x;
-    const int cib = tid / SP, pair = tid - cib * SP;        // cell in block, sample pair
-    const bool lane_on = cib < CB;
-    const int r = lane_on ? cib / K : 0, k = lane_on ? cib - r * K : 0;
-    const int s0 = 2 * pair;
-    const bool two = s0 + 1 < S;
-
-    for (int e = tid; e < K * TRI; e += blockDim.x) {
-        const int kk = e / TRI, idx = e - kk * TRI;
-        int i = 0;
-        while (tri(i + 1, 0) <= idx) ++i;
-        pk_lds[kk * PSTR + idx] = a.Pk[(kk * L + i) * L + (idx - tri(i, 0))];
-    }
-    float hkk[L], mkk[L], Wt[TRI];
-    const bool student = a.nu != nullptr;
-#pragma unroll
-    for (int i = 0; i < L; ++i) {
-        hkk[i] = lane_on ? a.hk[k * L + i] : 0.f;
-        mkk[i] = lane_on ? a.mk[k * L + i] : 0.f;
-#pragma unroll
-        for (int j = 0; j <= i; ++j) Wt[tri(i, j)] = lane_on ? a.Wk[(k * L + i) * L + j] : 0.f;
-    }
-    const float biask = lane_on ? a.bias[k] : 0.f, kappak = lane_on ? a.kappa[k] : 0.f;
-    const float nuk = (student && lane_on) ? a.nu[k] : 1.f, inv_nu = 1.0f / nuk;
-    const float invS = 1.0f / (float)S;
-    __syncthreads();
-
-    const long long ntiles = (a.N + RPB - 1) / RPB;
-    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const long long row = t * RPB + r;
-        const bool on = lane_on && row < a.N;
-        const long long cell = row * K + k;
-        // noise for this lane's two samples: issued first, consumed after the factorisation
-        float e0[L], e1[L];
-        {
-            const float* __restrict__ nz = a.noise + cell * (L * S) + s0;
-#pragma unroll
-            for (int i = 0; i < L; ++i) {
-                e0[i] = on ? nz[i * S] : 0.f;
-                e1[i] = (on && two) ? nz[i * S + 1] : 0.f;
-            }
-        }
-        float Lm[TRI], av[L];
-#pragma unroll
-        for (int i = 0; i < TRI; ++i) Lm[i] = lane_on ? pk_lds[k * PSTR + i] : 0.f;
-#pragma unroll
-        for (int i = 0; i < L; ++i) {
-            const float x1 = on ? a.eta1[row * L + i] : 0.f;
-            const float x2 = on ? a.eta2d[row * L + i] : -0.5f;
-            Lm[tri(i, i)] = fmaf(-2.f, x2, Lm[tri(i, i)]);
-            av[i] = x1 + hkk[i];
-        }
-        float ld;
-        cell_cholesky<L>(Lm, ld);
-        solve_lower<L>(Lm, av);
-        float aa = 0.f;
-#pragma unroll
-        for (int i = 0; i < L; ++i) aa = fmaf(av[i], av[i], aa);
-        const float c = on ? (biask + 0.5f * aa - ld) : -INFINITY;
-        if (lane_on && pair == 0) c_lds[cib] = c;
-
-        // two samples: z = a + eps, x = Lt^-T z (two independent chains), theta term
-        float z0[L], z1[L];
-        float eps2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < L; ++i) {
-            eps2 = fmaf(e0[i], e0[i], fmaf(e1[i], e1[i], eps2));
-            z0[i] = av[i] + e0[i];
-            z1[i] = av[i] + e1[i];
-        }
-#pragma unroll
-        for (int i = L - 1; i >= 0; --i) {
-            float t0 = z0[i], t1 = z1[i];
-#pragma unroll
-            for (int p = i + 1; p < L; ++p) {
-                t0 = fmaf(-Lm[tri(p, i)], z0[p], t0);
-                t1 = fmaf(-Lm[tri(p, i)], z1[p], t1);
-            }
-            z0[i] = t0 * Lm[tri(i, i)];
-            z1[i] = t1 * Lm[tri(i, i)];
-        }
-        if (on) {
-            float* __restrict__ xo = a.x + (cell * S + s0) * L;
-            if ((L & 3) == 0 && a.vec_ok) {
-#pragma unroll
-                for (int q = 0; q < L / 4; ++q) reinterpret_cast<float4*>(xo)[q] = make_float4(z0[4 * q], z0[4 * q + 1], z0[4 * q + 2], z0[4 * q + 3]);
-                if (two) {
-#pragma unroll
-                    for (int q = 0; q < L / 4; ++q) reinterpret_cast<float4*>(xo + L)[q] = make_float4(z1[4 * q], z1[4 * q + 1], z1[4 * q + 2], z1[4 * q + 3]);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < L; ++i) { xo[i] = z0[i]; if (two) xo[L + i] = z1[i]; }
-            }
-        }
-        float d0 = 0.f, d1 = 0.f;
-#pragma unroll
-        for (int i = 0; i < L; ++i) { z0[i] -= mkk[i]; z1[i] -= mkk[i]; }
-#pragma unroll
-        for (int i = 0; i < L; ++i) {
-            float y0 = 0.f, y1 = 0.f;
-#pragma unroll
-            for (int j = 0; j <= i; ++j) { y0 = fmaf(Wt[tri(i, j)], z0[j], y0); y1 = fmaf(Wt[tri(i, j)], z1[j], y1); }
-            d0 = fmaf(y0, y0, d0);
-            d1 = fmaf(y1, y1, d1);
-        }
-        float qth;
-        if (student) qth = (nuk + (float)L) * (log1pf(d0 * inv_nu) + (two ? log1pf(d1 * inv_nu) : 0.f));
-        else qth = d0 + (two ? d1 : 0.f);
-        if (lane_on) { e_lds[tid] = eps2; q_lds[tid] = qth; }
-        __syncthreads();
-        if (on && pair == 0) {
-            float mx = -INFINITY;
-            for (int j = 0; j < K; ++j) mx = fmaxf(mx, c_lds[r * K + j]);
-            float se = 0.f;
-            for (int j = 0; j < K; ++j) se += __expf(c_lds[r * K + j] - mx);
-            float es = 0.f, qs = 0.f;
-            for (int p = 0; p < SP; ++p) { es += e_lds[tid + p]; qs += q_lds[tid + p]; }
-            a.lz[cell] = c - mx - __logf(se);
-            a.Tp[cell] = -0.5f * L * LOG_2PI + ld - 0.5f * invS * es + 0.5f * invS * qs - kappak;
-        }
-        __syncthreads();
-    }
-}
-
 // =========================================================================================================
 // backward
 // =========================================================================================================
@@ -975,8 +664,8 @@ __global__ __launch_bounds__(SV_FWD_MAX_NW * WAVE) void svae_estep_fwd3_kernel(E
             if (!hv) del2.y = 0.f;
             if (student) {
                 const float sc = nuk + (float)L;
-                qth.x += sc * log1pf(del2.x * inv_nu);
-                qth.y += sc * log1pf(del2.y * inv_nu);
+                qth.x += sc * log1p_f(del2.x * inv_nu);
+                qth.y += sc * log1p_f(del2.y * inv_nu);
             } else {
                 qth += del2;
             }
@@ -1349,8 +1038,8 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
             if (!hv) del2.y = 0.f;
             if (student) {
                 const float sc = nuk + (float)L;
-                qth.x += sc * log1pf(del2.x * inv_nu);
-                qth.y += sc * log1pf(del2.y * inv_nu);
+                qth.x += sc * log1p_f(del2.x * inv_nu);
+                qth.y += sc * log1p_f(del2.y * inv_nu);
             } else {
                 qth += del2;
             }
@@ -1526,7 +1215,7 @@ __global__ __launch_bounds__(SV_FWD_MAX_NW * WAVE) void svae_estep_fwd_chunked_k
                     for (int j = 0; j <= i; ++j) y = fmaf(Wt[tri(i, j)], d[j], y);
                     del2 = fmaf(y, y, del2);
                 }
-                qth += student ? (nuk + (float)L) * log1pf(del2 * inv_nu) : del2;
+                qth += student ? (nuk + (float)L) * log1p_f(del2 * inv_nu) : del2;
                 if (lane_on) {
 #pragma unroll
                     for (int i = 0; i < L; ++i) cell[i * sc + s] = z[i];
@@ -1596,8 +1285,7 @@ int sv_blocks(long long N, int K) {
     long long b = (ntiles + SV_NW - 1) / SV_NW;
     // 512 = two 4-wave blocks per CU, all resident at once; with 1024 the second round of blocks starts unevenly
     // (measured at C3: backward 3.65 -> 3.44 ms)
-    static const int cap = getenv("VMP_SV_BLOCKS") ? atoi(getenv("VMP_SV_BLOCKS")) : 512;
-    if (b > cap) b = cap;
+    if (b > 512) b = 512;
     if (b > SV_MAX_BLOCKS) b = SV_MAX_BLOCKS;
     return (int)b;
 }
@@ -1671,25 +1359,6 @@ static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
         });
         return rc;
     }
-    {
-        const int SP = (S + 1) / 2;
-        static const int use_v2 = getenv("VMP_SV_FWD_V2") ? 1 : 0;   // measured slower than the staged form at C3 (4.1 vs 3.6 ms)
-        if (use_v2 && K * SP <= 512) {
-            int RPB = 512 / (K * SP);
-            if (RPB > 8) RPB = 8;
-            const int threads = ((RPB * K * SP + WAVE - 1) / WAVE) * WAVE;
-            const int CB = RPB * K;
-            const size_t lds2 = (size_t)(K * ((L * (L + 1) / 2) | 1) + CB + 2 * CB * SP + 2 * WAVE) * sizeof(float);
-            long long blocks2 = (N + RPB - 1) / RPB;
-            if (blocks2 > 256 * 6) blocks2 = 256 * 6;
-            rc = -1;
-            VMP_DISPATCH_L(L, {
-                hipLaunchKernelGGL((svae_estep_fwd2_kernel<LL>), dim3((int)blocks2), dim3(threads), lds2, static_cast<hipStream_t>(stream), a, RPB, SP);
-                rc = check_launch("svae_estep_fwd2_kernel");
-            });
-            return rc;
-        }
-    }
     if ((size_t)(L * S | 1) * WAVE * sizeof(float) > 36 * 1024) {
         // the cell's noise block does not fit the LDS tile: process the samples SC at a time
         int SC = (32 * 1024 / (int)(WAVE * sizeof(float))) / L;   // L*SC*64*4 B <= 32 KiB per wave
@@ -1706,9 +1375,7 @@ static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
         });
         return rc;
     }
-    static const int use_old = getenv("VMP_SV_FWD_OLD") ? 1 : 0;
-    static const int no_dma = getenv("VMP_SV_FWD_NODMA") ? 1 : 0;
-    if (!use_old && !no_dma && (L * S) % 4 == 0 && al16(noise)) {
+    if ((L * S) % 4 == 0 && al16(noise)) {
         // LDS-DMA kernel: cell stride CS = L*S rounded so that CS/4 is odd
         int CS = L * S;
         if (((CS >> 2) & 1) == 0) CS += 4;
@@ -1735,7 +1402,7 @@ static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
             return rc;
         }
     }
-    if (!use_old) {
+    {   // register-staged kernel: L*S not a multiple of 4, or a misaligned noise tensor
         const size_t table = (size_t)K * ((L * (L + 1) / 2) | 1) * sizeof(float);
         const size_t pw = (size_t)(WAVE * (L * S | 1) + WAVE) * sizeof(float);
         int nw3 = (int)((150 * 1024 - table) / pw);        // one block per CU, as many waves as 160 KiB of LDS hold
@@ -1760,22 +1427,6 @@ static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
         });
         return rc;
     }
-    const size_t per_wave = (size_t)(WAVE * (L * S | 1) + WAVE) * sizeof(float);
-    int nw = (int)((150 * 1024) / per_wave);                 // one block per CU, as many waves as 160 KiB of LDS hold
-    if (nw > SV_FWD_MAX_NW) nw = SV_FWD_MAX_NW;
-    if (nw < 1) nw = 1;
-    const size_t lds = per_wave * nw;
-    const int RPT = WAVE / K;
-    long long blocks = ((N + RPT - 1) / RPT + nw - 1) / nw;
-    if (blocks > 256) blocks = 256;
-    rc = -1;
-    VMP_DISPATCH_L(L, {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd_kernel<LL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((svae_estep_fwd_kernel<LL>), dim3((int)blocks), dim3(nw * WAVE), lds, static_cast<hipStream_t>(stream), a);
-        rc = check_launch("svae_estep_fwd_kernel");
-    });
-    return rc;
 }
 
 int vmp_svae_estep_fwd(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,

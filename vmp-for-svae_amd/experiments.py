@@ -107,8 +107,11 @@ def run(config, nb_iters=2000, size_minibatch=100, nb_samples=10, nb_samples_te=
         ratio_missing_data=0.1, checkpoint_freq=None, checkpoint_dir=None, graph=True, group=None):
     """One run of the reference driver (experiments.py:86-457).  Under torch.distributed (one process per GPU) every
     rank draws the same shuffled minibatch stream and trains on its tower_slice of each minibatch - the reference's
-    tf.split over towers (data.py:174-175, experiments.py:196-244); SVAETrainer.step sums moments / ELBO and averages
-    gradients over ranks, so the run equals the single-process run on the whole minibatch."""
+    tf.split over towers (data.py:174-175, experiments.py:196-244); SVAETrainer.step sums moments / ELBO and AVERAGES
+    gradients over ranks (helpers/tf_utils.py:52-87), i.e. the run equals the reference's nb_gpu = world run; a
+    single-process run on the whole minibatch SUMS the gradient over all rows instead (world x larger gradient).
+    Rank 0 alone prints and writes checkpoints (every rank holds identical parameters); metrics are evaluated by all
+    ranks, identically."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank(group) if world > 1 else 0
@@ -149,10 +152,10 @@ def run(config, nb_iters=2000, size_minibatch=100, nb_samples=10, nb_samples_te=
                 m.update(evaluate_imputation(tr, Xte, missing_data_mask, nb_samples_pert, nb_samples_te,
                                              seed=config.get('seed', 0)))
             history.append(m)
-            if verbose:
+            if verbose and rank == 0:
                 print('Iteration %5d\t\t%.4fsec\t\t%.4f   %s' % (i, time.time() - t0, m['neg_normed_elbo'],
                                                                  {k: round(v, 4) for k, v in m.items() if k not in ('iter', 'neg_normed_elbo')}))
-        if checkpoint_freq and checkpoint_dir and (i % checkpoint_freq == 0 or i == nb_iters - 1):
+        if checkpoint_freq and checkpoint_dir and rank == 0 and (i % checkpoint_freq == 0 or i == nb_iters - 1):
             import os
             os.makedirs(checkpoint_dir, exist_ok=True)
             save_checkpoint(tr, os.path.join(checkpoint_dir, '%s_iter%d.npz' % (log_id, i)))   # experiments.py:433-440

@@ -78,12 +78,34 @@ def _neutral_theta(K, Ld, device):
 
 class PhiTilde(object):
     """What e_step returns as `phi_tilde`: behaves like the reference's tuple (eta1 (N,K,L,1), eta2 (N,K,L,L))
-    - materialised only if indexed - and carries the fused per-cell ELBO terms for compute_elbo."""
+    - materialised only if indexed - and carries the fused per-cell ELBO terms for compute_elbo.  When e_step was not
+    given theta (the reference's own call order: inference(...) and THEN compute_elbo(..., theta, phi_tilde, ...),
+    experiments.py:209-229), theta_term() evaluates them afterwards from what e_step already had."""
 
-    def __init__(self, eta1_phi1, eta2_diag, eta1_phi2, P_phi2, T_prime, theta_key):
+    def __init__(self, eta1_phi1, eta2_diag, eta1_phi2, P_phi2, T_prime, theta_key, bias=None, noise=None, x=None):
         self._p = (eta1_phi1, eta2_diag, eta1_phi2, P_phi2)
         self.T_prime = T_prime
         self.theta_key = theta_key
+        self._bias, self._noise, self._x = bias, noise, x
+
+    def theta_term(self, theta, x_k_samps):
+        """T'_nk = mean_s[log N(x_nks; phi~_nk) - log p(x_nks, z=k | theta)] (reference svae.py:229-243) for a theta the
+        E-step did not see: one more launch of the fused forward kernel on the SAME (phi_enc, phi_gmm, noise) - it
+        reproduces the samples bit for bit - with this theta's (m_k, W_k, kappa_k); autograd reaches phi_enc / phi_gmm
+        (and a Student-t theta) through the fused backward kernel.  Backward is linear in the upstream gradients, so the
+        gradients of this call (upstream dT') and of the original e_step call (upstream dx, dlog_z) add up to exactly
+        what the one-pass form e_step(theta=theta) delivers."""
+        if self._noise is None:
+            raise L.VmpError('compute_elbo: this phi_tilde carries the terms of a different theta (e_step(theta=...) was '
+                             'called with another parameter set); re-run e_step with this theta or without one')
+        if x_k_samps is not self._x and not (torch.is_tensor(x_k_samps) and x_k_samps.data_ptr() == self._x.data_ptr()
+                                              and tuple(x_k_samps.shape) == tuple(self._x.shape)):
+            raise L.VmpError('compute_elbo: x_k_samps must be the samples e_step returned together with this phi_tilde')
+        e1, e2d, e1k, Pk = self._p
+        mk, Wk, kap, nu = _theta_pack(theta)
+        _, _, Tp = _svae_ops.SvaeEStepFn.apply(e1, e2d, e1k, Pk, self._bias, self._noise, mk, Wk, kap, nu)
+        self.T_prime, self.theta_key = Tp, _theta_key(theta)
+        return Tp
 
     def __len__(self):
         return 2
@@ -138,7 +160,10 @@ def e_step(phi_enc, phi_gmm, nb_samples, seed=0, name="e_step", noise=None, thet
         noise = torch.randn(N, K, Ld, nb_samples, generator=g, device=eta1_phi1.device)
     mk, Wk, kap, nu = _theta_pack(theta) if theta is not None else _neutral_theta(K, Ld, eta1_phi1.device)
     x, lz, Tp = _svae_ops.SvaeEStepFn.apply(eta1_phi1, eta2_diag, eta1_phi2, P, bias, noise, mk, Wk, kap, nu)
-    phi_tilde = PhiTilde(eta1_phi1, eta2_diag, eta1_phi2, P, Tp if theta is not None else None, _theta_key(theta))
+    # without theta the (phi, noise) the E-step ran on stay attached, so that compute_elbo can evaluate the theta term
+    # afterwards; with theta (the training path) nothing extra is kept alive
+    keep = dict(bias=bias, noise=noise, x=x) if theta is None else {}
+    phi_tilde = PhiTilde(eta1_phi1, eta2_diag, eta1_phi2, P, Tp if theta is not None else None, _theta_key(theta), **keep)
     return x, lz, phi_tilde, (None, None)
 
 
@@ -218,9 +243,8 @@ def compute_elbo(y, reconstructions, theta, phi_tilde, x_k_samps, log_z_given_y_
     """reference svae.py:199-262.  Returns (elbo, (neg_rec_err, numerator, denominator, regulariser))."""
     if decoder_type not in ('standard', 'bernoulli'):
         raise NotImplementedError("decoder_type '%s'" % decoder_type)
-    if not isinstance(phi_tilde, PhiTilde) or phi_tilde.T_prime is None or phi_tilde.theta_key != _theta_key(theta):
-        raise L.VmpError('compute_elbo needs the per-cell terms of the fused E-step: call e_step / inference with '
-                         'theta=<the same theta> (the stand-alone per-sample density kernels are not built yet)')
+    if not isinstance(phi_tilde, PhiTilde):
+        raise L.VmpError('compute_elbo: phi_tilde must be the object e_step / inference returned')
     r_nk = torch.exp(log_z_given_y_phi)
     if decoder_type == 'bernoulli':                               # svae.py:222-223: out_2 = logits
         rec = vae.expected_bernoulli_loglike(y, reconstructions[1], r_nk=r_nk)
@@ -229,7 +253,10 @@ def compute_elbo(y, reconstructions, theta, phi_tilde, x_k_samps, log_z_given_y_
     else:
         means, out_2 = reconstructions
         rec = vae.expected_diagonal_gaussian_loglike(y, means, out_2, weights=r_nk)
-    Tp = phi_tilde.T_prime
+    if phi_tilde.T_prime is not None and phi_tilde.theta_key == _theta_key(theta):
+        Tp = phi_tilde.T_prime                                    # e_step(theta=theta) evaluated them in its own pass
+    else:
+        Tp = phi_tilde.theta_term(theta, x_k_samps)               # the reference's call order (experiments.py:209-229)
     reg = (r_nk * (Tp + log_z_given_y_phi)).sum()
     elbo = rec - reg
     return elbo, ElboDetails(rec, reg, phi_tilde, x_k_samps, log_z_given_y_phi)
@@ -350,11 +377,12 @@ def inference(y, phi_gmm, encoder_layers, decoder_layers, nb_samples=10, stddev_
     return y_rec, x_given_y_phi, x_k_samples, x_samples, log_z, phi_gmm, phi_tilde
 
 
-def predict(y, phi_gmm, encoder_layers, decoder_layers, seed=0):
-    """reference svae.py:406-430."""
+def predict(y, phi_gmm, encoder_layers, decoder_layers, seed=0, noise=None, z_draws=None):
+    """reference svae.py:406-430: encode, E-step with ONE sample per component, draw z ~ q(z|y), decode the drawn
+    sample; returns (y_mean, argmax_k log r_nk).  `noise` (N,K,L,1) / `z_draws` (N,1) replace the two TF draws."""
     phi_enc = vae.make_encoder(y, layerspecs=encoder_layers)
-    x_k_samples, log_r_nk, _, _ = e_step(phi_enc, phi_gmm, 1, seed=seed)
-    x_samples = subsample_x(x_k_samples, log_r_nk, seed)[:, 0, :]
+    x_k_samples, log_r_nk, _, _ = e_step(phi_enc, phi_gmm, 1, seed=seed, noise=noise)
+    x_samples = subsample_x(x_k_samples, log_r_nk, seed, z_draws=z_draws)[:, 0, :]
     y_mean, _ = vae.make_decoder(x_samples, layerspecs=decoder_layers)
     return y_mean, torch.argmax(log_r_nk, dim=1)
 

@@ -91,8 +91,12 @@ def unpack_after_allreduce(buf, stats_shape, grad_shapes, n_scalars):
 class SVAETrainer(object):
     def __init__(self, K, Ld, U, Dy, nb_samples=10, lr=3e-4, lrcvi=0.2, decay_rate=0.95, stddev_init_nn=0.01, seed=0,
                  device='cuda', m_uniform=None, pi_normal=None, group=None, smm=False, dof=5.0, fused_decoder=True,
-                 rng='philox'):
+                 rng='philox', reference_call_order=False):
         self.K, self.L, self.S = K, Ld, nb_samples
+        # True: build the step exactly as experiments.py:209-229 does - svae.inference(...) WITHOUT theta, then
+        # svae.compute_elbo(..., theta, phi_tilde, ...), which evaluates the theta term in a second launch of the fused
+        # kernel (models/svae.py PhiTilde.theta_term).  False (default): theta goes into the E-step, one launch.
+        self.reference_call_order = bool(reference_call_order)
         self.lr, self.lrcvi0, self.decay_rate = lr, lrcvi, decay_rate
         self.group = group
         self.device = torch.device(device)
@@ -143,18 +147,21 @@ class SVAETrainer(object):
                 ts.append(p)
         return names, ts
 
-    def _step_seed(self):
-        """Seed of this step's draws: every tower (rank) draws its own noise, as the reference's per-tower ops do."""
+    def _step_seed(self, chunk_index=0):
+        """Seed of this step's draws: every tower (rank) draws its own noise, as the reference's per-tower ops do, and
+        every row chunk of a chunked step its own stream (the Philox counter of the in-kernel generator is the
+        chunk-RELATIVE cell index: one seed for all chunks would give row n of every chunk the same eps)."""
         import torch.distributed as dist
         rank = dist.get_rank(self.group) if (dist.is_available() and dist.is_initialized()) else 0
-        return self.seed + self.global_step + 1000003 * rank
+        return self.seed + self.global_step + 1000003 * rank + 15485863 * int(chunk_index)
 
-    def forward(self, y, noise=None, z_draws=None, u=None):
+    def forward(self, y, noise=None, z_draws=None, u=None, chunk_index=0):
         if noise is None and self.rng == 'philox':
             noise = 'philox'
         out = svae.inference(y, self.phi_gmm, self.encoder_layers, self.decoder_layers, self.S,
-                             stddev_init_nn=self.stddev_init_nn, seed=self._step_seed(), noise=noise,
-                             z_draws=z_draws, theta=self.theta, lazy_decoder=self.fused_decoder, u=u)
+                             stddev_init_nn=self.stddev_init_nn, seed=self._step_seed(chunk_index), noise=noise,
+                             z_draws=z_draws, theta=None if self.reference_call_order else self.theta,
+                             lazy_decoder=self.fused_decoder, u=u)
         y_rec, phi_enc, x_k, x_s, log_z, _, phi_tilde = out
         elbo_fn = svae.compute_elbo_smm if self.smm else svae.compute_elbo
         elbo, details = elbo_fn(y, y_rec, self.theta, phi_tilde, x_k, log_z, 'standard')
@@ -178,7 +185,7 @@ class SVAETrainer(object):
             ns = None if noise is None else noise[i:i + chunk]
             zs = None if z_draws is None else z_draws[i:i + chunk]
             us = None if u is None else u[i:i + chunk]
-            elbo, details, x_k, x_s, log_z = self.forward(ys, ns, zs, us)
+            elbo, details, x_k, x_s, log_z = self.forward(ys, ns, zs, us, chunk_index=ci)
             if params is None:
                 names, params = self.trainables()
             g = torch.autograd.grad(-elbo, params, allow_unused=True)
@@ -260,6 +267,7 @@ class GraphedSVAEStep(object):
                     m=[m.clone() for m in tr.opt.m] if had_opt else None,
                     v=[v.clone() for v in tr.opt.v] if had_opt else None,
                     gen=self.gen.get_state())
+        ws_before = dict(L._WS)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -282,8 +290,12 @@ class GraphedSVAEStep(object):
         with torch.cuda.graph(self.graph):
             self.out = tr.step(self.y, noise=self.noise, u=self.u, _dev_scalars=(self.rho, self.lr_t))
         self.gen.set_state(snap['gen'])     # the capture-time refresh drew nothing that a replay uses
-        # the captured kernels hold raw pointers into scratch buffers of the capture stream: keep them alive
-        self._ws_refs = dict(L._WS)
+        # the captured kernels hold raw pointers into the scratch buffers in use during the capture: keep exactly those
+        # alive with the graph, and drop the warm-up side stream's buffers (never used again)
+        self._ws_refs = {k: v for k, v in L._WS.items() if k not in ws_before or L._WS[k] is not ws_before[k]}
+        for k in self._ws_refs:                   # graph-pool memory: owned by this graph alone from here on
+            L._WS.pop(k, None)
+        L.release_workspaces(side)
 
     def _refresh(self):
         tr = self.tr
