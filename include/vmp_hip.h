@@ -322,6 +322,37 @@ int    vmp_comm_init_rank(void** comm_out, int nranks, const void* id, int rank)
 int    vmp_comm_destroy(void* comm);
 int    vmp_pack_allreduce(void* comm, double* buf, size_t n, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * T1 data-parallel iteration in ONE launch per rank (round 3).  The RCCL form above costs three dependent launches
+ * plus the collective (local reduction -> all-reduce -> posterior); here the finalize kernel of every rank
+ *   (1) reduces its own per-block partials (as vmp_mix_finalize_ws),
+ *   (2) PUSHES its un-shifted fp64 moments of component k into slot [parity][rank][k] of EVERY rank's exchange buffer
+ *       (plain stores, system-scope release, then a sequence word = iteration + 1),
+ *   (3) waits until the sequence words of all ranks for component k have arrived in its OWN buffer (bounded spin on
+ *       local memory), and sums the slots in rank order 0..G-1 - the same order on every rank, so all ranks obtain
+ *       bit-identical moments -, then
+ *   (4) continues with the posterior update and the E-step pack (as vmp_mix_finalize).
+ * Replaces the tower gather + M-step on the parameter device of experiments.py:247-260 for the pure mixture loop
+ * (gmm.py:258-263 over sharded rows).  Exchange buffers: one per rank, vmp_exch_bytes(G, K, D) bytes of uncached
+ * device memory (vmp_exch_alloc), exported with vmp_exch_export (VMP_EXCH_HANDLE_BYTES, shipped to the peers out of band)
+ * and mapped by every peer with vmp_exch_open; peers[g] = rank g's buffer as mapped in THIS process (peers[rank] = the
+ * local allocation).  `iteration` must increase by one per call on every rank (slots are double-buffered by parity).
+ * `status` (device int, may be NULL) is set to 1 if a wait timed out (~4 s): the results of that call are invalid.   */
+#define VMP_EXCH_MAX_RANKS 16
+#define VMP_EXCH_HANDLE_BYTES 64
+size_t vmp_exch_bytes(int nranks, int K, int D);
+int    vmp_exch_alloc(void** buf_out, size_t bytes);
+int    vmp_exch_free(void* buf);
+int    vmp_exch_export(void* buf, void* handle_out /* VMP_EXCH_HANDLE_BYTES */);
+int    vmp_exch_open(const void* handle, void** peer_out);
+int    vmp_exch_close(void* peer);
+int    vmp_mix_finalize_exchange(const void* workspace, const float* pivot, int64_t N, int D, int K, int flavour,
+                                 const float* alpha0, const float* beta0, const float* m0, const float* C0,
+                                 const float* v0, const float* kappa, float* alpha, float* beta, float* m, float* C,
+                                 float* v, float* xbar, float* S, float* pi, float* pack, double* stats_out,
+                                 void* const* peers, int nranks, int rank, unsigned long long iteration, int* status,
+                                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,37 @@ def main():
     res['run_params'] = np.concatenate([t.detach().cpu().numpy().reshape(-1) for t in params2])
     res['run_theta'] = np.concatenate([t.cpu().numpy().reshape(-1) for t in tr2.theta])
     res['run_elbo'] = np.float64(hist[-1]['neg_normed_elbo'])
+    # ---- T1 again with the ONE-LAUNCH exchange (vmp_mix_finalize_exchange): the finalize kernels of the two processes push
+    # their moments into each other's IPC-mapped buffers and sum them in rank order; no host staging, no collective library
+    try:
+        from vmp_for_svae_amd.models.parallel_mix import PeerExchange
+        import time
+        for name, flav in (('gmm', L.VMP_GMM), ('smm', L.VMP_SMM)):
+            kap = torch.full((r0.shape[1],), 5.0, device='cuda') if flav == L.VMP_SMM else None
+            ex = PeerExchange(r0.shape[1], x.shape[1])
+            loop = DistributedVMPLoop(dev(x[sl]), dev(r0[sl]), flav, kappa=kap, exchange=ex)
+            for it in range(3):
+                r = loop.step()
+                if it == 0:
+                    res['t1x_%s_r1' % name] = r.cpu().numpy()
+            res['t1x_%s_r' % name] = r.cpu().numpy()
+            for n_, t in zip(('alpha', 'beta', 'm', 'C', 'v'), loop.theta()):
+                res['t1x_%s_%s' % (name, n_)] = t.cpu().numpy()
+            # many iterations back to back: parity double-buffering and sequence words under skew between the two processes
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for it in range(200):
+                loop.step()
+            torch.cuda.synchronize()
+            res['t1x_%s_us_per_step' % name] = np.float64((time.perf_counter() - t0) / 200 * 1e6)
+            res['t1x_%s_r200' % name] = loop.r.cpu().numpy()
+            res['t1x_%s_m200' % name] = loop.theta()[2].cpu().numpy()
+            res['t1x_%s_status' % name] = ex.status.cpu().numpy()
+            dist.barrier()
+            ex.close()
+    except Exception as e:                                   # reported by the test, the other sections stay usable
+        res['t1x_error'] = np.array(repr(e))
     np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), **res)
     dist.barrier()
     dist.destroy_process_group()

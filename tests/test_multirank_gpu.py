@@ -114,6 +114,43 @@ def test_distributed_vmp_loop_two_ranks_equals_single_process(two_ranks):
             assert np.array_equal(ranks[0]['t1_%s_%s' % (name, n_)], ranks[1]['t1_%s_%s' % (name, n_)])   # replicas agree bitwise
 
 
+def test_one_launch_peer_exchange_two_ranks(two_ranks):
+    """vmp_mix_finalize_exchange (include/vmp_hip.h): the finalize kernels of two PROCESSES push their fp64 moments into each
+    other's IPC-mapped exchange buffers and sum them in rank order - no all-reduce launch, no host staging.  Same bars as the
+    gloo-staged path above; both ranks bitwise equal; 200 back-to-back iterations (parity double-buffering under skew)
+    without a timed-out wait."""
+    from vmp_for_svae_amd import _lib as L
+    from vmp_for_svae_amd.models import _mix
+    p, ranks = two_ranks
+    for rk in ranks:
+        assert 't1x_error' not in rk.files, str(rk['t1x_error'])
+    x, r0 = torch.as_tensor(p['t1_x']).cuda(), torch.as_tensor(p['t1_r0']).cuda()
+    for name, flav in (('gmm', L.VMP_GMM), ('smm', L.VMP_SMM)):
+        kap = torch.full((r0.shape[1],), 5.0, device='cuda') if flav == L.VMP_SMM else None
+        loop = _mix.VMPLoop(x, r0, flav, kappa=kap)
+        smm_f = 1.0 if flav == L.VMP_GMM else 13.0
+        for it, (key, tol_r) in enumerate((('r1', 2e-6 * smm_f), (None, None), ('r', 3e-5 * smm_f))):
+            r = loop.step()
+            if key is None:
+                continue
+            r_dist = np.concatenate([ranks[0]['t1x_%s_%s' % (name, key)], ranks[1]['t1x_%s_%s' % (name, key)]])
+            e = np.abs(r_dist - r.cpu().numpy()).max()
+            parity_log.record('abs', e, tol_r, 'peer-exchange %s r after %d iteration(s)' % (name, it + 1))
+            assert e <= tol_r, (name, it, e)
+        for n_, t in zip(('alpha', 'beta', 'm', 'C', 'v'), loop.theta()):
+            for rk in ranks:
+                assert _rel(rk['t1x_%s_%s' % (name, n_)], t.cpu().numpy(), 'peer-exchange %s %s' % (name, n_), 1e-5) <= 1e-5
+            assert np.array_equal(ranks[0]['t1x_%s_%s' % (name, n_)], ranks[1]['t1x_%s_%s' % (name, n_)])   # bitwise
+            # and bitwise the gloo-staged all-reduce path?  no: that one sums (rank0 + rank1) on the host in the same order,
+            # but its finalize runs from the all-reduced buffer - equal up to nothing: both are fp64 sums in rank order
+            assert np.array_equal(ranks[0]['t1x_%s_%s' % (name, n_)], ranks[0]['t1_%s_%s' % (name, n_)]), (name, n_)
+        for rk in ranks:
+            assert int(rk['t1x_%s_status' % name][0]) == 0, 'a wait of the in-kernel exchange timed out'
+            assert np.isfinite(rk['t1x_%s_r200' % name]).all()
+        assert np.array_equal(ranks[0]['t1x_%s_m200' % name], ranks[1]['t1x_%s_m200' % name])
+        parity_log.record('abs', float(ranks[0]['t1x_%s_us_per_step' % name]), None, 'peer-exchange %s us per step (2 ranks on one GPU, N=30011)' % name)
+
+
 def test_svae_trainer_two_ranks_follows_tower_semantics(two_ranks):
     from oracle import nets, svae_ref, train_ref
     p, ranks = two_ranks

@@ -63,6 +63,14 @@ _SIGNATURES = {
     'vmp_comm_init_rank': (_c.c_int, [_c.POINTER(_c.c_void_p), _c.c_int, _P, _c.c_int]),
     'vmp_comm_destroy': (_c.c_int, [_P]),
     'vmp_pack_allreduce': (_c.c_int, [_P, _P, _c.c_size_t, _P]),
+    'vmp_exch_bytes': (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int]),
+    'vmp_exch_alloc': (_c.c_int, [_c.POINTER(_c.c_void_p), _c.c_size_t]),
+    'vmp_exch_free': (_c.c_int, [_P]),
+    'vmp_exch_export': (_c.c_int, [_P, _P]),
+    'vmp_exch_open': (_c.c_int, [_P, _c.POINTER(_c.c_void_p)]),
+    'vmp_exch_close': (_c.c_int, [_P]),
+    'vmp_mix_finalize_exchange': (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int] + [_P] * 6 + [_P] * 9
+                                  + [_P, _P, _c.c_int, _c.c_int, _c.c_uint64, _P, _P]),
     'vmp_mix_finalize_ws': (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int] + [_P] * 6 + [_P] * 9 + [_P, _P]),
 }
 

@@ -92,4 +92,61 @@ int vmp_pack_allreduce(void* comm, double* buf, size_t n, void* stream) {
                                         static_cast<hipStream_t>(stream)), "vmp_pack_allreduce");
 }
 
+// ---- peer-visible exchange buffers (the one-launch distributed finalize of vmp_mix.hip) ------------------------------
+// One buffer per rank, in device memory every peer can write while kernels run: uncached (MTYPE_UC) VRAM, exported with
+// hipIpcGetMemHandle and mapped by the other ranks with hipIpcOpenMemHandle (xGMI peer access inside a node; two
+// processes sharing one GPU map the same physical memory).  Layout: vmp_exch_bytes.
+size_t vmp_exch_bytes(int nranks, int K, int D) {
+    if (nranks < 1 || nranks > VMP_EXCH_MAX_RANKS || K < 1 || D < 1) return 0;
+    const size_t swp = ((size_t)(2 + D + D * D) + 1 + 7) & ~(size_t)7;             // doubles per (sender, component) slot: moments + sum_k N_k
+    return 2 * (size_t)nranks * K * swp * sizeof(double) + 2 * (size_t)nranks * K * sizeof(unsigned long long);
+}
+
+int vmp_exch_alloc(void** buf_out, size_t bytes) {
+    if (!buf_out || !bytes) { set_error("vmp_exch_alloc: bad argument"); return VMP_E_BADARG; }
+    void* p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("vmp_exch_alloc: %s", hipGetErrorString(e)); return (int)e; }
+    e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { (void)hipFree(p); set_error("vmp_exch_alloc: %s", hipGetErrorString(e)); return (int)e; }
+    *buf_out = p;
+    return 0;
+}
+
+int vmp_exch_free(void* buf) {
+    if (!buf) return 0;
+    hipError_t e = hipFree(buf);
+    if (e != hipSuccess) { set_error("vmp_exch_free: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
+int vmp_exch_export(void* buf, void* handle_out) {
+    static_assert(sizeof(hipIpcMemHandle_t) == VMP_EXCH_HANDLE_BYTES, "IPC handle size");
+    if (!buf || !handle_out) { set_error("vmp_exch_export: null pointer"); return VMP_E_BADARG; }
+    hipIpcMemHandle_t h;
+    hipError_t e = hipIpcGetMemHandle(&h, buf);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("vmp_exch_export: %s", hipGetErrorString(e)); return (int)e; }
+    memcpy(handle_out, &h, sizeof(h));
+    return 0;
+}
+
+int vmp_exch_open(const void* handle, void** peer_out) {
+    if (!handle || !peer_out) { set_error("vmp_exch_open: null pointer"); return VMP_E_BADARG; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    void* p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("vmp_exch_open: %s", hipGetErrorString(e)); return (int)e; }
+    *peer_out = p;
+    return 0;
+}
+
+int vmp_exch_close(void* peer) {
+    if (!peer) return 0;
+    hipError_t e = hipIpcCloseMemHandle(peer);
+    if (e != hipSuccess) { set_error("vmp_exch_close: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
 }  // extern "C"

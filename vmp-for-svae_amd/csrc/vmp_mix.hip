@@ -125,6 +125,106 @@ __device__ __forceinline__ double readlane_d(double v, int src_lane) {
     return __hiloint2double(hi, lo);
 }
 
+// Block reduction of the fp64 moment accumulators (waves summed in a fixed order) and the per-block partial: shared by
+// the two pass kernels below.
+template <int D, int KT, int FLAV>
+__device__ __forceinline__ void pass_epilogue(const PassArgs& a, float* smem, const double (&dacc)[KT][Geo<D>::FT][4],
+                                              const double (&dn)[KT][4], int lane, int wave, int nw) {
+    using G = Geo<D>;
+    constexpr int FT = G::FT;
+    constexpr bool SMM = (FLAV == VMP_SMM);
+    const int K = a.K;
+    {
+        // ---- block reduction in fp64 (waves summed in a fixed order), then one partial per block
+        __syncthreads();
+        PASS_TS(3);
+        double* sc = reinterpret_cast<double*>(smem);          // [KT][FT+1][4][64]
+        constexpr int SLAB = KT * (FT + 1) * 4 * WAVE;
+        if (a.par_reduce) {
+            // every wave drops its accumulators into its own slab, then each thread sums the nw slabs of its
+            // elements: one LDS round trip instead of nw dependent read-modify-write rounds
+            double* mine = sc + wave * SLAB;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                    for (int ft = 0; ft < FT; ++ft) mine[((kt * (FT + 1) + ft) * 4 + c) * WAVE + lane] = dacc[kt][ft][c];
+                    mine[((kt * (FT + 1) + FT) * 4 + c) * WAVE + lane] = SMM ? dn[kt][c] : dacc[kt][0][c];
+                }
+            __syncthreads();
+            // all slab values of a thread's elements are requested before the first addition (a rolled loop of dependent
+            // read-add steps cost ~1.6 k cycles here); the additions keep the wave order
+            constexpr int EPT = 2, NWB = max_nw(KT);               // elements per thread and round; bound on nw
+            for (int e0 = threadIdx.x; e0 < SLAB; e0 += EPT * blockDim.x) {
+                double vals[EPT][NWB];
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    const int e = e0 + q * blockDim.x;
+#pragma unroll
+                    for (int w = 0; w < NWB; ++w) vals[q][w] = (e < SLAB && w < nw) ? sc[w * SLAB + e] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    const int e = e0 + q * blockDim.x;
+                    double t2 = vals[q][0];
+#pragma unroll
+                    for (int w = 1; w < NWB; ++w) t2 += vals[q][w];
+                    if (e < SLAB) sc[e] = t2;
+                }
+            }
+            __syncthreads();
+        } else {
+            for (int w = 0; w < nw; ++w) {
+                if (wave == w) {
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                            for (int ft = 0; ft < FT; ++ft) {
+                                const int idx = ((kt * (FT + 1) + ft) * 4 + c) * WAVE + lane;
+                                sc[idx] = (w == 0 ? 0.0 : sc[idx]) + dacc[kt][ft][c];
+                            }
+                            const int idn = ((kt * (FT + 1) + FT) * 4 + c) * WAVE + lane;
+                            sc[idn] = (w == 0 ? 0.0 : sc[idn]) + (SMM ? dn[kt][c] : dacc[kt][0][c]);
+                        }
+                }
+                __syncthreads();
+            }
+        }
+        PASS_TS(4);
+        // partials[k][block][PX]: one component's rows of all blocks are contiguous (what a finalize block streams);
+        // slot PF of every row = this block's sum_k N_k (the Dirichlet normaliser needs the total count)
+        constexpr int PX = G::PF + 1;
+        double* out = a.partials;
+        for (int e = threadIdx.x; e < KT * (FT + 1) * 4 * WAVE; e += blockDim.x) {
+            const int l = e & 63, c = (e >> 6) & 3, tf = (e >> 8) % (FT + 1), kt = (e >> 8) / (FT + 1);
+            const int k = kt * 16 + (l >> 4) * 4 + c;
+            if (k >= K) continue;
+            double* row = out + ((long long)k * MAX_BLOCKS + blockIdx.x) * PX;
+            if (tf < FT) {
+                const int f = tf * 16 + (l & 15);
+                if (f < G::F) row[f] = sc[e];
+            } else if ((l & 15) == 0) {
+                row[G::F] = sc[e];                             // Nk = sum_n r_nk
+            }
+        }
+        if (wave == 0) {                                       // lane k holds N_k; fixed-order sum; lane k writes row k's slot
+            double ntot = 0.0;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const int k = kt * 16 + (lane & 15), l = ((k & 15) >> 2) * 16, c = k & 3;
+                const double nk = (lane < 16 && k < K) ? sc[((kt * (FT + 1) + FT) * 4 + c) * WAVE + l] : 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) ntot += readlane_d(nk, j);
+            }
+            for (int k = lane; k < K; k += WAVE) out[((long long)k * MAX_BLOCKS + blockIdx.x) * PX + G::PF] = ntot;
+        }
+        PASS_TS(5);
+    }
+}
+
 template <int D, int KT, int FLAV, bool ESTEP, bool STATS, bool MASK>
 __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
     using G = Geo<D>;
@@ -526,95 +626,361 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
     }
 
     PASS_TS(2);
-    if constexpr (STATS) {
-        // ---- block reduction in fp64 (waves summed in a fixed order), then one partial per block
-        __syncthreads();
-        PASS_TS(3);
-        double* sc = reinterpret_cast<double*>(smem);          // [KT][FT+1][4][64]
-        constexpr int SLAB = KT * (FT + 1) * 4 * WAVE;
-        if (a.par_reduce) {
-            // every wave drops its accumulators into its own slab, then each thread sums the nw slabs of its
-            // elements: one LDS round trip instead of nw dependent read-modify-write rounds
-            double* mine = sc + wave * SLAB;
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-#pragma unroll
-                    for (int ft = 0; ft < FT; ++ft) mine[((kt * (FT + 1) + ft) * 4 + c) * WAVE + lane] = dacc[kt][ft][c];
-                    mine[((kt * (FT + 1) + FT) * 4 + c) * WAVE + lane] = SMM ? dn[kt][c] : dacc[kt][0][c];
-                }
-            __syncthreads();
-            // all slab values of a thread's elements are requested before the first addition (a rolled loop of dependent
-            // read-add steps cost ~1.6 k cycles here); the additions keep the wave order
-            constexpr int EPT = 2, NWB = max_nw(KT);               // elements per thread and round; bound on nw
-            for (int e0 = threadIdx.x; e0 < SLAB; e0 += EPT * blockDim.x) {
-                double vals[EPT][NWB];
-#pragma unroll
-                for (int q = 0; q < EPT; ++q) {
-                    const int e = e0 + q * blockDim.x;
-#pragma unroll
-                    for (int w = 0; w < NWB; ++w) vals[q][w] = (e < SLAB && w < nw) ? sc[w * SLAB + e] : 0.0;
-                }
-#pragma unroll
-                for (int q = 0; q < EPT; ++q) {
-                    const int e = e0 + q * blockDim.x;
-                    double t2 = vals[q][0];
-#pragma unroll
-                    for (int w = 1; w < NWB; ++w) t2 += vals[q][w];
-                    if (e < SLAB) sc[e] = t2;
-                }
-            }
-            __syncthreads();
-        } else {
-            for (int w = 0; w < nw; ++w) {
-                if (wave == w) {
-#pragma unroll
-                    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-#pragma unroll
-                            for (int ft = 0; ft < FT; ++ft) {
-                                const int idx = ((kt * (FT + 1) + ft) * 4 + c) * WAVE + lane;
-                                sc[idx] = (w == 0 ? 0.0 : sc[idx]) + dacc[kt][ft][c];
-                            }
-                            const int idn = ((kt * (FT + 1) + FT) * 4 + c) * WAVE + lane;
-                            sc[idn] = (w == 0 ? 0.0 : sc[idn]) + (SMM ? dn[kt][c] : dacc[kt][0][c]);
-                        }
-                }
-                __syncthreads();
-            }
-        }
-        PASS_TS(4);
-        // partials[k][block][PX]: one component's rows of all blocks are contiguous (what a finalize block streams);
-        // slot PF of every row = this block's sum_k N_k (the Dirichlet normaliser needs the total count)
-        constexpr int PX = G::PF + 1;
-        double* out = a.partials;
-        for (int e = threadIdx.x; e < KT * (FT + 1) * 4 * WAVE; e += blockDim.x) {
-            const int l = e & 63, c = (e >> 6) & 3, tf = (e >> 8) % (FT + 1), kt = (e >> 8) / (FT + 1);
-            const int k = kt * 16 + (l >> 4) * 4 + c;
-            if (k >= K) continue;
-            double* row = out + ((long long)k * MAX_BLOCKS + blockIdx.x) * PX;
-            if (tf < FT) {
-                const int f = tf * 16 + (l & 15);
-                if (f < G::F) row[f] = sc[e];
-            } else if ((l & 15) == 0) {
-                row[G::F] = sc[e];                             // Nk = sum_n r_nk
-            }
-        }
-        if (wave == 0) {                                       // lane k holds N_k; fixed-order sum; lane k writes row k's slot
-            double ntot = 0.0;
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                const int k = kt * 16 + (lane & 15), l = ((k & 15) >> 2) * 16, c = k & 3;
-                const double nk = (lane < 16 && k < K) ? sc[((kt * (FT + 1) + FT) * 4 + c) * WAVE + l] : 0.0;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) ntot += readlane_d(nk, j);
-            }
-            for (int k = lane; k < K; k += WAVE) out[((long long)k * MAX_BLOCKS + blockIdx.x) * PX + G::PF] = ntot;
-        }
-        PASS_TS(5);
+    if constexpr (STATS) pass_epilogue<D, KT, FLAV>(a, smem, dacc, dn, lane, wave, nw);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// The same pass with the E-part's quadratic forms ON THE XDL PIPE (round 3; K <= 16, no missing-data mask).
+//
+// Round-2 counters: ~100 of the 153 VALU instructions an 8-row group costs are the sixteen packed-fp32 forms
+// q_nk = ||W_k (x_n - m_k)||^2, and the kernel is VALU-issue bound.  Here  y = W_k x' + b_k  (x' = x - pivot,
+// b_k = -W_k (m_k - pivot), formed in fp64 once per kernel) is a GEMM on v_mfma_f32_16x16x32_bf16:
+//     M = data row (16 per MFMA),  N = component k (lane & 15),  one MFMA tile per output coordinate i of y,
+//     contraction = the D coordinates of x' - only 8 of the 32 k-slots - so the slots carry SEVERAL bf16 TERMS of the
+//     same values (v = h + m + l, 8 bits each): lane group g = lane >> 4 of the two MFMAs of a tile multiplies
+//         MFMA 1:  x'_h W_h | x'_h W_m | x'_m W_h | x'_h W_l        MFMA 2:  x'_l W_h | x'_m W_m | (1,1,1) (b_h,b_m,b_l) | 0
+//     i.e. the six products of order <= 2 (dropped: <= 2^-24 relative, the fp32 rounding level) plus the bias.
+// No expanded quadratic form x^T Theta x is ever evaluated: y is formed exactly as the fp32 chain formed it (same
+// cancellation between W x' and W m'), then q = sum_i y_i^2 costs 8 FMAs per cell in the accumulator registers.
+// Operands: the x' tile is split ONCE per row at staging time (lane = row) into an LDS image [row][x_h | x_m | x_l | 1 | 0]
+// (16 B each) that the A operands are fetched from with one ds_read_b128 per MFMA; W's terms live in 16 D VGPRs.
+// The accumulator layout (lane = (k, g), register v <-> tile row 4 g + v) is mapped to DATA rows 4 v + g, so that one
+// store instruction covers 4 consecutive rows x 16 components (256 B) and the moment GEMM's k-slots (tile, v) take
+// the responsibilities straight from the softmax registers.
+// Measured against the packed-fp32 kernel above on one box: see DESIGN.md section 6.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int AIS = 20;       // u32 per row of the bf16 A image: x_h(4) x_m(4) x_l(4) ones(4) zeros(4); 80 B: 16 rows hit 16 bank groups
+template <int D> constexpr int xdl_wave_floats() { return Geo<D>::XROWS * LS + TR * AIS; }
+
+template <int D, int FLAV, bool STATS>
+__global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
+    using G = Geo<D>;
+    constexpr int FT = G::FT, KT = 1;
+    constexpr bool SMM = (FLAV == VMP_SMM);
+    constexpr int DP = (D + 1) / 2;                          // coordinate pairs
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int K = a.K;
+    PASS_TS(0);
+    float* xl = smem + wave * xdl_wave_floats<D>();          // [XROWS][LS] fp32 (x - pivot), ones, zeros: moment features
+    unsigned* ai = reinterpret_cast<unsigned*>(xl + G::XROWS * LS);   // [64][AIS] bf16 terms of x - pivot: E-part A operands
+    constexpr int ONE = D, ZERO = D + 1;
+    // position of tile row t in a value-row of the fp32 image: the 4 rows {g, 4+g, 8+g, 12+g} of a 16-row sub-tile that one
+    // lane group owns are adjacent (one ds_read_b128 per feature factor)
+    const int ppos = (lane & ~15) + 4 * (lane & 3) + ((lane >> 2) & 3);
+    xl[ONE * LS + lane] = 1.0f;
+    xl[ZERO * LS + lane] = 0.0f;
+    {
+        u32x4 ones = u32x4{0x3F803F80u, 0x00003F80u, 0u, 0u}, zeros = u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(ai + lane * AIS + 12) = ones;
+        *reinterpret_cast<u32x4*>(ai + lane * AIS + 16) = zeros;
     }
+
+    const bool vec = a.vec_ok != 0;
+    long long lo, hi;
+    if (a.rpw_b == a.rpw) {
+        lo = ((long long)blockIdx.x * nw + wave) * a.rpw;
+        hi = lo + a.rpw;
+    } else {
+        const int hw = nw >> 1;
+        const long long base = (long long)blockIdx.x * hw * (a.rpw + a.rpw_b);
+        lo = wave < hw ? base + wave * a.rpw : base + hw * a.rpw + (wave - hw) * a.rpw_b;
+        hi = lo + (wave < hw ? a.rpw : a.rpw_b);
+    }
+    if (hi > a.N) hi = a.N;
+    float xr[D];
+    {
+        const long long n = lo + lane;
+#pragma unroll
+        for (int j = 0; j < D; ++j) xr[j] = 0.f;
+        if (n < hi) load_row<D>(a.x + n * D, xr, vec);
+    }
+    const int i16 = lane & 15, kk = lane >> 4;
+    float pv[D];
+    {
+        const float* __restrict__ pp = a.pivot ? a.pivot : a.x;
+        const bool hasp = a.pivot != nullptr;
+#pragma unroll
+        for (int j = 0; j < D; ++j) { const float v = pp[j]; pv[j] = hasp ? v : 0.f; }
+    }
+
+    // ---- B operands of the y GEMM: lane (k = i16, g = kk) holds the terms of W_k its lane group multiplies (see the header)
+    u32x4 B1[D], B2[D];
+    v2f pch;
+    float pua, pub;
+    {
+        const bool on = i16 < K;
+        const float* __restrict__ p = a.pack + (on ? i16 : 0) * G::PACK;
+        float raw[G::PACK];
+        if (G::PACK % 4 == 0 && (reinterpret_cast<uintptr_t>(a.pack) & 15) == 0) {
+#pragma unroll
+            for (int j = 0; j < G::PACK / 4; ++j) {
+                const float4 q = reinterpret_cast<const float4*>(p)[j];
+                raw[4 * j] = q.x; raw[4 * j + 1] = q.y; raw[4 * j + 2] = q.z; raw[4 * j + 3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < G::PACK; ++j) raw[j] = p[j];
+        }
+        pch.x = on ? raw[D + G::TRI] : -INFINITY;            // log2-domain constant; -inf switches the lane off
+        pch.y = on ? raw[D + G::TRI + 1] : 0.f;
+        pua = on ? raw[D + G::TRI + 2] : 0.f;
+        pub = on ? raw[D + G::TRI + 3] : 1.f;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double bi = 0.0;                                 // b_i = -sum_j W_ij (m_j - pivot_j), fp64
+#pragma unroll
+            for (int j = 0; j <= i; ++j) bi -= (double)raw[D + i * (i + 1) / 2 + j] * ((double)raw[j] - (double)pv[j]);
+            unsigned tb[3];
+            split_bf16<3>(v2f{(float)bi, 0.f}, tb);          // low halves: b_h, b_m, b_l
+            unsigned w1[4] = {0u, 0u, 0u, 0u}, w2[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int q = 0; q < DP; ++q) {
+                const int j0 = 2 * q, j1 = 2 * q + 1;
+                const float wa = j0 <= i ? raw[D + i * (i + 1) / 2 + j0] : 0.f;
+                const float wb = (j1 <= i && j1 < D) ? raw[D + i * (i + 1) / 2 + (j1 <= i ? j1 : 0)] : 0.f;
+                unsigned t3[3];
+                split_bf16<3>(v2f{wa, wb}, t3);
+                w1[q] = kk == 1 ? t3[1] : (kk == 3 ? t3[2] : t3[0]);       // W_h | W_m | W_h | W_l
+                w2[q] = kk == 0 ? t3[0] : (kk == 1 ? t3[1] : 0u);          // W_h | W_m | bias | 0
+            }
+            if (kk == 2) {
+                w2[0] = (tb[0] & 0xffffu) | (tb[1] << 16);                 // slots 0,1: b_h, b_m
+                w2[1] = tb[2] & 0xffffu;                                   // slot 2: b_l
+                w2[2] = 0u; w2[3] = 0u;
+            }
+            B1[i] = on ? u32x4{w1[0], w1[1], w1[2], w1[3]} : u32x4{0u, 0u, 0u, 0u};
+            B2[i] = on ? u32x4{w2[0], w2[1], w2[2], w2[3]} : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    // A operands: lane (m = i16, g = kk) reads term T[g] of tile row rho(m) = 4 (m & 3) + (m >> 2)
+    const int rho = 4 * (i16 & 3) + (i16 >> 2);
+    const int offA1 = rho * AIS + (kk == 2 ? 4 : 0);                       // x_h | x_h | x_m | x_h
+    const int offA2 = rho * AIS + (kk == 0 ? 8 : (kk == 1 ? 4 : (kk == 2 ? 12 : 16)));   // x_l | x_m | ones | zeros
+
+    // ---- moment GEMM B-operand addressing: lane = (feature column i16, k-slot group kk)
+    int offA[FT], offB[FT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+        const int f = ft * 16 + i16;
+        int ra = ZERO, rb = ZERO;
+        if (f == 0) { ra = ONE; rb = ONE; }
+        else if (f <= D) { ra = f - 1; rb = ONE; }
+        else if (f < G::F) {
+            int p = f - D - 1, d = 0;
+            while (p >= D - d) { p -= D - d; ++d; }
+            ra = d; rb = d + p;
+        }
+        offA[ft] = ra * LS + 4 * kk;
+        offB[ft] = rb * LS + 4 * kk;
+    }
+
+    f32x4 acc[KT][FT], acs[KT][FT];
+    f32x4 nacc[KT], nacs[KT];
+    double dacc[KT][FT][4];
+    double dn[KT][4];
+    nacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    nacs[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dn[0][c] = 0.0;
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+        acc[0][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acs[0][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dacc[0][ft][c] = 0.0;
+    }
+
+    for (long long row0 = lo; row0 < hi; row0 += TR) {
+        const int trows = (hi - row0 < TR) ? (int)(hi - row0) : TR;
+        // ---- stage this tile: lane = tile row.  fp32 image for the moment features, bf16 term image for the y GEMM
+        {
+            const bool valid = row0 + lane < hi;
+            float xs[2 * DP];
+#pragma unroll
+            for (int j = 0; j < 2 * DP; ++j) xs[j] = (valid && j < D) ? xr[j < D ? j : 0] - pv[j < D ? j : 0] : 0.f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) xl[j * LS + ppos] = xs[j];
+            unsigned th[4] = {0u, 0u, 0u, 0u}, tm[4] = {0u, 0u, 0u, 0u}, tl[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int q = 0; q < DP; ++q) {
+                unsigned t3[3];
+                split_bf16<3>(v2f{xs[2 * q], xs[2 * q + 1]}, t3);
+                th[q] = t3[0]; tm[q] = t3[1]; tl[q] = t3[2];
+            }
+            *reinterpret_cast<u32x4*>(ai + lane * AIS) = u32x4{th[0], th[1], th[2], th[3]};
+            *reinterpret_cast<u32x4*>(ai + lane * AIS + 4) = u32x4{tm[0], tm[1], tm[2], tm[3]};
+            *reinterpret_cast<u32x4*>(ai + lane * AIS + 8) = u32x4{tl[0], tl[1], tl[2], tl[3]};
+            const long long n2 = row0 + TR + lane;
+#pragma unroll
+            for (int j = 0; j < D; ++j) xr[j] = 0.f;
+            if (n2 < hi) load_row<D>(a.x + n2 * D, xr, vec);
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        const long long tbase = (row0 + kk) * K + i16;       // this lane's element of r/u for (row0 + kk, component i16)
+#pragma unroll 1
+        for (int n0 = 0; n0 < trows; n0 += 32) {
+            unsigned As[3][4], Rs[3][4], Bs[FT][3][4];       // [term h/m/l][k-slot pair: (sub-tile jj, v pair)]
+            const bool full = (K == 16) && (n0 + 32 <= trows);
+            auto subtile = [&](auto full_c, auto jj_c) __attribute__((always_inline)) {
+                constexpr bool FULL = decltype(full_c)::value;
+                constexpr int jj = decltype(jj_c)::value;
+                const int n16 = n0 + 16 * jj;                // first tile row of this 16-row sub-tile
+                if (!FULL && n16 >= trows) {                 // wave-uniform: nothing left
+                    if constexpr (STATS) {
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) {
+                            As[t][2 * jj] = 0u; As[t][2 * jj + 1] = 0u; Rs[t][2 * jj] = 0u; Rs[t][2 * jj + 1] = 0u;
+#pragma unroll
+                            for (int ft = 0; ft < FT; ++ft) { Bs[ft][t][2 * jj] = 0u; Bs[ft][t][2 * jj + 1] = 0u; }
+                        }
+                    }
+                    return;
+                }
+                // ---- y = W x' + b on the XDL pipe, q = |y|^2 in the accumulator registers
+                const bf16x8 a1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ai + n16 * AIS + offA1));
+                const bf16x8 a2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ai + n16 * AIS + offA2));
+                f32x4 y[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+                    y[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, __builtin_bit_cast(bf16x8, B1[i]), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+                    y[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, __builtin_bit_cast(bf16x8, B2[i]), y[i], 0, 0, 0);
+                f32x4 q4 = y[0] * y[0], q4b = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 1; i < D; ++i) {
+                    if (i & 1) q4b = __builtin_elementwise_fma(y[i], y[i], q4b);
+                    else q4 = __builtin_elementwise_fma(y[i], y[i], q4);
+                }
+                q4 += q4b;
+                // register v <-> data row n16 + 4 v + kk
+                v2f lg[2], uu[2], rr[2], w[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const v2f qh = v2f{q4[2 * h], q4[2 * h + 1]};
+                    lg[h] = pk_const_minus_scaled(qh, pch);                 // log2 rho
+                    if constexpr (SMM) uu[h] = v2f{pua * __builtin_amdgcn_rcpf(qh.x + pub), pua * __builtin_amdgcn_rcpf(qh.y + pub)};
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const v2f mx = row16_max2(lg[h]);
+                    lg[h] = v2f{__builtin_amdgcn_exp2f(lg[h].x - mx.x), __builtin_amdgcn_exp2f(lg[h].y - mx.y)};
+                    const v2f ssum = row16_sum2(lg[h]);
+                    v2f inv = v2f{__builtin_amdgcn_rcpf(ssum.x), __builtin_amdgcn_rcpf(ssum.y)};
+                    if constexpr (!FULL) {
+                        const bool va = row0 + n16 + 8 * h + kk < hi, vb = row0 + n16 + 8 * h + 4 + kk < hi;
+                        inv = v2f{va ? inv.x : 0.f, vb ? inv.y : 0.f};
+                    }
+                    rr[h] = lg[h] * inv;
+                    w[h] = SMM ? rr[h] * uu[h] : rr[h];
+                }
+                // ---- stores: for fixed v the 64 lanes cover rows n16 + 4 v .. + 3 x 16 components = 256 contiguous bytes
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float rv = rr[v >> 1][v & 1];
+                    if constexpr (FULL) {
+                        float* __restrict__ ro = a.r_out + tbase + (long long)(n16 + 4 * v) * 16;
+                        __builtin_nontemporal_store(rv, ro);
+                        if constexpr (SMM) __builtin_nontemporal_store(uu[v >> 1][v & 1], a.u_out + tbase + (long long)(n16 + 4 * v) * 16);
+                        if (a.logr_out) a.logr_out[tbase + (long long)(n16 + 4 * v) * 16] = logf(rv);
+                    } else {
+                        const bool sv = (row0 + n16 + 4 * v + kk < hi) && i16 < K;
+                        const long long o = tbase + (long long)(n16 + 4 * v) * K;
+                        if (sv) {
+                            a.r_out[o] = rv;
+                            if constexpr (SMM) a.u_out[o] = uu[v >> 1][v & 1];
+                            if (a.logr_out) a.logr_out[o] = logf(rv);
+                        }
+                    }
+                }
+                if constexpr (STATS) {
+                    unsigned t3[3];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        split_bf16<MOM_TERMS>(w[h], t3);
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) As[t][2 * jj + h] = t3[t];
+                        if constexpr (SMM) {
+                            split_bf16<MOM_TERMS>(rr[h], t3);
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) Rs[t][2 * jj + h] = t3[t];
+                        }
+                    }
+#pragma unroll
+                    for (int ft = 0; ft < FT; ++ft) {
+                        const f32x4 fa = *reinterpret_cast<const f32x4*>(&xl[offA[ft] + n16]);
+                        const f32x4 fb = *reinterpret_cast<const f32x4*>(&xl[offB[ft] + n16]);
+                        const f32x4 pr = fa * fb;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            split_bf16<MOM_TERMS>(v2f{pr[2 * h], pr[2 * h + 1]}, t3);
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) Bs[ft][t][2 * jj + h] = t3[t];
+                        }
+                    }
+                }
+            };
+            using std::integral_constant;
+            if (full) {
+                subtile(integral_constant<bool, true>{}, integral_constant<int, 0>{});
+                subtile(integral_constant<bool, true>{}, integral_constant<int, 1>{});
+            } else {
+                subtile(integral_constant<bool, false>{}, integral_constant<int, 0>{});
+                subtile(integral_constant<bool, false>{}, integral_constant<int, 1>{});
+            }
+
+            if constexpr (STATS) {
+                bf16x8 b[FT][3];
+#pragma unroll
+                for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        b[ft][t] = __builtin_bit_cast(bf16x8, u32x4{Bs[ft][t][0], Bs[ft][t][1], Bs[ft][t][2], Bs[ft][t][3]});
+                bf16x8 av[3], rv[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    av[t] = __builtin_bit_cast(bf16x8, u32x4{As[t][0], As[t][1], As[t][2], As[t][3]});
+                    if constexpr (SMM) rv[t] = __builtin_bit_cast(bf16x8, u32x4{Rs[t][0], Rs[t][1], Rs[t][2], Rs[t][3]});
+                }
+                // h h products and the five corrections in separate fp32 accumulators (see pass_kernel)
+#pragma unroll
+                for (int ta = 0; ta < MOM_TERMS; ++ta) {
+#pragma unroll
+                    for (int tb = 0; tb + ta < MOM_TERMS; ++tb) {
+#pragma unroll
+                        for (int ft = 0; ft < FT; ++ft) {
+                            if (ta + tb == 0) acc[0][ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ta], b[ft][tb], acc[0][ft], 0, 0, 0);
+                            else acs[0][ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ta], b[ft][tb], acs[0][ft], 0, 0, 0);
+                        }
+                    }
+                    if constexpr (SMM) {
+                        if (ta == 0) nacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rv[ta], b[0][0], nacc[0], 0, 0, 0);
+                        else nacs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rv[ta], b[0][0], nacs[0], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        if constexpr (STATS) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if constexpr (SMM) dn[0][c] += (double)nacc[0][c] + (double)nacs[0][c];
+#pragma unroll
+                for (int ft = 0; ft < FT; ++ft) dacc[0][ft][c] += (double)acc[0][ft][c] + (double)acs[0][ft][c];
+            }
+            nacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            nacs[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft) { acc[0][ft] = f32x4{0.f, 0.f, 0.f, 0.f}; acs[0][ft] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    PASS_TS(2);
+    if constexpr (STATS) pass_epilogue<D, 1, FLAV>(a, smem, dacc, dn, lane, wave, nw);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -636,6 +1002,11 @@ struct FinArgs {
     const float* pivot;        // the shift the pass kernel applied to x (src == 0 only; NULL: none)
     float *alpha, *beta, *m, *C, *v, *xbar, *S, *pi, *pack;
     double* stats_out;
+    // one-launch data-parallel form (vmp_mix_finalize_exchange): peer[g] = rank g's exchange buffer; nranks = 0: no exchange
+    double* peer[VMP_EXCH_MAX_RANKS];
+    int nranks, rank;
+    unsigned long long iter;
+    int* status;
 #ifdef VMP_DEBUG_TS
     long long* dbg_t;          // exploration builds only: 8 timestamps of block 0 / thread 0
 #endif
@@ -799,7 +1170,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
     const double beta0 = post ? (double)a.beta0[k] : 0.0, v0 = post ? (double)a.v0[k] : 0.0;
     const double alpha0 = post ? (double)a.alpha0[k] : 0.0;
     const double kap = (post && smm) ? (double)a.kappa[k] : 0.0;
-    const bool shifted = (a.src == 0) && (a.pivot != nullptr);
+    bool shifted = (a.src == 0) && (a.pivot != nullptr);
     double m0d = 0.0, m0e = 0.0, C0de = 0.0, cd = 0.0, ce = 0.0;
     if (tid < D * D) {
         const int d = tid / D, e = tid % D;
@@ -862,6 +1233,70 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
     __syncthreads();
     // st holds the moments of the SHIFTED data x - c (c = pivot, 0 if none); the public layout is un-shifted:
     //   sum w x = sx' + W c,   sum w x x^T = sxx' + c sx'^T + sx' c^T + W c c^T        (fp64)
+    if (a.nranks >= 1) {
+        // ---- sum over ranks inside this launch (see include/vmp_hip.h, vmp_mix_finalize_exchange): this block owns
+        // component k on its rank and exchanges with the blocks that own component k on the other ranks
+        constexpr int SWP = (G::SW + 1 + 7) & ~7;
+        const int par = (int)(a.iter & 1), G_ = a.nranks;
+        double val = 0.0;
+        if (tid < G::SW) {
+            val = st[tid];
+            if (shifted && tid >= 2) {
+                const double W = st[1];
+                if (tid < 2 + D) {
+                    val += W * (double)a.pivot[tid - 2];
+                } else {
+                    const int d = (tid - 2 - D) / D, e = (tid - 2 - D) % D;
+                    const double pd = a.pivot[d], pe = a.pivot[e];
+                    val += pd * st[2 + e] + st[2 + d] * pe + W * pd * pe;
+                }
+            }
+        } else if (tid == G::SW) {
+            val = ntot;
+        }
+        if (tid <= G::SW) {
+            for (int g = 0; g < G_; ++g) {
+                double* slot = a.peer[g] + (((size_t)par * G_ + a.rank) * K + k) * SWP;
+                __hip_atomic_store(slot + tid, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                 // system scope: the slots are visible before the words
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int g = 0; g < G_; ++g) {
+                unsigned long long* fl = reinterpret_cast<unsigned long long*>(a.peer[g] + (size_t)2 * G_ * K * SWP);
+                __hip_atomic_store(fl + ((size_t)par * G_ + a.rank) * K + k, a.iter + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        double* mine = a.peer[a.rank];
+        if (tid < G_) {
+            const unsigned long long* fl = reinterpret_cast<const unsigned long long*>(mine + (size_t)2 * G_ * K * SWP)
+                                           + ((size_t)par * G_ + tid) * K + k;
+            const long long t0 = wall_clock64();                          // 100 MHz
+            bool ok = false;
+            while (!ok) {
+                ok = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == a.iter + 1ull;
+                if (!ok) {
+                    if (wall_clock64() - t0 > 400000000ll) break;        // ~4 s: a peer never arrived
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            if (!ok && a.status) *a.status = 1;
+        }
+        __syncthreads();
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        __syncthreads();
+        if (tid <= G::SW) {
+            double s2 = 0.0;
+            for (int g = 0; g < G_; ++g)                                  // fixed rank order: identical on every rank
+                s2 += __hip_atomic_load(mine + (((size_t)par * G_ + g) * K + k) * SWP + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (tid < G::SW) st[tid] = s2; else ntot = s2;
+        }
+        shifted = false;                                                  // st now holds the GLOBAL moments in the caller's coordinates
+        cd = 0.0; ce = 0.0;
+        __syncthreads();
+    }
     if (a.stats_out) {
         for (int i = tid; i < G::SW; i += FIN_THREADS) {
             double val = st[i];
@@ -1091,11 +1526,11 @@ struct Plan {
     long long rpw, rpw_b;
 };
 
-Plan make_plan(long long N, int D, int K, int flavour, bool stats) {
+Plan make_plan(long long N, int D, int K, int flavour, bool stats, bool xdl = false) {
     Plan p;
     constexpr int tuned_blocks = 256;      // one 8-wave block per CU
     constexpr int tuned_nw = MAX_NW;
-    const size_t wreg = (size_t)(D + 2) * LS * sizeof(float);
+    const size_t wreg = (size_t)((D + 2) * LS + (xdl ? TR * AIS : 0)) * sizeof(float);
     int nw = tuned_nw;
     if (nw > max_nw((K + 15) / 16)) nw = max_nw((K + 15) / 16);
     if (nw < 1) nw = 1;
@@ -1162,8 +1597,27 @@ int launch_pass_dk(const PassArgs& a, const Plan& p, int flavour, bool estep, bo
     return check_launch("pass_kernel");
 }
 
+#ifndef VMP_T1_XDL
+#define VMP_T1_XDL 1          // 0: build without the XDL E-part (A/B measurements: tools/build_variant.sh)
+#endif
+// E-part on the XDL pipe: E-step launches with K <= 16 and no missing-data mask
+inline bool use_xdl(int K, bool estep, bool mask) { return VMP_T1_XDL && estep && !mask && K <= 16; }
+
+template <int D>
+int launch_pass_xdl(const PassArgs& a, const Plan& p, int flavour, bool stats, hipStream_t s) {
+    dim3 grid(p.blocks), block(p.nw * WAVE);
+#define VMP_LAUNCH_X(FL, S) do { \
+        if (p.lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pass_xdl_kernel<D, FL, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
+        hipLaunchKernelGGL((pass_xdl_kernel<D, FL, S>), grid, block, p.lds, s, a); } while (0)
+    if (flavour == VMP_GMM) { if (stats) VMP_LAUNCH_X(VMP_GMM, true); else VMP_LAUNCH_X(VMP_GMM, false); }
+    else { if (stats) VMP_LAUNCH_X(VMP_SMM, true); else VMP_LAUNCH_X(VMP_SMM, false); }
+#undef VMP_LAUNCH_X
+    return check_launch("pass_xdl_kernel");
+}
+
 template <int D>
 int launch_pass_d(const PassArgs& a, const Plan& p, int flavour, bool estep, bool stats, bool mask, hipStream_t s) {
+    if (use_xdl(a.K, estep, mask)) return launch_pass_xdl<D>(a, p, flavour, stats, s);
     const int KT = (a.K + 15) / 16;
     if (KT == 1) return launch_pass_dk<D, 1>(a, p, flavour, estep, stats, mask, s);
     if (KT == 2) return launch_pass_dk<D, 2>(a, p, flavour, estep, stats, mask, s);
@@ -1197,7 +1651,7 @@ static long long* g_dbg_pass = nullptr;
 static long long* g_dbg_t = nullptr;
 #endif
 int run_pass(PassArgs a, int D, int flavour, bool estep, bool stats, bool mask, hipStream_t s) {
-    Plan p = make_plan(a.N, D, a.K, flavour, stats);
+    Plan p = make_plan(a.N, D, a.K, flavour, stats, use_xdl(a.K, estep, mask));
     a.rpw = p.rpw;
     a.rpw_b = p.rpw_b;
     a.par_reduce = p.par_reduce;
@@ -1360,6 +1814,32 @@ int vmp_mix_stats_ws(const float* x, const float* r, const float* u, const float
     a.x = x; a.r_in = r; a.u_in = u; a.pivot = pivot; a.N = N; a.K = K; a.partials = static_cast<double*>(ws);
     a.vec_ok = aligned16(x) && aligned16(r) && (!u || aligned16(u));
     return run_pass(a, D, u ? VMP_SMM : VMP_GMM, false, true, false, static_cast<hipStream_t>(stream));
+}
+
+int vmp_mix_finalize_exchange(const void* ws, const float* pivot, int64_t N, int D, int K, int flavour, const float* alpha0,
+                              const float* beta0, const float* m0, const float* C0, const float* v0, const float* kappa,
+                              float* alpha, float* beta, float* m, float* C, float* v, float* xbar, float* S, float* pi,
+                              float* pack, double* stats_out, void* const* peers, int nranks, int rank,
+                              unsigned long long iteration, int* status, void* stream) {
+    int rc = check_dims(N, D, K);
+    if (rc) return rc;
+    if (!ws || !alpha0 || !beta0 || !m0 || !C0 || !v0 || !peers) { set_error("vmp_mix_finalize_exchange: null pointer"); return VMP_E_BADARG; }
+    if (nranks < 1 || nranks > VMP_EXCH_MAX_RANKS || rank < 0 || rank >= nranks) { set_error("vmp_mix_finalize_exchange: bad rank / nranks"); return VMP_E_BADARG; }
+    if (flavour == VMP_SMM && !kappa) { set_error("vmp_mix_finalize_exchange: SMM needs kappa"); return VMP_E_BADARG; }
+    FinArgs f{};
+    f.partials = static_cast<const double*>(ws);
+    f.nblk = make_plan(N, D, K, flavour, true).blocks;
+    f.K = K; f.flavour = flavour; f.src = 0;
+    f.do_post = (alpha || beta || m || C || v || xbar || S || pi || pack) ? 1 : 0;
+    f.alpha0 = alpha0; f.beta0 = beta0; f.m0 = m0; f.C0 = C0; f.v0 = v0; f.kappa = kappa;
+    f.alpha = alpha; f.beta = beta; f.m = m; f.C = C; f.v = v; f.xbar = xbar; f.S = S; f.pi = pi; f.pack = pack;
+    f.stats_out = stats_out; f.pivot = pivot;
+    for (int g = 0; g < nranks; ++g) {
+        if (!peers[g]) { set_error("vmp_mix_finalize_exchange: peers[%d] is null", g); return VMP_E_BADARG; }
+        f.peer[g] = static_cast<double*>(peers[g]);
+    }
+    f.nranks = nranks; f.rank = rank; f.iter = iteration; f.status = status;
+    return run_finalize(f, D, static_cast<hipStream_t>(stream));
 }
 
 int vmp_mix_finalize_ws(const void* ws, const float* pivot, int64_t N, int D, int K, int flavour, const float* alpha0, const float* beta0,

@@ -246,7 +246,15 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
                              float (&xo)[2 * L], float (&go)[2 * L]) {
             const bool live = on && s2 < S;
             const bool both = s2 + 1 < S;
+#if defined(SV_EXP) && SV_EXP == 1
             if (live) {
+#pragma unroll
+                for (int i = 0; i < 2 * L; ++i) { xo[i] = mu[i % L] + 0.01f * (float)(s2 + i); go[i] = 0.001f * (float)(i - s2); }
+            }
+            if (false) {
+#else
+            if (live) {
+#endif
                 if ((L & 3) == 0 && a.vec_ok) {
 #pragma unroll
                     for (int q = 0; q < L / 4; ++q) {
@@ -294,6 +302,11 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
             float xs[L], gx[L];
 #pragma unroll
             for (int i = 0; i < L; ++i) { xs[i] = xp[h * L + i]; gx[i] = gp[h * L + i]; }
+#if defined(SV_EXP) && SV_EXP == 2
+#pragma unroll
+            for (int i = 0; i < L; ++i) { Wsum[i] += gx[i] + xs[i]; }
+            continue;
+#endif
             // d/dx of the theta term of T':  (1/S) c_s W^T W (x - m),  c_s = 1 (Gaussian) or (nu+L)/(nu+delta^2)
             float d[L], y[L];
 #pragma unroll
@@ -455,6 +468,315 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
         if (f < PWa)
             for (int rr = 0; rr < RPT; ++rr) s2 += red[f * WAVE + rr * K + kk];
         out[e] = s2;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Backward, LDS-ring form (round 3).  What bounded the kernel above (measured): with the sample
+// arithmetic REMOVED it still takes 3.2 ms at C3, with the loads removed 1.9 ms - the time is the access pattern, not
+// the arithmetic: every lane fetches its own 64-byte piece of a 320-byte cell row, so each load instruction touches 64
+// different cache lines and the vector L1 spends its cycles on tag look-ups (TCP pending-stall 62 %).  Here the two
+// sample rows (x, dL/dx) of a sample PAIR of the wave's 64 cells are brought in by global_load_lds_dwordx4 with FOUR
+// ADJACENT LANES PER CELL (one 64-byte segment per lane quad: 16 look-ups per instruction instead of 64) into a per-wave
+// ring of two stages; a stage is drained to registers and re-requested for the pair after next BEFORE the arithmetic of
+// its pair starts, so two pairs (16 KB per wave, 128 KB per CU) are always in flight and no VGPR is spent on prefetch.
+// The LDS this needs comes from the per-component accumulators: the 4 rows of a tile are summed across lanes first
+// (fixed order: (r0 + r2) + (r1 + r3)), so a wave keeps [PWa][16] floats instead of a lane-private [PWa][64] column set.
+// One 8-wave block per CU.  Gaussian theta, K = 16 (a tile = 4 whole rows = 64 cells), even L and even S >= 4 (a sample
+// pair is L/2 16-byte pieces); everything else takes the kernel above.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SVR_NW = 8;
+template <int L> constexpr int svr_stage_floats() { return 2 * WAVE * 2 * L; }       // x pair + dx pair of 64 cells
+
+__device__ __forceinline__ float rows4_sum(float v) {          // sum over lanes l, l^16, l^32, l^48 (same component, 4 rows)
+    const float t = v + __shfl_xor(v, 32);
+    return t + __shfl_xor(t, 16);
+}
+
+template <int L>
+__global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwdArgs a, int nblk_abi) {
+    constexpr int TRI = SvGeo<L>::TRI;
+    constexpr int PW = 2 * (L + TRI + 1);
+    constexpr int TH = L + TRI + 1;                          // accumulator rows in use (Gaussian theta)
+    constexpr int PP = L / 2;                                // 16-byte pieces of one sample pair of one cell
+    constexpr int STG = svr_stage_floats<L>();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: tile indices and DMA bases stay scalar
+    const int K = a.K, S = a.S;
+    const int LSn = L * S, NP = S >> 1;
+    const int RPT = WAVE / K, CT = RPT * K;
+    constexpr int PSTR = TRI | 1;
+    const int tab = (K * PSTR + 3) & ~3;
+    float* pk_lds = smem;                                    // [K][PSTR]  lower triangle of P_k
+    float* ring = smem + tab + wave * (2 * STG);             // two stages: [x pair: 64 cells x 2L | dx pair: 64 cells x 2L]
+    float* accw = smem + tab + nw * (2 * STG) + wave * (TH * 16);   // this wave's per-component sums [TH][16]
+    float* scr = smem + tab + nw * (2 * STG) + nw * (TH * 16) + wave * WAVE;
+    const bool lane_on = true;                               // K == 16: every lane owns a cell
+    const int r = lane >> 4, k = lane & 15, rbase = r * 16;
+
+    for (int e = threadIdx.x; e < K * TRI; e += blockDim.x) {
+        const int kk = e / TRI, idx = e - kk * TRI;
+        int i = 0;
+        while (tri(i + 1, 0) <= idx) ++i;
+        const int j = idx - tri(i, 0);
+        pk_lds[kk * PSTR + idx] = a.Pk[(kk * L + i) * L + j];
+    }
+    for (int e = lane; e < TH * 16; e += WAVE) accw[e] = 0.f;
+    __syncthreads();
+
+    float hkk[L], mkk[L], Wt[TRI];
+    const int kc = lane_on ? k : 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const float hv = a.hk[kc * L + i], mv = a.mk[kc * L + i];
+        hkk[i] = lane_on ? hv : 0.f;
+        mkk[i] = lane_on ? mv : 0.f;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) { const float wv = a.Wk[(kc * L + i) * L + j]; Wt[tri(i, j)] = lane_on ? wv : 0.f; }
+    }
+
+    const long long ntiles = (a.N + RPT - 1) / RPT;
+    const long long tstride = (long long)gridDim.x * nw;
+    const float invS = 1.0f / (float)S;
+    // DMA slot walk: slot g = j*64 + lane of instruction j holds piece (g % PP) of tile cell (g / PP); for L = 8 the piece
+    // index is XOR-swizzled with bits 2-3 of the cell so that the 16 lanes a ds_read_b128 serves together hit 16 banks
+    int dcell[PP], dpiece[PP];
+#pragma unroll
+    for (int j = 0; j < PP; ++j) {
+        const int g = j * WAVE + lane;
+        dcell[j] = g / PP;
+        const int pc = g - dcell[j] * PP;
+        dpiece[j] = (PP == 4) ? (pc ^ ((dcell[j] >> 2) & 3)) : pc;
+    }
+    const int sw = (PP == 4) ? ((lane >> 2) & 3) : 0;       // read side of the same swizzle (this lane's cell = lane)
+    auto issue = [&](long long tt, int pp, float* stage) {
+        // pair pp of tile tt -> stage; cells past the end of the tensor are clamped to the tile's last valid cell
+        const long long cells_left = (a.N - tt * RPT) * K;
+        const int ncell = cells_left < CT ? (int)cells_left : CT;
+        const long long tile0 = tt * (long long)CT * LSn + pp * 2 * L;
+#pragma unroll
+        for (int j = 0; j < PP; ++j) {
+            const int cc = dcell[j] < ncell ? dcell[j] : ncell - 1;
+            const long long off = tile0 + (long long)cc * LSn + 4 * dpiece[j];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.x + off),
+                                             (__attribute__((address_space(3))) void*)(stage + j * (4 * WAVE)), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.Gx + off),
+                                             (__attribute__((address_space(3))) void*)(stage + WAVE * 2 * L + j * (4 * WAVE)), 16, 0, 0);
+        }
+    };
+
+    long long t = (long long)blockIdx.x * nw + wave;
+    int cur = 0;                                             // stage holding the pair about to be consumed
+    bool younger = true;                                     // was the pair after the one about to be consumed requested?
+    if (t < ntiles) {
+        issue(t, 0, ring);
+        if (NP > 1) issue(t, 1, ring + STG);
+        else if (t + tstride < ntiles) issue(t + tstride, 0, ring + STG);
+    }
+    for (; t < ntiles; t += tstride) {
+        const long long row = t * RPT + r;
+        const bool on = lane_on && row < a.N;
+        const long long rowc = on ? row : 0;
+        const long long cellid = rowc * K + kc;
+
+        float Lm[TRI], av[L], mu[L];
+#pragma unroll
+        for (int i = 0; i < TRI; ++i) Lm[i] = lane_on ? pk_lds[k * PSTR + i] : 0.f;
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const float e1v = a.eta1[rowc * L + i], e2v = a.eta2d[rowc * L + i];
+            const float e1 = on ? e1v : 0.f;
+            const float e2 = on ? e2v : -0.5f;
+            Lm[tri(i, i)] = fmaf(-2.f, e2, lane_on ? Lm[tri(i, i)] : 0.f);
+            av[i] = e1 + hkk[i];
+        }
+        const float glzv = a.Glz[cellid], gTv = a.GT[cellid], lzv = a.lz[cellid];
+        float ld;
+        cell_cholesky<L>(Lm, ld);
+        solve_lower<L>(Lm, av);
+#pragma unroll
+        for (int i = 0; i < L; ++i) mu[i] = av[i];
+        solve_lower_t<L>(Lm, mu);                           // mu~ = Pt^-1 ht
+
+        const float glz = on ? glzv : 0.f;
+        const float gT = on ? gTv : 0.f;
+        const float rnk = on ? __expf(lzv) : 0.f;
+        const float gsum = row_sum(glz, scr, lane, rbase, K);
+        const float Gc = glz - rnk * gsum;                  // through the log-sum-exp normalisation
+        const float Gld = gT - Gc;                          // T' has +ld, c has -ld
+
+        float Wsum[L], M[TRI];
+#pragma unroll
+        for (int i = 0; i < L; ++i) Wsum[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < TRI; ++i) M[i] = 0.f;
+        const float gts = gT * invS;
+        for (int p = 0; p < NP; ++p) {
+            float* stage = ring + cur * STG;
+            // The stage about to be read was requested two pairs ago.  If the pair in between was requested too, its 2*PP
+            // DMA instructions are the youngest ones in flight and may stay so; if it was not (no next tile for this wave),
+            // NOTHING younger exists and the count must drain to zero - waiting for "<= 2*PP outstanding" would then not wait
+            // at all (found as a run-to-run difference of the last pair of a wave's last tile).
+            if (!younger) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (PP == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (PP == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (PP == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            float xp[2 * L], gp[2 * L];
+#pragma unroll
+            for (int q = 0; q < PP; ++q) {
+                const f32x4 vx = *reinterpret_cast<const f32x4*>(stage + lane * (2 * L) + 4 * (q ^ sw));
+                const f32x4 vg = *reinterpret_cast<const f32x4*>(stage + WAVE * 2 * L + lane * (2 * L) + 4 * (q ^ sw));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { xp[4 * q + c] = vx[c]; gp[4 * q + c] = vg[c]; }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the stage is in registers: it may be overwritten
+#pragma unroll
+            for (int i = 0; i < 2 * L; ++i) asm volatile("" : "+v"(xp[i]), "+v"(gp[i]));
+            {   // re-request this stage for the pair after next (of this tile, or of this wave's next tile; NP >= 2: host)
+                const int pn = p + 2;
+                if (pn < NP) { issue(t, pn, stage); younger = true; }
+                else if (t + tstride < ntiles) { issue(t + tstride, pn - NP, stage); younger = true; }
+                else younger = false;
+            }
+            cur ^= 1;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float xs[L], gx[L];
+#pragma unroll
+                for (int i = 0; i < L; ++i) { xs[i] = on ? xp[h * L + i] : 0.f; gx[i] = on ? gp[h * L + i] : 0.f; }
+                // d/dx of the theta term of T':  (1/S) W^T W (x - m)
+                float d[L], y[L];
+#pragma unroll
+                for (int i = 0; i < L; ++i) d[i] = xs[i] - mkk[i];
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    float yy = 0.f;
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) yy = fmaf(Wt[tri(i, j)], d[j], yy);
+                    y[i] = yy;
+                }
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    const float gy = gts * y[i];
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) gx[j] = fmaf(Wt[tri(i, j)], gy, gx[j]);
+                }
+                solve_lower<L>(Lm, gx);                     // w_s = Lt^-1 gx_s
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    Wsum[i] += gx[i];
+                    const float e = xs[i] - mu[i];          // e_s = Lt^-T eps_s
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) M[tri(i, j)] = fmaf(e, gx[j], M[tri(i, j)]);
+                }
+            }
+        }
+        // ---- assemble dLoss/dht and dLoss/dPt (symmetric, lower triangle): as in svae_estep_bwd_kernel
+        float V[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) V[i] = Wsum[i];
+        solve_lower_t<L>(Lm, V);                            // V = Pt^-1 sum_s gx_s
+        float gh[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) gh[i] = fmaf(Gc, mu[i], V[i]);
+        float Cs[TRI], dg[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) dg[i] = 1.0f / Lm[tri(i, i)];
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                float s2 = 0.f;
+#pragma unroll
+                for (int pq = i; pq < L; ++pq) {
+                    const float lpi = (pq == i) ? dg[i] : Lm[tri(pq, i)];
+                    s2 = fmaf(lpi, -M[tri(pq, j)], s2);
+                }
+                Cs[tri(i, j)] = (i == j) ? (s2 + Gld) : s2;
+            }
+        float Y[TRI];
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            Y[tri(j, j)] = Lm[tri(j, j)];
+#pragma unroll
+            for (int i = j + 1; i < L; ++i) {
+                float s2 = 0.f;
+#pragma unroll
+                for (int pq = j; pq < i; ++pq) s2 = fmaf(Lm[tri(i, pq)], Y[tri(pq, j)], s2);
+                Y[tri(i, j)] = -s2 * Lm[tri(i, i)];
+            }
+        }
+        float gP[TRI];
+#pragma unroll
+        for (int i = 0; i < TRI; ++i) gP[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            float Zc[L];
+#pragma unroll
+            for (int q = 0; q < L; ++q) {
+                float s2 = 0.f;
+#pragma unroll
+                for (int pq = j; pq < L; ++pq) {
+                    const float cqp = (q >= pq) ? Cs[tri(q, pq)] : Cs[tri(pq, q)];
+                    s2 = fmaf(cqp, Y[tri(pq, j)], s2);
+                }
+                Zc[q] = s2;
+            }
+#pragma unroll
+            for (int i = j; i < L; ++i) {
+                float s2 = 0.f;
+#pragma unroll
+                for (int pq = i; pq < L; ++pq) s2 = fmaf(Y[tri(pq, i)], Zc[pq], s2);
+                gP[tri(i, j)] = 0.5f * s2;
+            }
+        }
+        // rank-one terms  - sym(V mu^T) - 1/2 Gc mu mu^T  =  -1/2 (tv mu^T + mu tv^T),  tv = V + 1/2 Gc mu
+        float tv[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) tv[i] = -0.5f * fmaf(0.5f * Gc, mu[i], V[i]);
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) gP[tri(i, j)] = fmaf(tv[i], mu[j], fmaf(mu[i], tv[j], gP[tri(i, j)]));
+
+        // ---- per-row sums (DPP / LDS scratch) and per-component sums: the tile's 4 rows first (fixed order), then the
+        //      wave's [TH][16] accumulator, updated by the 16 lanes of row 0 only
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const float s1 = row_sum(on ? gh[i] : 0.f, scr, lane, rbase, K);
+            const float s2 = row_sum(on ? gP[tri(i, i)] : 0.f, scr, lane, rbase, K);
+            if (on && k == 0) {
+                a.g_eta1[row * L + i] = s1;
+                a.g_eta2d[row * L + i] = -2.f * s2;          // p = -2 eta2d
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < L; ++i) { const float sv = rows4_sum(on ? gh[i] : 0.f); if (lane < 16) accw[i * 16 + lane] += sv; }
+#pragma unroll
+        for (int i = 0; i < TRI; ++i) { const float sv = rows4_sum(on ? gP[i] : 0.f); if (lane < 16) accw[(L + i) * 16 + lane] += sv; }
+        { const float sv = rows4_sum(on ? Gc : 0.f); if (lane < 16) accw[(L + TRI) * 16 + lane] += sv; }
+    }
+
+    // ---- block reduction: waves in a fixed order, then one partial row per block
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* out = a.partials + (long long)blockIdx.x * K * PW;
+    for (int e = threadIdx.x; e < K * PW; e += blockDim.x) {
+        const int kk = e / PW, f = e - kk * PW;
+        float s2 = 0.f;
+        if (f < TH) {
+            const float* base = smem + tab + nw * (2 * STG);
+            for (int w = 0; w < nw; ++w) s2 += base[w * (TH * 16) + f * 16 + kk];
+        }
+        out[e] = s2;
+    }
+    // rows of the partial buffer the ABI sized for more blocks than this kernel launches
+    for (int b = blockIdx.x + gridDim.x; b < nblk_abi; b += gridDim.x) {
+        float* z = a.partials + (long long)b * K * PW;
+        for (int e = threadIdx.x; e < K * PW; e += blockDim.x) z[e] = 0.f;
     }
 }
 
@@ -1498,6 +1820,29 @@ int vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk, c
     if (partial_bytes < (size_t)blocks * K * PW * sizeof(float)) { set_error("vmp_svae_estep_bwd: partials buffer too small"); return VMP_E_WS; }
     EBwdArgs a{eta1, eta2d, hk, Pk, bias, mk, Wk, nu, x, lz, Gx, Glz, GT, g_eta1, g_eta2d, partials, N, K, S, 0};
     a.vec_ok = al16(x) && al16(Gx);
+#ifndef VMP_T2_RING
+#define VMP_T2_RING 1         // 0: build without the LDS-ring backward kernel (A/B measurements: tools/build_variant.sh)
+#endif
+    if (VMP_T2_RING && !nu && K == 16 && (L & 1) == 0 && L >= 4 && (S & 1) == 0 && S >= 4 && a.vec_ok) {
+        // LDS-ring kernel (quad-coalesced LDS-DMA of sample pairs, two pairs in flight per wave): one 8-wave block per CU
+        const long long ntiles = (N + 3) / 4;
+        long long bl = (ntiles + SVR_NW - 1) / SVR_NW;
+        if (bl > 256) bl = 256;
+        const int TH = PW / 2;
+        const int tab = (K * ((L * (L + 1) / 2) | 1) + 3) & ~3;
+        const size_t ldsr = (size_t)(tab + SVR_NW * (2 * (2 * WAVE * 2 * L)) + SVR_NW * TH * 16 + SVR_NW * WAVE) * sizeof(float);
+        rc = -1;
+        switch (L) {
+#define VMP_RING(LL) case LL: \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_bwd_ring_kernel<LL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr); \
+            hipLaunchKernelGGL((svae_estep_bwd_ring_kernel<LL>), dim3((int)bl), dim3(SVR_NW * WAVE), ldsr, static_cast<hipStream_t>(stream), a, blocks); \
+            rc = check_launch("svae_estep_bwd_ring_kernel"); break;
+            VMP_RING(4) VMP_RING(6) VMP_RING(8)
+#undef VMP_RING
+            default: break;
+        }
+        return rc;
+    }
     const int PWa = nu ? PW : PW / 2;
     const size_t lds = (size_t)(K * ((L * (L + 1) / 2) | 1) + SV_NW * WAVE + PWa * WAVE + SV_NW * PWa * WAVE) * sizeof(float);
     rc = -1;

@@ -65,16 +65,78 @@ class PackComm(object):
             self._h = None
 
 
-class DistributedVMPLoop(_mix.VMPLoop):
-    """VMPLoop whose posterior update sees the statistics of ALL ranks' rows."""
+class PeerExchange(object):
+    """Peer-visible exchange buffers of the ONE-LAUNCH data-parallel finalize (include/vmp_hip.h,
+    vmp_mix_finalize_exchange): every rank allocates vmp_exch_bytes(G, K, D) of uncached device memory, exports its IPC
+    handle, gathers the G handles (any out-of-band channel; here torch.distributed's object all-gather - a one-time
+    set-up exchange of 64 bytes per rank) and maps the peers' buffers.  No collective library is on the step path: the
+    finalize kernels push their fp64 moments into each other's buffers and sum them in rank order."""
 
-    def __init__(self, x, r_init, flavour, kappa=None, u_init=None, prior=None, group=None, comm=None):
+    def __init__(self, K, D, group=None, rank=None, world=None, gather=None):
+        import ctypes
+        import torch.distributed as dist
+        self.world = dist.get_world_size(group) if world is None else int(world)
+        self.rank = dist.get_rank(group) if rank is None else int(rank)
+        if not 1 <= self.world <= 16:
+            raise L.VmpError('PeerExchange supports 1..16 ranks')
+        self.K, self.D = int(K), int(D)
+        nbytes = L.lib().vmp_exch_bytes(self.world, self.K, self.D)
+        buf = ctypes.c_void_p()
+        L.check(L.lib().vmp_exch_alloc(ctypes.byref(buf), nbytes), 'vmp_exch_alloc')
+        self._buf = buf
+        hb = ctypes.create_string_buffer(64)
+        L.check(L.lib().vmp_exch_export(buf, hb), 'vmp_exch_export')
+        if gather is not None:
+            handles = gather(hb.raw)                      # caller-supplied all-gather of the 64-byte handles
+        else:
+            handles = [None] * self.world
+            dist.all_gather_object(handles, hb.raw, group=group)
+        self._peers = []
+        for g, h in enumerate(handles):
+            if g == self.rank:
+                self._peers.append(ctypes.c_void_p(buf.value))
+            else:
+                pp = ctypes.c_void_p()
+                L.check(L.lib().vmp_exch_open(ctypes.create_string_buffer(h, 64), ctypes.byref(pp)), 'vmp_exch_open')
+                self._peers.append(pp)
+        self.table = (ctypes.c_void_p * self.world)(*[p.value for p in self._peers])
+        self.iteration = 0
+        self.status = torch.zeros(1, dtype=torch.int32, device='cuda')
+
+    def close(self):
+        for g, pp in enumerate(self._peers):
+            if g != self.rank:
+                L.lib().vmp_exch_close(pp)
+        self._peers = []
+        if self._buf is not None:
+            L.lib().vmp_exch_free(self._buf)
+            self._buf = None
+
+
+class DistributedVMPLoop(_mix.VMPLoop):
+    """VMPLoop whose posterior update sees the statistics of ALL ranks' rows.  exchange=PeerExchange(...): the whole
+    distributed finalize is ONE launch (moments pushed into the peers' buffers by the kernel itself); otherwise three
+    launches around one all-reduce (RCCL through torch.distributed or the C ABI's PackComm)."""
+
+    def __init__(self, x, r_init, flavour, kappa=None, u_init=None, prior=None, group=None, comm=None, exchange=None):
         super().__init__(x, r_init, flavour, kappa=kappa, u_init=u_init, prior=prior)
-        self.group, self.comm = group, comm
+        self.group, self.comm, self.exchange = group, comm, exchange
         self._stats = torch.empty((self.K, L.lib().vmp_mix_stats_words(self.D)), dtype=torch.float64,
                                   device=self.x.device)
 
     def finalize(self, stats_out=None):
+        if self.exchange is not None:
+            ex, p, pr = self.exchange, self.post, self.prior
+            L.check(L.lib().vmp_mix_finalize_exchange(
+                L.ptr(self.ws), L.ptr(self.pivot), self.N, self.D, self.K, self.flavour, L.ptr(pr[0]), L.ptr(pr[1]),
+                L.ptr(pr[2]), L.ptr(pr[3]), L.ptr(pr[4]), L.ptr(self.kappa), L.ptr(p['alpha']), L.ptr(p['beta']),
+                L.ptr(p['m']), L.ptr(p['C']), L.ptr(p['v']), L.ptr(p['xbar']), L.ptr(p['S']), L.ptr(p['pi']),
+                L.ptr(p['pack']), L.ptr(self._stats), ex.table, ex.world, ex.rank, ex.iteration, L.ptr(ex.status),
+                L.stream()), 'vmp_mix_finalize_exchange')
+            ex.iteration += 1
+            if stats_out is not None:
+                stats_out.copy_(self._stats)
+            return
         # local reduction of the per-block partials -> (K, SW) fp64; sum over ranks; global posterior + pack
         pr = self.prior
         L.check(L.lib().vmp_mix_finalize_ws(L.ptr(self.ws), L.ptr(self.pivot), self.N, self.D, self.K, self.flavour,
