@@ -1,12 +1,20 @@
 #!/usr/bin/env python3
 """bench.py - headline benchmark of the VMP hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gmm|smm] [--n ROWS --d D --k K]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gmm|smm|t2|t3] [--scaling weak|strong]
+                    [--n ROWS --d D --k K] [--exchange rccl|peer]
 
-A "step" is one VMP iteration (M-step -> E-step -> assign; reference models/gmm.py:258-263) over one batch
-of synthetic Gaussian-mixture data resident in HBM.  Default workload = BASELINE.json configs[2]:
-synthetic GMM N=1e6, D=8, K=16 per GPU (weak scaling: every rank holds N rows; the K-sized sufficient
-statistics are summed across ranks with one RCCL all-reduce per step).  Prints ONE JSON line on rank 0.
+A "step" is one pass of the hot path over one batch of synthetic Gaussian-mixture data resident in HBM:
+  gmm / smm  one VMP iteration (M-step -> E-step -> assign; reference models/gmm.py:258-263, smm.py:232-238).  Default =
+             BASELINE.json configs[2] (GMM N=1e6, D=8, K=16); --workload smm = configs[4]'s model (C5)
+  t2         the SVAE VMP step without the MLPs (fused E-step fwd + bwd, sub-sampling, M-step moments, CVI update)
+  t3         the full SVAE training step of experiments.py:196-267 (configs[3]'s step function at the C3 shape; C4)
+Multi-GPU (one rank per GPU): rows are sharded, ONE exchange of the K-sized statistics (+ gradients for t2 / t3) per step.
+  --scaling weak    every rank holds N rows (default; `value` = N x ranks / step time)
+  --scaling strong  the N rows are split over the ranks (rows / rank = N / G) - the reference's tf.split of ONE
+                    minibatch over its towers (data.py:174-175); `value` = N / step time
+With more than one rank the T1 line carries BOTH: the other mode is measured right after the headline and reported under
+extra.other_scaling.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -36,45 +44,19 @@ def synth(N, D, K, seed):
 
 
 def cpu_baseline(x, r0, workload, chunk=1 << 15, reps=3):
-    """The reference CPU path = the oracle (op-for-op torch-CPU fp32 restatement of models/gmm.py /
-    models/smm.py, pinned by tests/golden), timed on this host in N-chunks (the literal graph materialises
-    (N,K,D,D) temporaries).  One VMP step over a bounded sample of the workload; best of `reps`."""
-    from oracle import mixtures, dists
+    """The reference CPU path = the oracle (op-for-op torch-CPU fp32 restatement of models/gmm.py / models/smm.py, pinned by
+    tests/golden), timed on this host: ONE VMP step through oracle.mixtures.{gmm,smm}_inference_step_chunked - the very
+    function the full-size parity tests check the HIP path against - over a bounded sample of the workload (the literal
+    graph materialises (N,K,D,D) temporaries, hence the row chunks); best of `reps`."""
+    from oracle import mixtures
     Ns = min(x.shape[0], 1 << 18)                      # bounded sample: 262144 rows
     xs, rs = torch.as_tensor(x[:Ns]), torch.as_tensor(r0[:Ns])
-    K, D = rs.shape[1], xs.shape[1]
-    prior = mixtures.vmp_prior(K, D, torch.float32)
     us = torch.ones_like(rs)
-    kap = torch.full((K,), 5.0)
 
     def one_step():
-        # M-step, two passes over the chunks exactly as update_xk / update_Sk are written
-        w = rs * us if workload == 'smm' else rs
-        N_k = rs.sum(0)
-        W_k = w.sum(0)
-        sx = torch.zeros(K, D)
-        for i in range(0, Ns, chunk):
-            sx += torch.einsum('nk,nd->kd', w[i:i + chunk], xs[i:i + chunk])
-        x_k = sx / (W_k.unsqueeze(1) + (1e-20 if workload == 'smm' else 0.0))
-        S = torch.zeros(K, D, D)
-        for i in range(0, Ns, chunk):
-            d = xs[i:i + chunk].unsqueeze(1) - x_k.unsqueeze(0)
-            S += torch.einsum('nk,nkde->kde', w[i:i + chunk], torch.einsum('nkd,nke->nkde', d, d))
-        S_k = S / W_k.view(-1, 1, 1)
-        a0, b0, m0, C0, v0 = prior
-        alpha_k, beta_k = a0 + N_k, b0 + W_k
-        m_k = (b0.reshape(-1, 1) * m0 + W_k.unsqueeze(1) * x_k) / beta_k.unsqueeze(1)
-        q0 = x_k - m0
-        C_k = C0 + W_k.view(-1, 1, 1) * S_k + torch.einsum('k,kde->kde', b0 * W_k / beta_k, torch.einsum('kd,ke->kde', q0, q0))
-        v_k = v0 + N_k + (0 if workload == 'smm' else 1)
-        P_k = dists.inv(C_k)
-        out = []
-        for i in range(0, Ns, chunk):
-            if workload == 'smm':
-                out.append(mixtures.smm_e_step(xs[i:i + chunk], alpha_k, beta_k, m_k, P_k, v_k, kap)[0])
-            else:
-                out.append(mixtures.gmm_e_step(xs[i:i + chunk], alpha_k, beta_k, m_k, P_k, v_k)[0])
-        return torch.cat(out)
+        if workload == 'smm':
+            return mixtures.smm_inference_step_chunked(xs, rs, us, 5.0, chunk=chunk)[0]
+        return mixtures.gmm_inference_step_chunked(xs, rs, chunk=chunk)[0]
 
     # The thread count is part of the baseline: on the 256-hardware-thread host of the GPU box torch's intra-op pool
     # collapses when every thread is used (measured: 1.5e4 datapoints/s at 256 threads vs 7.3e5 at 32), so a few
@@ -94,7 +76,7 @@ def cpu_baseline(x, r0, workload, chunk=1 << 15, reps=3):
     torch.set_num_threads(best_t)
     return {'value': Ns / best, 'unit': 'datapoints/s', 'cores': best_t, 'kind': 'port',
             'steps_per_sec_at_sample': 1.0 / best, 'host_hw_threads': ncpu, 'thread_counts_tried': cands,
-            'sample': 'one %s VMP step (oracle, fp32, torch-CPU, N-chunks of %d) on the first %d rows of the workload; '
+            'sample': 'one %s VMP step (oracle.mixtures.*_inference_step_chunked, fp32, torch-CPU, N-chunks of %d) on the first %d rows of the workload; '
                       'fastest of %d timed runs at each of %s threads (best: %d threads)'
                       % (workload, chunk, Ns, reps, cands, best_t)}
 
@@ -351,13 +333,48 @@ def spawn_ranks(n, argv):
     return max(abs(rc) for rc in rcs)
 
 
+def shard_rows(n_total, rank, world):
+    """contiguous near-equal row ranges (tf.split semantics, data.py:174-175; remainder to the first ranks)"""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def dec_bwd_side_measurement(N, K, S, Ld, U, dev):
+    """The dominant kernel of the T3 step (fused decoder backward: value + all gradients of the reconstruction term from
+    one launch) timed on its own stream position with HIP events on a bounded row count, for the t3 roofline."""
+    from vmp_for_svae_amd.models import vae, _svae_ops
+    n = min(N, 262144)
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(n, K, S, Ld, device=dev, generator=g).requires_grad_(True)
+    y = torch.randn(n, Ld, device=dev, generator=g)
+    w = torch.softmax(torch.randn(n, K, device=dev, generator=g), 1)
+    params = [p_ for _, p_ in vae.net_variables('decoder_net')]
+    ts = []
+    for i in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _svae_ops.DecoderWeightedLoglikeFn.apply(y, x, w, *params)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ms = float(np.median(ts[1:]))
+    rows = float(n) * K * S
+    useful = 3 * 2.0 * rows * (Ld * U + U * U + U * 2 * Ld + Ld * Ld)     # fwd recompute + 2 x bwd
+    return ms * (float(N) / n), useful * (float(N) / n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--reps', type=int, default=31, help='repetitions of the timed region; the median is reported')
-    ap.add_argument('--workload', default='gmm', choices=['gmm', 'smm'])
+    ap.add_argument('--reps', type=int, default=31, help='repetitions of the timed region (gmm / smm); the median is reported')
+    ap.add_argument('--workload', default='gmm', choices=['gmm', 'smm', 't2', 't3'])
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--exchange', default='rccl', choices=['rccl', 'peer'],
+                    help='T1 multi-rank exchange: rccl = local reduce + RCCL all-reduce + posterior (3 launches); '
+                         'peer = ONE finalize launch pushing the moments into IPC-mapped peer buffers')
     ap.add_argument('--n', type=int, default=1_000_000)
     ap.add_argument('--d', type=int, default=8)
     ap.add_argument('--k', type=int, default=16)
@@ -391,35 +408,67 @@ def main():
 
     import vmp_for_svae_amd as V
     from vmp_for_svae_amd.models import _mix
-    from vmp_for_svae_amd.models.parallel_mix import DistributedVMPLoop
+    from vmp_for_svae_amd.models.parallel_mix import DistributedVMPLoop, PeerExchange
     L = V._lib
     L.lib()                                              # fail loudly if the HIP library is missing
 
     N, D, K = args.n, args.d, args.k
-    flav = L.VMP_SMM if args.workload == 'smm' else L.VMP_GMM
-    x_h, r0_h = synth(N, D, K, seed=rank)                # every rank: its own shard of the (virtual) N*world rows
-    x, r0 = torch.as_tensor(x_h).to(dev), torch.as_tensor(r0_h).to(dev)
-    kappa = torch.full((K,), 5.0, device=dev) if flav == L.VMP_SMM else None
-    loop = DistributedVMPLoop(x, r0, flav, kappa=kappa) if world > 1 else _mix.VMPLoop(x, r0, flav, kappa=kappa)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    walls, kerns = time_t1(loop, args.steps, args.warmup, max(1, args.reps), barrier, dist, dev)
-    dt = float(np.median(walls))
-    kern_ms = float(np.median(kerns))
-    assert torch.isfinite(loop.r).all()
-    extra = {}
-    # the side measurements are single-GPU experiments: under a multi-rank launch only the headline is measured (nothing
-    # after the timed region may be able to take the JSON line down with it)
-    if not args.no_extra and world == 1:
-        del loop
-        torch.cuda.empty_cache()
-        if world == 1:
-            # (a) what the data-parallel iteration costs on top of the plain one, with ONE rank (local reduction ->
-            #     RCCL all-reduce of the fp64 moments -> posterior + pack -> streaming pass)
+    def rows_for(mode):
+        """(rows on this rank, rows of the whole job) under weak / strong scaling"""
+        if mode == 'weak':
+            return N, N * world
+        lo, hi = shard_rows(N, rank, world)
+        return hi - lo, N
+
+    common = {'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': True, 'scaling': args.scaling,
+              'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'unit': 'datapoints/s'}
+    out, extra = None, {}
+
+    if args.workload in ('gmm', 'smm'):
+        flav = L.VMP_SMM if args.workload == 'smm' else L.VMP_GMM
+        kappa = torch.full((K,), 5.0, device=dev) if flav == L.VMP_SMM else None
+
+        def make_loop(n_rows, seed):
+            x_h_, r0_h_ = synth(n_rows, D, K, seed=seed)
+            x_, r0_ = torch.as_tensor(x_h_).to(dev), torch.as_tensor(r0_h_).to(dev)
+            if world > 1:
+                ex = PeerExchange(K, D) if args.exchange == 'peer' else None
+                lp = DistributedVMPLoop(x_, r0_, flav, kappa=kappa, exchange=ex)
+            else:
+                lp = _mix.VMPLoop(x_, r0_, flav, kappa=kappa)
+            return lp, x_h_, r0_h_, x_, r0_
+
+        n_loc, n_job = rows_for(args.scaling)
+        loop, x_h, r0_h, x, r0 = make_loop(n_loc, seed=rank)      # every rank: its own shard of the job's rows
+        walls, kerns = time_t1(loop, args.steps, args.warmup, max(1, args.reps), barrier, dist, dev)
+        dt = float(np.median(walls))
+        kern_ms = float(np.median(kerns))
+        assert torch.isfinite(loop.r).all()
+        if world > 1:
+            # the OTHER scaling mode, same launch: fewer repetitions, same timed-region protocol
+            other = 'strong' if args.scaling == 'weak' else 'weak'
+            del loop
+            torch.cuda.empty_cache()
+            n2, job2 = rows_for(other)
+            loop2 = make_loop(n2, seed=100 + rank)[0]
+            w2, k2 = time_t1(loop2, args.steps, args.warmup, 7, barrier, dist, dev)
+            d2 = float(np.median(w2))
+            extra['other_scaling'] = {'scaling': other, 'rows_per_rank': n2, 'rows_job': job2, 'ms_per_step': d2 / args.steps * 1e3,
+                                      'value': job2 / (d2 / args.steps), 'kernel_ms': float(np.median(k2)),
+                                      'exchange': args.exchange}
+            del loop2
+        # side measurements: single-GPU experiments (nothing after the timed region may take the JSON line down with it)
+        if not args.no_extra and world == 1:
+            del loop
+            torch.cuda.empty_cache()
+            # (a) what the data-parallel iteration costs on top of the plain one, with ONE rank: the 3-launch RCCL form
+            #     (local reduction -> all-reduce -> posterior + pack) and the ONE-launch peer-exchange form
             import torch.distributed as dist1
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29533')
@@ -428,78 +477,123 @@ def main():
             dw, _ = time_t1(dloop, args.steps, args.warmup, 7, lambda: torch.cuda.synchronize(), None, dev)
             dist1.destroy_process_group()
             d_us = float(np.median(dw)) / args.steps * 1e6
-            extra['t1_forced_dist_1rank'] = {'us_per_step': d_us, 'plain_us_per_step': dt / args.steps * 1e6,
-                                             'dist_overhead_us': d_us - dt / args.steps * 1e6}
             del dloop
-        del x, r0
-        torch.cuda.empty_cache()
-        if world == 1 and (N, D, K) == (1_000_000, 8, 16):
-            # (b) the cache-defeating size of SURVEY 8d: N=1e7 (x + r = 960 MB >> the 256 MiB Infinity Cache)
-            Nb = 10_000_000
-            g = torch.Generator(device=dev).manual_seed(5)
-            cb = torch.randn(K, D, device=dev, generator=g) * 5
-            xb = cb[torch.randint(0, K, (Nb,), device=dev, generator=g)] + torch.randn(Nb, D, device=dev, generator=g)
-            rb = torch.softmax(3 * torch.randn(Nb, K, device=dev, generator=g), dim=1)
-            bloop = _mix.VMPLoop(xb, rb, flav, kappa=kappa)
-            bw, bk = time_t1(bloop, 20, 5, 7, lambda: torch.cuda.synchronize(), None, dev)
-            b_ms, bk_ms = float(np.median(bw)) / 20 * 1e3, float(np.median(bk))
-            wordsb = (2 * D + 2 * K) if flav == L.VMP_GMM else (2 * D + 4 * K)
-            extra['t1_n1e7'] = {'ms_per_step': b_ms, 'datapoints_per_sec': Nb / (b_ms * 1e-3), 'kernel_ms': bk_ms,
-                                'algorithmic_GBps': 4.0 * Nb * wordsb / (bk_ms * 1e-3) / 1e9,
-                                'frac_hbm': 4.0 * Nb * wordsb / (bk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                'moved_GBps': 2.0 * Nb * wordsb / (bk_ms * 1e-3) / 1e9,
-                                'valu_frac': t1_flops(Nb, D, K) / (bk_ms * 1e-3) / FP32_PEAK_FLOPS}
-            del bloop, xb, rb
+            ex = PeerExchange(K, D, rank=0, world=1, gather=lambda h: [h])
+            ploop = DistributedVMPLoop(x, r0, flav, kappa=kappa, exchange=ex)
+            pw, _ = time_t1(ploop, args.steps, args.warmup, 7, lambda: torch.cuda.synchronize(), None, dev)
+            p_us = float(np.median(pw)) / args.steps * 1e6
+            assert int(ex.status.item()) == 0
+            del ploop
+            ex.close()
+            plain = dt / args.steps * 1e6
+            extra['t1_forced_dist_1rank'] = {'plain_us_per_step': plain, 'rccl_us_per_step': d_us, 'rccl_overhead_us': d_us - plain,
+                                             'peer_exchange_us_per_step': p_us, 'dist_overhead_us': p_us - plain}
+            del x, r0
             torch.cuda.empty_cache()
-        extra['t2_svae_vmp'] = bench_t2(N, D, K, args.s, 5, 2, dev, dist, world)
-        torch.cuda.empty_cache()
-        if world == 1:
+            if (N, D, K) == (1_000_000, 8, 16):
+                # (b) the cache-defeating size of SURVEY 8d: N=1e7 (x + r = 960 MB >> the 256 MiB Infinity Cache)
+                Nb = 10_000_000
+                g = torch.Generator(device=dev).manual_seed(5)
+                cb = torch.randn(K, D, device=dev, generator=g) * 5
+                xb = cb[torch.randint(0, K, (Nb,), device=dev, generator=g)] + torch.randn(Nb, D, device=dev, generator=g)
+                rb = torch.softmax(3 * torch.randn(Nb, K, device=dev, generator=g), dim=1)
+                bloop = _mix.VMPLoop(xb, rb, flav, kappa=kappa)
+                bw, bk = time_t1(bloop, 20, 5, 7, lambda: torch.cuda.synchronize(), None, dev)
+                b_ms, bk_ms = float(np.median(bw)) / 20 * 1e3, float(np.median(bk))
+                wordsb = (2 * D + 2 * K) if flav == L.VMP_GMM else (2 * D + 4 * K)
+                extra['t1_n1e7'] = {'ms_per_step': b_ms, 'datapoints_per_sec': Nb / (b_ms * 1e-3), 'kernel_ms': bk_ms,
+                                    'algorithmic_GBps': 4.0 * Nb * wordsb / (bk_ms * 1e-3) / 1e9,
+                                    'frac_hbm': 4.0 * Nb * wordsb / (bk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    'moved_GBps': 2.0 * Nb * wordsb / (bk_ms * 1e-3) / 1e9,
+                                    'valu_frac': t1_flops(Nb, D, K) / (bk_ms * 1e-3) / FP32_PEAK_FLOPS}
+                del bloop, xb, rb
+                torch.cuda.empty_cache()
+            extra['t2_svae_vmp'] = bench_t2(N, D, K, args.s, 5, 2, dev, None, 1)
+            torch.cuda.empty_cache()
             extra['t3_svae_train'] = bench_t3(N, D, K, args.s, args.u, 3, 1, dev, None)
             torch.cuda.empty_cache()
             # BASELINE configs[3]-sized model at the reference's minibatch size (Auto: Dy=6, L=8, K=10, U=50)
             extra['t3_minibatch64'] = bench_minibatch(64, 10, 8, 6, args.s, args.u, dev, cpu=not args.no_cpu_baseline)
             torch.cuda.empty_cache()
+        if rank == 0:
+            ms = dt / args.steps * 1e3
+            words = (2 * D + 2 * K) if flav == L.VMP_GMM else (2 * D + 4 * K)
+            alg_bytes = 4.0 * n_loc * words                  # T1 algorithmic bytes per step (this GPU's rows)
+            min_bytes = alg_bytes / 2                        # what the fused pass has to move: read x, write r (u)
+            achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+            traffic, traffic_src = None, None
+            tf = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % args.workload)
+            if os.path.exists(tf) and (n_loc, D, K) == (1_000_000, 8, 16):
+                tj = json.load(open(tf))
+                traffic = tj.get('hbm_bytes_per_launch')
+                traffic_src = 'committed rocprofv3 PMC summary (%s), not re-measured by this run' % tj.get('source', tf)
+            out = dict(common)
+            out.update({
+                'metric': 'vmp_step_datapoints_per_sec', 'value': n_job / (dt / args.steps), 'reps': len(walls), 'ms_per_step': ms,
+                'ms_per_step_min': min(walls) / args.steps * 1e3, 'ms_per_step_max': max(walls) / args.steps * 1e3,
+                'steps_per_sec': args.steps / dt,
+                'config': {'workload': 'T1 %s VMP step (M-step + E-step), synthetic GMM N=%d %s, D=%d, K=%d'
+                                       % (args.workload, N, 'per GPU' if args.scaling == 'weak' else 'in total (rows split over the ranks)', D, K),
+                           'N_per_gpu': n_loc, 'N_job': n_job, 'D': D, 'K': K,
+                           'parallelism': 'dp%d (rows sharded, 1 exchange of K-sized stats per step: %s)' % (world, args.exchange if world > 1 else 'none'),
+                           'timing': 'median over `reps` timed regions of `steps` steps each'},
+                # `achieved`/`frac` follow the contract: ALGORITHMIC bytes (4N(2D+2K), the un-fused M-pass +
+                # E-pass) / kernel time.  The fused pass MOVES half of that (x read once, r written once): `moved_*` is the
+                # physical HBM rate, `valu_frac` the fp32 arithmetic rate.
+                'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                             'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+                             'kernel': 'pass_xdl_kernel / pass_kernel <E-step + fused moments>', 'kernel_ms': kern_ms,
+                             'algorithmic_bytes_per_launch': alg_bytes,
+                             'moved_bytes_min_per_launch': min_bytes,
+                             'moved_GBps': min_bytes / (kern_ms * 1e-3) / 1e9,
+                             'moved_frac': min_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             'flops_per_launch': t1_flops(n_loc, D, K),
+                             'valu_frac': t1_flops(n_loc, D, K) / (kern_ms * 1e-3) / FP32_PEAK_FLOPS},
+            })
+            if world == 1 and not args.no_cpu_baseline:
+                out['cpu_baseline'] = cpu_baseline(x_h, r0_h, args.workload)
+                out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
+    else:
+        # ---- t2 / t3: millisecond-scale steps; `steps` capped so that the default flags finish in minutes
+        n_loc, n_job = rows_for(args.scaling)
+        steps = min(args.steps, 20)
+        warm = min(args.warmup, 3)
+        S, U = args.s, args.u
+        if args.workload == 't2':
+            res = bench_t2(n_loc, D, K, S, steps, warm, dev, dist, world)
+            ms = res['ms_per_step']
+            bwd_bytes = 4.0 * n_loc * (2.0 * K * S * D + 4 * D + 3 * K)
+            roof = {'bound': 'hbm', 'achieved': res['bwd_GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': res['bwd_frac_hbm'],
+                    'traffic': None, 'kernel': 'svae_estep_bwd_ring_kernel (+ partial reduce)', 'kernel_ms': res['bwd_kernel_ms'],
+                    'algorithmic_bytes_per_launch': bwd_bytes, 'fwd_kernel_ms': res['fwd_kernel_ms'], 'fwd_frac': res['fwd_frac_hbm']}
+            metric, wl = 'svae_vmp_step_datapoints_per_sec', 'T2 svae-vmp step (fused E-step fwd + bwd, sub-sampling, M-step, CVI), L=%d, K=%d, S=%d' % (D, K, S)
+            extra['t2'] = res
+        else:
+            res = bench_t3(n_loc, D, K, S, U, steps, warm, dev, None)
+            ms = res['ms_per_step']
+            k_ms, useful = dec_bwd_side_measurement(n_loc, K, S, D, U, dev)
+            tf_s = useful / (k_ms * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'achieved': 6.0 * tf_s, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': 6.0 * tf_s / 2500.0, 'traffic': None,
+                    'kernel': 'dec_bwd_kernel (bf16 x3 split: 6 MFMA products per fp32 product)', 'kernel_ms': k_ms,
+                    'useful_fp32_TFLOPs': tf_s, 'issued_over_useful': 6.0,
+                    'note': 'timed on min(N, 262144) rows and scaled to N (the kernel is linear in rows)'}
+            metric, wl = 'svae_train_step_datapoints_per_sec', 'T3 svae training step (experiments.py:196-267), L=Dy=%d, K=%d, S=%d, U=%d' % (D, K, S, U)
+            extra['t3'] = res
+        if dist is not None:
+            tt = torch.tensor([ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ms = tt.item()
+        if rank == 0:
+            out = dict(common)
+            out.update({'metric': metric, 'value': n_job / (ms * 1e-3), 'steps': steps, 'warmup': warm, 'ms_per_step': ms,
+                        'config': {'workload': wl + ', N=%d %s' % (N, 'per GPU' if args.scaling == 'weak' else 'in total'),
+                                   'N_per_gpu': n_loc, 'N_job': n_job, 'D': D, 'K': K,
+                                   'parallelism': 'dp%d (rows sharded, 1 packed all-reduce of moments + gradients per step)' % world},
+                        'roofline': roof})
 
     if rank == 0:
-        ms = dt / args.steps * 1e3
-        words = (2 * D + 2 * K) if flav == L.VMP_GMM else (2 * D + 4 * K)
-        alg_bytes = 4.0 * N * words                      # T1 algorithmic bytes per step (per GPU)
-        min_bytes = alg_bytes / 2                        # what the fused pass has to move: read x, write r (u)
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % args.workload)
-        if os.path.exists(tf) and (N, D, K) == (1_000_000, 8, 16):
-            tj = json.load(open(tf))
-            traffic = tj.get('hbm_bytes_per_launch')
-            traffic_src = 'committed rocprofv3 PMC summary (%s), not re-measured by this run' % tj.get('source', tf)
-        out = {
-            'metric': 'vmp_step_datapoints_per_sec', 'value': N * world / (dt / args.steps), 'unit': 'datapoints/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'reps': len(walls), 'ms_per_step': ms,
-            'ms_per_step_min': min(walls) / args.steps * 1e3, 'ms_per_step_max': max(walls) / args.steps * 1e3,
-            'steps_per_sec': args.steps / dt, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'T1 %s VMP step (M-step + E-step), synthetic GMM N=%d per GPU, D=%d, K=%d'
-                                   % (args.workload, N, D, K), 'N_per_gpu': N, 'D': D, 'K': K,
-                       'parallelism': 'dp%d (rows sharded, 1 all-reduce of K-sized stats per step)' % world,
-                       'timing': 'median over `reps` timed regions of `steps` steps each'},
-            # `achieved`/`frac` follow the contract: ALGORITHMIC bytes (4N(2D+2K), the un-fused M-pass +
-            # E-pass) / kernel time.  The fused pass MOVES half of that (x read once, r written once): `moved_*` is the
-            # physical HBM rate, `valu_frac` the fp32 arithmetic rate - the kernel is instruction-issue bound.
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'kernel': 'pass_kernel<E-step + fused moments>', 'kernel_ms': kern_ms,
-                         'algorithmic_bytes_per_launch': alg_bytes,
-                         'moved_bytes_min_per_launch': min_bytes,
-                         'moved_GBps': min_bytes / (kern_ms * 1e-3) / 1e9,
-                         'moved_frac': min_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         'flops_per_launch': t1_flops(N, D, K),
-                         'valu_frac': t1_flops(N, D, K) / (kern_ms * 1e-3) / FP32_PEAK_FLOPS},
-        }
         if extra:
             out['extra'] = extra
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(x_h, r0_h, args.workload)
-            out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist is not None:
         dist.destroy_process_group()

@@ -293,6 +293,19 @@ int    vmp_mix_mahalanobis(const float* x, const float* m, const float* P, const
                            const uint8_t* miss_mask, int64_t N, int D, int K, float* out, void* stream);
 int    vmp_student_t_logprob(const float* y, const float* mu, const float* W, const float* cst, const float* nu,
                              int64_t N, int K, int S, int D, float* out, void* stream);
+/* Adjoints of the two per-sample densities above - what TF's autodiff does through gaussian.py:74-105 and student_t.py:7-39
+ * when the reference differentiates compute_elbo (svae.py:236-243, 291-300; experiments.py:232):
+ *   vmp_gauss_logprob_nat_per_samp_bwd: g (N,K,S) upstream -> gx (N,K,S,D), geta1 (N,K,D), geta2 (N,K,D,D) (symmetric:
+ *       sum_s g_s (x_s x_s^T - E[x x^T]), the exponential-family identity; eta2 is read symmetrised as in the forward);
+ *   vmp_student_t_logprob_bwd: gy (N,K,S,D) and per-block partial sums over (n,s) of the gradients w.r.t. the K-sized
+ *       (mu_k (D) | W_k lower packed (D(D+1)/2) | cst_k): partials (vmp_student_t_bwd_blocks(N,S), K, D + D(D+1)/2 + 1),
+ *       summed over the first axis by the caller; nu is treated as a constant (the reference's DoF is not trainable,
+ *       experiments.py:163-165).                                                                                       */
+int    vmp_gauss_logprob_nat_per_samp_bwd(const float* x, const float* eta1, const float* eta2, const float* g, int64_t N,
+                                          int K, int S, int D, float* gx, float* geta1, float* geta2, void* stream);
+int    vmp_student_t_bwd_blocks(int64_t N, int S);
+int    vmp_student_t_logprob_bwd(const float* y, const float* mu, const float* W, const float* nu, const float* g, int64_t N,
+                                 int K, int S, int D, float* gy, float* partials, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Evaluation metrics: the (N,K,S,Dy)-sized part of losses.weighted_mse (losses.py:9-38) and

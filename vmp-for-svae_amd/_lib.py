@@ -44,6 +44,9 @@ _SIGNATURES = {
     'vmp_gauss_logprob_nat': (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _P, _P]),
     'vmp_mix_mahalanobis': (_c.c_int, [_P] * 6 + [_c.c_int64, _c.c_int, _c.c_int, _P, _P]),
     'vmp_student_t_logprob': (_c.c_int, [_P, _P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
+    'vmp_gauss_logprob_nat_per_samp_bwd': (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P]),
+    'vmp_student_t_bwd_blocks': (_c.c_int, [_c.c_int64, _c.c_int]),
+    'vmp_student_t_logprob_bwd': (_c.c_int, [_P, _P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
     'vmp_eval_cell_metrics': (_c.c_int, [_P, _P, _P, _P, _c.c_int, _P, _c.c_int, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
     'vmp_diag_gauss_loglike_fwd': (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _P, _P]),
     'vmp_diag_gauss_loglike_bwd': (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _P, _P, _P]),

@@ -650,7 +650,9 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
 // the responsibilities straight from the softmax registers.
 // Measured against the packed-fp32 kernel above on one box: see DESIGN.md section 6.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int AIS = 20;       // u32 per row of the bf16 A image: x_h(4) x_m(4) x_l(4) ones(4) zeros(4); 80 B: 16 rows hit 16 bank groups
+// u32 per row of the bf16 A image: x_h(4) x_m(4) x_l(4) ones(4) zeros(4) | (x_h|x_h)(4) (x_m|x_h)(4) (x_l|x_m)(4) of the
+// coordinates 0..3 (operands of the one-MFMA tiles, see below) | pad; 144 B = 9 16-byte slots: 16 rows hit 16 bank groups
+constexpr int AIS = 36;
 template <int D> constexpr int xdl_wave_floats() { return Geo<D>::XROWS * LS + TR * AIS; }
 
 template <int D, int FLAV, bool STATS>
@@ -706,7 +708,9 @@ __global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
     }
 
     // ---- B operands of the y GEMM: lane (k = i16, g = kk) holds the terms of W_k its lane group multiplies (see the header)
-    u32x4 B1[D], B2[D];
+    constexpr int NS = D < 4 ? D : 4;                        // output coordinates done by ONE MFMA (contraction over x'_0..3)
+    constexpr int NB = D > 4 ? D - 4 : 0;                    // output coordinates 4.. : two MFMAs (contraction over x'_0..7)
+    u32x4 Bsm[NS], B1[NB > 0 ? NB : 1], B2[NB > 0 ? NB : 1];
     v2f pch;
     float pua, pub;
     {
@@ -734,7 +738,8 @@ __global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
             for (int j = 0; j <= i; ++j) bi -= (double)raw[D + i * (i + 1) / 2 + j] * ((double)raw[j] - (double)pv[j]);
             unsigned tb[3];
             split_bf16<3>(v2f{(float)bi, 0.f}, tb);          // low halves: b_h, b_m, b_l
-            unsigned w1[4] = {0u, 0u, 0u, 0u}, w2[4] = {0u, 0u, 0u, 0u};
+            const unsigned bias0 = (tb[0] & 0xffffu) | (tb[1] << 16), bias1 = tb[2] & 0xffffu;   // slots (b_h, b_m), (b_l, 0)
+            unsigned th[4] = {0u, 0u, 0u, 0u}, tm[4] = {0u, 0u, 0u, 0u}, tl[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int q = 0; q < DP; ++q) {
                 const int j0 = 2 * q, j1 = 2 * q + 1;
@@ -742,22 +747,31 @@ __global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
                 const float wb = (j1 <= i && j1 < D) ? raw[D + i * (i + 1) / 2 + (j1 <= i ? j1 : 0)] : 0.f;
                 unsigned t3[3];
                 split_bf16<3>(v2f{wa, wb}, t3);
-                w1[q] = kk == 1 ? t3[1] : (kk == 3 ? t3[2] : t3[0]);       // W_h | W_m | W_h | W_l
-                w2[q] = kk == 0 ? t3[0] : (kk == 1 ? t3[1] : 0u);          // W_h | W_m | bias | 0
+                th[q] = t3[0]; tm[q] = t3[1]; tl[q] = t3[2];
             }
-            if (kk == 2) {
-                w2[0] = (tb[0] & 0xffffu) | (tb[1] << 16);                 // slots 0,1: b_h, b_m
-                w2[1] = tb[2] & 0xffffu;                                   // slot 2: b_l
-                w2[2] = 0u; w2[3] = 0u;
+            if (i < NS) {
+                // (W_h|W_m), (W_h|W_l), (W_h|W_m), bias  over the coordinate pairs (0,1), (2,3)
+                const u32x4 w = kk == 0 ? u32x4{th[0], th[1], tm[0], tm[1]}
+                              : kk == 1 ? u32x4{th[0], th[1], tl[0], tl[1]}
+                              : kk == 2 ? u32x4{th[0], th[1], tm[0], tm[1]}
+                                        : u32x4{bias0, bias1, 0u, 0u};
+                Bsm[i] = on ? w : u32x4{0u, 0u, 0u, 0u};
+            } else {
+                const int ib = i - 4;
+                // MFMA 1: W_h | W_m | W_h | W_l      MFMA 2: W_h | W_m | bias | 0
+                const u32x4 w1 = kk == 1 ? u32x4{tm[0], tm[1], tm[2], tm[3]} : kk == 3 ? u32x4{tl[0], tl[1], tl[2], tl[3]} : u32x4{th[0], th[1], th[2], th[3]};
+                const u32x4 w2 = kk == 0 ? u32x4{th[0], th[1], th[2], th[3]} : kk == 1 ? u32x4{tm[0], tm[1], tm[2], tm[3]}
+                               : kk == 2 ? u32x4{bias0, bias1, 0u, 0u} : u32x4{0u, 0u, 0u, 0u};
+                B1[ib < 0 ? 0 : ib] = on ? w1 : u32x4{0u, 0u, 0u, 0u};
+                B2[ib < 0 ? 0 : ib] = on ? w2 : u32x4{0u, 0u, 0u, 0u};
             }
-            B1[i] = on ? u32x4{w1[0], w1[1], w1[2], w1[3]} : u32x4{0u, 0u, 0u, 0u};
-            B2[i] = on ? u32x4{w2[0], w2[1], w2[2], w2[3]} : u32x4{0u, 0u, 0u, 0u};
         }
     }
     // A operands: lane (m = i16, g = kk) reads term T[g] of tile row rho(m) = 4 (m & 3) + (m >> 2)
     const int rho = 4 * (i16 & 3) + (i16 >> 2);
     const int offA1 = rho * AIS + (kk == 2 ? 4 : 0);                       // x_h | x_h | x_m | x_h
     const int offA2 = rho * AIS + (kk == 0 ? 8 : (kk == 1 ? 4 : (kk == 2 ? 12 : 16)));   // x_l | x_m | ones | zeros
+    const int offA3 = rho * AIS + (kk == 3 ? 12 : 20 + 4 * kk);                           // (x_h|x_h) | (x_m|x_h) | (x_l|x_m) | ones
 
     // ---- moment GEMM B-operand addressing: lane = (feature column i16, k-slot group kk)
     int offA[FT], offB[FT];
@@ -777,11 +791,13 @@ __global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
     }
 
     f32x4 acc[KT][FT], acs[KT][FT];
-    f32x4 nacc[KT], nacs[KT];
     double dacc[KT][FT][4];
     double dn[KT][4];
-    nacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    nacs[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // SMM: N_k = sum_n r_nk (the moment GEMM carries w = r u).  The lane owns component i16, so its rows' r are summed on the
+    // VALU (fp32 per tile, fp64 across tiles) and brought into the accumulator layout once, after the last row - instead of
+    // a second split of r and three more MFMAs per body.
+    float nsum = 0.f;
+    double dnl = 0.0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) dn[0][c] = 0.0;
 #pragma unroll
@@ -812,6 +828,9 @@ __global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
             *reinterpret_cast<u32x4*>(ai + lane * AIS) = u32x4{th[0], th[1], th[2], th[3]};
             *reinterpret_cast<u32x4*>(ai + lane * AIS + 4) = u32x4{tm[0], tm[1], tm[2], tm[3]};
             *reinterpret_cast<u32x4*>(ai + lane * AIS + 8) = u32x4{tl[0], tl[1], tl[2], tl[3]};
+            *reinterpret_cast<u32x4*>(ai + lane * AIS + 20) = u32x4{th[0], th[1], th[0], th[1]};
+            *reinterpret_cast<u32x4*>(ai + lane * AIS + 24) = u32x4{tm[0], tm[1], th[0], th[1]};
+            *reinterpret_cast<u32x4*>(ai + lane * AIS + 28) = u32x4{tl[0], tl[1], tm[0], tm[1]};
             const long long n2 = row0 + TR + lane;
 #pragma unroll
             for (int j = 0; j < D; ++j) xr[j] = 0.f;
@@ -822,17 +841,21 @@ __global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
         const long long tbase = (row0 + kk) * K + i16;       // this lane's element of r/u for (row0 + kk, component i16)
 #pragma unroll 1
         for (int n0 = 0; n0 < trows; n0 += 32) {
-            unsigned As[3][4], Rs[3][4], Bs[FT][3][4];       // [term h/m/l][k-slot pair: (sub-tile jj, v pair)]
             const bool full = (K == 16) && (n0 + 32 <= trows);
-            auto subtile = [&](auto full_c, auto jj_c) __attribute__((always_inline)) {
-                constexpr bool FULL = decltype(full_c)::value;
+            // One instance of the whole body (two sub-tiles + the moment MFMAs) per path: the operand registers of the MFMAs
+            // are written and consumed inside the same instance, so no register tuple has to be re-assembled where the two
+            // paths would merge (the first version paid 64 v_mov per body for that).
+            auto body = [&](auto full_c) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(full_c)::value;
+            unsigned As[3][4], Bs[FT][3][4];                 // [term h/m/l][k-slot pair: (sub-tile jj, v pair)]
+            auto subtile = [&](auto jj_c) __attribute__((always_inline)) {
                 constexpr int jj = decltype(jj_c)::value;
                 const int n16 = n0 + 16 * jj;                // first tile row of this 16-row sub-tile
                 if (!FULL && n16 >= trows) {                 // wave-uniform: nothing left
                     if constexpr (STATS) {
 #pragma unroll
                         for (int t = 0; t < 3; ++t) {
-                            As[t][2 * jj] = 0u; As[t][2 * jj + 1] = 0u; Rs[t][2 * jj] = 0u; Rs[t][2 * jj + 1] = 0u;
+                            As[t][2 * jj] = 0u; As[t][2 * jj + 1] = 0u;
 #pragma unroll
                             for (int ft = 0; ft < FT; ++ft) { Bs[ft][t][2 * jj] = 0u; Bs[ft][t][2 * jj + 1] = 0u; }
                         }
@@ -840,15 +863,23 @@ __global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
                     return;
                 }
                 // ---- y = W x' + b on the XDL pipe, q = |y|^2 in the accumulator registers
-                const bf16x8 a1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ai + n16 * AIS + offA1));
-                const bf16x8 a2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ai + n16 * AIS + offA2));
                 f32x4 y[D];
+                {
+                    const bf16x8 a3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ai + n16 * AIS + offA3));
 #pragma unroll
-                for (int i = 0; i < D; ++i)
-                    y[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, __builtin_bit_cast(bf16x8, B1[i]), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    for (int i = 0; i < NS; ++i)
+                        y[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, __builtin_bit_cast(bf16x8, Bsm[i]), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                }
+                if constexpr (NB > 0) {
+                    const bf16x8 a1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ai + n16 * AIS + offA1));
+                    const bf16x8 a2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ai + n16 * AIS + offA2));
 #pragma unroll
-                for (int i = 0; i < D; ++i)
-                    y[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, __builtin_bit_cast(bf16x8, B2[i]), y[i], 0, 0, 0);
+                    for (int i = 0; i < NB; ++i)
+                        y[4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, __builtin_bit_cast(bf16x8, B1[i]), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < NB; ++i)
+                        y[4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, __builtin_bit_cast(bf16x8, B2[i]), y[4 + i], 0, 0, 0);
+                }
                 f32x4 q4 = y[0] * y[0], q4b = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int i = 1; i < D; ++i) {
@@ -903,12 +934,8 @@ __global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
                         split_bf16<MOM_TERMS>(w[h], t3);
 #pragma unroll
                         for (int t = 0; t < 3; ++t) As[t][2 * jj + h] = t3[t];
-                        if constexpr (SMM) {
-                            split_bf16<MOM_TERMS>(rr[h], t3);
-#pragma unroll
-                            for (int t = 0; t < 3; ++t) Rs[t][2 * jj + h] = t3[t];
-                        }
                     }
+                    if constexpr (SMM) nsum += (rr[0].x + rr[0].y) + (rr[1].x + rr[1].y);
 #pragma unroll
                     for (int ft = 0; ft < FT; ++ft) {
                         const f32x4 fa = *reinterpret_cast<const f32x4*>(&xl[offA[ft] + n16]);
@@ -924,13 +951,8 @@ __global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
                 }
             };
             using std::integral_constant;
-            if (full) {
-                subtile(integral_constant<bool, true>{}, integral_constant<int, 0>{});
-                subtile(integral_constant<bool, true>{}, integral_constant<int, 1>{});
-            } else {
-                subtile(integral_constant<bool, false>{}, integral_constant<int, 0>{});
-                subtile(integral_constant<bool, false>{}, integral_constant<int, 1>{});
-            }
+            subtile(integral_constant<int, 0>{});
+            subtile(integral_constant<int, 1>{});
 
             if constexpr (STATS) {
                 bf16x8 b[FT][3];
@@ -939,12 +961,9 @@ __global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
 #pragma unroll
                     for (int t = 0; t < 3; ++t)
                         b[ft][t] = __builtin_bit_cast(bf16x8, u32x4{Bs[ft][t][0], Bs[ft][t][1], Bs[ft][t][2], Bs[ft][t][3]});
-                bf16x8 av[3], rv[3];
+                bf16x8 av[3];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    av[t] = __builtin_bit_cast(bf16x8, u32x4{As[t][0], As[t][1], As[t][2], As[t][3]});
-                    if constexpr (SMM) rv[t] = __builtin_bit_cast(bf16x8, u32x4{Rs[t][0], Rs[t][1], Rs[t][2], Rs[t][3]});
-                }
+                for (int t = 0; t < 3; ++t) av[t] = __builtin_bit_cast(bf16x8, u32x4{As[t][0], As[t][1], As[t][2], As[t][3]});
                 // h h products and the five corrections in separate fp32 accumulators (see pass_kernel)
 #pragma unroll
                 for (int ta = 0; ta < MOM_TERMS; ++ta) {
@@ -956,23 +975,20 @@ __global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
                             else acs[0][ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ta], b[ft][tb], acs[0][ft], 0, 0, 0);
                         }
                     }
-                    if constexpr (SMM) {
-                        if (ta == 0) nacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rv[ta], b[0][0], nacc[0], 0, 0, 0);
-                        else nacs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rv[ta], b[0][0], nacs[0], 0, 0, 0);
-                    }
                 }
             }
+            };   // body
+            if (full) body(std::integral_constant<bool, true>{});
+            else body(std::integral_constant<bool, false>{});
         }
 
         if constexpr (STATS) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                if constexpr (SMM) dn[0][c] += (double)nacc[0][c] + (double)nacs[0][c];
 #pragma unroll
                 for (int ft = 0; ft < FT; ++ft) dacc[0][ft][c] += (double)acc[0][ft][c] + (double)acs[0][ft][c];
             }
-            nacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            nacs[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (SMM) { dnl += (double)nsum; nsum = 0.f; }
 #pragma unroll
             for (int ft = 0; ft < FT; ++ft) { acc[0][ft] = f32x4{0.f, 0.f, 0.f, 0.f}; acs[0][ft] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         }
@@ -980,6 +996,22 @@ __global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
     }
 
     PASS_TS(2);
+    if constexpr (STATS && SMM) {
+        // N_k into the accumulator layout the epilogue reads: lane (g, column 0), register c <-> component 4 g + c
+        double tot = dnl;
+        {
+            int lo = __double2loint(tot), hi = __double2hiint(tot);
+            tot += __hiloint2double(__shfl_xor(hi, 32), __shfl_xor(lo, 32));
+            lo = __double2loint(tot); hi = __double2hiint(tot);
+            tot += __hiloint2double(__shfl_xor(hi, 16), __shfl_xor(lo, 16));          // (kk0 + kk2) + (kk1 + kk3): same on every lane
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int src = 4 * kk + c;                                               // a lane whose i16 is component 4 kk + c
+            const int lo = __shfl(__double2loint(tot), src), hi = __shfl(__double2hiint(tot), src);
+            dn[0][c] = __hiloint2double(hi, lo);
+        }
+    }
     if constexpr (STATS) pass_epilogue<D, 1, FLAV>(a, smem, dacc, dn, lane, wave, nw);
 }
 

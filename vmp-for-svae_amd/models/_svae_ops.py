@@ -175,38 +175,90 @@ def gauss_logprob_nat(x, eta1, eta2, weights=None):
     return out
 
 
+class GaussLogprobPerSampFn(torch.autograd.Function):
+    """gaussian.log_probability_nat_per_samp (reference gaussian.py:74-105): (x (N,K,S,D), eta1 (N,K,D), eta2 (N,K,D,D)) ->
+    (N,K,S), differentiable in all three (vmp_gauss_logprob_nat_per_samp / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, eta1, eta2):
+        x = _c(x, 'x_samps')
+        if x.dim() != 4:
+            raise AssertionError('x_samps must be of shape (N,K,S,D)')
+        N, K, S, D = x.shape
+        eta1 = _c(eta1, 'eta1', (N, K, D))
+        eta2 = _c(eta2, 'eta2', (N, K, D, D))
+        out = torch.empty(N, K, S, dtype=torch.float32, device=x.device)
+        L.check(L.lib().vmp_gauss_logprob_nat_per_samp(L.ptr(x), L.ptr(eta1), L.ptr(eta2), N, K, S, D, L.ptr(out),
+                                                       L.stream()), 'vmp_gauss_logprob_nat_per_samp')
+        ctx.save_for_backward(x, eta1, eta2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, eta1, eta2 = ctx.saved_tensors
+        N, K, S, D = x.shape
+        g = g.contiguous().float()
+        gx, ge1, ge2 = torch.empty_like(x), torch.empty_like(eta1), torch.empty_like(eta2)
+        L.check(L.lib().vmp_gauss_logprob_nat_per_samp_bwd(L.ptr(x), L.ptr(eta1), L.ptr(eta2), L.ptr(g), N, K, S, D, L.ptr(gx),
+                                                           L.ptr(ge1), L.ptr(ge2), L.stream()), 'vmp_gauss_logprob_nat_per_samp_bwd')
+        return gx, ge1, ge2
+
+
 def gauss_logprob_per_samp(x_samps, eta1, eta2):
-    """gaussian.log_probability_nat_per_samp (reference gaussian.py:74-105): (N,K,S).  Forward only."""
-    x = _c(x_samps.detach(), 'x_samps')
-    N, K, S, D = x.shape
-    eta1 = _c(eta1.detach(), 'eta1', (N, K, D))
-    eta2 = _c(eta2.detach(), 'eta2', (N, K, D, D))
-    out = torch.empty(N, K, S, dtype=torch.float32, device=x.device)
-    L.check(L.lib().vmp_gauss_logprob_nat_per_samp(L.ptr(x), L.ptr(eta1), L.ptr(eta2), N, K, S, D, L.ptr(out),
-                                                   L.stream()), 'vmp_gauss_logprob_nat_per_samp')
-    return out
+    """gaussian.log_probability_nat_per_samp (reference gaussian.py:74-105): (N,K,S); differentiable."""
+    return GaussLogprobPerSampFn.apply(x_samps, eta1, eta2)
+
+
+class StudentTLogprobFn(torch.autograd.Function):
+    """(y (N,K,S,D), mu (K,D), W (K,D,D) lower with W^T W = Sigma^-1, cst (K), v (K)) -> cst_k - 1/2 (v_k + D)
+    log1p(|W_k (y - mu_k)|^2 / v_k) (N,K,S); gradients to y, mu, W, cst (v: constant, as the reference's DoF)."""
+
+    @staticmethod
+    def forward(ctx, y, mu, W, cst, v):
+        y = _c(y, 'y')
+        N, K, S, D = y.shape
+        mu, W, cst, v = _c(mu, 'mu', (K, D)), _c(W, 'W', (K, D, D)), _c(cst, 'cst', (K,)), _c(v, 'v', (K,))
+        out = torch.empty(N, K, S, dtype=torch.float32, device=y.device)
+        L.check(L.lib().vmp_student_t_logprob(L.ptr(y), L.ptr(mu), L.ptr(W), L.ptr(cst), L.ptr(v), N, K, S, D, L.ptr(out),
+                                              L.stream()), 'vmp_student_t_logprob')
+        ctx.save_for_backward(y, mu, W, v)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y, mu, W, v = ctx.saved_tensors
+        N, K, S, D = y.shape
+        g = g.contiguous().float()
+        gy = torch.empty_like(y)
+        nb = L.lib().vmp_student_t_bwd_blocks(N, S)
+        TRI = D * (D + 1) // 2
+        part = torch.empty(nb, K, D + TRI + 1, dtype=torch.float32, device=y.device)
+        L.check(L.lib().vmp_student_t_logprob_bwd(L.ptr(y), L.ptr(mu), L.ptr(W), L.ptr(v), L.ptr(g), N, K, S, D, L.ptr(gy),
+                                                  L.ptr(part), L.stream()), 'vmp_student_t_logprob_bwd')
+        tot = part.double().sum(0)                                   # fixed order over the blocks, fp64
+        gmu = tot[:, :D].float()
+        gW = torch.zeros(K, D, D, dtype=torch.float32, device=y.device)
+        ii, jj = torch.tril_indices(D, D, device=y.device)
+        gW[:, ii, jj] = tot[:, D:D + TRI].float()
+        return gy, gmu, gW, tot[:, D + TRI].float(), None
 
 
 def student_t_logprob(y, mu, sigma, v):
     """student_t.log_probability_per_samp (reference student_t.py:7-39,59-61): (N,K,S).  The K scale matrices are
-    factorised once (K-sized, torch) instead of being tiled to (N,K,S,D,D).  Forward only."""
+    factorised once (K-sized, torch fp64, differentiable) instead of being tiled to (N,K,S,D,D); gradients reach y, mu and
+    sigma through vmp_student_t_logprob_bwd."""
     import math
-    y = _c(y.detach(), 'y')
     N, K, S, D = y.shape
     if tuple(mu.shape) != (K, D) or tuple(sigma.shape) != (K, D, D) or tuple(v.shape) != (K,):
         raise AssertionError('shape mismatch')
-    sig = sigma.detach().double()
+    sig = sigma.double()
     Lc = torch.linalg.cholesky(0.5 * (sig + sig.transpose(-1, -2)))
     eye = torch.eye(D, dtype=Lc.dtype, device=Lc.device).expand_as(Lc)
     W = torch.linalg.solve_triangular(Lc, eye, upper=False)
     vd = v.detach().double()
     cst = (torch.lgamma(0.5 * (vd + D)) - torch.lgamma(0.5 * vd) - 0.5 * D * torch.log(math.pi * vd)
            - torch.log(torch.diagonal(Lc, dim1=-2, dim2=-1)).sum(-1))
-    out = torch.empty(N, K, S, dtype=torch.float32, device=y.device)
-    L.check(L.lib().vmp_student_t_logprob(L.ptr(y), L.ptr(_c(mu.detach().float(), 'mu')), L.ptr(W.float().contiguous()),
-                                          L.ptr(cst.float().contiguous()), L.ptr(_c(v.detach().float(), 'v')), N, K, S, D,
-                                          L.ptr(out), L.stream()), 'vmp_student_t_logprob')
-    return out
+    return StudentTLogprobFn.apply(y, mu.float(), W.float().contiguous(), cst.float().contiguous(), v.detach().float())
 
 
 DECODER_PARAM_NAMES = ('layer_0/kernel', 'layer_0/bias', 'layer_1/kernel', 'layer_1/bias', 'gaussian_output/kernel',

@@ -95,12 +95,12 @@ class PhiTilde(object):
         (and a Student-t theta) through the fused backward kernel.  Backward is linear in the upstream gradients, so the
         gradients of this call (upstream dT') and of the original e_step call (upstream dx, dlog_z) add up to exactly
         what the one-pass form e_step(theta=theta) delivers."""
-        if self._noise is None:
-            raise L.VmpError('compute_elbo: this phi_tilde carries the terms of a different theta (e_step(theta=...) was '
-                             'called with another parameter set); re-run e_step with this theta or without one')
-        if x_k_samps is not self._x and not (torch.is_tensor(x_k_samps) and x_k_samps.data_ptr() == self._x.data_ptr()
-                                              and tuple(x_k_samps.shape) == tuple(self._x.shape)):
-            raise L.VmpError('compute_elbo: x_k_samps must be the samples e_step returned together with this phi_tilde')
+        own_x = self._x is not None and (x_k_samps is self._x or (torch.is_tensor(x_k_samps) and x_k_samps.data_ptr() == self._x.data_ptr()
+                                                                  and tuple(x_k_samps.shape) == tuple(self._x.shape)))
+        if self._noise is None or not own_x:
+            # other samples than the E-step's own (or a phi_tilde built for another theta): the reference's literal
+            # formulation (svae.py:229-243 / 288-300) on the stand-alone, differentiable density kernels
+            return _theta_term_literal(theta, self, x_k_samps)
         e1, e2d, e1k, Pk = self._p
         mk, Wk, kap, nu = _theta_pack(theta)
         _, _, Tp = _svae_ops.SvaeEStepFn.apply(e1, e2d, e1k, Pk, self._bias, self._noise, mk, Wk, kap, nu)
@@ -121,6 +121,31 @@ class PhiTilde(object):
 
     def __iter__(self):
         return iter((self[0], self[1]))
+
+
+def _theta_term_literal(theta, phi_tilde, x_k_samps):
+    """mean_s[ log N(x_s; phi~_nk) - log p(x_s, z=k | theta) ] exactly as the reference writes it (svae.py:229-243; SMM:
+    288-300): gaussian.log_probability_nat_per_samp on the materialised phi_tilde, and the same function on the tiled
+    E[theta] (stop_gradient, svae.py:211-214) resp. student_t.log_probability_per_samp - stand-alone HIP kernels with
+    backward kernels (csrc/vmp_density.hip), so gradients reach x_k_samps, phi_tilde and a Student-t theta."""
+    from ..distributions import student_t
+    N, K, S, Ld = x_k_samps.shape
+    x = x_k_samps.contiguous()
+    num = gaussian.log_probability_nat_per_samp(x, phi_tilde[0].squeeze(-1).contiguous(), phi_tilde[1].contiguous())
+    if len(theta) == 4:
+        alpha_nat, mu_k, L_raw, dof = theta
+        mu, sigma = unpack_smm((mu_k, L_raw))
+        den = student_t.log_probability_per_samp(x, mu, sigma, dof)
+        elp = dirichlet.expected_log_pi(dirichlet.natural_to_standard(alpha_nat)).detach()
+    else:
+        beta_k, m_k, C_k, v_k = niw.natural_to_standard(*theta[1:])
+        mu, sigma = niw.expected_values((beta_k, m_k, C_k, v_k))
+        e1t, e2t = gaussian.standard_to_natural(mu, sigma)
+        e1t, e2t = e1t.detach().float(), e2t.detach().float()
+        den = gaussian.log_probability_nat_per_samp(x, e1t.unsqueeze(0).expand(N, K, Ld).contiguous(),
+                                                    e2t.unsqueeze(0).expand(N, K, Ld, Ld).contiguous())
+        elp = dirichlet.expected_log_pi(dirichlet.natural_to_standard(theta[0])).detach()
+    return (num - den - elp.view(1, K, 1)).mean(-1)
 
 
 def _theta_key(theta):
