@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r02_bench.json, produced by `python bench.py` on an MI355X) carries every field of
+"""The committed bench line (profiles/r03_bench.json, produced by `python bench.py` on an MI355X) carries every field of
 the driver's contract, with the roofline arithmetic consistent with DESIGN.md's algorithmic bytes."""
 import json
 import os
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_schema():
-    d = json.load(open(os.path.join(ROOT, 'profiles', 'r02_bench.json')))
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r03_bench.json')))
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
@@ -28,6 +28,24 @@ def test_committed_bench_line_schema():
         assert k in c, k
     assert c['kind'] in ('reference', 'port') and c['unit'] == d['unit']
     assert abs(d['value'] - N * d['n_gpus'] / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    # the one-launch peer exchange costs <= 4 us on top of the single-GPU iteration (round-2 verdict, item 5c)
+    fd = d['extra']['t1_forced_dist_1rank']
+    assert fd['dist_overhead_us'] <= 4.0 and fd['rccl_overhead_us'] > fd['dist_overhead_us']
+    # the traffic figure names the build it was measured on
+    t = json.load(open(os.path.join(ROOT, 'profiles', 'traffic_gmm.json')))
+    assert 'round 3' in t['kernel'] and abs(t['hbm_bytes_per_launch'] - r['traffic']) < 0.02 * r['traffic']
+
+
+def test_other_workload_lines_schema():
+    """bench.py --workload {smm, t2, t3} (C5 / C4 bench commands) produce the same contract fields."""
+    for f in ('r03_bench_smm.json', 'r03_bench_t2.json', 'r03_bench_t3.json'):
+        d = json.loads(open(os.path.join(ROOT, 'profiles', f)).read().strip().splitlines()[-1])
+        for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                  'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+            assert k in d, (f, k)
+        r = d['roofline']
+        assert r['bound'] in ('hbm', 'mfma') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+        assert abs(d['value'] - d['config']['N_job'] / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
 
 
 def test_gpus_flag_is_not_ignored():

@@ -117,6 +117,9 @@ __device__ __forceinline__ v2f row16_sum2(v2f v) {
 }
 
 constexpr int MOM_TERMS = 3;
+#ifndef VMP_MOM_FLUSH
+#define VMP_MOM_FLUSH 2       // tiles of 64 rows between two fp32 -> fp64 flushes of the moment accumulators (both pass kernels)
+#endif
 
 __device__ __forceinline__ double readlane_d(double v, int src_lane) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -608,18 +611,21 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
         }
 
         if constexpr (STATS) {
+            // fp32 accumulators -> fp64 every VMP_MOM_FLUSH-th tile and after the wave's last tile (as pass_xdl_kernel)
+            if (((row0 - lo) / TR) % VMP_MOM_FLUSH == VMP_MOM_FLUSH - 1 || row0 + TR >= hi) {
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
+                for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if constexpr (SMM) dn[kt][c] += (double)nacc[kt][c] + (double)nacs[kt][c];
+                    for (int c = 0; c < 4; ++c) {
+                        if constexpr (SMM) dn[kt][c] += (double)nacc[kt][c] + (double)nacs[kt][c];
 #pragma unroll
-                    for (int ft = 0; ft < FT; ++ft) dacc[kt][ft][c] += (double)acc[kt][ft][c] + (double)acs[kt][ft][c];
+                        for (int ft = 0; ft < FT; ++ft) dacc[kt][ft][c] += (double)acc[kt][ft][c] + (double)acs[kt][ft][c];
+                    }
+                    nacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    nacs[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ft = 0; ft < FT; ++ft) { acc[kt][ft] = f32x4{0.f, 0.f, 0.f, 0.f}; acs[kt][ft] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                 }
-                nacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                nacs[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ft = 0; ft < FT; ++ft) { acc[kt][ft] = f32x4{0.f, 0.f, 0.f, 0.f}; acs[kt][ft] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -653,6 +659,7 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
 // u32 per row of the bf16 A image: x_h(4) x_m(4) x_l(4) ones(4) zeros(4) | (x_h|x_h)(4) (x_m|x_h)(4) (x_l|x_m)(4) of the
 // coordinates 0..3 (operands of the one-MFMA tiles, see below) | pad; 144 B = 9 16-byte slots: 16 rows hit 16 bank groups
 constexpr int AIS = 36;
+
 template <int D> constexpr int xdl_wave_floats() { return Geo<D>::XROWS * LS + TR * AIS; }
 
 template <int D, int FLAV, bool STATS>
@@ -983,14 +990,18 @@ __global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
         }
 
         if constexpr (STATS) {
+            // fp32 accumulators -> fp64 every VMP_MOM_FLUSH-th tile (default 2 = 128 rows; the fp64 conversions and additions run at a fraction of
+            // the fp32 rate: 48 of them per tile were ~5 % of the kernel) and after the wave's last tile
+            if (((row0 - lo) / TR) % VMP_MOM_FLUSH == VMP_MOM_FLUSH - 1 || row0 + TR >= hi) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < 4; ++c) {
 #pragma unroll
-                for (int ft = 0; ft < FT; ++ft) dacc[0][ft][c] += (double)acc[0][ft][c] + (double)acs[0][ft][c];
+                    for (int ft = 0; ft < FT; ++ft) dacc[0][ft][c] += (double)acc[0][ft][c] + (double)acs[0][ft][c];
+                }
+                if constexpr (SMM) { dnl += (double)nsum; nsum = 0.f; }
+#pragma unroll
+                for (int ft = 0; ft < FT; ++ft) { acc[0][ft] = f32x4{0.f, 0.f, 0.f, 0.f}; acs[0][ft] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             }
-            if constexpr (SMM) { dnl += (double)nsum; nsum = 0.f; }
-#pragma unroll
-            for (int ft = 0; ft < FT; ++ft) { acc[0][ft] = f32x4{0.f, 0.f, 0.f, 0.f}; acs[0][ft] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         }
         __builtin_amdgcn_wave_barrier();
     }

@@ -238,7 +238,11 @@ class GraphedSVAEStep(object):
     operating point (minibatches of 64-100 rows, experiments.py:26) the step is ~150 launches of microsecond kernels
     and is bound by launch overhead, not by the GPU.  Per call: copy the minibatch into the static input, refresh the
     noise / uniforms in place, write the two step-dependent scalars (CVI step size, bias-corrected Adam step size) to
-    device memory, replay.  GMM-SVAE, one process (the data-parallel step has a collective in the middle)."""
+    device memory, replay.  GMM-SVAE, one process (the data-parallel step has a collective in the middle).
+    Noise: the graph reads eps from a static (N,K,L,S) tensor that every call refills with torch's generator - i.e. the
+    stream of an eager trainer built with rng='torch' (call i here == step i there, bit for bit).  A trainer with
+    rng='philox' (the default: eps drawn inside the E-step kernel from a host-side seed) draws a DIFFERENT stream when
+    stepped eagerly: a seed baked into a captured launch could not advance per replay."""
 
     def __init__(self, trainer, y_example, warmup=3):
         tr = self.tr = trainer
