@@ -333,6 +333,47 @@ def spawn_ranks(n, argv):
     return max(abs(rc) for rc in rcs)
 
 
+def measure_traffic(workload, N, D, K):
+    """HBM bytes per launch of the fused pass kernel, measured NOW: two child processes run tools/t1_prof_target.py under
+    `rocprofv3 --kernel-trace --pmc` (FETCH_SIZE and WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes) BEFORE
+    this process touches the GPU; FETCH_SIZE x 2 (gfx950 tallies 128-byte requests at 64 bytes for wide coalesced reads),
+    WRITE_SIZE x 1.  Returns (bytes, description) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None, 'rocprofv3 not found'
+    out = tempfile.mkdtemp(prefix='vmp_pmc_', dir='/tmp')
+    env = dict(os.environ, N=str(N), D=str(D), K=str(K), FLAV=workload, REPS='3', TMPDIR='/tmp')
+    vals = {}
+    try:
+        for tag, ctr in (('f', 'FETCH_SIZE'), ('w', 'WRITE_SIZE')):
+            subprocess.run([exe, '--kernel-trace', '--pmc', ctr, '--output-format', 'csv', '-d', out, '-o', tag, '--',
+                            sys.executable, os.path.join(ROOT, 'tools', 't1_prof_target.py')], cwd='/tmp', env=env,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            v = []
+            for f in glob.glob(os.path.join(out, '**', '*%s_counter_collection.csv' % tag), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    n = row['Kernel_Name']
+                    fused = ('pass_xdl_kernel' in n and n.rstrip(')').split('>')[0].endswith('true')) or \
+                            ('pass_kernel<' in n and 'true, true, false>' in n)
+                    if fused and row['Counter_Name'] == ctr:
+                        v.append(float(row['Counter_Value']))
+            if not v:
+                return None, 'no fused pass kernel dispatch in the %s pass' % ctr
+            vals[ctr] = sum(v) / len(v)
+        return (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0, \
+            ('measured by this run: rocprofv3 --kernel-trace --pmc, separate passes, %s launches averaged; FETCH_SIZE %.1f KB x 2 + '
+             'WRITE_SIZE %.1f KB' % (len(v), vals['FETCH_SIZE'], vals['WRITE_SIZE']))
+    except Exception as e:                                  # the bench line must not depend on the profiler
+        return None, 'rocprofv3 pass failed: %r' % (e,)
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def shard_rows(n_total, rank, world):
     """contiguous near-equal row ranges (tf.split semantics, data.py:174-175; remainder to the first ranks)"""
     base, rem = divmod(n_total, world)
@@ -380,6 +421,7 @@ def main():
     ap.add_argument('--k', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the side measurements (T2 / T3 / N=1e7 / forced-dist)')
+    ap.add_argument('--no-traffic', action='store_true', help='do not run the two rocprofv3 counter passes that measure roofline.traffic')
     ap.add_argument('--s', type=int, default=10)
     ap.add_argument('--u', type=int, default=50)
     args = ap.parse_args()
@@ -393,6 +435,12 @@ def main():
     # banner, warnings) goes to stderr
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    # roofline.traffic of the dominant kernel, measured by THIS run (single-GPU T1 runs; child processes, started before
+    # this process initialises the GPU)
+    traffic_live = (None, 'not measured (multi-rank run, other workload, or --no-traffic / --no-extra)')
+    if (int(os.environ.get('WORLD_SIZE', '1')) == 1 and args.workload in ('gmm', 'smm') and not args.no_traffic
+            and not args.no_extra):
+        traffic_live = measure_traffic(args.workload, args.n, args.d, args.k)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
         sys.exit('bench.py: --gpus %d does not match WORLD_SIZE=%d' % (args.gpus, world))
@@ -521,12 +569,12 @@ def main():
             alg_bytes = 4.0 * n_loc * words                  # T1 algorithmic bytes per step (this GPU's rows)
             min_bytes = alg_bytes / 2                        # what the fused pass has to move: read x, write r (u)
             achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-            traffic, traffic_src = None, None
+            traffic, traffic_src = traffic_live
             tf = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % args.workload)
-            if os.path.exists(tf) and (n_loc, D, K) == (1_000_000, 8, 16):
+            if traffic is None and os.path.exists(tf) and (n_loc, D, K) == (1_000_000, 8, 16):
                 tj = json.load(open(tf))
                 traffic = tj.get('hbm_bytes_per_launch')
-                traffic_src = 'committed rocprofv3 PMC summary (%s), not re-measured by this run' % tj.get('source', tf)
+                traffic_src = 'committed rocprofv3 PMC summary (%s), not re-measured by this run [%s]' % (tj.get('source', tf), traffic_live[1])
             out = dict(common)
             out.update({
                 'metric': 'vmp_step_datapoints_per_sec', 'value': n_job / (dt / args.steps), 'reps': len(walls), 'ms_per_step': ms,

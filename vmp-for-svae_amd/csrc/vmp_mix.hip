@@ -1593,7 +1593,13 @@ Plan make_plan(long long N, int D, int K, int flavour, bool stats, bool xdl = fa
     // of the kernel runs one wave per SIMD with nothing to hide its latencies behind (s_setprio does not change it).  The
     // older waves therefore get the larger share, so that both mates finish together.  Ranges stay contiguous and fixed:
     // results remain deterministic.
-    const int split = flavour == VMP_SMM ? 62 : 64;   // % of a pair's rows for the older wave: measured optima (N = 3e5 .. 1e7)
+#ifndef VMP_SPLIT_GMM
+#define VMP_SPLIT_GMM 64
+#endif
+#ifndef VMP_SPLIT_SMM
+#define VMP_SPLIT_SMM 62
+#endif
+    const int split = flavour == VMP_SMM ? VMP_SPLIT_SMM : VMP_SPLIT_GMM;   // % of a pair's rows for the older wave: measured optima (N = 3e5 .. 1e7)
     if (nw == 8 && split != 50 && rpw >= 2 * TR) {
         long long cap = tuned_blocks < MAX_BLOCKS ? tuned_blocks : MAX_BLOCKS;
         long long pr = ((N + 4 * cap - 1) / (4 * cap) + 7) / 8 * 8;           // rows of a SIMD pair, all blocks in use
