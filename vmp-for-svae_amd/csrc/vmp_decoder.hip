@@ -296,13 +296,13 @@ __device__ __forceinline__ RowMap row_map(unsigned tile, int c, unsigned S, unsi
 
 // (unit 16t+4g+v, row c) activations of one layer -> the three bf16 terms of every value, packed per (v, v+1) pair:
 // ts[term][2t + p] = values v = 2p, 2p+1 of tile t.  Registers 4kb .. 4kb+3 of a term ARE the B operand of k-block kb.
-template <int UT>
+template <int UT, int TERMS = 3>
 __device__ __forceinline__ void split_tiles(const f32x4 (&h)[UT], unsigned (&ts)[3][4 * Img<UT>::KB]) {
 #pragma unroll
     for (int i = 0; i < 4 * Img<UT>::KB; ++i) {
         if (i < 2 * UT) {
             unsigned t3[3];
-            split_bf16<3>(v2f{h[i >> 1][2 * (i & 1)], h[i >> 1][2 * (i & 1) + 1]}, t3);
+            split_bf16<TERMS>(v2f{h[i >> 1][2 * (i & 1)], h[i >> 1][2 * (i & 1) + 1]}, t3);
             ts[0][i] = t3[0]; ts[1][i] = t3[1]; ts[2][i] = t3[2];
         } else {
             ts[0][i] = 0u; ts[1][i] = 0u; ts[2][i] = 0u;
@@ -311,20 +311,21 @@ __device__ __forceinline__ void split_tiles(const f32x4 (&h)[UT], unsigned (&ts)
 }
 
 // out[t'] += W . act over the hidden units (K = 16 UT, k-blocks of 32), W = weight image `img` with OT output tiles:
-// the six products of order <= 2 of the 3-term splits (hh, hm, hl, mh, mm, lh).
-template <int UT, int OT>
+// the six products of order <= 2 of the 3-term splits (hh, hm, hl, mh, mm, lh); TERMS = 2: the three products hh, hm, mh of
+// 2-term splits (relative error <= 2^-16 per product - the backward data path of large batches, see dec_bwd_kernel).
+template <int UT, int OT, int TERMS = 3>
 __device__ __forceinline__ void gemm_units(const float* __restrict__ img, int lane, const unsigned (&ts)[3][4 * Img<UT>::KB],
                                            f32x4 (&out)[OT]) {
     constexpr int KB = Img<UT>::KB;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
-        for (int ta = 0; ta < 3; ++ta) {
+        for (int ta = 0; ta < TERMS; ++ta) {
             u32x4 w[OT];
 #pragma unroll
             for (int tp = 0; tp < OT; ++tp) w[tp] = ldsu4(img + (((tp * KB + kb) * 3 + ta) * 64 + lane) * 4);
 #pragma unroll
-            for (int tb = 0; tb + ta < 3; ++tb) {
+            for (int tb = 0; tb + ta < TERMS; ++tb) {
                 const u32x4 bv = {ts[tb][4 * kb], ts[tb][4 * kb + 1], ts[tb][4 * kb + 2], ts[tb][4 * kb + 3]};
 #pragma unroll
                 for (int tp = 0; tp < OT; ++tp) out[tp] = mfma_bf(w[tp], bv, out[tp]);
@@ -333,7 +334,7 @@ __device__ __forceinline__ void gemm_units(const float* __restrict__ img, int la
     }
 }
 // the same with ONE output tile: one accumulator chain per k-block (a single chain would be 6 KB dependent instructions)
-template <int UT>
+template <int UT, int TERMS = 3>
 __device__ __forceinline__ f32x4 gemm_units_1(const float* __restrict__ img, int lane, const unsigned (&ts)[3][4 * Img<UT>::KB],
                                               f32x4 init) {
     constexpr int KB = Img<UT>::KB;
@@ -341,12 +342,12 @@ __device__ __forceinline__ f32x4 gemm_units_1(const float* __restrict__ img, int
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) acc[kb] = kb == 0 ? init : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ta = 0; ta < 3; ++ta) {
+    for (int ta = 0; ta < TERMS; ++ta) {
         u32x4 w[KB];
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) w[kb] = ldsu4(img + ((kb * 3 + ta) * 64 + lane) * 4);
 #pragma unroll
-        for (int tb = 0; tb + ta < 3; ++tb)
+        for (int tb = 0; tb + ta < TERMS; ++tb)
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 const u32x4 bv = {ts[tb][4 * kb], ts[tb][4 * kb + 1], ts[tb][4 * kb + 2], ts[tb][4 * kb + 3]};
@@ -381,11 +382,13 @@ __device__ __forceinline__ SOps slot_operands(const unsigned (&ds)[3][2]) {
     return SOps{u32x4{ds[0][0], ds[0][1], ds[0][0], ds[0][1]}, u32x4{ds[1][0], ds[1][1], ds[1][0], ds[1][1]},
                 u32x4{ds[0][0], ds[0][1], ds[2][0], ds[2][1]}};
 }
+template <int TERMS = 3>
 __device__ __forceinline__ f32x4 gemm_slots(const float* __restrict__ img, int lane, const SOps& so, f32x4 acc) {
-    const u32x4 a0 = ldsu4(img + lane * 4), a1 = ldsu4(img + 256 + lane * 4);
+    const u32x4 a0 = ldsu4(img + lane * 4);
     acc = mfma_bf(a0, so.hh, acc);
-    acc = mfma_bf(a0, so.mm, acc);
-    return mfma_bf(a1, so.hl, acc);
+    acc = mfma_bf(a0, so.mm, acc);                           // hh + mh + hm + mm
+    if constexpr (TERMS == 3) acc = mfma_bf(ldsu4(img + 256 + lane * 4), so.hl, acc);   // + lh + hl
+    return acc;
 }
 
 // forward of one 16-row tile.  onev >= 0 on the lanes that own the free padding unit of the last tile: that unit's
@@ -534,7 +537,13 @@ __device__ __forceinline__ u32x4 trb_read(const unsigned char* __restrict__ p) {
 // is not a multiple of 16 (FS); otherwise db1 is summed on the VALU.
 // GIN (gradient-input mode): the upstream gradients of (mean, var) are given per row instead of being derived from
 // the log-likelihood - the same kernel then is the backward pass of a stand-alone Gaussian-head MLP (the encoder).
-template <int UT, bool FS, bool GIN>
+// BT = bf16 terms per operand on the backward DATA path (dh1 = W2 dO, dh0 = W1 dh1pre, dx = W0 dh0pre + Ws dO): 3 = the six
+// products of fp32 accuracy; 2 = three products, relative error <= 2^-16 per product.  The consumers of that path are sums
+// over rows (the weight gradients, which take (h, m) terms of it anyway) and dL/dx, which the E-step backward and the
+// encoder sum over samples, components and rows - for batches of >= 2^19 sample rows the 2-term form's rounding is below
+// the fp32 rounding of those sums (gated by the 21-gradient bars of tests/test_fullsize_gpu.py at N = 65 536 and 1e5),
+// and it saves 34 of 195 MFMAs and 64 of 840 VALU instructions per 16-row tile.  Small batches keep BT = 3.
+template <int UT, bool FS, bool GIN, int BT>
 __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     using I = Img<UT>;
@@ -690,8 +699,10 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             for (int tp = 0; tp < UT; ++tp) dh1[tp] = mfma_bf(a0[tp], so.hh, zero4);
 #pragma unroll
             for (int tp = 0; tp < UT; ++tp) dh1[tp] = mfma_bf(a0[tp], so.mm, dh1[tp]);
+            if constexpr (BT == 3) {
 #pragma unroll
-            for (int tp = 0; tp < UT; ++tp) dh1[tp] = mfma_bf(a1[tp], so.hl, dh1[tp]);
+                for (int tp = 0; tp < UT; ++tp) dh1[tp] = mfma_bf(a1[tp], so.hl, dh1[tp]);
+            }
         }
         // ---- dW2 (and shortcut W): [h1 ; x]^T . dO
         wave_lds_order();
@@ -722,9 +733,9 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
         for (int tp = 0; tp < UT; ++tp) dh0[tp] = zero4;
         {
             unsigned d1s[3][4 * KB];
-            split_tiles<UT>(dh1, d1s);
+            split_tiles<UT, BT>(dh1, d1s);
             trb_write<UT>(scrQb, g, c, d1s);
-            gemm_units<UT, UT>(sm + I::B2, lane, d1s, dh0);
+            gemm_units<UT, UT, BT>(sm + I::B2, lane, d1s, dh0);
         }
         // ---- dW1 = h0^T . dh1pre
         wave_lds_order();
@@ -754,10 +765,10 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
         // ---- dx = W0 . dh0pre + Ws . dO(mean)
         {
             unsigned d0s[3][4 * KB];
-            split_tiles<UT>(dh0, d0s);
+            split_tiles<UT, BT>(dh0, d0s);
             trb_write<UT>(scrPb, g, c, d0s);
-            const f32x4 ds_ = gemm_slots(sm + I::B3S, lane, so, zero4);
-            const f32x4 dxv = gemm_units_1<UT>(sm + I::B3, lane, d0s, zero4) + ds_;        // [dim 4g+v][row c]
+            const f32x4 ds_ = gemm_slots<BT>(sm + I::B3S, lane, so, zero4);
+            const f32x4 dxv = gemm_units_1<UT, BT>(sm + I::B3, lane, d0s, zero4) + ds_;        // [dim 4g+v][row c]
             if (ok && a.dx) {
                 if (L == 8) {
                     if (g < 2) *reinterpret_cast<f32x4*>(a.dx + (size_t)row * 8 + 4 * g) = dxv;
@@ -931,19 +942,24 @@ int dec_bwd_launch(const DecArgs& a0, int blocks, hipStream_t s) {
     a.split = (a0.U & 15) ? 58 : 54;
     const int U = a.U;
     const int red_floats = (1 + BWD_WAVES / 2) * dec_geo(a.L, a.U, a.Dy).PW;     // epilogue: accumulator + 4 slabs
+#ifndef VMP_DEC_BT2_ROWS
+#define VMP_DEC_BT2_ROWS (1u << 19)   // sample rows from which the backward data path uses 2-term operands (0xffffffff: never)
+#endif
+    const bool bt2 = a.R >= (unsigned)VMP_DEC_BT2_ROWS;
+#define DEC_BWD_L(UTV, FSV, BTV)                                                                                      \
+    do {                                                                                                              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<UTV, FSV, GIN, BTV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((dec_bwd_kernel<UTV, FSV, GIN, BTV>), dim3(blocks), dim3(BWD_THREADS), lds, s, a);         \
+    } while (0)
 #define DEC_BWD(UTV)                                                                                                  \
     do {                                                                                                              \
         const int lds = (Img<UTV>::BWD_TOTAL > red_floats ? Img<UTV>::BWD_TOTAL : red_floats) * (int)sizeof(float);   \
-        if ((U & 15) == 0) {                                                                                          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<UTV, false, GIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-            hipLaunchKernelGGL((dec_bwd_kernel<UTV, false, GIN>), dim3(blocks), dim3(BWD_THREADS), lds, s, a);        \
-        } else {                                                                                                      \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<UTV, true, GIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-            hipLaunchKernelGGL((dec_bwd_kernel<UTV, true, GIN>), dim3(blocks), dim3(BWD_THREADS), lds, s, a);         \
-        }                                                                                                             \
+        if ((U & 15) == 0) { if (bt2) DEC_BWD_L(UTV, false, 2); else DEC_BWD_L(UTV, false, 3); }                      \
+        else { if (bt2) DEC_BWD_L(UTV, true, 2); else DEC_BWD_L(UTV, true, 3); }                                      \
     } while (0)
     DEC_DISPATCH(U, DEC_BWD);
 #undef DEC_BWD
+#undef DEC_BWD_L
     return check_launch(GIN ? "vmp_mlp_gauss_bwd" : "vmp_decoder_loglike_bwd");
 }
 
