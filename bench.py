@@ -113,8 +113,9 @@ def bench_t2(N, Ld, K, S, steps, warmup, dev, dist=None, world=1):
         xs = svae.subsample_x(x, lz, seed=i, nb_out=1)[:, 0, :].contiguous()
         st = _mix.raw_stats(xs, r)
         if dist is not None:
+            from vmp_for_svae_amd.models.parallel_mix import allreduce_sum_
             buf = torch.cat([st.reshape(-1)] + [gg.reshape(-1).double() for gg in grads[2:]])
-            dist.all_reduce(buf)
+            allreduce_sum_(buf)                               # RCCL all-reduce of the packed fp64 buffer (gloo: host-staged)
             st = buf[:st.numel()].reshape(st.shape)
         svae.update_gmm_params(theta, svae.m_step_from_stats(prior, st), 0.2)
 
@@ -129,11 +130,7 @@ def bench_t2(N, Ld, K, S, steps, warmup, dev, dist=None, world=1):
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
+    dt = max_over_ranks(dist, time.perf_counter() - t0, dev)
     # the same forward with eps drawn inside the kernel (Philox4x32-10), and what the noise tensor costs to produce
     evp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
     evr = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
@@ -271,6 +268,16 @@ def bench_minibatch(N, K, Ld, Dy, S, U, dev, steps=200, cpu=True):
     return res
 
 
+def max_over_ranks(dist, value, dev):
+    """MAX over ranks of a host scalar (the contract's timing rule); device tensor for RCCL, host tensor for gloo"""
+    if dist is None:
+        return value
+    on_dev = dist.get_backend() == 'nccl'
+    tt = torch.tensor([value], device=dev if on_dev else 'cpu', dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return tt.item()
+
+
 def time_t1(loop, steps, warmup, reps, barrier, dist, dev):
     """`reps` repetitions of the contract's timed region (barrier + synchronize, EXACTLY `steps` steps, barrier +
     synchronize; MAX over ranks), each preceded by nothing but the previous region.  Returns the per-region wall times (s)
@@ -295,11 +302,7 @@ def time_t1(loop, steps, warmup, reps, barrier, dist, dev):
             else:
                 loop.estep()
         barrier()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = tt.item()
+        dt = max_over_ranks(dist, time.perf_counter() - t0, dev)
         walls.append(dt)
         kern.append(float(np.mean([a.elapsed_time(b) for a, b in ev])))
     return walls, kern
@@ -450,7 +453,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        backend = os.environ.get('VMP_BENCH_BACKEND', 'nccl')    # tests: 'gloo' lets two ranks share ONE GPU (RCCL refuses that)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
@@ -627,10 +634,7 @@ def main():
                     'note': 'timed on min(N, 262144) rows and scaled to N (the kernel is linear in rows)'}
             metric, wl = 'svae_train_step_datapoints_per_sec', 'T3 svae training step (experiments.py:196-267), L=Dy=%d, K=%d, S=%d, U=%d' % (D, K, S, U)
             extra['t3'] = res
-        if dist is not None:
-            tt = torch.tensor([ms], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            ms = tt.item()
+        ms = max_over_ranks(dist, ms, dev)
         if rank == 0:
             out = dict(common)
             out.update({'metric': metric, 'value': n_job / (ms * 1e-3), 'steps': steps, 'warmup': warm, 'ms_per_step': ms,

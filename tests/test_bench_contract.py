@@ -60,3 +60,34 @@ def test_gpus_flag_is_not_ignored():
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=dict(env, WORLD_SIZE='4', RANK='0'),
                        capture_output=True, text=True)
     assert p.returncode != 0 and 'WORLD_SIZE' in (p.stderr + p.stdout)
+
+
+def test_shard_rows_is_tf_split():
+    """--scaling strong gives rank r the r-th contiguous share of the N rows (data.py:174-175 semantics: near-equal, in
+    order, covering every row exactly once)."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    b = importlib.util.module_from_spec(spec)
+    sys.modules['bench_mod'] = b
+    spec.loader.exec_module(b)
+    for n, w in ((1_000_000, 8), (1_000_003, 8), (10, 4), (7, 1)):
+        parts = [b.shard_rows(n, r, w) for r in range(w)]
+        assert parts[0][0] == 0 and parts[-1][1] == n
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+        sizes = [hi - lo for lo, hi in parts]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_traffic_measurement_never_takes_the_line_down(monkeypatch):
+    """measure_traffic returns (None, reason) instead of raising when the profiler is unavailable or fails."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location('bench_mod2', os.path.join(ROOT, 'bench.py'))
+    b = importlib.util.module_from_spec(spec)
+    sys.modules['bench_mod2'] = b
+    spec.loader.exec_module(b)
+    import shutil
+    monkeypatch.setattr(shutil, 'which', lambda _: '/bin/false')        # a "profiler" that exits 1
+    val, why = b.measure_traffic('gmm', 1000, 8, 16)
+    assert val is None and 'failed' in why
