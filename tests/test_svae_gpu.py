@@ -533,3 +533,29 @@ def test_compute_elbo_on_other_samples_than_the_e_steps(golden, case):
     eg = rel(gx, gxo.numpy())
     parity_log.record('rel', eg, 1e-4, 'd regulariser / d samples')
     assert eg <= 1e-4, eg
+
+
+@pytest.mark.parametrize('N,K,S,Ld', [(1000, 16, 10, 8), (777, 10, 4, 6), (50, 3, 2, 1), (130, 64, 3, 4), (9, 33, 5, 7)])
+def test_subsample_inverse_cdf(N, K, S, Ld):
+    """svae.subsample_x with uniforms (svae.py:122-151: z ~ Cat(exp log_z), x[n, z, s]): the lane-per-cell kernel's draw equals
+    a numpy inverse CDF wherever u is not within fp32 rounding of a CDF step, and the gathered rows are exact copies."""
+    from vmp_for_svae_amd.models import svae
+    rng = np.random.Generator(np.random.PCG64(N + K))
+    lz = np.log(rng.dirichlet(np.ones(K) * 0.5, size=N)).astype(np.float32)
+    x = rng.standard_normal((N, K, S, Ld)).astype(np.float32)
+    u = rng.random((N, S)).astype(np.float32)
+    out = svae.subsample_x(dev(x), dev(lz), u=dev(u)).cpu().numpy()
+    cdf = np.cumsum(np.exp(lz.astype(np.float64)), axis=1)
+    z = np.minimum((cdf[:, None, :-1] <= u[:, :, None]).sum(-1), K - 1)            # (N,S)
+    gap = np.abs(cdf[:, None, :] - u[:, :, None]).min(-1)
+    clear = gap > 1e-5
+    want = x[np.arange(N)[:, None], z, np.arange(S)[None, :]]                    # (N,S,L)
+    assert clear.mean() > 0.99
+    assert np.array_equal(out[clear], want[clear])
+    # every output row is SOME component's sample row of the right (n, s)
+    hit = (out[:, None, :, :] == x).all(-1).any(1)
+    assert hit.all()
+    # supplied indices: exact gather
+    zi = rng.integers(0, K, size=(N, S))
+    out2 = svae.subsample_x(dev(x), dev(lz), z_draws=dev(zi, torch.int64)).cpu().numpy()
+    assert np.array_equal(out2, x[np.arange(N)[:, None], zi, np.arange(S)[None, :]])

@@ -1558,6 +1558,8 @@ __global__ __launch_bounds__(SV_FWD_MAX_NW * WAVE) void svae_estep_fwd_chunked_k
     }
 }
 
+__device__ __forceinline__ bool al16_dev(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 struct SubArgs {
     const float* x;         // (N,K,S,L)
     const float* lz;        // (N,K)
@@ -1569,27 +1571,81 @@ struct SubArgs {
     int K, S, L, S_out;
 };
 
+// One (n,k) cell per lane, RPT = 64 / K whole rows per wave: log_z is read coalesced (a thread-per-row loop over k touched 64
+// cache lines per load instruction - the access pattern that bound the round-2 backward kernel), the inverse CDF is an
+// inclusive prefix sum over the K lanes of the row (shuffle-up steps, guarded so that they never cross a row) followed by a
+// count of the lanes whose cumulative probability does not exceed u; the chosen sample row leaves through the row's first
+// lanes, 16 bytes each where the layout allows it.
 __global__ __launch_bounds__(256) void subsample_kernel(SubArgs a) {
-    const long long tot = a.N * a.S_out;
-    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < tot; g += (long long)gridDim.x * blockDim.x) {
-        const long long n = g / a.S_out;
-        const int s = (int)(g - n * a.S_out);
-        int zk;
-        if (a.z) {
-            zk = (int)a.z[g];
-        } else {
-            const float uu = a.u[g];
-            float cum = 0.f;
-            zk = a.K - 1;
-            for (int k = 0; k < a.K; ++k) {
-                cum += __expf(a.lz[n * a.K + k]);
-                if (uu < cum) { zk = k; break; }
+    constexpr int UN = 4;                                    // tiles per wave and turn: their three dependent loads (log_z -> u -> sample row) overlap
+    const int lane = threadIdx.x & 63;
+    const int K = a.K, RPT = WAVE / K, CT = RPT * K;
+    const bool lane_on = lane < CT;
+    const int r = lane / K, k = lane - r * K, rbase = r * K;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const long long ntiles = (a.N + RPT - 1) / RPT;
+    const bool vec = (a.L & 3) == 0 && al16_dev(a.x) && al16_dev(a.out);
+    const unsigned long long rowmask = (K < 64 ? (1ull << K) : 0ull) - 1ull;
+    for (long long t0 = wave * UN; t0 < ntiles; t0 += nwaves * UN) {
+        long long n[UN];
+        bool on[UN];
+        float cum[UN];
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            n[q] = (t0 + q) * RPT + r;
+            on[q] = lane_on && n[q] < a.N;
+            cum[q] = on[q] ? a.lz[n[q] * K + k] : -INFINITY;
+        }
+#pragma unroll
+        for (int q = 0; q < UN; ++q) cum[q] = __expf(cum[q]);
+        if (!a.z) {
+            for (int o = 1; o < K; o <<= 1) {
+#pragma unroll
+                for (int q = 0; q < UN; ++q) {
+                    const float up = __shfl_up(cum[q], o);
+                    if (k >= o) cum[q] += up;
+                }
             }
         }
-        if (a.z_out) a.z_out[g] = zk;
-        const float* src = a.x + ((n * a.K + zk) * a.S + s) * a.L;
-        float* dst = a.out + g * a.L;
-        for (int l = 0; l < a.L; ++l) dst[l] = src[l];
+        for (int s = 0; s < a.S_out; ++s) {
+            int zk[UN];
+            if (a.z) {
+#pragma unroll
+                for (int q = 0; q < UN; ++q) zk[q] = on[q] ? (int)a.z[n[q] * a.S_out + s] : 0;
+            } else {
+                float uu[UN];
+#pragma unroll
+                for (int q = 0; q < UN; ++q) uu[q] = on[q] ? a.u[n[q] * a.S_out + s] : 0.f;
+#pragma unroll
+                for (int q = 0; q < UN; ++q) {
+                    const unsigned long long below = __ballot(on[q] && k < K - 1 && cum[q] <= uu[q]);   // lanes k with cdf_k <= u
+                    zk[q] = __popcll((below >> rbase) & rowmask);                                     // first k with u < cdf_k (K-1 if none)
+                }
+            }
+            if (vec) {
+                float4 v[UN];
+#pragma unroll
+                for (int q = 0; q < UN; ++q) {
+                    const bool act = on[q] && k < (a.L >> 2);
+                    const float* __restrict__ src = a.x + (((act ? n[q] : 0) * K + (act ? zk[q] : 0)) * a.S + s) * a.L;
+                    v[q] = reinterpret_cast<const float4*>(src)[act ? k : 0];
+                }
+#pragma unroll
+                for (int q = 0; q < UN; ++q)
+                    if (on[q] && k < (a.L >> 2)) reinterpret_cast<float4*>(a.out + (n[q] * a.S_out + s) * a.L)[k] = v[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < UN; ++q)
+                    if (on[q]) {
+                        const float* __restrict__ src = a.x + ((n[q] * K + zk[q]) * a.S + s) * a.L;
+                        float* __restrict__ dst = a.out + (n[q] * a.S_out + s) * a.L;
+                        for (int l = k; l < a.L; l += K) dst[l] = src[l];
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < UN; ++q)
+                if (on[q] && k == 0 && a.z_out) a.z_out[n[q] * a.S_out + s] = zk[q];
+        }
     }
 }
 
@@ -1860,7 +1916,9 @@ int vmp_svae_subsample(const float* x, const float* lz, const float* u, const in
         return VMP_E_BADARG;
     }
     SubArgs a{x, lz, u, reinterpret_cast<const long long*>(z), out, reinterpret_cast<long long*>(z_out), N, K, S, L, S_out};
-    long long blocks = (N * S_out + 255) / 256;
+    if (K > WAVE) { set_error("vmp_svae_subsample: K=%d > 64", K); return VMP_E_DIM; }
+    const int RPTs = WAVE / K;
+    long long blocks = ((N + RPTs - 1) / RPTs + 15) / 16;               // 4 waves per block, 4 tiles of RPT rows per wave and turn
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(subsample_kernel, dim3((int)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return check_launch("subsample_kernel");
