@@ -100,7 +100,10 @@ def test_estep_vs_oracle_shapes():
     from vmp_for_svae_amd.models import svae
     rng = np.random.Generator(np.random.PCG64(5))
     for (N, K, Ld, S) in [(5, 3, 2, 3), (37, 10, 6, 10), (64, 16, 8, 10), (130, 7, 5, 4), (9, 33, 3, 2), (20, 5, 1, 7), (3, 64, 4, 5),
-                          (21, 10, 2, 100), (11, 5, 8, 100), (7, 16, 6, 37)]:   # last three: S-chunked forward (L*S > 144)
+                          (21, 10, 2, 100), (11, 5, 8, 100), (7, 16, 6, 37),    # these three: S-chunked forward (L*S > 144)
+                          # K = 16, even L >= 4, even S >= 4: the LDS-ring backward kernel (partial last tile, L/2 = 2, 3, 4
+                          # pieces per pair, the shortest and a long sample loop)
+                          (33, 16, 4, 10), (50, 16, 6, 8), (13, 16, 8, 4), (9, 16, 8, 100), (257, 16, 8, 10)]:
         e1 = rng.standard_normal((N, Ld))
         e2 = -0.5 * (0.3 + rng.random((N, Ld)))
         mu_k = rng.standard_normal((K, Ld)) * 2

@@ -246,15 +246,7 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
                              float (&xo)[2 * L], float (&go)[2 * L]) {
             const bool live = on && s2 < S;
             const bool both = s2 + 1 < S;
-#if defined(SV_EXP) && SV_EXP == 1
             if (live) {
-#pragma unroll
-                for (int i = 0; i < 2 * L; ++i) { xo[i] = mu[i % L] + 0.01f * (float)(s2 + i); go[i] = 0.001f * (float)(i - s2); }
-            }
-            if (false) {
-#else
-            if (live) {
-#endif
                 if ((L & 3) == 0 && a.vec_ok) {
 #pragma unroll
                     for (int q = 0; q < L / 4; ++q) {
@@ -302,11 +294,6 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
             float xs[L], gx[L];
 #pragma unroll
             for (int i = 0; i < L; ++i) { xs[i] = xp[h * L + i]; gx[i] = gp[h * L + i]; }
-#if defined(SV_EXP) && SV_EXP == 2
-#pragma unroll
-            for (int i = 0; i < L; ++i) { Wsum[i] += gx[i] + xs[i]; }
-            continue;
-#endif
             // d/dx of the theta term of T':  (1/S) c_s W^T W (x - m),  c_s = 1 (Gaussian) or (nu+L)/(nu+delta^2)
             float d[L], y[L];
 #pragma unroll
