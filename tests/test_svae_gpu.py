@@ -103,7 +103,10 @@ def test_estep_vs_oracle_shapes():
                           (21, 10, 2, 100), (11, 5, 8, 100), (7, 16, 6, 37),    # these three: S-chunked forward (L*S > 144)
                           # K = 16, even L >= 4, even S >= 4: the LDS-ring backward kernel (partial last tile, L/2 = 2, 3, 4
                           # pieces per pair, the shortest and a long sample loop)
-                          (33, 16, 4, 10), (50, 16, 6, 8), (13, 16, 8, 4), (9, 16, 8, 100), (257, 16, 8, 10)]:
+                          (33, 16, 4, 10), (50, 16, 6, 8), (13, 16, 8, 4), (9, 16, 8, 100), (257, 16, 8, 10),
+                          # K != 16 with even L, S (the round-2 kernel: a run-time-K variant of the ring kernel measured SLOWER
+                          # than it at K = 10, 2.41 vs 2.14 ms at N = 1e6)
+                          (64, 10, 8, 10), (21, 3, 4, 6), (40, 19, 8, 10), (70, 1, 8, 10)]:
         e1 = rng.standard_normal((N, Ld))
         e2 = -0.5 * (0.3 + rng.random((N, Ld)))
         mu_k = rng.standard_normal((K, Ld)) * 2
