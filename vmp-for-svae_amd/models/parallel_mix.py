@@ -103,6 +103,13 @@ class PeerExchange(object):
         self.iteration = 0
         self.status = torch.zeros(1, dtype=torch.int32, device='cuda')
 
+    def check(self):
+        """Raise if a wait of an in-kernel exchange timed out (a peer never published: the iterations since are invalid).
+        Reads one device word: call it where a host synchronisation is acceptable, not once per iteration."""
+        if int(self.status.item()) != 0:
+            raise L.VmpError('vmp_mix_finalize_exchange: a rank did not publish its moments within the time-out '
+                             '(iteration %d, rank %d of %d)' % (self.iteration, self.rank, self.world))
+
     def close(self):
         for g, pp in enumerate(self._peers):
             if g != self.rank:
