@@ -270,6 +270,38 @@ int    vmp_decoder_loglike_bwd(const float* x, const float* y, const float* gA, 
                                const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws,
                                const float* bs1, const float* bs2, int64_t N, int K, int S, int L, int Dy, int U,
                                float* dx, float* dparams, float* ll, void* ws, size_t ws_bytes, void* stream);
+/* As vmp_decoder_loglike_bwd with the upstream gradient given through LOG weights: gA_nk = w_scale * exp(log_w_nk).  The
+ * ELBO's weights are r_nk = exp(log z_nk) (models/svae.py:216-219, vae.py:240): with w_scale = -sigma / 2S the launch
+ * returns sigma * d rec / d(x, parameters) without a separate exp / scaling pass over (N,K).  w_scale != 0.          */
+int    vmp_decoder_loglike_bwd_logw(const float* x, const float* y, const float* log_w, float w_scale, const float* W0,
+                                    const float* b0, const float* W1, const float* b1, const float* W2, const float* b2,
+                                    const float* Ws, const float* bs1, const float* bs2, int64_t N, int K, int S, int L,
+                                    int Dy, int U, float* dx, float* dparams, float* ll, void* ws, size_t ws_bytes,
+                                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Scalar tail of the SVAE ELBO (models/svae.py:216-254 compute_elbo; vae.py:232-250) - one launch
+ * ------------------------------------------------------------------------------------------------
+ * From log_z (N,K), T_prime (N,K) (the theta side of the regulariser, as the fused E-step returns it) and the
+ * per-sample reconstruction sums ll (N,K,S) of the decoder kernel:
+ *   r = exp(log_z);  rec = -1/(2S) sum_nk r_nk sum_s ll_nks - N Dy/2 log(2 pi);  reg = sum_nk r_nk (T'_nk + log_z_nk)
+ *   scalars = [elbo = rec - reg, rec, reg]   (fp64 sums, fixed order: deterministic)
+ *   g_log_z = sigma * d elbo / d log_z,  g_T_prime = sigma * d elbo / d T'   (sigma = -1 for loss = -elbo)
+ * ws: vmp_svae_elbo_tail_workspace_bytes() bytes, ZEROED by the caller before its first use (the kernel leaves it
+ * reusable); one workspace per concurrently running stream.                                                          */
+size_t vmp_svae_elbo_tail_workspace_bytes(void);
+int    vmp_svae_elbo_tail(const float* log_z, const float* T_prime, const float* ll, int64_t N, int K, int S, int Dy,
+                          float sigma, float* scalars, float* g_log_z, float* g_T_prime, float* r, void* ws,
+                          size_t ws_bytes, void* stream);
+
+/* tf.train.AdamOptimizer's update (TF 1.3; experiments.py:264-265) of n_tensors fp32 tensors in one launch per 32
+ * tensors:  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr_t m / (sqrt(v) + eps), where the caller supplies the
+ * bias-corrected step size lr_t = lr sqrt(1-b2^t)/(1-b1^t) - by value, or through lr_t_dev (a device float that
+ * overrides it: graph-captured steps refresh that word instead of re-capturing).  params/grads/m/v: HOST arrays of
+ * n_tensors device pointers; sizes: element counts.  The scalars are doubles: 1 - b is formed in fp64, then rounded.                                                                */
+int    vmp_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* m, float* const* v,
+                     const int64_t* sizes, double beta1, double beta2, double eps, double lr_t, const float* lr_t_dev,
+                     void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stand-alone per-cell log-densities (forward only; the training step uses the fused kernels above)

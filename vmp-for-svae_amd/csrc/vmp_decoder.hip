@@ -45,6 +45,7 @@ struct DecArgs {
     const float* x;        // (R, L)  rows = N*K*S
     const float* y;        // (N, Dy)
     const float* gA;       // (N, K)  backward: upstream gradient of A_nk = sum_s ll_row
+    float logw;            // != 0: gA holds LOG weights and the upstream gradient is logw * exp(gA) (vmp_decoder_loglike_bwd_logw)
     const float* gmean;    // (R, Dy) backward, gradient-input mode: upstream gradients of the two head outputs
     const float* gvar;     // (R, Dy)
     const float *W0, *b0, *W1, *b1, *W2, *b2, *Ws, *bs1, *bs2;
@@ -630,7 +631,8 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
         const bool ok = row < a.R;
         const TileIn cur = nxt;
         nxt = fetch(tile + 1);
-        const float xb0 = cur.xb0, xb1 = cur.xb1, ga = cur.ga;
+        const float xb0 = cur.xb0, xb1 = cur.xb1;
+        const float ga = (!GIN && a.logw != 0.f) ? (ok ? a.logw * expf(cur.ga) : 0.f) : cur.ga;
         const float yv[2] = {cur.p0, cur.p1}, gin_m[2] = {cur.p0, cur.p1}, gin_v[2] = {cur.q0, cur.q1};
 
         unsigned xs[3];
@@ -963,6 +965,37 @@ int dec_bwd_launch(const DecArgs& a0, int blocks, hipStream_t s) {
     return check_launch(GIN ? "vmp_mlp_gauss_bwd" : "vmp_decoder_loglike_bwd");
 }
 
+int decoder_loglike_bwd_impl(const char* what, float logw, const float* x, const float* y, const float* gA,
+                             const float* W0, const float* b0, const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws,
+                            const float* bs1, const float* bs2, int64_t N, int K, int S, int L, int Dy, int U, float* dx,
+                            float* dparams, float* ll, void* ws, size_t ws_bytes, void* stream) {
+    if (int e = dec_check(what, N, K, S, L, Dy, U)) return e;
+    if (!x || !y || !gA || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !Ws || !bs1 || !bs2 || !dx || !dparams || !ws) {
+        set_error("%s: NULL argument", what);
+        return VMP_E_BADARG;
+    }
+    const DecGeo q = dec_geo(L, U, Dy);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (N == 0) {
+        (void)hipMemsetAsync(dparams, 0, (size_t)q.PW * sizeof(float), s);
+        return check_launch(what);
+    }
+    const size_t need = (size_t)dec_bwd_blocks((long long)N * K * S) * (size_t)q.PW * sizeof(float);
+    if (ws_bytes < need) {
+        set_error("%s: workspace too small (%zu < %zu bytes)", what, ws_bytes, need);
+        return VMP_E_WS;
+    }
+    DecArgs a{};
+    a.x = x; a.y = y; a.gA = gA; a.W0 = W0; a.b0 = b0; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Ws = Ws; a.bs1 = bs1; a.bs2 = bs2;
+    a.dx = dx; a.part = static_cast<float*>(ws); a.ll = ll; a.logw = logw;
+    a.R = (unsigned)(N * K * S); a.K = (unsigned)K; a.S = (unsigned)S; a.L = L; a.Dy = Dy; a.U = U;
+    const int blocks = dec_bwd_blocks((long long)a.R);
+    if (int e = dec_bwd_launch<false>(a, blocks, s)) return e;
+    DecRedArgs r{a.part, bs2, dparams, blocks, q.PW, q.obs2, Dy};
+    hipLaunchKernelGGL(dec_reduce_kernel, dim3((q.PW + 63) / 64), dim3(64 * DEC_RED_GROUPS), 0, s, r);
+    return check_launch(what);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1004,31 +1037,20 @@ int vmp_decoder_loglike_bwd(const float* x, const float* y, const float* gA, con
                             const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws,
                             const float* bs1, const float* bs2, int64_t N, int K, int S, int L, int Dy, int U, float* dx,
                             float* dparams, float* ll, void* ws, size_t ws_bytes, void* stream) {
-    if (int e = dec_check("vmp_decoder_loglike_bwd", N, K, S, L, Dy, U)) return e;
-    if (!x || !y || !gA || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !Ws || !bs1 || !bs2 || !dx || !dparams || !ws) {
-        set_error("vmp_decoder_loglike_bwd: NULL argument");
+    return decoder_loglike_bwd_impl("vmp_decoder_loglike_bwd", 0.f, x, y, gA, W0, b0, W1, b1, W2, b2, Ws, bs1, bs2, N, K, S, L, Dy, U,
+                                    dx, dparams, ll, ws, ws_bytes, stream);
+}
+
+int vmp_decoder_loglike_bwd_logw(const float* x, const float* y, const float* log_w, float w_scale, const float* W0,
+                                 const float* b0, const float* W1, const float* b1, const float* W2, const float* b2,
+                                 const float* Ws, const float* bs1, const float* bs2, int64_t N, int K, int S, int L, int Dy,
+                                 int U, float* dx, float* dparams, float* ll, void* ws, size_t ws_bytes, void* stream) {
+    if (w_scale == 0.f) {
+        set_error("vmp_decoder_loglike_bwd_logw: w_scale must not be 0");
         return VMP_E_BADARG;
     }
-    const DecGeo q = dec_geo(L, U, Dy);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (N == 0) {
-        (void)hipMemsetAsync(dparams, 0, (size_t)q.PW * sizeof(float), s);
-        return check_launch("vmp_decoder_loglike_bwd");
-    }
-    if (ws_bytes < vmp_decoder_workspace_bytes(N, K, S, L, U, Dy)) {
-        set_error("vmp_decoder_loglike_bwd: workspace too small (%zu < %zu bytes)", ws_bytes,
-                  vmp_decoder_workspace_bytes(N, K, S, L, U, Dy));
-        return VMP_E_WS;
-    }
-    DecArgs a{};
-    a.x = x; a.y = y; a.gA = gA; a.W0 = W0; a.b0 = b0; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Ws = Ws; a.bs1 = bs1; a.bs2 = bs2;
-    a.dx = dx; a.part = static_cast<float*>(ws); a.ll = ll;
-    a.R = (unsigned)(N * K * S); a.K = (unsigned)K; a.S = (unsigned)S; a.L = L; a.Dy = Dy; a.U = U;
-    const int blocks = dec_bwd_blocks((long long)a.R);
-    if (int e = dec_bwd_launch<false>(a, blocks, s)) return e;
-    DecRedArgs r{a.part, bs2, dparams, blocks, q.PW, q.obs2, Dy};
-    hipLaunchKernelGGL(dec_reduce_kernel, dim3((q.PW + 63) / 64), dim3(64 * DEC_RED_GROUPS), 0, s, r);
-    return check_launch("vmp_decoder_loglike_bwd(reduce)");
+    return decoder_loglike_bwd_impl("vmp_decoder_loglike_bwd_logw", w_scale, x, y, log_w, W0, b0, W1, b1, W2, b2, Ws, bs1, bs2, N, K,
+                                    S, L, Dy, U, dx, dparams, ll, ws, ws_bytes, stream);
 }
 
 int vmp_mlp_gauss_bwd(const float* x, const float* gmean, const float* gvar, const float* W0, const float* b0,

@@ -1,6 +1,6 @@
 // K-sized parameter maps of the SVAE training step (reference models/svae.py:342-358 unpack_recognition_gmm,
 // :205-214 the theta side of compute_elbo via distributions/niw.py:8-43 + dirichlet.py:8-22, :154-176 m_step and
-// :376-403 update_gmm_params) as single-launch kernels: one thread per mixture component, fp64 inside, fp32 in/out.
+// :376-403 update_gmm_params) as single-launch kernels: one 64-lane block per mixture component, fp64 inside, fp32 in/out.
 // At the reference's real operating point (minibatches of 64-100 rows) the step is bound by the NUMBER of launches:
 // these maps were ~120 tiny torch kernels (batched Cholesky / triangular solves with host-side error checks, tril,
 // softplus, digamma ...) and their autograd; here they are 4 launches.
@@ -59,93 +59,102 @@ struct PhiArgs {
     int K, L;
 };
 
-__device__ __forceinline__ void log_softmax_stats(const float* __restrict__ piraw, int K, double& mx, double& lse) {
-    mx = -1e300;
-    for (int j = 0; j < K; ++j) mx = fmax(mx, (double)piraw[j]);
-    double s = 0.0;
-    for (int j = 0; j < K; ++j) s += exp((double)piraw[j] - mx);
-    lse = mx + log(s);
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+// r[idx] of a register array with a lane-dependent index (selects: no scratch memory)
+template <int L>
+__device__ __forceinline__ double pick(const double (&r)[L], int idx) {
+    double v = r[0];
+#pragma unroll
+    for (int q = 1; q < L; ++q) v = idx == q ? r[q] : v;
+    return v;
 }
 
+// One 64-lane block per component; lane (i, j) = (lane / L, lane % L) owns element (i, j) of the L x L matrices, lanes
+// j < K the K-sized softmax terms.  The transcendental work (softplus, log, exp - sequences of dozens of fp64
+// instructions each) is spread over the lanes; only the two triangular solves are serial (every lane runs them on
+// operands broadcast from LDS).  (One thread per component did all of it serially: 11-12 us per launch at L = 8.)
 template <int L, bool BWD>
 __global__ __launch_bounds__(PREP_THREADS) void phi_prep_kernel(PhiArgs a) {
-    const int k = threadIdx.x, K = a.K;
-    __shared__ double s_gb;
-    if (BWD && k == 0) {
-        double t = 0.0;
-        for (int j = 0; j < K; ++j) t += (double)a.g_bias[j];
-        s_gb = t;
+    static_assert(L * L <= PREP_THREADS, "one lane per matrix element");
+    const int k = blockIdx.x, lane = threadIdx.x, K = a.K;
+    __shared__ double Ls[L][L + 1];
+    __shared__ double Gm[L][L + 1];
+    __shared__ double inv_d[L];
+    const int i = lane / L, j = lane % L;
+    const bool in = lane < L * L;
+    const float* __restrict__ raw = a.Lraw + (size_t)k * L * L;
+    double lij = 0.0;
+    if (in) {
+        if (j < i) lij = (double)raw[i * L + j];
+        else if (j == i) lij = (double)(float)softplus_d((double)raw[i * L + i]);
+        Ls[i][j] = lij;
+        if (i == j) inv_d[i] = 1.0 / lij;
+        if (BWD) Gm[i][j] = (double)a.g_P[(size_t)k * L * L + i * L + j];
     }
+    const double pr = lane < K ? (double)a.piraw[lane] : -1e300;
+    const double mx = wave_max_d(pr);
+    const double se = wave_sum_d(lane < K ? exp(pr - mx) : 0.0);
+    const double logpi = (double)a.piraw[k] - (mx + log(se));
+    const double ld = wave_sum_d((in && i == j) ? log(lij) : 0.0);           // log det L
     __syncthreads();
-    if (k >= K) return;
-    double Lm[L][L];
-    load_Lk<L>(a.Lraw + (size_t)k * L * L, Lm);
-    double h[L], s[L];
+    double s[L];                                        // s = L^-1 h
+    double q2 = 0.0;
 #pragma unroll
-    for (int i = 0; i < L; ++i) h[i] = (double)a.mu[k * L + i];
-    double B = 0.0;
+    for (int r = 0; r < L; ++r) {
+        double t = (double)a.mu[k * L + r];
 #pragma unroll
-    for (int i = 0; i < L; ++i) {                       // s = L^-1 h
-        double t = h[i];
-#pragma unroll
-        for (int j = 0; j < i; ++j) t -= Lm[i][j] * s[j];
-        s[i] = t / Lm[i][i];
-        B += -0.5 * s[i] * s[i] + log(Lm[i][i]);
+        for (int c = 0; c < r; ++c) t -= Ls[r][c] * s[c];
+        s[r] = t * inv_d[r];
+        q2 += s[r] * s[r];
     }
-    double mx, lse;
-    log_softmax_stats(a.piraw, K, mx, lse);
-    const double logpi = (double)a.piraw[k] - lse;
     if (!BWD) {
+        if (in) {
+            a.Lk[(size_t)k * L * L + lane] = (float)lij;
+            double p = 0.0;
+            const int m = i < j ? i : j;
 #pragma unroll
-        for (int i = 0; i < L; ++i)
-#pragma unroll
-            for (int j = 0; j < L; ++j) {
-                a.Lk[((size_t)k * L + i) * L + j] = (float)Lm[i][j];
-                double p = 0.0;
-                const int m = i < j ? i : j;
-#pragma unroll
-                for (int q = 0; q <= m; ++q) p += Lm[i][q] * Lm[j][q];
-                a.P[((size_t)k * L + i) * L + j] = (float)p;
-            }
-        a.bias[k] = (float)(B + logpi);
+            for (int q = 0; q < L; ++q) p += q <= m ? Ls[i][q] * Ls[j][q] : 0.0;
+            a.P[(size_t)k * L * L + lane] = (float)p;
+        }
+        if (lane == 0) a.bias[k] = (float)(-0.5 * q2 + ld + logpi);
         return;
     }
     // ---- backward
     double u[L];                                        // u = L^-T s = P^-1 h
 #pragma unroll
-    for (int i = L - 1; i >= 0; --i) {
-        double t = s[i];
+    for (int r = L - 1; r >= 0; --r) {
+        double t = s[r];
 #pragma unroll
-        for (int j = i + 1; j < L; ++j) t -= Lm[j][i] * u[j];
-        u[i] = t / Lm[i][i];
+        for (int c = r + 1; c < L; ++c) t -= Ls[c][r] * u[c];
+        u[r] = t * inv_d[r];
     }
+    const double s_gb = wave_sum_d(lane < K ? (double)a.g_bias[lane] : 0.0);
     const double gb = (double)a.g_bias[k];
+    if (lane < L) a.g_mu[k * L + lane] = (float)((double)a.g_hk[k * L + lane] - gb * pick<L>(u, lane));
+    if (lane == 0) a.g_piraw[k] = (float)(gb - exp(logpi) * s_gb);
+    if (in) {
+        double g = 0.0;
+        if (j <= i) {
 #pragma unroll
-    for (int i = 0; i < L; ++i) a.g_mu[k * L + i] = (float)((double)a.g_hk[k * L + i] - gb * u[i]);
-    a.g_piraw[k] = (float)(gb - exp(logpi) * s_gb);
-    const float* __restrict__ G = a.g_P + (size_t)k * L * L;
-    double Gs[L][L];                                    // G + G^T
-#pragma unroll
-    for (int i = 0; i < L; ++i)
-#pragma unroll
-        for (int j = 0; j < L; ++j) Gs[i][j] = (double)G[i * L + j] + (double)G[j * L + i];
-#pragma unroll
-    for (int i = 0; i < L; ++i)
-#pragma unroll
-        for (int j = 0; j < L; ++j) {
-            double g = 0.0;
-            if (j <= i) {
-#pragma unroll
-                for (int q = j; q < L; ++q) g += Gs[i][q] * Lm[q][j];        // (G + G^T) L
-                g += gb * u[i] * s[j];
-                if (i == j) {
-                    g += gb / Lm[i][i];
-                    const double r = (double)a.Lraw[((size_t)k * L + i) * L + i];
-                    g *= 1.0 / (1.0 + exp(-r));         // softplus'
-                }
+            for (int q = 0; q < L; ++q) g += q >= j ? (Gm[i][q] + Gm[q][i]) * Ls[q][j] : 0.0;    // (G + G^T) L
+            g += gb * pick<L>(u, i) * pick<L>(s, j);
+            if (i == j) {
+                g += gb * inv_d[i];
+                const double r = (double)raw[i * L + i];
+                g *= 1.0 / (1.0 + exp(-r));             // softplus'
             }
-            a.g_Lraw[((size_t)k * L + i) * L + j] = (float)g;
         }
+        a.g_Lraw[(size_t)k * L * L + lane] = (float)g;
+    }
 }
 
 struct ThetaArgs {
@@ -156,51 +165,62 @@ struct ThetaArgs {
     int K, L;
 };
 
+// Block per component, lane (i, j) per matrix element as in phi_prep_kernel: the two digammas run side by side in lanes 0
+// and 1, the Cholesky factor is built column by column in LDS (rows in parallel), the columns of its inverse in parallel.
 template <int L>
 __global__ __launch_bounds__(PREP_THREADS) void theta_pack_kernel(ThetaArgs a) {
-    const int k = threadIdx.x, K = a.K;
-    if (k >= K) return;
-    double asum = 0.0;
-    for (int j = 0; j < K; ++j) asum += (double)a.alpha[j] + 1.0;            // dirichlet.natural_to_standard
-    const double elp = digamma_dd((double)a.alpha[k] + 1.0) - digamma_dd(asum);
-    const double beta = (double)a.beta[k], nu = (double)a.vhat[k] - (double)(L + 2);   // niw.natural_to_standard
-    double mv[L], C[L][L];
-#pragma unroll
-    for (int i = 0; i < L; ++i) mv[i] = (double)a.b[k * L + i] / beta;
-#pragma unroll
-    for (int i = 0; i < L; ++i)
-#pragma unroll
-        for (int j = 0; j < L; ++j) C[i][j] = (double)a.A[((size_t)k * L + i) * L + j] - (double)a.b[k * L + i] * mv[j];
-    // E[Sigma] = (nu sym(C)^-1)^-1 = sym(C) / nu  (niw.expected_values); Cholesky, then W = Lc^-1
-    double Lc[L][L];
+    static_assert(L * L <= PREP_THREADS, "one lane per matrix element");
+    const int k = blockIdx.x, lane = threadIdx.x, K = a.K;
+    __shared__ double Cs[L][L + 1];                     // sym(C) / nu, overwritten by its Cholesky factor (lower)
+    __shared__ double inv_d[L];
+    const int i = lane / L, j = lane % L;
+    const bool in = lane < L * L;
+    const double asum = wave_sum_d(lane < K ? (double)a.alpha[lane] + 1.0 : 0.0);            // dirichlet.natural_to_standard
+    const double dg = lane < 2 ? digamma_dd(lane == 0 ? (double)a.alpha[k] + 1.0 : asum) : 0.0;
+    const double elp = __shfl(dg, 0) - __shfl(dg, 1);
+    const double beta = (double)a.beta[k], nu = (double)a.vhat[k] - (double)(L + 2);         // niw.natural_to_standard
     const double inv_nu = 1.0 / nu;
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-#pragma unroll
-        for (int i = j; i < L; ++i) {
-            double t = 0.5 * (C[i][j] + C[j][i]) * inv_nu;
-#pragma unroll
-            for (int q = 0; q < j; ++q) t -= Lc[i][q] * Lc[j][q];
-            Lc[i][j] = (i == j) ? sqrt(t) : t / Lc[j][j];
-        }
+    if (in) {
+        const double bi = (double)a.b[k * L + i], bj = (double)a.b[k * L + j];
+        const double cij = (double)a.A[((size_t)k * L + i) * L + j] - bi * (bj / beta);
+        const double cji = (double)a.A[((size_t)k * L + j) * L + i] - bj * (bi / beta);
+        Cs[i][j] = 0.5 * (cij + cji) * inv_nu;          // E[Sigma] = sym(C) / nu  (niw.expected_values)
     }
-    double kap = -0.5 * L * 1.8378770664093454836 + elp;
+    __syncthreads();
+    // Cholesky: column c; lanes r = lane < L take the rows r >= c; every lane also forms the pivot itself
 #pragma unroll
-    for (int j = 0; j < L; ++j) {                       // column j of Lc^-1
+    for (int c = 0; c < L; ++c) {
+        const int r = lane < L ? lane : c;
+        double t = Cs[r][c], d = Cs[c][c];
+#pragma unroll
+        for (int q = 0; q < c; ++q) {
+            t -= Cs[r][q] * Cs[c][q];
+            d -= Cs[c][q] * Cs[c][q];
+        }
+        const double sd = sqrt(d);
+        __syncthreads();
+        if (lane < L && lane >= c) Cs[lane][c] = lane == c ? sd : t / sd;
+        if (lane == c) inv_d[c] = 1.0 / sd;
+        __syncthreads();
+    }
+    // W = Lc^-1: lane c < L solves for column c
+    double wdiag = 1.0;
+    if (lane < L) {
+        const int c = lane;
         double w[L];
 #pragma unroll
-        for (int i = 0; i < L; ++i) {
-            double t = (i == j) ? 1.0 : 0.0;
+        for (int r = 0; r < L; ++r) {
+            double t = r == c ? 1.0 : 0.0;
 #pragma unroll
-            for (int q = j; q < i; ++q) t -= Lc[i][q] * w[q];
-            w[i] = (i < j) ? 0.0 : t / Lc[i][i];
-            a.W[((size_t)k * L + i) * L + j] = (float)w[i];
+            for (int q = 0; q < r; ++q) t -= Cs[r][q] * w[q];
+            w[r] = r < c ? 0.0 : t * inv_d[r];
+            if (r == c) wdiag = w[r];
+            a.W[((size_t)k * L + r) * L + c] = (float)w[r];
         }
-        kap += log(w[j]);
+        a.m[k * L + lane] = (float)((double)a.b[k * L + lane] / beta);
     }
-#pragma unroll
-    for (int i = 0; i < L; ++i) a.m[k * L + i] = (float)mv[i];
-    a.kappa[k] = (float)kap;
+    const double lw = wave_sum_d(lane < L ? log(wdiag) : 0.0);
+    if (lane == 0) a.kappa[k] = (float)(-0.5 * L * 1.8378770664093454836 + elp + lw);
 }
 
 struct CviArgs {
@@ -307,7 +327,7 @@ int vmp_svae_phi_prep_fwd(const float* mu_k, const float* L_raw, const float* pi
     if (!mu_k || !L_raw || !pi_raw || !Lk || !P || !bias) { set_error("vmp_svae_phi_prep_fwd: NULL argument"); return VMP_E_BADARG; }
     PhiArgs a{};
     a.mu = mu_k; a.Lraw = L_raw; a.piraw = pi_raw; a.Lk = Lk; a.P = P; a.bias = bias; a.K = K; a.L = L;
-#define PREP_CALL(LL) hipLaunchKernelGGL((phi_prep_kernel<LL, false>), dim3(1), dim3(PREP_THREADS), 0, static_cast<hipStream_t>(stream), a)
+#define PREP_CALL(LL) hipLaunchKernelGGL((phi_prep_kernel<LL, false>), dim3(K), dim3(PREP_THREADS), 0, static_cast<hipStream_t>(stream), a)
     PREP_DISPATCH_L(L, PREP_CALL)
 #undef PREP_CALL
     return check_launch("vmp_svae_phi_prep_fwd");
@@ -323,7 +343,7 @@ int vmp_svae_phi_prep_bwd(const float* mu_k, const float* L_raw, const float* pi
     PhiArgs a{};
     a.mu = mu_k; a.Lraw = L_raw; a.piraw = pi_raw; a.g_hk = g_hk; a.g_P = g_P; a.g_bias = g_bias;
     a.g_mu = g_mu; a.g_Lraw = g_Lraw; a.g_piraw = g_piraw; a.K = K; a.L = L;
-#define PREP_CALL(LL) hipLaunchKernelGGL((phi_prep_kernel<LL, true>), dim3(1), dim3(PREP_THREADS), 0, static_cast<hipStream_t>(stream), a)
+#define PREP_CALL(LL) hipLaunchKernelGGL((phi_prep_kernel<LL, true>), dim3(K), dim3(PREP_THREADS), 0, static_cast<hipStream_t>(stream), a)
     PREP_DISPATCH_L(L, PREP_CALL)
 #undef PREP_CALL
     return check_launch("vmp_svae_phi_prep_bwd");
@@ -347,7 +367,7 @@ int vmp_svae_theta_pack(const float* alpha, const float* A, const float* b, cons
     if (int e = prep_check("vmp_svae_theta_pack", K, L)) return e;
     if (!alpha || !A || !b || !beta || !v_hat || !m || !W || !kappa) { set_error("vmp_svae_theta_pack: NULL argument"); return VMP_E_BADARG; }
     ThetaArgs a{alpha, A, b, beta, v_hat, m, W, kappa, K, L};
-#define PREP_CALL(LL) hipLaunchKernelGGL((theta_pack_kernel<LL>), dim3(1), dim3(PREP_THREADS), 0, static_cast<hipStream_t>(stream), a)
+#define PREP_CALL(LL) hipLaunchKernelGGL((theta_pack_kernel<LL>), dim3(K), dim3(PREP_THREADS), 0, static_cast<hipStream_t>(stream), a)
     PREP_DISPATCH_L(L, PREP_CALL)
 #undef PREP_CALL
     return check_launch("vmp_svae_theta_pack");

@@ -9,6 +9,16 @@ def _c(t, name, shape=None):
     return L.dev_f32(t, name, shape)
 
 
+class GradSeed(object):
+    """The upstream gradient a caller will differentiate the ELBO with, announced beforehand: `tensor` (0-dim, on the
+    device) is what it passes as grad_outputs, `value` its content.  FusedElboFn folds the factor into its one backward
+    launch and recognises the tensor by address - no rescaling pass, no host read-back (graph capture)."""
+
+    def __init__(self, value, device):
+        self.value = float(value)
+        self.tensor = torch.full((), float(value), dtype=torch.float32, device=device)
+
+
 class PhiloxNoise(object):
     """Stand-in for the (N,K,L,S) noise tensor: "generate it in the kernel" (csrc/vmp_svae.hip, Philox4x32-10 keyed by
     `seed`; include/vmp_hip.h vmp_svae_estep_fwd_rng).  The reference draws eps inside the step the same way
@@ -385,6 +395,86 @@ class DecoderWeightedLoglikeFn(torch.autograd.Function):
         return (None, dx, A * g) + tuple(grads)
 
 
+_TAIL_WS = {}
+
+
+def _tail_workspace(device):
+    """Zero-initialised scratch of vmp_svae_elbo_tail (block partials + a ticket the kernel resets itself), one per device
+    and stream."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _TAIL_WS.get(key)
+    if ws is None:
+        ws = _TAIL_WS[key] = torch.zeros(L.lib().vmp_svae_elbo_tail_workspace_bytes(), dtype=torch.uint8, device=device)
+    return ws
+
+
+class FusedElboFn(torch.autograd.Function):
+    """(y, x (N,K,S,L), log_z (N,K), T' (N,K), 9 decoder parameters) -> (elbo, rec, reg, r): compute_elbo of reference
+    svae.py:199-262 for the fused decoder in three launches (decoder value + gradients with r = exp(log_z) formed inside
+    the kernel, the reduction of its per-block parameter partials, and the scalar tail) instead of those plus ~24 (N,K)-
+    sized torch launches.  `seed` is the upstream gradient the caller WILL pass for elbo (a 0-dim tensor, e.g. -1 for
+    loss = -elbo; None = +1): the stored gradients are pre-multiplied by it, and backward only rescales - with a few
+    launches - when handed a different tensor.  rec, reg and r are returned for reporting / the M-step and carry no
+    gradient."""
+
+    @staticmethod
+    def forward(ctx, y, x, lz, Tp, seed, sigma, *params):
+        x = _c(x, 'x_k_samples')
+        if x.dim() != 4:
+            raise L.VmpError('x must have shape (N,K,S,L)')
+        N, K, S, _ = x.shape
+        params = [_c(p, n) for p, n in zip(params, DECODER_PARAM_NAMES)]
+        Ld, U, Dy = _decoder_dims(x, params)
+        y = _c(y, 'y', (N, Dy))
+        lz = _c(lz, 'log_z', (N, K))
+        Tp = _c(Tp, 'T_prime', (N, K))
+        f32 = dict(dtype=torch.float32, device=x.device)
+        ll = torch.empty(N, K, S, **f32)
+        dx = torch.empty_like(x)
+        dp = torch.empty(L.lib().vmp_decoder_param_words(Ld, U, Dy), **f32)
+        nbytes = L.lib().vmp_decoder_workspace_bytes(N, K, S, Ld, U, Dy)
+        ws = L.workspace(x.device, nbytes)
+        sigma = float(sigma)
+        L.check(L.lib().vmp_decoder_loglike_bwd_logw(L.ptr(x), L.ptr(y), L.ptr(lz), -sigma * 0.5 / S, *[L.ptr(p) for p in params],
+                                                     N, K, S, Ld, Dy, U, L.ptr(dx), L.ptr(dp), L.ptr(ll), L.ptr(ws), nbytes,
+                                                     L.stream()), 'vmp_decoder_loglike_bwd_logw')
+        scal = torch.empty(3, **f32)
+        g_lz, g_Tp, r = torch.empty(N, K, **f32), torch.empty(N, K, **f32), torch.empty(N, K, **f32)
+        tws = _tail_workspace(x.device)
+        L.check(L.lib().vmp_svae_elbo_tail(L.ptr(lz), L.ptr(Tp), L.ptr(ll), N, K, S, Dy, sigma, L.ptr(scal), L.ptr(g_lz),
+                                           L.ptr(g_Tp), L.ptr(r), L.ptr(tws), tws.numel(), L.stream()), 'vmp_svae_elbo_tail')
+        ctx.save_for_backward(dx, dp, g_lz, g_Tp)
+        ctx.pshapes = [tuple(p.shape) for p in params]
+        ctx.seed, ctx.sigma = seed, sigma
+        elbo, rec, reg = scal[0], scal[1], scal[2]
+        ctx.mark_non_differentiable(rec, reg, r)
+        ctx.set_materialize_grads(False)        # no zero-filled gradients for the three reporting outputs
+        return elbo, rec, reg, r
+
+    @staticmethod
+    def backward(ctx, g, _g_rec, _g_reg, _g_r):
+        dx, dp, g_lz, g_Tp = ctx.saved_tensors
+        if g is None:
+            return (None,) * (6 + len(ctx.pshapes))
+        if not (ctx.seed is not None and g.data_ptr() == ctx.seed.data_ptr()):
+            # the stored gradients are sigma * d elbo and the caller differentiates with another upstream tensor: rescale
+            # (dx is (N,K,S,L)-sized - outside a graph capture one scalar read-back decides whether that pass is needed)
+            if torch.cuda.is_current_stream_capturing():
+                f = g / ctx.sigma
+            else:
+                f = float(g) / ctx.sigma
+            if not (isinstance(f, float) and f == 1.0):
+                dx, dp, g_lz, g_Tp = dx * f, dp * f, g_lz * f, g_Tp * f
+        grads, o = [], 0
+        for shp in ctx.pshapes:
+            n = 1
+            for v in shp:
+                n *= v
+            grads.append(dp[o:o + n].reshape(shp))
+            o += n
+        return (None, dx, g_lz, g_Tp, None, None) + tuple(grads)
+
+
 def decoder_outputs(x, params):
     """(mean, var) of the decoder on x (..., L) through the fused forward kernel (no gradient)."""
     shape = tuple(x.shape)
@@ -414,7 +504,7 @@ class PhiPrepFn(torch.autograd.Function):
         L.check(L.lib().vmp_svae_phi_prep_fwd(L.ptr(mu_k), L.ptr(L_raw), L.ptr(pi_raw), K, Ld, L.ptr(Lk), L.ptr(P),
                                               L.ptr(bias), L.stream()), 'vmp_svae_phi_prep_fwd')
         ctx.save_for_backward(mu_k, L_raw, pi_raw)
-        return mu_k.detach().clone(), P, bias
+        return mu_k.view_as(mu_k), P, bias         # h_k IS mu_k (svae.py:345): a view, not a copy launch
 
     @staticmethod
     def backward(ctx, g_hk, g_P, g_bias):

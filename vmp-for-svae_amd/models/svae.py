@@ -264,12 +264,27 @@ def m_step_smm(smm_prior, r_nk):
     return dirichlet.standard_to_natural(alpha_0 + N_k)
 
 
-def compute_elbo(y, reconstructions, theta, phi_tilde, x_k_samps, log_z_given_y_phi, decoder_type):
-    """reference svae.py:199-262.  Returns (elbo, (neg_rec_err, numerator, denominator, regulariser))."""
+def compute_elbo(y, reconstructions, theta, phi_tilde, x_k_samps, log_z_given_y_phi, decoder_type, grad_seed=None):
+    """reference svae.py:199-262.  Returns (elbo, (neg_rec_err, numerator, denominator, regulariser)).
+    grad_seed (_svae_ops.GradSeed, optional): the upstream gradient the caller will differentiate elbo with (the trainer:
+    -1, loss = -elbo) - lets the fused path skip every rescaling launch."""
     if decoder_type not in ('standard', 'bernoulli'):
         raise NotImplementedError("decoder_type '%s'" % decoder_type)
     if not isinstance(phi_tilde, PhiTilde):
         raise L.VmpError('compute_elbo: phi_tilde must be the object e_step / inference returned')
+    if decoder_type == 'standard' and isinstance(reconstructions, vae.LazyReconstruction):
+        # fused decoder: value, the three scalars and every gradient seed from three launches (_svae_ops.FusedElboFn)
+        if phi_tilde.T_prime is not None and phi_tilde.theta_key == _theta_key(theta):
+            Tp = phi_tilde.T_prime
+        else:
+            Tp = phi_tilde.theta_term(theta, x_k_samps)
+        seed_t = None if grad_seed is None else grad_seed.tensor
+        sigma = 1.0 if grad_seed is None else grad_seed.value
+        elbo, rec, reg, r_nk = _svae_ops.FusedElboFn.apply(y, reconstructions.x, log_z_given_y_phi, Tp, seed_t, sigma,
+                                                          *reconstructions.params)
+        details = ElboDetails(rec, reg, phi_tilde, x_k_samps, log_z_given_y_phi)
+        details.r_nk = r_nk
+        return elbo, details
     r_nk = torch.exp(log_z_given_y_phi)
     if decoder_type == 'bernoulli':                               # svae.py:222-223: out_2 = logits
         rec = vae.expected_bernoulli_loglike(y, reconstructions[1], r_nk=r_nk)
@@ -296,6 +311,7 @@ class ElboDetails(object):
 
     def __init__(self, rec, reg, phi_tilde, x_k, log_z):
         self._rec, self._reg = rec, reg
+        self.r_nk = None            # exp(log_z) when the fused tail produced it (the M-step reuses it)
         self._lazy = (phi_tilde, x_k, log_z)
         self._nd = None
 
@@ -327,10 +343,10 @@ class ElboDetails(object):
         return iter((self[0], self[1], self[2], self[3]))
 
 
-def compute_elbo_smm(y, reconstructions, theta, phi_tilde, x_k_samps, log_z_given_y_phi, decoder_type):
+def compute_elbo_smm(y, reconstructions, theta, phi_tilde, x_k_samps, log_z_given_y_phi, decoder_type, grad_seed=None):
     """reference svae.py:265-322: as compute_elbo with the Student-t density of theta = (alpha, mu_k, L_k, DoF)
     (distributions/student_t.py:7-39); the per-sample densities come from the fused E-step (e_step(theta=theta))."""
-    return compute_elbo(y, reconstructions, theta, phi_tilde, x_k_samps, log_z_given_y_phi, decoder_type)
+    return compute_elbo(y, reconstructions, theta, phi_tilde, x_k_samps, log_z_given_y_phi, decoder_type, grad_seed=grad_seed)
 
 
 def update_gmm_params(current_gmm_params, gmm_params_star, step_size, name='cvi_update_theta'):

@@ -21,7 +21,7 @@ import math
 import torch
 
 from . import _lib as L
-from .models import _mix, svae, vae
+from .models import _mix, _svae_ops, svae, vae
 
 
 def exponential_decay(lr0, global_step, decay_steps, decay_rate):
@@ -40,6 +40,9 @@ class TFAdam(object):
         self.v = [torch.zeros_like(p) for p in self.params]
         self.t = 0
 
+    def _fused_ok(self):
+        return all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in self.params)
+
     def lr_t(self, t):
         return self.lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
 
@@ -47,8 +50,24 @@ class TFAdam(object):
     def apply_gradients(self, grads, lr_t_dev=None):
         """lr_t_dev: the bias-corrected step size as a 0-dim device tensor (graph-captured steps: the caller advances
         self.t and refreshes the tensor before every replay); default: computed here from the step count."""
-        # contiguous gradients with the parameters' strides keep torch on the multi-tensor fast path
         grads = [g.to(p.dtype).contiguous() for g, p in zip(grads, self.params)]
+        if self._fused_ok():
+            # one launch for all tensors (csrc/vmp_step.hip) instead of 7 multi-tensor launches
+            import ctypes
+            n = len(self.params)
+            arr = ctypes.c_void_p * n
+            if lr_t_dev is None:
+                self.t += 1
+                lr_t, lr_p = self.lr_t(self.t), None
+            else:
+                lr_t, lr_p = 0.0, L.ptr(lr_t_dev)
+            L.check(L.lib().vmp_adam_step(n, arr(*[p.data_ptr() for p in self.params]), arr(*[g.data_ptr() for g in grads]),
+                                          arr(*[m.data_ptr() for m in self.m]), arr(*[v.data_ptr() for v in self.v]),
+                                          (ctypes.c_int64 * n)(*[p.numel() for p in self.params]), self.b1, self.b2,
+                                          self.eps, lr_t, lr_p, L.stream()), 'vmp_adam_step')
+            return
+        # torch fallback for what the kernel does not take (non-fp32 / non-contiguous / CPU parameters): contiguous
+        # gradients with the parameters' strides keep torch on the multi-tensor fast path
         torch._foreach_mul_(self.m, self.b1)
         torch._foreach_add_(self.m, grads, alpha=1.0 - self.b1)
         torch._foreach_mul_(self.v, self.b2)
@@ -126,6 +145,7 @@ class SVAETrainer(object):
             self.gmm_prior = self.gmm_prior[0]
         self.global_step = 0
         self.opt = None
+        self._neg_one = None        # GradSeed(-1): the step differentiates loss = -elbo by passing this as grad_outputs
         # the MLP variables are created HERE from `seed` (not lazily by the first forward pass, whose seed also carries the
         # step number and the rank): every replica starts from the same weights
         if not vae.net_variables('encoder_net'):
@@ -164,7 +184,9 @@ class SVAETrainer(object):
                              lazy_decoder=self.fused_decoder, u=u)
         y_rec, phi_enc, x_k, x_s, log_z, _, phi_tilde = out
         elbo_fn = svae.compute_elbo_smm if self.smm else svae.compute_elbo
-        elbo, details = elbo_fn(y, y_rec, self.theta, phi_tilde, x_k, log_z, 'standard')
+        if self._neg_one is None:
+            self._neg_one = _svae_ops.GradSeed(-1.0, self.device)
+        elbo, details = elbo_fn(y, y_rec, self.theta, phi_tilde, x_k, log_z, 'standard', grad_seed=self._neg_one)
         return elbo, details, x_k, x_s, log_z
 
     def step(self, y, noise=None, z_draws=None, chunk=None, u=None, _dev_scalars=None):
@@ -188,9 +210,9 @@ class SVAETrainer(object):
             elbo, details, x_k, x_s, log_z = self.forward(ys, ns, zs, us, chunk_index=ci)
             if params is None:
                 names, params = self.trainables()
-            g = torch.autograd.grad(-elbo, params, allow_unused=True)
+            g = torch.autograd.grad(elbo, params, grad_outputs=self._neg_one.tensor, allow_unused=True)   # loss = -elbo
             g = [torch.zeros_like(p) if gi is None else gi for gi, p in zip(g, params)]
-            r_nk = torch.exp(log_z.detach())
+            r_nk = details.r_nk if details.r_nk is not None else torch.exp(log_z.detach())
             if self.smm:                                                              # svae.m_step_smm: N_k only
                 from .models import gmm as _gmm
                 st = _gmm.update_Nk(r_nk.contiguous()).double().reshape(-1, 1)
@@ -199,7 +221,10 @@ class SVAETrainer(object):
             grads = g if grads is None else [a + b for a, b in zip(grads, g)]
             stats = st if stats is None else stats + st
             rec, reg = details[0], details[3]                # the two debug scalars in between are computed on access only
-            elbo_t, rec_t, reg_t = elbo_t + elbo.detach(), rec_t + rec.detach(), reg_t + reg.detach()
+            if ci == 0:
+                elbo_t, rec_t, reg_t = elbo.detach(), rec.detach(), reg.detach()
+            else:
+                elbo_t, rec_t, reg_t = elbo_t + elbo.detach(), rec_t + rec.detach(), reg_t + reg.detach()
             if rows <= chunk:
                 keep = dict(log_z=log_z.detach(), x_samples=x_s.detach(), x_k=x_k.detach())
             del elbo, details, x_k, x_s, log_z
