@@ -58,7 +58,16 @@ struct DecArgs {
     unsigned K, S;
     int L, Dy, U;
     int split;             // backward: % of a SIMD pair's tiles that go to the older wave (see dec_bwd_kernel)
+    int red_one;           // backward epilogue: all 8 waves' slabs fit the LDS at once (one round instead of two)
+#ifdef VMP_DEBUG_TS
+    long long* dbg_t;      // exploration builds only (tools/build_variant.sh ts -DVMP_DEBUG_TS): stage stamps of block 0, thread 0
+#endif
 };
+#ifdef VMP_DEBUG_TS
+#define DEC_TS(i) do { if (a.dbg_t && blockIdx.x == 0 && threadIdx.x == 0) { a.dbg_t[i] = clock64(); a.dbg_t[32 + (i)] = wall_clock64(); } } while (0)
+#else
+#define DEC_TS(i) do { } while (0)
+#endif
 
 struct DecGeo {
     int oW0, ob0, oW1, ob1, oW2, ob2, oWs, obs1, obs2, PW;
@@ -172,6 +181,11 @@ __device__ __forceinline__ f32x4 tanh4(f32x4 z) { return f32x4{tanh1(z[0]), tanh
 // hidden unit behind k-slot j of lane group g in k-block kb
 __device__ __forceinline__ int kslot_unit(int g, int j, int kb) { return 16 * (2 * kb + (j >> 2)) + 4 * g + (j & 3); }
 
+// Two phases: every global load of the thread is ISSUED first (fully unrolled, values held in registers), then the values
+// are split and stored.  Interleaved (load - split - store per element, as this function first was) a thread paid one
+// exposed L2 / HBM round trip per loop iteration and phase - about 10 of them in the backward kernel - which is most of
+// the run time of a one-tile-per-wave launch (the reference's minibatches of 64-100 rows); at C3 sizes the fill is
+// amortised over thousands of tiles either way.
 template <int UT, bool BWD, int THREADS>
 __device__ void fill_images(float* __restrict__ sm, const DecArgs& a) {
     using I = Img<UT>;
@@ -179,87 +193,149 @@ __device__ void fill_images(float* __restrict__ sm, const DecArgs& a) {
     unsigned* __restrict__ smu = reinterpret_cast<unsigned*>(sm);
     const int L = a.L, U = a.U, Dy = a.Dy;
     const int tid = threadIdx.x;
+    constexpr int N1 = (BWD ? 2 : 1) * UT * KB * 256, IT1 = N1 / THREADS;      // F1 (+ B2)
+    constexpr int N2 = (BWD ? 2 : 1) * KB * 256, IT2 = N2 / THREADS;           // F2 (+ B3)
+    constexpr int N0 = (UT + 1) * 64, IT0 = (N0 + THREADS - 1) / THREADS;      // F0 + F2S, B1 + B3S
+    static_assert(N1 % THREADS == 0 && N2 % THREADS == 0, "whole iterations");
+    // ---- phase 1: loads
     // F0: A[i = unit 16t'+c][dims g, 4+g] = W0[dim][unit]; F2S: A[i = slot c][dims g, 4+g] = Ws[dim][d] for the mean slots
-    for (int i = tid; i < (UT + 1) * 64; i += THREADS) {
+    v2f w0[IT0];
+#pragma unroll
+    for (int it = 0; it < IT0; ++it) {
+        const int i = tid + it * THREADS;
         const int l = i & 63, tp = i >> 6, g = l >> 4, c = l & 15;
-        v2f w;
-        if (tp < UT) {
-            const int unit = 16 * tp + c;
-            w[0] = (g < L && unit < U) ? a.W0[g * U + unit] : 0.f;
-            w[1] = (4 + g < L && unit < U) ? a.W0[(4 + g) * U + unit] : 0.f;
-        } else {
-            const int d = slot_d(c), ty = slot_ty(c);
-            w[0] = (g < L && d < Dy && ty == 0) ? a.Ws[g * Dy + d] : 0.f;
-            w[1] = (4 + g < L && d < Dy && ty == 0) ? a.Ws[(4 + g) * Dy + d] : 0.f;
+        v2f w{0.f, 0.f};
+        if (i < N0) {
+            if (tp < UT) {
+                const int unit = 16 * tp + c;
+                w[0] = (g < L && unit < U) ? a.W0[g * U + unit] : 0.f;
+                w[1] = (4 + g < L && unit < U) ? a.W0[(4 + g) * U + unit] : 0.f;
+            } else {
+                const int d = slot_d(c), ty = slot_ty(c);
+                w[0] = (g < L && d < Dy && ty == 0) ? a.Ws[g * Dy + d] : 0.f;
+                w[1] = (4 + g < L && d < Dy && ty == 0) ? a.Ws[(4 + g) * Dy + d] : 0.f;
+            }
         }
+        w0[it] = w;
+    }
+    // F1: A[i = out 16t'+c][k-slot -> in] = W1[in][out];  B2: A[i = in 16t'+c][k-slot -> out] = W1[in][out]
+    v2f w1[IT1];
+#pragma unroll
+    for (int it = 0; it < IT1; ++it) {
+        const int i = tid + it * THREADS;
+        const int dw = i & 3, l = (i >> 2) & 63, e0 = i >> 8, bw = e0 >= UT * KB, e = bw ? e0 - UT * KB : e0;
+        const int kb = e % KB, tp = e / KB, g = l >> 4, c = l & 15;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = 2 * dw + h, ku = kslot_unit(g, j, kb), mu = 16 * tp + c;
+            const int in = bw ? mu : ku, out = bw ? ku : mu;
+            w1[it][h] = (ku < 16 * UT && in < U && out < U) ? a.W1[in * U + out] : 0.f;
+        }
+    }
+    // F2: A[i = slot c][k-slot -> unit] = W2[unit][ty*Dy + d];  B3: A[i = dim c][k-slot -> unit] = W0[dim][unit]
+    v2f w2[IT2];
+#pragma unroll
+    for (int it = 0; it < IT2; ++it) {
+        const int i = tid + it * THREADS;
+        const int dw = i & 3, l = (i >> 2) & 63, e0 = i >> 8, bw = e0 >= KB, kb = bw ? e0 - KB : e0, g = l >> 4, c = l & 15;
+        const int d = slot_d(c), ty = slot_ty(c);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int unit = kslot_unit(g, 2 * dw + h, kb);
+            if (bw) w2[it][h] = (unit < U && c < L) ? a.W0[c * U + unit] : 0.f;
+            else w2[it][h] = (unit < U && d < Dy) ? a.W2[unit * 2 * Dy + ty * Dy + d] : 0.f;
+        }
+    }
+    // B1: A[i = unit 16t'+c][slots 4g..4g+3] = W2[unit][o(slot)];  B3S: A[i = dim c][slots 4g..4g+3] = Ws[dim][d], mean slots
+    v2f w3[BWD ? IT0 : 1][2];
+    if (BWD) {
+#pragma unroll
+        for (int it = 0; it < IT0; ++it) {
+            const int i = tid + it * THREADS;
+            const int l = i & 63, tp = i >> 6, g = l >> 4, c = l & 15;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                v2f w{0.f, 0.f};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int m = 4 * g + 2 * p + h, d = slot_d(m), ty = slot_ty(m);
+                    if (i < N0) {
+                        if (tp < UT) w[h] = (16 * tp + c < U && d < Dy) ? a.W2[(16 * tp + c) * 2 * Dy + ty * Dy + d] : 0.f;
+                        else w[h] = (c < L && d < Dy && ty == 0) ? a.Ws[c * Dy + d] : 0.f;
+                    }
+                }
+                w3[it][p] = w;
+            }
+        }
+    }
+    float bias0[(16 * UT + THREADS - 1) / THREADS], bias1[(16 * UT + THREADS - 1) / THREADS];
+#pragma unroll
+    for (int it = 0; it < (16 * UT + THREADS - 1) / THREADS; ++it) {
+        const int i = tid + it * THREADS;
+        bias0[it] = i < U ? a.b0[i] : 0.f;
+        bias1[it] = i < U ? a.b1[i] : 0.f;
+    }
+    float bo = 0.f, bsp = 0.f;
+    if (tid < 16) {
+        const int d = slot_d(tid), ty = slot_ty(tid);
+        bo = d < Dy ? (ty == 0 ? a.b2[d] + a.bs1[d] : a.b2[Dy + d]) : 0.f;
+    }
+    if (tid < 8) bsp = tid < Dy ? a.bs2[tid] : 0.f;
+    // ---- phase 2: split and store
+#pragma unroll
+    for (int it = 0; it < IT0; ++it) {
+        const int i = tid + it * THREADS;
+        if (i >= N0) break;
+        const int l = i & 63, tp = i >> 6;
         unsigned t3[3];
-        split_bf16<3>(w, t3);
+        split_bf16<3>(w0[it], t3);
         unsigned* __restrict__ pa = smu + (tp < UT ? I::F0A + (tp * 64 + l) * 4 : I::F2SA + l * 4);
         unsigned* __restrict__ pb = smu + (tp < UT ? I::F0B + (tp * 64 + l) * 2 : I::F2SB + l * 2);
         pa[0] = t3[0]; pa[1] = t3[1]; pa[2] = t3[2]; pa[3] = t3[0];
         pb[0] = t3[1]; pb[1] = t3[0];
     }
-    // F1: A[i = out 16t'+c][k-slot -> in] = W1[in][out];  B2: A[i = in 16t'+c][k-slot -> out] = W1[in][out]
-    for (int i = tid; i < (BWD ? 2 : 1) * UT * KB * 256; i += THREADS) {
-        const int dw = i & 3, l = (i >> 2) & 63, e0 = i >> 8, bw = e0 >= UT * KB, e = bw ? e0 - UT * KB : e0;
-        const int kb = e % KB, tp = e / KB, g = l >> 4, c = l & 15;
-        v2f w;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int j = 2 * dw + h, ku = kslot_unit(g, j, kb), mu = 16 * tp + c;
-            const int in = bw ? mu : ku, out = bw ? ku : mu;
-            w[h] = (ku < 16 * UT && in < U && out < U) ? a.W1[in * U + out] : 0.f;
-        }
+    for (int it = 0; it < IT1; ++it) {
+        const int i = tid + it * THREADS;
+        const int dw = i & 3, l = (i >> 2) & 63, e0 = i >> 8, bw = e0 >= UT * KB, e = bw ? e0 - UT * KB : e0;
         unsigned t3[3];
-        split_bf16<3>(w, t3);
+        split_bf16<3>(w1[it], t3);
 #pragma unroll
         for (int term = 0; term < 3; ++term) smu[(bw ? I::B2 : I::F1) + ((e * 3 + term) * 64 + l) * 4 + dw] = t3[term];
     }
-    // F2: A[i = slot c][k-slot -> unit] = W2[unit][ty*Dy + d];  B3: A[i = dim c][k-slot -> unit] = W0[dim][unit]
-    for (int i = tid; i < (BWD ? 2 : 1) * KB * 256; i += THREADS) {
-        const int dw = i & 3, l = (i >> 2) & 63, e0 = i >> 8, bw = e0 >= KB, kb = bw ? e0 - KB : e0, g = l >> 4, c = l & 15;
-        const int d = slot_d(c), ty = slot_ty(c);
-        v2f w;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int unit = kslot_unit(g, 2 * dw + h, kb);
-            if (bw) w[h] = (unit < U && c < L) ? a.W0[c * U + unit] : 0.f;
-            else w[h] = (unit < U && d < Dy) ? a.W2[unit * 2 * Dy + ty * Dy + d] : 0.f;
-        }
+    for (int it = 0; it < IT2; ++it) {
+        const int i = tid + it * THREADS;
+        const int dw = i & 3, l = (i >> 2) & 63, e0 = i >> 8, bw = e0 >= KB, kb = bw ? e0 - KB : e0;
         unsigned t3[3];
-        split_bf16<3>(w, t3);
+        split_bf16<3>(w2[it], t3);
 #pragma unroll
         for (int term = 0; term < 3; ++term) smu[(bw ? I::B3 : I::F2) + ((kb * 3 + term) * 64 + l) * 4 + dw] = t3[term];
     }
-    for (int i = tid; i < 16 * UT; i += THREADS) {
-        sm[I::BIAS0 + i] = i < U ? a.b0[i] : 0.f;
-        sm[I::BIAS1 + i] = i < U ? a.b1[i] : 0.f;
+#pragma unroll
+    for (int it = 0; it < (16 * UT + THREADS - 1) / THREADS; ++it) {
+        const int i = tid + it * THREADS;
+        if (i < 16 * UT) {
+            sm[I::BIAS0 + i] = bias0[it];
+            sm[I::BIAS1 + i] = bias1[it];
+        }
     }
-    if (tid < 16) {
-        const int d = slot_d(tid), ty = slot_ty(tid);
-        sm[I::BIASO + tid] = d < Dy ? (ty == 0 ? a.b2[d] + a.bs1[d] : a.b2[Dy + d]) : 0.f;
-    }
+    if (tid < 16) sm[I::BIASO + tid] = bo;
     if (tid < 8) {
-        const float b = tid < Dy ? a.bs2[tid] : 0.f;
-        sm[I::SP2 + tid] = log1p_f(expf(b));            // the reference's naive form (vae.py:116)
-        sm[I::SG2 + tid] = 1.0f / (1.0f + expf(-b));
+        sm[I::SP2 + tid] = log1p_f(expf(bsp));          // the reference's naive form (vae.py:116)
+        sm[I::SG2 + tid] = 1.0f / (1.0f + expf(-bsp));
     }
     if (BWD) {
-        // B1: A[i = unit 16t'+c][slots 4g..4g+3] = W2[unit][o(slot)];  B3S: A[i = dim c][slots 4g..4g+3] = Ws[dim][d], mean slots
-        for (int i = tid; i < (UT + 1) * 64; i += THREADS) {
-            const int l = i & 63, tp = i >> 6, g = l >> 4, c = l & 15;
+#pragma unroll
+        for (int it = 0; it < IT0; ++it) {
+            const int i = tid + it * THREADS;
+            if (i >= N0) break;
+            const int l = i & 63, tp = i >> 6;
             unsigned th[2], tm[2], tl[2];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                v2f w;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int m = 4 * g + 2 * p + h, d = slot_d(m), ty = slot_ty(m);
-                    if (tp < UT) w[h] = (16 * tp + c < U && d < Dy) ? a.W2[(16 * tp + c) * 2 * Dy + ty * Dy + d] : 0.f;
-                    else w[h] = (c < L && d < Dy && ty == 0) ? a.Ws[c * Dy + d] : 0.f;
-                }
                 unsigned t3[3];
-                split_bf16<3>(w, t3);
+                split_bf16<3>(w3[it][p], t3);
                 th[p] = t3[0]; tm[p] = t3[1]; tl[p] = t3[2];
             }
             unsigned* __restrict__ q = smu + (tp < UT ? I::B1 + (tp * 2 * 64 + l) * 4 : I::B3S + l * 4);
@@ -546,10 +622,12 @@ __device__ __forceinline__ u32x4 trb_read(const unsigned char* __restrict__ p) {
 // and it saves 34 of 195 MFMAs and 64 of 840 VALU instructions per 16-row tile.  Small batches keep BT = 3.
 template <int UT, bool FS, bool GIN, int BT>
 __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
+    DEC_TS(0);
     extern __shared__ __attribute__((aligned(16))) float sm[];
     using I = Img<UT>;
     constexpr int KB = I::KB;
     fill_images<UT, true, BWD_THREADS>(sm, a);
+    DEC_TS(1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
     float* __restrict__ scr = sm + I::SCR + wave * (I::XSZ + I::PSZ + I::QSZ);
     unsigned char* __restrict__ scrXb = reinterpret_cast<unsigned char*>(scr);
@@ -598,6 +676,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
     const unsigned p0 = min(b0 + (wave & 3) * tpp, b1), p1 = min(p0 + tpp, b1);
     const unsigned pm = min(p0 + (tpp >= 8u ? (tpp * (unsigned)a.split + 50u) / 100u : (tpp + 1u) / 2u), p1);   // few tiles: even shares
     const unsigned t0 = wave < 4 ? p0 : pm, t1 = wave < 4 ? pm : p1;
+    DEC_TS(2);
     // per-tile inputs of a lane: x[row c][g], x[row c][4+g] and either (gA, y) or the two upstream gradient pairs; the
     // NEXT tile's are fetched while the current tile is processed
     struct TileIn {
@@ -795,32 +874,54 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
     // ---- reduce the per-wave accumulators through LDS.  Every parameter index is owned by exactly one (lane,
     // register) of a wave, so each wave drops its accumulators into a slab of its own with plain stores (a turn-taking
     // read-modify-write over 8 waves cost ~50 us per launch - most of the kernel at minibatch sizes); then all threads
-    // sum the slabs in wave order (deterministic).  Two rounds of BWD_WAVES/2 slabs stay inside the LDS allocation.
+    // sum the slabs in wave order (deterministic).  One round when the 8 slabs fit the LDS (a.red_one: U <= 50 or so),
+    // else two rounds of 4 - the same sequence of additions either way.  (At minibatch sizes this epilogue is a third of
+    // the launch, and the two rounds ran one after the other: 8.0 of 16.7 us for the encoder's backward at 64 rows.)
     const DecGeo q = dec_geo(L, U, Dy);
     __syncthreads();                                    // everybody is done with the operand images
-    constexpr int HALF = BWD_WAVES / 2;
+    DEC_TS(3);
+    const int HALF = a.red_one ? BWD_WAVES : BWD_WAVES / 2;
     float* __restrict__ accum = sm;
-    for (int round = 0; round < 2; ++round) {
-        if (wave / HALF == round) {
+    // waves without a tile (few-tile launches) hold all-zero accumulators: they neither store a slab nor are they read
+    unsigned has = 0;
+#pragma unroll
+    for (int w = 0; w < BWD_WAVES; ++w) {
+        const unsigned wp0 = min(b0 + (w & 3) * tpp, b1), wp1 = min(wp0 + tpp, b1);
+        const unsigned wpm = min(wp0 + (tpp >= 8u ? (tpp * (unsigned)a.split + 50u) / 100u : (tpp + 1u) / 2u), wp1);
+        if ((w < 4 ? wpm - wp0 : wp1 - wpm) > 0) has |= 1u << w;
+    }
+    for (int round = 0; round < BWD_WAVES / HALF; ++round) {
+        if (wave / HALF == round && ((has >> wave) & 1u)) {
             float* __restrict__ slab = sm + (1 + wave % HALF) * q.PW;
+            // Padding elements (units >= U, dims >= L ...) go to a dump word behind the last slab through an index
+            // select, not around a branch: with ~100 conditional stores the exec-mask bookkeeping was 15 instructions
+            // per store, SGPR spills included (1800 instructions: 3.5 us per launch at minibatch sizes).
+            const int dump = (1 + HALF) * q.PW - (1 + wave % HALF) * q.PW;
+            const int base1 = q.oW1 + 4 * g * U + c;
 #pragma unroll
             for (int ti = 0; ti < UT; ++ti)
 #pragma unroll
-                for (int tj = 0; tj < UT; ++tj)
+                for (int v = 0; v < 4; ++v) {
+                    const bool okin = 16 * ti + 4 * g + v < U;
+#pragma unroll
+                    for (int tj = 0; tj < UT; ++tj) {
+                        const bool ok = okin && 16 * tj + c < U;
+                        slab[ok ? base1 + (16 * ti + v) * U + 16 * tj : dump] = aW1[ti][tj][v];
+                    }
+                }
+            {
+                const int d = slot_d(c), ty = slot_ty(c);
+                const int base2 = q.oW2 + 4 * g * 2 * Dy + ty * Dy + d, base0 = q.oW0 + 4 * g * U + c;
+#pragma unroll
+                for (int t = 0; t < UT; ++t)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        const int in = 16 * ti + 4 * g + v, out = 16 * tj + c;
-                        if (in < U && out < U) slab[q.oW1 + in * U + out] = aW1[ti][tj][v];
+                        const bool ok2 = 16 * t + 4 * g + v < U && d < Dy;
+                        slab[ok2 ? base2 + (16 * t + v) * 2 * Dy : dump] = aW2[t][v];
+                        const bool ok0 = 4 * g + v < L && 16 * t + c < U;
+                        slab[ok0 ? base0 + v * U + 16 * t : dump] = aW0[t][v];
                     }
-#pragma unroll
-            for (int t = 0; t < UT; ++t)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int unit = 16 * t + 4 * g + v, d = slot_d(c), ty = slot_ty(c);
-                    if (unit < U && d < Dy) slab[q.oW2 + unit * 2 * Dy + ty * Dy + d] = aW2[t][v];
-                    const int dim = 4 * g + v, u2 = 16 * t + c;
-                    if (dim < L && u2 < U) slab[q.oW0 + dim * U + u2] = aW0[t][v];
-                }
+            }
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int dim = 4 * g + v, d = slot_d(c), ty = slot_ty(c);
@@ -864,17 +965,33 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
                 if (c == 0 && d < Dy) slab[q.obs2 + d] = s2_;
             }
         }
+        if (round == 0) DEC_TS(6);
         __syncthreads();
-        for (int i = threadIdx.x; i < q.PW; i += BWD_THREADS) {
-            float t = round ? accum[i] : 0.f;
+        if (round == 0) DEC_TS(7);
+        // four parameters per thread and pass: their slab reads are in flight together
+        for (int i0 = threadIdx.x; i0 < q.PW; i0 += 4 * BWD_THREADS) {
+            float t[4];
+            int ix[4];
 #pragma unroll
-            for (int w = 0; w < HALF; ++w) t += sm[(1 + w) * q.PW + i];
-            accum[i] = t;
+            for (int u = 0; u < 4; ++u) {
+                ix[u] = i0 + u * BWD_THREADS < q.PW ? i0 + u * BWD_THREADS : i0;
+                t[u] = round ? accum[ix[u]] : 0.f;
+            }
+            for (int w = 0; w < HALF; ++w) {
+                if (!((has >> (round * HALF + w)) & 1u)) continue;            // wave-uniform
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] += sm[(1 + w) * q.PW + ix[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * BWD_THREADS < q.PW) accum[i0 + u * BWD_THREADS] = t[u];
         }
         __syncthreads();
     }
     // sigmoid(bs2) factor of d/d bs2 log1p(exp(bs2)) is applied by the reduce kernel
+    DEC_TS(4);
     for (int i = threadIdx.x; i < q.PW; i += BWD_THREADS) a.part[(size_t)blockIdx.x * q.PW + i] = accum[i];
+    DEC_TS(5);
 }
 
 struct DecRedArgs {
@@ -908,11 +1025,20 @@ int dec_blocks(long long rows, int waves_per_block, int max_blocks) {
     if (b < 1) b = 1;
     return (int)b;
 }
+#ifdef VMP_DEBUG_TS
+static long long* g_dbg_dec = nullptr;
+#endif
 int dec_fwd_blocks(long long rows) {
     constexpr int bpc = 16;   // blocks per CU: 4 are resident (82 VGPRs, 39 KB LDS), the rest back-fill as the older blocks - which the sequencer favours - finish (2 -> 4 -> 16: 4.5 -> 3.9 -> 3.5 ms per 4.2e7 rows)
     return dec_blocks(rows, FWD_THREADS / WAVE, 256 * bpc);
 }
-int dec_bwd_blocks(long long rows) { return dec_blocks(rows, BWD_WAVES, 256); }            // 1 block per CU
+// 1 block per CU.  Few tiles (<= 4 per CU): one tile per SIMD - waves 0-3 of a block take one each and waves 4-7 none, so
+// that a block's epilogue (every wave with work stores a PW-word slab, then the slabs are summed) runs with one wave per
+// SIMD and four slabs; with 8 one-tile waves per block it was 40 % of the launch at the reference's minibatch sizes.
+int dec_bwd_blocks(long long rows) {
+    const long long tiles = (rows + 15) / 16;
+    return tiles <= 4 * 256 ? dec_blocks(rows, BWD_WAVES / 2, 256) : dec_blocks(rows, BWD_WAVES, 256);
+}
 
 int dec_check(const char* what, long long N, int K, int S, int L, int Dy, int U) {
     if (N < 0 || K < 1 || S < 1 || L < 1 || L > 8 || Dy < 1 || Dy > 8 || U < 1 || U > 64) {
@@ -941,9 +1067,14 @@ template <bool GIN>
 int dec_bwd_launch(const DecArgs& a0, int blocks, hipStream_t s) {
     // measured optimum at 4.2e7 rows: 58 % for U = 50 (10.0 -> 9.3 ms), 54 % for U = 64 (11.8 -> 11.3 ms)
     DecArgs a = a0;
+#ifdef VMP_DEBUG_TS
+    a.dbg_t = g_dbg_dec;
+#endif
     a.split = (a0.U & 15) ? 58 : 54;
     const int U = a.U;
-    const int red_floats = (1 + BWD_WAVES / 2) * dec_geo(a.L, a.U, a.Dy).PW;     // epilogue: accumulator + 4 slabs
+    const int PWl = dec_geo(a.L, a.U, a.Dy).PW;
+    a.red_one = ((size_t)(1 + BWD_WAVES) * PWl + 64) * sizeof(float) <= 160u * 1024u;     // accumulator + 8 slabs inside the CU's LDS
+    const int red_floats = (1 + (a.red_one ? BWD_WAVES : BWD_WAVES / 2)) * PWl + 64;   // epilogue: accumulator + slabs + dump word
 #ifndef VMP_DEC_BT2_ROWS
 #define VMP_DEC_BT2_ROWS (1u << 19)   // sample rows from which the backward data path uses 2-term operands (0xffffffff: never)
 #endif
@@ -1000,6 +1131,9 @@ int decoder_loglike_bwd_impl(const char* what, float logw, const float* x, const
 
 extern "C" {
 
+#ifdef VMP_DEBUG_TS
+void vmp_debug_set_decoder_timestamps(long long* p) { g_dbg_dec = p; }    // exploration builds only (tools/dec_ts.py)
+#endif
 int vmp_decoder_param_words(int L, int U, int Dy) { return dec_geo(L, U, Dy).PW; }
 
 size_t vmp_decoder_workspace_bytes(int64_t N, int K, int S, int L, int U, int Dy) {

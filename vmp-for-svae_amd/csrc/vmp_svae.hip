@@ -24,6 +24,7 @@ using namespace vmp;
 
 namespace {
 
+constexpr int SV_AST = 65;          // row stride of the generic backward kernel's LDS accumulators (see there)
 constexpr int SV_NW = 4;            // waves per block (backward); forward: as many as the LDS noise tiles allow
 constexpr int SV_FWD_MAX_NW = 8;
 constexpr int SV_MAX_BLOCKS = 2048;
@@ -46,6 +47,9 @@ struct EFwdArgs {
     long long N;
     int K, S, vec_ok;
     unsigned long long seed;   // in-kernel noise (noise == NULL): Philox4x32-10 key
+#ifdef VMP_DEBUG_TS
+    long long* dbg_t;
+#endif
 };
 
 template <int L>
@@ -111,6 +115,7 @@ __device__ __forceinline__ float row_sum(float v, float* scr, int lane, int rbas
     scr[lane] = v;
     __builtin_amdgcn_wave_barrier();
     float s = 0.f;
+#pragma unroll 4                                     // reads issued ahead of the (in-order) adds: one LDS latency per 4 values, not per value
     for (int j = 0; j < K; ++j) s += scr[rbase + j];
     __builtin_amdgcn_wave_barrier();
     return s;
@@ -120,6 +125,7 @@ __device__ __forceinline__ float row_max(float v, float* scr, int lane, int rbas
     scr[lane] = v;
     __builtin_amdgcn_wave_barrier();
     float m = -INFINITY;
+#pragma unroll 4
     for (int j = 0; j < K; ++j) m = fmaxf(m, scr[rbase + j]);
     __builtin_amdgcn_wave_barrier();
     return m;
@@ -147,9 +153,24 @@ struct EBwdArgs {
     float* partials;        // (nblk, K, 2(L+TRI+1)): g_hk | g_Pk (lower, symmetric gradient) | g_bias | g_mk | g_Wk (lower) | g_kappa
     long long N;
     int K, S, vec_ok;
+#ifdef VMP_DEBUG_TS
+    long long* dbg_t;       // exploration builds only (tools/build_variant.sh ts -DVMP_DEBUG_TS): stage time stamps of block 0, wave 0
+#endif
 };
+#ifdef VMP_DEBUG_TS
+#define SV_TS(i) do { if (a.dbg_t && blockIdx.x == 0 && threadIdx.x == 0) { a.dbg_t[i] = clock64(); a.dbg_t[32 + (i)] = wall_clock64(); } } while (0)
+#define SV_USE(v) asm volatile("" :: "v"(v))
+#else
+#define SV_TS(i) do { } while (0)
+#define SV_USE(v) do { } while (0)
+#endif
 
-template <int L>
+// ONE = every wave owns at most one tile (small batches: the reference's minibatches of 64-100 rows).  Nothing can then
+// be overlapped ACROSS tiles, and the kernel as written for streaming pays its memory round trips one after the other
+// (P_k table, parameters, eta, upstream gradients, first sample pair: 60 % of the wave's cycles were waits at N = 64).
+// The ONE form requests every per-cell input - eta, the (N,K) gradients and the first TWO sample pairs - before the
+// block's P_k table is staged, and keeps two pairs in flight in the sample loop.
+template <int L, bool ONE>
 __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a) {
     constexpr int TRI = SvGeo<L>::TRI;
     constexpr int PW = 2 * (L + TRI + 1);
@@ -163,23 +184,81 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
     float* pk_lds = smem;                                   // [K][PSTR]  lower triangle of P_k
     float* scr = smem + K * PSTR + wave * WAVE;
     const int PWa = (a.nu != nullptr) ? PW : TH;            // accumulator rows in use (theta-side sums only for Student-t)
-    float* red = smem + K * PSTR + nw * WAVE;               // block reduction scratch [PWa][64]
-    float* accl = red + PWa * WAVE + wave * (PWa * WAVE);   // this wave's accumulators [PWa][64], lane-private columns
+    // row stride 65, not 64: the epilogue reads these arrays ACROSS rows (lane <-> row index), and with a stride of 64
+    // words every lane of such a read hits the same LDS bank (measured: 8 us of a 28 us launch at N = 64)
+    constexpr int AST = SV_AST;
+    float* rows = smem + K * PSTR + nw * WAVE + wave * (2 * L * AST);   // this wave's row-sum scratch [2L][65]
+    float* acc0 = smem + K * PSTR + nw * WAVE + nw * (2 * L * AST);
+    float* accl = acc0 + wave * (PWa * AST);                // this wave's accumulators [PWa][65], lane-private columns
     const bool lane_on = lane < CT;
     const int r = lane / K, k = lane - r * K, rbase = lane_on ? r * K : 0;
-
-    for (int e = threadIdx.x; e < K * TRI; e += blockDim.x) {
-        const int kk = e / TRI, idx = e - kk * TRI;
-        int i = 0;
-        while (tri(i + 1, 0) <= idx) ++i;
-        const int j = idx - tri(i, 0);
-        pk_lds[kk * PSTR + idx] = a.Pk[(kk * L + i) * L + j];
+    const int kc = lane_on ? k : 0;                         // unconditional loads from clamped indices + selects
+    const long long ntiles = (a.N + RPT - 1) / RPT;
+    SV_TS(0);
+    const float invS = 1.0f / (float)S;
+    float nxs[2 * L], ngx[2 * L];
+    float nxs2[ONE ? 2 * L : 1], ngx2[ONE ? 2 * L : 1];     // ONE: the pair after next
+    float pe1[ONE ? L : 1], pe2[ONE ? L : 1], pg[3] = {0.f, 0.f, 0.f};
+    // Rows are fetched TWO samples at a time: 2*L floats = one 64-byte segment per array per lane, requested by
+    // back-to-back loads.  Fetching a single 32-byte row per iteration made every row its own L2 request (the
+    // other half of the segment is evicted from the 32 KiB L1 before the next sample needs it): 329 M requests
+    // of ~31 B per launch at C3 (TCP_TCC_READ_REQ), i.e. the kernel was bound by L1<->L2 requests, not by HBM.
+    // (one branch around the whole group of loads: skipping the tail prefetches matters - an unconditional
+    //  clamped version measured 27% slower)
+    auto load_pair = [&](const float* __restrict__ xc, const float* __restrict__ gc, bool on, int s2,
+                         float (&xo)[2 * L], float (&go)[2 * L]) {
+        const bool live = on && s2 < S;
+        const bool both = s2 + 1 < S;
+        if (live) {
+            if ((L & 3) == 0 && a.vec_ok) {
+#pragma unroll
+                for (int q = 0; q < L / 4; ++q) {
+                    const float4 v = reinterpret_cast<const float4*>(xc + s2 * L)[q];
+                    const float4 w = reinterpret_cast<const float4*>(gc + s2 * L)[q];
+                    xo[4 * q] = v.x; xo[4 * q + 1] = v.y; xo[4 * q + 2] = v.z; xo[4 * q + 3] = v.w;
+                    go[4 * q] = w.x; go[4 * q + 1] = w.y; go[4 * q + 2] = w.z; go[4 * q + 3] = w.w;
+                }
+                if (both) {
+#pragma unroll
+                    for (int q = 0; q < L / 4; ++q) {
+                        const float4 v = reinterpret_cast<const float4*>(xc + (s2 + 1) * L)[q];
+                        const float4 w = reinterpret_cast<const float4*>(gc + (s2 + 1) * L)[q];
+                        xo[L + 4 * q] = v.x; xo[L + 4 * q + 1] = v.y; xo[L + 4 * q + 2] = v.z; xo[L + 4 * q + 3] = v.w;
+                        go[L + 4 * q] = w.x; go[L + 4 * q + 1] = w.y; go[L + 4 * q + 2] = w.z; go[L + 4 * q + 3] = w.w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < L; ++i) { xo[i] = xc[s2 * L + i]; go[i] = gc[s2 * L + i]; }
+                if (both) {
+#pragma unroll
+                    for (int i = 0; i < L; ++i) { xo[L + i] = xc[(s2 + 1) * L + i]; go[L + i] = gc[(s2 + 1) * L + i]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            xo[i] = live ? xo[i] : 0.f; go[i] = live ? go[i] : 0.f;
+            xo[L + i] = (live && both) ? xo[L + i] : 0.f; go[L + i] = (live && both) ? go[L + i] : 0.f;
+        }
+    };
+    if constexpr (ONE) {
+        const long long t = (long long)blockIdx.x * nw + wave;
+        const long long row = t * RPT + r;
+        const bool on = lane_on && t < ntiles && row < a.N;
+        const long long rowc = on ? row : 0;
+        const long long cellid = rowc * K + kc;
+        load_pair(a.x + cellid * LSn, a.Gx + cellid * LSn, on, 0, nxs, ngx);
+        load_pair(a.x + cellid * LSn, a.Gx + cellid * LSn, on, 2, nxs2, ngx2);
+#pragma unroll
+        for (int i = 0; i < L; ++i) { pe1[i] = a.eta1[rowc * L + i]; pe2[i] = a.eta2d[rowc * L + i]; }
+        pg[0] = a.Glz[cellid]; pg[1] = a.GT[cellid]; pg[2] = a.lz[cellid];
     }
-    __syncthreads();
+    SV_TS(1);
 
+    // (requested before the table is staged: one memory round trip for both)
     float hkk[L], mkk[L], Wt[TRI];
     const bool student = a.nu != nullptr;
-    const int kc = lane_on ? k : 0;                         // unconditional loads from clamped indices + selects
 #pragma unroll
     for (int i = 0; i < L; ++i) {
         const float hv = a.hk[kc * L + i], mv = a.mk[kc * L + i];
@@ -190,12 +269,21 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
     }
     const float nuv = *(student ? a.nu + kc : a.bias);
     const float nuk = (student && lane_on) ? nuv : 1.f;
-    for (int i = 0; i < PWa; ++i) accl[i * WAVE + lane] = 0.f;  // sums over this lane's cells (fixed k)
 
-    const long long ntiles = (a.N + RPT - 1) / RPT;
-    const float invS = 1.0f / (float)S;
-    float nxs[2 * L], ngx[2 * L];
-    bool first_tile = true;
+    for (int e = threadIdx.x; e < K * TRI; e += blockDim.x) {
+        const int kk = e / TRI, idx = e - kk * TRI;
+        int i = 0;
+        while (tri(i + 1, 0) <= idx) ++i;
+        const int j = idx - tri(i, 0);
+        pk_lds[kk * PSTR + idx] = a.Pk[(kk * L + i) * L + j];
+    }
+    __syncthreads();
+    SV_TS(2);
+    SV_USE(hkk[0] + Wt[0] + nuk); SV_TS(3);
+    for (int i = 0; i < PWa; ++i) accl[i * AST + lane] = 0.f;  // sums over this lane's cells (fixed k)
+    SV_TS(4);
+
+    bool first_tile = !ONE;
     for (long long t = (long long)blockIdx.x * nw + wave; t < ntiles; t += (long long)gridDim.x * nw) {
         const long long row = t * RPT + r;
         const bool on = lane_on && row < a.N;
@@ -207,7 +295,7 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
         for (int i = 0; i < TRI; ++i) Lm[i] = lane_on ? pk_lds[k * PSTR + i] : 0.f;
 #pragma unroll
         for (int i = 0; i < L; ++i) {
-            const float e1v = a.eta1[rowc * L + i], e2v = a.eta2d[rowc * L + i];
+            const float e1v = ONE ? pe1[i] : a.eta1[rowc * L + i], e2v = ONE ? pe2[i] : a.eta2d[rowc * L + i];
             const float e1 = on ? e1v : 0.f;
             const float e2 = on ? e2v : -0.5f;
             Lm[tri(i, i)] = fmaf(-2.f, e2, lane_on ? Lm[tri(i, i)] : 0.f);
@@ -219,14 +307,16 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
 #pragma unroll
         for (int i = 0; i < L; ++i) mu[i] = av[i];
         solve_lower_t<L>(Lm, mu);                           // mu~ = Pt^-1 ht
+        SV_USE(mu[0]); SV_TS(5);
 
-        const float glzv = a.Glz[cellid], gTv = a.GT[cellid], lzv = a.lz[cellid];
+        const float glzv = ONE ? pg[0] : a.Glz[cellid], gTv = ONE ? pg[1] : a.GT[cellid], lzv = ONE ? pg[2] : a.lz[cellid];
         const float glz = on ? glzv : 0.f;
         const float gT = on ? gTv : 0.f;
         const float rnk = on ? __expf(lzv) : 0.f;
         const float gsum = row_sum(glz, scr, lane, rbase, K);
         const float Gc = glz - rnk * gsum;                  // through the log-sum-exp normalisation
         const float Gld = gT - Gc;                          // T' has +ld, c has -ld
+        SV_USE(Gld); SV_TS(6);
 
         float Wsum[L], M[TRI];
 #pragma unroll
@@ -236,49 +326,6 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
         const float gts = gT * invS;
         const float* __restrict__ xc = a.x + cellid * LSn;
         const float* __restrict__ gc = a.Gx + cellid * LSn;
-        // Rows are fetched TWO samples at a time: 2*L floats = one 64-byte segment per array per lane, requested by
-        // back-to-back loads.  Fetching a single 32-byte row per iteration made every row its own L2 request (the
-        // other half of the segment is evicted from the 32 KiB L1 before the next sample needs it): 329 M requests
-        // of ~31 B per launch at C3 (TCP_TCC_READ_REQ), i.e. the kernel was bound by L1<->L2 requests, not by HBM.
-        // (one branch around the whole group of loads: skipping the tail prefetches matters - an unconditional
-        //  clamped version measured 27% slower)
-        auto load_pair = [&](const float* __restrict__ xc, const float* __restrict__ gc, bool on, int s2,
-                             float (&xo)[2 * L], float (&go)[2 * L]) {
-            const bool live = on && s2 < S;
-            const bool both = s2 + 1 < S;
-            if (live) {
-                if ((L & 3) == 0 && a.vec_ok) {
-#pragma unroll
-                    for (int q = 0; q < L / 4; ++q) {
-                        const float4 v = reinterpret_cast<const float4*>(xc + s2 * L)[q];
-                        const float4 w = reinterpret_cast<const float4*>(gc + s2 * L)[q];
-                        xo[4 * q] = v.x; xo[4 * q + 1] = v.y; xo[4 * q + 2] = v.z; xo[4 * q + 3] = v.w;
-                        go[4 * q] = w.x; go[4 * q + 1] = w.y; go[4 * q + 2] = w.z; go[4 * q + 3] = w.w;
-                    }
-                    if (both) {
-#pragma unroll
-                        for (int q = 0; q < L / 4; ++q) {
-                            const float4 v = reinterpret_cast<const float4*>(xc + (s2 + 1) * L)[q];
-                            const float4 w = reinterpret_cast<const float4*>(gc + (s2 + 1) * L)[q];
-                            xo[L + 4 * q] = v.x; xo[L + 4 * q + 1] = v.y; xo[L + 4 * q + 2] = v.z; xo[L + 4 * q + 3] = v.w;
-                            go[L + 4 * q] = w.x; go[L + 4 * q + 1] = w.y; go[L + 4 * q + 2] = w.z; go[L + 4 * q + 3] = w.w;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < L; ++i) { xo[i] = xc[s2 * L + i]; go[i] = gc[s2 * L + i]; }
-                    if (both) {
-#pragma unroll
-                        for (int i = 0; i < L; ++i) { xo[L + i] = xc[(s2 + 1) * L + i]; go[L + i] = gc[(s2 + 1) * L + i]; }
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < L; ++i) {
-                xo[i] = live ? xo[i] : 0.f; go[i] = live ? go[i] : 0.f;
-                xo[L + i] = (live && both) ? xo[L + i] : 0.f; go[L + i] = (live && both) ? go[L + i] : 0.f;
-            }
-        };
         // nxs / ngx: the next pair, in flight while this one is used.  The FIRST pair of a tile was requested before the
         // previous tile's assembly phase (below), so its latency is covered by ~4 k cycles of arithmetic instead of being
         // exposed behind the Cholesky of every tile.
@@ -287,7 +334,13 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
             float xp[2 * L], gp[2 * L];
 #pragma unroll
             for (int i = 0; i < 2 * L; ++i) { xp[i] = nxs[i]; gp[i] = ngx[i]; }
-            if (s0 + 2 < S) load_pair(xc, gc, on, s0 + 2, nxs, ngx);
+            if constexpr (ONE) {
+#pragma unroll
+                for (int i = 0; i < 2 * L; ++i) { nxs[i] = nxs2[i]; ngx[i] = ngx2[i]; }
+                if (s0 + 4 < S) load_pair(xc, gc, on, s0 + 4, nxs2, ngx2);
+            } else {
+                if (s0 + 2 < S) load_pair(xc, gc, on, s0 + 2, nxs, ngx);
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
             if (h == 1 && s0 + 1 >= S) break;
@@ -325,11 +378,11 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
 #pragma unroll
                     for (int j = 0; j <= i; ++j) {
                         tx[j] = fmaf(Wt[tri(i, j)], gy, tx[j]);
-                        accl[(TH + L + tri(i, j)) * WAVE + lane] += gy * d[j];
+                        accl[(TH + L + tri(i, j)) * AST + lane] += gy * d[j];
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < L; ++j) accl[(TH + j) * WAVE + lane] -= tx[j];
+                for (int j = 0; j < L; ++j) accl[(TH + j) * AST + lane] -= tx[j];
             }
             solve_lower<L>(Lm, gx);                         // w_s = Lt^-1 gx_s
 #pragma unroll
@@ -341,7 +394,8 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
             }
             }
         }
-        {   // first sample pair of this wave's NEXT tile
+        SV_USE(Wsum[0] + M[0]); SV_TS(7);
+        if constexpr (!ONE) {   // first sample pair of this wave's NEXT tile
             const long long tn = t + (long long)gridDim.x * nw;
             const long long rown = tn * RPT + r;
             const bool onn = lane_on && tn < ntiles && rown < a.N;
@@ -419,43 +473,96 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
 #pragma unroll
             for (int j = 0; j <= i; ++j)
                 gP[tri(i, j)] += -0.5f * (V[i] * mu[j] + mu[i] * V[j]) - 0.5f * Gc * mu[i] * mu[j];
+        SV_USE(gP[0]); SV_TS(8);
 
         // ---- per-component sums (registers) and per-row sums (through LDS)
         if (on) {
 #pragma unroll
-            for (int i = 0; i < L; ++i) accl[i * WAVE + lane] += gh[i];
+            for (int i = 0; i < L; ++i) accl[i * AST + lane] += gh[i];
 #pragma unroll
-            for (int i = 0; i < TRI; ++i) accl[(L + i) * WAVE + lane] += gP[i];
-            accl[(L + TRI) * WAVE + lane] += Gc;
-            if (student) accl[(TH + L + TRI) * WAVE + lane] -= gT;   // T' has -kappa_k
+            for (int i = 0; i < TRI; ++i) accl[(L + i) * AST + lane] += gP[i];
+            accl[(L + TRI) * AST + lane] += Gc;
+            if (student) accl[(TH + L + TRI) * AST + lane] -= gT;   // T' has -kappa_k
         }
+        if (K == 16) {                                      // a row = one 16-lane DPP row
 #pragma unroll
-        for (int i = 0; i < L; ++i) {
-            const float s1 = row_sum(on ? gh[i] : 0.f, scr, lane, rbase, K);
-            const float s2 = row_sum(on ? gP[tri(i, i)] : 0.f, scr, lane, rbase, K);
-            if (on && k == 0) {
-                a.g_eta1[row * L + i] = s1;
-                a.g_eta2d[row * L + i] = -2.f * s2;          // p = -2 eta2d
+            for (int i = 0; i < L; ++i) {
+                const float s1 = row_sum(on ? gh[i] : 0.f, scr, lane, rbase, K);
+                const float s2 = row_sum(on ? gP[tri(i, i)] : 0.f, scr, lane, rbase, K);
+                if (on && k == 0) {
+                    a.g_eta1[row * L + i] = s1;
+                    a.g_eta2d[row * L + i] = -2.f * s2;      // p = -2 eta2d
+                }
             }
+        } else {
+            // all 2L values of every lane go to LDS at once; sum (row rr, quantity i) is formed by lane q = rr * 2L + i.
+            // (2L row_sum calls one after the other were 2L dependent LDS round trips: 4.3 us of a 28 us launch at N = 64)
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                rows[i * AST + lane] = on ? gh[i] : 0.f;
+                rows[(L + i) * AST + lane] = on ? gP[tri(i, i)] : 0.f;
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int q0 = lane; q0 < 2 * L * RPT; q0 += 2 * WAVE) {     // two sums per lane: independent LDS reads in flight
+                const int q1 = q0 + WAVE;
+                const bool has1 = q1 < 2 * L * RPT;
+                const int rr0 = q0 / (2 * L), i0 = q0 - rr0 * (2 * L);
+                const int rr1 = has1 ? q1 / (2 * L) : rr0, i1 = has1 ? q1 - rr1 * (2 * L) : i0;
+                const float* __restrict__ p0 = rows + i0 * AST + rr0 * K;
+                const float* __restrict__ p1 = rows + i1 * AST + rr1 * K;
+                float sq0 = 0.f, sq1 = 0.f;
+#pragma unroll 4
+                for (int j = 0; j < K; ++j) { sq0 += p0[j]; sq1 += p1[j]; }
+                const long long row0 = t * RPT + rr0, row1 = t * RPT + rr1;
+                if (row0 < a.N) {
+                    if (i0 < L) a.g_eta1[row0 * L + i0] = sq0;
+                    else a.g_eta2d[row0 * L + (i0 - L)] = -2.f * sq0;   // p = -2 eta2d
+                }
+                if (has1 && row1 < a.N) {
+                    if (i1 < L) a.g_eta1[row1 * L + i1] = sq1;
+                    else a.g_eta2d[row1 * L + (i1 - L)] = -2.f * sq1;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
+        SV_TS(9);
     }
 
-    // ---- block reduction of the per-component sums: lanes with equal k, all waves, fixed order
+    // ---- block reduction of the per-component sums: lanes with equal k of all waves, fixed order (row, then wave).
+    // (The waves used to fold their accumulators into one array one after the other - nw rounds of PWa dependent LDS
+    //  read-modify-writes between barriers: 8 us of a 28 us launch at N = 64.)
     __syncthreads();
-    for (int w = 0; w < nw; ++w) {
-        if (wave == w) {
-            for (int i = 0; i < PWa; ++i) red[i * WAVE + lane] = (w == 0 ? 0.f : red[i * WAVE + lane]) + accl[i * WAVE + lane];
-        }
-        __syncthreads();
-    }
+    SV_TS(10);
     float* out = a.partials + (long long)blockIdx.x * K * PW;
-    for (int e = threadIdx.x; e < K * PW; e += blockDim.x) {
-        const int kk = e / PW, f = e - kk * PW;
-        float s2 = 0.f;
-        if (f < PWa)
-            for (int rr = 0; rr < RPT; ++rr) s2 += red[f * WAVE + rr * K + kk];
-        out[e] = s2;
+    constexpr int EPT = 4;                                  // elements per thread and round: EPT * SV_NW independent LDS reads in flight
+    for (int e0 = threadIdx.x; e0 < K * PW; e0 += SV_NW * WAVE * EPT) {
+        float s2[EPT];
+        int off[EPT];
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            const int e = e0 + u * SV_NW * WAVE;
+            const int kk = e / PW, f = e - kk * PW;
+            off[u] = (e < K * PW && f < PWa) ? f * AST + kk : -1;
+            s2[u] = 0.f;
+        }
+        for (int rr = 0; rr < RPT; ++rr) {
+            float v[SV_NW][EPT];
+#pragma unroll
+            for (int w = 0; w < SV_NW; ++w)
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) v[w][u] = acc0[w * (PWa * AST) + (off[u] < 0 ? 0 : off[u]) + rr * K];
+#pragma unroll
+            for (int w = 0; w < SV_NW; ++w)
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) s2[u] += v[w][u];
+        }
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            const int e = e0 + u * SV_NW * WAVE;
+            if (e < K * PW) out[e] = off[u] < 0 ? 0.f : s2[u];
+        }
     }
+    SV_TS(11);
 }
 
 
@@ -1122,15 +1229,8 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
     const bool lane_on = lane < CT;
     const int r = lane / K, k = lane - r * K, rbase = lane_on ? r * K : 0;
     const bool k16 = (K == 16);
+    SV_TS(16);
 
-    for (int e = threadIdx.x; e < K * TRI; e += blockDim.x) {
-        const int kk = e / TRI, idx = e - kk * TRI;
-        int i = 0;
-        while (tri(i + 1, 0) <= idx) ++i;
-        const int j = idx - tri(i, 0);
-        pk_lds[kk * PSTR + idx] = a.Pk[(kk * L + i) * L + j];
-    }
-    __syncthreads();
 
     float hkk[L];
     v2f mk2[LP], Wt2[TP];
@@ -1158,6 +1258,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
         biask = lane_on ? bv : 0.f; kappak = lane_on ? kv : 0.f; nuk = (student && lane_on) ? nv : 1.f;
     }
     const float inv_nu = 1.0f / nuk;
+    SV_USE(inv_nu + hkk[0] + Wt2[0][0] + biask); SV_TS(18);
 
     const long long ntiles = (a.N + RPT - 1) / RPT;
     const float invLS = 1.0f / (float)LSn, invS = 1.0f / (float)S;
@@ -1229,6 +1330,16 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
 #pragma unroll
         for (int i = 0; i < L; ++i) { e1r[i] = a.eta1[rc0 * L + i]; e2r[i] = a.eta2d[rc0 * L + i]; }
     }
+    // (the P_k table is staged AFTER the first tile's requests are out: one memory round trip for all of them)
+    for (int e = threadIdx.x; e < K * TRI; e += blockDim.x) {
+        const int kk = e / TRI, idx = e - kk * TRI;
+        int i = 0;
+        while (tri(i + 1, 0) <= idx) ++i;
+        const int j = idx - tri(i, 0);
+        pk_lds[kk * PSTR + idx] = a.Pk[(kk * L + i) * L + j];
+    }
+    __syncthreads();
+    SV_TS(17);
     for (; t < ntiles; t += tstride) {
         float* et = buf0 + (RNG ? 0 : cur) * (WAVE * CS);
         const long long row = t * RPT + r;
@@ -1266,6 +1377,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
             se = row_sum(ex, scr, lane, rbase, K);
         }
         const float lz = c - mx - __logf(se);
+        SV_USE(lz); SV_TS(19);
 
         // The factorisation above needed no noise: the previous tile's stores had that long to drain.  Now: next tile's
         // rows (plain loads), then ONE wait that retires this tile's DMA (issued a tile ago), the old stores and those
@@ -1279,6 +1391,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < L; ++i) asm volatile("" : "+v"(e1r[i]), "+v"(e2r[i]));
+        SV_TS(20);
         if constexpr (!RNG) { if (t + tstride < ntiles) issue_dma(t + tstride, buf0 + (cur ^ 1) * (WAVE * CS)); }
 
         v2f Lm2[TP], av2[LP];
@@ -1352,7 +1465,28 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
             } else {
                 qth += del2;
             }
-            if (lane_on) {
+            if (!full) {
+                // tiles that are not 64 whole cells (K does not divide 64, or the last rows): every lane stores its own
+                // cell's two sample rows - 2 * 4L contiguous bytes - straight from registers.  (Staging them in LDS and
+                // copying out element by element cost ~20 index instructions per float: 3.9 us of a 12 us launch at
+                // N = 64, K = 10, and 40 % on top of the arithmetic of every K = 10 tile at any N.)
+                if (on) {
+                    float* __restrict__ xo = a.x + cellid * (unsigned long long)LSn + (unsigned)(s * L);
+                    if ((L & 3) == 0 && a.vec_ok) {
+#pragma unroll
+                        for (int q = 0; q < L / 4; ++q)
+                            reinterpret_cast<float4*>(xo)[q] = float4{z[4 * q].x, z[4 * q + 1].x, z[4 * q + 2].x, z[4 * q + 3].x};
+                        if (hv) {
+#pragma unroll
+                            for (int q = 0; q < L / 4; ++q)
+                                reinterpret_cast<float4*>(xo + L)[q] = float4{z[4 * q].y, z[4 * q + 1].y, z[4 * q + 2].y, z[4 * q + 3].y};
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < L; ++i) { xo[i] = z[i].x; if (hv) xo[L + i] = z[i].y; }
+                    }
+                }
+            } else if (lane_on) {
 #pragma unroll
                 for (int i = 0; i < L; ++i) {
                     if constexpr (ST != 0 && (ST & 1) == 0) {
@@ -1369,6 +1503,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
             a.Tp[row * K + k] = -0.5f * L * LOG_2PI + ld - 0.5f * invS * (eps2.x + eps2.y) + 0.5f * invS * (qth.x + qth.y) - kappak;
         }
         __builtin_amdgcn_wave_barrier();
+        SV_TS(21);
 
         // ---- samples out: (cell, S, L) layout, coalesced
         {
@@ -1413,16 +1548,10 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
                             if (it0 + u < Q) g4[(it0 + u) * WAVE] = v[u];
                     }
                 }
-            } else {
-                for (int o = lane; o < tot; o += WAVE) {
-                    const int c2 = (int)(((float)o + 0.5f) * invLS);
-                    const int rem = o - c2 * LSn;
-                    const int s = rem / L, l = rem - s * L;
-                    g[o] = et[c2 * CS + l * S + s];
-                }
             }
         }
         __builtin_amdgcn_wave_barrier();
+        SV_TS(22);
         cur ^= 1;
     }
 }
@@ -1644,6 +1773,9 @@ int check_sv(long long N, int K, int L, int S) {
     return 0;
 }
 
+#ifdef VMP_DEBUG_TS
+static long long* g_dbg_svae = nullptr;
+#endif
 int sv_blocks(long long N, int K) {
     const int RPT = WAVE / K;
     const long long ntiles = (N + RPT - 1) / RPT;
@@ -1674,6 +1806,9 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" {
 
+#ifdef VMP_DEBUG_TS
+void vmp_debug_set_svae_timestamps(long long* p) { g_dbg_svae = p; }      // exploration builds only (tools/svae_ts.py)
+#endif
 int vmp_svae_bwd_partial_words(int L) { return 2 * (L + L * (L + 1) / 2 + 1); }
 
 size_t vmp_svae_workspace_bytes(int64_t N, int K, int L) {
@@ -1699,6 +1834,9 @@ static int fwd4_plan(int K, int L, int S, int& CS, size_t& lds4, bool rng = fals
 }
 
 static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
+#ifdef VMP_DEBUG_TS
+    a.dbg_t = g_dbg_svae;
+#endif
     const long long N = a.N;
     const int K = a.K, S = a.S;
     const float* noise = a.noise;
@@ -1863,6 +2001,9 @@ int vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk, c
     if (partial_bytes < (size_t)blocks * K * PW * sizeof(float)) { set_error("vmp_svae_estep_bwd: partials buffer too small"); return VMP_E_WS; }
     EBwdArgs a{eta1, eta2d, hk, Pk, bias, mk, Wk, nu, x, lz, Gx, Glz, GT, g_eta1, g_eta2d, partials, N, K, S, 0};
     a.vec_ok = al16(x) && al16(Gx);
+#ifdef VMP_DEBUG_TS
+    a.dbg_t = g_dbg_svae;
+#endif
 #ifndef VMP_T2_RING
 #define VMP_T2_RING 1         // 0: build without the LDS-ring backward kernel (A/B measurements: tools/build_variant.sh)
 #endif
@@ -1887,10 +2028,13 @@ int vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk, c
         return rc;
     }
     const int PWa = nu ? PW : PW / 2;
-    const size_t lds = (size_t)(K * ((L * (L + 1) / 2) | 1) + SV_NW * WAVE + PWa * WAVE + SV_NW * PWa * WAVE) * sizeof(float);
+    const size_t lds = (size_t)(K * ((L * (L + 1) / 2) | 1) + SV_NW * WAVE + SV_NW * 2 * L * SV_AST + SV_NW * PWa * SV_AST) * sizeof(float);
     rc = -1;
+    const long long ntiles_g = (N + WAVE / K - 1) / (WAVE / K);
+    const bool one = ntiles_g <= (long long)blocks * SV_NW;       // every wave has at most one tile: latency form
     VMP_DISPATCH_L(L, {
-        hipLaunchKernelGGL((svae_estep_bwd_kernel<LL>), dim3(blocks), dim3(SV_NW * WAVE), lds, static_cast<hipStream_t>(stream), a);
+        if (one) hipLaunchKernelGGL((svae_estep_bwd_kernel<LL, true>), dim3(blocks), dim3(SV_NW * WAVE), lds, static_cast<hipStream_t>(stream), a);
+        else hipLaunchKernelGGL((svae_estep_bwd_kernel<LL, false>), dim3(blocks), dim3(SV_NW * WAVE), lds, static_cast<hipStream_t>(stream), a);
         rc = check_launch("svae_estep_bwd_kernel");
     });
     return rc;
