@@ -209,6 +209,17 @@ int    vmp_svae_bwd_reduce(const float* partials, int nblk, int K, int L, float*
                            float* g_mk, float* g_W, float* g_kappa, void* stream);
 int    vmp_svae_theta_pack(const float* alpha, const float* A, const float* b, const float* beta, const float* v_hat,
                            int K, int L, float* m, float* W, float* kappa, void* stream);
+/* vmp_svae_phi_prep_fwd and vmp_svae_theta_pack (independent K-sized maps, both run once per training step) in ONE launch. */
+int    vmp_svae_prep_fwd(const float* mu_k, const float* L_raw, const float* pi_raw, const float* alpha, const float* A,
+                         const float* b, const float* beta, const float* v_hat, int K, int L, float* Lk, float* P,
+                         float* bias, float* m, float* W, float* kappa, void* stream);
+/* Small batches (N <= 512 rows: the reference's minibatches), one process: the M-step moments of (x_samples (N,L), r (N,K))
+ * - exactly vmp_mix_stats' small-batch sums, written to stats_out (K, 2+L+L*L) fp64 - and vmp_svae_cvi_update from them in
+ * ONE launch.  Arguments as vmp_svae_cvi_update.                                                                      */
+int    vmp_svae_stats_cvi(const float* x_samples, const float* r, int64_t N, const float* p_alpha, const float* p_A,
+                          const float* p_b, const float* p_beta, const float* p_vhat, float* t_alpha, float* t_A,
+                          float* t_b, float* t_beta, float* t_vhat, float* s_alpha, float* s_A, float* s_b, float* s_beta,
+                          float* s_vhat, const float* rho_dev, float rho, int K, int L, double* stats_out, void* stream);
 int    vmp_svae_cvi_update(const double* stats, const float* p_alpha, const float* p_A, const float* p_b,
                            const float* p_beta, const float* p_vhat, float* t_alpha, float* t_A, float* t_b,
                            float* t_beta, float* t_vhat, float* s_alpha, float* s_A, float* s_b, float* s_beta,
@@ -266,6 +277,17 @@ int    vmp_mlp_gauss_bwd(const float* x, const float* gmean, const float* gvar, 
                          const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws,
                          const float* bs1, const float* bs2, int64_t R, int L, int Dy, int U, float* dx, float* dparams,
                          void* ws, size_t ws_bytes, void* stream);
+/* The same MLP with either Gaussian head of models/vae.py:28-50 (make_gaussian_layer): outputs (out1, out2) =
+ * (mean, var_scale * var) - var_scale = 1: 'standard' (mean, softplus), var_scale = -1/2: the encoder's 'natparam' head
+ * (eta1, -1/2 softplus) of experiments.py:139 - so that the head's scaling costs no launch of its own, forward or
+ * backward (g_out2 is the upstream gradient of out2).  x (R,L); out1, out2, g_out1, g_out2 (R,Dy).              */
+int    vmp_mlp_gauss_head_fwd(const float* x, const float* W0, const float* b0, const float* W1, const float* b1,
+                              const float* W2, const float* b2, const float* Ws, const float* bs1, const float* bs2,
+                              int64_t R, int L, int Dy, int U, float var_scale, float* out1, float* out2, void* stream);
+int    vmp_mlp_gauss_head_bwd(const float* x, const float* g_out1, const float* g_out2, float var_scale, const float* W0,
+                              const float* b0, const float* W1, const float* b1, const float* W2, const float* b2,
+                              const float* Ws, const float* bs1, const float* bs2, int64_t R, int L, int Dy, int U,
+                              float* dx, float* dparams, void* ws, size_t ws_bytes, void* stream);
 int    vmp_decoder_loglike_bwd(const float* x, const float* y, const float* gA, const float* W0, const float* b0,
                                const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws,
                                const float* bs1, const float* bs2, int64_t N, int K, int S, int L, int Dy, int U,
@@ -278,6 +300,16 @@ int    vmp_decoder_loglike_bwd_logw(const float* x, const float* y, const float*
                                     const float* Ws, const float* bs1, const float* bs2, int64_t N, int K, int S, int L,
                                     int Dy, int U, float* dx, float* dparams, float* ll, void* ws, size_t ws_bytes,
                                     void* stream);
+
+/* compute_elbo for the fused decoder in TWO launches: vmp_decoder_loglike_bwd_logw with w_scale = -sigma / 2S, then ONE
+ * launch in which some blocks reduce the decoder's parameter partials and the others run vmp_svae_elbo_tail (below) -
+ * both wait for the decoder kernel only.  Arguments as those two calls; tail_ws as vmp_svae_elbo_tail's ws.  N >= 1.   */
+int    vmp_decoder_elbo(const float* x, const float* y, const float* log_z, const float* T_prime, float sigma,
+                        const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
+                        const float* b2, const float* Ws, const float* bs1, const float* bs2, int64_t N, int K, int S,
+                        int L, int Dy, int U, float* dx, float* dparams, float* ll, float* scalars, float* g_log_z,
+                        float* g_T_prime, float* r, void* ws, size_t ws_bytes, void* tail_ws, size_t tail_ws_bytes,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Scalar tail of the SVAE ELBO (models/svae.py:216-254 compute_elbo; vae.py:232-250) - one launch

@@ -122,3 +122,77 @@ def test_fused_elbo_fn_matches_unfused_composition(dims):
         f = 1.0 if upstream is None or upstream == -1.0 else -upstream
         for a, b in zip(got_g, want_g):
             assert rel(a, b * f) < 2e-5
+
+
+@pytest.mark.parametrize('N,K,Ld', [(64, 10, 8), (100, 16, 6), (1, 3, 2), (512, 5, 8)])
+def test_stats_cvi_one_launch_equals_the_two(N, K, Ld):
+    """vmp_svae_stats_cvi (M-step moments + CVI update in one launch) == vmp_mix_stats followed by vmp_svae_cvi_update,
+    bit for bit, with the step size by value and through the device word."""
+    from vmp_for_svae_amd.models import _mix, _svae_ops, svae
+    g = torch.Generator(device='cuda').manual_seed(N + K)
+    x = torch.randn(N, Ld, device='cuda', generator=g) * 2
+    r = torch.softmax(torch.randn(N, K, device='cuda', generator=g), -1)
+    prior, theta0 = svae.init_mm(K, Ld, seed=1)
+    for rho_dev in (None, torch.full((), 0.17, device='cuda')):
+        th_a = [t.clone() for t in theta0]
+        th_b = [t.clone() for t in theta0]
+        st_a = _mix.raw_stats(x, r)
+        star_a = _svae_ops.cvi_update(prior, th_a, st_a, 0.17 if rho_dev is None else 0.0, rho_dev=rho_dev)
+        st_b, star_b = _svae_ops.stats_cvi(x, r, prior, th_b, 0.17 if rho_dev is None else 0.0, rho_dev=rho_dev)
+        assert torch.equal(st_a, st_b)
+        for a, b in zip(th_a + star_a, th_b + star_b):
+            assert torch.equal(a, b)
+    import vmp_for_svae_amd as V
+    with pytest.raises(V._lib.VmpError):                  # larger batches take the two-call form
+        _svae_ops.stats_cvi(torch.randn(513, Ld, device='cuda'), torch.rand(513, K, device='cuda'), prior, [t.clone() for t in theta0], 0.1)
+
+
+@pytest.mark.parametrize('K,Ld', [(10, 8), (16, 6), (3, 1), (64, 8)])
+def test_prep_one_launch_equals_the_two(K, Ld):
+    """PhiPrepFn with theta (vmp_svae_prep_fwd: recognition unpacking + theta packing in one launch) == PhiPrepFn without
+    + theta_pack_gmm, bit for bit; gradients w.r.t. the recognition parameters unchanged."""
+    from vmp_for_svae_amd.models import _svae_ops, svae
+    prior, theta = svae.init_mm(K, Ld, seed=2)
+    g = torch.Generator(device='cuda').manual_seed(K)
+    with torch.no_grad():
+        theta[1].add_(0.3 * torch.eye(Ld, device='cuda'))
+        theta[2].add_(torch.randn(K, Ld, device='cuda', generator=g) * 0.1)
+    phi = [p.detach().clone().requires_grad_(True) for p in svae.init_recognition_params(theta, K, seed=2)]
+    a = _svae_ops.PhiPrepFn.apply(*phi)
+    m, W, kap = _svae_ops.theta_pack_gmm(theta)
+    phi2 = [p.detach().clone().requires_grad_(True) for p in phi]
+    b = _svae_ops.PhiPrepFn.apply(*phi2, *theta)
+    for u, v in zip(list(a) + [m, W, kap], b):
+        assert torch.equal(u, v)
+    assert not b[3].requires_grad and not b[5].requires_grad
+    G = [torch.randn_like(t) for t in a]
+    ga = torch.autograd.grad(list(a), phi, G)
+    gb = torch.autograd.grad(list(b[:3]), phi2, G)
+    for u, v in zip(ga, gb):
+        assert torch.equal(u, v)
+
+
+def test_gauss_head_scale_inside_the_kernels():
+    """GaussMLPFn with the 'natparam' head scale (-1/2, applied inside the forward / backward kernels) == the 'standard'
+    head followed by a torch multiplication: outputs and every gradient."""
+    from test_decoder_gpu import make_case
+    from vmp_for_svae_amd.models import _svae_ops
+    N, K, S, Ld, Dy, U = 70, 1, 1, 6, 8, 50
+    x, y, r, w = make_case(N, K, S, Ld, Dy, U, seed=9)
+    T = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device='cuda')
+    xs = T(x).reshape(N, Ld)
+    g = torch.Generator(device='cuda').manual_seed(4)
+    G1, G2 = torch.randn(N, Dy, device='cuda', generator=g), torch.randn(N, Dy, device='cuda', generator=g)
+    res = []
+    for fused in (False, True):
+        xi = xs.clone().requires_grad_(True)
+        ws = [T(a).requires_grad_(True) for a in w]
+        if fused:
+            o1, o2 = _svae_ops.GaussMLPFn.apply(xi, -0.5, *ws)
+        else:
+            o1, v = _svae_ops.GaussMLPFn.apply(xi, 1.0, *ws)
+            o2 = -0.5 * v
+        gr = torch.autograd.grad([o1, o2], [xi] + ws, [G1, G2])
+        res.append([o1, o2] + list(gr))
+    for a, b in zip(*res):
+        assert rel(b, a) < 3e-6

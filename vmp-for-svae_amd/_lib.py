@@ -58,13 +58,19 @@ _SIGNATURES = {
     'vmp_decoder_loglike_bwd': (_c.c_int, [_P] * 12 + [_c.c_int64] + [_c.c_int] * 5 + [_P, _P, _P, _P, _c.c_size_t, _P]),
     'vmp_decoder_loglike_bwd_logw': (_c.c_int, [_P] * 3 + [_c.c_float] + [_P] * 9 + [_c.c_int64] + [_c.c_int] * 5
                                      + [_P, _P, _P, _P, _c.c_size_t, _P]),
+    'vmp_mlp_gauss_head_fwd': (_c.c_int, [_P] * 10 + [_c.c_int64] + [_c.c_int] * 3 + [_c.c_float, _P, _P, _P]),
+    'vmp_mlp_gauss_head_bwd': (_c.c_int, [_P] * 3 + [_c.c_float] + [_P] * 9 + [_c.c_int64] + [_c.c_int] * 3 + [_P, _P, _P, _c.c_size_t, _P]),
+    'vmp_decoder_elbo': (_c.c_int, [_P] * 4 + [_c.c_float] + [_P] * 9 + [_c.c_int64] + [_c.c_int] * 5 + [_P] * 8
+                         + [_c.c_size_t, _P, _c.c_size_t, _P]),
     'vmp_svae_elbo_tail_workspace_bytes': (_c.c_size_t, []),
     'vmp_svae_elbo_tail': (_c.c_int, [_P] * 3 + [_c.c_int64] + [_c.c_int] * 3 + [_c.c_float] + [_P] * 5 + [_c.c_size_t, _P]),
     'vmp_adam_step': (_c.c_int, [_c.c_int] + [_P] * 5 + [_c.c_double] * 4 + [_P, _P]),
     'vmp_svae_phi_prep_fwd': (_c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _P, _P, _P, _P]),
+    'vmp_svae_prep_fwd': (_c.c_int, [_P] * 8 + [_c.c_int, _c.c_int] + [_P] * 7),
     'vmp_svae_phi_prep_bwd': (_c.c_int, [_P] * 6 + [_c.c_int, _c.c_int] + [_P] * 4),
     'vmp_svae_bwd_reduce': (_c.c_int, [_P, _c.c_int, _c.c_int, _c.c_int] + [_P] * 7),
     'vmp_svae_theta_pack': (_c.c_int, [_P] * 5 + [_c.c_int, _c.c_int] + [_P] * 4),
+    'vmp_svae_stats_cvi': (_c.c_int, [_P, _P, _c.c_int64] + [_P] * 16 + [_c.c_float, _c.c_int, _c.c_int, _P, _P]),
     'vmp_svae_cvi_update': (_c.c_int, [_P] * 17 + [_c.c_float, _c.c_int, _c.c_int, _P]),
     'vmp_mlp_gauss_bwd': (_c.c_int, [_P] * 12 + [_c.c_int64] + [_c.c_int] * 3 + [_P, _P, _P, _c.c_size_t, _P]),
     'vmp_comm_unique_id': (_c.c_int, [_P]),

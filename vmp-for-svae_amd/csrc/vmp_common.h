@@ -135,4 +135,41 @@ inline int pack_words(int D)  { return D + D * (D + 1) / 2 + 4; }
 inline int stats_words(int D) { return 2 + D + D * D; }
 inline int partial_words(int D) { return 1 + D + D * (D + 1) / 2 + 1; }
 
+// ---- raw moments of a SMALL batch ------------------------------------------------------------------------
+// (the training step at the reference's minibatch sizes, experiments.py:26: 64-100 rows): one block of 12 x 80 threads per
+// component, thread (row group g, statistic i) sums the rows n = g (mod 12) in fp64 on the un-shifted data, the group sums
+// are added in a fixed order.  One launch of a few microseconds instead of pivot + streaming pass + reduction (three
+// launches, ~22 us at N = 64, most of it fixed cost).  Shared by vmp_mix_stats (vmp_mix.hip) and the fused moments + CVI
+// update of the SVAE training step (vmp_prep.hip).
+struct SmallStatsArgs { const float* x; const float* r; const float* u; double* stats; int N, D, K; };
+constexpr int SMALL_STATS_MAX_N = 512;
+constexpr int SMALL_STATS_GROUPS = 12;          // row groups per component: 12 x 80 threads, <= 6 rows each at N = 64
+// statistic i (< 2 + D + D*D) of component k in the threads of row group 0 (threadIdx.x < 80); other threads: garbage
+__device__ __forceinline__ double small_stats_component(const SmallStatsArgs& a, int k, double (*part)[80]) {
+    const int g = threadIdx.x / 80, i = threadIdx.x % 80;
+    const int D = a.D, SW = 2 + D + D * D;
+    double s = 0.0;
+    if (i < SW) {
+        const int d = i < 2 + D ? (i < 2 ? 0 : i - 2) : (i - 2 - D) / D, e = i < 2 + D ? 0 : (i - 2 - D) % D;
+#pragma unroll 2
+        for (int n = g; n < a.N; n += SMALL_STATS_GROUPS) {
+            const float rf = a.r[(long long)n * a.K + k];
+            const float wf = a.u ? rf * a.u[(long long)n * a.K + k] : rf;          // w = r u in fp32, as the pass kernel forms it
+            const double xd = (double)a.x[(long long)n * D + d], xe = (double)a.x[(long long)n * D + e];
+            double t;
+            if (i == 0) t = rf;
+            else if (i == 1) t = wf;
+            else if (i < 2 + D) t = (double)wf * xd;
+            else t = (double)wf * xd * xe;
+            s += t;
+        }
+    }
+    part[g][i] = s;
+    __syncthreads();
+    double t = part[0][i];
+#pragma unroll
+    for (int j = 1; j < SMALL_STATS_GROUPS; ++j) t += part[j][i];
+    return t;
+}
+
 }  // namespace vmp

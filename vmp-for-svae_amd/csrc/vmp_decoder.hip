@@ -32,6 +32,7 @@
 // (tools/ubench/xdl_overlap.hip): beside enough VALU work a bf16 MFMA costs ~10-12 issue cycles of its SIMD, i.e. the
 // XDL pipe overlaps the VALU only partially; the kernels are bound by VALU + MFMA issue.
 #include "vmp_common.h"
+#include "vmp_tail.h"
 
 using namespace vmp;
 
@@ -59,6 +60,8 @@ struct DecArgs {
     int L, Dy, U;
     int split;             // backward: % of a SIMD pair's tiles that go to the older wave (see dec_bwd_kernel)
     int red_one;           // backward epilogue: all 8 waves' slabs fit the LDS at once (one round instead of two)
+    float vscale;          // the second head output is vscale * var (forward) and its upstream gradient is scaled alike
+                           // (backward, gradient-input mode): 1 = 'standard' head, -1/2 = the encoder's 'natparam' head
 #ifdef VMP_DEBUG_TS
     long long* dbg_t;      // exploration builds only (tools/build_variant.sh ts -DVMP_DEBUG_TS): stage stamps of block 0, thread 0
 #endif
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void dec_fwd_kernel(DecArgs a) {
                 const int d = 2 * g + j;
                 if (d < Dy) {
                     a.mean[(size_t)row * Dy + d] = mu[j];
-                    a.var[(size_t)row * Dy + d] = vr[j];
+                    a.var[(size_t)row * Dy + d] = vr[j] * a.vscale;
                 }
             }
         }
@@ -695,7 +698,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             const bool d0 = ok && 2 * g < Dy, d1 = ok && 2 * g + 1 < Dy;
             const float m0 = a.gmean[(size_t)rr * Dy + (d0 ? 2 * g : 0)], v0 = a.gvar[(size_t)rr * Dy + (d0 ? 2 * g : 0)];
             const float m1 = a.gmean[(size_t)rr * Dy + (d1 ? 2 * g + 1 : 0)], v1 = a.gvar[(size_t)rr * Dy + (d1 ? 2 * g + 1 : 0)];
-            t.p0 = d0 ? m0 : 0.f; t.p1 = d1 ? m1 : 0.f; t.q0 = d0 ? v0 : 0.f; t.q1 = d1 ? v1 : 0.f;
+            t.p0 = d0 ? m0 : 0.f; t.p1 = d1 ? m1 : 0.f; t.q0 = d0 ? v0 * a.vscale : 0.f; t.q1 = d1 ? v1 * a.vscale : 0.f;
         } else {
             const RowMap rm = row_map(tile, c, a.S, a.K, invS, invK, ncells);
             t.ga = ok ? a.gA[rm.cell] : 0.f;
@@ -1003,10 +1006,10 @@ struct DecRedArgs {
 // 64 consecutive parameters per block; lane group bg = tid / 64 sums the block rows b = bg, bg + 16, .. (independent coalesced
 // loads instead of one chain of `blocks` dependent ones), the 16 group sums are added in a fixed order.
 constexpr int DEC_RED_GROUPS = 16;
-__global__ __launch_bounds__(64 * DEC_RED_GROUPS) void dec_reduce_kernel(DecRedArgs r) {
+__device__ __forceinline__ void dec_reduce_body(const DecRedArgs& r, const int blk) {
     __shared__ double part[DEC_RED_GROUPS][64];
     const int eg = threadIdx.x & 63, bg = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + eg;
+    const int i = blk * 64 + eg;
     double s = 0.0;
     if (i < r.PW)
         for (int b = bg; b < r.blocks; b += DEC_RED_GROUPS) s += (double)r.part[(size_t)b * r.PW + i];
@@ -1016,6 +1019,14 @@ __global__ __launch_bounds__(64 * DEC_RED_GROUPS) void dec_reduce_kernel(DecRedA
     for (int g2 = 1; g2 < DEC_RED_GROUPS; ++g2) s += part[g2][eg];
     if (i >= r.obs2) s *= 1.0 / (1.0 + exp(-(double)r.bs2[i - r.obs2]));
     r.out[i] = (float)s;
+}
+__global__ __launch_bounds__(64 * DEC_RED_GROUPS) void dec_reduce_kernel(DecRedArgs r) { dec_reduce_body(r, blockIdx.x); }
+
+// The reduction of the decoder's parameter partials and the scalar tail of the ELBO (vmp_tail.h) both wait for the decoder
+// kernel and for nothing else: one launch, blocks [0, red_blocks) reduce, the others run the tail.
+__global__ __launch_bounds__(64 * DEC_RED_GROUPS) void dec_reduce_tail_kernel(DecRedArgs r, TailArgs t, int red_blocks) {
+    if ((int)blockIdx.x < red_blocks) dec_reduce_body(r, blockIdx.x);
+    else elbo_tail_body(t, blockIdx.x - red_blocks, gridDim.x - red_blocks);
 }
 
 int dec_blocks(long long rows, int waves_per_block, int max_blocks) {
@@ -1096,7 +1107,7 @@ int dec_bwd_launch(const DecArgs& a0, int blocks, hipStream_t s) {
     return check_launch(GIN ? "vmp_mlp_gauss_bwd" : "vmp_decoder_loglike_bwd");
 }
 
-int decoder_loglike_bwd_impl(const char* what, float logw, const float* x, const float* y, const float* gA,
+int decoder_loglike_bwd_impl(const char* what, float logw, const TailArgs* tail, unsigned tail_blocks, const float* x, const float* y, const float* gA,
                              const float* W0, const float* b0, const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws,
                             const float* bs1, const float* bs2, int64_t N, int K, int S, int L, int Dy, int U, float* dx,
                             float* dparams, float* ll, void* ws, size_t ws_bytes, void* stream) {
@@ -1118,10 +1129,69 @@ int decoder_loglike_bwd_impl(const char* what, float logw, const float* x, const
     }
     DecArgs a{};
     a.x = x; a.y = y; a.gA = gA; a.W0 = W0; a.b0 = b0; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Ws = Ws; a.bs1 = bs1; a.bs2 = bs2;
-    a.dx = dx; a.part = static_cast<float*>(ws); a.ll = ll; a.logw = logw;
+    a.dx = dx; a.part = static_cast<float*>(ws); a.ll = ll; a.logw = logw; a.vscale = 1.0f;
     a.R = (unsigned)(N * K * S); a.K = (unsigned)K; a.S = (unsigned)S; a.L = L; a.Dy = Dy; a.U = U;
     const int blocks = dec_bwd_blocks((long long)a.R);
     if (int e = dec_bwd_launch<false>(a, blocks, s)) return e;
+    DecRedArgs r{a.part, bs2, dparams, blocks, q.PW, q.obs2, Dy};
+    const int red_blocks = (q.PW + 63) / 64;
+    if (tail) hipLaunchKernelGGL(dec_reduce_tail_kernel, dim3(red_blocks + tail_blocks), dim3(64 * DEC_RED_GROUPS), 0, s, r, *tail, red_blocks);
+    else hipLaunchKernelGGL(dec_reduce_kernel, dim3(red_blocks), dim3(64 * DEC_RED_GROUPS), 0, s, r);
+    return check_launch(what);
+}
+
+int decoder_fwd_impl(const char* what, float vscale, const float* x, const float* y, const float* W0, const float* b0, const float* W1,
+                            const float* b1, const float* W2, const float* b2, const float* Ws, const float* bs1,
+                            const float* bs2, int64_t N, int K, int S, int L, int Dy, int U, float* ll, float* mean,
+                            float* var, void* stream) {
+    if (int e = dec_check(what, N, K, S, L, Dy, U)) return e;
+    if (!x || (!y && ll) || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !Ws || !bs1 || !bs2 || (!ll && !mean) || (!mean != !var)) {
+        set_error("%s: NULL argument", what);
+        return VMP_E_BADARG;
+    }
+    if (N == 0) return 0;
+    DecArgs a{};
+    a.x = x; a.y = y; a.W0 = W0; a.b0 = b0; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Ws = Ws; a.bs1 = bs1; a.bs2 = bs2;
+    a.ll = ll; a.mean = mean; a.var = var; a.vscale = vscale;
+    a.R = (unsigned)(N * K * S); a.K = (unsigned)K; a.S = (unsigned)S; a.L = L; a.Dy = Dy; a.U = U;
+    const int blocks = dec_fwd_blocks((long long)a.R);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define DEC_FWD(UTV)                                                                                                  \
+    do {                                                                                                              \
+        const int lds = Img<UTV>::FWD_END * (int)sizeof(float);                                                       \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fwd_kernel<UTV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((dec_fwd_kernel<UTV>), dim3(blocks), dim3(FWD_THREADS), lds, s, a);                        \
+    } while (0)
+    DEC_DISPATCH(U, DEC_FWD);
+#undef DEC_FWD
+    return check_launch(what);
+}
+
+int mlp_gauss_bwd_impl(const char* what, float vscale, const float* x, const float* gmean, const float* gvar, const float* W0, const float* b0,
+                      const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws, const float* bs1,
+                      const float* bs2, int64_t R, int L, int Dy, int U, float* dx, float* dparams, void* ws,
+                      size_t ws_bytes, void* stream) {
+    if (int e = dec_check(what, R, 1, 1, L, Dy, U)) return e;
+    if (!x || !gmean || !gvar || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !Ws || !bs1 || !bs2 || !dparams || !ws) {
+        set_error("%s: NULL argument", what);
+        return VMP_E_BADARG;
+    }
+    const DecGeo q = dec_geo(L, U, Dy);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (R == 0) {
+        (void)hipMemsetAsync(dparams, 0, (size_t)q.PW * sizeof(float), s);
+        return check_launch(what);
+    }
+    if (ws_bytes < (size_t)dec_bwd_blocks((long long)R) * (size_t)q.PW * sizeof(float)) {
+        set_error("%s: workspace too small", what);
+        return VMP_E_WS;
+    }
+    DecArgs a{};
+    a.x = x; a.gmean = gmean; a.gvar = gvar; a.W0 = W0; a.b0 = b0; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Ws = Ws;
+    a.bs1 = bs1; a.bs2 = bs2; a.dx = dx; a.part = static_cast<float*>(ws); a.vscale = vscale;
+    a.R = (unsigned)R; a.K = 1; a.S = 1; a.L = L; a.Dy = Dy; a.U = U;
+    const int blocks = dec_bwd_blocks((long long)a.R);
+    if (int e = dec_bwd_launch<true>(a, blocks, s)) return e;
     DecRedArgs r{a.part, bs2, dparams, blocks, q.PW, q.obs2, Dy};
     hipLaunchKernelGGL(dec_reduce_kernel, dim3((q.PW + 63) / 64), dim3(64 * DEC_RED_GROUPS), 0, s, r);
     return check_launch(what);
@@ -1144,34 +1214,22 @@ int vmp_decoder_loglike_fwd(const float* x, const float* y, const float* W0, con
                             const float* b1, const float* W2, const float* b2, const float* Ws, const float* bs1,
                             const float* bs2, int64_t N, int K, int S, int L, int Dy, int U, float* ll, float* mean,
                             float* var, void* stream) {
-    if (int e = dec_check("vmp_decoder_loglike_fwd", N, K, S, L, Dy, U)) return e;
-    if (!x || (!y && ll) || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !Ws || !bs1 || !bs2 || (!ll && !mean) || (!mean != !var)) {
-        set_error("vmp_decoder_loglike_fwd: NULL argument");
-        return VMP_E_BADARG;
-    }
-    if (N == 0) return 0;
-    DecArgs a{};
-    a.x = x; a.y = y; a.W0 = W0; a.b0 = b0; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Ws = Ws; a.bs1 = bs1; a.bs2 = bs2;
-    a.ll = ll; a.mean = mean; a.var = var;
-    a.R = (unsigned)(N * K * S); a.K = (unsigned)K; a.S = (unsigned)S; a.L = L; a.Dy = Dy; a.U = U;
-    const int blocks = dec_fwd_blocks((long long)a.R);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-#define DEC_FWD(UTV)                                                                                                  \
-    do {                                                                                                              \
-        const int lds = Img<UTV>::FWD_END * (int)sizeof(float);                                                       \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fwd_kernel<UTV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        hipLaunchKernelGGL((dec_fwd_kernel<UTV>), dim3(blocks), dim3(FWD_THREADS), lds, s, a);                        \
-    } while (0)
-    DEC_DISPATCH(U, DEC_FWD);
-#undef DEC_FWD
-    return check_launch("vmp_decoder_loglike_fwd");
+    return decoder_fwd_impl("vmp_decoder_loglike_fwd", 1.0f, x, y, W0, b0, W1, b1, W2, b2, Ws, bs1, bs2, N, K, S, L, Dy, U, ll, mean, var,
+                            stream);
+}
+
+int vmp_mlp_gauss_head_fwd(const float* x, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
+                           const float* b2, const float* Ws, const float* bs1, const float* bs2, int64_t R, int L, int Dy, int U,
+                           float var_scale, float* out1, float* out2, void* stream) {
+    return decoder_fwd_impl("vmp_mlp_gauss_head_fwd", var_scale, x, nullptr, W0, b0, W1, b1, W2, b2, Ws, bs1, bs2, R, 1, 1, L, Dy, U,
+                            nullptr, out1, out2, stream);
 }
 
 int vmp_decoder_loglike_bwd(const float* x, const float* y, const float* gA, const float* W0, const float* b0,
                             const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws,
                             const float* bs1, const float* bs2, int64_t N, int K, int S, int L, int Dy, int U, float* dx,
                             float* dparams, float* ll, void* ws, size_t ws_bytes, void* stream) {
-    return decoder_loglike_bwd_impl("vmp_decoder_loglike_bwd", 0.f, x, y, gA, W0, b0, W1, b1, W2, b2, Ws, bs1, bs2, N, K, S, L, Dy, U,
+    return decoder_loglike_bwd_impl("vmp_decoder_loglike_bwd", 0.f, nullptr, 0, x, y, gA, W0, b0, W1, b1, W2, b2, Ws, bs1, bs2, N, K, S, L, Dy, U,
                                     dx, dparams, ll, ws, ws_bytes, stream);
 }
 
@@ -1183,38 +1241,47 @@ int vmp_decoder_loglike_bwd_logw(const float* x, const float* y, const float* lo
         set_error("vmp_decoder_loglike_bwd_logw: w_scale must not be 0");
         return VMP_E_BADARG;
     }
-    return decoder_loglike_bwd_impl("vmp_decoder_loglike_bwd_logw", w_scale, x, y, log_w, W0, b0, W1, b1, W2, b2, Ws, bs1, bs2, N, K,
+    return decoder_loglike_bwd_impl("vmp_decoder_loglike_bwd_logw", w_scale, nullptr, 0, x, y, log_w, W0, b0, W1, b1, W2, b2, Ws, bs1, bs2, N, K,
                                     S, L, Dy, U, dx, dparams, ll, ws, ws_bytes, stream);
+}
+
+int vmp_decoder_elbo(const float* x, const float* y, const float* log_z, const float* T_prime, float sigma, const float* W0,
+                     const float* b0, const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws,
+                     const float* bs1, const float* bs2, int64_t N, int K, int S, int L, int Dy, int U, float* dx,
+                     float* dparams, float* ll, float* scalars, float* g_log_z, float* g_T_prime, float* r, void* ws,
+                     size_t ws_bytes, void* tail_ws, size_t tail_ws_bytes, void* stream) {
+    if (sigma == 0.f || !ll || !log_z || !T_prime || !scalars || !g_log_z || !g_T_prime || !r || !tail_ws) {
+        set_error("vmp_decoder_elbo: NULL argument or sigma == 0");
+        return VMP_E_BADARG;
+    }
+    if (tail_ws_bytes < tail_workspace_bytes()) {
+        set_error("vmp_decoder_elbo: tail workspace too small (%zu < %zu bytes)", tail_ws_bytes, tail_workspace_bytes());
+        return VMP_E_WS;
+    }
+    if (N <= 0 || K < 1 || S < 1) {
+        set_error("vmp_decoder_elbo: N = %lld, K = %d, S = %d", (long long)N, K, S);
+        return VMP_E_DIM;
+    }
+    TailArgs t{};
+    const unsigned tb = tail_setup(t, log_z, T_prime, ll, N, K, S, Dy, sigma, scalars, g_log_z, g_T_prime, r, tail_ws, 64 * DEC_RED_GROUPS);
+    return decoder_loglike_bwd_impl("vmp_decoder_elbo", -sigma * 0.5f / (float)S, &t, tb, x, y, log_z, W0, b0, W1, b1, W2, b2, Ws, bs1,
+                                    bs2, N, K, S, L, Dy, U, dx, dparams, ll, ws, ws_bytes, stream);
 }
 
 int vmp_mlp_gauss_bwd(const float* x, const float* gmean, const float* gvar, const float* W0, const float* b0,
                       const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws, const float* bs1,
                       const float* bs2, int64_t R, int L, int Dy, int U, float* dx, float* dparams, void* ws,
                       size_t ws_bytes, void* stream) {
-    if (int e = dec_check("vmp_mlp_gauss_bwd", R, 1, 1, L, Dy, U)) return e;
-    if (!x || !gmean || !gvar || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !Ws || !bs1 || !bs2 || !dparams || !ws) {
-        set_error("vmp_mlp_gauss_bwd: NULL argument");
-        return VMP_E_BADARG;
-    }
-    const DecGeo q = dec_geo(L, U, Dy);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (R == 0) {
-        (void)hipMemsetAsync(dparams, 0, (size_t)q.PW * sizeof(float), s);
-        return check_launch("vmp_mlp_gauss_bwd");
-    }
-    if (ws_bytes < vmp_decoder_workspace_bytes(R, 1, 1, L, U, Dy)) {
-        set_error("vmp_mlp_gauss_bwd: workspace too small");
-        return VMP_E_WS;
-    }
-    DecArgs a{};
-    a.x = x; a.gmean = gmean; a.gvar = gvar; a.W0 = W0; a.b0 = b0; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Ws = Ws;
-    a.bs1 = bs1; a.bs2 = bs2; a.dx = dx; a.part = static_cast<float*>(ws);
-    a.R = (unsigned)R; a.K = 1; a.S = 1; a.L = L; a.Dy = Dy; a.U = U;
-    const int blocks = dec_bwd_blocks((long long)a.R);
-    if (int e = dec_bwd_launch<true>(a, blocks, s)) return e;
-    DecRedArgs r{a.part, bs2, dparams, blocks, q.PW, q.obs2, Dy};
-    hipLaunchKernelGGL(dec_reduce_kernel, dim3((q.PW + 63) / 64), dim3(64 * DEC_RED_GROUPS), 0, s, r);
-    return check_launch("vmp_mlp_gauss_bwd(reduce)");
+    return mlp_gauss_bwd_impl("vmp_mlp_gauss_bwd", 1.0f, x, gmean, gvar, W0, b0, W1, b1, W2, b2, Ws, bs1, bs2, R, L, Dy, U, dx, dparams,
+                              ws, ws_bytes, stream);
+}
+
+int vmp_mlp_gauss_head_bwd(const float* x, const float* g_out1, const float* g_out2, float var_scale, const float* W0,
+                           const float* b0, const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws,
+                           const float* bs1, const float* bs2, int64_t R, int L, int Dy, int U, float* dx, float* dparams,
+                           void* ws, size_t ws_bytes, void* stream) {
+    return mlp_gauss_bwd_impl("vmp_mlp_gauss_head_bwd", var_scale, x, g_out1, g_out2, W0, b0, W1, b1, W2, b2, Ws, bs1, bs2, R, L, Dy, U,
+                              dx, dparams, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -1531,41 +1531,12 @@ __global__ __launch_bounds__(1024) void pivot_kernel(PivotArgs a) {
     }
 }
 
-// Raw moments of a SMALL batch (the training step at the reference's minibatch sizes, experiments.py:26: 64-100 rows):
-// one block per component, thread (row group g, statistic i) sums the rows n = g (mod 12) in fp64 on the un-shifted data,
-// the group sums are added in a fixed order.  One launch of a few microseconds instead of pivot + streaming pass +
-// reduction (three launches, ~22 us at N = 64, most of it fixed cost).
-struct SmallStatsArgs { const float* x; const float* r; const float* u; double* stats; int N, D, K; };
-constexpr int SMALL_STATS_MAX_N = 512;
-constexpr int SMALL_STATS_GROUPS = 12;          // row groups per component: 12 x 80 threads, <= 6 rows each at N = 64
+// Raw moments of a SMALL batch: small_stats_component (vmp_common.h), one block per component.
 __global__ __launch_bounds__(SMALL_STATS_GROUPS * 80) void small_stats_kernel(SmallStatsArgs a) {
     __shared__ double part[SMALL_STATS_GROUPS][80];
-    const int k = blockIdx.x, g = threadIdx.x / 80, i = threadIdx.x % 80;
-    const int D = a.D, SW = 2 + D + D * D;
-    double s = 0.0;
-    if (i < SW) {
-        const int d = i < 2 + D ? (i < 2 ? 0 : i - 2) : (i - 2 - D) / D, e = i < 2 + D ? 0 : (i - 2 - D) % D;
-#pragma unroll 2
-        for (int n = g; n < a.N; n += SMALL_STATS_GROUPS) {
-            const float rf = a.r[(long long)n * a.K + k];
-            const float wf = a.u ? rf * a.u[(long long)n * a.K + k] : rf;          // w = r u in fp32, as the pass kernel forms it
-            const double xd = (double)a.x[(long long)n * D + d], xe = (double)a.x[(long long)n * D + e];
-            double t;
-            if (i == 0) t = rf;
-            else if (i == 1) t = wf;
-            else if (i < 2 + D) t = (double)wf * xd;
-            else t = (double)wf * xd * xe;
-            s += t;
-        }
-    }
-    part[g][i] = s;
-    __syncthreads();
-    if (g == 0 && i < SW) {
-        double t = part[0][i];
-#pragma unroll
-        for (int j = 1; j < SMALL_STATS_GROUPS; ++j) t += part[j][i];
-        a.stats[(long long)k * SW + i] = t;
-    }
+    const int SW = 2 + a.D + a.D * a.D, i = threadIdx.x % 80;
+    const double t = small_stats_component(a, blockIdx.x, part);
+    if (threadIdx.x < 80 && i < SW) a.stats[(long long)blockIdx.x * SW + i] = t;
 }
 
 // ---------------------------------------------------------------------------------------------------------

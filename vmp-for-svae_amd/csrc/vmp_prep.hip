@@ -83,9 +83,9 @@ __device__ __forceinline__ double pick(const double (&r)[L], int idx) {
 // instructions each) is spread over the lanes; only the two triangular solves are serial (every lane runs them on
 // operands broadcast from LDS).  (One thread per component did all of it serially: 11-12 us per launch at L = 8.)
 template <int L, bool BWD>
-__global__ __launch_bounds__(PREP_THREADS) void phi_prep_kernel(PhiArgs a) {
+__device__ __forceinline__ void phi_prep_body(const PhiArgs& a, const int k) {
     static_assert(L * L <= PREP_THREADS, "one lane per matrix element");
-    const int k = blockIdx.x, lane = threadIdx.x, K = a.K;
+    const int lane = threadIdx.x, K = a.K;
     __shared__ double Ls[L][L + 1];
     __shared__ double Gm[L][L + 1];
     __shared__ double inv_d[L];
@@ -167,10 +167,13 @@ struct ThetaArgs {
 
 // Block per component, lane (i, j) per matrix element as in phi_prep_kernel: the two digammas run side by side in lanes 0
 // and 1, the Cholesky factor is built column by column in LDS (rows in parallel), the columns of its inverse in parallel.
+template <int L, bool BWD>
+__global__ __launch_bounds__(PREP_THREADS) void phi_prep_kernel(PhiArgs a) { phi_prep_body<L, BWD>(a, blockIdx.x); }
+
 template <int L>
-__global__ __launch_bounds__(PREP_THREADS) void theta_pack_kernel(ThetaArgs a) {
+__device__ __forceinline__ void theta_pack_body(const ThetaArgs& a, const int k) {
     static_assert(L * L <= PREP_THREADS, "one lane per matrix element");
-    const int k = blockIdx.x, lane = threadIdx.x, K = a.K;
+    const int lane = threadIdx.x, K = a.K;
     __shared__ double Cs[L][L + 1];                     // sym(C) / nu, overwritten by its Cholesky factor (lower)
     __shared__ double inv_d[L];
     const int i = lane / L, j = lane % L;
@@ -223,6 +226,17 @@ __global__ __launch_bounds__(PREP_THREADS) void theta_pack_kernel(ThetaArgs a) {
     if (lane == 0) a.kappa[k] = (float)(-0.5 * L * 1.8378770664093454836 + elp + lw);
 }
 
+template <int L>
+__global__ __launch_bounds__(PREP_THREADS) void theta_pack_kernel(ThetaArgs a) { theta_pack_body<L>(a, blockIdx.x); }
+
+// Both K-sized forward maps of a training step in ONE launch: blocks [0, K) unpack the recognition GMM, blocks [K, 2K) pack
+// theta - they are independent, and at minibatch sizes a launch costs as much as either of them.
+template <int L>
+__global__ __launch_bounds__(PREP_THREADS) void prep_both_kernel(PhiArgs a, ThetaArgs t) {
+    if ((int)blockIdx.x < a.K) phi_prep_body<L, false>(a, blockIdx.x);
+    else theta_pack_body<L>(t, blockIdx.x - a.K);
+}
+
 struct CviArgs {
     const double* stats;                           // (K, 2+L+L*L): [Nk | Wk | sx | sxx]
     const float *p_alpha, *p_A, *p_b, *p_beta, *p_vhat;   // prior (natural)
@@ -238,29 +252,51 @@ __device__ __forceinline__ void cvi_one(float* __restrict__ t, float* __restrict
     t[i] = t[i] * (1.0f - rho) + rho * star;       // update_gmm_params: theta <- (1-rho) theta + rho theta*
 }
 
+// element f (< L*L + L + 3) of component k; st = that component's raw moments [Nk | Wk | sx | sxx]
+__device__ __forceinline__ void cvi_element(const CviArgs& a, const double* __restrict__ st, int k, int f, float rho) {
+    const int L = a.L;
+    const float Nk = (float)st[0];
+    if (f < L * L) {
+        const size_t i = (size_t)k * L * L + f;
+        cvi_one(a.t_A, a.s_A, a.p_A[i] + (float)st[2 + L + f], rho, i);
+    } else if (f < L * L + L) {
+        const int d = f - L * L;
+        const size_t i = (size_t)k * L + d;
+        cvi_one(a.t_b, a.s_b, a.p_b[i] + (float)st[2 + d], rho, i);
+    } else if (f == L * L + L) {
+        cvi_one(a.t_alpha, a.s_alpha, a.p_alpha[k] + Nk, rho, k);
+    } else if (f == L * L + L + 1) {
+        cvi_one(a.t_beta, a.s_beta, a.p_beta[k] + Nk, rho, k);
+    } else {
+        cvi_one(a.t_vhat, a.s_vhat, a.p_vhat[k] + Nk + 1.0f, rho, k);   // the +1 of gmm.update_vk (gmm.py:81)
+    }
+}
+
 __global__ __launch_bounds__(256) void cvi_kernel(CviArgs a) {
     const int K = a.K, L = a.L, SW = 2 + L + L * L;
     const float rho = a.rho_dev ? *a.rho_dev : a.rho;
     const int per = L * L + L + 3;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < K * per; e += gridDim.x * blockDim.x) {
         const int k = e / per, f = e - k * per;
-        const double* __restrict__ st = a.stats + (size_t)k * SW;
-        const float Nk = (float)st[0];
-        if (f < L * L) {
-            const size_t i = (size_t)k * L * L + f;
-            cvi_one(a.t_A, a.s_A, a.p_A[i] + (float)st[2 + L + f], rho, i);
-        } else if (f < L * L + L) {
-            const int d = f - L * L;
-            const size_t i = (size_t)k * L + d;
-            cvi_one(a.t_b, a.s_b, a.p_b[i] + (float)st[2 + d], rho, i);
-        } else if (f == L * L + L) {
-            cvi_one(a.t_alpha, a.s_alpha, a.p_alpha[k] + Nk, rho, k);
-        } else if (f == L * L + L + 1) {
-            cvi_one(a.t_beta, a.s_beta, a.p_beta[k] + Nk, rho, k);
-        } else {
-            cvi_one(a.t_vhat, a.s_vhat, a.p_vhat[k] + Nk + 1.0f, rho, k);   // the +1 of gmm.update_vk (gmm.py:81)
-        }
+        cvi_element(a, a.stats + (size_t)k * SW, k, f, rho);
     }
+}
+
+// M-step moments of a small batch AND the CVI update in one launch (the single-process training step at minibatch sizes:
+// the moments of the whole minibatch are in hand, no all-reduce between the two): block k sums component k's moments
+// (small_stats_component, vmp_common.h), publishes them, and updates component k of theta from the copy in LDS.
+__global__ __launch_bounds__(SMALL_STATS_GROUPS * 80) void stats_cvi_kernel(SmallStatsArgs sa, CviArgs a) {
+    __shared__ double part[SMALL_STATS_GROUPS][80];
+    __shared__ double st[80];
+    const int k = blockIdx.x, L = a.L, SW = 2 + L + L * L, i = threadIdx.x % 80;
+    const double t = small_stats_component(sa, k, part);
+    if (threadIdx.x < 80 && i < SW) {
+        st[i] = t;
+        sa.stats[(long long)k * SW + i] = t;
+    }
+    __syncthreads();
+    const float rho = a.rho_dev ? *a.rho_dev : a.rho;
+    for (int f = threadIdx.x; f < L * L + L + 3; f += blockDim.x) cvi_element(a, st, k, f, rho);
 }
 
 // Reduction of the fused E-step backward kernel's per-block partial sums (vmp_svae_estep_bwd: (nblk, K, PW) with
@@ -371,6 +407,45 @@ int vmp_svae_theta_pack(const float* alpha, const float* A, const float* b, cons
     PREP_DISPATCH_L(L, PREP_CALL)
 #undef PREP_CALL
     return check_launch("vmp_svae_theta_pack");
+}
+
+int vmp_svae_prep_fwd(const float* mu_k, const float* L_raw, const float* pi_raw, const float* alpha, const float* A,
+                      const float* b, const float* beta, const float* v_hat, int K, int L, float* Lk, float* P, float* bias,
+                      float* m, float* W, float* kappa, void* stream) {
+    if (int e = prep_check("vmp_svae_prep_fwd", K, L)) return e;
+    if (!mu_k || !L_raw || !pi_raw || !Lk || !P || !bias || !alpha || !A || !b || !beta || !v_hat || !m || !W || !kappa) {
+        set_error("vmp_svae_prep_fwd: NULL argument");
+        return VMP_E_BADARG;
+    }
+    PhiArgs a{};
+    a.mu = mu_k; a.Lraw = L_raw; a.piraw = pi_raw; a.Lk = Lk; a.P = P; a.bias = bias; a.K = K; a.L = L;
+    ThetaArgs t{alpha, A, b, beta, v_hat, m, W, kappa, K, L};
+#define PREP_CALL(LL) hipLaunchKernelGGL((prep_both_kernel<LL>), dim3(2 * K), dim3(PREP_THREADS), 0, static_cast<hipStream_t>(stream), a, t)
+    PREP_DISPATCH_L(L, PREP_CALL)
+#undef PREP_CALL
+    return check_launch("vmp_svae_prep_fwd");
+}
+
+int vmp_svae_stats_cvi(const float* x_samples, const float* r, int64_t N, const float* p_alpha, const float* p_A, const float* p_b,
+                       const float* p_beta, const float* p_vhat, float* t_alpha, float* t_A, float* t_b, float* t_beta,
+                       float* t_vhat, float* s_alpha, float* s_A, float* s_b, float* s_beta, float* s_vhat,
+                       const float* rho_dev, float rho, int K, int L, double* stats_out, void* stream) {
+    if (int e = prep_check("vmp_svae_stats_cvi", K, L)) return e;
+    if (N < 0 || N > SMALL_STATS_MAX_N) {
+        set_error("vmp_svae_stats_cvi: N = %lld outside 0..%d (larger batches: vmp_mix_stats + vmp_svae_cvi_update)", (long long)N,
+                  SMALL_STATS_MAX_N);
+        return VMP_E_DIM;
+    }
+    if ((N > 0 && (!x_samples || !r)) || !stats_out || !p_alpha || !p_A || !p_b || !p_beta || !p_vhat || !t_alpha || !t_A || !t_b ||
+        !t_beta || !t_vhat) {
+        set_error("vmp_svae_stats_cvi: NULL argument");
+        return VMP_E_BADARG;
+    }
+    SmallStatsArgs sa{x_samples, r, nullptr, stats_out, (int)N, L, K};
+    CviArgs a{stats_out, p_alpha, p_A, p_b, p_beta, p_vhat, t_alpha, t_A, t_b, t_beta, t_vhat,
+              s_alpha, s_A, s_b, s_beta, s_vhat, rho_dev, rho, K, L};
+    hipLaunchKernelGGL(stats_cvi_kernel, dim3(K), dim3(SMALL_STATS_GROUPS * 80), 0, static_cast<hipStream_t>(stream), sa, a);
+    return check_launch("vmp_svae_stats_cvi");
 }
 
 int vmp_svae_cvi_update(const double* stats, const float* p_alpha, const float* p_A, const float* p_b, const float* p_beta,

@@ -1,0 +1,98 @@
+// Scalar tail of the SVAE ELBO as a device function (see vmp_step.hip): shared by the stand-alone launch
+// (vmp_svae_elbo_tail) and the launch that runs it beside the decoder's partial reduction (vmp_decoder_elbo).
+#pragma once
+#include "vmp_common.h"
+
+namespace vmp {
+
+constexpr int TAIL_MAX_BLOCKS = 1024;
+constexpr int TAIL_MAX_WAVES = 16;      // block sizes up to 1024 threads
+
+struct TailArgs {
+    const float* lz;      // (NK)
+    const float* Tp;      // (NK)
+    const float* ll;      // (NK, S) per-sample reconstruction sums of the decoder kernel
+    float* g_lz;          // (NK)  sigma * d elbo / d log z
+    float* g_Tp;          // (NK)  sigma * d elbo / d T'
+    float* r;             // (NK)  exp(log z)
+    float* scal;          // [elbo, rec, reg]
+    double* part;         // (blocks, 2)
+    unsigned* ticket;     // zero between launches (the last block resets it)
+    long long NK;
+    int S;
+    float sigma;
+    double cst;           // N Dy / 2 log(2 pi)
+};
+
+__device__ __forceinline__ double tail_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// block tb of ntb (any block size that is a multiple of 64, <= 1024)
+__device__ __forceinline__ void elbo_tail_body(const TailArgs& a, const unsigned tb, const unsigned ntb) {
+    __shared__ double sm[2][TAIL_MAX_WAVES];
+    __shared__ unsigned last;
+    const float hs = 0.5f / (float)a.S;
+    double wa = 0.0, rg = 0.0;
+    for (long long c = (long long)tb * blockDim.x + threadIdx.x; c < a.NK; c += (long long)ntb * blockDim.x) {
+        const float lz = a.lz[c], tp = a.Tp[c];
+        const float r = expf(lz);
+        const float* __restrict__ lr = a.ll + c * a.S;
+        float A = 0.f;
+        for (int s = 0; s < a.S; ++s) A += lr[s];
+        const float w = hs * r;
+        wa += (double)w * (double)A;
+        rg += (double)r * (double)(tp + lz);
+        a.r[c] = r;
+        a.g_lz[c] = -a.sigma * (w * A + r * (tp + lz + 1.0f));
+        a.g_Tp[c] = -a.sigma * r;
+    }
+    wa = tail_wave_sum(wa);
+    rg = tail_wave_sum(rg);
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE, nwv = blockDim.x / WAVE;
+    if (lane == 0) { sm[0][wave] = wa; sm[1][wave] = rg; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int i = 0; i < nwv; ++i) { s0 += sm[0][i]; s1 += sm[1][i]; }
+        // partials are published and read with device-scope atomics: the blocks of a launch sit on different XCDs (own L2s)
+        __hip_atomic_store(a.part + 2 * tb, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.part + 2 * tb + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == ntb - 1;
+    }
+    __syncthreads();
+    if (!last || threadIdx.x != 0) return;
+    __threadfence();
+    double s0 = 0.0, s1 = 0.0;
+    for (unsigned b = 0; b < ntb; ++b) {                             // fixed order: deterministic
+        s0 += __hip_atomic_load(a.part + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s1 += __hip_atomic_load(a.part + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const double rec = -s0 - a.cst;
+    a.scal[0] = (float)(rec - s1);
+    a.scal[1] = (float)rec;
+    a.scal[2] = (float)s1;
+    __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+inline size_t tail_workspace_bytes() { return (size_t)TAIL_MAX_BLOCKS * 2 * sizeof(double) + 64; }
+
+// fills a TailArgs and returns the number of blocks of `threads` threads to run it on
+inline unsigned tail_setup(TailArgs& a, const float* log_z, const float* T_prime, const float* ll, long long N, int K, int S, int Dy,
+                           float sigma, float* scalars, float* g_log_z, float* g_T_prime, float* r, void* ws, int threads) {
+    a.lz = log_z; a.Tp = T_prime; a.ll = ll; a.g_lz = g_log_z; a.g_Tp = g_T_prime; a.r = r; a.scal = scalars;
+    a.ticket = static_cast<unsigned*>(ws);
+    a.part = reinterpret_cast<double*>(static_cast<char*>(ws) + 64);
+    a.NK = N * K; a.S = S; a.sigma = sigma;
+    a.cst = (double)N * Dy * 0.5 * 1.8378770664093453;             // log(2 pi)
+    long long blocks = (a.NK + threads - 1) / threads;
+    if (blocks > TAIL_MAX_BLOCKS) blocks = TAIL_MAX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+}  // namespace vmp

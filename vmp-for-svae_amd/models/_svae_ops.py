@@ -410,9 +410,9 @@ def _tail_workspace(device):
 
 class FusedElboFn(torch.autograd.Function):
     """(y, x (N,K,S,L), log_z (N,K), T' (N,K), 9 decoder parameters) -> (elbo, rec, reg, r): compute_elbo of reference
-    svae.py:199-262 for the fused decoder in three launches (decoder value + gradients with r = exp(log_z) formed inside
-    the kernel, the reduction of its per-block parameter partials, and the scalar tail) instead of those plus ~24 (N,K)-
-    sized torch launches.  `seed` is the upstream gradient the caller WILL pass for elbo (a 0-dim tensor, e.g. -1 for
+    svae.py:199-262 for the fused decoder in two launches (decoder value + gradients with r = exp(log_z) formed inside
+    the kernel; then the reduction of its per-block parameter partials beside the scalar tail) instead of those plus ~24
+    (N,K)-sized torch launches.  `seed` is the upstream gradient the caller WILL pass for elbo (a 0-dim tensor, e.g. -1 for
     loss = -elbo; None = +1): the stored gradients are pre-multiplied by it, and backward only rescales - with a few
     launches - when handed a different tensor.  rec, reg and r are returned for reporting / the M-step and carry no
     gradient."""
@@ -435,14 +435,20 @@ class FusedElboFn(torch.autograd.Function):
         nbytes = L.lib().vmp_decoder_workspace_bytes(N, K, S, Ld, U, Dy)
         ws = L.workspace(x.device, nbytes)
         sigma = float(sigma)
-        L.check(L.lib().vmp_decoder_loglike_bwd_logw(L.ptr(x), L.ptr(y), L.ptr(lz), -sigma * 0.5 / S, *[L.ptr(p) for p in params],
-                                                     N, K, S, Ld, Dy, U, L.ptr(dx), L.ptr(dp), L.ptr(ll), L.ptr(ws), nbytes,
-                                                     L.stream()), 'vmp_decoder_loglike_bwd_logw')
         scal = torch.empty(3, **f32)
         g_lz, g_Tp, r = torch.empty(N, K, **f32), torch.empty(N, K, **f32), torch.empty(N, K, **f32)
         tws = _tail_workspace(x.device)
-        L.check(L.lib().vmp_svae_elbo_tail(L.ptr(lz), L.ptr(Tp), L.ptr(ll), N, K, S, Dy, sigma, L.ptr(scal), L.ptr(g_lz),
-                                           L.ptr(g_Tp), L.ptr(r), L.ptr(tws), tws.numel(), L.stream()), 'vmp_svae_elbo_tail')
+        if N > 0:
+            # decoder value + gradients (r = exp(log_z) formed in the kernel), then partial reduction and scalar tail together
+            L.check(L.lib().vmp_decoder_elbo(L.ptr(x), L.ptr(y), L.ptr(lz), L.ptr(Tp), sigma, *[L.ptr(p) for p in params], N, K, S,
+                                             Ld, Dy, U, L.ptr(dx), L.ptr(dp), L.ptr(ll), L.ptr(scal), L.ptr(g_lz), L.ptr(g_Tp),
+                                             L.ptr(r), L.ptr(ws), nbytes, L.ptr(tws), tws.numel(), L.stream()), 'vmp_decoder_elbo')
+        else:
+            L.check(L.lib().vmp_decoder_loglike_bwd_logw(L.ptr(x), L.ptr(y), L.ptr(lz), -sigma * 0.5 / S, *[L.ptr(p) for p in params],
+                                                         N, K, S, Ld, Dy, U, L.ptr(dx), L.ptr(dp), L.ptr(ll), L.ptr(ws), nbytes,
+                                                         L.stream()), 'vmp_decoder_loglike_bwd_logw')
+            L.check(L.lib().vmp_svae_elbo_tail(L.ptr(lz), L.ptr(Tp), L.ptr(ll), N, K, S, Dy, sigma, L.ptr(scal), L.ptr(g_lz),
+                                               L.ptr(g_Tp), L.ptr(r), L.ptr(tws), tws.numel(), L.stream()), 'vmp_svae_elbo_tail')
         ctx.save_for_backward(dx, dp, g_lz, g_Tp)
         ctx.pshapes = [tuple(p.shape) for p in params]
         ctx.seed, ctx.sigma = seed, sigma
@@ -490,24 +496,38 @@ def decoder_outputs(x, params):
 
 
 class PhiPrepFn(torch.autograd.Function):
-    """(mu_k, L_k_raw, pi_k_raw) -> (h_k = mu_k, P_k = L L^T, bias_k) - the K-sized inputs of the fused E-step -
-    one launch forward, one backward (reference svae.py:342-358 and :70-92; csrc/vmp_prep.hip)."""
+    """(mu_k, L_k_raw, pi_k_raw [, the 5 natural GMM theta tensors]) -> (h_k = mu_k, P_k = L L^T, bias_k [, m_k, W_k, kappa_k])
+    - the K-sized inputs of the fused E-step - one launch forward, one backward (reference svae.py:342-358 and :70-92;
+    csrc/vmp_prep.hip).  With theta the packed theta (theta_pack_gmm: no gradient, as the reference's stop_gradient,
+    svae.py:211-214) comes out of the SAME launch."""
 
     @staticmethod
-    def forward(ctx, mu_k, L_raw, pi_raw):
+    def forward(ctx, mu_k, L_raw, pi_raw, *theta):
         mu_k = _c(mu_k, 'phi_gmm/mu_k')
         K, Ld = mu_k.shape
         L_raw = _c(L_raw, 'phi_gmm/L_k', (K, Ld, Ld))
         pi_raw = _c(pi_raw, 'phi_gmm/log_pi_k', (K,))
         f32 = dict(dtype=torch.float32, device=mu_k.device)
         Lk, P, bias = torch.empty(K, Ld, Ld, **f32), torch.empty(K, Ld, Ld, **f32), torch.empty(K, **f32)
+        ctx.save_for_backward(mu_k, L_raw, pi_raw)
+        ctx.n_theta = len(theta)
+        ctx.set_materialize_grads(False)           # no zero-filled gradients for the packed-theta outputs
+        if theta:
+            if len(theta) != 5:
+                raise L.VmpError('PhiPrepFn: theta must be the 5 natural NIW / Dirichlet tensors')
+            alpha, A, b, beta, v_hat = [_c(t, n) for t, n in zip(theta, ('alpha', 'A', 'b', 'beta', 'v_hat'))]
+            m, W, kappa = torch.empty(K, Ld, **f32), torch.empty(K, Ld, Ld, **f32), torch.empty(K, **f32)
+            L.check(L.lib().vmp_svae_prep_fwd(L.ptr(mu_k), L.ptr(L_raw), L.ptr(pi_raw), L.ptr(alpha), L.ptr(A), L.ptr(b),
+                                              L.ptr(beta), L.ptr(v_hat), K, Ld, L.ptr(Lk), L.ptr(P), L.ptr(bias), L.ptr(m),
+                                              L.ptr(W), L.ptr(kappa), L.stream()), 'vmp_svae_prep_fwd')
+            ctx.mark_non_differentiable(m, W, kappa)
+            return mu_k.view_as(mu_k), P, bias, m, W, kappa
         L.check(L.lib().vmp_svae_phi_prep_fwd(L.ptr(mu_k), L.ptr(L_raw), L.ptr(pi_raw), K, Ld, L.ptr(Lk), L.ptr(P),
                                               L.ptr(bias), L.stream()), 'vmp_svae_phi_prep_fwd')
-        ctx.save_for_backward(mu_k, L_raw, pi_raw)
         return mu_k.view_as(mu_k), P, bias         # h_k IS mu_k (svae.py:345): a view, not a copy launch
 
     @staticmethod
-    def backward(ctx, g_hk, g_P, g_bias):
+    def backward(ctx, g_hk, g_P, g_bias, *_unused):
         mu_k, L_raw, pi_raw = ctx.saved_tensors
         K, Ld = mu_k.shape
         z = lambda g, ref: torch.zeros_like(ref) if g is None else g.contiguous().float()
@@ -518,7 +538,7 @@ class PhiPrepFn(torch.autograd.Function):
         L.check(L.lib().vmp_svae_phi_prep_bwd(L.ptr(mu_k), L.ptr(L_raw), L.ptr(pi_raw), L.ptr(g_hk), L.ptr(g_P),
                                               L.ptr(g_bias), K, Ld, L.ptr(g_mu), L.ptr(g_L), L.ptr(g_pi), L.stream()),
                 'vmp_svae_phi_prep_bwd')
-        return g_mu, g_L, g_pi
+        return (g_mu, g_L, g_pi) + (None,) * ctx.n_theta
 
 
 def theta_pack_gmm(theta):
@@ -552,13 +572,38 @@ def cvi_update(gmm_prior, theta, stats, rho, want_star=True, rho_dev=None):
     return star if want_star else None
 
 
+STATS_CVI_MAX_ROWS = 512          # SMALL_STATS_MAX_N of the library
+
+
+def stats_cvi(x_samples, r_nk, gmm_prior, theta, rho, want_star=True, rho_dev=None):
+    """M-step moments of a small batch (<= 512 rows) AND cvi_update from them in one launch (vmp_svae_stats_cvi): the
+    single-process whole-minibatch training step.  Returns (stats (K, 2+L+L*L) fp64, theta* or None)."""
+    x = _c(x_samples.detach(), 'x_samples')
+    N, Ld = x.shape
+    pri = [_c(t.detach(), 'prior') for t in gmm_prior]
+    K = pri[2].shape[0]
+    r = _c(r_nk.detach(), 'r_nk', (N, K))
+    for t in theta:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise L.VmpError('theta must be contiguous fp32 GPU tensors')
+    stats = torch.empty(K, 2 + Ld + Ld * Ld, dtype=torch.float64, device=x.device)
+    star = [torch.empty_like(t) for t in theta] if want_star else [None] * 5
+    L.check(L.lib().vmp_svae_stats_cvi(L.ptr(x), L.ptr(r), N, *[L.ptr(t) for t in pri], *[L.ptr(t) for t in theta],
+                                       *[L.ptr(t) for t in star], L.ptr(rho_dev), float(rho), K, Ld, L.ptr(stats), L.stream()),
+            'vmp_svae_stats_cvi')
+    for t in theta:
+        torch.autograd.graph.increment_version(t)
+    return stats, (star if want_star else None)
+
+
 class GaussMLPFn(torch.autograd.Function):
-    """(x (R,L), 9 parameters) -> (mean, var) (R,Dy) of the two-tanh-layer Gaussian-head MLP with shortcut (reference
-    vae.py:75-128, 'standard' head) through the fused MFMA kernels, differentiable: one launch forward, one (+ the
-    partial reduce) backward.  The encoder's 'natparam' head is (mean, -1/2 var) (vae.py:38-42,108-111)."""
+    """(x (R,L), head scale, 9 parameters) -> (out1, out2) (R,Dy) of the two-tanh-layer Gaussian-head MLP with shortcut
+    (reference vae.py:75-128) through the fused MFMA kernels, differentiable: one launch forward, one (+ the partial
+    reduce) backward.  Head scale 1: 'standard' (mean, var); -1/2: the encoder's 'natparam' head (eta1, -1/2 var)
+    (vae.py:38-42,108-111) - applied inside the kernels."""
 
     @staticmethod
-    def forward(ctx, x, *params):
+    def forward(ctx, x, var_scale, *params):
         x = _c(x, 'mlp input')
         if x.dim() != 2:
             raise L.VmpError('input must have shape (R, L)')
@@ -567,10 +612,11 @@ class GaussMLPFn(torch.autograd.Function):
         R = x.shape[0]
         mean = torch.empty(R, Dy, dtype=torch.float32, device=x.device)
         var = torch.empty(R, Dy, dtype=torch.float32, device=x.device)
-        L.check(L.lib().vmp_decoder_loglike_fwd(L.ptr(x), None, *[L.ptr(p) for p in params], R, 1, 1, Ld, Dy, U, None,
-                                                L.ptr(mean), L.ptr(var), L.stream()), 'vmp_decoder_loglike_fwd')
+        L.check(L.lib().vmp_mlp_gauss_head_fwd(L.ptr(x), *[L.ptr(p) for p in params], R, Ld, Dy, U, float(var_scale), L.ptr(mean),
+                                               L.ptr(var), L.stream()), 'vmp_mlp_gauss_head_fwd')
         ctx.save_for_backward(x, *params)
         ctx.dims = (R, Ld, Dy, U)
+        ctx.var_scale = float(var_scale)
         return mean, var
 
     @staticmethod
@@ -584,6 +630,7 @@ class GaussMLPFn(torch.autograd.Function):
         dp = torch.empty(L.lib().vmp_decoder_param_words(Ld, U, Dy), dtype=torch.float32, device=x.device)
         nbytes = L.lib().vmp_decoder_workspace_bytes(R, 1, 1, Ld, U, Dy)
         ws = L.workspace(x.device, nbytes)
-        L.check(L.lib().vmp_mlp_gauss_bwd(L.ptr(x), L.ptr(g_mean), L.ptr(g_var), *[L.ptr(p) for p in params], R, Ld, Dy, U,
-                                          L.ptr(dx), L.ptr(dp), L.ptr(ws), nbytes, L.stream()), 'vmp_mlp_gauss_bwd')
-        return (dx,) + tuple(_split_flat(dp, params))
+        L.check(L.lib().vmp_mlp_gauss_head_bwd(L.ptr(x), L.ptr(g_mean), L.ptr(g_var), ctx.var_scale, *[L.ptr(p) for p in params],
+                                               R, Ld, Dy, U, L.ptr(dx), L.ptr(dp), L.ptr(ws), nbytes, L.stream()),
+                'vmp_mlp_gauss_head_bwd')
+        return (dx, None) + tuple(_split_flat(dp, params))

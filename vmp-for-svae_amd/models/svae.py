@@ -173,8 +173,11 @@ def e_step(phi_enc, phi_gmm, nb_samples, seed=0, name="e_step", noise=None, thet
     densities compute_elbo needs are evaluated in the same pass."""
     eta1_phi1, eta2_diag = phi_enc
     N, Ld = eta1_phi1.shape
-    # unpack_recognition_gmm + the k-only part of compute_log_z_given_y in one launch (autograd: one more)
-    eta1_phi2, P, bias = _svae_ops.PhiPrepFn.apply(*phi_gmm)
+    # unpack_recognition_gmm + the k-only part of compute_log_z_given_y in one launch (autograd: one more); a natural
+    # GMM theta is packed by the same launch
+    gmm_theta = theta is not None and len(theta) == 5
+    prep = _svae_ops.PhiPrepFn.apply(*phi_gmm, *([t.detach() for t in theta] if gmm_theta else []))
+    eta1_phi2, P, bias = prep[:3]
     K = eta1_phi2.shape[0]
     if isinstance(noise, str):
         if noise != 'philox':
@@ -183,7 +186,10 @@ def e_step(phi_enc, phi_gmm, nb_samples, seed=0, name="e_step", noise=None, thet
     elif noise is None:
         g = torch.Generator(device=eta1_phi1.device).manual_seed(int(seed))
         noise = torch.randn(N, K, Ld, nb_samples, generator=g, device=eta1_phi1.device)
-    mk, Wk, kap, nu = _theta_pack(theta) if theta is not None else _neutral_theta(K, Ld, eta1_phi1.device)
+    if gmm_theta:
+        mk, Wk, kap, nu = prep[3], prep[4], prep[5], None
+    else:
+        mk, Wk, kap, nu = _theta_pack(theta) if theta is not None else _neutral_theta(K, Ld, eta1_phi1.device)
     x, lz, Tp = _svae_ops.SvaeEStepFn.apply(eta1_phi1, eta2_diag, eta1_phi2, P, bias, noise, mk, Wk, kap, nu)
     # without theta the (phi, noise) the E-step ran on stay attached, so that compute_elbo can evaluate the theta term
     # afterwards; with theta (the training path) nothing extra is kept alive

@@ -109,8 +109,7 @@ def make_encoder(input, layerspecs=None, stddev_init=1., param_device=None, seed
         layerspecs = [(100, torch.tanh), (100, torch.tanh), (10, 'standard')]
     if input.is_cuda and input.dim() == 2 and _fused_mlp_eligible(input.shape[-1], layerspecs):
         ps = decoder_variables(input.shape[-1], layerspecs, stddev_init, seed, input.device, name='encoder_net')
-        mean, var = _svae_ops.GaussMLPFn.apply(input, *ps)
-        return (mean, var) if layerspecs[-1][1] == 'standard' else (mean, -0.5 * var)
+        return _svae_ops.GaussMLPFn.apply(input, 1.0 if layerspecs[-1][1] == 'standard' else -0.5, *ps)
     return make_nnet(input, layerspecs, stddev_init, 'encoder_net', param_device, seed)
 
 

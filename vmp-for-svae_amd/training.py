@@ -202,6 +202,9 @@ class SVAETrainer(object):
         grads = stats = None
         elbo_t = rec_t = reg_t = 0.0
         keep = {}
+        r_whole = None
+        # the M-step moments and the CVI update are one launch when nothing has to be summed in between (chunks, ranks)
+        fused_m = (not self.smm) and world == 1 and rows <= chunk and 0 < rows <= _svae_ops.STATS_CVI_MAX_ROWS
         for ci, i in enumerate(range(0, rows, chunk)):
             ys = y[i:i + chunk]
             ns = None if noise is None else noise[i:i + chunk]
@@ -213,13 +216,16 @@ class SVAETrainer(object):
             g = torch.autograd.grad(elbo, params, grad_outputs=self._neg_one.tensor, allow_unused=True)   # loss = -elbo
             g = [torch.zeros_like(p) if gi is None else gi for gi, p in zip(g, params)]
             r_nk = details.r_nk if details.r_nk is not None else torch.exp(log_z.detach())
-            if self.smm:                                                              # svae.m_step_smm: N_k only
+            if fused_m:
+                st = None                                                             # moments + CVI in one launch below
+            elif self.smm:                                                            # svae.m_step_smm: N_k only
                 from .models import gmm as _gmm
                 st = _gmm.update_Nk(r_nk.contiguous()).double().reshape(-1, 1)
             else:
                 st = _mix.raw_stats(x_s.detach().contiguous(), r_nk.contiguous())  # HIP: (K, 2+L+L*L) fp64
             grads = g if grads is None else [a + b for a, b in zip(grads, g)]
-            stats = st if stats is None else stats + st
+            if not fused_m:
+                stats = st if stats is None else stats + st
             rec, reg = details[0], details[3]                # the two debug scalars in between are computed on access only
             if ci == 0:
                 elbo_t, rec_t, reg_t = elbo.detach(), rec.detach(), reg.detach()
@@ -227,6 +233,7 @@ class SVAETrainer(object):
                 elbo_t, rec_t, reg_t = elbo_t + elbo.detach(), rec_t + rec.detach(), reg_t + reg.detach()
             if rows <= chunk:
                 keep = dict(log_z=log_z.detach(), x_samples=x_s.detach(), x_k=x_k.detach())
+                r_whole = r_nk
             del elbo, details, x_k, x_s, log_z
         if world > 1:
             buf = pack_for_allreduce(stats, grads, [elbo_t, rec_t, reg_t])
@@ -238,7 +245,11 @@ class SVAETrainer(object):
         lrcvi = exponential_decay(self.lrcvi0, self.global_step, 1000, self.decay_rate)
         if self.opt is None:
             self.opt = TFAdam(params, self.lr)
-        if self.smm:                                                                # experiments.py:252-256
+        if fused_m:                                                                 # whole minibatch, one process, <= 512 rows
+            rho_dev = None if _dev_scalars is None else _dev_scalars[0]
+            stats, theta_star = _svae_ops.stats_cvi(keep['x_samples'], r_whole, self.gmm_prior, self.theta,
+                                                    0.0 if rho_dev is not None else lrcvi, rho_dev=rho_dev)
+        elif self.smm:                                                              # experiments.py:252-256
             theta_star = [self.gmm_prior + stats[:, 0].float()]
             svae.update_gmm_params(self.theta[:1], theta_star, lrcvi)
         elif _dev_scalars is not None:
