@@ -159,9 +159,16 @@ int    vmp_svae_estep_fwd(const float* eta1, const float* eta2d, const float* hk
  * vmp_svae_philox_noise writes that stream as a tensor (tests; callers that want to keep the draw).               */
 int    vmp_svae_rng_in_kernel(int K, int L, int S);
 int    vmp_svae_philox_noise(uint64_t seed, int64_t N, int K, int L, int S, float* noise, void* stream);
+int    vmp_svae_philox_noise_dev(const uint64_t* seed_dev, int64_t N, int K, int L, int S, float* noise, void* stream);   /* key from a device word */
 int    vmp_svae_estep_fwd_rng(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
                               uint64_t seed, const float* mk, const float* Wk, const float* kappa, const float* nu,
                               int64_t N, int K, int L, int S, float* x, float* lz, float* Tp, float* noise_ws, void* stream);
+/* The same with the key read from a DEVICE word at execution time (in-kernel shapes only, vmp_svae_rng_in_kernel != 0): a
+ * launch captured in a HIP graph draws fresh noise on every replay once the caller refreshes *seed_dev.            */
+int    vmp_svae_estep_fwd_rng_dev(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
+                                  const uint64_t* seed_dev, const float* mk, const float* Wk, const float* kappa,
+                                  const float* nu, int64_t N, int K, int L, int S, float* x, float* lz, float* Tp,
+                                  void* stream);
 
 /* Backward of the above: given dLoss/dx (N,K,S,L) (from the decoder), dLoss/dlog_z (N,K), dLoss/dT' (N,K), writes
  * dLoss/deta1, dLoss/deta2d (N,L) and per-block partial sums over n of dLoss/d{hk, Pk, bias}:
@@ -182,6 +189,11 @@ int    vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk
  * u (N,S_out) - replacing tf.multinomial - or the supplied index z (N,S_out) when z != NULL.  out (N,S_out,L).  */
 int    vmp_svae_subsample(const float* x, const float* lz, const float* u, const int64_t* z, int64_t N, int K, int S,
                           int L, int S_out, float* out, int64_t* z_out, void* stream);
+/* The same with the uniforms drawn in the kernel: u_ns = top 24 bits of word 0 of Philox4x32-10(key = seed, counter =
+ * (n low, n high, s, 0x5bb5a3c1)) * 2^-24 - a stream apart from the E-step's normals (whose counter word 3 is 0).  The key
+ * is `seed`, or *seed_dev when seed_dev != NULL (graph-captured steps).                                              */
+int    vmp_svae_subsample_rng(const float* x, const float* lz, uint64_t seed, const uint64_t* seed_dev, int64_t N, int K,
+                              int S, int L, int S_out, float* out, int64_t* z_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K-sized parameter maps of the training step, one launch each (one thread per component, fp64 inside)
@@ -325,6 +337,11 @@ size_t vmp_svae_elbo_tail_workspace_bytes(void);
 int    vmp_svae_elbo_tail(const float* log_z, const float* T_prime, const float* ll, int64_t N, int K, int S, int Dy,
                           float sigma, float* scalars, float* g_log_z, float* g_T_prime, float* r, void* ws,
                           size_t ws_bytes, void* stream);
+
+/* Writes the 16 bytes [Philox key (u64) | CVI step size (f32) | Adam step size (f32)] that a graph-captured training step
+ * reads at run time (vmp_svae_estep_fwd_rng_dev / vmp_svae_subsample_rng seed_dev, vmp_svae_cvi_update rho_dev,
+ * vmp_adam_step lr_t_dev = dst16 + 0 / 8 / 12): one launch, values passed by value.                                  */
+int    vmp_svae_step_scalars(void* dst16, uint64_t philox_key, float cvi_step, float adam_step, void* stream);
 
 /* tf.train.AdamOptimizer's update (TF 1.3; experiments.py:264-265) of n_tensors fp32 tensors in one launch per 32
  * tensors:  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr_t m / (sqrt(v) + eps), where the caller supplies the

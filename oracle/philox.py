@@ -66,3 +66,22 @@ def cell_noise(seed, cells, L, S):
                 if i < L and s < S:
                     out[:, i, s] = z[:, b, j]
     return out
+
+
+SUBSAMPLE_TAG = 0x5bb5a3c1
+
+
+def subsample_uniforms(seed, N, S_out):
+    """(N, S_out) float32 uniforms in [0,1) of the categorical draw (csrc/vmp_svae.hip subsample_kernel, rng mode): top 24
+    bits of word 0 of Philox4x32-10(key = seed, counter = (n low, n high, s, SUBSAMPLE_TAG)) * 2^-24."""
+    n = np.arange(N, dtype=np.uint64)
+    ctr = np.zeros((N, S_out, 4), dtype=np.uint32)
+    ctr[..., 0] = (n & np.uint64(0xFFFFFFFF)).astype(np.uint32)[:, None]
+    ctr[..., 1] = (n >> np.uint64(32)).astype(np.uint32)[:, None]
+    ctr[..., 2] = np.arange(S_out, dtype=np.uint32)[None, :]
+    ctr[..., 3] = np.uint32(SUBSAMPLE_TAG)
+    key = np.zeros((N, S_out, 2), dtype=np.uint32)
+    key[..., 0] = np.uint32(seed & 0xFFFFFFFF)
+    key[..., 1] = np.uint32((seed >> 32) & 0xFFFFFFFF)
+    w = philox4x32_10(ctr, key)[..., 0]
+    return ((w >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)

@@ -119,3 +119,72 @@ def test_trainer_default_noise_is_reproducible_and_seed_dependent():
     assert all(torch.equal(a, b) for a, b in zip(wa, wb)) and ea == eb and all(torch.equal(a, b) for a, b in zip(pa, pb))
     assert ea != ec and not all(torch.equal(a, c) for a, c in zip(wa, wc))
     assert all(np.isfinite(ea)) and ea[0] != ea[1]                           # a new draw every step
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,K,S,Ld', [(300, 10, 10, 8), (64, 16, 4, 6), (7, 3, 5, 1)])
+def test_subsample_in_kernel_uniforms_equal_oracle(N, K, S, Ld):
+    """subsample_x(u='philox'): the kernel's own uniforms are the oracle's (Philox counter (n, s, tag)) - the drawn
+    components equal the inverse CDF evaluated with the oracle's uniforms, with the key by value and in a device word."""
+    import vmp_for_svae_amd as V
+    from vmp_for_svae_amd.models import _svae_ops, svae
+    L = V._lib
+    g = torch.Generator(device='cuda').manual_seed(N)
+    x = torch.randn(N, K, S, Ld, device='cuda', generator=g)
+    lz = torch.log_softmax(torch.randn(N, K, device='cuda', generator=g), -1)
+    seed = 0x1234567890ABCDEF
+    u = torch.tensor(philox.subsample_uniforms(seed, N, S), device='cuda')
+    want = svae.subsample_x(x, lz, u=u)
+    got = svae.subsample_x(x, lz, seed=seed, u='philox')
+    assert torch.equal(got, want)
+    key = seed - (1 << 64) if seed >= 1 << 63 else seed
+    sd = torch.tensor([key], dtype=torch.int64, device='cuda')
+    got2 = svae.subsample_x(x, lz, u=_svae_ops.PhiloxNoise(0, S, seed_dev=sd))
+    assert torch.equal(got2, want)
+
+
+@pytest.mark.gpu
+def test_estep_key_from_device_word():
+    """vmp_svae_estep_fwd_rng_dev: the E-step with its Philox key read from a device word == the by-value form."""
+    from vmp_for_svae_amd.models import _svae_ops, svae
+    N, K, Ld, S = 200, 10, 8, 10
+    g = torch.Generator(device='cuda').manual_seed(1)
+    e1 = torch.randn(N, Ld, device='cuda', generator=g)
+    e2 = -0.5 - torch.rand(N, Ld, device='cuda', generator=g)
+    _, theta = svae.init_mm(K, Ld, seed=0)
+    phi = list(svae.init_recognition_params(theta, K, seed=0))
+    a = svae.e_step((e1, e2), phi, S, seed=77, noise='philox', theta=theta)
+    sd = torch.tensor([77], dtype=torch.int64, device='cuda')
+    b = svae.e_step((e1, e2), phi, S, noise=_svae_ops.PhiloxNoise(0, S, seed_dev=sd), theta=theta)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2].T_prime, b[2].T_prime)
+    sd.fill_(78)
+    c = svae.e_step((e1, e2), phi, S, noise=_svae_ops.PhiloxNoise(0, S, seed_dev=sd), theta=theta)
+    assert not torch.equal(a[0], c[0])
+
+
+@pytest.mark.gpu
+def test_graphed_step_with_in_kernel_noise_follows_the_eager_trainer():
+    """GraphedSVAEStep of a default (rng='philox') trainer: eps and the draw's uniforms come from the captured kernels,
+    keyed by a device word the call refreshes - call i is training step i of the same trainer stepped eagerly."""
+    from vmp_for_svae_amd.models import vae
+    from vmp_for_svae_amd.training import SVAETrainer, GraphedSVAEStep
+    K, Ld, U, Dy, S, N = 10, 8, 50, 6, 10, 64
+    g = torch.Generator(device='cuda').manual_seed(5)
+    ys = [torch.randn(N, Dy, device='cuda', generator=g) * 2 for _ in range(4)]
+
+    def fresh():
+        vae.reset_variables()
+        return SVAETrainer(K, Ld, U, Dy, nb_samples=S, lr=3e-3, lrcvi=0.2, decay_rate=0.95, stddev_init_nn=0.1, seed=3)
+    tr = fresh()
+    elbos = [tr.step(ys[i])['elbo'].item() for i in range(4)]
+    want = [p.detach().clone() for p in tr.trainables()[1]] + [t.clone() for t in tr.theta]
+    tr2 = fresh()
+    gs = GraphedSVAEStep(tr2, ys[0], warmup=2)
+    assert gs.in_kernel_rng and gs.noise is None and tr2.global_step == 0 and tr2.opt.t == 0
+    got_elbo = [gs(ys[i])['elbo'].item() for i in range(4)]
+    got = list(tr2.trainables()[1]) + list(tr2.theta)
+    for a, b in zip(got_elbo, elbos):
+        assert abs(a - b) <= 2e-5 * abs(b), (a, b)
+    for a, b in zip(got, want):
+        err = ((a.detach().double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-300)).item()
+        assert err < 2e-5, err

@@ -316,7 +316,7 @@ def test_graphed_step_matches_eager():
 
     def fresh():
         vae.reset_variables()
-        return SVAETrainer(K, Ld, U, Dy, nb_samples=S, lr=3e-3, lrcvi=0.2, decay_rate=0.95, stddev_init_nn=0.1, seed=3)
+        return SVAETrainer(K, Ld, U, Dy, nb_samples=S, lr=3e-3, lrcvi=0.2, decay_rate=0.95, stddev_init_nn=0.1, seed=3, rng='torch')
     # eager reference run: call i of the graphed stepper must be training step i (the warm-up steps of the capture do
     # not train and do not consume the generator)
     tr = fresh()

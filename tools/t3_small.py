@@ -45,3 +45,10 @@ for _ in range(200):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 200
 print('T3 small GRAPHED N=%d: %.3f ms/step (%.0f steps/s)  elbo %.3f' % (N, dt * 1e3, 1 / dt, float(out['elbo'])))
+# ---- what the per-call refreshes outside the graph cost: replay alone
+t0 = time.perf_counter()
+for _ in range(200):
+    gs.graph.replay()
+torch.cuda.synchronize()
+dt2 = (time.perf_counter() - t0) / 200
+print('T3 small GRAPHED replay only: %.3f ms/step' % (dt2 * 1e3))

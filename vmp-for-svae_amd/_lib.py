@@ -35,6 +35,9 @@ _SIGNATURES = {
     'vmp_svae_rng_in_kernel': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int]),
     'vmp_svae_philox_noise': (_c.c_int, [_c.c_uint64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
     'vmp_svae_estep_fwd_rng': (_c.c_int, [_P] * 5 + [_c.c_uint64] + [_P] * 4 + [_c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _P]),
+    'vmp_svae_philox_noise_dev': (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
+    'vmp_svae_estep_fwd_rng_dev': (_c.c_int, [_P] * 10 + [_c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P]),
+    'vmp_svae_subsample_rng': (_c.c_int, [_P, _P, _c.c_uint64, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
     'vmp_svae_bwd_partial_words': (_c.c_int, [_c.c_int]),
     'vmp_svae_bwd_blocks': (_c.c_int, [_c.c_int64, _c.c_int]),
     'vmp_svae_workspace_bytes': (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int]),
@@ -64,6 +67,7 @@ _SIGNATURES = {
                          + [_c.c_size_t, _P, _c.c_size_t, _P]),
     'vmp_svae_elbo_tail_workspace_bytes': (_c.c_size_t, []),
     'vmp_svae_elbo_tail': (_c.c_int, [_P] * 3 + [_c.c_int64] + [_c.c_int] * 3 + [_c.c_float] + [_P] * 5 + [_c.c_size_t, _P]),
+    'vmp_svae_step_scalars': (_c.c_int, [_P, _c.c_uint64, _c.c_float, _c.c_float, _P]),
     'vmp_adam_step': (_c.c_int, [_c.c_int] + [_P] * 5 + [_c.c_double] * 4 + [_P, _P]),
     'vmp_svae_phi_prep_fwd': (_c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _P, _P, _P, _P]),
     'vmp_svae_prep_fwd': (_c.c_int, [_P] * 8 + [_c.c_int, _c.c_int] + [_P] * 7),

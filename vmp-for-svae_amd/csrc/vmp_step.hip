@@ -61,9 +61,24 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(AdamArgs a) {
     }
 }
 
+// [Philox key | CVI step size | Adam step size] of a graph-captured training step: the values travel in the launch packet
+// (by value), so the caller needs no staging buffer that an asynchronous copy could still be reading when it is rewritten.
+struct Words16 { unsigned long long key; float rho, lr_t; };
+__global__ void step_scalars_kernel(Words16* dst, Words16 v) { *dst = v; }
+
 }  // namespace
 
 extern "C" {
+
+int vmp_svae_step_scalars(void* dst16, uint64_t philox_key, float cvi_step, float adam_step, void* stream) {
+    if (!dst16 || (reinterpret_cast<uintptr_t>(dst16) & 7)) {
+        set_error("vmp_svae_step_scalars: dst16 must be an 8-byte aligned device pointer to 16 bytes");
+        return VMP_E_BADARG;
+    }
+    hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), static_cast<Words16*>(dst16),
+                       Words16{(unsigned long long)philox_key, cvi_step, adam_step});
+    return check_launch("vmp_svae_step_scalars");
+}
 
 size_t vmp_svae_elbo_tail_workspace_bytes(void) { return tail_workspace_bytes(); }
 

@@ -47,6 +47,7 @@ struct EFwdArgs {
     long long N;
     int K, S, vec_ok;
     unsigned long long seed;   // in-kernel noise (noise == NULL): Philox4x32-10 key
+    const unsigned long long* seed_dev;   // non-NULL: the key is read from this device word (graph-captured steps refresh it)
 #ifdef VMP_DEBUG_TS
     long long* dbg_t;
 #endif
@@ -1171,7 +1172,7 @@ __device__ __forceinline__ void philox_normal4(unsigned long long cell, unsigned
     hi = box_muller(c[2], c[3]);
 }
 
-struct NoiseArgs { float* out; long long cells; int L, S; unsigned long long seed; };
+struct NoiseArgs { float* out; long long cells; int L, S; unsigned long long seed; const unsigned long long* seed_dev; };
 // Materialises the same stream as a (cells, L, S) tensor: for shapes the in-kernel path does not cover, and for tests.
 __global__ __launch_bounds__(256) void philox_noise_kernel(NoiseArgs a) {
     const int SP = (a.S + 1) >> 1, LP = (a.L + 1) >> 1, NB = SP * LP;
@@ -1180,7 +1181,7 @@ __global__ __launch_bounds__(256) void philox_noise_kernel(NoiseArgs a) {
         const long long cell = e / NB;
         const int b = (int)(e - cell * NB), ip = b / SP, sp = b - ip * SP;
         v2f lo, hi;
-        philox_normal4((unsigned long long)cell, (unsigned)b, a.seed, lo, hi);
+        philox_normal4((unsigned long long)cell, (unsigned)b, a.seed_dev ? *a.seed_dev : a.seed, lo, hi);
         float* o = a.out + cell * a.L * a.S;
         const int i = 2 * ip, s2 = 2 * sp;
         o[i * a.S + s2] = lo.x;
@@ -1229,6 +1230,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
     const bool lane_on = lane < CT;
     const int r = lane / K, k = lane - r * K, rbase = lane_on ? r * K : 0;
     const bool k16 = (K == 16);
+    const unsigned long long rng_seed = (RNG && a.seed_dev) ? *a.seed_dev : a.seed;
     SV_TS(16);
 
 
@@ -1410,7 +1412,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
 #pragma unroll
                 for (int ip = 0; ip < LP; ++ip) {
                     v2f lo, hi;
-                    philox_normal4(cellid, (unsigned)ip * SPn + ((unsigned)s2 >> 1), a.seed, lo, hi);
+                    philox_normal4(cellid, (unsigned)ip * SPn + ((unsigned)s2 >> 1), rng_seed, lo, hi);
                     eo[2 * ip] = lo;
                     if (2 * ip + 1 < L) eo[2 * ip + 1] = hi;
                 }
@@ -1685,6 +1687,9 @@ struct SubArgs {
     long long* z_out;       // (N,S_out) chosen component (may be NULL)
     long long N;
     int K, S, L, S_out;
+    int rng;                // u == z == NULL: uniforms from Philox4x32-10, key = seed, counter = (n, s, tag)
+    unsigned long long seed;
+    const unsigned long long* seed_dev;   // non-NULL: key read from this device word
 };
 
 // One (n,k) cell per lane, RPT = 64 / K whole rows per wave: log_z is read coalesced (a thread-per-row loop over k touched 64
@@ -1702,6 +1707,7 @@ __global__ __launch_bounds__(256) void subsample_kernel(SubArgs a) {
     const long long ntiles = (a.N + RPT - 1) / RPT;
     const bool vec = (a.L & 3) == 0 && al16_dev(a.x) && al16_dev(a.out);
     const unsigned long long rowmask = (K < 64 ? (1ull << K) : 0ull) - 1ull;
+    const unsigned long long sub_seed = a.seed_dev ? *a.seed_dev : a.seed;
     for (long long t0 = wave * UN; t0 < ntiles; t0 += nwaves * UN) {
         long long n[UN];
         bool on[UN];
@@ -1731,7 +1737,16 @@ __global__ __launch_bounds__(256) void subsample_kernel(SubArgs a) {
             } else {
                 float uu[UN];
 #pragma unroll
-                for (int q = 0; q < UN; ++q) uu[q] = on[q] ? a.u[n[q] * a.S_out + s] : 0.f;
+                for (int q = 0; q < UN; ++q) {
+                    if (a.rng) {
+                        // one Philox block per (row, draw); the tag word keeps this stream apart from the E-step's normals
+                        unsigned c[4] = {(unsigned)n[q], (unsigned)((unsigned long long)n[q] >> 32), (unsigned)s, 0x5bb5a3c1u};
+                        philox4x32_10(c, (unsigned)sub_seed, (unsigned)(sub_seed >> 32));
+                        uu[q] = (float)(c[0] >> 8) * 5.9604644775390625e-08f;      // [0, 1)
+                    } else {
+                        uu[q] = on[q] ? a.u[n[q] * a.S_out + s] : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < UN; ++q) {
                     const unsigned long long below = __ballot(on[q] && k < K - 1 && cum[q] <= uu[q]);   // lanes k with cdf_k <= u
@@ -1952,16 +1967,25 @@ int vmp_svae_rng_in_kernel(int K, int L, int S) {
     return (K >= 1 && K <= 64 && L >= 1 && L <= 8 && fwd4_plan(K, L, S, CS, lds4, true) >= 1) ? 1 : 0;
 }
 
-int vmp_svae_philox_noise(uint64_t seed, int64_t N, int K, int L, int S, float* noise, void* stream) {
+static int philox_noise_impl(uint64_t seed, const uint64_t* seed_dev, int64_t N, int K, int L, int S, float* noise, void* stream) {
     int rc = check_sv(N, K, L, S);
     if (rc) return rc;
     if (!noise) { set_error("vmp_svae_philox_noise: null pointer"); return VMP_E_BADARG; }
-    NoiseArgs na{noise, (long long)N * K, L, S, (unsigned long long)seed};
+    NoiseArgs na{noise, (long long)N * K, L, S, (unsigned long long)seed, reinterpret_cast<const unsigned long long*>(seed_dev)};
     const long long total = na.cells * ((S + 1) / 2) * ((L + 1) / 2);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(philox_noise_kernel, dim3((int)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), na);
     return check_launch("philox_noise_kernel");
+}
+
+int vmp_svae_philox_noise(uint64_t seed, int64_t N, int K, int L, int S, float* noise, void* stream) {
+    return philox_noise_impl(seed, nullptr, N, K, L, S, noise, stream);
+}
+
+int vmp_svae_philox_noise_dev(const uint64_t* seed_dev, int64_t N, int K, int L, int S, float* noise, void* stream) {
+    if (!seed_dev) { set_error("vmp_svae_philox_noise_dev: null pointer"); return VMP_E_BADARG; }
+    return philox_noise_impl(0, seed_dev, N, K, L, S, noise, stream);
 }
 
 int vmp_svae_estep_fwd_rng(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
@@ -1984,6 +2008,25 @@ int vmp_svae_estep_fwd_rng(const float* eta1, const float* eta2d, const float* h
     a.noise = noise_ws;
     a.vec_ok = al16(noise_ws) && al16(x);
     return run_fwd(a, L, stream, false);
+}
+
+int vmp_svae_estep_fwd_rng_dev(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
+                               const uint64_t* seed_dev, const float* mk, const float* Wk, const float* kappa, const float* nu,
+                               int64_t N, int K, int L, int S, float* x, float* lz, float* Tp, void* stream) {
+    int rc = check_sv(N, K, L, S);
+    if (rc) return rc;
+    if (!eta1 || !eta2d || !hk || !Pk || !bias || !seed_dev || !mk || !Wk || !kappa || !x || !lz || !Tp) {
+        set_error("vmp_svae_estep_fwd_rng_dev: null pointer");
+        return VMP_E_BADARG;
+    }
+    if (!vmp_svae_rng_in_kernel(K, L, S)) {
+        set_error("vmp_svae_estep_fwd_rng_dev: K=%d L=%d S=%d is outside the in-kernel generator's shapes (vmp_svae_rng_in_kernel)", K, L, S);
+        return VMP_E_DIM;
+    }
+    EFwdArgs a{eta1, eta2d, hk, Pk, bias, nullptr, mk, Wk, kappa, nu, x, lz, Tp, N, K, S, 0, 0ull,
+               reinterpret_cast<const unsigned long long*>(seed_dev)};
+    a.vec_ok = al16(x);
+    return run_fwd(a, L, stream, true);
 }
 
 int vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
@@ -2040,19 +2083,31 @@ int vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk, c
     return rc;
 }
 
-int vmp_svae_subsample(const float* x, const float* lz, const float* u, const int64_t* z, int64_t N, int K, int S, int L,
-                       int S_out, float* out, int64_t* z_out, void* stream) {
-    if (!x || !lz || (!u && !z) || !out || N <= 0 || K <= 0 || S <= 0 || L <= 0 || S_out <= 0 || S_out > S) {
-        set_error("vmp_svae_subsample: bad argument");
+static int subsample_impl(const char* what, const float* x, const float* lz, const float* u, const int64_t* z, int rng, uint64_t seed,
+                          const uint64_t* seed_dev, int64_t N, int K, int S, int L, int S_out, float* out, int64_t* z_out,
+                          void* stream) {
+    if (!x || !lz || (!u && !z && !rng) || !out || N <= 0 || K <= 0 || S <= 0 || L <= 0 || S_out <= 0 || S_out > S) {
+        set_error("%s: bad argument", what);
         return VMP_E_BADARG;
     }
-    SubArgs a{x, lz, u, reinterpret_cast<const long long*>(z), out, reinterpret_cast<long long*>(z_out), N, K, S, L, S_out};
-    if (K > WAVE) { set_error("vmp_svae_subsample: K=%d > 64", K); return VMP_E_DIM; }
+    SubArgs a{x, lz, u, reinterpret_cast<const long long*>(z), out, reinterpret_cast<long long*>(z_out), N, K, S, L, S_out,
+              rng, (unsigned long long)seed, reinterpret_cast<const unsigned long long*>(seed_dev)};
+    if (K > WAVE) { set_error("%s: K=%d > 64", what, K); return VMP_E_DIM; }
     const int RPTs = WAVE / K;
     long long blocks = ((N + RPTs - 1) / RPTs + 15) / 16;               // 4 waves per block, 4 tiles of RPT rows per wave and turn
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(subsample_kernel, dim3((int)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
-    return check_launch("subsample_kernel");
+    return check_launch(what);
+}
+
+int vmp_svae_subsample(const float* x, const float* lz, const float* u, const int64_t* z, int64_t N, int K, int S, int L,
+                       int S_out, float* out, int64_t* z_out, void* stream) {
+    return subsample_impl("vmp_svae_subsample", x, lz, u, z, 0, 0, nullptr, N, K, S, L, S_out, out, z_out, stream);
+}
+
+int vmp_svae_subsample_rng(const float* x, const float* lz, uint64_t seed, const uint64_t* seed_dev, int64_t N, int K, int S,
+                           int L, int S_out, float* out, int64_t* z_out, void* stream) {
+    return subsample_impl("vmp_svae_subsample_rng", x, lz, nullptr, nullptr, 1, seed, seed_dev, N, K, S, L, S_out, out, z_out, stream);
 }
 
 }  // extern "C"

@@ -24,12 +24,19 @@ class PhiloxNoise(object):
     `seed`; include/vmp_hip.h vmp_svae_estep_fwd_rng).  The reference draws eps inside the step the same way
     (models/svae.py:113-114).  materialise() returns the identical stream as a tensor."""
 
-    def __init__(self, seed, nb_samples):
+    def __init__(self, seed, nb_samples, seed_dev=None):
+        """seed_dev: a one-element int64 device tensor that holds the key instead of `seed` - read by the kernel when it
+        RUNS, so that a launch captured in a HIP graph draws fresh noise per replay (in-kernel shapes only)."""
         self.seed, self.S = int(seed) & 0xFFFFFFFFFFFFFFFF, int(nb_samples)
+        self.seed_dev = seed_dev
 
     def materialise(self, N, K, Ld, device):
         out = torch.empty(N, K, Ld, self.S, dtype=torch.float32, device=device)
-        L.check(L.lib().vmp_svae_philox_noise(self.seed, N, K, Ld, self.S, L.ptr(out), L.stream()), 'vmp_svae_philox_noise')
+        if self.seed_dev is not None:
+            L.check(L.lib().vmp_svae_philox_noise_dev(L.ptr(self.seed_dev), N, K, Ld, self.S, L.ptr(out), L.stream()),
+                    'vmp_svae_philox_noise_dev')
+        else:
+            L.check(L.lib().vmp_svae_philox_noise(self.seed, N, K, Ld, self.S, L.ptr(out), L.stream()), 'vmp_svae_philox_noise')
         return out
 
 
@@ -60,7 +67,12 @@ class SvaeEStepFn(torch.autograd.Function):
         x = torch.empty(N, K, S, Ld, **f32)
         lz = torch.empty(N, K, **f32)
         Tp = torch.empty(N, K, **f32)
-        if rng is not None:
+        if rng is not None and rng.seed_dev is not None:
+            L.check(L.lib().vmp_svae_estep_fwd_rng_dev(L.ptr(eta1), L.ptr(eta2d), L.ptr(hk), L.ptr(Pk), L.ptr(bias),
+                                                       L.ptr(rng.seed_dev), L.ptr(mk), L.ptr(Wk), L.ptr(kappa), L.ptr(nu), N, K,
+                                                       Ld, S, L.ptr(x), L.ptr(lz), L.ptr(Tp), L.stream()),
+                    'vmp_svae_estep_fwd_rng_dev')
+        elif rng is not None:
             ws = None
             if not L.lib().vmp_svae_rng_in_kernel(K, Ld, S):     # shape outside the in-kernel path: same stream via a scratch tensor
                 ws = torch.empty(N, K, Ld, S, **f32)

@@ -183,6 +183,8 @@ def e_step(phi_enc, phi_gmm, nb_samples, seed=0, name="e_step", noise=None, thet
         if noise != 'philox':
             raise ValueError("noise must be a tensor, None or 'philox'")
         noise = _svae_ops.PhiloxNoise(seed, nb_samples)
+    elif isinstance(noise, _svae_ops.PhiloxNoise):
+        pass                                                 # caller-built (e.g. with the key in a device word)
     elif noise is None:
         g = torch.Generator(device=eta1_phi1.device).manual_seed(int(seed))
         noise = torch.randn(N, K, Ld, nb_samples, generator=g, device=eta1_phi1.device)
@@ -215,13 +217,24 @@ def sample_x_per_comp(eta1, eta2, nb_samples, seed=0, noise=None):
 
 def subsample_x(x_k_samples, log_q_z_given_y, seed=0, z_draws=None, nb_out=None, u=None):
     """reference svae.py:122-151: z_ns ~ Cat(exp log_q), gather x[n, z_ns, s].  HIP kernel vmp_svae_subsample;
-    `z_draws` (N,S) replaces tf.multinomial (default: inverse CDF of torch.rand with `seed`).  `nb_out` < S only
+    `z_draws` (N,S) replaces tf.multinomial (default: inverse CDF of torch.rand with `seed`; u='philox': of uniforms
+    drawn inside the kernel from Philox4x32-10 keyed by `seed`).  `nb_out` < S only
     produces the first nb_out sample columns (the reference's caller keeps s = 0, svae.py:514)."""
     x = L.dev_f32(x_k_samples.detach(), 'x_k_samples')
     N, K, S, Ld = x.shape
     lz = L.dev_f32(log_q_z_given_y.detach(), 'log_q_z_given_y', (N, K))
     So = S if nb_out is None else int(nb_out)
     z = None
+    if z_draws is None and (isinstance(u, str) or isinstance(u, _svae_ops.PhiloxNoise)):
+        # uniforms drawn inside the kernel (Philox4x32-10 keyed by `seed`, or by the device word of a PhiloxNoise)
+        if isinstance(u, str) and u != 'philox':
+            raise ValueError("u must be a tensor, None or 'philox'")
+        sd = u.seed_dev if isinstance(u, _svae_ops.PhiloxNoise) else None
+        key = (u.seed if isinstance(u, _svae_ops.PhiloxNoise) else int(seed)) & 0xFFFFFFFFFFFFFFFF
+        out = torch.empty(N, So, Ld, dtype=torch.float32, device=x.device)
+        L.check(L.lib().vmp_svae_subsample_rng(L.ptr(x), L.ptr(lz), key, L.ptr(sd), N, K, S, Ld, So, L.ptr(out), None, L.stream()),
+                'vmp_svae_subsample_rng')
+        return out
     if z_draws is not None:
         u = None
         z = z_draws[:, :So].to(torch.int64).contiguous()
@@ -420,6 +433,8 @@ def inference(y, phi_gmm, encoder_layers, decoder_layers, nb_samples=10, stddev_
     x_k_samples, log_z, phi_tilde, _ = e_step(x_given_y_phi, phi_gmm, nb_samples, seed=seed, noise=noise, theta=theta)
     y_rec = vae.make_decoder(x_k_samples, layerspecs=decoder_layers, stddev_init=stddev_init_nn, seed=seed,
                              lazy=lazy_decoder)
+    if u is None and z_draws is None and (isinstance(noise, str) or isinstance(noise, _svae_ops.PhiloxNoise)):
+        u = noise                                            # in-kernel noise: the draw's uniforms come from the same generator
     x_samples = subsample_x(x_k_samples, log_z, seed, z_draws=z_draws, nb_out=1, u=u)[:, 0, :]
     return y_rec, x_given_y_phi, x_k_samples, x_samples, log_z, phi_gmm, phi_tilde
 

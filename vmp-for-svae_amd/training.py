@@ -175,8 +175,16 @@ class SVAETrainer(object):
         rank = dist.get_rank(self.group) if (dist.is_available() and dist.is_initialized()) else 0
         return self.seed + self.global_step + 1000003 * rank + 15485863 * int(chunk_index)
 
-    def forward(self, y, noise=None, z_draws=None, u=None, chunk_index=0):
-        if noise is None and self.rng == 'philox':
+    def forward(self, y, noise=None, z_draws=None, u=None, chunk_index=0, _seed_dev=None):
+        if noise is None and _seed_dev is not None:
+            # graph-captured step: the key sits in a device word.  At minibatch sizes the stand-alone generator (all elements
+            # in parallel, ~3 us) + the E-step kernel that reads a noise tensor beat generating inside the E-step kernel, where
+            # one wave per SIMD pays the Philox rounds serially (+8 us at N = 64); the stream is the same one.
+            pn = _svae_ops.PhiloxNoise(0, self.S, seed_dev=_seed_dev)
+            noise = pn.materialise(y.shape[0], self.K, self.L, y.device)
+            if u is None and z_draws is None:
+                u = pn
+        elif noise is None and self.rng == 'philox':
             noise = 'philox'
         out = svae.inference(y, self.phi_gmm, self.encoder_layers, self.decoder_layers, self.S,
                              stddev_init_nn=self.stddev_init_nn, seed=self._step_seed(chunk_index), noise=noise,
@@ -192,8 +200,8 @@ class SVAETrainer(object):
     def step(self, y, noise=None, z_draws=None, chunk=None, u=None, _dev_scalars=None):
         """One training step.  `chunk` rows at a time (the ELBO is a sum over datapoints, so gradients and
         moments simply accumulate over chunks) - needed when N*K*S decoder rows do not fit at once.
-        `u` (N,1) supplies the uniforms of the categorical sub-sampling; `_dev_scalars` = (lrcvi, lr_t) as 0-dim
-        device tensors is what GraphedSVAEStep captures with (step counters are then advanced by the caller)."""
+        `u` (N,1) supplies the uniforms of the categorical sub-sampling; `_dev_scalars` = (lrcvi, lr_t[, Philox key]) as
+        one-element device tensors is what GraphedSVAEStep captures with (step counters are then advanced by the caller)."""
         import torch.distributed as dist
         world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
         rows = y.shape[0]
@@ -210,7 +218,8 @@ class SVAETrainer(object):
             ns = None if noise is None else noise[i:i + chunk]
             zs = None if z_draws is None else z_draws[i:i + chunk]
             us = None if u is None else u[i:i + chunk]
-            elbo, details, x_k, x_s, log_z = self.forward(ys, ns, zs, us, chunk_index=ci)
+            elbo, details, x_k, x_s, log_z = self.forward(ys, ns, zs, us, chunk_index=ci,
+                                                          _seed_dev=None if _dev_scalars is None or len(_dev_scalars) < 3 else _dev_scalars[2])
             if params is None:
                 names, params = self.trainables()
             g = torch.autograd.grad(elbo, params, grad_outputs=self._neg_one.tensor, allow_unused=True)   # loss = -elbo
@@ -275,10 +284,11 @@ class GraphedSVAEStep(object):
     and is bound by launch overhead, not by the GPU.  Per call: copy the minibatch into the static input, refresh the
     noise / uniforms in place, write the two step-dependent scalars (CVI step size, bias-corrected Adam step size) to
     device memory, replay.  GMM-SVAE, one process (the data-parallel step has a collective in the middle).
-    Noise: the graph reads eps from a static (N,K,L,S) tensor that every call refills with torch's generator - i.e. the
-    stream of an eager trainer built with rng='torch' (call i here == step i there, bit for bit).  A trainer with
-    rng='philox' (the default: eps drawn inside the E-step kernel from a host-side seed) draws a DIFFERENT stream when
-    stepped eagerly: a seed baked into a captured launch could not advance per replay."""
+    Noise.  Trainer with rng='philox' (the default): eps and the uniforms of the categorical draw are generated INSIDE the
+    captured kernels from a Philox key the kernels read from a device word at run time; a call writes [key | CVI step size |
+    Adam step size] with ONE launch (vmp_svae_step_scalars) and replays - the very stream of the same trainer stepped eagerly
+    (call i here == step i there).  Trainer with rng='torch': the graph reads eps / u from static tensors that every call
+    refills with torch's generator (three more launches per call), again the stream of that trainer stepped eagerly."""
 
     def __init__(self, trainer, y_example, warmup=3):
         tr = self.tr = trainer
@@ -288,10 +298,17 @@ class GraphedSVAEStep(object):
         N = y_example.shape[0]
         f32 = dict(dtype=torch.float32, device=dev)
         self.y = y_example.to(**f32).clone()
-        self.noise = torch.empty(N, tr.K, tr.L, tr.S, **f32)
-        self.u = torch.empty(N, 1, **f32)
-        self.rho = torch.zeros((), **f32)
-        self.lr_t = torch.zeros((), **f32)
+        self.in_kernel_rng = tr.rng == 'philox' and bool(L.lib().vmp_svae_rng_in_kernel(tr.K, tr.L, tr.S))
+        # [Philox key (int64) | CVI step size (f32) | Adam step size (f32)]: 16 bytes, refreshed by one launch per call
+        self._dev16 = torch.zeros(16, dtype=torch.uint8, device=dev)
+        self.seed_dev = self._dev16[:8].view(torch.int64)
+        self.rho = self._dev16[8:12].view(torch.float32)
+        self.lr_t = self._dev16[12:16].view(torch.float32)
+        if self.in_kernel_rng:
+            self.noise = self.u = None
+        else:
+            self.noise = torch.empty(N, tr.K, tr.L, tr.S, **f32)
+            self.u = torch.empty(N, 1, **f32)
         self.gen = torch.Generator(device=dev).manual_seed(int(tr.seed))
         # Warm-up steps (they create the variables / Adam slots and size the workspaces) must not train: everything a
         # step mutates is snapshotted first and put back before the capture, so that call number i of this object
@@ -313,7 +330,7 @@ class GraphedSVAEStep(object):
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):
                 self._refresh()
-                tr.step(self.y, noise=self.noise, u=self.u)
+                tr.step(self.y, noise=self.noise, u=self.u)      # (in-kernel noise: both None - the trainer's own default)
             with torch.no_grad():
                 for p, q in zip(params, snap['params']):
                     p.copy_(q)
@@ -328,7 +345,8 @@ class GraphedSVAEStep(object):
         self._refresh()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.out = tr.step(self.y, noise=self.noise, u=self.u, _dev_scalars=(self.rho, self.lr_t))
+            self.out = tr.step(self.y, noise=self.noise, u=self.u,
+                               _dev_scalars=(self.rho, self.lr_t) + ((self.seed_dev,) if self.in_kernel_rng else ()))
         self.gen.set_state(snap['gen'])     # the capture-time refresh drew nothing that a replay uses
         # the captured kernels hold raw pointers into the scratch buffers in use during the capture: keep exactly those
         # alive with the graph, and drop the warm-up side stream's buffers (never used again)
@@ -339,11 +357,13 @@ class GraphedSVAEStep(object):
 
     def _refresh(self):
         tr = self.tr
-        self.noise.normal_(generator=self.gen)
-        self.u.uniform_(generator=self.gen)
-        self.rho.fill_(exponential_decay(tr.lrcvi0, tr.global_step, 1000, tr.decay_rate))
-        if tr.opt is not None:
-            self.lr_t.fill_(tr.opt.lr_t(tr.opt.t + 1))
+        if not self.in_kernel_rng:
+            self.noise.normal_(generator=self.gen)
+            self.u.uniform_(generator=self.gen)
+        L.check(L.lib().vmp_svae_step_scalars(L.ptr(self._dev16), tr._step_seed(0) & 0xFFFFFFFFFFFFFFFF,
+                                              exponential_decay(tr.lrcvi0, tr.global_step, 1000, tr.decay_rate),
+                                              tr.opt.lr_t(tr.opt.t + 1) if tr.opt is not None else 0.0, L.stream()),
+                'vmp_svae_step_scalars')
 
     def __call__(self, y):
         tr = self.tr
