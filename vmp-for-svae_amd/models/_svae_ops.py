@@ -420,6 +420,13 @@ def _tail_workspace(device):
     return ws
 
 
+def release_tail_workspaces(stream):
+    """Forget (and return) the tail scratch of `stream`: a graph capture takes ownership of the buffer its captured launch
+    points into; a temporary warm-up stream's buffer is simply dropped."""
+    sid = stream.cuda_stream
+    return [_TAIL_WS.pop(k) for k in [k for k in _TAIL_WS if k[1] == sid]]
+
+
 class FusedElboFn(torch.autograd.Function):
     """(y, x (N,K,S,L), log_z (N,K), T' (N,K), 9 decoder parameters) -> (elbo, rec, reg, r): compute_elbo of reference
     svae.py:199-262 for the fused decoder in two launches (decoder value + gradients with r = exp(log_z) formed inside

@@ -344,7 +344,8 @@ class GraphedSVAEStep(object):
         self.gen.set_state(snap['gen'])
         self._refresh()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        cap_stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.graph(self.graph, stream=cap_stream):
             self.out = tr.step(self.y, noise=self.noise, u=self.u,
                                _dev_scalars=(self.rho, self.lr_t) + ((self.seed_dev,) if self.in_kernel_rng else ()))
         self.gen.set_state(snap['gen'])     # the capture-time refresh drew nothing that a replay uses
@@ -354,6 +355,8 @@ class GraphedSVAEStep(object):
         for k in self._ws_refs:                   # graph-pool memory: owned by this graph alone from here on
             L._WS.pop(k, None)
         L.release_workspaces(side)
+        _svae_ops.release_tail_workspaces(side)
+        self._tail_refs = _svae_ops.release_tail_workspaces(cap_stream)    # graph-pool memory the captured tail launch points into
 
     def _refresh(self):
         tr = self.tr
