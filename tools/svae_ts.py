@@ -26,7 +26,7 @@ for it in range(4):
     if it == 0:
         continue
     fn = ['P_k table + barrier', 'parameters arrived', 'eta + Cholesky + log z', 'noise / rows arrived', 'sample loop + lz, Tp stores', 'samples copied out']
-    print('FORWARD total %.2f us' % ((t[48 + 6] - t[48]) / 100.0))
+    print('FORWARD total %.2f us (+ %.2f us from kernel entry to the first stage stamp)' % ((t[48 + 6] - t[48]) / 100.0, (t[48] - t[55]) / 100.0))
     for i, n in enumerate(fn):
         print('   %-28s %7d cycles  %6.2f us' % (n, t[16 + i + 1] - t[16 + i], (t[48 + i + 1] - t[48 + i]) / 100.0))
     print('BACKWARD total %d cycles = %.2f us (wall clock, 100 MHz)' % (t[11] - t[0], (t[32 + 11] - t[32]) / 100.0))

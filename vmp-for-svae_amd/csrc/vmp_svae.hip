@@ -1207,6 +1207,7 @@ __global__ __launch_bounds__(256) void philox_noise_kernel(NoiseArgs a) {
 // the LDS tile then only serves the (cell, S, L) output transposition.
 template <int L, int ST, bool RNG>
 __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(EFwdArgs a, int CS_rt) {
+    SV_TS(23);
     constexpr int TRI = SvGeo<L>::TRI;
     constexpr int TP = (TRI + 1) / 2, LP = (L + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
