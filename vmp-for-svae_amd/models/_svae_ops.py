@@ -413,7 +413,7 @@ _TAIL_WS = {}
 def _tail_workspace(device):
     """Zero-initialised scratch of vmp_svae_elbo_tail (block partials + a ticket the kernel resets itself), one per device
     and stream."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, L._raw_stream(device.index))
     ws = _TAIL_WS.get(key)
     if ws is None:
         ws = _TAIL_WS[key] = torch.zeros(L.lib().vmp_svae_elbo_tail_workspace_bytes(), dtype=torch.uint8, device=device)
