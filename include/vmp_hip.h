@@ -313,9 +313,9 @@ int    vmp_decoder_loglike_bwd_logw(const float* x, const float* y, const float*
                                     int Dy, int U, float* dx, float* dparams, float* ll, void* ws, size_t ws_bytes,
                                     void* stream);
 
-/* compute_elbo for the fused decoder in TWO launches: vmp_decoder_loglike_bwd_logw with w_scale = -sigma / 2S, then ONE
- * launch in which some blocks reduce the decoder's parameter partials and the others run vmp_svae_elbo_tail (below) -
- * both wait for the decoder kernel only.  Arguments as those two calls; tail_ws as vmp_svae_elbo_tail's ws.  N >= 1.   */
+/* compute_elbo for the fused decoder in THREE launches: vmp_decoder_loglike_bwd_logw with w_scale = -sigma / 2S, then ONE
+ * launch in which some blocks reduce the decoder's parameter partials and the others run the (N,K) pass of
+ * vmp_svae_elbo_tail (below) - both wait for the decoder kernel only - then the one-wave sum of the tail's partials.  Arguments as those two calls; tail_ws as vmp_svae_elbo_tail's ws.  N >= 1.   */
 int    vmp_decoder_elbo(const float* x, const float* y, const float* log_z, const float* T_prime, float sigma,
                         const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
                         const float* b2, const float* Ws, const float* bs1, const float* bs2, int64_t N, int K, int S,
@@ -324,15 +324,15 @@ int    vmp_decoder_elbo(const float* x, const float* y, const float* log_z, cons
                         void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Scalar tail of the SVAE ELBO (models/svae.py:216-254 compute_elbo; vae.py:232-250) - one launch
+ * Scalar tail of the SVAE ELBO (models/svae.py:216-254 compute_elbo; vae.py:232-250) - two launches
  * ------------------------------------------------------------------------------------------------
  * From log_z (N,K), T_prime (N,K) (the theta side of the regulariser, as the fused E-step returns it) and the
  * per-sample reconstruction sums ll (N,K,S) of the decoder kernel:
  *   r = exp(log_z);  rec = -1/(2S) sum_nk r_nk sum_s ll_nks - N Dy/2 log(2 pi);  reg = sum_nk r_nk (T'_nk + log_z_nk)
  *   scalars = [elbo = rec - reg, rec, reg]   (fp64 sums, fixed order: deterministic)
  *   g_log_z = sigma * d elbo / d log_z,  g_T_prime = sigma * d elbo / d T'   (sigma = -1 for loss = -elbo)
- * ws: vmp_svae_elbo_tail_workspace_bytes() bytes, ZEROED by the caller before its first use (the kernel leaves it
- * reusable); one workspace per concurrently running stream.                                                          */
+ * Two launches: the (N,K) pass with per-block partial sums, then a one-wave sum of the partials in a fixed order.
+ * ws: vmp_svae_elbo_tail_workspace_bytes() bytes of scratch (no initialisation needed); one per concurrently running stream. */
 size_t vmp_svae_elbo_tail_workspace_bytes(void);
 int    vmp_svae_elbo_tail(const float* log_z, const float* T_prime, const float* ll, int64_t N, int K, int S, int Dy,
                           float sigma, float* scalars, float* g_log_z, float* g_T_prime, float* r, void* ws,

@@ -23,14 +23,15 @@ def rel(got, want):
                                             (40000, 16, 10, 8, 2.5), (0, 4, 2, 3, 1.0)])
 def test_elbo_tail_kernel(N, K, S, Dy, sigma):
     """elbo / rec / reg, r and the two gradient seeds of ONE launch vs torch fp64; several grid shapes (one block, many
-    blocks, grid-stride), launched twice on the same workspace (the ticket must come back to zero)."""
+    blocks, grid-stride), launched twice on the same workspace - which holds OTHER data's partials from the launch before."""
     import vmp_for_svae_amd as V
     L = V._lib
     g = torch.Generator(device='cuda').manual_seed(N + K)
     lz = torch.log_softmax(torch.randn(N, K, device='cuda', generator=g) * 2, -1)
     Tp = torch.randn(N, K, device='cuda', generator=g) * 3 - 5
     ll = torch.randn(N, K, S, device='cuda', generator=g) * 4 + 10
-    ws = torch.zeros(L.lib().vmp_svae_elbo_tail_workspace_bytes(), dtype=torch.uint8, device='cuda')
+    ws = torch.empty(L.lib().vmp_svae_elbo_tail_workspace_bytes(), dtype=torch.uint8, device='cuda')
+    ws.view(torch.float64).fill_(1e30)                       # whatever a previous launch left there must not matter
     for _ in range(2):
         scal = torch.full((3,), float('nan'), device='cuda')
         g_lz, g_Tp, r = (torch.full((N, K), float('nan'), device='cuda') for _ in range(3))
@@ -49,7 +50,6 @@ def test_elbo_tail_kernel(N, K, S, Dy, sigma):
             glz, gTp = torch.autograd.grad(sigma * elbo, [lz64, Tp64])
             assert rel(r, r64) < 3e-7
             assert rel(g_lz, glz) < 1e-6 and rel(g_Tp, gTp) < 3e-7
-        assert int(ws[:4].view(torch.int32).item()) == 0
 
 
 def test_adam_step_kernel():

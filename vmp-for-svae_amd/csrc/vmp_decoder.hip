@@ -1024,6 +1024,7 @@ __global__ __launch_bounds__(64 * DEC_RED_GROUPS) void dec_reduce_kernel(DecRedA
 
 // The reduction of the decoder's parameter partials and the scalar tail of the ELBO (vmp_tail.h) both wait for the decoder
 // kernel and for nothing else: one launch, blocks [0, red_blocks) reduce, the others run the tail.
+__global__ __launch_bounds__(WAVE) void dec_elbo_final_kernel(TailArgs t, unsigned ntb) { elbo_final_body(t, ntb); }
 __global__ __launch_bounds__(64 * DEC_RED_GROUPS) void dec_reduce_tail_kernel(DecRedArgs r, TailArgs t, int red_blocks) {
     if ((int)blockIdx.x < red_blocks) dec_reduce_body(r, blockIdx.x);
     else elbo_tail_body(t, blockIdx.x - red_blocks, gridDim.x - red_blocks);
@@ -1135,7 +1136,10 @@ int decoder_loglike_bwd_impl(const char* what, float logw, const TailArgs* tail,
     if (int e = dec_bwd_launch<false>(a, blocks, s)) return e;
     DecRedArgs r{a.part, bs2, dparams, blocks, q.PW, q.obs2, Dy};
     const int red_blocks = (q.PW + 63) / 64;
-    if (tail) hipLaunchKernelGGL(dec_reduce_tail_kernel, dim3(red_blocks + tail_blocks), dim3(64 * DEC_RED_GROUPS), 0, s, r, *tail, red_blocks);
+    if (tail) {
+        hipLaunchKernelGGL(dec_reduce_tail_kernel, dim3(red_blocks + tail_blocks), dim3(64 * DEC_RED_GROUPS), 0, s, r, *tail, red_blocks);
+        hipLaunchKernelGGL(dec_elbo_final_kernel, dim3(1), dim3(WAVE), 0, s, *tail, tail_blocks);      // the three scalars, behind a kernel boundary
+    }
     else hipLaunchKernelGGL(dec_reduce_kernel, dim3(red_blocks), dim3(64 * DEC_RED_GROUPS), 0, s, r);
     return check_launch(what);
 }

@@ -5,8 +5,8 @@
 // vae.py:232-250)
 //     rec = -1/(2S) sum_nk r_nk A_nk - N Dy/2 log(2 pi),   reg = sum_nk r_nk (T'_nk + log z_nk),   elbo = rec - reg
 // with r = exp(log z) and A_nk = sum_s ll_nks, and autograd runs the same chain backwards: ~24 elementwise / reduction
-// launches of 2 us each for (N,K)-sized tensors.  elbo_tail_kernel produces the three scalars, r, and the gradients of
-// sigma * elbo w.r.t. log z and T' in one launch.  adam_kernel is tf.train.AdamOptimizer's update (TF 1.3:
+// launches of 2 us each for (N,K)-sized tensors.  elbo_tail_kernel produces r, the gradients of sigma * elbo w.r.t. log z
+// and T' and per-block partial sums of the three scalars in one launch; elbo_final_kernel (one wave) adds the partials.  adam_kernel is tf.train.AdamOptimizer's update (TF 1.3:
 // lr_t = lr sqrt(1-b2^t)/(1-b1^t); var -= lr_t m / (sqrt(v) + eps)) for ALL parameter tensors in one launch.
 #include "vmp_common.h"
 #include "vmp_tail.h"
@@ -18,6 +18,7 @@ namespace {
 constexpr int TAIL_THREADS = 256;
 
 __global__ __launch_bounds__(TAIL_THREADS) void elbo_tail_kernel(TailArgs a) { elbo_tail_body(a, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(WAVE) void elbo_final_kernel(TailArgs a, unsigned ntb) { elbo_final_body(a, ntb); }
 
 // ---- Adam ------------------------------------------------------------------------------------------------------------
 constexpr int ADAM_MAX_TENSORS = 32;
@@ -99,6 +100,7 @@ int vmp_svae_elbo_tail(const float* log_z, const float* T_prime, const float* ll
     TailArgs a{};
     const unsigned blocks = tail_setup(a, log_z, T_prime, ll, N, K, S, Dy, sigma, scalars, g_log_z, g_T_prime, r, ws, TAIL_THREADS);
     hipLaunchKernelGGL(elbo_tail_kernel, dim3(blocks), dim3(TAIL_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(elbo_final_kernel, dim3(1), dim3(WAVE), 0, static_cast<hipStream_t>(stream), a, blocks);
     return check_launch("vmp_svae_elbo_tail");
 }
 

@@ -17,7 +17,6 @@ struct TailArgs {
     float* r;             // (NK)  exp(log z)
     float* scal;          // [elbo, rec, reg]
     double* part;         // (blocks, 2)
-    unsigned* ticket;     // zero between launches (the last block resets it)
     long long NK;
     int S;
     float sigma;
@@ -33,7 +32,6 @@ __device__ __forceinline__ double tail_wave_sum(double v) {
 // block tb of ntb (any block size that is a multiple of 64, <= 1024)
 __device__ __forceinline__ void elbo_tail_body(const TailArgs& a, const unsigned tb, const unsigned ntb) {
     __shared__ double sm[2][TAIL_MAX_WAVES];
-    __shared__ unsigned last;
     const float hs = 0.5f / (float)a.S;
     double wa = 0.0, rg = 0.0;
     for (long long c = (long long)tb * blockDim.x + threadIdx.x; c < a.NK; c += (long long)ntb * blockDim.x) {
@@ -57,36 +55,37 @@ __device__ __forceinline__ void elbo_tail_body(const TailArgs& a, const unsigned
     if (threadIdx.x == 0) {
         double s0 = 0.0, s1 = 0.0;
         for (int i = 0; i < nwv; ++i) { s0 += sm[0][i]; s1 += sm[1][i]; }
-        // partials are published and read with device-scope atomics: the blocks of a launch sit on different XCDs (own L2s)
-        __hip_atomic_store(a.part + 2 * tb, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.part + 2 * tb + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        last = t == ntb - 1;
+        a.part[2 * tb] = s0;
+        a.part[2 * tb + 1] = s1;
     }
-    __syncthreads();
-    if (!last || threadIdx.x != 0) return;
-    __threadfence();
-    double s0 = 0.0, s1 = 0.0;
-    for (unsigned b = 0; b < ntb; ++b) {                             // fixed order: deterministic
-        s0 += __hip_atomic_load(a.part + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s1 += __hip_atomic_load(a.part + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const double rec = -s0 - a.cst;
-    a.scal[0] = (float)(rec - s1);
-    a.scal[1] = (float)rec;
-    a.scal[2] = (float)s1;
-    __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-inline size_t tail_workspace_bytes() { return (size_t)TAIL_MAX_BLOCKS * 2 * sizeof(double) + 64; }
+// The per-block partials are summed by a SEPARATE single-wave launch (elbo_final_body), i.e. behind a kernel boundary.
+// A one-launch form - last block by ticket, partials published with device-scope atomics - was in use for a few hours: it
+// passed 5 000 repetitions of a determinism stress and then produced ONE wrong ELBO (1.2 % off: a block's partial of the
+// PREVIOUS launch) in the middle of a long test session.  The stress could not see it (same inputs every repetition: stale
+// partials equal fresh ones).  One more 2 us launch is the price of not depending on cross-XCD visibility inside a kernel.
+__device__ __forceinline__ void elbo_final_body(const TailArgs& a, const unsigned ntb) {
+    const int lane = threadIdx.x;                                   // one wave
+    double s0 = 0.0, s1 = 0.0;
+    for (unsigned b = lane; b < ntb; b += WAVE) { s0 += a.part[2 * b]; s1 += a.part[2 * b + 1]; }   // fixed assignment: deterministic
+    s0 = tail_wave_sum(s0);
+    s1 = tail_wave_sum(s1);
+    if (lane == 0) {
+        const double rec = -s0 - a.cst;
+        a.scal[0] = (float)(rec - s1);
+        a.scal[1] = (float)rec;
+        a.scal[2] = (float)s1;
+    }
+}
+
+inline size_t tail_workspace_bytes() { return (size_t)TAIL_MAX_BLOCKS * 2 * sizeof(double); }
 
 // fills a TailArgs and returns the number of blocks of `threads` threads to run it on
 inline unsigned tail_setup(TailArgs& a, const float* log_z, const float* T_prime, const float* ll, long long N, int K, int S, int Dy,
                            float sigma, float* scalars, float* g_log_z, float* g_T_prime, float* r, void* ws, int threads) {
     a.lz = log_z; a.Tp = T_prime; a.ll = ll; a.g_lz = g_log_z; a.g_Tp = g_T_prime; a.r = r; a.scal = scalars;
-    a.ticket = static_cast<unsigned*>(ws);
-    a.part = reinterpret_cast<double*>(static_cast<char*>(ws) + 64);
+    a.part = static_cast<double*>(ws);
     a.NK = N * K; a.S = S; a.sigma = sigma;
     a.cst = (double)N * Dy * 0.5 * 1.8378770664093453;             // log(2 pi)
     long long blocks = (a.NK + threads - 1) / threads;

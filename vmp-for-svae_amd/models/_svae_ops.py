@@ -411,12 +411,11 @@ _TAIL_WS = {}
 
 
 def _tail_workspace(device):
-    """Zero-initialised scratch of vmp_svae_elbo_tail (block partials + a ticket the kernel resets itself), one per device
-    and stream."""
+    """Scratch of vmp_svae_elbo_tail / vmp_decoder_elbo (per-block partial sums), one per device and stream."""
     key = (device.index, L._raw_stream(device.index))
     ws = _TAIL_WS.get(key)
     if ws is None:
-        ws = _TAIL_WS[key] = torch.zeros(L.lib().vmp_svae_elbo_tail_workspace_bytes(), dtype=torch.uint8, device=device)
+        ws = _TAIL_WS[key] = torch.empty(L.lib().vmp_svae_elbo_tail_workspace_bytes(), dtype=torch.uint8, device=device)
     return ws
 
 
