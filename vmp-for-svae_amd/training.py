@@ -65,6 +65,8 @@ class TFAdam(object):
                                           arr(*[m.data_ptr() for m in self.m]), arr(*[v.data_ptr() for v in self.v]),
                                           (ctypes.c_int64 * n)(*[p.numel() for p in self.params]), self.b1, self.b2,
                                           self.eps, lr_t, lr_p, L.stream()), 'vmp_adam_step')
+            for p in self.params:                          # written behind autograd's back: a graph that saved them must notice
+                torch.autograd.graph.increment_version(p)
             return
         # torch fallback for what the kernel does not take (non-fp32 / non-contiguous / CPU parameters): contiguous
         # gradients with the parameters' strides keep torch on the multi-tensor fast path
