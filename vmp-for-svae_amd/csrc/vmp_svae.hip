@@ -857,20 +857,44 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
 
         // ---- per-row sums (DPP / LDS scratch) and per-component sums: the tile's 4 rows first (fixed order), then the
         //      wave's [TH][16] accumulator, updated by the 16 lanes of row 0 only
+        {
+            float s1[L], s2[L];
 #pragma unroll
-        for (int i = 0; i < L; ++i) {
-            const float s1 = row_sum(on ? gh[i] : 0.f, scr, lane, rbase, K);
-            const float s2 = row_sum(on ? gP[tri(i, i)] : 0.f, scr, lane, rbase, K);
-            if (on && k == 0) {
-                a.g_eta1[row * L + i] = s1;
-                a.g_eta2d[row * L + i] = -2.f * s2;          // p = -2 eta2d
+            for (int i = 0; i < L; ++i) {
+                s1[i] = row_sum(on ? gh[i] : 0.f, scr, lane, rbase, K);
+                s2[i] = -2.f * row_sum(on ? gP[tri(i, i)] : 0.f, scr, lane, rbase, K);      // p = -2 eta2d
+            }
+            if (on && k == 0) {                             // one masked block: 2L stores to two contiguous rows
+#pragma unroll
+                for (int i = 0; i < L; ++i) { a.g_eta1[row * L + i] = s1[i]; a.g_eta2d[row * L + i] = s2[i]; }
             }
         }
+        // All cross-row sums first (in place), then ONE masked block that updates the LDS accumulators in batches: the reads
+        // of a batch are issued together and waited for once.  (`if (lane < 16) accw[..] += sv` per value was 45 exec-mask
+        // switches and 45 LDS read - wait - add - write round trips in a row per tile.)
 #pragma unroll
-        for (int i = 0; i < L; ++i) { const float sv = rows4_sum(on ? gh[i] : 0.f); if (lane < 16) accw[i * 16 + lane] += sv; }
+        for (int i = 0; i < L; ++i) gh[i] = rows4_sum(on ? gh[i] : 0.f);
 #pragma unroll
-        for (int i = 0; i < TRI; ++i) { const float sv = rows4_sum(on ? gP[i] : 0.f); if (lane < 16) accw[(L + i) * 16 + lane] += sv; }
-        { const float sv = rows4_sum(on ? Gc : 0.f); if (lane < 16) accw[(L + TRI) * 16 + lane] += sv; }
+        for (int i = 0; i < TRI; ++i) gP[i] = rows4_sum(on ? gP[i] : 0.f);
+        const float gcs = rows4_sum(on ? Gc : 0.f);
+        if (lane < 16) {
+            constexpr int CH = 9;                                          // values per batch (TH = L + TRI + 1; 45 = 5 x 9 at L = 8)
+#pragma unroll
+            for (int c0 = 0; c0 < TH; c0 += CH) {
+                float oldv[CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u)
+                    if (c0 + u < TH) oldv[u] = accw[(c0 + u) * 16 + lane];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < CH; ++u) asm volatile("" : "+v"(oldv[u]));
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const int i = c0 + u;
+                    if (i < TH) accw[i * 16 + lane] = oldv[u] + (i < L ? gh[i < L ? i : 0] : i < L + TRI ? gP[(i >= L && i < L + TRI) ? i - L : 0] : gcs);
+                }
+            }
+        }
     }
 
     // ---- block reduction: waves in a fixed order, then one partial row per block
