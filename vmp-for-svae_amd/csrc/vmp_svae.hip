@@ -488,6 +488,8 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
         if (K == 16 || !ONE) {                              // K = 16: a row is one 16-lane DPP row.  Streaming sizes keep the
                                                             // call-per-value form: the batched form below measured 13 % SLOWER
                                                             // there (K = 10, N = 1e6: 2.07 -> 2.38 ms) - it pays at one tile per wave
+                                                            // (so did a form with the row-leader lanes summing from the batched
+                                                            // scratch: 2.12 -> 2.45 ms; the kernel sits at the 256-VGPR limit)
 #pragma unroll
             for (int i = 0; i < L; ++i) {
                 const float s1 = row_sum(on ? gh[i] : 0.f, scr, lane, rbase, K);
