@@ -188,3 +188,31 @@ def test_graphed_step_with_in_kernel_noise_follows_the_eager_trainer():
     for a, b in zip(got, want):
         err = ((a.detach().double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-300)).item()
         assert err < 2e-5, err
+
+
+@pytest.mark.gpu
+def test_graphed_step_keyed_noise_for_a_shape_outside_the_e_step_generator():
+    """L*S not a multiple of 4 (the E-step kernel's built-in generator does not cover it): the graph still draws the trainer's
+    Philox stream (stand-alone generator, device key) and follows the eager trainer."""
+    import vmp_for_svae_amd as V
+    from vmp_for_svae_amd.models import vae
+    from vmp_for_svae_amd.training import SVAETrainer, GraphedSVAEStep
+    K, Ld, U, Dy, S, N = 5, 3, 20, 4, 5, 48
+    assert not V._lib.lib().vmp_svae_rng_in_kernel(K, Ld, S)
+    g = torch.Generator(device='cuda').manual_seed(9)
+    ys = [torch.randn(N, Dy, device='cuda', generator=g) for _ in range(3)]
+
+    def fresh():
+        vae.reset_variables()
+        return SVAETrainer(K, Ld, U, Dy, nb_samples=S, lr=3e-3, stddev_init_nn=0.1, seed=4)
+    tr = fresh()
+    elbos = [tr.step(y)['elbo'].item() for y in ys]
+    want = [p.detach().clone() for p in tr.trainables()[1]]
+    tr2 = fresh()
+    gs = GraphedSVAEStep(tr2, ys[0], warmup=2)
+    assert gs.in_kernel_rng
+    got = [gs(y)['elbo'].item() for y in ys]
+    for a, b in zip(got, elbos):
+        assert abs(a - b) <= 2e-5 * abs(b), (a, b)
+    for a, b in zip(tr2.trainables()[1], want):
+        assert ((a.detach().double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-300)).item() < 2e-5

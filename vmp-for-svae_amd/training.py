@@ -300,7 +300,9 @@ class GraphedSVAEStep(object):
         N = y_example.shape[0]
         f32 = dict(dtype=torch.float32, device=dev)
         self.y = y_example.to(**f32).clone()
-        self.in_kernel_rng = tr.rng == 'philox' and bool(L.lib().vmp_svae_rng_in_kernel(tr.K, tr.L, tr.S))
+        # the trainer's own Philox stream, keyed by a device word, generated by captured kernels (any shape: the graph uses the
+        # stand-alone generator, which covers the shapes the E-step kernel's built-in generator does not)
+        self.in_kernel_rng = tr.rng == 'philox'
         # [Philox key (int64) | CVI step size (f32) | Adam step size (f32)]: 16 bytes, refreshed by one launch per call
         self._dev16 = torch.zeros(16, dtype=torch.uint8, device=dev)
         self.seed_dev = self._dev16[:8].view(torch.int64)
