@@ -216,3 +216,28 @@ def test_graphed_step_keyed_noise_for_a_shape_outside_the_e_step_generator():
         assert abs(a - b) <= 2e-5 * abs(b), (a, b)
     for a, b in zip(tr2.trainables()[1], want):
         assert ((a.detach().double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-300)).item() < 2e-5
+
+
+@pytest.mark.gpu
+def test_graphed_smm_svae_step_follows_the_eager_trainer():
+    """The graph-captured step of the Student-t (SMM) SVAE - trainable theta/mu_k, theta/L_k, Dirichlet CVI update with
+    the step size in a device word - against the same trainer stepped eagerly."""
+    from vmp_for_svae_amd.models import vae
+    from vmp_for_svae_amd.training import SVAETrainer, GraphedSVAEStep
+    K, Ld, U, Dy, S, N = 6, 4, 20, 4, 10, 64
+    g = torch.Generator(device='cuda').manual_seed(10)
+    ys = [torch.randn(N, Dy, device='cuda', generator=g) for _ in range(3)]
+
+    def fresh():
+        vae.reset_variables()
+        return SVAETrainer(K, Ld, U, Dy, nb_samples=S, lr=3e-3, stddev_init_nn=0.1, seed=5, smm=True)
+    tr = fresh()
+    elbos = [tr.step(y)['elbo'].item() for y in ys]
+    want = [p.detach().clone() for p in tr.trainables()[1]] + [tr.theta[0].clone()]
+    tr2 = fresh()
+    gs = GraphedSVAEStep(tr2, ys[0], warmup=2)
+    got = [gs(y)['elbo'].item() for y in ys]
+    for a, b in zip(got, elbos):
+        assert abs(a - b) <= 2e-5 * abs(b), (a, b)
+    for a, b in zip(list(tr2.trainables()[1]) + [tr2.theta[0]], want):
+        assert ((a.detach().double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-300)).item() < 3e-5

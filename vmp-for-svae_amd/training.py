@@ -262,7 +262,12 @@ class SVAETrainer(object):
                                                     0.0 if rho_dev is not None else lrcvi, rho_dev=rho_dev)
         elif self.smm:                                                              # experiments.py:252-256
             theta_star = [self.gmm_prior + stats[:, 0].float()]
-            svae.update_gmm_params(self.theta[:1], theta_star, lrcvi)
+            if _dev_scalars is not None:                                            # graph capture: the step size is a device word
+                with torch.no_grad():
+                    rho_d = _dev_scalars[0].reshape(())
+                    self.theta[0].mul_(1.0 - rho_d).add_(theta_star[0].to(self.theta[0].dtype) * rho_d)
+            else:
+                svae.update_gmm_params(self.theta[:1], theta_star, lrcvi)
         elif _dev_scalars is not None:
             theta_star = svae.cvi_update_from_stats(self.gmm_prior, self.theta, stats.double(), 0.0,
                                                     step_size_dev=_dev_scalars[0])
@@ -285,7 +290,7 @@ class GraphedSVAEStep(object):
     operating point (minibatches of 64-100 rows, experiments.py:26) the step is ~150 launches of microsecond kernels
     and is bound by launch overhead, not by the GPU.  Per call: copy the minibatch into the static input, refresh the
     noise / uniforms in place, write the two step-dependent scalars (CVI step size, bias-corrected Adam step size) to
-    device memory, replay.  GMM-SVAE, one process (the data-parallel step has a collective in the middle).
+    device memory, replay.  GMM- and SMM-SVAE, one process (the data-parallel step has a collective in the middle).
     Noise.  Trainer with rng='philox' (the default): eps and the uniforms of the categorical draw are generated INSIDE the
     captured kernels from a Philox key the kernels read from a device word at run time; a call writes [key | CVI step size |
     Adam step size] with ONE launch (vmp_svae_step_scalars) and replays - the very stream of the same trainer stepped eagerly
@@ -294,8 +299,6 @@ class GraphedSVAEStep(object):
 
     def __init__(self, trainer, y_example, warmup=3):
         tr = self.tr = trainer
-        if tr.smm:
-            raise NotImplementedError('graph capture covers the GMM-SVAE step')
         dev = tr.device
         N = y_example.shape[0]
         f32 = dict(dtype=torch.float32, device=dev)
