@@ -138,7 +138,7 @@ def run(config, nb_iters=2000, size_minibatch=100, nb_samples=10, nb_samples_te=
     stepper = None
     for i in range(nb_iters):
         yb = next(batches)
-        if graph and not smm and dev.type == 'cuda':
+        if graph and dev.type == 'cuda':
             if stepper is None:
                 from .training import GraphedSVAEStep
                 stepper = GraphedSVAEStep(tr, yb)
