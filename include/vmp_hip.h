@@ -10,7 +10,7 @@
  *   - plain C symbols; every pointer is a DEVICE pointer unless the name ends in _host;
  *   - row-major, batch-leading fp32 tensors exactly as the reference lays them out: x (N,D), r (N,K),
  *     (K,D,D), (N,K,S,L) ...; integer sizes: N int64, everything else int;
- *   - caller allocates inputs, outputs and workspace; the library never allocates device memory;
+ *   - caller allocates inputs, outputs and workspace; the library never allocates device memory (one exception: vmp_exch_alloc, the uncached IPC exchange buffer of the peer form);
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
  *   - return 0 = ok, <0 = invalid argument (VMP_E_*), >0 = hipError_t of a failed launch;
  *     vmp_last_error() returns a thread-local message for the last non-zero return;

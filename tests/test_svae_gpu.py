@@ -106,7 +106,12 @@ def test_estep_vs_oracle_shapes():
                           (33, 16, 4, 10), (50, 16, 6, 8), (13, 16, 8, 4), (9, 16, 8, 100), (257, 16, 8, 10),
                           # K != 16 with even L, S (the round-2 kernel: a run-time-K variant of the ring kernel measured SLOWER
                           # than it at K = 10, 2.41 vs 2.14 ms at N = 1e6)
-                          (64, 10, 8, 10), (21, 3, 4, 6), (40, 19, 8, 10), (70, 1, 8, 10)]:
+                          (64, 10, 8, 10), (21, 3, 4, 6), (40, 19, 8, 10), (70, 1, 8, 10),
+                          # 8 <= K < 16 on the ring kernel (round 4: 64 // K whole rows per wave tile), several blocks, ragged ends
+                          (2050, 10, 8, 10), (700, 12, 6, 4), (333, 9, 4, 8), (1000, 8, 8, 6), (515, 15, 8, 10), (1201, 13, 6, 10),
+                          # ... which takes over from the generic kernel's one-tile-per-wave form above 2048 wave tiles only:
+                          (12500, 10, 8, 4), (8301, 15, 8, 4), (16501, 8, 6, 4), (14403, 9, 4, 6), (10302, 12, 8, 4), (8303, 13, 6, 4),
+                          (8205, 16, 8, 4)]:
         e1 = rng.standard_normal((N, Ld))
         e2 = -0.5 * (0.3 + rng.random((N, Ld)))
         mu_k = rng.standard_normal((K, Ld)) * 2
@@ -146,6 +151,58 @@ def test_estep_vs_oracle_shapes():
         for a_, b_, n_ in zip(gp, go, ('eta1', 'eta2d', 'mu_k', 'L_k', 'log_pi_k')):
             # fp32 accumulation over N*S sample adjoints: tolerance 2e-4 at S<=10, growing as sqrt(S/10)
             assert rel(a_, b_.numpy()) < 2e-4 * max(1.0, S / 10.0) ** 0.5, (tag, n_, rel(a_, b_.numpy()))
+
+
+def test_estep_vs_oracle_shapes_student_t():
+    """The same comparison with a Student-t theta (svae.py:265-322, student_t.py:7-39: the theta term of T' is
+    (nu+L)/2 log1p(delta^2/nu), theta/mu_k and theta/L_k are trainable): shapes with SEVERAL blocks of the backward kernels, so
+    that the N*K*S-reduced gradients of mu_k / L_k cross the per-block partials and the reduce kernel (the goldens hold
+    N = 7 and N = 10: one block).  K = 16 and 8 <= K < 16 with even L, S take the LDS-ring kernel, the rest the generic one."""
+    from oracle import svae_ref, dists
+    from vmp_for_svae_amd.models import svae
+    rng = np.random.Generator(np.random.PCG64(15))
+    for (N, K, Ld, S) in [(300, 16, 8, 10), (1500, 16, 8, 10), (1031, 16, 6, 4), (700, 10, 8, 10), (2050, 10, 8, 10), (999, 12, 4, 6),
+                          (411, 7, 5, 3), (800, 16, 8, 5), (513, 9, 8, 8), (257, 33, 2, 4),
+                          # 8 <= K < 16: the ring kernel takes over above 2048 wave tiles (64 // K rows each)
+                          (12500, 10, 8, 4), (8301, 15, 6, 4), (16501, 8, 8, 4), (10302, 12, 4, 6), (8303, 13, 8, 4)]:
+        e1 = rng.standard_normal((N, Ld))
+        e2 = -0.5 * (0.3 + rng.random((N, Ld)))
+        mu_k = rng.standard_normal((K, Ld)) * 2
+        Lraw = rng.standard_normal((K, Ld, Ld)) * 0.4
+        pir = rng.standard_normal(K)
+        noise = rng.standard_normal((N, K, Ld, S))
+        th_mu = rng.standard_normal((K, Ld)) * 1.5
+        th_L = np.tril(rng.standard_normal((K, Ld, Ld)) * 0.4) + 0.8 * np.eye(Ld)
+        alpha_nat = rng.random(K) * 3.0
+        dof = 2.5 + 5.0 * rng.random(K)
+
+        def to(a, g=False):
+            return torch.tensor(a, dtype=torch.float64, requires_grad=g)
+        oe1, oe2, omu, oL, opi, otm, otL = to(e1, True), to(e2, True), to(mu_k, True), to(Lraw, True), to(pir, True), to(th_mu, True), to(th_L, True)
+        x_o, lz_o, pt_o, _ = svae_ref.e_step((oe1, oe2), [omu, oL, opi], to(noise))
+        mu_th, sig_th = svae_ref.unpack_smm([otm, otL])
+        elp = dists.dir_expected_log_pi(dists.dir_natural_to_standard(to(alpha_nat)))
+        num = dists.gauss_log_probability_nat_per_samp(x_o, pt_o[0].reshape(N, K, Ld), pt_o[1])
+        den = dists.student_t_log_probability_per_samp(x_o, mu_th, sig_th, to(dof)) + elp.view(1, K, 1)
+        Tp_o = (num - den).mean(-1)
+        wx = to(rng.standard_normal((N, K, S, Ld)))
+        loss_o = (x_o * wx).sum() + (torch.exp(lz_o) * (Tp_o + lz_o)).sum()
+        go = torch.autograd.grad(loss_o, [oe1, oe2, omu, oL, opi, otm, otL])
+
+        def f(a, g=False):
+            return torch.tensor(a, dtype=torch.float32, device='cuda', requires_grad=g)
+        pe1, pe2, pmu, pL, ppi, ptm, ptL = f(e1, True), f(e2, True), f(mu_k, True), f(Lraw, True), f(pir, True), f(th_mu, True), f(th_L, True)
+        th = [f(alpha_nat), ptm, ptL, f(dof)]
+        x_p, lz_p, pt_p, _ = svae.e_step((pe1, pe2), [pmu, pL, ppi], S, noise=f(noise), theta=th)
+        loss_p = (x_p * wx.float().cuda()).sum() + (torch.exp(lz_p) * (pt_p.T_prime + lz_p)).sum()
+        gp = torch.autograd.grad(loss_p, [pe1, pe2, pmu, pL, ppi, ptm, ptL])
+        tag = (N, K, Ld, S)
+        assert rel(x_p, x_o.detach().numpy()) < 3e-5, tag
+        assert np.abs(np.exp(lz_p.detach().double().cpu().numpy()) - np.exp(lz_o.detach().numpy())).max() < 2e-5, tag
+        assert rel(pt_p.T_prime, Tp_o.detach().numpy()) < 5e-5, tag
+        for a_, b_, n_ in zip(gp, go, ('eta1', 'eta2d', 'mu_k', 'L_k', 'log_pi_k', 'theta/mu_k', 'theta/L_k')):
+            e = rel(a_, b_.numpy())
+            assert e < 2e-4 * max(1.0, S / 10.0) ** 0.5, (tag, n_, e)
 
 
 @pytest.mark.parametrize('case,literal', [('svae_smm_tiny', False), ('svae_smm_l8', False), ('svae_smm_l8', True)])

@@ -1302,6 +1302,12 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
                 double* slot = a.peer[g] + (((size_t)par * G_ + a.rank) * K + k) * SWP;
                 __hip_atomic_store(slot + tid, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+            // EVERY storing wave (SW + 1 = 75 doubles at D = 8: waves 0 and 1) releases and drains its OWN slot stores
+            // before the barrier: a workgroup barrier does not wait for another wave's outstanding vector stores
+            // (s_waitcnt lgkmcnt(0); s_barrier), so the publisher's vmcnt(0) below covers wave 0 only
+            // (tests/test_abi.py::test_peer_exchange_release_covers_every_storing_wave checks the shipped code object)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
         if (tid == 0) {

@@ -17,18 +17,12 @@
 // noise tile eps (layout (cell, L, S)) is brought in with coalesced vector loads and staged in LDS with an odd
 // cell stride (conflict-free per-lane reads); the samples x are written back into the same LDS slots and leave
 // with coalesced stores in the reference's (cell, S, L) layout.
-#include "vmp_common.h"
+#include "vmp_svae_cell.h"
 #include <stdlib.h>
 
 using namespace vmp;
 
 namespace {
-
-constexpr int SV_AST = 65;          // row stride of the generic backward kernel's LDS accumulators (see there)
-constexpr int SV_NW = 4;            // waves per block (backward); forward: as many as the LDS noise tiles allow
-constexpr int SV_FWD_MAX_NW = 8;
-constexpr int SV_MAX_BLOCKS = 2048;
-constexpr float LOG_2PI = 1.8378770664093454836f;
 
 struct EFwdArgs {
     const float* eta1;      // (N,L)   encoder eta1
@@ -53,118 +47,6 @@ struct EFwdArgs {
 #endif
 };
 
-template <int L>
-struct SvGeo {
-    static constexpr int TRI = L * (L + 1) / 2;
-};
-
-// lower-triangular packed index (row-major), i >= j
-__host__ __device__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
-
-// Cholesky of the cell matrix (lower, packed).  On return Lm holds the factor with the DIAGONAL REPLACED BY ITS
-// RECIPROCAL rd_j = 1/Lt_jj (every later use multiplies by it), and half_logdet = sum_j log Lt_jj.
-// Right-looking form: once column j is final, every remaining entry takes its update -L_ij L_qj at once.  Each entry still
-// receives its terms in the order p = 0, 1, 2, ... (bitwise the same result as the left-looking loop), but the updates
-// of one column are mutually independent, so the dependency chain is L steps deep instead of ~L^2/2 - with two waves
-// per SIMD that is what the VALU waits on (SQ_WAIT_INST_ANY 30 % of the backward kernel in round 1).
-template <int L>
-__device__ __forceinline__ void cell_cholesky(float (&Lm)[SvGeo<L>::TRI], float& half_logdet) {
-    float prod_log = 0.f;
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-        const float s = Lm[tri(j, j)];
-        const float rd = __builtin_amdgcn_rsqf(s);
-        prod_log += __logf(s);
-#pragma unroll
-        for (int i = j + 1; i < L; ++i) Lm[tri(i, j)] *= rd;
-        Lm[tri(j, j)] = rd;
-#pragma unroll
-        for (int i = j + 1; i < L; ++i)
-#pragma unroll
-            for (int q = j + 1; q <= i; ++q) Lm[tri(i, q)] = fmaf(-Lm[tri(i, j)], Lm[tri(q, j)], Lm[tri(i, q)]);
-    }
-    half_logdet = 0.5f * prod_log;
-}
-
-// v <- Lt^-1 v   (forward substitution, column-oriented: v_j final -> all v_i, i > j, updated independently; the terms
-// reach every v_i in the same order p = 0, 1, ... as in the row-oriented loop; diagonal of Lm holds reciprocals)
-template <int L>
-__device__ __forceinline__ void solve_lower(const float (&Lm)[SvGeo<L>::TRI], float (&v)[L]) {
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-        v[j] *= Lm[tri(j, j)];
-#pragma unroll
-        for (int i = j + 1; i < L; ++i) v[i] = fmaf(-Lm[tri(i, j)], v[j], v[i]);
-    }
-}
-
-// v <- Lt^-T v   (back substitution, column-oriented; terms reach v_i in the order p = L-1, L-2, ...: the row-oriented
-// loop summed p = i+1, ..., L-1, so the rounding differs in the last bits)
-template <int L>
-__device__ __forceinline__ void solve_lower_t(const float (&Lm)[SvGeo<L>::TRI], float (&v)[L]) {
-#pragma unroll
-    for (int j = L - 1; j >= 0; --j) {
-        v[j] *= Lm[tri(j, j)];
-#pragma unroll
-        for (int i = 0; i < j; ++i) v[i] = fmaf(-Lm[tri(j, i)], v[j], v[i]);
-    }
-}
-
-// sum / max over the K lanes of this lane's row, through a 64-float LDS scratch
-__device__ __forceinline__ float row_sum(float v, float* scr, int lane, int rbase, int K) {
-    if (K == 16) return row16_sum(v);            // a row = one 16-lane DPP row: 4 rotations instead of 17 LDS accesses + 16 adds
-    scr[lane] = v;
-    __builtin_amdgcn_wave_barrier();
-    float s = 0.f;
-#pragma unroll 4                                     // reads issued ahead of the (in-order) adds: one LDS latency per 4 values, not per value
-    for (int j = 0; j < K; ++j) s += scr[rbase + j];
-    __builtin_amdgcn_wave_barrier();
-    return s;
-}
-__device__ __forceinline__ float row_max(float v, float* scr, int lane, int rbase, int K) {
-    if (K == 16) return row16_max(v);
-    scr[lane] = v;
-    __builtin_amdgcn_wave_barrier();
-    float m = -INFINITY;
-#pragma unroll 4
-    for (int j = 0; j < K; ++j) m = fmaxf(m, scr[rbase + j]);
-    __builtin_amdgcn_wave_barrier();
-    return m;
-}
-
-// =========================================================================================================
-// backward
-// =========================================================================================================
-struct EBwdArgs {
-    const float* eta1;
-    const float* eta2d;
-    const float* hk;
-    const float* Pk;
-    const float* bias;
-    const float* mk;
-    const float* Wk;
-    const float* nu;        // (K) or NULL
-    const float* x;         // (N,K,S,L) samples from the forward pass
-    const float* lz;        // (N,K)
-    const float* Gx;        // (N,K,S,L) dLoss/dx  (from the decoder)
-    const float* Glz;       // (N,K)     dLoss/dlog_z
-    const float* GT;        // (N,K)     dLoss/dT'
-    float* g_eta1;          // (N,L)
-    float* g_eta2d;         // (N,L)
-    float* partials;        // (nblk, K, 2(L+TRI+1)): g_hk | g_Pk (lower, symmetric gradient) | g_bias | g_mk | g_Wk (lower) | g_kappa
-    long long N;
-    int K, S, vec_ok;
-#ifdef VMP_DEBUG_TS
-    long long* dbg_t;       // exploration builds only (tools/build_variant.sh ts -DVMP_DEBUG_TS): stage time stamps of block 0, wave 0
-#endif
-};
-#ifdef VMP_DEBUG_TS
-#define SV_TS(i) do { if (a.dbg_t && blockIdx.x == 0 && threadIdx.x == 0) { a.dbg_t[i] = clock64(); a.dbg_t[32 + (i)] = wall_clock64(); } } while (0)
-#define SV_USE(v) asm volatile("" :: "v"(v))
-#else
-#define SV_TS(i) do { } while (0)
-#define SV_USE(v) do { } while (0)
-#endif
 
 // ONE = every wave owns at most one tile (small batches: the reference's minibatches of 64-100 rows).  Nothing can then
 // be overlapped ACROSS tiles, and the kernel as written for streaming pays its memory round trips one after the other
@@ -571,353 +453,6 @@ __global__ __launch_bounds__(SV_NW * WAVE) void svae_estep_bwd_kernel(EBwdArgs a
 }
 
 
-// ---------------------------------------------------------------------------------------------------------
-// Backward, LDS-ring form (round 3).  What bounded the kernel above (measured): with the sample
-// arithmetic REMOVED it still takes 3.2 ms at C3, with the loads removed 1.9 ms - the time is the access pattern, not
-// the arithmetic: every lane fetches its own 64-byte piece of a 320-byte cell row, so each load instruction touches 64
-// different cache lines and the vector L1 spends its cycles on tag look-ups (TCP pending-stall 62 %).  Here the two
-// sample rows (x, dL/dx) of a sample PAIR of the wave's 64 cells are brought in by global_load_lds_dwordx4 with FOUR
-// ADJACENT LANES PER CELL (one 64-byte segment per lane quad: 16 look-ups per instruction instead of 64) into a per-wave
-// ring of two stages; a stage is drained to registers and re-requested for the pair after next BEFORE the arithmetic of
-// its pair starts, so two pairs (16 KB per wave, 128 KB per CU) are always in flight and no VGPR is spent on prefetch.
-// The LDS this needs comes from the per-component accumulators: the 4 rows of a tile are summed across lanes first
-// (fixed order: (r0 + r2) + (r1 + r3)), so a wave keeps [PWa][16] floats instead of a lane-private [PWa][64] column set.
-// One 8-wave block per CU.  Gaussian theta, K = 16 (a tile = 4 whole rows = 64 cells), even L and even S >= 4 (a sample
-// pair is L/2 16-byte pieces); everything else takes the kernel above.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int SVR_NW = 8;
-template <int L> constexpr int svr_stage_floats() { return 2 * WAVE * 2 * L; }       // x pair + dx pair of 64 cells
-
-// sum over lanes l, l^16, l^32, l^48 (same component, 4 rows) on the VALU: gfx950's v_permlane32_swap / v_permlane16_swap
-// exchange the 32-lane halves / the odd and even 16-lane rows of two registers, so (lower + upper) and then (even + odd) are
-// two swaps and two adds - the same sums, bit for bit, as v + shfl_xor(v, 32) and t + shfl_xor(t, 16), which compile to
-// ds_bpermute_b32: an address computation, an LDS-crossbar round trip and a wait per exchange, 90 of them per tile.
-#ifndef VMP_ROWS4_SHFL
-#define VMP_ROWS4_SHFL 0      // 1: the ds_bpermute form (A/B measurements: tools/build_variant.sh)
-#endif
-__device__ __forceinline__ float rows4_sum(float v) {
-#if VMP_ROWS4_SHFL
-    const float t = v + __shfl_xor(v, 32);
-    return t + __shfl_xor(t, 16);
-#else
-    const unsigned x = __float_as_uint(v);
-    const auto h = __builtin_amdgcn_permlane32_swap(x, x, false, false);      // h[0] = lower-half values, h[1] = upper-half values
-    const float t = __uint_as_float(h[0]) + __uint_as_float(h[1]);
-    const unsigned y = __float_as_uint(t);
-    const auto q = __builtin_amdgcn_permlane16_swap(y, y, false, false);      // q[0] = even-row values, q[1] = odd-row values
-    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
-#endif
-}
-
-template <int L>
-__global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwdArgs a, int nblk_abi) {
-    constexpr int TRI = SvGeo<L>::TRI;
-    constexpr int PW = 2 * (L + TRI + 1);
-    constexpr int TH = L + TRI + 1;                          // accumulator rows in use (Gaussian theta)
-    constexpr int PP = L / 2;                                // 16-byte pieces of one sample pair of one cell
-    constexpr int STG = svr_stage_floats<L>();
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: tile indices and DMA bases stay scalar
-    const int K = a.K, S = a.S;
-    const int LSn = L * S, NP = S >> 1;
-    const int RPT = WAVE / K, CT = RPT * K;
-    constexpr int PSTR = TRI | 1;
-    const int tab = (K * PSTR + 3) & ~3;
-    float* pk_lds = smem;                                    // [K][PSTR]  lower triangle of P_k
-    float* ring = smem + tab + wave * (2 * STG);             // two stages: [x pair: 64 cells x 2L | dx pair: 64 cells x 2L]
-    float* accw = smem + tab + nw * (2 * STG) + wave * (TH * 16);   // this wave's per-component sums [TH][16]
-    float* scr = smem + tab + nw * (2 * STG) + nw * (TH * 16) + wave * WAVE;
-    const bool lane_on = true;                               // K == 16: every lane owns a cell
-    const int r = lane >> 4, k = lane & 15, rbase = r * 16;
-
-    for (int e = threadIdx.x; e < K * TRI; e += blockDim.x) {
-        const int kk = e / TRI, idx = e - kk * TRI;
-        int i = 0;
-        while (tri(i + 1, 0) <= idx) ++i;
-        const int j = idx - tri(i, 0);
-        pk_lds[kk * PSTR + idx] = a.Pk[(kk * L + i) * L + j];
-    }
-    for (int e = lane; e < TH * 16; e += WAVE) accw[e] = 0.f;
-    __syncthreads();
-
-    float hkk[L], mkk[L], Wt[TRI];
-    const int kc = lane_on ? k : 0;
-#pragma unroll
-    for (int i = 0; i < L; ++i) {
-        const float hv = a.hk[kc * L + i], mv = a.mk[kc * L + i];
-        hkk[i] = lane_on ? hv : 0.f;
-        mkk[i] = lane_on ? mv : 0.f;
-#pragma unroll
-        for (int j = 0; j <= i; ++j) { const float wv = a.Wk[(kc * L + i) * L + j]; Wt[tri(i, j)] = lane_on ? wv : 0.f; }
-    }
-
-    const long long ntiles = (a.N + RPT - 1) / RPT;
-    const long long tstride = (long long)gridDim.x * nw;
-    const float invS = 1.0f / (float)S;
-    // DMA slot walk: slot g = j*64 + lane of instruction j holds piece (g % PP) of tile cell (g / PP); for L = 8 the piece
-    // index is XOR-swizzled with bits 2-3 of the cell so that the 16 lanes a ds_read_b128 serves together hit 16 banks
-    int dcell[PP], dpiece[PP];
-#pragma unroll
-    for (int j = 0; j < PP; ++j) {
-        const int g = j * WAVE + lane;
-        dcell[j] = g / PP;
-        const int pc = g - dcell[j] * PP;
-        dpiece[j] = (PP == 4) ? (pc ^ ((dcell[j] >> 2) & 3)) : pc;
-    }
-    const int sw = (PP == 4) ? ((lane >> 2) & 3) : 0;       // read side of the same swizzle (this lane's cell = lane)
-    auto issue = [&](long long tt, int pp, float* stage) {
-        // pair pp of tile tt -> stage; cells past the end of the tensor are clamped to the tile's last valid cell
-        const long long cells_left = (a.N - tt * RPT) * K;
-        const int ncell = cells_left < CT ? (int)cells_left : CT;
-        const long long tile0 = tt * (long long)CT * LSn + pp * 2 * L;
-#pragma unroll
-        for (int j = 0; j < PP; ++j) {
-            const int cc = dcell[j] < ncell ? dcell[j] : ncell - 1;
-            const long long off = tile0 + (long long)cc * LSn + 4 * dpiece[j];
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.x + off),
-                                             (__attribute__((address_space(3))) void*)(stage + j * (4 * WAVE)), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.Gx + off),
-                                             (__attribute__((address_space(3))) void*)(stage + WAVE * 2 * L + j * (4 * WAVE)), 16, 0, 0);
-        }
-    };
-
-    long long t = (long long)blockIdx.x * nw + wave;
-    int cur = 0;                                             // stage holding the pair about to be consumed
-    bool younger = true;                                     // was the pair after the one about to be consumed requested?
-    if (t < ntiles) {
-        issue(t, 0, ring);
-        if (NP > 1) issue(t, 1, ring + STG);
-        else if (t + tstride < ntiles) issue(t + tstride, 0, ring + STG);
-    }
-    for (; t < ntiles; t += tstride) {
-        const long long row = t * RPT + r;
-        const bool on = lane_on && row < a.N;
-        const long long rowc = on ? row : 0;
-        const long long cellid = rowc * K + kc;
-
-        float Lm[TRI], av[L], mu[L];
-#pragma unroll
-        for (int i = 0; i < TRI; ++i) Lm[i] = lane_on ? pk_lds[k * PSTR + i] : 0.f;
-#pragma unroll
-        for (int i = 0; i < L; ++i) {
-            const float e1v = a.eta1[rowc * L + i], e2v = a.eta2d[rowc * L + i];
-            const float e1 = on ? e1v : 0.f;
-            const float e2 = on ? e2v : -0.5f;
-            Lm[tri(i, i)] = fmaf(-2.f, e2, lane_on ? Lm[tri(i, i)] : 0.f);
-            av[i] = e1 + hkk[i];
-        }
-        const float glzv = a.Glz[cellid], gTv = a.GT[cellid], lzv = a.lz[cellid];
-        float ld;
-        cell_cholesky<L>(Lm, ld);
-        solve_lower<L>(Lm, av);
-#pragma unroll
-        for (int i = 0; i < L; ++i) mu[i] = av[i];
-        solve_lower_t<L>(Lm, mu);                           // mu~ = Pt^-1 ht
-
-        const float glz = on ? glzv : 0.f;
-        const float gT = on ? gTv : 0.f;
-        const float rnk = on ? __expf(lzv) : 0.f;
-        const float gsum = row_sum(glz, scr, lane, rbase, K);
-        const float Gc = glz - rnk * gsum;                  // through the log-sum-exp normalisation
-        const float Gld = gT - Gc;                          // T' has +ld, c has -ld
-
-        float Wsum[L], M[TRI];
-#pragma unroll
-        for (int i = 0; i < L; ++i) Wsum[i] = 0.f;
-#pragma unroll
-        for (int i = 0; i < TRI; ++i) M[i] = 0.f;
-        const float gts = gT * invS;
-        for (int p = 0; p < NP; ++p) {
-            float* stage = ring + cur * STG;
-            // The stage about to be read was requested two pairs ago.  If the pair in between was requested too, its 2*PP
-            // DMA instructions are the youngest ones in flight and may stay so; if it was not (no next tile for this wave),
-            // NOTHING younger exists and the count must drain to zero - waiting for "<= 2*PP outstanding" would then not wait
-            // at all (found as a run-to-run difference of the last pair of a wave's last tile).
-            if (!younger) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (PP == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (PP == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (PP == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            float xp[2 * L], gp[2 * L];
-#pragma unroll
-            for (int q = 0; q < PP; ++q) {
-                const f32x4 vx = *reinterpret_cast<const f32x4*>(stage + lane * (2 * L) + 4 * (q ^ sw));
-                const f32x4 vg = *reinterpret_cast<const f32x4*>(stage + WAVE * 2 * L + lane * (2 * L) + 4 * (q ^ sw));
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { xp[4 * q + c] = vx[c]; gp[4 * q + c] = vg[c]; }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the stage is in registers: it may be overwritten
-#pragma unroll
-            for (int i = 0; i < 2 * L; ++i) asm volatile("" : "+v"(xp[i]), "+v"(gp[i]));
-            {   // re-request this stage for the pair after next (of this tile, or of this wave's next tile; NP >= 2: host)
-                const int pn = p + 2;
-                if (pn < NP) { issue(t, pn, stage); younger = true; }
-                else if (t + tstride < ntiles) { issue(t + tstride, pn - NP, stage); younger = true; }
-                else younger = false;
-            }
-            cur ^= 1;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float xs[L], gx[L];
-#pragma unroll
-                for (int i = 0; i < L; ++i) { xs[i] = on ? xp[h * L + i] : 0.f; gx[i] = on ? gp[h * L + i] : 0.f; }
-                // d/dx of the theta term of T':  (1/S) W^T W (x - m)
-                float d[L], y[L];
-#pragma unroll
-                for (int i = 0; i < L; ++i) d[i] = xs[i] - mkk[i];
-#pragma unroll
-                for (int i = 0; i < L; ++i) {
-                    float yy = 0.f;
-#pragma unroll
-                    for (int j = 0; j <= i; ++j) yy = fmaf(Wt[tri(i, j)], d[j], yy);
-                    y[i] = yy;
-                }
-#pragma unroll
-                for (int i = 0; i < L; ++i) {
-                    const float gy = gts * y[i];
-#pragma unroll
-                    for (int j = 0; j <= i; ++j) gx[j] = fmaf(Wt[tri(i, j)], gy, gx[j]);
-                }
-                solve_lower<L>(Lm, gx);                     // w_s = Lt^-1 gx_s
-#pragma unroll
-                for (int i = 0; i < L; ++i) {
-                    Wsum[i] += gx[i];
-                    const float e = xs[i] - mu[i];          // e_s = Lt^-T eps_s
-#pragma unroll
-                    for (int j = 0; j <= i; ++j) M[tri(i, j)] = fmaf(e, gx[j], M[tri(i, j)]);
-                }
-            }
-        }
-        // ---- assemble dLoss/dht and dLoss/dPt (symmetric, lower triangle): as in svae_estep_bwd_kernel
-        float V[L];
-#pragma unroll
-        for (int i = 0; i < L; ++i) V[i] = Wsum[i];
-        solve_lower_t<L>(Lm, V);                            // V = Pt^-1 sum_s gx_s
-        float gh[L];
-#pragma unroll
-        for (int i = 0; i < L; ++i) gh[i] = fmaf(Gc, mu[i], V[i]);
-        float Cs[TRI], dg[L];
-#pragma unroll
-        for (int i = 0; i < L; ++i) dg[i] = 1.0f / Lm[tri(i, i)];
-#pragma unroll
-        for (int i = 0; i < L; ++i)
-#pragma unroll
-            for (int j = 0; j <= i; ++j) {
-                float s2 = 0.f;
-#pragma unroll
-                for (int pq = i; pq < L; ++pq) {
-                    const float lpi = (pq == i) ? dg[i] : Lm[tri(pq, i)];
-                    s2 = fmaf(lpi, -M[tri(pq, j)], s2);
-                }
-                Cs[tri(i, j)] = (i == j) ? (s2 + Gld) : s2;
-            }
-        float Y[TRI];
-#pragma unroll
-        for (int j = 0; j < L; ++j) {
-            Y[tri(j, j)] = Lm[tri(j, j)];
-#pragma unroll
-            for (int i = j + 1; i < L; ++i) {
-                float s2 = 0.f;
-#pragma unroll
-                for (int pq = j; pq < i; ++pq) s2 = fmaf(Lm[tri(i, pq)], Y[tri(pq, j)], s2);
-                Y[tri(i, j)] = -s2 * Lm[tri(i, i)];
-            }
-        }
-        float gP[TRI];
-#pragma unroll
-        for (int i = 0; i < TRI; ++i) gP[i] = 0.f;
-#pragma unroll
-        for (int j = 0; j < L; ++j) {
-            float Zc[L];
-#pragma unroll
-            for (int q = 0; q < L; ++q) {
-                float s2 = 0.f;
-#pragma unroll
-                for (int pq = j; pq < L; ++pq) {
-                    const float cqp = (q >= pq) ? Cs[tri(q, pq)] : Cs[tri(pq, q)];
-                    s2 = fmaf(cqp, Y[tri(pq, j)], s2);
-                }
-                Zc[q] = s2;
-            }
-#pragma unroll
-            for (int i = j; i < L; ++i) {
-                float s2 = 0.f;
-#pragma unroll
-                for (int pq = i; pq < L; ++pq) s2 = fmaf(Y[tri(pq, i)], Zc[pq], s2);
-                gP[tri(i, j)] = 0.5f * s2;
-            }
-        }
-        // rank-one terms  - sym(V mu^T) - 1/2 Gc mu mu^T  =  -1/2 (tv mu^T + mu tv^T),  tv = V + 1/2 Gc mu
-        float tv[L];
-#pragma unroll
-        for (int i = 0; i < L; ++i) tv[i] = -0.5f * fmaf(0.5f * Gc, mu[i], V[i]);
-#pragma unroll
-        for (int i = 0; i < L; ++i)
-#pragma unroll
-            for (int j = 0; j <= i; ++j) gP[tri(i, j)] = fmaf(tv[i], mu[j], fmaf(mu[i], tv[j], gP[tri(i, j)]));
-
-        // ---- per-row sums (DPP / LDS scratch) and per-component sums: the tile's 4 rows first (fixed order), then the
-        //      wave's [TH][16] accumulator, updated by the 16 lanes of row 0 only
-        {
-            float s1[L], s2[L];
-#pragma unroll
-            for (int i = 0; i < L; ++i) {
-                s1[i] = row_sum(on ? gh[i] : 0.f, scr, lane, rbase, K);
-                s2[i] = -2.f * row_sum(on ? gP[tri(i, i)] : 0.f, scr, lane, rbase, K);      // p = -2 eta2d
-            }
-            if (on && k == 0) {                             // one masked block: 2L stores to two contiguous rows
-#pragma unroll
-                for (int i = 0; i < L; ++i) { a.g_eta1[row * L + i] = s1[i]; a.g_eta2d[row * L + i] = s2[i]; }
-            }
-        }
-        // All cross-row sums first (in place), then ONE masked block that updates the LDS accumulators in batches: the reads
-        // of a batch are issued together and waited for once.  (`if (lane < 16) accw[..] += sv` per value was 45 exec-mask
-        // switches and 45 LDS read - wait - add - write round trips in a row per tile.)
-#pragma unroll
-        for (int i = 0; i < L; ++i) gh[i] = rows4_sum(on ? gh[i] : 0.f);
-#pragma unroll
-        for (int i = 0; i < TRI; ++i) gP[i] = rows4_sum(on ? gP[i] : 0.f);
-        const float gcs = rows4_sum(on ? Gc : 0.f);
-        if (lane < 16) {
-            constexpr int CH = 9;                                          // values per batch (TH = L + TRI + 1; 45 = 5 x 9 at L = 8)
-#pragma unroll
-            for (int c0 = 0; c0 < TH; c0 += CH) {
-                float oldv[CH];
-#pragma unroll
-                for (int u = 0; u < CH; ++u)
-                    if (c0 + u < TH) oldv[u] = accw[(c0 + u) * 16 + lane];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int u = 0; u < CH; ++u) asm volatile("" : "+v"(oldv[u]));
-#pragma unroll
-                for (int u = 0; u < CH; ++u) {
-                    const int i = c0 + u;
-                    if (i < TH) accw[i * 16 + lane] = oldv[u] + (i < L ? gh[i < L ? i : 0] : i < L + TRI ? gP[(i >= L && i < L + TRI) ? i - L : 0] : gcs);
-                }
-            }
-        }
-    }
-
-    // ---- block reduction: waves in a fixed order, then one partial row per block
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    float* out = a.partials + (long long)blockIdx.x * K * PW;
-    for (int e = threadIdx.x; e < K * PW; e += blockDim.x) {
-        const int kk = e / PW, f = e - kk * PW;
-        float s2 = 0.f;
-        if (f < TH) {
-            const float* base = smem + tab + nw * (2 * STG);
-            for (int w = 0; w < nw; ++w) s2 += base[w * (TH * 16) + f * 16 + kk];
-        }
-        out[e] = s2;
-    }
-    // rows of the partial buffer the ABI sized for more blocks than this kernel launches
-    for (int b = blockIdx.x + gridDim.x; b < nblk_abi; b += gridDim.x) {
-        float* z = a.partials + (long long)b * K * PW;
-        for (int e = threadIdx.x; e < K * PW; e += blockDim.x) z[e] = 0.f;
-    }
-}
 
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2095,31 +1630,18 @@ int vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk, c
 #ifndef VMP_T2_RING
 #define VMP_T2_RING 1         // 0: build without the LDS-ring backward kernel (A/B measurements: tools/build_variant.sh)
 #endif
-    if (VMP_T2_RING && !nu && K == 16 && (L & 1) == 0 && L >= 4 && (S & 1) == 0 && S >= 4 && a.vec_ok) {
-        // LDS-ring kernel (quad-coalesced LDS-DMA of sample pairs, two pairs in flight per wave): one 8-wave block per CU
-        const long long ntiles = (N + 3) / 4;
-        long long bl = (ntiles + SVR_NW - 1) / SVR_NW;
-        if (bl > 256) bl = 256;
-        const int TH = PW / 2;
-        const int tab = (K * ((L * (L + 1) / 2) | 1) + 3) & ~3;
-        const size_t ldsr = (size_t)(tab + SVR_NW * (2 * (2 * WAVE * 2 * L)) + SVR_NW * TH * 16 + SVR_NW * WAVE) * sizeof(float);
-        rc = -1;
-        switch (L) {
-#define VMP_RING(LL) case LL: \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_bwd_ring_kernel<LL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr); \
-            hipLaunchKernelGGL((svae_estep_bwd_ring_kernel<LL>), dim3((int)bl), dim3(SVR_NW * WAVE), ldsr, static_cast<hipStream_t>(stream), a, blocks); \
-            rc = check_launch("svae_estep_bwd_ring_kernel"); break;
-            VMP_RING(4) VMP_RING(6) VMP_RING(8)
-#undef VMP_RING
-            default: break;
-        }
-        return rc;
+    const long long ntiles_g = (N + WAVE / K - 1) / (WAVE / K);
+    const bool one = ntiles_g <= (long long)blocks * SV_NW;       // every wave has at most one tile: latency form
+    if (VMP_T2_RING && (K == 16 || !one)) {
+        // LDS-ring kernels (vmp_svae_ring.hip: quad-coalesced LDS-DMA of sample pairs, two pairs in flight per wave; 8 <= K <= 16,
+        // even L >= 4, even S >= 4, Gaussian or Student-t theta).  Batches of one tile per wave with K != 16 keep the generic
+        // kernel's latency form (tuned at the reference's minibatch size).
+        rc = svae_bwd_ring_launch(a, L, blocks, stream);
+        if (rc != -2) return rc;
     }
     const int PWa = nu ? PW : PW / 2;
     const size_t lds = (size_t)(K * ((L * (L + 1) / 2) | 1) + SV_NW * WAVE + SV_NW * 2 * L * SV_AST + SV_NW * PWa * SV_AST) * sizeof(float);
     rc = -1;
-    const long long ntiles_g = (N + WAVE / K - 1) / (WAVE / K);
-    const bool one = ntiles_g <= (long long)blocks * SV_NW;       // every wave has at most one tile: latency form
     VMP_DISPATCH_L(L, {
         if (one) hipLaunchKernelGGL((svae_estep_bwd_kernel<LL, true>), dim3(blocks), dim3(SV_NW * WAVE), lds, static_cast<hipStream_t>(stream), a);
         else hipLaunchKernelGGL((svae_estep_bwd_kernel<LL, false>), dim3(blocks), dim3(SV_NW * WAVE), lds, static_cast<hipStream_t>(stream), a);

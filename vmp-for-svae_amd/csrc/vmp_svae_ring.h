@@ -1,0 +1,574 @@
+// T2 backward, LDS-ring form (round 3; round 4: any 8 <= K <= 16 and the Student-t theta).
+// Replaces TF's autodiff through models/svae.py:14-119 and the two per-sample densities of compute_elbo(_smm)
+// (svae.py:229-252, 265-322; distributions/gaussian.py:74-105, student_t.py:7-39).
+//
+// What bounded the generic kernel (vmp_svae.hip; measured): with the sample arithmetic REMOVED it still
+// takes 3.2 ms at C3, with the loads removed 1.9 ms - the time is the access pattern, not the arithmetic: every lane fetches
+// its own 64-byte piece of a 320-byte cell row, so each load instruction touches 64 different cache lines and the vector L1
+// spends its cycles on tag look-ups (TCP pending-stall 62 %).  Here the two sample rows (x, dL/dx) of a sample PAIR of the
+// wave's cells are brought in by global_load_lds_dwordx4 with FOUR ADJACENT LANES PER CELL (one 64-byte segment per lane
+// quad: 16 look-ups per instruction instead of 64) into a per-wave ring of two stages; a stage is drained to registers and
+// re-requested for the pair after next BEFORE the arithmetic of its pair starts, so two pairs (16 KB per wave, 128 KB per CU)
+// are always in flight and no VGPR is spent on prefetch.  The LDS this needs comes from the per-component accumulators: the
+// rows of a tile are summed across lanes first (fixed order), so a wave keeps [rows][16] floats instead of a lane-private
+// [rows][64] column set.  One block per CU.  Even L >= 4 and even S >= 4 (a sample pair is L/2 16-byte pieces).
+//
+// Tile = RPT whole data rows = CT = RPT*K consecutive cells, one cell per lane (lane = cell index inside the tile):
+//   K = 16   RPT = 4: a data row is one 16-lane DPP row, lanes l, l^16, l^32, l^48 own the same component - row sums by DPP
+//            rotations, component sums by v_permlane32_swap / v_permlane16_swap;
+//   8 <= K < 16 (round 4; C2/C4's K = 10: 60 of 64 lanes busy - a 16-lane-per-row layout with masked lanes would run the
+//            VALU-bound cell arithmetic at K/16 of the lanes and lose to the generic kernel): RPT = 64 / K in {4..8}
+//            rows whose lanes do NOT line up with the DPP rows.  Every value that has to be summed across lanes is first GATHERED
+//            into the K = 16 arrangement - ds_bpermute: lane (dr, col) of gather g takes the value of tile cell
+//            (4g + dr) * K + col, or 0 - after which the very same DPP / permlane reductions apply; two gathers cover
+//            8 rows.  ds_bpermute uses the LDS crossbar but no LDS memory (~130 per tile; the K = 16 kernel ran 90 of them per
+//            tile before round 3's permlane form and lost < 1 % to them).
+// Student-t theta (round 4; BASELINE configs[4]): the theta term of T' is (nu+L)/2 log1p(delta^2/nu), so the sample loop
+// scales W^T W (x - m) by c_s = (nu+L)/(nu+delta_s^2), and theta/mu_k, theta/L_k are trainable: per cell
+//   cy = sum_s g_s y_s,  Qy = sum_s g_s y_s d_s^T (lower),  g_s = gT c_s / S,  d = x - m,  y = W d
+// stay in registers over the cell's S samples (the generic kernel does 44 LDS read-modify-writes per SAMPLE), then
+// dL/dm = -W^T cy and dL/dW = Qy join the tile's cross-lane sums and the wave's LDS accumulators ([2(L+TRI+1)][16] floats
+// instead of [L+TRI+1][16]: at L = 8 seven waves per CU fit the 160 KB instead of eight).
+#pragma once
+#include "vmp_svae_cell.h"
+
+using namespace vmp;
+
+namespace {
+
+// LDS table of the Student-t theta parameters (per component): rows of the lower-triangular W padded to whole 16-byte
+// pieces, then m and h (padded to LP)
+template <int L>
+struct SvRingTab {
+    __host__ __device__ static constexpr int rlen(int i) { return ((i + 1) + 3) & ~3; }
+    __host__ __device__ static constexpr int roff(int i) { return i == 0 ? 0 : roff(i - 1) + rlen(i - 1); }
+    static constexpr int WTOT = roff(L);
+    static constexpr int LP = (L + 3) & ~3;
+    static constexpr int RAW = WTOT + 2 * LP;
+    static constexpr int TST = ((RAW / 4) & 1) ? RAW : RAW + 4;      // odd number of 16-byte pieces
+};
+
+template <int L, bool K16, bool STUDENT>
+__global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwdArgs a, int nblk_abi) {
+    constexpr int TRI = SvGeo<L>::TRI;
+    constexpr int PW = 2 * (L + TRI + 1);
+    constexpr int TH = L + TRI + 1;                          // phi-side sums; theta-side sums (Student-t) follow at TH
+    constexpr int PWa = STUDENT ? PW : TH;                   // accumulator rows in use
+    constexpr int PP = L / 2;                                // 16-byte pieces of one sample pair of one cell
+    constexpr int STG = svr_stage_floats<L>();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: tile indices and DMA bases stay scalar
+    const int K = K16 ? 16 : a.K, S = a.S;
+    const int LSn = L * S, NP = S >> 1;
+    const int RPT = K16 ? 4 : WAVE / K, CT = RPT * K;
+    constexpr int PSTR = TRI | 1;
+    // Student-t: the theta parameters of a component live in an LDS table instead of 52 VGPRs per lane (with the 44 theta-side
+    // sums of the cell the L = 8 sample loop spilled): [W rows, each padded to whole 16-byte pieces | m | h], stride = odd
+    // number of 16-byte pieces (16 components -> 16 different bank groups; equal components read one address)
+    constexpr int TST = STUDENT ? SvRingTab<L>::TST : 0;
+    const int tab = ((K * PSTR + 3) & ~3) + K * TST;
+    float* pk_lds = smem;                                    // [K][PSTR]  lower triangle of P_k
+    float* th_lds = smem + ((K * PSTR + 3) & ~3);            // [K][TST]   Student-t only
+    float* ring = smem + tab + wave * (2 * STG);             // two stages: [x pair: 64 cells x 2L | dx pair: 64 cells x 2L]
+    float* accw = smem + tab + nw * (2 * STG) + wave * (PWa * 16);   // this wave's per-component sums [PWa][16]
+    const bool lane_on = K16 ? true : lane < CT;
+    const int r = K16 ? lane >> 4 : lane / K, k = K16 ? lane & 15 : lane - r * K;
+
+    // ---- the K = 16 arrangement of a tile with K < 16: gather g puts tile row 4g + dr into DPP row dr, component col in column col
+    const int dr = lane >> 4, col = lane & 15;
+    const bool gv0 = !K16 && col < K && dr < RPT, gv1 = !K16 && col < K && 4 + dr < RPT;
+    const int ga0 = 4 * (gv0 ? dr * K + col : 0), ga1 = 4 * (gv1 ? (4 + dr) * K + col : 0);   // byte addresses for ds_bpermute
+    // (the exchange is executed by ALL lanes and the result selected afterwards: inside `gv ? bpermute(..) : 0` it would run
+    //  under the exec mask of the gv lanes only, and a ds_bpermute that reads from a disabled lane returns 0)
+    auto gat0 = [&](float v) { const float t_ = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga0, __float_as_uint(v))); return gv0 ? t_ : 0.f; };
+    auto gat1 = [&](float v) { const float t_ = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga1, __float_as_uint(v))); return gv1 ? t_ : 0.f; };
+    // sum over the tile's rows of the value each cell holds, per component: in lanes 0..15 (column = component)
+    auto comp_sum = [&](float v) -> float {
+        if constexpr (K16) return rows4_sum(v);
+        else return rows4_sum(RPT > 4 ? gat0(v) + gat1(v) : gat0(v));
+    };
+    // where lane (r, k) finds the sum of ITS row after the gathered row sums: DPP row r & 3, columns 0..7 hold gather 0's sum
+    // (rows 0..3), columns 8..15 gather 1's (rows 4..7)
+    const int back = 4 * ((r & 3) * 16 + (r < 4 ? 0 : 8));
+
+    for (int e = threadIdx.x; e < K * TRI; e += blockDim.x) {
+        const int kk = e / TRI, idx = e - kk * TRI;
+        int i = 0;
+        while (tri(i + 1, 0) <= idx) ++i;
+        const int j = idx - tri(i, 0);
+        pk_lds[kk * PSTR + idx] = a.Pk[(kk * L + i) * L + j];
+    }
+    for (int e = lane; e < PWa * 16; e += WAVE) accw[e] = 0.f;
+    if constexpr (STUDENT) {
+        using T = SvRingTab<L>;
+        for (int e = threadIdx.x; e < K * TST; e += blockDim.x) {
+            const int kk = e / TST, f = e - kk * TST;
+            float v = 0.f;
+            if (f < T::WTOT) {
+                int i = 0;
+                while (i + 1 < L && T::roff(i + 1) <= f) ++i;
+                const int j = f - T::roff(i);
+                if (j <= i) v = a.Wk[(kk * L + i) * L + j];
+            } else if (f < T::WTOT + T::LP) {
+                if (f - T::WTOT < L) v = a.mk[kk * L + (f - T::WTOT)];
+            } else if (f < T::WTOT + 2 * T::LP) {
+                if (f - T::WTOT - T::LP < L) v = a.hk[kk * L + (f - T::WTOT - T::LP)];
+            }
+            th_lds[e] = v;
+        }
+    }
+    __syncthreads();
+
+    const int kc = lane_on ? k : 0;
+    float hkk[STUDENT ? 1 : L], mkk[STUDENT ? 1 : L], Wt[STUDENT ? 1 : TRI];
+    if constexpr (!STUDENT) {
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const float hv = a.hk[kc * L + i], mv = a.mk[kc * L + i];
+            hkk[i] = lane_on ? hv : 0.f;
+            mkk[i] = lane_on ? mv : 0.f;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) { const float wv = a.Wk[(kc * L + i) * L + j]; Wt[tri(i, j)] = lane_on ? wv : 0.f; }
+        }
+    }
+    float nuk = 1.f;
+    if constexpr (STUDENT) { const float nv = a.nu[kc]; nuk = lane_on ? nv : 1.f; }
+    const int th_off = kc * TST;                             // this lane's row of the theta table
+
+    const long long ntiles = (a.N + RPT - 1) / RPT;
+    const long long tstride = (long long)gridDim.x * nw;
+    const float invS = 1.0f / (float)S;
+    // DMA slot walk: slot g = j*64 + lane of instruction j holds piece (g % PP) of tile cell (g / PP); for L = 8 the piece
+    // index is XOR-swizzled with bits 2-3 of the cell so that the 16 lanes a ds_read_b128 serves together hit 16 banks
+    int dcell[PP], dpiece[PP];
+#pragma unroll
+    for (int j = 0; j < PP; ++j) {
+        const int g = j * WAVE + lane;
+        dcell[j] = g / PP;
+        const int pc = g - dcell[j] * PP;
+        dpiece[j] = (PP == 4) ? (pc ^ ((dcell[j] >> 2) & 3)) : pc;
+    }
+    const int sw = (PP == 4) ? ((lane >> 2) & 3) : 0;       // read side of the same swizzle (this lane's cell = lane)
+    auto issue = [&](long long tt, int pp, float* stage) {
+        // pair pp of tile tt -> stage; cells past the end of the tile / of the tensor are clamped to the tile's last valid cell
+        const long long cells_left = (a.N - tt * RPT) * K;
+        const int ncell = cells_left < CT ? (int)cells_left : CT;
+        const long long tile0 = tt * (long long)CT * LSn + pp * 2 * L;
+#pragma unroll
+        for (int j = 0; j < PP; ++j) {
+            const int cc = dcell[j] < ncell ? dcell[j] : ncell - 1;
+            const long long off = tile0 + (long long)cc * LSn + 4 * dpiece[j];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.x + off),
+                                             (__attribute__((address_space(3))) void*)(stage + j * (4 * WAVE)), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.Gx + off),
+                                             (__attribute__((address_space(3))) void*)(stage + WAVE * 2 * L + j * (4 * WAVE)), 16, 0, 0);
+        }
+    };
+
+    long long t = (long long)blockIdx.x * nw + wave;
+    int cur = 0;                                             // stage holding the pair about to be consumed
+    bool younger = true;                                     // was the pair after the one about to be consumed requested?
+    if (t < ntiles) {
+        issue(t, 0, ring);
+        if (NP > 1) issue(t, 1, ring + STG);
+        else if (t + tstride < ntiles) issue(t + tstride, 0, ring + STG);
+    }
+    for (; t < ntiles; t += tstride) {
+        const long long row = t * RPT + r;
+        const bool on = lane_on && row < a.N;
+        const long long rowc = on ? row : 0;
+        const long long cellid = rowc * K + kc;
+
+        float Lm[TRI], av[L], mu[L];
+#pragma unroll
+        for (int i = 0; i < TRI; ++i) Lm[i] = lane_on ? pk_lds[kc * PSTR + i] : 0.f;
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const float e1v = a.eta1[rowc * L + i], e2v = a.eta2d[rowc * L + i];
+            const float e1 = on ? e1v : 0.f;
+            const float e2 = on ? e2v : -0.5f;
+            Lm[tri(i, i)] = fmaf(-2.f, e2, lane_on ? Lm[tri(i, i)] : 0.f);
+            if constexpr (STUDENT) av[i] = e1 + (lane_on ? th_lds[th_off + SvRingTab<L>::WTOT + SvRingTab<L>::LP + i] : 0.f);
+            else av[i] = e1 + hkk[i];
+        }
+        const float glzv = a.Glz[cellid], gTv = a.GT[cellid], lzv = a.lz[cellid];
+        float ld;
+        cell_cholesky<L>(Lm, ld);
+        solve_lower<L>(Lm, av);
+#pragma unroll
+        for (int i = 0; i < L; ++i) mu[i] = av[i];
+        solve_lower_t<L>(Lm, mu);                           // mu~ = Pt^-1 ht
+
+        const float glz = on ? glzv : 0.f;
+        const float gT = on ? gTv : 0.f;
+        const float rnk = on ? __expf(lzv) : 0.f;
+        float gsum;
+        if constexpr (K16) {
+            gsum = row16_sum(glz);
+        } else {
+            const float t0 = row16_sum(gat0(glz)), t1 = RPT > 4 ? row16_sum(gat1(glz)) : 0.f;
+            gsum = __uint_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_uint(col < 8 ? t0 : t1)));
+        }
+        const float Gc = glz - rnk * gsum;                  // through the log-sum-exp normalisation
+        const float Gld = gT - Gc;                          // T' has +ld, c has -ld
+
+        float Wsum[L], M[TRI];
+#pragma unroll
+        for (int i = 0; i < L; ++i) Wsum[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < TRI; ++i) M[i] = 0.f;
+        float cy[STUDENT ? L : 1], Qy[STUDENT ? TRI : 1];   // Student-t: theta-side sums of this cell
+        if constexpr (STUDENT) {
+#pragma unroll
+            for (int i = 0; i < L; ++i) cy[i] = 0.f;
+#pragma unroll
+            for (int i = 0; i < TRI; ++i) Qy[i] = 0.f;
+        }
+        const float gts = gT * invS;
+        const float nuL = nuk + (float)L;
+        float mm[STUDENT ? L : 1];                          // Student-t: m_k - mu~, so that x_s - mu~ = (x_s - m_k) + mm
+        if constexpr (STUDENT) {
+#pragma unroll
+            for (int i = 0; i < L; ++i) mm[i] = th_lds[th_off + SvRingTab<L>::WTOT + i] - mu[i];
+        }
+        for (int p = 0; p < NP; ++p) {
+            float* stage = ring + cur * STG;
+            // The stage about to be read was requested two pairs ago.  If the pair in between was requested too, its 2*PP
+            // DMA instructions are the youngest ones in flight and may stay so; if it was not (no next tile for this wave),
+            // NOTHING younger exists and the count must drain to zero - waiting for "<= 2*PP outstanding" would then not wait
+            // at all (found as a run-to-run difference of the last pair of a wave's last tile).
+            if (!younger) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (PP == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (PP == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (PP == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            float xp[2 * L], gp[2 * L];
+#pragma unroll
+            for (int q = 0; q < PP; ++q) {
+                const f32x4 vx = *reinterpret_cast<const f32x4*>(stage + lane * (2 * L) + 4 * (q ^ sw));
+                const f32x4 vg = *reinterpret_cast<const f32x4*>(stage + WAVE * 2 * L + lane * (2 * L) + 4 * (q ^ sw));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { xp[4 * q + c] = vx[c]; gp[4 * q + c] = vg[c]; }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the stage is in registers: it may be overwritten
+#pragma unroll
+            for (int i = 0; i < 2 * L; ++i) asm volatile("" : "+v"(xp[i]), "+v"(gp[i]));
+            {   // re-request this stage for the pair after next (of this tile, or of this wave's next tile; NP >= 2: host)
+                const int pn = p + 2;
+                if (pn < NP) { issue(t, pn, stage); younger = true; }
+                else if (t + tstride < ntiles) { issue(t + tstride, pn - NP, stage); younger = true; }
+                else younger = false;
+            }
+            cur ^= 1;
+            if constexpr (STUDENT) {
+                // both samples of the pair against each row of W (one LDS read of the row serves two samples)
+                using T = SvRingTab<L>;
+                float d[2][L], y[2][L], gx[2][L], del2[2] = {0.f, 0.f};
+                {
+                    int mo = th_off + T::WTOT;
+                    asm volatile("" : "+v"(mo));                       // not hoisted out of the sample loop
+#pragma unroll
+                    for (int i = 0; i < L; ++i) {
+                        const float mv = th_lds[mo + i];
+                        d[0][i] = (on ? xp[i] : 0.f) - mv; d[1][i] = (on ? xp[L + i] : 0.f) - mv;
+                        gx[0][i] = on ? gp[i] : 0.f; gx[1][i] = on ? gp[L + i] : 0.f;
+                    }
+                }
+                int wo = th_off;
+                asm volatile("" : "+v"(wo));
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    float w[8];
+#pragma unroll
+                    for (int q = 0; q <= i / 4; ++q) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(th_lds + wo + T::roff(i) + 4 * q);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) w[4 * q + c] = wv[c];
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        float yy = 0.f;
+#pragma unroll
+                        for (int j = 0; j <= i; ++j) yy = fmaf(w[j], d[h][j], yy);
+                        y[h][i] = yy;
+                        del2[h] = fmaf(yy, yy, del2[h]);
+                    }
+                }
+                // c_s = (nu+L)/(nu+delta^2) (student_t.py:31-37 differentiated)
+                const float gc0 = gts * nuL * __builtin_amdgcn_rcpf(nuk + del2[0]), gc1 = gts * nuL * __builtin_amdgcn_rcpf(nuk + del2[1]);
+                asm volatile("" : "+v"(wo));                           // second pass: the rows are read again, not kept
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    float w[8];
+#pragma unroll
+                    for (int q = 0; q <= i / 4; ++q) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(th_lds + wo + T::roff(i) + 4 * q);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) w[4 * q + c] = wv[c];
+                    }
+                    const float gy0 = gc0 * y[0][i], gy1 = gc1 * y[1][i];
+                    cy[i] += gy0 + gy1;
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) {
+                        gx[0][j] = fmaf(w[j], gy0, gx[0][j]);
+                        gx[1][j] = fmaf(w[j], gy1, gx[1][j]);
+                        Qy[tri(i, j)] = fmaf(gy1, d[1][j], fmaf(gy0, d[0][j], Qy[tri(i, j)]));
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    solve_lower<L>(Lm, gx[h]);                  // w_s = Lt^-1 gx_s
+#pragma unroll
+                    for (int i = 0; i < L; ++i) {
+                        Wsum[i] += gx[h][i];
+                        const float e = d[h][i] + mm[i];        // e_s = x_s - mu~ = Lt^-T eps_s
+#pragma unroll
+                        for (int j = 0; j <= i; ++j) M[tri(i, j)] = fmaf(e, gx[h][j], M[tri(i, j)]);
+                    }
+                }
+            } else {
+    #pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float xs[L], gx[L];
+    #pragma unroll
+                    for (int i = 0; i < L; ++i) { xs[i] = on ? xp[h * L + i] : 0.f; gx[i] = on ? gp[h * L + i] : 0.f; }
+                    // d/dx of the theta term of T':  (1/S) c_s W^T W (x - m),  c_s = 1 (Gaussian) or (nu+L)/(nu+delta^2)
+                    float d[L], y[L];
+    #pragma unroll
+                    for (int i = 0; i < L; ++i) d[i] = xs[i] - mkk[i];
+    #pragma unroll
+                    for (int i = 0; i < L; ++i) {
+                        float yy = 0.f;
+    #pragma unroll
+                        for (int j = 0; j <= i; ++j) yy = fmaf(Wt[tri(i, j)], d[j], yy);
+                        y[i] = yy;
+                    }
+                    const float gcs = gts;
+    #pragma unroll
+                    for (int i = 0; i < L; ++i) {
+                        const float gy = gcs * y[i];
+    #pragma unroll
+                        for (int j = 0; j <= i; ++j) gx[j] = fmaf(Wt[tri(i, j)], gy, gx[j]);
+                    }
+                    solve_lower<L>(Lm, gx);                     // w_s = Lt^-1 gx_s
+    #pragma unroll
+                    for (int i = 0; i < L; ++i) {
+                        Wsum[i] += gx[i];
+                        const float e = xs[i] - mu[i];          // e_s = Lt^-T eps_s
+    #pragma unroll
+                        for (int j = 0; j <= i; ++j) M[tri(i, j)] = fmaf(e, gx[j], M[tri(i, j)]);
+                    }
+                }
+            }
+        }
+        // ---- Student-t: this cell's theta-side gradients join the wave's accumulators (rows TH..PW-1) now, so that their
+        //      registers are free during the assembly below:  dL/dm = -W^T cy,  dL/dW = Qy,  dL/dkappa = -gT
+        if constexpr (STUDENT) {
+            float tx[L];
+#pragma unroll
+            for (int j = 0; j < L; ++j) tx[j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                float w[8];
+#pragma unroll
+                for (int q = 0; q <= i / 4; ++q) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(th_lds + th_off + SvRingTab<L>::roff(i) + 4 * q);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) w[4 * q + c] = wv[c];
+                }
+#pragma unroll
+                for (int j = 0; j <= i; ++j) tx[j] = fmaf(w[j], cy[i], tx[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < L; ++j) tx[j] = comp_sum(-tx[j]);
+#pragma unroll
+            for (int i = 0; i < TRI; ++i) Qy[i] = comp_sum(Qy[i]);
+            const float gks = comp_sum(-gT);
+            if (lane < 16) {
+                constexpr int CH = 9;
+#pragma unroll
+                for (int c0 = 0; c0 < TH; c0 += CH) {
+                    float oldv[CH];
+#pragma unroll
+                    for (int u = 0; u < CH; ++u)
+                        if (c0 + u < TH) oldv[u] = accw[(TH + c0 + u) * 16 + lane];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) asm volatile("" : "+v"(oldv[u]));
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) {
+                        const int i = c0 + u;
+                        if (i < TH) accw[(TH + i) * 16 + lane] = oldv[u] + (i < L ? tx[i < L ? i : 0] : i < L + TRI ? Qy[(i >= L && i < L + TRI) ? i - L : 0] : gks);
+                    }
+                }
+            }
+        }
+        // ---- assemble dLoss/dht and dLoss/dPt (symmetric, lower triangle): as in svae_estep_bwd_kernel
+        float V[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) V[i] = Wsum[i];
+        solve_lower_t<L>(Lm, V);                            // V = Pt^-1 sum_s gx_s
+        float gh[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) gh[i] = fmaf(Gc, mu[i], V[i]);
+        float Cs[TRI], dg[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) dg[i] = 1.0f / Lm[tri(i, i)];
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                float s2 = 0.f;
+#pragma unroll
+                for (int pq = i; pq < L; ++pq) {
+                    const float lpi = (pq == i) ? dg[i] : Lm[tri(pq, i)];
+                    s2 = fmaf(lpi, -M[tri(pq, j)], s2);
+                }
+                Cs[tri(i, j)] = (i == j) ? (s2 + Gld) : s2;
+            }
+        float Y[TRI];
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            Y[tri(j, j)] = Lm[tri(j, j)];
+#pragma unroll
+            for (int i = j + 1; i < L; ++i) {
+                float s2 = 0.f;
+#pragma unroll
+                for (int pq = j; pq < i; ++pq) s2 = fmaf(Lm[tri(i, pq)], Y[tri(pq, j)], s2);
+                Y[tri(i, j)] = -s2 * Lm[tri(i, i)];
+            }
+        }
+        float gP[TRI];
+#pragma unroll
+        for (int i = 0; i < TRI; ++i) gP[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            float Zc[L];
+#pragma unroll
+            for (int q = 0; q < L; ++q) {
+                float s2 = 0.f;
+#pragma unroll
+                for (int pq = j; pq < L; ++pq) {
+                    const float cqp = (q >= pq) ? Cs[tri(q, pq)] : Cs[tri(pq, q)];
+                    s2 = fmaf(cqp, Y[tri(pq, j)], s2);
+                }
+                Zc[q] = s2;
+            }
+#pragma unroll
+            for (int i = j; i < L; ++i) {
+                float s2 = 0.f;
+#pragma unroll
+                for (int pq = i; pq < L; ++pq) s2 = fmaf(Y[tri(pq, i)], Zc[pq], s2);
+                gP[tri(i, j)] = 0.5f * s2;
+            }
+        }
+        // rank-one terms  - sym(V mu^T) - 1/2 Gc mu mu^T  =  -1/2 (tv mu^T + mu tv^T),  tv = V + 1/2 Gc mu
+        float tv[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) tv[i] = -0.5f * fmaf(0.5f * Gc, mu[i], V[i]);
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) gP[tri(i, j)] = fmaf(tv[i], mu[j], fmaf(mu[i], tv[j], gP[tri(i, j)]));
+
+        // ---- per-row sums (over the components of a data row) -> d eta of the encoder
+        if constexpr (K16) {
+            float s1[L], s2[L];
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                s1[i] = row16_sum(on ? gh[i] : 0.f);
+                s2[i] = -2.f * row16_sum(on ? gP[tri(i, i)] : 0.f);      // p = -2 eta2d
+            }
+            if (on && k == 0) {                             // one masked block: 2L stores to two contiguous rows
+#pragma unroll
+                for (int i = 0; i < L; ++i) { a.g_eta1[row * L + i] = s1[i]; a.g_eta2d[row * L + i] = s2[i]; }
+            }
+        } else {
+            // gathered: the lane in column 0 of DPP row dr stores tile rows dr (gather 0) and 4 + dr (gather 1)
+            float s1a[L], s2a[L], s1b[L], s2b[L];
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                const float v1 = on ? gh[i] : 0.f, v2 = on ? gP[tri(i, i)] : 0.f;
+                s1a[i] = row16_sum(gat0(v1));
+                s2a[i] = -2.f * row16_sum(gat0(v2));
+                if (RPT > 4) { s1b[i] = row16_sum(gat1(v1)); s2b[i] = -2.f * row16_sum(gat1(v2)); }
+            }
+            const long long rowa = t * RPT + dr, rowb = rowa + 4;
+            if (col == 0 && dr < RPT && rowa < a.N) {
+#pragma unroll
+                for (int i = 0; i < L; ++i) { a.g_eta1[rowa * L + i] = s1a[i]; a.g_eta2d[rowa * L + i] = s2a[i]; }
+            }
+            if (RPT > 4 && col == 0 && 4 + dr < RPT && rowb < a.N) {
+#pragma unroll
+                for (int i = 0; i < L; ++i) { a.g_eta1[rowb * L + i] = s1b[i]; a.g_eta2d[rowb * L + i] = s2b[i]; }
+            }
+        }
+        // ---- per-component sums: all cross-row sums first (in place), then ONE masked block that updates the LDS accumulators
+        // in batches: the reads of a batch are issued together and waited for once.  (`if (lane < 16) accw[..] += sv` per value
+        // was 45 exec-mask switches and 45 LDS read - wait - add - write round trips in a row per tile.)
+#pragma unroll
+        for (int i = 0; i < L; ++i) gh[i] = comp_sum(on ? gh[i] : 0.f);
+#pragma unroll
+        for (int i = 0; i < TRI; ++i) gP[i] = comp_sum(on ? gP[i] : 0.f);
+        const float gcs2 = comp_sum(on ? Gc : 0.f);
+        if (lane < 16) {
+            constexpr int CH = 9;                                          // values per batch (TH = L + TRI + 1; 45 = 5 x 9 at L = 8)
+#pragma unroll
+            for (int c0 = 0; c0 < TH; c0 += CH) {
+                float oldv[CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u)
+                    if (c0 + u < TH) oldv[u] = accw[(c0 + u) * 16 + lane];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < CH; ++u) asm volatile("" : "+v"(oldv[u]));
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const int i = c0 + u;
+                    if (i < TH) accw[i * 16 + lane] = oldv[u] + (i < L ? gh[i < L ? i : 0] : i < L + TRI ? gP[(i >= L && i < L + TRI) ? i - L : 0] : gcs2);
+                }
+            }
+        }
+    }
+
+    // ---- block reduction: waves in a fixed order, then one partial row per block
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* out = a.partials + (long long)blockIdx.x * K * PW;
+    for (int e = threadIdx.x; e < K * PW; e += blockDim.x) {
+        const int kk = e / PW, f = e - kk * PW;
+        float s2 = 0.f;
+        if (f < PWa) {
+            const float* base = smem + tab + nw * (2 * STG);
+            for (int w = 0; w < nw; ++w) s2 += base[w * (PWa * 16) + f * 16 + kk];
+        }
+        out[e] = s2;
+    }
+    // rows of the partial buffer the ABI sized for more blocks than this kernel launches
+    for (int b = blockIdx.x + gridDim.x; b < nblk_abi; b += gridDim.x) {
+        float* z = a.partials + (long long)b * K * PW;
+        for (int e = threadIdx.x; e < K * PW; e += blockDim.x) z[e] = 0.f;
+    }
+}
+
+template <int L, bool K16, bool STUDENT>
+int launch(const EBwdArgs& a, int nblk_abi, void* stream) {
+    constexpr int TRI = L * (L + 1) / 2, TH = L + TRI + 1, PWa = STUDENT ? 2 * TH : TH;
+    const int K = a.K, RPT = WAVE / K;
+    const int tab = ((K * (TRI | 1) + 3) & ~3) + (STUDENT ? K * SvRingTab<L>::TST : 0);
+    const int per_wave = 2 * svr_stage_floats<L>() + PWa * 16;
+    int nw = (int)((160 * 1024 / sizeof(float) - tab) / per_wave);
+    if (nw > SVR_NW) nw = SVR_NW;
+    if (nw < 4) return -2;
+    const long long ntiles = (a.N + RPT - 1) / RPT;
+    long long bl = (ntiles + nw - 1) / nw;
+    if (bl > 256) bl = 256;                                  // one block per CU
+    const size_t lds = (size_t)(tab + nw * per_wave) * sizeof(float);
+    auto kern = svae_estep_bwd_ring_kernel<L, K16, STUDENT>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((int)bl), dim3(nw * WAVE), lds, static_cast<hipStream_t>(stream), a, nblk_abi);
+    return check_launch("svae_estep_bwd_ring_kernel");
+}
+
+}  // namespace
