@@ -13,7 +13,11 @@ phi = [p.detach().to(dev).contiguous() for p in svae.init_recognition_params(the
 theta = [t.to(dev).contiguous() for t in theta]
 with torch.no_grad():
     hk, P, bias = _svae_ops.PhiPrepFn.apply(*[p.detach() for p in phi])        # K-sized inputs from the prep kernels
+if os.environ.get('SMM', '0') == '1':                       # Student-t theta (svae.py:265-322): [alpha, mu_k, L_k, dof]
+    mu_t, L_t = svae.make_loc_scale_variables([t.cpu() for t in prior], 'cpu')
+    theta = [theta[0], (mu_t.detach() + torch.randn(K, Ld)).to(dev), L_t.detach().to(dev), torch.full((K,), 5.0, device=dev)]
 mk, Wk, kap, nu = svae._theta_pack(theta)
+mk, Wk = mk.detach().contiguous(), Wk.detach().contiguous()
 g = torch.Generator(device=dev).manual_seed(0)
 eta1 = torch.randn(N, Ld, device=dev, generator=g).requires_grad_(True)
 eta2d = (-0.5 * torch.log1p(torch.exp(torch.randn(N, Ld, device=dev, generator=g)))).requires_grad_(True)
@@ -21,7 +25,7 @@ noise = torch.randn(N, K, Ld, S, device=dev, generator=g)
 Gx = torch.randn(N, K, S, Ld, device=dev, generator=g) * 0.01
 Glz = torch.randn(N, K, device=dev, generator=g) * 0.1
 for it in range(int(os.environ.get('REPS', 3))):
-    x, lz, Tp = _svae_ops.SvaeEStepFn.apply(eta1, eta2d, hk, P, bias, noise, mk, Wk, kap, None)
+    x, lz, Tp = _svae_ops.SvaeEStepFn.apply(eta1, eta2d, hk, P, bias, noise, mk, Wk, kap, nu)
     r = torch.exp(lz.detach())
     torch.autograd.backward([x, lz, Tp], [Gx, Glz, r])
     xs = svae.subsample_x(x.detach(), lz.detach(), seed=it, nb_out=1)[:, 0, :].contiguous()

@@ -7,6 +7,13 @@ N = int(os.environ.get('N', 1000000)); Ld, K, S = 8, int(os.environ.get('K', 16)
 dev = 'cuda'
 prior, theta = svae.init_mm(K, Ld, seed=0, param_device=dev)
 phi = [p.detach().requires_grad_(True) for p in svae.init_recognition_params(theta, K, seed=0, param_device=dev)]
+th_params = []
+if os.environ.get('SMM', '0') == '1':                       # Student-t theta (svae.py:265-322): [alpha, mu_k, L_k, dof]
+    mu_t, L_t = svae.make_loc_scale_variables(prior, dev)
+    with torch.no_grad():
+        mu_t.add_(torch.randn(K, Ld, device=dev, generator=torch.Generator(device=dev).manual_seed(1)))
+    theta = [theta[0].clone(), mu_t, L_t, torch.full((K,), 5.0, device=dev)]
+    th_params = [mu_t, L_t]
 g = torch.Generator(device=dev).manual_seed(0)
 eta1 = torch.randn(N, Ld, device=dev, generator=g).requires_grad_(True)
 eta2d = (-0.5 * torch.nn.functional.softplus(torch.randn(N, Ld, device=dev, generator=g))).requires_grad_(True)
@@ -21,7 +28,7 @@ for it in range(8):
     b.record()
     r = torch.exp(lz.detach())
     b2 = torch.cuda.Event(enable_timing=True); b2.record()
-    grads = torch.autograd.grad([x, lz, pt.T_prime], [eta1, eta2d] + phi, [Gx, Glz, r])
+    grads = torch.autograd.grad([x, lz, pt.T_prime], [eta1, eta2d] + phi + th_params, [Gx, Glz, r])
     c.record()
     torch.cuda.synchronize()
     if it >= 2:
@@ -37,4 +44,4 @@ for it in range(8):
         tp.append(a.elapsed_time(b))
     del x, lz, pt
 print('T2 forward with in-kernel Philox noise: %.3f ms' % np.median(tp))
-print('T2 N=%d K=%d: fwd %.3f ms  bwd %.3f ms   (bwd 10.4 GB -> %.0f GB/s = %.2f of 8 TB/s)' % (N, K, np.median(tf), np.median(tb), 4.0 * N * (2.0 * K * S * Ld + 4 * Ld + 3 * K) / (np.median(tb) * 1e-3) / 1e9, 4.0 * N * (2.0 * K * S * Ld + 4 * Ld + 3 * K) / (np.median(tb) * 1e-3) / 8e12))
+print('T2 N=%d K=%d SMM=%s: fwd %.3f ms  bwd %.3f ms   (bwd -> %.0f GB/s = %.2f of 8 TB/s)' % (N, K, os.environ.get('SMM', '0'), np.median(tf), np.median(tb), 4.0 * N * (2.0 * K * S * Ld + 4 * Ld + 3 * K) / (np.median(tb) * 1e-3) / 1e9, 4.0 * N * (2.0 * K * S * Ld + 4 * Ld + 3 * K) / (np.median(tb) * 1e-3) / 8e12))

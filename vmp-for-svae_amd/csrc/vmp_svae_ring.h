@@ -83,10 +83,51 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
     //  under the exec mask of the gv lanes only, and a ds_bpermute that reads from a disabled lane returns 0)
     auto gat0 = [&](float v) { const float t_ = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga0, __float_as_uint(v))); return gv0 ? t_ : 0.f; };
     auto gat1 = [&](float v) { const float t_ = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga1, __float_as_uint(v))); return gv1 ? t_ : 0.f; };
-    // sum over the tile's rows of the value each cell holds, per component: in lanes 0..15 (column = component)
-    auto comp_sum = [&](float v) -> float {
-        if constexpr (K16) return rows4_sum(v);
-        else return rows4_sum(RPT > 4 ? gat0(v) + gat1(v) : gat0(v));
+    // The TH values a cell contributes to its component's sums -> this wave's LDS accumulator rows [row0, row0 + TH).  Batches
+    // of CH: (K < 16: the 2 CH gathers of the batch issued back to back,) the batch's accumulator words requested by lanes
+    // 0..15, ONE wait for both, the cross-row sums on the VALU, one masked block of stores.  (One value at a time was a chain
+    // of exchange -> wait -> sum per value: ~210 s_waitcnt per tile in the first K < 16 build.)
+    auto acc_batches = [&](const float (&vals)[TH], int row0) {
+        constexpr int CH = 9;                                              // TH = L + TRI + 1; 45 = 5 x 9 at L = 8
+#pragma unroll
+        for (int c0 = 0; c0 < TH; c0 += CH) {
+            float t0[CH], t1[CH], oldv[CH];
+            if constexpr (!K16) {
+#pragma unroll
+                for (int u = 0; u < CH; ++u)
+                    if (c0 + u < TH) t0[u] = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga0, __float_as_uint(vals[c0 + u])));
+                if (RPT > 4) {
+#pragma unroll
+                    for (int u = 0; u < CH; ++u)
+                        if (c0 + u < TH) t1[u] = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga1, __float_as_uint(vals[c0 + u])));
+                }
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int u = 0; u < CH; ++u)
+                    if (c0 + u < TH) oldv[u] = accw[(row0 + c0 + u) * 16 + lane];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                if (c0 + u < TH) {
+                    asm volatile("" : "+v"(oldv[u]));
+                    if constexpr (K16) {
+                        t0[u] = rows4_sum(vals[c0 + u]);
+                    } else {
+                        asm volatile("" : "+v"(t0[u]));
+                        float g_ = gv0 ? t0[u] : 0.f;
+                        if (RPT > 4) { asm volatile("" : "+v"(t1[u])); g_ += gv1 ? t1[u] : 0.f; }
+                        t0[u] = rows4_sum(g_);
+                    }
+                }
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int u = 0; u < CH; ++u)
+                    if (c0 + u < TH) accw[(row0 + c0 + u) * 16 + lane] = oldv[u] + t0[u];
+            }
+        }
     };
     // where lane (r, k) finds the sum of ITS row after the gathered row sums: DPP row r & 3, columns 0..7 hold gather 0's sum
     // (rows 0..3), columns 8..15 gather 1's (rows 4..7)
@@ -121,15 +162,22 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
     __syncthreads();
 
     const int kc = lane_on ? k : 0;
-    float hkk[STUDENT ? 1 : L], mkk[STUDENT ? 1 : L], Wt[STUDENT ? 1 : TRI];
+    // Gaussian theta: the component's parameters stay in this lane's registers for the whole kernel, W in the padded pair
+    // layout of the sample loop (below)
+    constexpr int TPRk = ((L + 1) * (L + 1)) / 4;
+    float hkk[STUDENT ? 1 : L];
+    v2f m2[STUDENT ? 1 : L / 2], W2[STUDENT ? 1 : TPRk];
     if constexpr (!STUDENT) {
 #pragma unroll
         for (int i = 0; i < L; ++i) {
             const float hv = a.hk[kc * L + i], mv = a.mk[kc * L + i];
             hkk[i] = lane_on ? hv : 0.f;
-            mkk[i] = lane_on ? mv : 0.f;
+            m2[i / 2][i & 1] = lane_on ? mv : 0.f;
 #pragma unroll
-            for (int j = 0; j <= i; ++j) { const float wv = a.Wk[(kc * L + i) * L + j]; Wt[tri(i, j)] = lane_on ? wv : 0.f; }
+            for (int j = 0; j < 2 * ((i + 2) / 2); ++j) {
+                const float wv = a.Wk[(kc * L + i) * L + (j <= i ? j : i)];
+                W2[((i + 1) * (i + 1)) / 4 + j / 2][j & 1] = (lane_on && j <= i) ? wv : 0.f;
+            }
         }
     }
     float nuk = 1.f;
@@ -150,15 +198,28 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
         dpiece[j] = (PP == 4) ? (pc ^ ((dcell[j] >> 2) & 3)) : pc;
     }
     const int sw = (PP == 4) ? ((lane >> 2) & 3) : 0;       // read side of the same swizzle (this lane's cell = lane)
+    // L = 8: a sample pair of a cell is 64 bytes, a cell row S/2 of them.  With S/2 odd every second cell row starts in the
+    // middle of a 128-byte L2 line, and that line holds the LAST pair of the cell before it: requested S/2 - 1 pair-times
+    // apart, the line has left the L2 in between and crosses the fabric twice (TCC_MISS 28.8 M for 20 M lines at N = 250 000,
+    // profiles/r04_t2_pmc_summary.txt).  Such cells take their pairs in ROTATED order (1, 2, .., S/2 - 1, 0; nothing in the
+    // arithmetic depends on the order of a cell's samples): its pair 0 is then asked for by the SAME DMA instruction as its
+    // neighbour's last pair - one 128-byte request.
+    const bool rotate = (PP == 4) && (NP & 1);
     auto issue = [&](long long tt, int pp, float* stage) {
         // pair pp of tile tt -> stage; cells past the end of the tile / of the tensor are clamped to the tile's last valid cell
         const long long cells_left = (a.N - tt * RPT) * K;
         const int ncell = cells_left < CT ? (int)cells_left : CT;
-        const long long tile0 = tt * (long long)CT * LSn + pp * 2 * L;
+        const long long tile0 = tt * (long long)CT * LSn;
+        const int par0 = (int)((tt * CT) & 1);               // parity of the tile's first cell
 #pragma unroll
         for (int j = 0; j < PP; ++j) {
-            const int cc = dcell[j] < ncell ? dcell[j] : ncell - 1;
-            const long long off = tile0 + (long long)cc * LSn + 4 * dpiece[j];
+            // L = 8: the slot walk is recomputed from the lane (shifts and masks) instead of living in 8 registers
+            const int dc = (PP == 4) ? ((j * WAVE + lane) >> 2) : dcell[j];
+            const int dp = (PP == 4) ? ((lane & 3) ^ ((dc >> 2) & 3)) : dpiece[j];
+            const int cc = dc < ncell ? dc : ncell - 1;
+            int pe = pp;
+            if (rotate) { pe = pp + ((cc + par0) & 1); pe = pe >= NP ? pe - NP : pe; }
+            const long long off = tile0 + (long long)cc * LSn + pe * 2 * L + 4 * dp;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.x + off),
                                              (__attribute__((address_space(3))) void*)(stage + j * (4 * WAVE)), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.Gx + off),
@@ -213,25 +274,62 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
         const float Gc = glz - rnk * gsum;                  // through the log-sum-exp normalisation
         const float Gld = gT - Gc;                          // T' has +ld, c has -ld
 
-        float Wsum[L], M[TRI];
+        // ---- packed layouts of the sample loop (round 4).  Every product of the loop runs as v_pk_fma_f32 over PAIRS OF ADJACENT
+        // COLUMNS (two floats that are neighbours in memory are neighbours in registers: no packing moves):
+        //   rows of a lower triangle (W, M, Qy) padded to whole pairs: row i = RP(i) = (i+2)/2 pairs at RO(i) = (i+1)^2/4;
+        //   the Cholesky factor by COLUMNS in row pairs (forward substitution updates the rows below the pivot):
+        //   column j = pairs q0(j) = (j+1)/2 .. L/2-1 at CO(j) = j L/2 - j^2/4; the half that would hold the diagonal (j even)
+        //   is a don't-care, that row is updated by a scalar fma; reciprocal diagonal in rd[].
+        // A parameter that multiplies a pair is broadcast from one half of a register pair by the pk_*_b helpers (vmp_common.h:
+        // the operand forms that are safe beside bf16 MFMAs).  The per-sample `on ? x : 0` selects are gone (64 VALU per pair):
+        // an inactive lane reads the clamped copy of a valid cell (finite values), its upstream gradients gT, glz are zero and
+        // everything it accumulates is masked when the tile's sums are formed.
+        constexpr int LH = L / 2;
+        auto RO = [](int i) { return ((i + 1) * (i + 1)) / 4; };
+        auto RPn = [](int i) { return (i + 2) / 2; };
+        constexpr int TPR = ((L + 1) * (L + 1)) / 4;             // pairs of a padded row-major triangle
+        auto CO = [](int j) { return j * (L / 2) - (j * j) / 4; };
+        auto Q0 = [](int j) { return (j + 1) / 2; };
+        constexpr int TPC = L * (L / 2) - (L * L) / 4;           // pairs of the column-major strict lower triangle
+        // Gaussian theta: packed storage.  Student-t: the round's first form is kept - scalar arithmetic, every row of W read
+        // ONCE per sample pair from the LDS table and used for both samples: the packed form of it was slower in both variants
+        // tried (two samples together: spills inside the pair loop, whose reloads drain the DMA ring - vmcnt is in order;
+        // one sample at a time: twice the table reads, SQ_LDS_BANK_CONFLICT 6 M -> 21 M cycles; 2.89 -> 3.15 ms at C3)
+        v2f LC[STUDENT ? 1 : TPC];
+        float rd[L];
 #pragma unroll
-        for (int i = 0; i < L; ++i) Wsum[i] = 0.f;
+        for (int j = 0; j < L; ++j) rd[j] = Lm[tri(j, j)];
+        if constexpr (!STUDENT) {
 #pragma unroll
-        for (int i = 0; i < TRI; ++i) M[i] = 0.f;
-        float cy[STUDENT ? L : 1], Qy[STUDENT ? TRI : 1];   // Student-t: theta-side sums of this cell
+            for (int j = 0; j < L; ++j)
+#pragma unroll
+                for (int q = Q0(j); q < LH; ++q)
+                    LC[CO(j) + q - Q0(j)] = v2f{2 * q > j ? Lm[tri(2 * q > j ? 2 * q : j + 1, j)] : 0.f, Lm[tri(2 * q + 1, j)]};
+        }
+        auto LM = [&](int i, int j) -> float {               // i >= j; the diagonal holds reciprocals
+            if constexpr (STUDENT) return Lm[tri(i, j)];
+            else return i == j ? rd[i] : LC[CO(j) + i / 2 - Q0(j)][i & 1];
+        };
+
+        v2f Wsum2[STUDENT ? 1 : LH], M2[STUDENT ? 1 : TPR], mu2[STUDENT ? 1 : LH];
+        float Wsum[STUDENT ? L : 1], M[STUDENT ? TRI : 1], cy[STUDENT ? L : 1], Qy[STUDENT ? TRI : 1], mm[STUDENT ? L : 1];
         if constexpr (STUDENT) {
 #pragma unroll
-            for (int i = 0; i < L; ++i) cy[i] = 0.f;
+            for (int i = 0; i < L; ++i) { Wsum[i] = 0.f; cy[i] = 0.f; mm[i] = th_lds[th_off + SvRingTab<L>::WTOT + i] - mu[i]; }
 #pragma unroll
-            for (int i = 0; i < TRI; ++i) Qy[i] = 0.f;
+            for (int i = 0; i < TRI; ++i) { M[i] = 0.f; Qy[i] = 0.f; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < LH; ++q) { Wsum2[q] = v2f{0.f, 0.f}; mu2[q] = v2f{mu[2 * q], mu[2 * q + 1]}; }
+#pragma unroll
+            for (int i = 0; i < TPR; ++i) M2[i] = v2f{0.f, 0.f};
         }
+        auto MU = [&](int i) -> float {                      // (one copy of mu~ lives across the sample loop)
+            if constexpr (STUDENT) return mu[i];
+            else return mu2[i / 2][i & 1];
+        };
         const float gts = gT * invS;
         const float nuL = nuk + (float)L;
-        float mm[STUDENT ? L : 1];                          // Student-t: m_k - mu~, so that x_s - mu~ = (x_s - m_k) + mm
-        if constexpr (STUDENT) {
-#pragma unroll
-            for (int i = 0; i < L; ++i) mm[i] = th_lds[th_off + SvRingTab<L>::WTOT + i] - mu[i];
-        }
         for (int p = 0; p < NP; ++p) {
             float* stage = ring + cur * STG;
             // The stage about to be read was requested two pairs ago.  If the pair in between was requested too, its 2*PP
@@ -243,17 +341,21 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
             else if (PP == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else if (PP == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            float xp[2 * L], gp[2 * L];
+            v2f xq[2][LH], gq[2][LH];                       // [sample of the pair][column pair]
 #pragma unroll
             for (int q = 0; q < PP; ++q) {
                 const f32x4 vx = *reinterpret_cast<const f32x4*>(stage + lane * (2 * L) + 4 * (q ^ sw));
                 const f32x4 vg = *reinterpret_cast<const f32x4*>(stage + WAVE * 2 * L + lane * (2 * L) + 4 * (q ^ sw));
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { xp[4 * q + c] = vx[c]; gp[4 * q + c] = vg[c]; }
+                // floats 4q .. 4q+3 of the cell's 2L-float pair row: sample (4q) / L, columns (4q) % L ..
+                const int h0 = (4 * q) / L, c0 = ((4 * q) % L) / 2, h1 = (4 * q + 2) / L, c1 = ((4 * q + 2) % L) / 2;
+                xq[h0][c0] = v2f{vx[0], vx[1]}; xq[h1][c1] = v2f{vx[2], vx[3]};
+                gq[h0][c0] = v2f{vg[0], vg[1]}; gq[h1][c1] = v2f{vg[2], vg[3]};
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the stage is in registers: it may be overwritten
 #pragma unroll
-            for (int i = 0; i < 2 * L; ++i) asm volatile("" : "+v"(xp[i]), "+v"(gp[i]));
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < LH; ++q) asm volatile("" : "+v"(xq[h][q]), "+v"(gq[h][q]));
             {   // re-request this stage for the pair after next (of this tile, or of this wave's next tile; NP >= 2: host)
                 const int pn = p + 2;
                 if (pn < NP) { issue(t, pn, stage); younger = true; }
@@ -271,8 +373,8 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
 #pragma unroll
                     for (int i = 0; i < L; ++i) {
                         const float mv = th_lds[mo + i];
-                        d[0][i] = (on ? xp[i] : 0.f) - mv; d[1][i] = (on ? xp[L + i] : 0.f) - mv;
-                        gx[0][i] = on ? gp[i] : 0.f; gx[1][i] = on ? gp[L + i] : 0.f;
+                        d[0][i] = xq[0][i / 2][i & 1] - mv; d[1][i] = xq[1][i / 2][i & 1] - mv;
+                        gx[0][i] = gq[0][i / 2][i & 1]; gx[1][i] = gq[1][i / 2][i & 1];
                     }
                 }
                 int wo = th_off;
@@ -328,40 +430,121 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
                     }
                 }
             } else {
+                // HH samples of the pair are processed together: the Student-t kernel reads every row of W from its LDS table and
+                // one read serves both samples (per-sample reads would keep the LDS pipe as busy as the VALU); the Gaussian kernel
+                // (W in registers) takes them one after the other (24 fewer live registers)
+                constexpr int HH = 1;
     #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    float xs[L], gx[L];
+                for (int hb = 0; hb < 2; hb += HH) {
+                    // d = x - m,  y = W d  (row i: pair products summed in two half-sums),  d/dx of the theta term of T':
+                    // (1/S) c_s W^T W d with c_s = 1 (Gaussian) or (nu+L)/(nu+delta^2) (student_t.py:31-37 differentiated)
+                    v2f d2[HH][LH], y2[HH][LH], gx2[HH][LH];
+                    if constexpr (STUDENT) {
+                        int mo = th_off + SvRingTab<L>::WTOT;
+                        asm volatile("" : "+v"(mo));                       // not hoisted out of the sample loop
     #pragma unroll
-                    for (int i = 0; i < L; ++i) { xs[i] = on ? xp[h * L + i] : 0.f; gx[i] = on ? gp[h * L + i] : 0.f; }
-                    // d/dx of the theta term of T':  (1/S) c_s W^T W (x - m),  c_s = 1 (Gaussian) or (nu+L)/(nu+delta^2)
-                    float d[L], y[L];
+                        for (int q4 = 0; q4 < (LH + 1) / 2; ++q4) {    // 16-byte reads (m is padded to whole pieces): ds_read_b128
+                            const f32x4 m4 = *reinterpret_cast<const f32x4*>(th_lds + mo + 4 * q4);
     #pragma unroll
-                    for (int i = 0; i < L; ++i) d[i] = xs[i] - mkk[i];
+                            for (int c = 0; c < 2; ++c) {
+                                const int q = 2 * q4 + c;
+                                if (q < LH) {
+                                    const v2f mq = v2f{m4[2 * c], m4[2 * c + 1]};
     #pragma unroll
-                    for (int i = 0; i < L; ++i) {
-                        float yy = 0.f;
+                                    for (int h = 0; h < HH; ++h) d2[h][q] = xq[hb + h][q] - mq;
+                                }
+                            }
+                        }
+                    } else {
     #pragma unroll
-                        for (int j = 0; j <= i; ++j) yy = fmaf(Wt[tri(i, j)], d[j], yy);
-                        y[i] = yy;
+                        for (int q = 0; q < LH; ++q)
+    #pragma unroll
+                            for (int h = 0; h < HH; ++h) d2[h][q] = xq[hb + h][q] - m2[q];
                     }
-                    const float gcs = gts;
+                    int wo = th_off;
+                    if constexpr (STUDENT) asm volatile("" : "+v"(wo));
+                    // row i of W in pairs.  Student-t: 16-byte reads from the LDS table (rows are padded to whole pieces; 8-byte reads,
+                    // which the compiler pairs into ds_read2_b64, ran into bank conflicts: SQ_LDS_BANK_CONFLICT 56 M vs 0.7 M cycles)
+                    auto load_row = [&](int i, v2f (&wr)[LH]) {
+                        if constexpr (STUDENT) {
+    #pragma unroll
+                            for (int q4 = 0; q4 < (RPn(i) + 1) / 2; ++q4) {
+                                const f32x4 w4 = *reinterpret_cast<const f32x4*>(th_lds + wo + SvRingTab<L>::roff(i) + 4 * q4);
+                                wr[2 * q4] = v2f{w4[0], w4[1]};
+                                if (2 * q4 + 1 < LH) wr[2 * q4 + 1] = v2f{w4[2], w4[3]};
+                            }
+                        } else {
+    #pragma unroll
+                            for (int q = 0; q < RPn(i); ++q) wr[q] = W2[RO(i) + q];
+                        }
+                    };
     #pragma unroll
                     for (int i = 0; i < L; ++i) {
-                        const float gy = gcs * y[i];
+                        v2f wr[LH];
+                        load_row(i, wr);
     #pragma unroll
-                        for (int j = 0; j <= i; ++j) gx[j] = fmaf(Wt[tri(i, j)], gy, gx[j]);
+                        for (int h = 0; h < HH; ++h) {
+                            v2f acc = wr[0] * d2[h][0];
+    #pragma unroll
+                            for (int q = 1; q < RPn(i); ++q) acc = __builtin_elementwise_fma(wr[q], d2[h][q], acc);
+                            y2[h][i / 2][i & 1] = acc[0] + acc[1];
+                        }
                     }
-                    solve_lower<L>(Lm, gx);                     // w_s = Lt^-1 gx_s
+    #pragma unroll
+                    for (int h = 0; h < HH; ++h) {
+                        v2f gcs2 = v2f{gts, gts};
+                        if constexpr (STUDENT) {
+                            v2f dd = y2[h][0] * y2[h][0];
+    #pragma unroll
+                            for (int q = 1; q < LH; ++q) dd = __builtin_elementwise_fma(y2[h][q], y2[h][q], dd);
+                            const float gcs = gts * nuL * __builtin_amdgcn_rcpf(nuk + (dd[0] + dd[1]));
+                            gcs2 = v2f{gcs, gcs};
+                        }
+    #pragma unroll
+                        for (int q = 0; q < LH; ++q) { y2[h][q] = y2[h][q] * gcs2; gx2[h][q] = gq[hb + h][q]; }   // y2 <- gy = c_s y / S
+                    }
+                    if constexpr (STUDENT) asm volatile("" : "+v"(wo));   // second pass: the rows are read again, not kept
     #pragma unroll
                     for (int i = 0; i < L; ++i) {
-                        Wsum[i] += gx[i];
-                        const float e = xs[i] - mu[i];          // e_s = Lt^-T eps_s
+                        v2f wr[LH];
+                        load_row(i, wr);
     #pragma unroll
-                        for (int j = 0; j <= i; ++j) M[tri(i, j)] = fmaf(e, gx[j], M[tri(i, j)]);
+                        for (int h = 0; h < HH; ++h)
+    #pragma unroll
+                            for (int q = 0; q < RPn(i); ++q) {
+                                gx2[h][q] = pk_fma_b(wr[q], y2[h][i / 2], gx2[h][q], i & 1);                       // gx += W^T gy
+                            }
+                    }
+    #pragma unroll
+                    for (int h = 0; h < HH; ++h) {
+                        // w_s = Lt^-1 gx_s: forward substitution by columns, the rows below the pivot in pairs
+    #pragma unroll
+                        for (int j = 0; j < L; ++j) {
+                            gx2[h][j / 2][j & 1] *= rd[j];
+                            if ((j & 1) == 0) {
+                                gx2[h][j / 2][1] = fmaf(-LC[CO(j)][1], gx2[h][j / 2][0], gx2[h][j / 2][1]);
+    #pragma unroll
+                                for (int q = Q0(j) + 1; q < LH; ++q) gx2[h][q] = pk_fnma_b(LC[CO(j) + q - Q0(j)], gx2[h][j / 2], gx2[h][q], 0);
+                            } else {
+    #pragma unroll
+                                for (int q = Q0(j); q < LH; ++q) gx2[h][q] = pk_fnma_b(LC[CO(j) + q - Q0(j)], gx2[h][j / 2], gx2[h][q], 1);
+                            }
+                        }
+                        v2f e2[LH];
+    #pragma unroll
+                        for (int q = 0; q < LH; ++q) { Wsum2[q] = Wsum2[q] + gx2[h][q]; e2[q] = xq[hb + h][q] - mu2[q]; }   // e_s = Lt^-T eps_s
+    #pragma unroll
+                        for (int i = 0; i < L; ++i)
+    #pragma unroll
+                            for (int q = 0; q < RPn(i); ++q) M2[RO(i) + q] = pk_fma_b(gx2[h][q], e2[i / 2], M2[RO(i) + q], i & 1);
                     }
                 }
             }
         }
+        auto MM = [&](int i, int j) -> float {               // i >= j
+            if constexpr (STUDENT) return M[tri(i, j)];
+            else return M2[RO(i) + j / 2][j & 1];
+        };
         // ---- Student-t: this cell's theta-side gradients join the wave's accumulators (rows TH..PW-1) now, so that their
         //      registers are free during the assembly below:  dL/dm = -W^T cy,  dL/dW = Qy,  dL/dkappa = -gT
         if constexpr (STUDENT) {
@@ -380,41 +563,35 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
 #pragma unroll
                 for (int j = 0; j <= i; ++j) tx[j] = fmaf(w[j], cy[i], tx[j]);
             }
+            float tvals[TH];
 #pragma unroll
-            for (int j = 0; j < L; ++j) tx[j] = comp_sum(-tx[j]);
+            for (int j = 0; j < L; ++j) tvals[j] = -tx[j];
 #pragma unroll
-            for (int i = 0; i < TRI; ++i) Qy[i] = comp_sum(Qy[i]);
-            const float gks = comp_sum(-gT);
-            if (lane < 16) {
-                constexpr int CH = 9;
+            for (int i = 0; i < L; ++i)
 #pragma unroll
-                for (int c0 = 0; c0 < TH; c0 += CH) {
-                    float oldv[CH];
-#pragma unroll
-                    for (int u = 0; u < CH; ++u)
-                        if (c0 + u < TH) oldv[u] = accw[(TH + c0 + u) * 16 + lane];
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int u = 0; u < CH; ++u) asm volatile("" : "+v"(oldv[u]));
-#pragma unroll
-                    for (int u = 0; u < CH; ++u) {
-                        const int i = c0 + u;
-                        if (i < TH) accw[(TH + i) * 16 + lane] = oldv[u] + (i < L ? tx[i < L ? i : 0] : i < L + TRI ? Qy[(i >= L && i < L + TRI) ? i - L : 0] : gks);
-                    }
-                }
-            }
+                for (int j = 0; j <= i; ++j) tvals[L + tri(i, j)] = Qy[tri(i, j)];
+            tvals[L + TRI] = -gT;
+            acc_batches(tvals, TH);
         }
         // ---- assemble dLoss/dht and dLoss/dPt (symmetric, lower triangle): as in svae_estep_bwd_kernel
         float V[L];
 #pragma unroll
-        for (int i = 0; i < L; ++i) V[i] = Wsum[i];
-        solve_lower_t<L>(Lm, V);                            // V = Pt^-1 sum_s gx_s
+        for (int i = 0; i < L; ++i) {
+            if constexpr (STUDENT) V[i] = Wsum[i];
+            else V[i] = Wsum2[i / 2][i & 1];
+        }
+#pragma unroll
+        for (int j = L - 1; j >= 0; --j) {                  // V = Pt^-1 sum_s gx_s  (back substitution, as solve_lower_t)
+            V[j] *= rd[j];
+#pragma unroll
+            for (int i = 0; i < j; ++i) V[i] = fmaf(-LM(j, i), V[j], V[i]);
+        }
         float gh[L];
 #pragma unroll
-        for (int i = 0; i < L; ++i) gh[i] = fmaf(Gc, mu[i], V[i]);
+        for (int i = 0; i < L; ++i) gh[i] = fmaf(Gc, MU(i), V[i]);
         float Cs[TRI], dg[L];
 #pragma unroll
-        for (int i = 0; i < L; ++i) dg[i] = 1.0f / Lm[tri(i, i)];
+        for (int i = 0; i < L; ++i) dg[i] = 1.0f / rd[i];
 #pragma unroll
         for (int i = 0; i < L; ++i)
 #pragma unroll
@@ -422,21 +599,21 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
                 float s2 = 0.f;
 #pragma unroll
                 for (int pq = i; pq < L; ++pq) {
-                    const float lpi = (pq == i) ? dg[i] : Lm[tri(pq, i)];
-                    s2 = fmaf(lpi, -M[tri(pq, j)], s2);
+                    const float lpi = (pq == i) ? dg[i] : LM(pq, i);
+                    s2 = fmaf(lpi, -MM(pq, j), s2);
                 }
                 Cs[tri(i, j)] = (i == j) ? (s2 + Gld) : s2;
             }
         float Y[TRI];
 #pragma unroll
         for (int j = 0; j < L; ++j) {
-            Y[tri(j, j)] = Lm[tri(j, j)];
+            Y[tri(j, j)] = rd[j];
 #pragma unroll
             for (int i = j + 1; i < L; ++i) {
                 float s2 = 0.f;
 #pragma unroll
-                for (int pq = j; pq < i; ++pq) s2 = fmaf(Lm[tri(i, pq)], Y[tri(pq, j)], s2);
-                Y[tri(i, j)] = -s2 * Lm[tri(i, i)];
+                for (int pq = j; pq < i; ++pq) s2 = fmaf(LM(i, pq), Y[tri(pq, j)], s2);
+                Y[tri(i, j)] = -s2 * rd[i];
             }
         }
         float gP[TRI];
@@ -466,11 +643,11 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
         // rank-one terms  - sym(V mu^T) - 1/2 Gc mu mu^T  =  -1/2 (tv mu^T + mu tv^T),  tv = V + 1/2 Gc mu
         float tv[L];
 #pragma unroll
-        for (int i = 0; i < L; ++i) tv[i] = -0.5f * fmaf(0.5f * Gc, mu[i], V[i]);
+        for (int i = 0; i < L; ++i) tv[i] = -0.5f * fmaf(0.5f * Gc, MU(i), V[i]);
 #pragma unroll
         for (int i = 0; i < L; ++i)
 #pragma unroll
-            for (int j = 0; j <= i; ++j) gP[tri(i, j)] = fmaf(tv[i], mu[j], fmaf(mu[i], tv[j], gP[tri(i, j)]));
+            for (int j = 0; j <= i; ++j) gP[tri(i, j)] = fmaf(tv[i], MU(j), fmaf(MU(i), tv[j], gP[tri(i, j)]));
 
         // ---- per-row sums (over the components of a data row) -> d eta of the encoder
         if constexpr (K16) {
@@ -488,11 +665,26 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
             // gathered: the lane in column 0 of DPP row dr stores tile rows dr (gather 0) and 4 + dr (gather 1)
             float s1a[L], s2a[L], s1b[L], s2b[L];
 #pragma unroll
-            for (int i = 0; i < L; ++i) {
+            for (int i = 0; i < L; ++i) {                   // all exchanges first, one wait, then the DPP sums
                 const float v1 = on ? gh[i] : 0.f, v2 = on ? gP[tri(i, i)] : 0.f;
-                s1a[i] = row16_sum(gat0(v1));
-                s2a[i] = -2.f * row16_sum(gat0(v2));
-                if (RPT > 4) { s1b[i] = row16_sum(gat1(v1)); s2b[i] = -2.f * row16_sum(gat1(v2)); }
+                s1a[i] = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga0, __float_as_uint(v1)));
+                s2a[i] = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga0, __float_as_uint(v2)));
+                if (RPT > 4) {
+                    s1b[i] = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga1, __float_as_uint(v1)));
+                    s2b[i] = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga1, __float_as_uint(v2)));
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                asm volatile("" : "+v"(s1a[i]), "+v"(s2a[i]));
+                s1a[i] = row16_sum(gv0 ? s1a[i] : 0.f);
+                s2a[i] = -2.f * row16_sum(gv0 ? s2a[i] : 0.f);           // p = -2 eta2d
+                if (RPT > 4) {
+                    asm volatile("" : "+v"(s1b[i]), "+v"(s2b[i]));
+                    s1b[i] = row16_sum(gv1 ? s1b[i] : 0.f);
+                    s2b[i] = -2.f * row16_sum(gv1 ? s2b[i] : 0.f);
+                }
             }
             const long long rowa = t * RPT + dr, rowb = rowa + 4;
             if (col == 0 && dr < RPT && rowa < a.N) {
@@ -504,31 +696,15 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
                 for (int i = 0; i < L; ++i) { a.g_eta1[rowb * L + i] = s1b[i]; a.g_eta2d[rowb * L + i] = s2b[i]; }
             }
         }
-        // ---- per-component sums: all cross-row sums first (in place), then ONE masked block that updates the LDS accumulators
-        // in batches: the reads of a batch are issued together and waited for once.  (`if (lane < 16) accw[..] += sv` per value
-        // was 45 exec-mask switches and 45 LDS read - wait - add - write round trips in a row per tile.)
+        // ---- per-component sums (acc_batches above)
+        {
+            float pvals[TH];
 #pragma unroll
-        for (int i = 0; i < L; ++i) gh[i] = comp_sum(on ? gh[i] : 0.f);
+            for (int i = 0; i < L; ++i) pvals[i] = on ? gh[i] : 0.f;
 #pragma unroll
-        for (int i = 0; i < TRI; ++i) gP[i] = comp_sum(on ? gP[i] : 0.f);
-        const float gcs2 = comp_sum(on ? Gc : 0.f);
-        if (lane < 16) {
-            constexpr int CH = 9;                                          // values per batch (TH = L + TRI + 1; 45 = 5 x 9 at L = 8)
-#pragma unroll
-            for (int c0 = 0; c0 < TH; c0 += CH) {
-                float oldv[CH];
-#pragma unroll
-                for (int u = 0; u < CH; ++u)
-                    if (c0 + u < TH) oldv[u] = accw[(c0 + u) * 16 + lane];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int u = 0; u < CH; ++u) asm volatile("" : "+v"(oldv[u]));
-#pragma unroll
-                for (int u = 0; u < CH; ++u) {
-                    const int i = c0 + u;
-                    if (i < TH) accw[i * 16 + lane] = oldv[u] + (i < L ? gh[i < L ? i : 0] : i < L + TRI ? gP[(i >= L && i < L + TRI) ? i - L : 0] : gcs2);
-                }
-            }
+            for (int i = 0; i < TRI; ++i) pvals[L + i] = on ? gP[i] : 0.f;
+            pvals[L + TRI] = on ? Gc : 0.f;
+            acc_batches(pvals, 0);
         }
     }
 
