@@ -527,7 +527,7 @@ def main():
             x_h_, r0_h_ = synth(n_rows, D, K, seed=seed)
             x_, r0_ = torch.as_tensor(x_h_).to(dev), torch.as_tensor(r0_h_).to(dev)
             if world > 1:
-                ex = PeerExchange(K, D) if args.exchange == 'peer' else None
+                ex = PeerExchange(K, D) if args.exchange == 'peer' else None      # (its constructor ends with a rendezvous of the ranks)
                 lp = DistributedVMPLoop(x_, r0_, flav, kappa=kappa, exchange=ex)
             else:
                 lp = _mix.VMPLoop(x_, r0_, flav, kappa=kappa)
@@ -535,22 +535,33 @@ def main():
 
         n_loc, n_job = rows_for(args.scaling)
         loop, x_h, r0_h, x, r0 = make_loop(n_loc, seed=rank)      # every rank: its own shard of the job's rows
+        barrier()                                                 # every rank has its data and its loop before the first exchange
         walls, kerns = time_t1(loop, args.steps, args.warmup, max(1, args.reps), barrier, dist, dev)
         dt = float(np.median(walls))
         kern_ms = float(np.median(kerns))
         assert torch.isfinite(loop.r).all()
         if world > 1:
+            loop.check()                                          # a timed-out in-kernel wait voids the line: fail, do not print it
+        if world > 1:
             # the OTHER scaling mode, same launch: fewer repetitions, same timed-region protocol
             other = 'strong' if args.scaling == 'weak' else 'weak'
+            barrier()
+            if loop.exchange is not None:
+                loop.exchange.close()                             # after the barrier: no peer is polling or pushing any more
             del loop
             torch.cuda.empty_cache()
             n2, job2 = rows_for(other)
             loop2 = make_loop(n2, seed=100 + rank)[0]
+            barrier()
             w2, k2 = time_t1(loop2, args.steps, args.warmup, 7, barrier, dist, dev)
+            loop2.check()
             d2 = float(np.median(w2))
             extra['other_scaling'] = {'scaling': other, 'rows_per_rank': n2, 'rows_job': job2, 'ms_per_step': d2 / args.steps * 1e3,
                                       'value': job2 / (d2 / args.steps), 'kernel_ms': float(np.median(k2)),
                                       'exchange': args.exchange}
+            barrier()
+            if loop2.exchange is not None:
+                loop2.exchange.close()
             del loop2
         # side measurements: single-GPU experiments (nothing after the timed region may take the JSON line down with it)
         if not args.no_extra and world == 1:
@@ -563,13 +574,13 @@ def main():
             os.environ.setdefault('MASTER_PORT', '29533')
             dist1.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
             dloop = DistributedVMPLoop(x, r0, flav, kappa=kappa)
-            dw, _ = time_t1(dloop, args.steps, args.warmup, 7, lambda: torch.cuda.synchronize(), None, dev)
+            dw, _ = time_t1(dloop, args.steps, args.warmup, max(1, args.reps), lambda: torch.cuda.synchronize(), None, dev)
             dist1.destroy_process_group()
             d_us = float(np.median(dw)) / args.steps * 1e6
             del dloop
             ex = PeerExchange(K, D, rank=0, world=1, gather=lambda h: [h])
             ploop = DistributedVMPLoop(x, r0, flav, kappa=kappa, exchange=ex)
-            pw, _ = time_t1(ploop, args.steps, args.warmup, 7, lambda: torch.cuda.synchronize(), None, dev)
+            pw, _ = time_t1(ploop, args.steps, args.warmup, max(1, args.reps), lambda: torch.cuda.synchronize(), None, dev)
             p_us = float(np.median(pw)) / args.steps * 1e6
             ex.check()
             del ploop

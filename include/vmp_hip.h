@@ -352,6 +352,18 @@ int    vmp_adam_step(int n_tensors, float* const* params, const float* const* gr
                      const int64_t* sizes, double beta1, double beta2, double eps, double lr_t, const float* lr_t_dev,
                      void* stream);
 
+/* Data-parallel training step (experiments.py:247-265; helpers/tf_utils.py:52-87 average_gradients): the tower gather
+ * becomes ONE packed fp64 buffer per rank, summed by one all-reduce (vmp_pack_allreduce / torch.distributed).
+ * vmp_pack_f64: dst = [src_0 | src_1 | ...] converted to fp64, one launch per 32 tensors (src: HOST array of device
+ *   pointers; src_is_f64[t] != 0: tensor t already holds doubles).
+ * vmp_adam_step_packed: vmp_adam_step whose gradient of tensor t is gscale * gbuf[goffsets[t] ...] (gscale = 1 / ranks:
+ *   the mean over the towers, formed in fp64 and rounded once); grads_out (nullable, or NULL entries): the averaged fp32
+ *   gradient is also stored there (what the trainer reports).                                                              */
+int    vmp_pack_f64(int n_tensors, const void* const* src, const int* src_is_f64, const int64_t* sizes, double* dst, void* stream);
+int    vmp_adam_step_packed(int n_tensors, float* const* params, const double* gbuf, const int64_t* goffsets, double gscale,
+                            float* const* grads_out, float* const* m, float* const* v, const int64_t* sizes, double beta1,
+                            double beta2, double eps, double lr_t, const float* lr_t_dev, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Stand-alone per-cell log-densities (forward only; the training step uses the fused kernels above)
  * ------------------------------------------------------------------------------------------------

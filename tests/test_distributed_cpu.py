@@ -90,6 +90,16 @@ def test_pack_unpack_roundtrip():
     assert sc.tolist() == [1.5, -2.0]
 
 
+def test_pack_exchange_buffer_host_form():
+    """host tensors (this suite has no GPU): pack_exchange_buffer falls back to the torch form and reports the gradient offsets"""
+    from vmp_for_svae_amd import training
+    st = torch.arange(12, dtype=torch.float64).reshape(3, 4)
+    gs = [torch.randn(2, 3), torch.randn(5)]
+    sc = [torch.tensor(1.5), torch.tensor(-2.0)]
+    buf, goffs = training.pack_exchange_buffer(st, gs, sc)
+    assert torch.equal(buf, training.pack_for_allreduce(st, gs, sc)) and goffs == [12, 18]
+
+
 def test_tf_adam_matches_oracle_formulation():
     from vmp_for_svae_amd.training import TFAdam, exponential_decay
     p = torch.nn.Parameter(torch.tensor([1.0, -2.0, 3.0]))

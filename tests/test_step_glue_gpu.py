@@ -83,6 +83,43 @@ def test_adam_step_kernel():
         assert ((cat(p0) - pw).abs() <= 3e-7 * (cat(p).abs() + lr_t * (mw / (vw.sqrt() + eps)).abs()) + 1e-6 * lr_t * (mw / (vw.sqrt() + eps)).abs()).all()
 
 
+def test_pack_f64_and_packed_adam_kernels():
+    """The data-parallel step's exchange (experiments.py:247-265, tf_utils.py:52-87): vmp_pack_f64 writes [moments (fp64) | all
+    gradients (fp32 -> fp64) | scalars] with one launch; vmp_adam_step_packed applies Adam with gradient = gscale * buffer slice
+    (the mean over the ranks, formed in fp64) and stores the averaged fp32 gradient.  Against torch; 40 tensors = two batches."""
+    import vmp_for_svae_amd as V
+    from vmp_for_svae_amd import training
+    L = V._lib
+    g = torch.Generator(device='cuda').manual_seed(12)
+    sizes = [1, 7, 1024, 1025, 2500, 50, 400, 3000, 12, 5000] * 4
+    stats = torch.randn(16, 74, device='cuda', generator=g, dtype=torch.float64)
+    grads = [torch.randn(n, device='cuda', generator=g) for n in sizes]
+    scal = [torch.randn((), device='cuda', generator=g, dtype=torch.float64), torch.randn((), device='cuda', generator=g),
+            torch.randn((), device='cuda', generator=g, dtype=torch.float64)]
+    buf, goffs = training.pack_exchange_buffer(stats, grads, scal)
+    want = training.pack_for_allreduce(stats, grads, scal)
+    assert buf.dtype == torch.float64 and torch.equal(buf, want)
+    assert goffs[0] == stats.numel() and goffs[1] == stats.numel() + sizes[0]
+    # two "ranks": the all-reduced buffer is the sum of two packs; Adam from it with gscale = 1/2
+    grads_b = [torch.randn(n, device='cuda', generator=g) for n in sizes]
+    buf2, _ = training.pack_exchange_buffer(stats, grads_b, scal)
+    tot = buf + buf2
+    params = [torch.nn.Parameter(torch.randn(n, device='cuda', generator=g)) for n in sizes]
+    opt_a, opt_b = training.TFAdam(params, 3e-3), None
+    ref_params = [torch.nn.Parameter(p.detach().clone()) for p in params]
+    opt_b = training.TFAdam(ref_params, 3e-3)
+    for step in range(2):
+        gout = [torch.empty_like(p) for p in params]
+        opt_a.apply_packed(tot, goffs, 0.5, gout)
+        mean = [((a.double() + b.double()) * 0.5).float() for a, b in zip(grads, grads_b)]
+        opt_b.apply_gradients(mean)
+        for go, mg in zip(gout, mean):
+            assert torch.equal(go, mg)
+        for pa, pb in zip(params, ref_params):
+            assert torch.equal(pa, pb)                      # same kernel arithmetic on the same fp32 gradient
+    assert opt_a.t == opt_b.t == 2
+
+
 @pytest.mark.parametrize('dims', [(9, 10, 10, 6, 6, 50), (33, 16, 10, 8, 8, 50), (70, 3, 4, 2, 2, 20)])
 def test_fused_elbo_fn_matches_unfused_composition(dims):
     """compute_elbo through FusedElboFn (value, details, every gradient) == the same ELBO composed from the weighted

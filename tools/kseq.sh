@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/kseq.sh <tag> <marker-kernel-substring> <script> [args...] : rocprofv3 kernel trace; prints the ordered kernel
 # sequence between the last two launches of the marker kernel (= one step of an iterative script)
-R=$GRAFT_REPO_ROOT; TAG=$1; shift; MARK=$1; shift; S=$1; shift; OUT=$R/gpurun_out/kseq_$TAG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+R=$(cd "$(dirname "$0")/.." && pwd); [ -n "$R" ] || exit 1; TAG=$1; shift; MARK=$1; shift; S=$1; shift; OUT=$R/gpurun_out/kseq_$TAG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $OUT -o k -- python3 $R/$S "$@" > $OUT/stdout.txt 2>&1
 tail -2 $OUT/stdout.txt
 python3 - <<PY

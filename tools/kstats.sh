@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/kstats.sh <tag> <script> : rocprofv3 kernel stats (true GPU durations) for our kernels
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/ks_$1; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+R=$(cd "$(dirname "$0")/.." && pwd); [ -n "$R" ] || exit 1; OUT=$R/gpurun_out/ks_$1; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o k -- python3 $R/$2 > /dev/null 2>&1
 python3 - <<PY
 import csv

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/kstats_all.sh <tag> <script> [args...] : rocprofv3 kernel stats, every kernel, sorted by total time
-R=$GRAFT_REPO_ROOT; TAG=$1; shift; S=$1; shift; OUT=$R/gpurun_out/ks_$TAG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+R=$(cd "$(dirname "$0")/.." && pwd); [ -n "$R" ] || exit 1; TAG=$1; shift; S=$1; shift; OUT=$R/gpurun_out/ks_$TAG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o k -- python3 $R/$S "$@" > $OUT/stdout.txt 2>&1
 tail -2 $OUT/stdout.txt
 python3 - <<PY

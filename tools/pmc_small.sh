@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/pmc_small.sh <outdir> : two PMC passes over the minibatch-64 training step; per-kernel means of the counters
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; T=$R/tools/t3_small_prof.py; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+R=$(cd "$(dirname "$0")/.." && pwd); [ -n "$R" ] || exit 1; OUT=$R/gpurun_out/$1; T=$R/tools/t3_small_prof.py; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $OUT -o p1 -- python3 $T 64 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d $OUT -o p2 -- python3 $T 64 > /dev/null 2>&1
 python3 - <<PY

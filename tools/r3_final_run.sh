@@ -2,7 +2,7 @@
 # Round-3 evidence run on the GPU box (everything lands in gpurun_out/, summaries are copied to profiles/ afterwards):
 #   full GPU test suite, the default bench line, rocprofv3 kernel stats of the headline command and of one T3 step,
 #   the T1 counter passes (traffic), and the t2 / t3 / smm bench workloads.
-R=$GRAFT_REPO_ROOT; cd $R
+R=$(cd "$(dirname "$0")/.." && pwd); [ -n "$R" ] || exit 1; cd $R
 python -m pytest tests -m gpu -q > gpurun_out/r03_pytest_gpu.log 2>&1; grep -a 'passed\|failed' gpurun_out/r03_pytest_gpu.log | tail -2
 python bench.py > gpurun_out/r03_bench.json 2> gpurun_out/r03_bench.err; tail -c 300 gpurun_out/r03_bench.err
 cd /tmp; export TMPDIR=/tmp

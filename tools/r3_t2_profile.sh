@@ -2,7 +2,7 @@
 # T2 backward before/after (round 3): rocprofv3 counters of the round-2 kernel (libvmp_hip_r2.so, built with -DVMP_T2_RING=0)
 # and the LDS-ring kernel, same box, separate passes (kernel-trace only), N rows from $N (default 250000).
 # Output: gpurun_out/r3_t2_pmc_{old,ring}.txt
-R=$GRAFT_REPO_ROOT
+R=$(cd "$(dirname "$0")/.." && pwd); [ -n "$R" ] || exit 1
 export REPS=2 N=${N:-250000}
 cd /tmp; export TMPDIR=/tmp
 for v in old ring; do

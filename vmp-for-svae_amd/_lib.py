@@ -1,6 +1,7 @@
 """ctypes binding of lib/libvmp_hip.so (C ABI: include/vmp_hip.h).  No fallback: if the library is
 missing or a tensor is not a contiguous fp32 GPU tensor, the call raises."""
 import ctypes
+import threading
 import os
 
 import torch
@@ -69,6 +70,8 @@ _SIGNATURES = {
     'vmp_svae_elbo_tail': (_c.c_int, [_P] * 3 + [_c.c_int64] + [_c.c_int] * 3 + [_c.c_float] + [_P] * 5 + [_c.c_size_t, _P]),
     'vmp_svae_step_scalars': (_c.c_int, [_P, _c.c_uint64, _c.c_float, _c.c_float, _P]),
     'vmp_adam_step': (_c.c_int, [_c.c_int] + [_P] * 5 + [_c.c_double] * 4 + [_P, _P]),
+    'vmp_pack_f64': (_c.c_int, [_c.c_int] + [_P] * 5),
+    'vmp_adam_step_packed': (_c.c_int, [_c.c_int, _P, _P, _P, _c.c_double] + [_P] * 4 + [_c.c_double] * 4 + [_P, _P]),
     'vmp_svae_phi_prep_fwd': (_c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _P, _P, _P, _P]),
     'vmp_svae_prep_fwd': (_c.c_int, [_P] * 8 + [_c.c_int, _c.c_int] + [_P] * 7),
     'vmp_svae_phi_prep_bwd': (_c.c_int, [_P] * 6 + [_c.c_int, _c.c_int] + [_P] * 4),
@@ -156,28 +159,47 @@ def stream():
 
 _WS = {}
 _WS_MAX = 16          # scratch buffers kept at most (least recently used beyond that are released to torch's allocator)
+_WS_LOCK = threading.Lock()     # the cache is shared by all host threads: pop / insert / evict are one critical section
 
 
 def release_workspaces(stream=None):
     """Forget the scratch buffers of `stream` (all streams if None); the memory returns to torch's caching allocator once
     the kernels queued on it have run (stream-ordered)."""
     sid = None if stream is None else stream.cuda_stream
-    for k in [k for k in _WS if sid is None or k[2] == sid]:
-        del _WS[k]
+    with _WS_LOCK:
+        for k in [k for k in _WS if sid is None or k[2] == sid]:
+            del _WS[k]
+
+
+def snapshot_workspaces():
+    with _WS_LOCK:
+        return dict(_WS)
+
+
+def take_workspaces(stream, before):
+    """Remove and return the scratch buffers of `stream` that are not in the snapshot `before` (a graph capture takes
+    ownership of the buffers its captured launches point into)."""
+    sid = stream.cuda_stream
+    with _WS_LOCK:
+        mine = {k: v for k, v in _WS.items() if k[2] == sid and (k not in before or before[k] is not v)}
+        for k in mine:
+            del _WS[k]
+    return mine
 
 
 def workspace(device, nbytes):
     """Scratch buffer owned by the host side (the library never allocates), private to the calling (device, stream,
     host thread): kernels of one stream serialise on it, calls on other streams / from other threads get their own, so
-    the C ABI's "callable concurrently from any host thread" holds through this layer as well.  A buffer that has to grow
-    is replaced; the old one is released to torch's stream-ordered caching allocator (same stream: safe)."""
-    import threading
+    the C ABI's "callable concurrently from any host thread" holds through this layer as well (the cache itself is
+    guarded by a lock).  A buffer that has to grow is replaced; the old one is released to torch's stream-ordered caching
+    allocator (same stream: safe)."""
     sid = _raw_stream(device.index) if device.type == 'cuda' else 0
     key = (device.type, device.index, sid, threading.get_ident())
-    buf = _WS.pop(key, None)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-    _WS[key] = buf                                   # (re-)inserted last: dict order = recency
-    while len(_WS) > _WS_MAX:                        # streams / threads that went away do not pin memory for ever
-        del _WS[next(iter(_WS))]
+    with _WS_LOCK:
+        buf = _WS.pop(key, None)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf                               # (re-)inserted last: dict order = recency
+        while len(_WS) > _WS_MAX:                    # streams / threads that went away do not pin memory for ever
+            del _WS[next(iter(_WS))]
     return buf

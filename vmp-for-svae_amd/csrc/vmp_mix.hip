@@ -58,7 +58,9 @@ struct PassArgs {
 // In-kernel time stamps (tools/pass_ts.py) exist only in -DVMP_DEBUG_TS builds: the shipped library has no debug
 // exports and no process-global state.
 #ifdef VMP_DEBUG_TS
-#define PASS_TS(i) do { if (a.dbg_t && (blockIdx.x == 0 || blockIdx.x == 100) && (threadIdx.x & 63) == 0) a.dbg_t[(blockIdx.x ? 64 : 0) + (threadIdx.x >> 6) * 8 + (i)] = clock64(); } while (0)
+#define PASS_TS(i) do { if (a.dbg_t && (blockIdx.x == 0 || blockIdx.x == 100) && (threadIdx.x & 63) == 0) { a.dbg_t[(blockIdx.x ? 64 : 0) + (threadIdx.x >> 6) * 8 + (i)] = clock64(); \
+    if ((i) == 0 && threadIdx.x == 0) a.dbg_t[(blockIdx.x ? 64 : 0) + 7] = wall_clock64();          /* 100 MHz, comparable ACROSS kernels: launch gaps */ \
+    if ((i) == 5 && threadIdx.x == 64) a.dbg_t[(blockIdx.x ? 64 : 0) + 8 + 7] = wall_clock64(); } } while (0)
 #else
 #define PASS_TS(i) do { } while (0)
 #endif
@@ -815,6 +817,11 @@ __global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
         for (int c = 0; c < 4; ++c) dacc[0][ft][c] = 0.0;
     }
 
+#ifdef VMP_DEBUG_TS
+    asm volatile("" :: "v"(xr[0]), "v"(pv[0]), "v"(pch.x), "v"(B1[0][0]));      // the stamp below is taken when rows, pivot and pack have ARRIVED
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    PASS_TS(1);
     for (long long row0 = lo; row0 < hi; row0 += TR) {
         const int trows = (hi - row0 < TR) ? (int)(hi - row0) : TR;
         // ---- stage this tile: lane = tile row.  fp32 image for the moment features, bf16 term image for the y GEMM
@@ -1056,7 +1063,7 @@ struct FinArgs {
 };
 
 #ifdef VMP_DEBUG_TS
-#define FIN_TS(i) do { if (a.dbg_t && blockIdx.x == 0 && tid == 0) a.dbg_t[i] = clock64(); } while (0)
+#define FIN_TS(i) do { if (a.dbg_t && blockIdx.x == 0 && tid == 0) { a.dbg_t[i] = clock64(); if ((i) == 0) a.dbg_t[6] = wall_clock64(); if ((i) == 5) a.dbg_t[7] = wall_clock64(); } } while (0)
 #else
 #define FIN_TS(i) do { } while (0)
 #endif

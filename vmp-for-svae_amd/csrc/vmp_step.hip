@@ -62,6 +62,75 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(AdamArgs a) {
     }
 }
 
+// ---- data-parallel step: one packed fp64 buffer [moments | all gradients | scalars] ------------------------------------
+// (the reference gathers per-tower gradients and averages them tensor by tensor, experiments.py:247-260 / tf_utils.py:52-87;
+//  here every rank packs once, ONE all-reduce sums the buffer, and Adam reads the averaged gradients straight from it)
+struct PackArgs {
+    const void* src[ADAM_MAX_TENSORS];
+    unsigned n[ADAM_MAX_TENSORS];
+    unsigned off[ADAM_MAX_TENSORS];         // element offset in dst
+    unsigned end_block[ADAM_MAX_TENSORS];
+    unsigned f64mask;                        // bit t: src[t] holds doubles (else floats)
+    double* dst;
+    int nt;
+};
+__global__ __launch_bounds__(ADAM_THREADS) void pack_f64_kernel(PackArgs a) {
+    int t = 0;
+    while (t < a.nt - 1 && blockIdx.x >= a.end_block[t]) ++t;
+    const unsigned first = t ? a.end_block[t - 1] : 0u;
+    const unsigned base = (blockIdx.x - first) * ADAM_CHUNK;
+    const unsigned n = a.n[t];
+    double* __restrict__ d = a.dst + a.off[t];
+    const bool f64 = (a.f64mask >> t) & 1u;
+#pragma unroll
+    for (int j = 0; j < ADAM_CHUNK / ADAM_THREADS; ++j) {
+        const unsigned i = base + j * ADAM_THREADS + threadIdx.x;
+        if (i >= n) break;
+        d[i] = f64 ? static_cast<const double*>(a.src[t])[i] : (double)static_cast<const float*>(a.src[t])[i];
+    }
+}
+
+struct AdamPackedArgs {
+    float* p[ADAM_MAX_TENSORS];
+    float* gout[ADAM_MAX_TENSORS];          // nullable: the averaged gradient is also written here (fp32)
+    float* m[ADAM_MAX_TENSORS];
+    float* v[ADAM_MAX_TENSORS];
+    unsigned n[ADAM_MAX_TENSORS];
+    unsigned off[ADAM_MAX_TENSORS];         // element offset of the tensor's gradient in gbuf
+    unsigned end_block[ADAM_MAX_TENSORS];
+    const double* gbuf;
+    const float* lr_t_dev;
+    double gscale;
+    float lr_t, b1, b2, c1, c2, eps;
+    int nt;
+};
+__global__ __launch_bounds__(ADAM_THREADS) void adam_packed_kernel(AdamPackedArgs a) {
+    int t = 0;
+    while (t < a.nt - 1 && blockIdx.x >= a.end_block[t]) ++t;
+    const unsigned first = t ? a.end_block[t - 1] : 0u;
+    const unsigned base = (blockIdx.x - first) * ADAM_CHUNK;
+    const float lr_t = a.lr_t_dev ? *a.lr_t_dev : a.lr_t;
+    const float c1 = a.c1, c2 = a.c2;
+    float* __restrict__ p = a.p[t];
+    const double* __restrict__ g = a.gbuf + a.off[t];
+    float* __restrict__ go = a.gout[t];
+    float* __restrict__ m = a.m[t];
+    float* __restrict__ v = a.v[t];
+    const unsigned n = a.n[t];
+#pragma unroll
+    for (int j = 0; j < ADAM_CHUNK / ADAM_THREADS; ++j) {
+        const unsigned i = base + j * ADAM_THREADS + threadIdx.x;
+        if (i >= n) break;
+        const float gi = (float)(g[i] * a.gscale);          // mean over the ranks in fp64, rounded once (tf_utils.py:79)
+        if (go) go[i] = gi;
+        const float mi = m[i] * a.b1 + c1 * gi;
+        const float vi = v[i] * a.b2 + c2 * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_t * (mi / (__fsqrt_rn(vi) + a.eps));
+    }
+}
+
 // [Philox key | CVI step size | Adam step size] of a graph-captured training step: the values travel in the launch packet
 // (by value), so the caller needs no staging buffer that an asynchronous copy could still be reading when it is rewritten.
 struct Words16 { unsigned long long key; float rho, lr_t; };
@@ -102,6 +171,72 @@ int vmp_svae_elbo_tail(const float* log_z, const float* T_prime, const float* ll
     hipLaunchKernelGGL(elbo_tail_kernel, dim3(blocks), dim3(TAIL_THREADS), 0, static_cast<hipStream_t>(stream), a);
     hipLaunchKernelGGL(elbo_final_kernel, dim3(1), dim3(WAVE), 0, static_cast<hipStream_t>(stream), a, blocks);
     return check_launch("vmp_svae_elbo_tail");
+}
+
+int vmp_pack_f64(int n_tensors, const void* const* src, const int* src_is_f64, const int64_t* sizes, double* dst, void* stream) {
+    if (n_tensors < 0 || (n_tensors > 0 && (!src || !src_is_f64 || !sizes || !dst))) {
+        set_error("vmp_pack_f64: bad arguments");
+        return VMP_E_BADARG;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int t = 0;
+    unsigned long long off = 0;
+    while (t < n_tensors) {
+        PackArgs a{};
+        unsigned blocks = 0;
+        int nt = 0;
+        for (; t < n_tensors && nt < ADAM_MAX_TENSORS; ++t) {
+            if (sizes[t] < 0 || off + (unsigned long long)sizes[t] >= 4294967296ULL || (sizes[t] > 0 && !src[t])) {
+                set_error("vmp_pack_f64: tensor %d: NULL pointer or size out of range", t);
+                return VMP_E_BADARG;
+            }
+            if (sizes[t] == 0) continue;
+            a.src[nt] = src[t]; a.n[nt] = (unsigned)sizes[t]; a.off[nt] = (unsigned)off;
+            if (src_is_f64[t]) a.f64mask |= 1u << nt;
+            off += (unsigned long long)sizes[t];
+            blocks += (unsigned)((sizes[t] + ADAM_CHUNK - 1) / ADAM_CHUNK);
+            a.end_block[nt] = blocks;
+            ++nt;
+        }
+        if (!nt) continue;
+        a.nt = nt; a.dst = dst;
+        hipLaunchKernelGGL(pack_f64_kernel, dim3(blocks), dim3(ADAM_THREADS), 0, s, a);
+    }
+    return check_launch("vmp_pack_f64");
+}
+
+int vmp_adam_step_packed(int n_tensors, float* const* params, const double* gbuf, const int64_t* goffsets, double gscale,
+                         float* const* grads_out, float* const* m, float* const* v, const int64_t* sizes, double beta1,
+                         double beta2, double eps, double lr_t, const float* lr_t_dev, void* stream) {
+    if (n_tensors < 0 || (n_tensors > 0 && (!params || !gbuf || !goffsets || !m || !v || !sizes))) {
+        set_error("vmp_adam_step_packed: bad arguments");
+        return VMP_E_BADARG;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int t = 0;
+    while (t < n_tensors) {
+        AdamPackedArgs a{};
+        unsigned blocks = 0;
+        int nt = 0;
+        for (; t < n_tensors && nt < ADAM_MAX_TENSORS; ++t) {
+            if (sizes[t] < 0 || sizes[t] >= 2147483648LL || goffsets[t] < 0 || goffsets[t] + sizes[t] >= 4294967296LL || !params[t] ||
+                !m[t] || !v[t]) {
+                set_error("vmp_adam_step_packed: tensor %d: NULL pointer or size / offset out of range", t);
+                return VMP_E_BADARG;
+            }
+            if (sizes[t] == 0) continue;
+            a.p[nt] = params[t]; a.gout[nt] = grads_out ? grads_out[t] : nullptr; a.m[nt] = m[t]; a.v[nt] = v[t];
+            a.n[nt] = (unsigned)sizes[t]; a.off[nt] = (unsigned)goffsets[t];
+            blocks += (unsigned)((sizes[t] + ADAM_CHUNK - 1) / ADAM_CHUNK);
+            a.end_block[nt] = blocks;
+            ++nt;
+        }
+        if (!nt) continue;
+        a.nt = nt; a.gbuf = gbuf; a.gscale = gscale; a.lr_t_dev = lr_t_dev; a.lr_t = (float)lr_t; a.b1 = (float)beta1;
+        a.b2 = (float)beta2; a.c1 = (float)(1.0 - beta1); a.c2 = (float)(1.0 - beta2); a.eps = (float)eps;
+        hipLaunchKernelGGL(adam_packed_kernel, dim3(blocks), dim3(ADAM_THREADS), 0, s, a);
+    }
+    return check_launch("vmp_adam_step_packed");
 }
 
 int vmp_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* m, float* const* v,

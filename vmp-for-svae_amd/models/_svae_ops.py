@@ -1,5 +1,7 @@
 """torch.autograd wrappers of the T2 / reconstruction HIP kernels (C ABI: include/vmp_hip.h).
 No CPU fallback: tensors must be contiguous fp32 GPU tensors."""
+import threading
+
 import torch
 
 from .. import _lib as L
@@ -12,7 +14,8 @@ def _c(t, name, shape=None):
 class GradSeed(object):
     """The upstream gradient a caller will differentiate the ELBO with, announced beforehand: `tensor` (0-dim, on the
     device) is what it passes as grad_outputs, `value` its content.  FusedElboFn folds the factor into its one backward
-    launch and recognises the tensor by address - no rescaling pass, no host read-back (graph capture)."""
+    launch and recognises the tensor by address - no rescaling pass, no host read-back (graph capture).  The tensor must not
+    be written to after it has been announced (FusedElboFn checks its version counter and falls back to rescaling)."""
 
     def __init__(self, value, device):
         self.value = float(value)
@@ -408,14 +411,21 @@ class DecoderWeightedLoglikeFn(torch.autograd.Function):
 
 
 _TAIL_WS = {}
+_TAIL_WS_MAX = 16
+_TAIL_LOCK = threading.Lock()
 
 
 def _tail_workspace(device):
-    """Scratch of vmp_svae_elbo_tail / vmp_decoder_elbo (per-block partial sums), one per device and stream."""
-    key = (device.index, L._raw_stream(device.index))
-    ws = _TAIL_WS.get(key)
-    if ws is None:
-        ws = _TAIL_WS[key] = torch.empty(L.lib().vmp_svae_elbo_tail_workspace_bytes(), dtype=torch.uint8, device=device)
+    """Scratch of vmp_svae_elbo_tail / vmp_decoder_elbo (per-block partial sums), one per device, stream and host thread;
+    least recently used entries beyond _TAIL_WS_MAX are dropped (streams that went away do not pin memory)."""
+    key = (device.index, L._raw_stream(device.index), threading.get_ident())
+    with _TAIL_LOCK:
+        ws = _TAIL_WS.pop(key, None)
+        if ws is None:
+            ws = torch.empty(L.lib().vmp_svae_elbo_tail_workspace_bytes(), dtype=torch.uint8, device=device)
+        _TAIL_WS[key] = ws
+        while len(_TAIL_WS) > _TAIL_WS_MAX:
+            del _TAIL_WS[next(iter(_TAIL_WS))]
     return ws
 
 
@@ -423,7 +433,8 @@ def release_tail_workspaces(stream):
     """Forget (and return) the tail scratch of `stream`: a graph capture takes ownership of the buffer its captured launch
     points into; a temporary warm-up stream's buffer is simply dropped."""
     sid = stream.cuda_stream
-    return [_TAIL_WS.pop(k) for k in [k for k in _TAIL_WS if k[1] == sid]]
+    with _TAIL_LOCK:
+        return [_TAIL_WS.pop(k) for k in [k for k in _TAIL_WS if k[1] == sid]]
 
 
 class FusedElboFn(torch.autograd.Function):
@@ -470,6 +481,7 @@ class FusedElboFn(torch.autograd.Function):
         ctx.save_for_backward(dx, dp, g_lz, g_Tp)
         ctx.pshapes = [tuple(p.shape) for p in params]
         ctx.seed, ctx.sigma = seed, sigma
+        ctx.seed_version = None if seed is None else seed._version      # the announced tensor must not be written to afterwards
         elbo, rec, reg = scal[0], scal[1], scal[2]
         ctx.mark_non_differentiable(rec, reg, r)
         ctx.set_materialize_grads(False)        # no zero-filled gradients for the three reporting outputs
@@ -480,7 +492,10 @@ class FusedElboFn(torch.autograd.Function):
         dx, dp, g_lz, g_Tp = ctx.saved_tensors
         if g is None:
             return (None,) * (6 + len(ctx.pshapes))
-        if not (ctx.seed is not None and g.data_ptr() == ctx.seed.data_ptr()):
+        # recognised = the very tensor that was announced (same storage) AND untouched since (an in-place rescale or sign flip of
+        # the announced tensor bumps its version counter: its content is then no longer the sigma folded into the gradients)
+        same = ctx.seed is not None and g.data_ptr() == ctx.seed.data_ptr() and ctx.seed._version == ctx.seed_version
+        if not same:
             # the stored gradients are sigma * d elbo and the caller differentiates with another upstream tensor: rescale
             # (dx is (N,K,S,L)-sized - outside a graph capture one scalar read-back decides whether that pass is needed)
             if torch.cuda.is_current_stream_capturing():

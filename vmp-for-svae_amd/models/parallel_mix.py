@@ -102,6 +102,18 @@ class PeerExchange(object):
         self.table = (ctypes.c_void_p * self.world)(*[p.value for p in self._peers])
         self.iteration = 0
         self.status = torch.zeros(1, dtype=torch.int32, device='cuda')
+        # nobody may publish into a buffer a peer has not mapped yet, and the in-kernel wait is bounded (~4 s): without this
+        # rendezvous a start skew between the ranks (data generation, uploads) could time a rank out before its peers arrive,
+        # after which the sequence words never match again
+        torch.cuda.synchronize()
+        if gather is None and self.world > 1:
+            dist.barrier(group)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def check(self):
         """Raise if a wait of an in-kernel exchange timed out (a peer never published: the iterations since are invalid).
@@ -111,11 +123,13 @@ class PeerExchange(object):
                              '(iteration %d, rank %d of %d)' % (self.iteration, self.rank, self.world))
 
     def close(self):
-        for g, pp in enumerate(self._peers):
+        """Unmap the peers' buffers and free this rank's (idempotent).  With several ranks call it after a barrier: a peer
+        may still be polling or pushing."""
+        peers, self._peers = getattr(self, '_peers', []), []
+        for g, pp in enumerate(peers):
             if g != self.rank:
                 L.lib().vmp_exch_close(pp)
-        self._peers = []
-        if self._buf is not None:
+        if getattr(self, '_buf', None) is not None:
             L.lib().vmp_exch_free(self._buf)
             self._buf = None
 
@@ -159,3 +173,20 @@ class DistributedVMPLoop(_mix.VMPLoop):
                                          L.ptr(p['pack']), L.stream()), 'vmp_mix_finalize')
         if stats_out is not None:
             stats_out.copy_(self._stats)
+
+    def check(self):
+        """Raise if an in-kernel wait of the peer exchange timed out (reads one device word: a host synchronisation)."""
+        if self.exchange is not None:
+            self.exchange.check()
+
+    def theta(self):
+        self.check()                                      # the caller is about to read the posterior: a rank that timed out must not pass
+        return super().theta()
+
+    def run(self, iterations):
+        """`iterations` data-parallel VMP iterations (the base class enqueues the SINGLE-process iteration through one C call;
+        here every iteration has its exchange)."""
+        for _ in range(int(iterations)):
+            self.step()
+        self.check()
+        return self.r

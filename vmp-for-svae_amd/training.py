@@ -47,6 +47,32 @@ class TFAdam(object):
         return self.lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
 
     @torch.no_grad()
+    def apply_packed(self, gbuf, goffsets, gscale, grads_out, lr_t_dev=None):
+        """Adam step whose gradient of tensor i is gscale * gbuf[goffsets[i]:...] (the all-reduced fp64 exchange buffer of the
+        data-parallel step, gscale = 1 / ranks); the averaged fp32 gradients are also written to grads_out.  One launch."""
+        import ctypes
+        if not (self._fused_ok() and gbuf.is_cuda):
+            gs = [(gbuf[o:o + p.numel()] * gscale).to(p.dtype).reshape(p.shape) for o, p in zip(goffsets, self.params)]
+            for go, g in zip(grads_out, gs):
+                go.copy_(g)
+            return self.apply_gradients(gs, lr_t_dev=lr_t_dev)
+        n = len(self.params)
+        arr = ctypes.c_void_p * n
+        if lr_t_dev is None:
+            self.t += 1
+            lr_t, lr_p = self.lr_t(self.t), None
+        else:
+            lr_t, lr_p = 0.0, L.ptr(lr_t_dev)
+        L.check(L.lib().vmp_adam_step_packed(n, arr(*[p.data_ptr() for p in self.params]), L.ptr(gbuf),
+                                             (ctypes.c_int64 * n)(*goffsets), float(gscale),
+                                             arr(*[g.data_ptr() for g in grads_out]), arr(*[m.data_ptr() for m in self.m]),
+                                             arr(*[v.data_ptr() for v in self.v]),
+                                             (ctypes.c_int64 * n)(*[p.numel() for p in self.params]), self.b1, self.b2, self.eps,
+                                             lr_t, lr_p, L.stream()), 'vmp_adam_step_packed')
+        for p in self.params:
+            torch.autograd.graph.increment_version(p)
+
+    @torch.no_grad()
     def apply_gradients(self, grads, lr_t_dev=None):
         """lr_t_dev: the bias-corrected step size as a 0-dim device tensor (graph-captured steps: the caller advances
         self.t and refreshes the tensor before every replay); default: computed here from the step count."""
@@ -84,6 +110,29 @@ class TFAdam(object):
             upd = torch._foreach_div(self.m, denom)
             torch._foreach_mul_(upd, lr_t_dev)
             torch._foreach_sub_(data, upd)
+
+
+def pack_exchange_buffer(stats, grads, scalars):
+    """[stats (fp64) | grads (flattened, fp64) | scalars] -> one contiguous fp64 buffer with ONE launch (vmp_pack_f64, pointer
+    table in the launch packet) instead of a torch.cat over ~25 .double() copies.  Returns (buffer, gradient offsets).
+    Replaces the tower gather of experiments.py:247-260."""
+    import ctypes
+    ts = [stats.reshape(-1)] + [g.reshape(-1) for g in grads] + [s.reshape(-1) for s in scalars]
+    ok = all(t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.float64) for t in ts)
+    sizes = [t.numel() for t in ts]
+    offs, o = [], 0
+    for n_ in sizes:
+        offs.append(o)
+        o += n_
+    goffs = offs[1:1 + len(grads)]
+    if not ok:                                                # host tensors (gloo tests on CPU): the torch form
+        return torch.cat([t.double() for t in ts]), goffs
+    buf = torch.empty(o, dtype=torch.float64, device=stats.device)
+    n = len(ts)
+    L.check(L.lib().vmp_pack_f64(n, (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts]),
+                                 (ctypes.c_int * n)(*[int(t.dtype == torch.float64) for t in ts]),
+                                 (ctypes.c_int64 * n)(*sizes), L.ptr(buf), L.stream()), 'vmp_pack_f64')
+    return buf, goffs
 
 
 def pack_for_allreduce(stats, grads, scalars):
@@ -246,13 +295,18 @@ class SVAETrainer(object):
                 keep = dict(log_z=log_z.detach(), x_samples=x_s.detach(), x_k=x_k.detach())
                 r_whole = r_nk
             del elbo, details, x_k, x_s, log_z
+        packed = None
         if world > 1:
-            buf = pack_for_allreduce(stats, grads, [elbo_t, rec_t, reg_t])
+            # ONE pack launch, ONE all-reduce, and (below) ONE Adam launch that reads the averaged gradients from the buffer:
+            # the exchange adds three launches to the step (it was a torch.cat over ~25 fp64 copies, ~25 slices and 21 divisions)
+            grads = [g.contiguous() for g in grads]
+            buf, goffs = pack_exchange_buffer(stats, grads, [elbo_t, rec_t, reg_t])
             from .models.parallel_mix import allreduce_sum_
             allreduce_sum_(buf, self.group)
-            stats, g64, sc = unpack_after_allreduce(buf, tuple(stats.shape), [tuple(g.shape) for g in grads], 3)
-            grads = [(g / world).to(torch.float32) for g in g64]                    # average_gradients (tf_utils.py:79)
-            elbo_t, rec_t, reg_t = sc[0], sc[1], sc[2]
+            ns = stats.numel()
+            stats = buf[:ns].reshape(stats.shape)
+            elbo_t, rec_t, reg_t = buf[-3], buf[-2], buf[-1]
+            packed = (buf, goffs, 1.0 / world)                                      # average_gradients (tf_utils.py:79)
         lrcvi = exponential_decay(self.lrcvi0, self.global_step, 1000, self.decay_rate)
         if self.opt is None:
             self.opt = TFAdam(params, self.lr)
@@ -273,7 +327,12 @@ class SVAETrainer(object):
                                                     step_size_dev=_dev_scalars[0])
         else:                                                                       # experiments.py:258-260
             theta_star = svae.cvi_update_from_stats(self.gmm_prior, self.theta, stats.double(), lrcvi)
-        if _dev_scalars is not None:
+        if packed is not None:
+            grads = [g if g.dtype == torch.float32 else g.float() for g in grads]   # receive the averaged gradients (reported)
+            self.opt.apply_packed(packed[0], packed[1], packed[2], grads, lr_t_dev=None if _dev_scalars is None else _dev_scalars[1])
+            if _dev_scalars is None:
+                self.global_step += 1
+        elif _dev_scalars is not None:
             self.opt.apply_gradients(grads, lr_t_dev=_dev_scalars[1])
         else:
             self.opt.apply_gradients(grads)                                         # experiments.py:264-265
@@ -331,7 +390,7 @@ class GraphedSVAEStep(object):
                     m=[m.clone() for m in tr.opt.m] if had_opt else None,
                     v=[v.clone() for v in tr.opt.v] if had_opt else None,
                     gen=self.gen.get_state())
-        ws_before = dict(L._WS)
+        ws_before = L.snapshot_workspaces()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -358,10 +417,8 @@ class GraphedSVAEStep(object):
         self.gen.set_state(snap['gen'])     # the capture-time refresh drew nothing that a replay uses
         # the captured kernels hold raw pointers into the scratch buffers in use during the capture: keep exactly those
         # alive with the graph, and drop the warm-up side stream's buffers (never used again)
-        self._ws_refs = {k: v for k, v in L._WS.items() if k not in ws_before or L._WS[k] is not ws_before[k]}
-        for k in self._ws_refs:                   # graph-pool memory: owned by this graph alone from here on
-            L._WS.pop(k, None)
-        L.release_workspaces(side)
+        L.release_workspaces(side)                # first: the side stream's scratch must not end up among the graph's references
+        self._ws_refs = L.take_workspaces(cap_stream, ws_before)    # graph-pool memory: owned by this graph alone from here on
         _svae_ops.release_tail_workspaces(side)
         self._tail_refs = _svae_ops.release_tail_workspaces(cap_stream)    # graph-pool memory the captured tail launch points into
 
