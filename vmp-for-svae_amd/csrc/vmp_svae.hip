@@ -928,7 +928,12 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
         const bool on = lane_on && row < a.N;
         const long long rows_here = (a.N - t * RPT) < RPT ? (a.N - t * RPT) : RPT;
         const int tot = (int)rows_here * K * LSn;
-        const bool full = a.vec_ok && (L & 3) == 0 && CT == WAVE && rows_here == RPT;
+        // full = every one of the tile's CT cells is valid: the samples leave through the LDS image as coalesced float4 stores of
+        // the tile's CT * L * S contiguous floats.  (Round 4: also for K that does not divide 64 - CT = (64 / K) K < 64 cells - whose
+        // lanes used to store their own rows straight from registers: 16 bytes per lane at a 4 L S byte stride, four partial
+        // writes per 64-byte segment.)
+        const bool full = a.vec_ok && (L & 3) == 0 && rows_here == RPT;
+        const int nf4 = CT * Q;                             // float4s of a full tile
 
         // ---- cell factorisation
         float Lm[TRI], av[L];
@@ -1103,13 +1108,13 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
 #pragma unroll
                         for (int u = 0; u < CB; ++u) {
                             if (it0 + u < Qc) {
-                                const float* src = et + co_off[it0 + u];
+                                const float* src = et + ((it0 + u) * WAVE + lane < nf4 ? co_off[it0 + u] : 0);
                                 v[u].x = src[0]; v[u].y = src[S]; v[u].z = src[2 * S]; v[u].w = src[3 * S];
                             }
                         }
 #pragma unroll
                         for (int u = 0; u < CB; ++u)
-                            if (it0 + u < Qc) g4[(it0 + u) * WAVE] = v[u];
+                            if (it0 + u < Qc && (it0 + u) * WAVE + lane < nf4) g4[(it0 + u) * WAVE] = v[u];
                     }
                 } else {
                     int c2 = o_first, rem = orem_first;
@@ -1119,7 +1124,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
                         for (int u = 0; u < CB; ++u) {
                             if (it0 + u < Q) {
                                 const int s = rem / L4, l4 = rem - s * L4;
-                                const float* src = et + c2 * CS + (4 * l4) * S + s;
+                                const float* src = et + (c2 < CT ? c2 : 0) * CS + (4 * l4) * S + s;
                                 v[u].x = src[0]; v[u].y = src[S]; v[u].z = src[2 * S]; v[u].w = src[3 * S];
                                 c2 += dco; rem += dro;
                                 if (rem >= Q) { rem -= Q; c2 += 1; }
@@ -1127,7 +1132,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
                         }
 #pragma unroll
                         for (int u = 0; u < CB; ++u)
-                            if (it0 + u < Q) g4[(it0 + u) * WAVE] = v[u];
+                            if (it0 + u < Q && (it0 + u) * WAVE + lane < nf4) g4[(it0 + u) * WAVE] = v[u];
                     }
                 }
             }
