@@ -430,114 +430,48 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
                     }
                 }
             } else {
-                // HH samples of the pair are processed together: the Student-t kernel reads every row of W from its LDS table and
-                // one read serves both samples (per-sample reads would keep the LDS pipe as busy as the VALU); the Gaussian kernel
-                // (W in registers) takes them one after the other (24 fewer live registers)
-                constexpr int HH = 1;
-    #pragma unroll
-                for (int hb = 0; hb < 2; hb += HH) {
-                    // d = x - m,  y = W d  (row i: pair products summed in two half-sums),  d/dx of the theta term of T':
-                    // (1/S) c_s W^T W d with c_s = 1 (Gaussian) or (nu+L)/(nu+delta^2) (student_t.py:31-37 differentiated)
-                    v2f d2[HH][LH], y2[HH][LH], gx2[HH][LH];
-                    if constexpr (STUDENT) {
-                        int mo = th_off + SvRingTab<L>::WTOT;
-                        asm volatile("" : "+v"(mo));                       // not hoisted out of the sample loop
-    #pragma unroll
-                        for (int q4 = 0; q4 < (LH + 1) / 2; ++q4) {    // 16-byte reads (m is padded to whole pieces): ds_read_b128
-                            const f32x4 m4 = *reinterpret_cast<const f32x4*>(th_lds + mo + 4 * q4);
-    #pragma unroll
-                            for (int c = 0; c < 2; ++c) {
-                                const int q = 2 * q4 + c;
-                                if (q < LH) {
-                                    const v2f mq = v2f{m4[2 * c], m4[2 * c + 1]};
-    #pragma unroll
-                                    for (int h = 0; h < HH; ++h) d2[h][q] = xq[hb + h][q] - mq;
-                                }
-                            }
-                        }
-                    } else {
-    #pragma unroll
-                        for (int q = 0; q < LH; ++q)
-    #pragma unroll
-                            for (int h = 0; h < HH; ++h) d2[h][q] = xq[hb + h][q] - m2[q];
+                // Gaussian theta, packed (see the layouts above); the two samples of the pair one after the other
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    // d = x - m,  y = W d  (row i: pair products summed in two half-sums),  gy = y gT / S,  gx += W^T gy:
+                    // d/dx of the theta term of T' (1/S) W^T W d
+                    v2f d2[LH], y2[LH], gx2[LH];
+#pragma unroll
+                    for (int q = 0; q < LH; ++q) d2[q] = xq[h][q] - m2[q];
+#pragma unroll
+                    for (int i = 0; i < L; ++i) {
+                        v2f acc = W2[RO(i)] * d2[0];
+#pragma unroll
+                        for (int q = 1; q < RPn(i); ++q) acc = __builtin_elementwise_fma(W2[RO(i) + q], d2[q], acc);
+                        y2[i / 2][i & 1] = acc[0] + acc[1];
                     }
-                    int wo = th_off;
-                    if constexpr (STUDENT) asm volatile("" : "+v"(wo));
-                    // row i of W in pairs.  Student-t: 16-byte reads from the LDS table (rows are padded to whole pieces; 8-byte reads,
-                    // which the compiler pairs into ds_read2_b64, ran into bank conflicts: SQ_LDS_BANK_CONFLICT 56 M vs 0.7 M cycles)
-                    auto load_row = [&](int i, v2f (&wr)[LH]) {
-                        if constexpr (STUDENT) {
-    #pragma unroll
-                            for (int q4 = 0; q4 < (RPn(i) + 1) / 2; ++q4) {
-                                const f32x4 w4 = *reinterpret_cast<const f32x4*>(th_lds + wo + SvRingTab<L>::roff(i) + 4 * q4);
-                                wr[2 * q4] = v2f{w4[0], w4[1]};
-                                if (2 * q4 + 1 < LH) wr[2 * q4 + 1] = v2f{w4[2], w4[3]};
-                            }
+                    const v2f gts2 = v2f{gts, gts};
+#pragma unroll
+                    for (int q = 0; q < LH; ++q) { y2[q] = y2[q] * gts2; gx2[q] = gq[h][q]; }
+#pragma unroll
+                    for (int i = 0; i < L; ++i)
+#pragma unroll
+                        for (int q = 0; q < RPn(i); ++q) gx2[q] = pk_fma_b(W2[RO(i) + q], y2[i / 2], gx2[q], i & 1);
+                    // w_s = Lt^-1 gx_s: forward substitution by columns, the rows below the pivot in pairs
+#pragma unroll
+                    for (int j = 0; j < L; ++j) {
+                        gx2[j / 2][j & 1] *= rd[j];
+                        if ((j & 1) == 0) {
+                            gx2[j / 2][1] = fmaf(-LC[CO(j)][1], gx2[j / 2][0], gx2[j / 2][1]);
+#pragma unroll
+                            for (int q = Q0(j) + 1; q < LH; ++q) gx2[q] = pk_fnma_b(LC[CO(j) + q - Q0(j)], gx2[j / 2], gx2[q], 0);
                         } else {
-    #pragma unroll
-                            for (int q = 0; q < RPn(i); ++q) wr[q] = W2[RO(i) + q];
-                        }
-                    };
-    #pragma unroll
-                    for (int i = 0; i < L; ++i) {
-                        v2f wr[LH];
-                        load_row(i, wr);
-    #pragma unroll
-                        for (int h = 0; h < HH; ++h) {
-                            v2f acc = wr[0] * d2[h][0];
-    #pragma unroll
-                            for (int q = 1; q < RPn(i); ++q) acc = __builtin_elementwise_fma(wr[q], d2[h][q], acc);
-                            y2[h][i / 2][i & 1] = acc[0] + acc[1];
+#pragma unroll
+                            for (int q = Q0(j); q < LH; ++q) gx2[q] = pk_fnma_b(LC[CO(j) + q - Q0(j)], gx2[j / 2], gx2[q], 1);
                         }
                     }
-    #pragma unroll
-                    for (int h = 0; h < HH; ++h) {
-                        v2f gcs2 = v2f{gts, gts};
-                        if constexpr (STUDENT) {
-                            v2f dd = y2[h][0] * y2[h][0];
-    #pragma unroll
-                            for (int q = 1; q < LH; ++q) dd = __builtin_elementwise_fma(y2[h][q], y2[h][q], dd);
-                            const float gcs = gts * nuL * __builtin_amdgcn_rcpf(nuk + (dd[0] + dd[1]));
-                            gcs2 = v2f{gcs, gcs};
-                        }
-    #pragma unroll
-                        for (int q = 0; q < LH; ++q) { y2[h][q] = y2[h][q] * gcs2; gx2[h][q] = gq[hb + h][q]; }   // y2 <- gy = c_s y / S
-                    }
-                    if constexpr (STUDENT) asm volatile("" : "+v"(wo));   // second pass: the rows are read again, not kept
-    #pragma unroll
-                    for (int i = 0; i < L; ++i) {
-                        v2f wr[LH];
-                        load_row(i, wr);
-    #pragma unroll
-                        for (int h = 0; h < HH; ++h)
-    #pragma unroll
-                            for (int q = 0; q < RPn(i); ++q) {
-                                gx2[h][q] = pk_fma_b(wr[q], y2[h][i / 2], gx2[h][q], i & 1);                       // gx += W^T gy
-                            }
-                    }
-    #pragma unroll
-                    for (int h = 0; h < HH; ++h) {
-                        // w_s = Lt^-1 gx_s: forward substitution by columns, the rows below the pivot in pairs
-    #pragma unroll
-                        for (int j = 0; j < L; ++j) {
-                            gx2[h][j / 2][j & 1] *= rd[j];
-                            if ((j & 1) == 0) {
-                                gx2[h][j / 2][1] = fmaf(-LC[CO(j)][1], gx2[h][j / 2][0], gx2[h][j / 2][1]);
-    #pragma unroll
-                                for (int q = Q0(j) + 1; q < LH; ++q) gx2[h][q] = pk_fnma_b(LC[CO(j) + q - Q0(j)], gx2[h][j / 2], gx2[h][q], 0);
-                            } else {
-    #pragma unroll
-                                for (int q = Q0(j); q < LH; ++q) gx2[h][q] = pk_fnma_b(LC[CO(j) + q - Q0(j)], gx2[h][j / 2], gx2[h][q], 1);
-                            }
-                        }
-                        v2f e2[LH];
-    #pragma unroll
-                        for (int q = 0; q < LH; ++q) { Wsum2[q] = Wsum2[q] + gx2[h][q]; e2[q] = xq[hb + h][q] - mu2[q]; }   // e_s = Lt^-T eps_s
-    #pragma unroll
-                        for (int i = 0; i < L; ++i)
-    #pragma unroll
-                            for (int q = 0; q < RPn(i); ++q) M2[RO(i) + q] = pk_fma_b(gx2[h][q], e2[i / 2], M2[RO(i) + q], i & 1);
-                    }
+                    v2f e2[LH];
+#pragma unroll
+                    for (int q = 0; q < LH; ++q) { Wsum2[q] = Wsum2[q] + gx2[q]; e2[q] = xq[h][q] - mu2[q]; }   // e_s = Lt^-T eps_s
+#pragma unroll
+                    for (int i = 0; i < L; ++i)
+#pragma unroll
+                        for (int q = 0; q < RPn(i); ++q) M2[RO(i) + q] = pk_fma_b(gx2[q], e2[i / 2], M2[RO(i) + q], i & 1);
                 }
             }
         }
