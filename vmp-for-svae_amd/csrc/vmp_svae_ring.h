@@ -670,6 +670,9 @@ int launch(const EBwdArgs& a, int nblk_abi, void* stream) {
     const int per_wave = 2 * svr_stage_floats<L>() + PWa * 16;
     int nw = (int)((160 * 1024 / sizeof(float) - tab) / per_wave);
     if (nw > SVR_NW) nw = SVR_NW;
+#ifdef VMP_RING_MAXW
+    if (nw > VMP_RING_MAXW) nw = VMP_RING_MAXW;            // A/B builds: fewer waves per CU
+#endif
     if (nw < 4) return -2;
     const long long ntiles = (a.N + RPT - 1) / RPT;
     long long bl = (ntiles + nw - 1) / nw;
