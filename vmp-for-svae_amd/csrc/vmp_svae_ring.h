@@ -23,6 +23,7 @@
 //            (4g + dr) * K + col, or 0 - after which the very same DPP / permlane reductions apply; two gathers cover
 //            8 rows.  ds_bpermute uses the LDS crossbar but no LDS memory (~130 per tile; the K = 16 kernel ran 90 of them per
 //            tile before round 3's permlane form and lost < 1 % to them).
+// Row sums (d eta of the encoder): a reduce-scatter over the 16 lanes of a data row leaves value c in lane c; one store per tile.
 // Student-t theta (round 4; BASELINE configs[4]): the theta term of T' is (nu+L)/2 log1p(delta^2/nu), so the sample loop
 // scales W^T W (x - m) by c_s = (nu+L)/(nu+delta_s^2), and theta/mu_k, theta/L_k are trainable: per cell
 //   cy = sum_s g_s y_s,  Qy = sum_s g_s y_s d_s^T (lower),  g_s = gT c_s / S,  d = x - m,  y = W d
@@ -48,8 +49,46 @@ struct SvRingTab {
     static constexpr int TST = ((RAW / 4) & 1) ? RAW : RAW + 4;      // odd number of 16-byte pieces
 };
 
-template <int L, bool K16, bool STUDENT>
-__global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwdArgs a, int nblk_abi) {
+// Sixteen values per lane, summed over the 16 lanes of every DPP row: on return lane c of the row holds the total of value c
+// (v[0]).  Recursive halving with the lane pairings xor 8 (row_ror:8), xor 7 (row_half_mirror), xor 2 and xor 1 (quad_perm): at
+// every stage a lane keeps the half of its values whose index bit matches its own lane bit and adds its partner's partial sums of
+// that half - 15 exchanges instead of 16 all-reduces of 4 rotations each, and the result is already spread one value per lane,
+// which is what ONE coalesced store of the row sums needs.
+__device__ __forceinline__ float row16_reduce_scatter(float (&v)[16], int c) {
+#define VMP_RS(N, BIT, CTRL)                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < N; ++j) {                                                                      \
+        const bool up = (c & BIT) != 0;                                                                                  \
+        const float keep = up ? v[j + N] : v[j], send = up ? v[j] : v[j + N];                                            \
+        v[j] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xf, 0xf, true));        \
+    }
+    VMP_RS(8, 8, 0x128) VMP_RS(4, 4, 0x141) VMP_RS(2, 2, 0x4E) VMP_RS(1, 1, 0xB1)
+#undef VMP_RS
+    return v[0];
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the counter takes an immediate): exact for n <= 40, else drains
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define VMP_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    switch (n) {
+        VMP_W(1) VMP_W(2) VMP_W(3) VMP_W(4) VMP_W(5) VMP_W(6) VMP_W(7) VMP_W(8) VMP_W(9) VMP_W(10) VMP_W(11) VMP_W(12) VMP_W(13)
+        VMP_W(14) VMP_W(15) VMP_W(16) VMP_W(17) VMP_W(18) VMP_W(19) VMP_W(20) VMP_W(21) VMP_W(22) VMP_W(23) VMP_W(24) VMP_W(25)
+        VMP_W(26) VMP_W(27) VMP_W(28) VMP_W(29) VMP_W(30) VMP_W(31) VMP_W(32) VMP_W(33) VMP_W(34) VMP_W(35) VMP_W(36) VMP_W(37)
+        VMP_W(38) VMP_W(39) VMP_W(40)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef VMP_W
+}
+
+// NSTG = 2: eight waves per CU (two per SIMD), two stages per wave (rounds 3 / 4).
+// NSTG = 4: FOUR waves per CU - one per SIMD, 512 registers - and four stages per wave: the same 128 KB per CU in flight,
+//           requested four pairs ahead; no form is register-starved (the Student-t theta keeps W and all its sums in registers and
+//           runs the packed sample loop), and every memory operation inside the tile loop sits on a COUNTED wait: the tile's small
+//           inputs come by DMA one tile ahead, the row sums leave with one store per tile (see below).
+template <int L, bool K16, bool STUDENT, int NSTG>
+__global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bwd_ring_kernel(EBwdArgs a, int nblk_abi) {
+    constexpr bool SP = STUDENT && NSTG == 4;                // Student-t, parameters in registers, packed sample loop
+    constexpr bool ST = STUDENT && NSTG == 2;                // Student-t, parameters in an LDS table, scalar sample loop
+    constexpr bool PF = NSTG == 4;                           // small inputs of a tile prefetched by DMA
     constexpr int TRI = SvGeo<L>::TRI;
     constexpr int PW = 2 * (L + TRI + 1);
     constexpr int TH = L + TRI + 1;                          // phi-side sums; theta-side sums (Student-t) follow at TH
@@ -66,12 +105,14 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
     // Student-t: the theta parameters of a component live in an LDS table instead of 52 VGPRs per lane (with the 44 theta-side
     // sums of the cell the L = 8 sample loop spilled): [W rows, each padded to whole 16-byte pieces | m | h], stride = odd
     // number of 16-byte pieces (16 components -> 16 different bank groups; equal components read one address)
-    constexpr int TST = STUDENT ? SvRingTab<L>::TST : 0;
+    constexpr int TST = ST ? SvRingTab<L>::TST : 0;
     const int tab = ((K * PSTR + 3) & ~3) + K * TST;
     float* pk_lds = smem;                                    // [K][PSTR]  lower triangle of P_k
     float* th_lds = smem + ((K * PSTR + 3) & ~3);            // [K][TST]   Student-t only
-    float* ring = smem + tab + wave * (2 * STG);             // two stages: [x pair: 64 cells x 2L | dx pair: 64 cells x 2L]
-    float* accw = smem + tab + nw * (2 * STG) + wave * (PWa * 16);   // this wave's per-component sums [PWa][16]
+    float* ring = smem + tab + wave * (NSTG * STG);          // NSTG stages: [x pair: 64 cells x 2L | dx pair: 64 cells x 2L]
+    float* accw = smem + tab + nw * (NSTG * STG) + wave * (PWa * 16);   // this wave's per-component sums [PWa][16]
+    constexpr int PFW = PF ? 5 * WAVE : 0;                   // [eta1 rows | eta2d rows | dL/dT' | dL/dlog z | log z] of the next tile
+    float* pfb = smem + tab + nw * (NSTG * STG) + nw * (PWa * 16) + wave * PFW;
     const bool lane_on = K16 ? true : lane < CT;
     const int r = K16 ? lane >> 4 : lane / K, k = K16 ? lane & 15 : lane - r * K;
 
@@ -141,7 +182,7 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
         pk_lds[kk * PSTR + idx] = a.Pk[(kk * L + i) * L + j];
     }
     for (int e = lane; e < PWa * 16; e += WAVE) accw[e] = 0.f;
-    if constexpr (STUDENT) {
+    if constexpr (ST) {
         using T = SvRingTab<L>;
         for (int e = threadIdx.x; e < K * TST; e += blockDim.x) {
             const int kk = e / TST, f = e - kk * TST;
@@ -165,9 +206,9 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
     // Gaussian theta: the component's parameters stay in this lane's registers for the whole kernel, W in the padded pair
     // layout of the sample loop (below)
     constexpr int TPRk = ((L + 1) * (L + 1)) / 4;
-    float hkk[STUDENT ? 1 : L];
-    v2f m2[STUDENT ? 1 : L / 2], W2[STUDENT ? 1 : TPRk];
-    if constexpr (!STUDENT) {
+    float hkk[ST ? 1 : L];
+    v2f m2[ST ? 1 : L / 2], W2[ST ? 1 : TPRk];
+    if constexpr (!ST) {
 #pragma unroll
         for (int i = 0; i < L; ++i) {
             const float hv = a.hk[kc * L + i], mv = a.mk[kc * L + i];
@@ -227,14 +268,46 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
         }
     };
 
+    // the tile's small inputs, one tile ahead (NSTG = 4): five DMA instructions, issued right BEFORE the request of the tile's pair 0
+    auto prefetch = [&](long long tt) {
+        if constexpr (PF) {
+            const long long rows_left = a.N - tt * RPT;
+            const int nrow = rows_left < RPT ? (int)rows_left : RPT;
+            const int ne = nrow * L, nc = nrow * K;
+            const int le = lane < ne ? lane : ne - 1, lc = lane < nc ? lane : nc - 1;      // clamped: always a valid element
+            const long long e0 = tt * (long long)RPT * L, c0 = tt * (long long)CT;
+#define VMP_PF(SRC, SLOT) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC), \
+                                                           (__attribute__((address_space(3))) void*)(pfb + (SLOT) * WAVE), 4, 0, 0)
+            VMP_PF(a.eta1 + e0 + le, 0); VMP_PF(a.eta2d + e0 + le, 1); VMP_PF(a.GT + c0 + lc, 2); VMP_PF(a.Glz + c0 + lc, 3);
+            VMP_PF(a.lz + c0 + lc, 4);
+#undef VMP_PF
+        }
+    };
+    // Requests are a FIFO over the wave's pairs (tile t0, pairs 0 .. NP-1; tile t0 + tstride, ...), one stage each, slot = sequence
+    // number mod NSTG.  `outst` requests are outstanding when a pair is about to be consumed; the one it needs is the OLDEST, so
+    // everything issued after it may stay in flight:  (outst - 1) stage requests of 2 PP DMA instructions, plus the five prefetch
+    // instructions that precede a pair-0 request if one of those younger requests is a pair 0 (at most one: NP >= NSTG).  The row-sum
+    // stores of a tile are NOT counted (whether a predicated store issues depends on the exec mask): at worst the wait also covers
+    // the first one or two DMA instructions of the next stage.  Anything the compiler adds (a spill reload) only makes the wait
+    // stricter, never too lax.
     long long t = (long long)blockIdx.x * nw + wave;
-    int cur = 0;                                             // stage holding the pair about to be consumed
-    bool younger = true;                                     // was the pair after the one about to be consumed requested?
-    if (t < ntiles) {
-        issue(t, 0, ring);
-        if (NP > 1) issue(t, 1, ring + STG);
-        else if (t + tstride < ntiles) issue(t + tstride, 0, ring + STG);
-    }
+    long long rt = t;                                        // request cursor: tile
+    int rp = 0, rslot = 0, cslot = 0, outst = 0;             // ... pair, slot; consumer slot; outstanding requests
+    auto request_next = [&]() {
+        if (rt < ntiles) {
+            if (rp == 0) prefetch(rt);
+            issue(rt, rp, ring + rslot * STG);
+            rslot = rslot + 1 == NSTG ? 0 : rslot + 1;
+            ++outst;
+            if (++rp == NP) { rp = 0; rt += tstride; }
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < NSTG; ++j) request_next();
+    auto allowed_behind = [&](int p) {                       // VMEM operations younger than the request of pair p of the current tile
+        const int younger = outst - 1;
+        return younger * (2 * PP) + ((PF && p + younger >= NP) ? 5 : 0);
+    };
     for (; t < ntiles; t += tstride) {
         const long long row = t * RPT + r;
         const bool on = lane_on && row < a.N;
@@ -244,16 +317,22 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
         float Lm[TRI], av[L], mu[L];
 #pragma unroll
         for (int i = 0; i < TRI; ++i) Lm[i] = lane_on ? pk_lds[kc * PSTR + i] : 0.f;
+        if constexpr (PF) wait_vmcnt(allowed_behind(0));     // pair 0 of this tile and everything older - its prefetch - has landed
+        const int ro = (lane_on ? r : 0) * L;
 #pragma unroll
         for (int i = 0; i < L; ++i) {
-            const float e1v = a.eta1[rowc * L + i], e2v = a.eta2d[rowc * L + i];
+            float e1v, e2v;
+            if constexpr (PF) { e1v = pfb[ro + i]; e2v = pfb[WAVE + ro + i]; }
+            else { e1v = a.eta1[rowc * L + i]; e2v = a.eta2d[rowc * L + i]; }
             const float e1 = on ? e1v : 0.f;
             const float e2 = on ? e2v : -0.5f;
             Lm[tri(i, i)] = fmaf(-2.f, e2, lane_on ? Lm[tri(i, i)] : 0.f);
-            if constexpr (STUDENT) av[i] = e1 + (lane_on ? th_lds[th_off + SvRingTab<L>::WTOT + SvRingTab<L>::LP + i] : 0.f);
+            if constexpr (ST) av[i] = e1 + (lane_on ? th_lds[th_off + SvRingTab<L>::WTOT + SvRingTab<L>::LP + i] : 0.f);
             else av[i] = e1 + hkk[i];
         }
-        const float glzv = a.Glz[cellid], gTv = a.GT[cellid], lzv = a.lz[cellid];
+        float glzv, gTv, lzv;
+        if constexpr (PF) { const int pl = lane_on ? lane : 0; gTv = pfb[2 * WAVE + pl]; glzv = pfb[3 * WAVE + pl]; lzv = pfb[4 * WAVE + pl]; }
+        else { glzv = a.Glz[cellid]; gTv = a.GT[cellid]; lzv = a.lz[cellid]; }
         float ld;
         cell_cholesky<L>(Lm, ld);
         solve_lower<L>(Lm, av);
@@ -295,11 +374,11 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
         // ONCE per sample pair from the LDS table and used for both samples: the packed form of it was slower in both variants
         // tried (two samples together: spills inside the pair loop, whose reloads drain the DMA ring - vmcnt is in order;
         // one sample at a time: twice the table reads, SQ_LDS_BANK_CONFLICT 6 M -> 21 M cycles; 2.89 -> 3.15 ms at C3)
-        v2f LC[STUDENT ? 1 : TPC];
+        v2f LC[ST ? 1 : TPC];
         float rd[L];
 #pragma unroll
         for (int j = 0; j < L; ++j) rd[j] = Lm[tri(j, j)];
-        if constexpr (!STUDENT) {
+        if constexpr (!ST) {
 #pragma unroll
             for (int j = 0; j < L; ++j)
 #pragma unroll
@@ -307,13 +386,20 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
                     LC[CO(j) + q - Q0(j)] = v2f{2 * q > j ? Lm[tri(2 * q > j ? 2 * q : j + 1, j)] : 0.f, Lm[tri(2 * q + 1, j)]};
         }
         auto LM = [&](int i, int j) -> float {               // i >= j; the diagonal holds reciprocals
-            if constexpr (STUDENT) return Lm[tri(i, j)];
+            if constexpr (ST) return Lm[tri(i, j)];
             else return i == j ? rd[i] : LC[CO(j) + i / 2 - Q0(j)][i & 1];
         };
 
-        v2f Wsum2[STUDENT ? 1 : LH], M2[STUDENT ? 1 : TPR], mu2[STUDENT ? 1 : LH];
-        float Wsum[STUDENT ? L : 1], M[STUDENT ? TRI : 1], cy[STUDENT ? L : 1], Qy[STUDENT ? TRI : 1], mm[STUDENT ? L : 1];
-        if constexpr (STUDENT) {
+        v2f Wsum2[ST ? 1 : LH], M2[ST ? 1 : TPR], mu2[ST ? 1 : LH];
+        v2f cy2[SP ? LH : 1], Qy2[SP ? TPR : 1];             // Student-t, packed: theta-side sums of this cell
+        if constexpr (SP) {
+#pragma unroll
+            for (int q = 0; q < LH; ++q) cy2[q] = v2f{0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < TPR; ++i) Qy2[i] = v2f{0.f, 0.f};
+        }
+        float Wsum[ST ? L : 1], M[ST ? TRI : 1], cy[ST ? L : 1], Qy[ST ? TRI : 1], mm[ST ? L : 1];
+        if constexpr (ST) {
 #pragma unroll
             for (int i = 0; i < L; ++i) { Wsum[i] = 0.f; cy[i] = 0.f; mm[i] = th_lds[th_off + SvRingTab<L>::WTOT + i] - mu[i]; }
 #pragma unroll
@@ -325,22 +411,15 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
             for (int i = 0; i < TPR; ++i) M2[i] = v2f{0.f, 0.f};
         }
         auto MU = [&](int i) -> float {                      // (one copy of mu~ lives across the sample loop)
-            if constexpr (STUDENT) return mu[i];
+            if constexpr (ST) return mu[i];
             else return mu2[i / 2][i & 1];
         };
         const float gts = gT * invS;
         const float nuL = nuk + (float)L;
         for (int p = 0; p < NP; ++p) {
-            float* stage = ring + cur * STG;
-            // The stage about to be read was requested two pairs ago.  If the pair in between was requested too, its 2*PP
-            // DMA instructions are the youngest ones in flight and may stay so; if it was not (no next tile for this wave),
-            // NOTHING younger exists and the count must drain to zero - waiting for "<= 2*PP outstanding" would then not wait
-            // at all (found as a run-to-run difference of the last pair of a wave's last tile).
-            if (!younger) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (PP == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (PP == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (PP == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            float* stage = ring + cslot * STG;
+            // the stage about to be read holds the OLDEST outstanding request (see allowed_behind)
+            wait_vmcnt(allowed_behind(p));
             v2f xq[2][LH], gq[2][LH];                       // [sample of the pair][column pair]
 #pragma unroll
             for (int q = 0; q < PP; ++q) {
@@ -356,14 +435,10 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int q = 0; q < LH; ++q) asm volatile("" : "+v"(xq[h][q]), "+v"(gq[h][q]));
-            {   // re-request this stage for the pair after next (of this tile, or of this wave's next tile; NP >= 2: host)
-                const int pn = p + 2;
-                if (pn < NP) { issue(t, pn, stage); younger = true; }
-                else if (t + tstride < ntiles) { issue(t + tstride, pn - NP, stage); younger = true; }
-                else younger = false;
-            }
-            cur ^= 1;
-            if constexpr (STUDENT) {
+            cslot = cslot + 1 == NSTG ? 0 : cslot + 1;
+            --outst;
+            request_next();                                 // the freed slot takes the next pair of the wave's sequence
+            if constexpr (ST) {
                 // both samples of the pair against each row of W (one LDS read of the row serves two samples)
                 using T = SvRingTab<L>;
                 float d[2][L], y[2][L], gx[2][L], del2[2] = {0.f, 0.f};
@@ -430,7 +505,8 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
                     }
                 }
             } else {
-                // Gaussian theta, packed (see the layouts above); the two samples of the pair one after the other
+                // packed form (see the layouts above; Gaussian theta, and the Student-t theta of the four-stage kernel); the two samples of
+                // the pair one after the other
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     // d = x - m,  y = W d  (row i: pair products summed in two half-sums),  gy = y gT / S,  gx += W^T gy:
@@ -445,13 +521,27 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
                         for (int q = 1; q < RPn(i); ++q) acc = __builtin_elementwise_fma(W2[RO(i) + q], d2[q], acc);
                         y2[i / 2][i & 1] = acc[0] + acc[1];
                     }
-                    const v2f gts2 = v2f{gts, gts};
+                    v2f gts2 = v2f{gts, gts};
+                    if constexpr (SP) {                     // c_s = (nu+L)/(nu+delta^2)  (student_t.py:31-37 differentiated)
+                        v2f dd = y2[0] * y2[0];
+#pragma unroll
+                        for (int q = 1; q < LH; ++q) dd = __builtin_elementwise_fma(y2[q], y2[q], dd);
+                        const float gcs = gts * nuL * __builtin_amdgcn_rcpf(nuk + (dd[0] + dd[1]));
+                        gts2 = v2f{gcs, gcs};
+                    }
 #pragma unroll
                     for (int q = 0; q < LH; ++q) { y2[q] = y2[q] * gts2; gx2[q] = gq[h][q]; }
+                    if constexpr (SP) {
+#pragma unroll
+                        for (int q = 0; q < LH; ++q) cy2[q] = cy2[q] + y2[q];
+                    }
 #pragma unroll
                     for (int i = 0; i < L; ++i)
 #pragma unroll
-                        for (int q = 0; q < RPn(i); ++q) gx2[q] = pk_fma_b(W2[RO(i) + q], y2[i / 2], gx2[q], i & 1);
+                        for (int q = 0; q < RPn(i); ++q) {
+                            gx2[q] = pk_fma_b(W2[RO(i) + q], y2[i / 2], gx2[q], i & 1);                          // gx += W^T gy
+                            if constexpr (SP) Qy2[RO(i) + q] = pk_fma_b(d2[q], y2[i / 2], Qy2[RO(i) + q], i & 1);  // Qy += gy d^T
+                        }
                     // w_s = Lt^-1 gx_s: forward substitution by columns, the rows below the pivot in pairs
 #pragma unroll
                     for (int j = 0; j < L; ++j) {
@@ -476,7 +566,7 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
             }
         }
         auto MM = [&](int i, int j) -> float {               // i >= j
-            if constexpr (STUDENT) return M[tri(i, j)];
+            if constexpr (ST) return M[tri(i, j)];
             else return M2[RO(i) + j / 2][j & 1];
         };
         // ---- Student-t: this cell's theta-side gradients join the wave's accumulators (rows TH..PW-1) now, so that their
@@ -485,17 +575,24 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
             float tx[L];
 #pragma unroll
             for (int j = 0; j < L; ++j) tx[j] = 0.f;
+            if constexpr (SP) {
 #pragma unroll
-            for (int i = 0; i < L; ++i) {
-                float w[8];
+                for (int i = 0; i < L; ++i)
 #pragma unroll
-                for (int q = 0; q <= i / 4; ++q) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(th_lds + th_off + SvRingTab<L>::roff(i) + 4 * q);
+                    for (int j = 0; j <= i; ++j) tx[j] = fmaf(W2[RO(i) + j / 2][j & 1], cy2[i / 2][i & 1], tx[j]);
+            } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) w[4 * q + c] = wv[c];
+                for (int i = 0; i < L; ++i) {
+                    float w[8];
+#pragma unroll
+                    for (int q = 0; q <= i / 4; ++q) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(th_lds + th_off + SvRingTab<L>::roff(i) + 4 * q);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) w[4 * q + c] = wv[c];
+                    }
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) tx[j] = fmaf(w[j], cy[i], tx[j]);
                 }
-#pragma unroll
-                for (int j = 0; j <= i; ++j) tx[j] = fmaf(w[j], cy[i], tx[j]);
             }
             float tvals[TH];
 #pragma unroll
@@ -503,7 +600,7 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
 #pragma unroll
             for (int i = 0; i < L; ++i)
 #pragma unroll
-                for (int j = 0; j <= i; ++j) tvals[L + tri(i, j)] = Qy[tri(i, j)];
+                for (int j = 0; j <= i; ++j) tvals[L + tri(i, j)] = SP ? Qy2[SP ? RO(i) + j / 2 : 0][j & 1] : Qy[ST ? tri(i, j) : 0];
             tvals[L + TRI] = -gT;
             acc_batches(tvals, TH);
         }
@@ -511,7 +608,7 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
         float V[L];
 #pragma unroll
         for (int i = 0; i < L; ++i) {
-            if constexpr (STUDENT) V[i] = Wsum[i];
+            if constexpr (ST) V[i] = Wsum[i];
             else V[i] = Wsum2[i / 2][i & 1];
         }
 #pragma unroll
@@ -583,52 +680,43 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
 #pragma unroll
             for (int j = 0; j <= i; ++j) gP[tri(i, j)] = fmaf(tv[i], MU(j), fmaf(MU(i), tv[j], gP[tri(i, j)]));
 
-        // ---- per-row sums (over the components of a data row) -> d eta of the encoder
+        // ---- per-row sums (over the components of a data row) -> d eta of the encoder.  The 2 L sums of a data row are formed by
+        // a reduce-scatter over the row's 16 lanes (row16_reduce_scatter) and leave with ONE store instruction per tile: lane
+        // (row, c) stores value c - d eta1[c] for c < L, d eta2d[c - L] for L <= c < 2 L - to two contiguous 4 L-byte rows (the
+        // first form stored them with 2 L instructions from one lane per row; the four-stage kernel counts its memory operations)
+        auto store_row_sums = [&](float (&v)[16], long long row_, bool row_ok) {
+            const float tot = row16_reduce_scatter(v, col);
+            const bool is1 = col < L;
+            float* dst = (is1 ? a.g_eta1 : a.g_eta2d) + row_ * L + (is1 ? col : col - L);
+            if (row_ok && col < 2 * L) *dst = is1 ? tot : -2.f * tot;      // p = -2 eta2d
+        };
         if constexpr (K16) {
-            float s1[L], s2[L];
+            float v[16];
 #pragma unroll
-            for (int i = 0; i < L; ++i) {
-                s1[i] = row16_sum(on ? gh[i] : 0.f);
-                s2[i] = -2.f * row16_sum(on ? gP[tri(i, i)] : 0.f);      // p = -2 eta2d
-            }
-            if (on && k == 0) {                             // one masked block: 2L stores to two contiguous rows
-#pragma unroll
-                for (int i = 0; i < L; ++i) { a.g_eta1[row * L + i] = s1[i]; a.g_eta2d[row * L + i] = s2[i]; }
-            }
+            for (int i = 0; i < 16; ++i) v[i] = i < L ? (on ? gh[i < L ? i : 0] : 0.f) : i < 2 * L ? (on ? gP[tri(i < 2 * L && i >= L ? i - L : 0, i < 2 * L && i >= L ? i - L : 0)] : 0.f) : 0.f;
+            store_row_sums(v, t * RPT + dr, t * RPT + dr < a.N);
         } else {
-            // gathered: the lane in column 0 of DPP row dr stores tile rows dr (gather 0) and 4 + dr (gather 1)
-            float s1a[L], s2a[L], s1b[L], s2b[L];
+            // gathered: DPP row dr holds tile row dr (gather 0) and tile row 4 + dr (gather 1)
+            float va[16], vb[16];
 #pragma unroll
-            for (int i = 0; i < L; ++i) {                   // all exchanges first, one wait, then the DPP sums
-                const float v1 = on ? gh[i] : 0.f, v2 = on ? gP[tri(i, i)] : 0.f;
-                s1a[i] = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga0, __float_as_uint(v1)));
-                s2a[i] = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga0, __float_as_uint(v2)));
-                if (RPT > 4) {
-                    s1b[i] = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga1, __float_as_uint(v1)));
-                    s2b[i] = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga1, __float_as_uint(v2)));
+            for (int i = 0; i < 16; ++i) {                  // all exchanges first, one wait, then the sums
+                const float x_ = i < L ? (on ? gh[i < L ? i : 0] : 0.f) : i < 2 * L ? (on ? gP[tri(i < 2 * L && i >= L ? i - L : 0, i < 2 * L && i >= L ? i - L : 0)] : 0.f) : 0.f;
+                va[i] = 0.f; vb[i] = 0.f;
+                if (i < 2 * L) {
+                    va[i] = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga0, __float_as_uint(x_)));
+                    if (RPT > 4) vb[i] = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga1, __float_as_uint(x_)));
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int i = 0; i < L; ++i) {
-                asm volatile("" : "+v"(s1a[i]), "+v"(s2a[i]));
-                s1a[i] = row16_sum(gv0 ? s1a[i] : 0.f);
-                s2a[i] = -2.f * row16_sum(gv0 ? s2a[i] : 0.f);           // p = -2 eta2d
-                if (RPT > 4) {
-                    asm volatile("" : "+v"(s1b[i]), "+v"(s2b[i]));
-                    s1b[i] = row16_sum(gv1 ? s1b[i] : 0.f);
-                    s2b[i] = -2.f * row16_sum(gv1 ? s2b[i] : 0.f);
-                }
+            for (int i = 0; i < 2 * L; ++i) {
+                asm volatile("" : "+v"(va[i]));
+                va[i] = gv0 ? va[i] : 0.f;
+                if (RPT > 4) { asm volatile("" : "+v"(vb[i])); vb[i] = gv1 ? vb[i] : 0.f; }
             }
             const long long rowa = t * RPT + dr, rowb = rowa + 4;
-            if (col == 0 && dr < RPT && rowa < a.N) {
-#pragma unroll
-                for (int i = 0; i < L; ++i) { a.g_eta1[rowa * L + i] = s1a[i]; a.g_eta2d[rowa * L + i] = s2a[i]; }
-            }
-            if (RPT > 4 && col == 0 && 4 + dr < RPT && rowb < a.N) {
-#pragma unroll
-                for (int i = 0; i < L; ++i) { a.g_eta1[rowb * L + i] = s1b[i]; a.g_eta2d[rowb * L + i] = s2b[i]; }
-            }
+            store_row_sums(va, rowa, dr < RPT && rowa < a.N);
+            if (RPT > 4) store_row_sums(vb, rowb, 4 + dr < RPT && rowb < a.N);
         }
         // ---- per-component sums (acc_batches above)
         {
@@ -650,7 +738,7 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
         const int kk = e / PW, f = e - kk * PW;
         float s2 = 0.f;
         if (f < PWa) {
-            const float* base = smem + tab + nw * (2 * STG);
+            const float* base = smem + tab + nw * (NSTG * STG);
             for (int w = 0; w < nw; ++w) s2 += base[w * (PWa * 16) + f * 16 + kk];
         }
         out[e] = s2;
@@ -662,14 +750,15 @@ __global__ __launch_bounds__(SVR_NW * WAVE) void svae_estep_bwd_ring_kernel(EBwd
     }
 }
 
-template <int L, bool K16, bool STUDENT>
-int launch(const EBwdArgs& a, int nblk_abi, void* stream) {
+template <int L, bool K16, bool STUDENT, int NSTG>
+int launch_n(const EBwdArgs& a, int nblk_abi, void* stream) {
     constexpr int TRI = L * (L + 1) / 2, TH = L + TRI + 1, PWa = STUDENT ? 2 * TH : TH;
     const int K = a.K, RPT = WAVE / K;
-    const int tab = ((K * (TRI | 1) + 3) & ~3) + (STUDENT ? K * SvRingTab<L>::TST : 0);
-    const int per_wave = 2 * svr_stage_floats<L>() + PWa * 16;
+    const int tab = ((K * (TRI | 1) + 3) & ~3) + ((STUDENT && NSTG == 2) ? K * SvRingTab<L>::TST : 0);
+    const int per_wave = NSTG * svr_stage_floats<L>() + PWa * 16 + (NSTG == 4 ? 5 * WAVE : 0);
+    const int maxw = NSTG == 2 ? SVR_NW : 4;
     int nw = (int)((160 * 1024 / sizeof(float) - tab) / per_wave);
-    if (nw > SVR_NW) nw = SVR_NW;
+    if (nw > maxw) nw = maxw;
 #ifdef VMP_RING_MAXW
     if (nw > VMP_RING_MAXW) nw = VMP_RING_MAXW;            // A/B builds: fewer waves per CU
 #endif
@@ -678,10 +767,27 @@ int launch(const EBwdArgs& a, int nblk_abi, void* stream) {
     long long bl = (ntiles + nw - 1) / nw;
     if (bl > 256) bl = 256;                                  // one block per CU
     const size_t lds = (size_t)(tab + nw * per_wave) * sizeof(float);
-    auto kern = svae_estep_bwd_ring_kernel<L, K16, STUDENT>;
+    auto kern = svae_estep_bwd_ring_kernel<L, K16, STUDENT, NSTG>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((int)bl), dim3(nw * WAVE), lds, static_cast<hipStream_t>(stream), a, nblk_abi);
     return check_launch("svae_estep_bwd_ring_kernel");
+}
+
+#ifndef VMP_RING_STAGES
+#define VMP_RING_STAGES 2      // 2: eight waves per CU, two stages each (shipped).  4: one wave per SIMD, four stages, where S / 2 >= 4 and
+#endif                         //    the batch has >= 1024 wave tiles - measured SLOWER; A/B builds only
+template <int L, bool K16, bool STUDENT>
+int launch(const EBwdArgs& a, int nblk_abi, void* stream) {
+    if constexpr (VMP_RING_STAGES == 4) {
+        const long long ntiles = (a.N + WAVE / a.K - 1) / (WAVE / a.K);
+        // four stages need S / 2 >= 4 pairs per tile (a request never runs more than one tile ahead) and enough tiles to give every
+        // one of the 1024 waves of the chip work; smaller batches keep the eight-wave form
+        if ((a.S >> 1) >= 4 && ntiles >= 1024) {
+            const int rc = launch_n<L, K16, STUDENT, 4>(a, nblk_abi, stream);
+            if (rc != -2) return rc;
+        }
+    }
+    return launch_n<L, K16, STUDENT, 2>(a, nblk_abi, stream);
 }
 
 }  // namespace
