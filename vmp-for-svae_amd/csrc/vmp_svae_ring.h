@@ -84,6 +84,14 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 //           requested four pairs ahead; no form is register-starved (the Student-t theta keeps W and all its sums in registers and
 //           runs the packed sample loop), and every memory operation inside the tile loop sits on a COUNTED wait: the tile's small
 //           inputs come by DMA one tile ahead, the row sums leave with one store per tile (see below).
+#ifdef VMP_DEBUG_TS
+// exploration builds: clock64 stamps of ONE tile (the 9th of block 0, wave 0) - tools/ring_ts.py
+#define RG_TS(i) do { if (a.dbg_t && blockIdx.x == 0 && wave == 0 && tile_it == 8 && lane == 0) a.dbg_t[i] = clock64(); } while (0)
+#define RG_USE(v) asm volatile("" :: "v"(v))
+#else
+#define RG_TS(i) do { } while (0)
+#define RG_USE(v) do { } while (0)
+#endif
 template <int L, bool K16, bool STUDENT, int NSTG>
 __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bwd_ring_kernel(EBwdArgs a, int nblk_abi) {
     constexpr bool SP = STUDENT && NSTG == 4;                // Student-t, parameters in registers, packed sample loop
@@ -124,50 +132,65 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
     //  under the exec mask of the gv lanes only, and a ds_bpermute that reads from a disabled lane returns 0)
     auto gat0 = [&](float v) { const float t_ = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga0, __float_as_uint(v))); return gv0 ? t_ : 0.f; };
     auto gat1 = [&](float v) { const float t_ = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga1, __float_as_uint(v))); return gv1 ? t_ : 0.f; };
-    // The TH values a cell contributes to its component's sums -> this wave's LDS accumulator rows [row0, row0 + TH).  Batches
-    // of CH: (K < 16: the 2 CH gathers of the batch issued back to back,) the batch's accumulator words requested by lanes
-    // 0..15, ONE wait for both, the cross-row sums on the VALU, one masked block of stores.  (One value at a time was a chain
-    // of exchange -> wait -> sum per value: ~210 s_waitcnt per tile in the first K < 16 build.)
+    // The TH values a cell contributes to its component's sums -> this wave's LDS accumulator rows [row0, row0 + TH).
+    // Four values at a time are summed over the tile's rows by a REDUCE-SCATTER across the four DPP rows: v_permlane32_swap of two
+    // values leaves [a.lo | b.lo], [a.hi | b.hi], whose sum holds a's half-sums in lanes 0..31 and b's in lanes 32..63 (one swap + one
+    // add for TWO values); v_permlane16_swap of two such results does the same across odd / even rows.  Three swaps + three adds per four
+    // values (an all-reduce per value was two swaps + two adds EACH), and the result register holds, in DPP row dr, the total of value
+    // 4 j + {0, 2, 1, 3}[dr] for component col: all 64 lanes then update the accumulators - 12 LDS reads and 12 writes per call instead
+    // of 45 + 45 by 16 lanes (stage stamps, profiles/r04_ring_stage_stamps.txt: this step was 3.3 k of a tile's 24.5 k cycles at K = 16,
+    // 6.8 k of 31.9 k at K = 10, and ran twice per tile for the Student-t theta).  K < 16: the values are first gathered into the K = 16
+    // arrangement (ds_bpermute, all exchanges of a chunk issued together, one wait).
     auto acc_batches = [&](const float (&vals)[TH], int row0) {
-        constexpr int CH = 9;                                              // TH = L + TRI + 1; 45 = 5 x 9 at L = 8
+        constexpr int NG = (TH + 3) / 4;                                   // groups of four values
+        constexpr int GC = 3;                                              // groups per chunk (12 values)
+        const int vm = ((dr & 1) << 1) | (dr >> 1);                        // {0, 2, 1, 3}[dr]
 #pragma unroll
-        for (int c0 = 0; c0 < TH; c0 += CH) {
-            float t0[CH], t1[CH], oldv[CH];
-            if constexpr (!K16) {
+        for (int g0 = 0; g0 < NG; g0 += GC) {
+            float w[4 * GC];
+            if constexpr (K16) {
 #pragma unroll
-                for (int u = 0; u < CH; ++u)
-                    if (c0 + u < TH) t0[u] = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga0, __float_as_uint(vals[c0 + u])));
-                if (RPT > 4) {
+                for (int u = 0; u < 4 * GC; ++u) w[u] = (4 * g0 + u < TH) ? vals[4 * g0 + u < TH ? 4 * g0 + u : 0] : 0.f;
+            } else {
+                float t0[4 * GC], t1[4 * GC];
 #pragma unroll
-                    for (int u = 0; u < CH; ++u)
-                        if (c0 + u < TH) t1[u] = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga1, __float_as_uint(vals[c0 + u])));
+                for (int u = 0; u < 4 * GC; ++u) {
+                    t0[u] = 0.f; t1[u] = 0.f;
+                    if (4 * g0 + u < TH) {
+                        t0[u] = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga0, __float_as_uint(vals[4 * g0 + u < TH ? 4 * g0 + u : 0])));
+                        if (RPT > 4) t1[u] = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga1, __float_as_uint(vals[4 * g0 + u < TH ? 4 * g0 + u : 0])));
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < 4 * GC; ++u) {
+                    asm volatile("" : "+v"(t0[u]));
+                    w[u] = gv0 ? t0[u] : 0.f;
+                    if (RPT > 4) { asm volatile("" : "+v"(t1[u])); w[u] += gv1 ? t1[u] : 0.f; }
                 }
             }
-            if (lane < 16) {
+            float R[GC], oldv[GC];
+            int addr[GC];
 #pragma unroll
-                for (int u = 0; u < CH; ++u)
-                    if (c0 + u < TH) oldv[u] = accw[(row0 + c0 + u) * 16 + lane];
+            for (int g = 0; g < GC; ++g) {
+                if (g0 + g < NG) {
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w[4 * g]), __float_as_uint(w[4 * g + 1]), false, false);
+                    const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w[4 * g + 2]), __float_as_uint(w[4 * g + 3]), false, false);
+                    const float P = __uint_as_float(s1[0]) + __uint_as_float(s1[1]), Q = __uint_as_float(s2[0]) + __uint_as_float(s2[1]);
+                    const auto s3 = __builtin_amdgcn_permlane16_swap(__float_as_uint(P), __float_as_uint(Q), false, false);
+                    R[g] = __uint_as_float(s3[0]) + __uint_as_float(s3[1]);
+                    const int vi = 4 * (g0 + g) + vm;
+                    addr[g] = vi < TH ? (row0 + vi) * 16 + col : -1;
+                    oldv[g] = accw[addr[g] < 0 ? 0 : addr[g]];
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                if (c0 + u < TH) {
-                    asm volatile("" : "+v"(oldv[u]));
-                    if constexpr (K16) {
-                        t0[u] = rows4_sum(vals[c0 + u]);
-                    } else {
-                        asm volatile("" : "+v"(t0[u]));
-                        float g_ = gv0 ? t0[u] : 0.f;
-                        if (RPT > 4) { asm volatile("" : "+v"(t1[u])); g_ += gv1 ? t1[u] : 0.f; }
-                        t0[u] = rows4_sum(g_);
-                    }
+            for (int g = 0; g < GC; ++g)
+                if (g0 + g < NG) {
+                    asm volatile("" : "+v"(oldv[g]));
+                    if (addr[g] >= 0) accw[addr[g]] = oldv[g] + R[g];
                 }
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int u = 0; u < CH; ++u)
-                    if (c0 + u < TH) accw[(row0 + c0 + u) * 16 + lane] = oldv[u] + t0[u];
-            }
         }
     };
     // where lane (r, k) finds the sum of ITS row after the gathered row sums: DPP row r & 3, columns 0..7 hold gather 0's sum
@@ -246,20 +269,46 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
     // arithmetic depends on the order of a cell's samples): its pair 0 is then asked for by the SAME DMA instruction as its
     // neighbour's last pair - one 128-byte request.
     const bool rotate = (PP == 4) && (NP & 1);
+    // Per-lane part of the DMA source address, fixed for the whole kernel: byte offset of (cell, piece) inside a FULL tile and the
+    // cell's parity.  A request then costs one add and a three-instruction pair rotation per DMA instruction on top of a wave-uniform
+    // base (the stage stamps showed 670-1900 cycles per re-request: ~85 VALU instructions of 64-bit address arithmetic per 8 DMAs).
+    unsigned cbyte[PP], cpar[PP];
+#pragma unroll
+    for (int j = 0; j < PP; ++j) {
+        const int dc = (PP == 4) ? ((j * WAVE + lane) >> 2) : dcell[j];
+        const int dp = (PP == 4) ? ((lane & 3) ^ ((dc >> 2) & 3)) : dpiece[j];
+        const int cc = dc < CT ? dc : CT - 1;                // K < 16: slots past the tile's CT cells re-fetch its last cell
+        cbyte[j] = (unsigned)(cc * LSn + 4 * dp) * 4u;
+        cpar[j] = (unsigned)cc & 1u;
+    }
     auto issue = [&](long long tt, int pp, float* stage) {
         // pair pp of tile tt -> stage; cells past the end of the tile / of the tensor are clamped to the tile's last valid cell
         const long long cells_left = (a.N - tt * RPT) * K;
-        const int ncell = cells_left < CT ? (int)cells_left : CT;
         const long long tile0 = tt * (long long)CT * LSn;
-        const int par0 = (int)((tt * CT) & 1);               // parity of the tile's first cell
+        const unsigned par0 = (unsigned)((tt * CT) & 1);     // parity of the tile's first cell
+        const char* __restrict__ xb = reinterpret_cast<const char*>(a.x + tile0);      // wave-uniform bases
+        const char* __restrict__ gb = reinterpret_cast<const char*>(a.Gx + tile0);
+        if (cells_left >= CT) {                              // full tile (all but the last one)
+#pragma unroll
+            for (int j = 0; j < PP; ++j) {
+                unsigned pe = (unsigned)pp;
+                if (rotate) { pe = (unsigned)pp + (cpar[j] ^ par0); pe = pe >= (unsigned)NP ? pe - (unsigned)NP : pe; }
+                const unsigned ob = cbyte[j] + pe * (unsigned)(2 * L * 4);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + ob),
+                                                 (__attribute__((address_space(3))) void*)(stage + j * (4 * WAVE)), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + ob),
+                                                 (__attribute__((address_space(3))) void*)(stage + WAVE * 2 * L + j * (4 * WAVE)), 16, 0, 0);
+            }
+            return;
+        }
+        const int ncell = (int)cells_left;
 #pragma unroll
         for (int j = 0; j < PP; ++j) {
-            // L = 8: the slot walk is recomputed from the lane (shifts and masks) instead of living in 8 registers
             const int dc = (PP == 4) ? ((j * WAVE + lane) >> 2) : dcell[j];
             const int dp = (PP == 4) ? ((lane & 3) ^ ((dc >> 2) & 3)) : dpiece[j];
             const int cc = dc < ncell ? dc : ncell - 1;
             int pe = pp;
-            if (rotate) { pe = pp + ((cc + par0) & 1); pe = pe >= NP ? pe - NP : pe; }
+            if (rotate) { pe = pp + ((cc + (int)par0) & 1); pe = pe >= NP ? pe - NP : pe; }
             const long long off = tile0 + (long long)cc * LSn + pe * 2 * L + 4 * dp;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.x + off),
                                              (__attribute__((address_space(3))) void*)(stage + j * (4 * WAVE)), 16, 0, 0);
@@ -308,7 +357,10 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
         const int younger = outst - 1;
         return younger * (2 * PP) + ((PF && p + younger >= NP) ? 5 : 0);
     };
+    int tile_it = -1;
     for (; t < ntiles; t += tstride) {
+        ++tile_it;
+        RG_TS(0);
         const long long row = t * RPT + r;
         const bool on = lane_on && row < a.N;
         const long long rowc = on ? row : 0;
@@ -339,6 +391,7 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
 #pragma unroll
         for (int i = 0; i < L; ++i) mu[i] = av[i];
         solve_lower_t<L>(Lm, mu);                           // mu~ = Pt^-1 ht
+        RG_USE(mu[0]); RG_TS(1);
 
         const float glz = on ? glzv : 0.f;
         const float gT = on ? gTv : 0.f;
@@ -352,6 +405,7 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
         }
         const float Gc = glz - rnk * gsum;                  // through the log-sum-exp normalisation
         const float Gld = gT - Gc;                          // T' has +ld, c has -ld
+        RG_USE(Gld); RG_TS(2);
 
         // ---- packed layouts of the sample loop (round 4).  Every product of the loop runs as v_pk_fma_f32 over PAIRS OF ADJACENT
         // COLUMNS (two floats that are neighbours in memory are neighbours in registers: no packing moves):
@@ -420,6 +474,7 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
             float* stage = ring + cslot * STG;
             // the stage about to be read holds the OLDEST outstanding request (see allowed_behind)
             wait_vmcnt(allowed_behind(p));
+            RG_TS(3 + 4 * p);
             v2f xq[2][LH], gq[2][LH];                       // [sample of the pair][column pair]
 #pragma unroll
             for (int q = 0; q < PP; ++q) {
@@ -435,9 +490,11 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int q = 0; q < LH; ++q) asm volatile("" : "+v"(xq[h][q]), "+v"(gq[h][q]));
+            RG_TS(4 + 4 * p);
             cslot = cslot + 1 == NSTG ? 0 : cslot + 1;
             --outst;
             request_next();                                 // the freed slot takes the next pair of the wave's sequence
+            RG_TS(5 + 4 * p);
             if constexpr (ST) {
                 // both samples of the pair against each row of W (one LDS read of the row serves two samples)
                 using T = SvRingTab<L>;
@@ -564,6 +621,8 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
                         for (int q = 0; q < RPn(i); ++q) M2[RO(i) + q] = pk_fma_b(gx2[q], e2[i / 2], M2[RO(i) + q], i & 1);
                 }
             }
+            if constexpr (ST) { RG_USE(M[0]); } else { RG_USE(M2[0]); }
+            RG_TS(6 + 4 * p);
         }
         auto MM = [&](int i, int j) -> float {               // i >= j
             if constexpr (ST) return M[tri(i, j)];
@@ -604,6 +663,7 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
             tvals[L + TRI] = -gT;
             acc_batches(tvals, TH);
         }
+        RG_TS(23);
         // ---- assemble dLoss/dht and dLoss/dPt (symmetric, lower triangle): as in svae_estep_bwd_kernel
         float V[L];
 #pragma unroll
@@ -680,6 +740,7 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
 #pragma unroll
             for (int j = 0; j <= i; ++j) gP[tri(i, j)] = fmaf(tv[i], MU(j), fmaf(MU(i), tv[j], gP[tri(i, j)]));
 
+        RG_USE(gP[0]); RG_TS(24);
         // ---- per-row sums (over the components of a data row) -> d eta of the encoder.  The 2 L sums of a data row are formed by
         // a reduce-scatter over the row's 16 lanes (row16_reduce_scatter) and leave with ONE store instruction per tile: lane
         // (row, c) stores value c - d eta1[c] for c < L, d eta2d[c - L] for L <= c < 2 L - to two contiguous 4 L-byte rows (the
@@ -718,6 +779,7 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
             store_row_sums(va, rowa, dr < RPT && rowa < a.N);
             if (RPT > 4) store_row_sums(vb, rowb, 4 + dr < RPT && rowb < a.N);
         }
+        RG_TS(25);
         // ---- per-component sums (acc_batches above)
         {
             float pvals[TH];
@@ -728,6 +790,7 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
             pvals[L + TRI] = on ? Gc : 0.f;
             acc_batches(pvals, 0);
         }
+        RG_TS(26);
     }
 
     // ---- block reduction: waves in a fixed order, then one partial row per block
