@@ -115,6 +115,27 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// sum over lanes l, l^16, l^32, l^48 (same component, 4 rows) on the VALU: gfx950's v_permlane32_swap / v_permlane16_swap
+// exchange the 32-lane halves / the odd and even 16-lane rows of two registers, so (lower + upper) and then (even + odd) are
+// two swaps and two adds - the same sums, bit for bit, as v + shfl_xor(v, 32) and t + shfl_xor(t, 16), which compile to
+// ds_bpermute_b32: an address computation, an LDS-crossbar round trip and a wait per exchange, 90 of them per tile.
+#ifndef VMP_ROWS4_SHFL
+#define VMP_ROWS4_SHFL 0      // 1: the ds_bpermute form (A/B measurements: tools/build_variant.sh)
+#endif
+__device__ __forceinline__ float rows4_sum(float v) {
+#if VMP_ROWS4_SHFL
+    const float t = v + __shfl_xor(v, 32);
+    return t + __shfl_xor(t, 16);
+#else
+    const unsigned x = __float_as_uint(v);
+    const auto h = __builtin_amdgcn_permlane32_swap(x, x, false, false);      // h[0] = lower-half values, h[1] = upper-half values
+    const float t = __uint_as_float(h[0]) + __uint_as_float(h[1]);
+    const unsigned y = __float_as_uint(t);
+    const auto q = __builtin_amdgcn_permlane16_swap(y, y, false, false);      // q[0] = even-row values, q[1] = odd-row values
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+#endif
+}
+
 // ---- error plumbing (thread-local message) ------------------------------------------------
 void set_error(const char* fmt, ...);
 int  check_launch(const char* what);

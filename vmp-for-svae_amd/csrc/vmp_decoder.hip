@@ -68,8 +68,11 @@ struct DecArgs {
 };
 #ifdef VMP_DEBUG_TS
 #define DEC_TS(i) do { if (a.dbg_t && blockIdx.x == 0 && threadIdx.x == 0) { a.dbg_t[i] = clock64(); a.dbg_t[32 + (i)] = wall_clock64(); } } while (0)
+// stage stamps of ONE streaming tile (the 9th of block 0, wave 0): tools/dec_tile_ts.py
+#define DEC_TT(i) do { if (a.dbg_t && blockIdx.x == 0 && threadIdx.x == 0 && tile == t0 + 8) a.dbg_t[64 + (i)] = clock64(); } while (0)
 #else
 #define DEC_TS(i) do { } while (0)
+#define DEC_TT(i) do { } while (0)
 #endif
 
 struct DecGeo {
@@ -552,8 +555,7 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void dec_fwd_kernel(DecArgs a) {
             const float term = df * df * rcp_f(vr[j]) + __logf(vr[j] + 1e-8f);
             acc += d < Dy ? term : 0.f;
         }
-        acc += __shfl_xor(acc, 16);
-        acc += __shfl_xor(acc, 32);
+        acc = rows4_sum(acc);                                    // same order of additions as the backward kernel's value
         if (ok && g == 0 && a.ll) a.ll[row] = acc;
         if (ok && a.mean) {
 #pragma unroll
@@ -711,6 +713,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
     for (unsigned tile = t0; tile < t1; ++tile) {
         const unsigned row = tile * 16u + c;
         const bool ok = row < a.R;
+        DEC_TT(0);
         const TileIn cur = nxt;
         nxt = fetch(tile + 1);
         const float xb0 = cur.xb0, xb1 = cur.xb1;
@@ -730,6 +733,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
                 *reinterpret_cast<unsigned*>(q + term * 512) = __builtin_amdgcn_perm(nb, xs[term], sel);
             }
         }
+        DEC_TT(1);
         f32x4 h0[UT], h1[UT], O;
         {
             unsigned h0s[3][4 * KB], h1s[3][4 * KB];
@@ -738,6 +742,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             trb_write<UT>(scrQb, g, c, h1s);
         }
 
+        DEC_TT(2);
         // ---- reconstruction term: gradients w.r.t. the output slots
         f32x4 dO;
         float llacc = 0.f;
@@ -757,8 +762,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             if (!GIN && a.ll) llacc += dv ? df * df * iv + __logf(vr + 1e-8f) : 0.f;
         }
         if (!GIN && a.ll) {                                      // value and gradient in one pass (wave-uniform branch)
-            llacc += __shfl_xor(llacc, 16);
-            llacc += __shfl_xor(llacc, 32);
+            llacc = rows4_sum(llacc);                            // over the 4 lane groups: two VALU lane swaps (was two ds_bpermute round trips)
             if (ok && g == 0) a.ll[row] = llacc;
         }
         unsigned dOs[3][2];
@@ -770,6 +774,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
         }
         trb_write<1>(scrOb, g, c, dOs);
         const SOps so = slot_operands(dOs);
+        DEC_TT(3);
         // ---- dh1 = W2 . dO
         f32x4 dh1[UT];
         {
@@ -788,6 +793,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
                 for (int tp = 0; tp < UT; ++tp) dh1[tp] = mfma_bf(a1[tp], so.hl, dh1[tp]);
             }
         }
+        DEC_TT(4);
         // ---- dW2 (and shortcut W): [h1 ; x]^T . dO
         wave_lds_order();
         u32x4 xT;
@@ -803,6 +809,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             aWs = mfma_bf(xT, dTh, aWs);
             aWs = mfma_bf(xT, dTm, aWs);
         }
+        DEC_TT(5);
         // ---- through tanh of layer 1
 #pragma unroll
         for (int tp = 0; tp < UT; ++tp) {
@@ -811,6 +818,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             if (!FS) ab1[tp] += dh1[tp];
         }
         wave_lds_order();
+        DEC_TT(6);
         // ---- dh0 = W1 . dh1pre, and the terms of dh1pre transposed for dW1
         f32x4 dh0[UT];
 #pragma unroll
@@ -821,6 +829,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             trb_write<UT>(scrQb, g, c, d1s);
             gemm_units<UT, UT, BT>(sm + I::B2, lane, d1s, dh0);
         }
+        DEC_TT(7);
         // ---- dW1 = h0^T . dh1pre
         wave_lds_order();
         {
@@ -839,6 +848,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
                 for (int tj = 0; tj < UT; ++tj) aW1[ti][tj] = mfma_bf(h0T, dTm[tj], aW1[ti][tj]);
             }
         }
+        DEC_TT(8);
         // ---- through tanh of layer 0
 #pragma unroll
         for (int tp = 0; tp < UT; ++tp) {
@@ -846,6 +856,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             for (int v = 0; v < 4; ++v) dh0[tp][v] *= 1.0f - h0[tp][v] * h0[tp][v];
         }
         wave_lds_order();
+        DEC_TT(9);
         // ---- dx = W0 . dh0pre + Ws . dO(mean)
         {
             unsigned d0s[3][4 * KB];
@@ -863,6 +874,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
                 }
             }
         }
+        DEC_TT(10);
         // ---- dW0 = x^T . dh0pre
         wave_lds_order();
 #pragma unroll
@@ -872,6 +884,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             aW0[tj] = mfma_bf(xT, dTm, aW0[tj]);
         }
         wave_lds_order();
+        DEC_TT(11);
     }
 
     // ---- reduce the per-wave accumulators through LDS.  Every parameter index is owned by exactly one (lane,
