@@ -922,7 +922,17 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
     }
     __syncthreads();
     SV_TS(17);
+#ifdef VMP_DEBUG_TS
+    int fw_it = -1;
+#define FW_TS(i) do { if (a.dbg_t && blockIdx.x == 0 && wave == 0 && fw_it == 8 && lane == 0) a.dbg_t[64 + (i)] = clock64(); } while (0)
+#else
+#define FW_TS(i) do { } while (0)
+#endif
     for (; t < ntiles; t += tstride) {
+#ifdef VMP_DEBUG_TS
+        ++fw_it;
+#endif
+        FW_TS(0);
         float* et = buf0 + (RNG ? 0 : cur) * (WAVE * CS);
         const long long row = t * RPT + r;
         const bool on = lane_on && row < a.N;
@@ -964,7 +974,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
             se = row_sum(ex, scr, lane, rbase, K);
         }
         const float lz = c - mx - __logf(se);
-        SV_USE(lz); SV_TS(19);
+        SV_USE(lz); SV_TS(19); FW_TS(1);
 
         // The factorisation above needed no noise: the previous tile's stores had that long to drain.  Now: next tile's
         // rows (plain loads), then ONE wait that retires this tile's DMA (issued a tile ago), the old stores and those
@@ -975,10 +985,15 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
 #pragma unroll
             for (int i = 0; i < L; ++i) { e1r[i] = a.eta1[rcn * L + i]; e2r[i] = a.eta2d[rcn * L + i]; }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!RNG) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < L; ++i) asm volatile("" : "+v"(e1r[i]), "+v"(e2r[i]));
-        SV_TS(20);
+            for (int i = 0; i < L; ++i) asm volatile("" : "+v"(e1r[i]), "+v"(e2r[i]));
+        }
+        // (in-kernel noise: there is no DMA to retire; the next tile's rows are simply requested here and waited for by the compiler
+        //  where the next factorisation uses them - a whole sample loop later.  The explicit vmcnt(0) also waited, in order, for the
+        //  PREVIOUS tile's sample stores: 3.3 k of a tile's 22.4 k cycles, profiles/r04_ring_stage_stamps.txt)
+        SV_TS(20); FW_TS(2);
         if constexpr (!RNG) { if (t + tstride < ntiles) issue_dma(t + tstride, buf0 + (cur ^ 1) * (WAVE * CS)); }
 
         v2f Lm2[TP], av2[LP];
@@ -1090,7 +1105,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
             a.Tp[row * K + k] = -0.5f * L * LOG_2PI + ld - 0.5f * invS * (eps2.x + eps2.y) + 0.5f * invS * (qth.x + qth.y) - kappak;
         }
         __builtin_amdgcn_wave_barrier();
-        SV_TS(21);
+        SV_TS(21); FW_TS(3);
 
         // ---- samples out: (cell, S, L) layout, coalesced
         {
@@ -1138,7 +1153,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
             }
         }
         __builtin_amdgcn_wave_barrier();
-        SV_TS(22);
+        SV_TS(22); FW_TS(4);
         cur ^= 1;
     }
 }
