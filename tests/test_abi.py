@@ -124,6 +124,35 @@ def test_peer_exchange_release_covers_every_storing_wave():
     assert seen >= 1
 
 
+def test_ring_backward_kernels_do_not_spill():
+    """The LDS-ring backward kernels of the SVAE E-step (csrc/vmp_svae_ring.h; TF's autodiff through svae.py:14-119, 229-252,
+    265-322) keep two sample pairs per wave in flight with COUNTED waits (s_waitcnt vmcnt(n)): vmcnt completes in order, so a
+    register-spill reload inside the sample loop can only be waited for with vmcnt(0) - it drains the ring (measured: Student-t
+    kernel 2.93 -> 3.68 ms with three reloads per pair).  Every instance in the shipped library must
+    fit its registers: private segment size 0 in the code object's metadata."""
+    import re
+    import subprocess
+    import sys
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import erratum_scan as E
+    readelf = E.OBJDUMP.replace('llvm-objdump', 'llvm-readelf')
+    if not os.path.exists(readelf):
+        pytest.skip('llvm-readelf not available')
+    blob = open(os.path.join(ROOT, 'vmp-for-svae_amd', 'lib', 'libvmp_hip.so'), 'rb').read()
+    seen = {}
+    for img in E.code_objects(blob):
+        with tempfile.NamedTemporaryFile(suffix='.co') as f:
+            f.write(img)
+            f.flush()
+            txt = subprocess.run([readelf, '--notes', f.name], capture_output=True, text=True).stdout
+        for m in re.finditer(r'\.name:\s+(\S*svae_estep_bwd_ring_kernel\S*).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)', txt, re.S):
+            seen[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+    assert len(seen) >= 12, sorted(seen)                       # L in {4, 6, 8} x (K = 16 | K < 16) x (Gaussian | Student-t)
+    spilled = {k: v for k, v in seen.items() if v[0] != 0}
+    assert not spilled, spilled
+
+
 def test_no_debug_exports_or_env_knobs_in_the_shipped_library():
     """include/vmp_hip.h promises 'no global state': the debug time-stamp hooks exist only in -DVMP_DEBUG_TS builds and
     no source reads the environment."""
