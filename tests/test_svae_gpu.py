@@ -115,7 +115,9 @@ def test_estep_vs_oracle_shapes():
                           # L = 8 with S / 2 odd: cells that start in mid-line take their pairs in rotated order (3 and 7 pairs)
                           (300, 16, 8, 6), (50, 16, 8, 14), (12501, 10, 8, 6),
                           # >= 1024 wave tiles with S / 2 >= 4: the shapes a four-stage build (-DVMP_RING_STAGES=4) takes
-                          (4101, 16, 8, 10), (6201, 10, 8, 8)]:
+                          (4101, 16, 8, 10), (6201, 10, 8, 8),
+                          # odd K (an odd number of cells per tile: the parity of a tile's first cell alternates) with rotated pairs
+                          (8301, 15, 8, 6), (14405, 9, 8, 6)]:
         e1 = rng.standard_normal((N, Ld))
         e2 = -0.5 * (0.3 + rng.random((N, Ld)))
         mu_k = rng.standard_normal((K, Ld)) * 2
@@ -170,7 +172,8 @@ def test_estep_vs_oracle_shapes_student_t():
                           # 8 <= K < 16: the ring kernel takes over above 2048 wave tiles (64 // K rows each)
                           (12500, 10, 8, 4), (8301, 15, 6, 4), (16501, 8, 8, 4), (10302, 12, 4, 6), (8303, 13, 8, 4),
                           (300, 16, 8, 6), (12501, 10, 8, 6),          # rotated pair order (S / 2 odd at L = 8)
-                          (4101, 16, 8, 10), (6201, 10, 8, 8)]:        # >= 1024 wave tiles with S / 2 >= 4 (four-stage builds)
+                          (4101, 16, 8, 10), (6201, 10, 8, 8),         # >= 1024 wave tiles with S / 2 >= 4 (four-stage builds)
+                          (8301, 15, 8, 6)]:                           # odd K with rotated pairs
         e1 = rng.standard_normal((N, Ld))
         e2 = -0.5 * (0.3 + rng.random((N, Ld)))
         mu_k = rng.standard_normal((K, Ld)) * 2
