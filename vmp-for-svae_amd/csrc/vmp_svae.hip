@@ -784,6 +784,9 @@ __global__ __launch_bounds__(256) void philox_noise_kernel(NoiseArgs a) {
 // compiler-generated wait ever covers a DMA in flight.
 // RNG = true: no noise tensor at all - eps is generated in registers (Philox4x32-10, above) right where it is consumed;
 // the LDS tile then only serves the (cell, S, L) output transposition.
+#ifndef VMP_FWD_BC_TILE
+#define VMP_FWD_BC_TILE 1
+#endif
 template <int L, int ST, bool RNG>
 __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(EFwdArgs a, int CS_rt) {
     SV_TS(23);
@@ -805,8 +808,13 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
     // two tile buffers per wave (the noise of the next tile arrives by DMA while this one is processed); with in-kernel noise
     // nothing is prefetched: ONE buffer, which lets 7 waves instead of 4 share the LDS of a CU
     constexpr int NBUF = RNG ? 1 : 2;
-    float* buf0 = smem + tab + wave * (NBUF * WAVE * CS + WAVE);
-    float* scr = buf0 + NBUF * WAVE * CS;
+    // cells per tile buffer: the noise-tensor form sizes its two buffers by the tile's CT = (64 / K) K cells, which at K = 10
+    // (60 cells) lets a FOURTH wave share the CU's 160 KB (VMP_FWD_BC_TILE, host side: fwd_tile_cells)
+    const int BC = (!RNG && VMP_FWD_BC_TILE) ? CT : WAVE;
+    // the 64-float scratch of the K != 16 row reductions: its own words with one buffer (in-kernel noise); with two buffers it
+    // lies in the OTHER buffer, which is idle between the previous tile's copy-out and the DMA issued after the softmax
+    constexpr int SCRW = RNG ? WAVE : 0;
+    float* buf0 = smem + tab + wave * (NBUF * BC * CS + SCRW);
     const bool lane_on = lane < CT;
     const int r = lane / K, k = lane - r * K, rbase = lane_on ? r * K : 0;
     const bool k16 = (K == 16);
@@ -894,8 +902,9 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
             const int cc = c < ncell ? c : ncell - 1;
             const int ss = sl < Q ? sl : Q - 1;
             const float* src = g + (long long)cc * LSn + 4 * ss;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(buf + w * (4 * WAVE)), 16, 0, 0);
+            if (c < BC)                                     // slots past the buffer's last cell (BC < 64) are not written
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(buf + w * (4 * WAVE)), 16, 0, 0);
             c += dcs; sl += drs;
             if (sl >= QS) { sl -= QS; c += 1; }
         }
@@ -933,7 +942,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
         ++fw_it;
 #endif
         FW_TS(0);
-        float* et = buf0 + (RNG ? 0 : cur) * (WAVE * CS);
+        float* et = buf0 + (RNG ? 0 : cur) * (BC * CS);
         const long long row = t * RPT + r;
         const bool on = lane_on && row < a.N;
         const long long rows_here = (a.N - t * RPT) < RPT ? (a.N - t * RPT) : RPT;
@@ -969,6 +978,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
             ex = on ? __expf(c - mx) : 0.f;
             se = row16_sum(ex);
         } else {
+            float* scr = buf0 + (RNG ? 1 : (cur ^ 1)) * (BC * CS);
             mx = row_max(c, scr, lane, rbase, K);
             ex = on ? __expf(c - mx) : 0.f;
             se = row_sum(ex, scr, lane, rbase, K);
@@ -994,7 +1004,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
         //  where the next factorisation uses them - a whole sample loop later.  The explicit vmcnt(0) also waited, in order, for the
         //  PREVIOUS tile's sample stores: 3.3 k of a tile's 22.4 k cycles, profiles/r04_ring_stage_stamps.txt)
         SV_TS(20); FW_TS(2);
-        if constexpr (!RNG) { if (t + tstride < ntiles) issue_dma(t + tstride, buf0 + (cur ^ 1) * (WAVE * CS)); }
+        if constexpr (!RNG) { if (t + tstride < ntiles) issue_dma(t + tstride, buf0 + (cur ^ 1) * (BC * CS)); }
 
         v2f Lm2[TP], av2[LP];
 #pragma unroll
@@ -1498,8 +1508,9 @@ static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
         int CS = L * S;
         if (((CS >> 2) & 1) == 0) CS += 4;
         const size_t table = (size_t)((K * ((L * (L + 1) / 2) | 1) + 3) & ~3) * sizeof(float);
-        const size_t pw = (size_t)(2 * WAVE * CS + WAVE) * sizeof(float);
-        int nw4 = (int)((158 * 1024 - table) / pw);
+        const int BC = VMP_FWD_BC_TILE ? (WAVE / K) * K : WAVE;   // cells per tile buffer (the kernel's BC)
+        const size_t pw = (size_t)(2 * BC * CS) * sizeof(float);      // (the row-reduction scratch lies in the idle buffer)
+        int nw4 = (int)((160 * 1024 - table) / pw);
         if (nw4 > 4) nw4 = 4;
         if (nw4 >= 1) {
             const size_t lds4 = table + pw * nw4;
