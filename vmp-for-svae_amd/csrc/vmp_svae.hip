@@ -784,6 +784,20 @@ __global__ __launch_bounds__(256) void philox_noise_kernel(NoiseArgs a) {
 // compiler-generated wait ever covers a DMA in flight.
 // RNG = true: no noise tensor at all - eps is generated in registers (Philox4x32-10, above) right where it is consumed;
 // the LDS tile then only serves the (cell, S, L) output transposition.
+// Noise-tensor form: the tile's noise DMA carries nt (bit 1) and its sample stores are streaming stores (bit 0) - a tile's 20 KB are
+// requested once, whole lines at a time, and its 20 KB of samples are not read again by this kernel.  Same box: K = 16 2.00 -> 1.88
+// and 2.07 -> 1.91 ms, K = 10 1.36 -> 1.28, Student-t 2.50 -> 2.34; either bit alone: 0-3 %.  (The in-kernel-noise form keeps plain
+// stores: VALU-bound, and at minibatch sizes the decoder reads the samples microseconds later.  The ring backward is the opposite
+// case - the two halves of a 128-byte line are asked for by different DMA instructions and the second must hit in L2: nt there
+// cost 40 %, csrc/vmp_svae_ring.h VMP_RING_NT.)
+#ifndef VMP_T2_NT
+#define VMP_T2_NT 3
+#endif
+template <bool NT>
+__device__ __forceinline__ void st_x4(float4* p, const float4& v) {
+    if constexpr (NT) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
+    else *p = v;
+}
 #ifndef VMP_FWD_BC_TILE
 #define VMP_FWD_BC_TILE 1
 #endif
@@ -893,7 +907,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
 #pragma unroll
                 for (int w = 0; w < QSc; ++w)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + dma_off[w]),
-                                                     (__attribute__((address_space(3))) void*)(buf + w * (4 * WAVE)), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void*)(buf + w * (4 * WAVE)), 16, 0, (VMP_T2_NT & 2) ? 2 : 0);
                 return;
             }
         }
@@ -904,7 +918,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
             const float* src = g + (long long)cc * LSn + 4 * ss;
             if (c < BC)                                     // slots past the buffer's last cell (BC < 64) are not written
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(buf + w * (4 * WAVE)), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(buf + w * (4 * WAVE)), 16, 0, (VMP_T2_NT & 2) ? 2 : 0);
             c += dcs; sl += drs;
             if (sl >= QS) { sl -= QS; c += 1; }
         }
@@ -1139,7 +1153,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
                         }
 #pragma unroll
                         for (int u = 0; u < CB; ++u)
-                            if (it0 + u < Qc && (it0 + u) * WAVE + lane < nf4) g4[(it0 + u) * WAVE] = v[u];
+                            if (it0 + u < Qc && (it0 + u) * WAVE + lane < nf4) st_x4<!RNG && (VMP_T2_NT & 1) != 0>(g4 + (it0 + u) * WAVE, v[u]);
                     }
                 } else {
                     int c2 = o_first, rem = orem_first;
@@ -1157,7 +1171,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
                         }
 #pragma unroll
                         for (int u = 0; u < CB; ++u)
-                            if (it0 + u < Q && (it0 + u) * WAVE + lane < nf4) g4[(it0 + u) * WAVE] = v[u];
+                            if (it0 + u < Q && (it0 + u) * WAVE + lane < nf4) st_x4<!RNG && (VMP_T2_NT & 1) != 0>(g4 + (it0 + u) * WAVE, v[u]);
                     }
                 }
             }

@@ -84,6 +84,9 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 //           requested four pairs ahead; no form is register-starved (the Student-t theta keeps W and all its sums in registers and
 //           runs the packed sample loop), and every memory operation inside the tile loop sits on a COUNTED wait: the tile's small
 //           inputs come by DMA one tile ahead, the row sums leave with one store per tile (see below).
+#ifndef VMP_RING_NT
+#define VMP_RING_NT 0        // A/B: 2 = the sample DMA carries nt
+#endif
 #ifdef VMP_DEBUG_TS
 // exploration builds: clock64 stamps of ONE tile (the 9th of block 0, wave 0) - tools/ring_ts.py
 #define RG_TS(i) do { if (a.dbg_t && blockIdx.x == 0 && wave == 0 && tile_it == 8 && lane == 0) a.dbg_t[i] = clock64(); } while (0)
@@ -295,9 +298,9 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
                 if (rotate) { pe = (unsigned)pp + (cpar[j] ^ par0); pe = pe >= (unsigned)NP ? pe - (unsigned)NP : pe; }
                 const unsigned ob = cbyte[j] + pe * (unsigned)(2 * L * 4);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + ob),
-                                                 (__attribute__((address_space(3))) void*)(stage + j * (4 * WAVE)), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(stage + j * (4 * WAVE)), 16, 0, VMP_RING_NT);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + ob),
-                                                 (__attribute__((address_space(3))) void*)(stage + WAVE * 2 * L + j * (4 * WAVE)), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(stage + WAVE * 2 * L + j * (4 * WAVE)), 16, 0, VMP_RING_NT);
             }
             return;
         }
@@ -311,9 +314,9 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
             if (rotate) { pe = pp + ((cc + (int)par0) & 1); pe = pe >= NP ? pe - NP : pe; }
             const long long off = tile0 + (long long)cc * LSn + pe * 2 * L + 4 * dp;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.x + off),
-                                             (__attribute__((address_space(3))) void*)(stage + j * (4 * WAVE)), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(stage + j * (4 * WAVE)), 16, 0, VMP_RING_NT);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.Gx + off),
-                                             (__attribute__((address_space(3))) void*)(stage + WAVE * 2 * L + j * (4 * WAVE)), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(stage + WAVE * 2 * L + j * (4 * WAVE)), 16, 0, VMP_RING_NT);
         }
     };
 
