@@ -824,11 +824,11 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
     constexpr int NBUF = RNG ? 1 : 2;
     // cells per tile buffer: the noise-tensor form sizes its two buffers by the tile's CT = (64 / K) K cells, which at K = 10
     // (60 cells) lets a FOURTH wave share the CU's 160 KB (VMP_FWD_BC_TILE, host side: fwd_tile_cells)
-    const int BC = (!RNG && VMP_FWD_BC_TILE) ? CT : WAVE;
-    // the 64-float scratch of the K != 16 row reductions: its own words with one buffer (in-kernel noise); with two buffers it
-    // lies in the OTHER buffer, which is idle between the previous tile's copy-out and the DMA issued after the softmax
-    constexpr int SCRW = RNG ? WAVE : 0;
-    float* buf0 = smem + tab + wave * (NBUF * BC * CS + SCRW);
+    const int BC = VMP_FWD_BC_TILE ? CT : WAVE;
+    // the 64-float scratch of the K != 16 row reductions lies in a tile buffer that is idle during the softmax: with two buffers the
+    // OTHER one (between the previous tile's copy-out and the DMA issued after the softmax), with one buffer (in-kernel noise) the
+    // buffer itself (between the previous tile's copy-out and this tile's first sample)
+    float* buf0 = smem + tab + wave * (NBUF * BC * CS);
     const bool lane_on = lane < CT;
     const int r = lane / K, k = lane - r * K, rbase = lane_on ? r * K : 0;
     const bool k16 = (K == 16);
@@ -992,7 +992,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
             ex = on ? __expf(c - mx) : 0.f;
             se = row16_sum(ex);
         } else {
-            float* scr = buf0 + (RNG ? 1 : (cur ^ 1)) * (BC * CS);
+            float* scr = buf0 + (RNG ? 0 : (cur ^ 1)) * (BC * CS);
             mx = row_max(c, scr, lane, rbase, K);
             ex = on ? __expf(c - mx) : 0.f;
             se = row_sum(ex, scr, lane, rbase, K);
@@ -1464,8 +1464,9 @@ static int fwd4_plan(int K, int L, int S, int& CS, size_t& lds4, bool rng = fals
     CS = L * S;
     if (((CS >> 2) & 1) == 0) CS += 4;
     const size_t table = (size_t)((K * ((L * (L + 1) / 2) | 1) + 3) & ~3) * sizeof(float);
-    const size_t pw = (size_t)((rng ? 1 : 2) * WAVE * CS + WAVE) * sizeof(float);
-    int nw4 = (int)((158 * 1024 - table) / pw);
+    const int BC = VMP_FWD_BC_TILE ? (WAVE / K) * K : WAVE;      // cells per tile buffer (the kernel's BC)
+    const size_t pw = (size_t)((rng ? 1 : 2) * BC * CS) * sizeof(float);
+    int nw4 = (int)((160 * 1024 - table) / pw);
     if (nw4 > (rng ? 8 : 4)) nw4 = rng ? 8 : 4;
     if (nw4 < 1) return 0;
     lds4 = table + pw * nw4;
