@@ -801,7 +801,10 @@ __device__ __forceinline__ void st_x4(float4* p, const float4& v) {
 #ifndef VMP_FWD_BC_TILE
 #define VMP_FWD_BC_TILE 1
 #endif
-template <int L, int ST, bool RNG>
+#ifndef VMP_FWD_PAIR_STAGE
+#define VMP_FWD_PAIR_STAGE 1          // 0: A/B builds without the per-pair staging form
+#endif
+template <int L, int ST, bool RNG, bool PS = false>
 __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(EFwdArgs a, int CS_rt) {
     SV_TS(23);
     constexpr int TRI = SvGeo<L>::TRI;
@@ -828,7 +831,15 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
     // the 64-float scratch of the K != 16 row reductions lies in a tile buffer that is idle during the softmax: with two buffers the
     // OTHER one (between the previous tile's copy-out and the DMA issued after the softmax), with one buffer (in-kernel noise) the
     // buffer itself (between the previous tile's copy-out and this tile's first sample)
-    float* buf0 = smem + tab + wave * (NBUF * BC * CS);
+    // PST (in-kernel noise, L = 8): no tile buffer at all.  The samples of a pair leave through a 4 KB per-wave staging area in OUTPUT
+    // order - lane = cell writes its four 16-byte pieces [sample][coordinates 0-3 | 4-7] with ds_write_b128, four adjacent lanes read
+    // back the 64 contiguous bytes of ONE cell and store them (16 cells x 64 B per store instruction): 4 + 4 LDS instructions per pair
+    // instead of 8 writes + 16 gathered 4-byte reads, and eight waves per CU where the tile buffer allows seven (K = 16, K = 9).
+    // (Where the tile buffer already admits eight waves - K = 10, 12: 60-cell tiles - this form measured 0-5 % SLOWER, same box;
+    // the host picks it only when it adds a wave: fwd4_plan.)  Piece j of cell c lies at position
+    // j ^ ((c >> 1) & 3) of the cell's 64 bytes: every 8-lane group of both the writes and the reads covers all 32 banks.
+    constexpr bool PST = RNG && L == 8 && PS;
+    float* buf0 = smem + tab + wave * (PST ? WAVE * 16 : NBUF * BC * CS);
     const bool lane_on = lane < CT;
     const int r = lane / K, k = lane - r * K, rbase = lane_on ? r * K : 0;
     const bool k16 = (K == 16);
@@ -967,6 +978,10 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
         // writes per 64-byte segment.)
         const bool full = a.vec_ok && (L & 3) == 0 && rows_here == RPT;
         const int nf4 = CT * Q;                             // float4s of a full tile
+        // PST: wave-uniform base of the tile's samples, number of valid cells
+        const long long tu = ((long long)__builtin_amdgcn_readfirstlane((int)(t >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+        float* __restrict__ xtile = a.x + tu * CT * LSn;
+        const int ncell_t = (int)rows_here * K;
 
         // ---- cell factorisation
         float Lm[TRI], av[L];
@@ -992,7 +1007,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
             ex = on ? __expf(c - mx) : 0.f;
             se = row16_sum(ex);
         } else {
-            float* scr = buf0 + (RNG ? 0 : (cur ^ 1)) * (BC * CS);
+            float* scr = buf0 + ((RNG || PST) ? 0 : (cur ^ 1)) * (BC * CS);
             mx = row_max(c, scr, lane, rbase, K);
             ex = on ? __expf(c - mx) : 0.f;
             se = row_sum(ex, scr, lane, rbase, K);
@@ -1091,7 +1106,38 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
             } else {
                 qth += del2;
             }
-            if (!full) {
+            if constexpr (PST) {
+                float* wp = buf0 + lane * 16;
+                const int sw = (lane >> 1) & 3;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {               // piece j = [sample j >> 1][coordinates 4 (j & 1) ..]
+                    const int i0 = 4 * (j & 1), h2 = j >> 1;
+                    *reinterpret_cast<f32x4*>(wp + 4 * (j ^ sw)) = f32x4{z[i0][h2], z[i0 + 1][h2], z[i0 + 2][h2], z[i0 + 3][h2]};
+                }
+                __builtin_amdgcn_wave_barrier();
+                // lane -> (cell 16 it + (lane >> 2), piece lane & 3); the cell's swizzle ((cell >> 1) & 3) does not depend on `it`
+                const float* rp = buf0 + (lane >> 2) * 16 + 4 * ((lane & 3) ^ ((lane >> 3) & 3));
+                f32x4 ov[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) ov[it] = *reinterpret_cast<const f32x4*>(rp + it * 256);
+                const int pc = lane & 3;
+                const bool pok = hv || pc < 2;              // an odd S: the last pair has one sample
+                float* __restrict__ gs = xtile + (unsigned)(s * L);      // wave-uniform: scalar base + 32-bit lane offset
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int cc = 16 * it + (lane >> 2);
+                    if (cc < ncell_t && pok) {
+                        const unsigned ob = (unsigned)(cc * LSn + 4 * pc) * 4u;
+                        if (a.vec_ok) {
+                            asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(ob), "v"(ov[it]), "s"(gs) : "memory");
+                        } else {
+                            float* dst = gs + (ob >> 2);
+                            dst[0] = ov[it][0]; dst[1] = ov[it][1]; dst[2] = ov[it][2]; dst[3] = ov[it][3];
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else if (!full) {
                 // tiles that are not 64 whole cells (K does not divide 64, or the last rows): every lane stores its own
                 // cell's two sample rows - 2 * 4L contiguous bytes - straight from registers.  (Staging them in LDS and
                 // copying out element by element cost ~20 index instructions per float: 3.9 us of a 12 us launch at
@@ -1134,7 +1180,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
         // ---- samples out: (cell, S, L) layout, coalesced
         {
             float* __restrict__ g = a.x + t * CT * LSn;
-            if (full) {
+            if (!PST && full) {
                 float4* __restrict__ g4 = reinterpret_cast<float4*>(g) + lane;
                 constexpr int L4 = (L / 4 > 0) ? L / 4 : 1;
                 // batches of CB float4s: all their LDS reads in flight before the first store (one wave per SIMD: nobody
@@ -1458,16 +1504,23 @@ size_t vmp_svae_workspace_bytes(int64_t N, int K, int L) {
 int vmp_svae_bwd_blocks(int64_t N, int K) { return sv_blocks(N, K); }
 
 // LDS-DMA / in-kernel-noise forward kernel: launch geometry, or 0 waves when the shape is not covered
-static int fwd4_plan(int K, int L, int S, int& CS, size_t& lds4, bool rng = false) {
+static int fwd4_plan(int K, int L, int S, int& CS, size_t& lds4, bool rng = false, bool* pair_stage = nullptr) {
+    if (pair_stage) *pair_stage = false;
     if ((L * S) % 4 != 0) return 0;
     if ((size_t)(L * S | 1) * WAVE * sizeof(float) > 36 * 1024) return 0;
     CS = L * S;
     if (((CS >> 2) & 1) == 0) CS += 4;
     const size_t table = (size_t)((K * ((L * (L + 1) / 2) | 1) + 3) & ~3) * sizeof(float);
     const int BC = VMP_FWD_BC_TILE ? (WAVE / K) * K : WAVE;      // cells per tile buffer (the kernel's BC)
-    const size_t pw = (size_t)((rng ? 1 : 2) * BC * CS) * sizeof(float);
+    size_t pw = (size_t)((rng ? 1 : 2) * BC * CS) * sizeof(float);
     int nw4 = (int)((160 * 1024 - table) / pw);
     if (nw4 > (rng ? 8 : 4)) nw4 = rng ? 8 : 4;
+    if (rng && L == 8 && VMP_FWD_PAIR_STAGE && nw4 < 8 && pair_stage) {
+        // in-kernel noise, and the tile buffer leaves a wave slot empty (K = 16: seven waves): the per-pair staging form (PST)
+        *pair_stage = true;
+        pw = (size_t)WAVE * 16 * sizeof(float);
+        nw4 = 8;
+    }
     if (nw4 < 1) return 0;
     lds4 = table + pw * nw4;
     return nw4;
@@ -1484,14 +1537,23 @@ static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
     if (rng) {
         int CS = 0;
         size_t lds4 = 0;
-        const int nw4 = fwd4_plan(K, L, S, CS, lds4, true);
+        bool ps = false;
+        const int nw4 = fwd4_plan(K, L, S, CS, lds4, true, &ps);
         if (nw4 < 1) { set_error("in-kernel noise covers L*S %% 4 == 0 tiles that fit the LDS only (L=%d, S=%d)", L, S); return VMP_E_DIM; }
         const int RPT4 = WAVE / K;
         long long bl = ((N + RPT4 - 1) / RPT4 + nw4 - 1) / nw4;
         if (bl > 256) bl = 256;
         rc = -1;
         VMP_DISPATCH_L(L, {
-            if (S == 10) {
+            if (LL == 8 && ps) {
+                if (S == 10) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<8, 10, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                    hipLaunchKernelGGL((svae_estep_fwd4_kernel<8, 10, true, true>), dim3((int)bl), dim3(nw4 * WAVE), lds4, static_cast<hipStream_t>(stream), a, CS);
+                } else {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<8, 0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                    hipLaunchKernelGGL((svae_estep_fwd4_kernel<8, 0, true, true>), dim3((int)bl), dim3(nw4 * WAVE), lds4, static_cast<hipStream_t>(stream), a, CS);
+                }
+            } else if (S == 10) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<LL, 10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
                 hipLaunchKernelGGL((svae_estep_fwd4_kernel<LL, 10, true>), dim3((int)bl), dim3(nw4 * WAVE), lds4, static_cast<hipStream_t>(stream), a, CS);
             } else {
