@@ -46,7 +46,9 @@ def test_kernel_stream_equals_oracle(N, K, Ld, S):
 @pytest.mark.parametrize('N,K,Ld,S', [(1000, 16, 8, 10), (77, 10, 6, 10), (50, 5, 2, 10), (40, 4, 3, 5), (33, 16, 8, 6),
                                       # the per-pair staging form of the L = 8 kernel (K whose tile buffer admits seven waves): odd S (a last
                                       # pair with one sample), ragged last tiles, K < 16 with 63-cell tiles, several blocks
-                                      (37, 16, 8, 5), (5003, 16, 8, 10), (130, 9, 8, 10), (20, 7, 8, 3), (301, 8, 8, 4)])
+                                      (37, 16, 8, 5), (5003, 16, 8, 10), (130, 9, 8, 10), (20, 7, 8, 3), (301, 8, 8, 4),
+                                      # S too large for a tile buffer (evaluation runs: S = 100): the staging form has no S-sized buffer
+                                      (50, 16, 8, 20), (21, 10, 8, 24), (9, 16, 8, 100)])
 def test_in_kernel_noise_equals_materialised_stream(N, K, Ld, S):
     """E-step with eps drawn in the kernel == E-step fed with the same stream as a tensor (value AND gradients)."""
     from vmp_for_svae_amd.models import svae, _svae_ops

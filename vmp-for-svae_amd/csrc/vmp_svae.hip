@@ -825,12 +825,9 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
     // two tile buffers per wave (the noise of the next tile arrives by DMA while this one is processed); with in-kernel noise
     // nothing is prefetched: ONE buffer, which lets 7 waves instead of 4 share the LDS of a CU
     constexpr int NBUF = RNG ? 1 : 2;
-    // cells per tile buffer: the noise-tensor form sizes its two buffers by the tile's CT = (64 / K) K cells, which at K = 10
-    // (60 cells) lets a FOURTH wave share the CU's 160 KB (VMP_FWD_BC_TILE, host side: fwd_tile_cells)
+    // cells per tile buffer: the buffers are sized by the tile's CT = (64 / K) K cells, which at K = 10 (60 cells) lets a FOURTH
+    // wave of the noise-tensor form (an EIGHTH of the in-kernel-noise form) share the CU's 160 KB (host side: fwd4_plan, run_fwd)
     const int BC = VMP_FWD_BC_TILE ? CT : WAVE;
-    // the 64-float scratch of the K != 16 row reductions lies in a tile buffer that is idle during the softmax: with two buffers the
-    // OTHER one (between the previous tile's copy-out and the DMA issued after the softmax), with one buffer (in-kernel noise) the
-    // buffer itself (between the previous tile's copy-out and this tile's first sample)
     // PST (in-kernel noise, L = 8): no tile buffer at all.  The samples of a pair leave through a 4 KB per-wave staging area in OUTPUT
     // order - lane = cell writes its four 16-byte pieces [sample][coordinates 0-3 | 4-7] with ds_write_b128, four adjacent lanes read
     // back the 64 contiguous bytes of ONE cell and store them (16 cells x 64 B per store instruction): 4 + 4 LDS instructions per pair
@@ -1007,7 +1004,10 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
             ex = on ? __expf(c - mx) : 0.f;
             se = row16_sum(ex);
         } else {
-            float* scr = buf0 + ((RNG || PST) ? 0 : (cur ^ 1)) * (BC * CS);
+            // the 64-float scratch of the K != 16 row reductions lies in LDS that is idle during the softmax: with two buffers the
+            // OTHER one (between the previous tile's copy-out and the DMA issued after the softmax), with one buffer or the pair
+            // staging area (in-kernel noise) that area itself (between the previous tile's last store and this tile's first sample)
+            float* scr = buf0 + (RNG ? 0 : (cur ^ 1)) * (BC * CS);
             mx = row_max(c, scr, lane, rbase, K);
             ex = on ? __expf(c - mx) : 0.f;
             se = row_sum(ex, scr, lane, rbase, K);
@@ -1506,17 +1506,18 @@ int vmp_svae_bwd_blocks(int64_t N, int K) { return sv_blocks(N, K); }
 // LDS-DMA / in-kernel-noise forward kernel: launch geometry, or 0 waves when the shape is not covered
 static int fwd4_plan(int K, int L, int S, int& CS, size_t& lds4, bool rng = false, bool* pair_stage = nullptr) {
     if (pair_stage) *pair_stage = false;
-    if ((L * S) % 4 != 0) return 0;
-    if ((size_t)(L * S | 1) * WAVE * sizeof(float) > 36 * 1024) return 0;
     CS = L * S;
     if (((CS >> 2) & 1) == 0) CS += 4;
     const size_t table = (size_t)((K * ((L * (L + 1) / 2) | 1) + 3) & ~3) * sizeof(float);
     const int BC = VMP_FWD_BC_TILE ? (WAVE / K) * K : WAVE;      // cells per tile buffer (the kernel's BC)
     size_t pw = (size_t)((rng ? 1 : 2) * BC * CS) * sizeof(float);
-    int nw4 = (int)((160 * 1024 - table) / pw);
+    // the tile-buffer forms: whole 16-byte pieces per cell, and a cell's noise block inside the per-wave LDS tile
+    const bool fits = (L * S) % 4 == 0 && (size_t)(L * S | 1) * WAVE * sizeof(float) <= 36 * 1024;
+    int nw4 = fits ? (int)((160 * 1024 - table) / pw) : 0;
     if (nw4 > (rng ? 8 : 4)) nw4 = rng ? 8 : 4;
     if (rng && L == 8 && VMP_FWD_PAIR_STAGE && nw4 < 8 && pair_stage) {
-        // in-kernel noise, and the tile buffer leaves a wave slot empty (K = 16: seven waves): the per-pair staging form (PST)
+        // in-kernel noise, and the tile buffer leaves a wave slot empty (K = 16: seven waves) or does not fit at all (large S:
+        // evaluation runs use S = 100, experiments.py:283): the per-pair staging form (PST), which has no S-sized buffer
         *pair_stage = true;
         pw = (size_t)WAVE * 16 * sizeof(float);
         nw4 = 8;
@@ -1652,7 +1653,8 @@ int vmp_svae_estep_fwd(const float* eta1, const float* eta2d, const float* hk, c
 int vmp_svae_rng_in_kernel(int K, int L, int S) {
     int CS = 0;
     size_t lds4 = 0;
-    return (K >= 1 && K <= 64 && L >= 1 && L <= 8 && fwd4_plan(K, L, S, CS, lds4, true) >= 1) ? 1 : 0;
+    bool ps = false;
+    return (K >= 1 && K <= 64 && L >= 1 && L <= 8 && fwd4_plan(K, L, S, CS, lds4, true, &ps) >= 1) ? 1 : 0;
 }
 
 static int philox_noise_impl(uint64_t seed, const uint64_t* seed_dev, int64_t N, int K, int L, int S, float* noise, void* stream) {
