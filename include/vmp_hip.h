@@ -154,8 +154,8 @@ int    vmp_svae_estep_fwd(const float* eta1, const float* eta2d, const float* hk
  * Same operation with eps generated where it is consumed: Philox4x32-10 keyed by `seed`, counter = (cell low, cell high,
  * block, 0), cell = n K + k, block b = (i >> 1) ceil(S/2) + (s >> 1) -> Box-Muller normals of elements (i,s), (i,s+1),
  * (i+1,s), (i+1,s+1) of the cell's (L,S) noise block.  No (N,K,L,S) tensor is read or written; the backward pass needs
- * none (it works from the saved samples x).  Shapes outside the in-kernel path (vmp_svae_rng_in_kernel == 0: L*S not a
- * multiple of 4, or a cell tile larger than the LDS) materialise the same stream in `noise_ws` (N,K,L,S) first.
+ * none (it works from the saved samples x).  Shapes outside the in-kernel path (vmp_svae_rng_in_kernel == 0: L < 8 and L*S
+ * not a multiple of 4 or a cell tile larger than the LDS; L = 8 is covered for every S) materialise the same stream in `noise_ws` (N,K,L,S) first.
  * vmp_svae_philox_noise writes that stream as a tensor (tests; callers that want to keep the draw).               */
 int    vmp_svae_rng_in_kernel(int K, int L, int S);
 int    vmp_svae_philox_noise(uint64_t seed, int64_t N, int K, int L, int S, float* noise, void* stream);

@@ -1540,7 +1540,7 @@ static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
         size_t lds4 = 0;
         bool ps = false;
         const int nw4 = fwd4_plan(K, L, S, CS, lds4, true, &ps);
-        if (nw4 < 1) { set_error("in-kernel noise covers L*S %% 4 == 0 tiles that fit the LDS only (L=%d, S=%d)", L, S); return VMP_E_DIM; }
+        if (nw4 < 1) { set_error("in-kernel noise covers L = 8, and L < 8 with L*S %% 4 == 0 tiles that fit the LDS (L=%d, S=%d)", L, S); return VMP_E_DIM; }
         const int RPT4 = WAVE / K;
         long long bl = ((N + RPT4 - 1) / RPT4 + nw4 - 1) / nw4;
         if (bl > 256) bl = 256;
