@@ -35,6 +35,19 @@ def test_size_helpers():
     assert lib.vmp_mix_workspace_bytes(10**6, 8, 16) > 0
 
 
+def test_in_kernel_noise_plan_is_host_logic():
+    """vmp_svae_rng_in_kernel (include/vmp_hip.h; eps of svae.py:113-114 drawn inside the E-step): a pure host query.  L = 8 is covered
+    for every S (the per-pair staging form has no S-sized buffer: evaluation runs use S = 100, experiments.py:283); L < 8 needs whole
+    16-byte pieces per cell and a cell tile inside the LDS."""
+    import vmp_for_svae_amd as V
+    q = V._lib.lib().vmp_svae_rng_in_kernel
+    assert q(16, 8, 10) == 1 and q(10, 8, 10) == 1 and q(16, 8, 100) == 1 and q(9, 8, 7) == 1
+    assert q(16, 4, 10) == 1 and q(5, 2, 10) == 1
+    assert q(16, 7, 10) == 0                     # 70 floats per cell: not a multiple of 4
+    assert q(16, 6, 100) == 0                    # 600-float cells: no tile buffer, and the staging form is the L = 8 kernel's
+    assert q(0, 8, 10) == 0 and q(65, 8, 10) == 0 and q(16, 9, 10) == 0
+
+
 def test_no_cpu_fallback():
     import vmp_for_svae_amd as V
     from vmp_for_svae_amd.models import gmm, _mix
