@@ -82,9 +82,97 @@ def cpu_baseline(x, r0, workload, chunk=1 << 15, reps=3):
 
 
 
-def bench_t2(N, Ld, K, S, steps, warmup, dev, dist=None, world=1, smm=False):
+def _best_threads(fn, cands, reps):
+    """fastest of `reps` timed calls of fn() at each thread count (one untimed call first); (seconds, threads)"""
+    best, best_t = float('inf'), cands[0]
+    for th in cands:
+        torch.set_num_threads(th)
+        fn()
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            dt = time.perf_counter() - t0
+            if dt < best:
+                best, best_t = dt, th
+    torch.set_num_threads(best_t)
+    return best, best_t
+
+
+def _cpu_model_inputs(K, Ld, Dy, U, Ns, S, seed=1):
+    """synthetic inputs of the oracle's SVAE step (weights ~ N(0, 0.01^2), y = GMM data, eps ~ N(0,1))"""
+    from oracle import nets, svae_ref
+    rng = np.random.Generator(np.random.PCG64(seed))
+    w = {}
+    for scope, din, dout in (('encoder_net', Dy, Ld), ('decoder_net', Ld, Dy)):
+        shapes = {'layer_0/kernel': (din, U), 'layer_0/bias': (U,), 'layer_1/kernel': (U, U), 'layer_1/bias': (U,),
+                  'gaussian_output/kernel': (U, 2 * dout), 'gaussian_output/bias': (2 * dout,), 'shortcut/b1': (dout,),
+                  'shortcut/b2': (dout,)}
+        for n_, shp in shapes.items():
+            w[scope + '/' + n_] = torch.as_tensor((rng.standard_normal(shp) * 0.01).astype(np.float32))
+        w[scope + '/shortcut/W'] = torch.as_tensor(nets.rand_partial_isometry(din, dout, 1., 0).astype(np.float32))
+    prior, theta = svae_ref.init_mm(K, Ld, torch.as_tensor(rng.random((K, Ld)).astype(np.float32)), torch.float32)
+    phi = svae_ref.init_recognition_params(theta, torch.as_tensor(rng.standard_normal(K).astype(np.float32)))
+    noise = torch.as_tensor(rng.standard_normal((Ns, K, Ld, S)).astype(np.float32))
+    zd = torch.as_tensor(rng.integers(0, K, size=(Ns, S)))
+    return rng, w, prior, theta, phi, noise, zd
+
+
+def _smm_theta(prior, theta, rng, K, Ld):
+    """Student-t theta of the oracle (svae.py:265-322): (alpha_nat, mu_k, L_k raw, DoF), components spread out"""
+    from oracle import svae_ref
+    mu_t, L_t = svae_ref.make_loc_scale(prior)
+    mu_t = mu_t + torch.as_tensor(rng.standard_normal((K, Ld)).astype(np.float32))
+    return [theta[0].clone(), mu_t, L_t, torch.full((K,), 5.0)], prior[0]
+
+
+def cpu_baseline_t2(K, Ld, S, smm=False, Ns=8192, reps=2):
+    """The reference CPU path of the T2 unit ("fwd+bwd+M-step for T2/T3"): oracle.train_ref.vmp_step_t2 - the
+    literal restatement of svae.e_step, the regulariser of compute_elbo(_smm), autodiff, subsample_x, m_step and
+    update_gmm_params (models/svae.py:14-262, 376-403) in fp32 torch-CPU - on a bounded sample of Ns rows of the same shape."""
+    from oracle import train_ref
+    rng, _, prior, theta, phi, noise, zd = _cpu_model_inputs(K, Ld, Ld, 8, Ns, S)
+    if smm:
+        theta, prior = _smm_theta(prior, theta, rng, K, Ld)
+    e1 = torch.as_tensor(rng.standard_normal((Ns, Ld)).astype(np.float32))
+    e2 = -0.5 * torch.nn.functional.softplus(torch.as_tensor(rng.standard_normal((Ns, Ld)).astype(np.float32)))
+    Gx = torch.as_tensor(rng.standard_normal((Ns, K, S, Ld)).astype(np.float32)) * 0.01
+    Glz = torch.as_tensor(rng.standard_normal((Ns, K)).astype(np.float32)) * 0.1
+    ncpu = os.cpu_count() or 1
+    cands = sorted({t for t in (8, 32) if t <= ncpu}) or [ncpu]
+    best, best_t = _best_threads(lambda: train_ref.vmp_step_t2(phi, theta, prior, e1, e2, noise, zd, Gx, Glz, 0.2, smm=smm, chunk=4096), cands, reps)
+    return {'value': Ns / best, 'unit': 'datapoints/s', 'cores': best_t, 'kind': 'port', 'host_hw_threads': ncpu,
+            'thread_counts_tried': cands, 'seconds_per_step_at_sample': best,
+            'sample': 'one T2 %s-svae VMP step (oracle.train_ref.vmp_step_t2: e_step fwd + regulariser + autodiff + subsample + m_step + CVI, '
+                      'fp32 torch-CPU, N-chunks of 4096) on %d rows of the workload shape (K=%d, L=%d, S=%d); fastest of %d timed runs at each of %s threads'
+                      % ('smm' if smm else 'gmm', Ns, K, Ld, S, reps, cands)}
+
+
+def cpu_baseline_t3(K, Ld, S, U, smm=False, Ns=8192, reps=2):
+    """The reference CPU path of the T3 unit: oracle.train_ref.train_step (experiments.py:196-267 op for op: encoder, E-step,
+    decoder, ELBO, autodiff of all 21 / 23 variables, M-step, CVI, TF-Adam) in fp32 torch-CPU on a bounded sample of Ns rows."""
+    from oracle import nets, train_ref
+    rng, w, prior, theta, phi, noise, zd = _cpu_model_inputs(K, Ld, Ld, U, Ns, S)
+    if smm:
+        theta, prior = _smm_theta(prior, theta, rng, K, Ld)
+    st = train_ref.State(phi, {n_: w['encoder_net/' + n_] for n_ in nets.NET_VARS},
+                         {n_: w['decoder_net/' + n_] for n_ in nets.NET_VARS}, theta, prior, smm=smm)
+    y = torch.as_tensor(synth(Ns, Ld, K, seed=7)[0])
+    ncpu = os.cpu_count() or 1
+    cands = sorted({t for t in (8, 32) if t <= ncpu}) or [ncpu]
+    best, best_t = _best_threads(lambda: train_ref.train_step(st, y, noise, zd, 3e-4, 0.2, 0.95, towers=max(1, Ns // 4096)), cands, reps)
+    return {'value': Ns / best, 'unit': 'datapoints/s', 'cores': best_t, 'kind': 'port', 'host_hw_threads': ncpu,
+            'thread_counts_tried': cands, 'seconds_per_step_at_sample': best,
+            'sample': 'one T3 %s-svae training step (oracle.train_ref.train_step = experiments.py:196-267, fp32 torch-CPU, towers of 4096 rows) '
+                      'on %d rows of the workload shape (K=%d, L=Dy=%d, S=%d, U=%d); fastest of %d timed runs at each of %s threads'
+                      % ('smm' if smm else 'gmm', Ns, K, Ld, S, U, reps, cands)}
+
+
+def bench_t2(N, Ld, K, S, steps, warmup, dev, dist=None, world=1, smm=False, cpu=False):
     """T2: SVAE VMP step without the MLPs - fused E-step forward (log_z, samples, regulariser terms),
     its backward (given decoder-side gradients), categorical sub-sampling, M-step moments and the CVI update.
+    The step draws its OWN noise, as sample_x_per_comp does (svae.py:113-114).  Headline (`ms_per_step`): the form SVAETrainer runs
+    by default - eps generated inside the forward kernel, fresh key every step; algorithmic bytes 4N(2KSL + 2K + 4L).  Side
+    measurement (`noise_tensor`): the same step with a noise TENSOR, its per-step normal_() INSIDE the timed step; 4N(4KSL + 2K + 4L).
     smm=True: Student-t theta (svae.py:265-322; theta/mu_k, theta/L_k trainable, M-step = N_k only, experiments.py:154-176)."""
     import vmp_for_svae_amd as V
     from vmp_for_svae_amd.models import svae, _mix
@@ -101,81 +189,95 @@ def bench_t2(N, Ld, K, S, steps, warmup, dev, dist=None, world=1, smm=False):
         theta = [theta[0].clone(), mu_t, L_t, torch.full((K,), 5.0, device=dev)]
         prior = prior[0]
         th_params = [mu_t, L_t]
-    noise = torch.randn(N, K, Ld, S, device=dev, generator=g)
     Gx = torch.randn(N, K, S, Ld, device=dev, generator=g) * 0.01
     Glz = torch.randn(N, K, device=dev, generator=g) * 0.1
-    evf = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    evb = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    E = lambda: [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
 
-    def one(i, timed):
-        if timed:
-            evf[i][0].record()
-        x, lz, pt, _ = svae.e_step((eta1, eta2d), phi, S, noise=noise, theta=theta)
-        if timed:
-            evf[i][1].record()
-        r = torch.exp(lz.detach())
-        if timed:
-            evb[i][0].record()
-        grads = torch.autograd.grad([x, lz, pt.T_prime], [eta1, eta2d] + phi + th_params, [Gx, Glz, r])
-        if timed:
-            evb[i][1].record()
-        xs = svae.subsample_x(x, lz, seed=i, nb_out=1)[:, 0, :].contiguous()
-        if smm:                                               # svae.m_step_smm: N_k only (svae.py:179-196)
-            from vmp_for_svae_amd.models import gmm as _gmm
-            st = _gmm.update_Nk(r.contiguous()).double().reshape(-1, 1)
-        else:
-            st = _mix.raw_stats(xs, r)
+    def run(mode):
+        """`warmup` + `steps` self-contained steps; returns (seconds, mean ms of [noise draw, forward, backward])"""
+        noise = torch.empty(N, K, Ld, S, device=dev) if mode == 'tensor' else None
+        ev = [E() for _ in range(5)]
+
+        def one(i, timed):
+            if timed:
+                ev[0][i].record()
+            if mode == 'tensor':
+                noise.normal_(generator=g)                    # the step's draw (tf.random_normal, svae.py:113-114)
+                if timed:
+                    ev[1][i].record()
+                x, lz, pt, _ = svae.e_step((eta1, eta2d), phi, S, noise=noise, theta=theta)
+            else:
+                if timed:
+                    ev[1][i].record()
+                x, lz, pt, _ = svae.e_step((eta1, eta2d), phi, S, seed=1000 + i, noise='philox', theta=theta)
+            if timed:
+                ev[2][i].record()
+            r = torch.exp(lz.detach())
+            if timed:
+                ev[3][i].record()
+            grads = torch.autograd.grad([x, lz, pt.T_prime], [eta1, eta2d] + phi + th_params, [Gx, Glz, r])
+            if timed:
+                ev[4][i].record()
+            xs = svae.subsample_x(x, lz, seed=i, nb_out=1)[:, 0, :].contiguous()
+            if smm:                                               # svae.m_step_smm: N_k only (svae.py:179-196)
+                from vmp_for_svae_amd.models import gmm as _gmm
+                st = _gmm.update_Nk(r.contiguous()).double().reshape(-1, 1)
+            else:
+                st = _mix.raw_stats(xs, r)
+            if dist is not None:
+                from vmp_for_svae_amd.models.parallel_mix import allreduce_sum_
+                buf = torch.cat([st.reshape(-1)] + [gg.reshape(-1).double() for gg in grads[2:]])
+                allreduce_sum_(buf)                               # RCCL all-reduce of the packed fp64 buffer (gloo: host-staged)
+                st = buf[:st.numel()].reshape(st.shape)
+            if smm:
+                svae.update_gmm_params(theta[:1], [prior + st[:, 0].float()], 0.2)
+            else:
+                svae.update_gmm_params(theta, svae.m_step_from_stats(prior, st), 0.2)
+
+        for i in range(warmup):
+            one(i, False)
         if dist is not None:
-            from vmp_for_svae_amd.models.parallel_mix import allreduce_sum_
-            buf = torch.cat([st.reshape(-1)] + [gg.reshape(-1).double() for gg in grads[2:]])
-            allreduce_sum_(buf)                               # RCCL all-reduce of the packed fp64 buffer (gloo: host-staged)
-            st = buf[:st.numel()].reshape(st.shape)
-        if smm:
-            svae.update_gmm_params(theta[:1], [prior + st[:, 0].float()], 0.2)
-        else:
-            svae.update_gmm_params(theta, svae.m_step_from_stats(prior, st), 0.2)
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one(i, True)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt_ = max_over_ranks(dist, time.perf_counter() - t0, dev)
+        ms = [float(np.mean([a.elapsed_time(b) for a, b in zip(ev[j], ev[j + 1])])) for j in (0, 1, 3)]
+        del noise
+        torch.cuda.empty_cache()
+        return dt_, ms
 
-    for i in range(warmup):
-        one(i, False)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        one(i, True)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = max_over_ranks(dist, time.perf_counter() - t0, dev)
-    # the same forward with eps drawn inside the kernel (Philox4x32-10), and what the noise tensor costs to produce
-    evp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
-    evr = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
-    with torch.no_grad():
-        for i in range(4):
-            evp[i][0].record()
-            xp, lzp, ptp, _ = svae.e_step((eta1, eta2d), phi, S, seed=i, noise='philox', theta=theta)
-            evp[i][1].record()
-            del xp, lzp, ptp
-            evr[i][0].record()
-            noise.normal_(generator=g)
-            evr[i][1].record()
-    torch.cuda.synchronize()
-    p_ms = float(np.median([a.elapsed_time(b) for a, b in evp[1:]]))
-    r_ms = float(np.median([a.elapsed_time(b) for a, b in evr[1:]]))
-    f_ms = float(np.mean([a.elapsed_time(b) for a, b in evf]))
-    b_ms = float(np.mean([a.elapsed_time(b) for a, b in evb]))
-    alg = 4.0 * N * (4.0 * K * S * Ld + 2 * K + 4 * Ld)         # SURVEY 8d T2 bytes per step, injected noise
-    fwd_bytes = 4.0 * N * (2.0 * K * S * Ld + 2 * Ld + 2 * K)   # reads eps + eta, writes x + log_z + T'
-    bwd_bytes = 4.0 * N * (2.0 * K * S * Ld + 4 * Ld + 3 * K)   # reads x + dx + (lz, dlz, dT'), writes d eta
-    return {'steps_per_sec': steps / dt, 'ms_per_step': dt / steps * 1e3, 'datapoints_per_sec': N * world * steps / dt,
-            'algorithmic_bytes_per_step': alg, 'algorithmic_GBps_whole_step': alg / (dt / steps) / 1e9,
-            'fwd_kernel_ms': f_ms, 'bwd_kernel_ms': b_ms, 'fwd_in_kernel_philox_ms': p_ms, 'noise_tensor_randn_ms': r_ms,
-            'fwd_GBps': fwd_bytes / (f_ms * 1e-3) / 1e9, 'bwd_GBps': bwd_bytes / (b_ms * 1e-3) / 1e9,
-            'fwd_frac_hbm': fwd_bytes / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'bwd_frac_hbm': bwd_bytes / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            'config': 'T2 %s-svae-vmp N=%d per GPU, L=%d, K=%d, S=%d (fwd+bwd of the fused E-step, sub-sampling, M-step, CVI)' % ('smm' if smm else 'gmm', N, Ld, K, S)}
+    dt, (_, f_ms, b_ms) = run('philox')
+    dt_n, (rn_ms, fn_ms, bn_ms) = run('tensor')
+    alg = 4.0 * N * (2.0 * K * S * Ld + 2 * K + 4 * Ld)          # SURVEY 8d T2 bytes per step, in-kernel generator
+    alg_n = 4.0 * N * (4.0 * K * S * Ld + 2 * K + 4 * Ld)        # ... with an injected noise tensor
+    fwd_bytes = 4.0 * N * (1.0 * K * S * Ld + 2 * Ld + 2 * K)    # reads eta, writes x + log_z + T'
+    fwd_bytes_n = 4.0 * N * (2.0 * K * S * Ld + 2 * Ld + 2 * K)  # + reads eps
+    bwd_bytes = 4.0 * N * (2.0 * K * S * Ld + 4 * Ld + 3 * K)    # reads x + dx + (lz, dlz, dT'), writes d eta
+    gb = lambda by, ms_: by / (ms_ * 1e-3) / 1e9
+    res = {'steps_per_sec': steps / dt, 'ms_per_step': dt / steps * 1e3, 'datapoints_per_sec': N * world * steps / dt,
+           'noise': 'drawn inside the forward kernel, fresh key every step (SVAETrainer default)',
+           'algorithmic_bytes_per_step': alg, 'algorithmic_GBps_whole_step': alg / (dt / steps) / 1e9,
+           'frac_hbm_whole_step': alg / (dt / steps) / 1e9 / HBM_PEAK_GBS,
+           'fwd_kernel_ms': f_ms, 'bwd_kernel_ms': b_ms,
+           'fwd_GBps': gb(fwd_bytes, f_ms), 'bwd_GBps': gb(bwd_bytes, b_ms),
+           'fwd_frac_hbm': gb(fwd_bytes, f_ms) / HBM_PEAK_GBS, 'bwd_frac_hbm': gb(bwd_bytes, b_ms) / HBM_PEAK_GBS,
+           'noise_tensor': {'ms_per_step': dt_n / steps * 1e3, 'includes': 'the per-step normal_() of the (N,K,L,S) tensor',
+                            'randn_ms': rn_ms, 'fwd_kernel_ms': fn_ms, 'bwd_kernel_ms': bn_ms,
+                            'algorithmic_bytes_per_step': alg_n, 'frac_hbm_whole_step': alg_n / (dt_n / steps) / 1e9 / HBM_PEAK_GBS,
+                            'fwd_frac_hbm': gb(fwd_bytes_n, fn_ms) / HBM_PEAK_GBS, 'bwd_frac_hbm': gb(bwd_bytes, bn_ms) / HBM_PEAK_GBS},
+           'config': 'T2 %s-svae-vmp N=%d per GPU, L=%d, K=%d, S=%d (own noise draw, fwd+bwd of the fused E-step, sub-sampling, M-step, CVI)' % ('smm' if smm else 'gmm', N, Ld, K, S)}
+    if cpu:
+        res['cpu_baseline'] = cpu_baseline_t2(K, Ld, S, smm=smm)
+        res['speedup_vs_cpu_baseline'] = res['datapoints_per_sec'] / res['cpu_baseline']['value']
+    return res
 
 
-def bench_t3(N, Ld, K, S, U, steps, warmup, dev, chunk, smm=False):
+def bench_t3(N, Ld, K, S, U, steps, warmup, dev, chunk, smm=False, cpu=False):
     """T3: the full training step of experiments.py:196-267 (encoder / decoder MLP + reconstruction term in the fused
     MFMA kernels; fused E-step kernels; all gradients, TF-Adam, CVI) on synthetic y = GMM data with Dy = L.  Timed with
     eps drawn inside the E-step kernel (the trainer's default, rng='philox') and, next to it, read from a torch.randn
@@ -186,6 +288,9 @@ def bench_t3(N, Ld, K, S, U, steps, warmup, dev, chunk, smm=False):
     against 34 ms from every run with more warm-up)."""
     from vmp_for_svae_amd.models import vae
     from vmp_for_svae_amd.training import SVAETrainer
+    if warmup < 3 or steps < 5:
+        print('bench_t3: warmup %d -> %d, steps %d -> %d (the caching allocator needs 3 steps to reach its steady state)'
+              % (warmup, max(3, warmup), steps, max(5, steps)), file=sys.stderr)
     warmup, steps = max(3, warmup), max(5, steps)
     x_h, _ = synth(N, Ld, K, seed=7)
     y = torch.as_tensor(x_h).to(dev)
@@ -217,15 +322,19 @@ def bench_t3(N, Ld, K, S, U, steps, warmup, dev, chunk, smm=False):
 
     def stats(v):
         return {'first': v[0], 'min': min(v), 'median': float(np.median(v)), 'max': max(v)}
-    return {'steps_per_sec': steps / dt, 'ms_per_step': dt / steps * 1e3, 'datapoints_per_sec': N * steps / dt,
-            'steps': steps, 'warmup': warmup, 'per_step_ms': stats(per),
-            # side measurement: the MEDIAN step (one 361 ms step of a host hiccup once made the mean 100 ms; the mean stays next to it)
-            'ms_per_step_noise_tensor_randn': float(np.median(per_p)), 'mean_ms_per_step_noise_tensor_randn': dt_p / steps * 1e3,
-            'per_step_ms_noise_tensor_randn': stats(per_p),
-            'elbo_per_datapoint': elbo / N, 'decoder_rows_per_step': rows,
-            'decoder_useful_TFLOPs_over_whole_step': dec_flop / (dt / steps) / 1e12,
-            'config': 'T3 %s-svae-train N=%d (%s), L=Dy=%d, K=%d, S=%d, U=%d' % (
-                'smm' if smm else 'gmm', N, 'one pass' if chunk is None else 'chunks of %d' % chunk, Ld, K, S, U)}
+    res = {'steps_per_sec': steps / dt, 'ms_per_step': dt / steps * 1e3, 'datapoints_per_sec': N * steps / dt,
+           'steps': steps, 'warmup': warmup, 'per_step_ms': stats(per),
+           # the same step with a torch.randn noise tensor: the SAME two statistics as the headline (wall-clock mean over the timed
+           # region, per-step HIP-event min / median / max) - compare like with like
+           'noise_tensor_randn': {'ms_per_step': dt_p / steps * 1e3, 'per_step_ms': stats(per_p)},
+           'elbo_per_datapoint': elbo / N, 'decoder_rows_per_step': rows,
+           'decoder_useful_TFLOPs_over_whole_step': dec_flop / (dt / steps) / 1e12,
+           'config': 'T3 %s-svae-train N=%d (%s), L=Dy=%d, K=%d, S=%d, U=%d' % (
+               'smm' if smm else 'gmm', N, 'one pass' if chunk is None else 'chunks of %d' % chunk, Ld, K, S, U)}
+    if cpu:
+        res['cpu_baseline'] = cpu_baseline_t3(K, Ld, S, U, smm=smm)
+        res['speedup_vs_cpu_baseline'] = res['datapoints_per_sec'] / res['cpu_baseline']['value']
+    return res
 
 
 def bench_minibatch(N, K, Ld, Dy, S, U, dev, steps=200, cpu=True):
@@ -610,9 +719,9 @@ def main():
                                     'valu_frac': t1_flops(Nb, D, K) / (bk_ms * 1e-3) / FP32_PEAK_FLOPS}
                 del bloop, xb, rb
                 torch.cuda.empty_cache()
-            extra['t2_svae_vmp'] = bench_t2(N, D, K, args.s, 5, 2, dev, None, 1)
+            extra['t2_svae_vmp'] = bench_t2(N, D, K, args.s, 5, 2, dev, None, 1, cpu=not args.no_cpu_baseline)
             torch.cuda.empty_cache()
-            extra['t3_svae_train'] = bench_t3(N, D, K, args.s, args.u, 5, 3, dev, None)
+            extra['t3_svae_train'] = bench_t3(N, D, K, args.s, args.u, 5, 3, dev, None, cpu=not args.no_cpu_baseline)
             torch.cuda.empty_cache()
             # BASELINE configs[3]-sized model at the reference's minibatch size (Auto: Dy=6, L=8, K=10, U=50)
             extra['t3_minibatch64'] = bench_minibatch(64, 10, 8, 6, args.s, args.u, dev, cpu=not args.no_cpu_baseline)
@@ -662,7 +771,7 @@ def main():
         warm = min(args.warmup, 3)
         S, U = args.s, args.u
         if args.workload == 't2':
-            res = bench_t2(n_loc, D, K, S, steps, warm, dev, dist, world, smm=args.smm)
+            res = bench_t2(n_loc, D, K, S, steps, warm, dev, dist, world, smm=args.smm, cpu=(world == 1 and not args.no_cpu_baseline))
             ms = res['ms_per_step']
             bwd_bytes = 4.0 * n_loc * (2.0 * K * S * D + 4 * D + 3 * K)
             roof = {'bound': 'hbm', 'achieved': res['bwd_GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': res['bwd_frac_hbm'],
@@ -671,7 +780,7 @@ def main():
             metric, wl = 'svae_vmp_step_datapoints_per_sec', 'T2 %ssvae-vmp step (fused E-step fwd + bwd, sub-sampling, M-step, CVI), L=%d, K=%d, S=%d' % ('Student-t (smm) ' if args.smm else '', D, K, S)
             extra['t2'] = res
         else:
-            res = bench_t3(n_loc, D, K, S, U, steps, warm, dev, None, smm=args.smm)
+            res = bench_t3(n_loc, D, K, S, U, steps, warm, dev, None, smm=args.smm, cpu=(world == 1 and not args.no_cpu_baseline))
             ms = res['ms_per_step']
             k_ms, useful, issued, mf = dec_bwd_side_measurement(n_loc, K, S, D, U, dev)
             tf_s = useful / (k_ms * 1e-3) / 1e12
@@ -692,6 +801,9 @@ def main():
                                    'N_per_gpu': n_loc, 'N_job': n_job, 'D': D, 'K': K,
                                    'parallelism': 'dp%d (rows sharded, 1 packed all-reduce of moments + gradients per step)' % world},
                         'roofline': roof})
+            if 'cpu_baseline' in res:
+                out['cpu_baseline'] = res['cpu_baseline']
+                out['speedup_vs_cpu_baseline'] = out['value'] / res['cpu_baseline']['value']
 
     if rank == 0:
         if extra:

@@ -151,9 +151,10 @@ int    vmp_svae_estep_fwd(const float* eta1, const float* eta2d, const float* hk
                           const float* noise, const float* mk, const float* Wk, const float* kappa, const float* nu,
                           int64_t N, int K, int L, int S, float* x, float* lz, float* Tp, void* stream);
 /* In-kernel noise (models/svae.py:113-114 draws eps inside the step: tf.random_normal, i.e. TensorFlow's Philox stream).
- * Same operation with eps generated where it is consumed: Philox4x32-10 keyed by `seed`, counter = (cell low, cell high,
- * block, 0), cell = n K + k, block b = (i >> 1) ceil(S/2) + (s >> 1) -> Box-Muller normals of elements (i,s), (i,s+1),
- * (i+1,s), (i+1,s+1) of the cell's (L,S) noise block.  No (N,K,L,S) tensor is read or written; the backward pass needs
+ * Same operation with eps generated where it is consumed: Philox4x32-7 (Random123's philox4x32 at 7 rounds) keyed by `seed`,
+ * counter = (cell low, cell high, block, 0), cell = n K + k, block b = (s >> 1) ceil(L/3) + j -> three Box-Muller pairs from
+ * 21-bit uniforms: (eps[i,s], eps[i,s+1]) for i = 3j, 3j+1, 3j+2 of the cell's (L,S) noise block (bit layout: csrc/vmp_svae.hip,
+ * oracle/philox.py).  No (N,K,L,S) tensor is read or written; the backward pass needs
  * none (it works from the saved samples x).  Shapes outside the in-kernel path (vmp_svae_rng_in_kernel == 0: L < 8 and L*S
  * not a multiple of 4 or a cell tile larger than the LDS; L = 8 is covered for every S) materialise the same stream in `noise_ws` (N,K,L,S) first.
  * vmp_svae_philox_noise writes that stream as a tensor (tests; callers that want to keep the draw).               */
@@ -189,7 +190,7 @@ int    vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk
  * u (N,S_out) - replacing tf.multinomial - or the supplied index z (N,S_out) when z != NULL.  out (N,S_out,L).  */
 int    vmp_svae_subsample(const float* x, const float* lz, const float* u, const int64_t* z, int64_t N, int K, int S,
                           int L, int S_out, float* out, int64_t* z_out, void* stream);
-/* The same with the uniforms drawn in the kernel: u_ns = top 24 bits of word 0 of Philox4x32-10(key = seed, counter =
+/* The same with the uniforms drawn in the kernel: u_ns = top 24 bits of word 0 of Philox4x32-7(key = seed, counter =
  * (n low, n high, s, 0x5bb5a3c1)) * 2^-24 - a stream apart from the E-step's normals (whose counter word 3 is 0).  The key
  * is `seed`, or *seed_dev when seed_dev != NULL (graph-captured steps).                                              */
 int    vmp_svae_subsample_rng(const float* x, const float* lz, uint64_t seed, const uint64_t* seed_dev, int64_t N, int K,

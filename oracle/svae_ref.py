@@ -91,6 +91,15 @@ def _regulariser(r_nk, log_num, log_den):
     return reg, d1, d2
 
 
+def _reconstruction(y, reconstructions, r_nk):
+    """the decoder term of both ELBOs (vae.py:233-248); reconstructions=None leaves it out (the T2 unit of SURVEY 8d: VMP
+    step without the MLPs and without the reconstruction term)."""
+    if reconstructions is None:
+        return r_nk.new_zeros(())
+    means, var = reconstructions
+    return nets.expected_diagonal_gaussian_loglike(y, means, var, weights=r_nk)
+
+
 def compute_elbo(y, reconstructions, theta, phi_tilde, x_k, log_z):
     """svae.py:199-262 (Gaussian decoder).  Returns (elbo, (rec, num, den, reg))."""
     beta_k, m_k, C_k, v_k = dists.niw_natural_to_standard(*theta[1:])
@@ -99,8 +108,7 @@ def compute_elbo(y, reconstructions, theta, phi_tilde, x_k, log_z):
     elp = dists.dir_expected_log_pi(dists.dir_natural_to_standard(theta[0]))
     eta1_th, eta2_th, elp = eta1_th.detach(), eta2_th.detach(), elp.detach()
     r_nk = torch.exp(log_z)
-    means, var = reconstructions
-    rec = nets.expected_diagonal_gaussian_loglike(y, means, var, weights=r_nk)
+    rec = _reconstruction(y, reconstructions, r_nk)
     eta1_t, eta2_t = phi_tilde
     N, K, L, _ = eta2_t.shape
     log_num = dists.gauss_log_probability_nat_per_samp(x_k, eta1_t.reshape(N, K, L), eta2_t) + log_z.unsqueeze(2)
@@ -117,8 +125,7 @@ def compute_elbo_smm(y, reconstructions, theta, phi_tilde, x_k, log_z):
     elp = dists.dir_expected_log_pi(dists.dir_natural_to_standard(theta[0])).detach()
     dof = theta[3].detach()
     r_nk = torch.exp(log_z)
-    means, var = reconstructions
-    rec = nets.expected_diagonal_gaussian_loglike(y, means, var, weights=r_nk)
+    rec = _reconstruction(y, reconstructions, r_nk)
     eta1_t, eta2_t = phi_tilde
     N, K, L, _ = eta2_t.shape
     log_num = dists.gauss_log_probability_nat_per_samp(x_k, eta1_t.reshape(N, K, L), eta2_t) + log_z.unsqueeze(2)

@@ -98,3 +98,44 @@ def train_step(st, y, noise, z_draws, lr, lrcvi0, decay_rate, towers=1, b1=0.9, 
     st.global_step += 1
     return dict(elbo=torch.stack(elbos).sum(), details=torch.stack(details).sum(0), grads=dict(zip(names, grads)),
                 theta_star=theta_star, lrcvi=lrcvi, x_samples=torch.cat(xs_all), log_z=torch.cat(lz_all))
+
+
+def vmp_step_t2(phi_gmm, theta, gmm_prior, eta1, eta2d, noise, z_draws, Gx, Glz, lrcvi, smm=False, chunk=None):
+    """The T2 unit of SURVEY 8d on the reference graph: svae.e_step (svae.py:14-119), the regulariser part of compute_elbo(_smm)
+    (svae.py:229-254 / 265-322), autodiff of  -elbo_reg + <x_k, Gx> + <log_z, Glz>  w.r.t. the encoder outputs and phi_gmm (+ the
+    trainable theta/mu_k, theta/L_k of the Student-t model) - Gx, Glz standing for what the decoder and the reconstruction term send
+    back (experiments.py:232) -, svae.subsample_x (s = 0 kept, svae.py:514), svae.m_step(_smm) and update_gmm_params
+    (svae.py:154-196, 376-403).  `chunk`: rows per pass (the literal graph materialises (N,K,L,L) and (N,K,S,L) temporaries); the
+    K-sized gradients and the M-step inputs are summed / concatenated over the passes.
+    Returns dict(reg, g_eta1, g_eta2d, g_phi (3), g_theta (0 or 2), theta_new, log_z, x_samples)."""
+    N = eta1.shape[0]
+    chunk = N if chunk is None else chunk
+    phi = [p.detach().clone().requires_grad_(True) for p in phi_gmm]
+    th = [t.detach().clone() for t in theta]
+    th_tr = []
+    if smm:
+        th[1].requires_grad_(True)
+        th[2].requires_grad_(True)
+        th_tr = [th[1], th[2]]
+    g_k, g1, g2, regs, xs_all, lz_all = None, [], [], [], [], []
+    for lo in range(0, N, chunk):
+        sl = slice(lo, min(N, lo + chunk))
+        e1 = eta1[sl].detach().clone().requires_grad_(True)
+        e2 = eta2d[sl].detach().clone().requires_grad_(True)
+        x_k, log_z, phi_tilde, _ = svae_ref.e_step((e1, e2), phi, noise[sl])
+        elbo, det = (svae_ref.compute_elbo_smm if smm else svae_ref.compute_elbo)(None, None, th, phi_tilde, x_k, log_z)
+        loss = -elbo + (x_k * Gx[sl]).sum() + (log_z * Glz[sl]).sum()
+        gr = torch.autograd.grad(loss, [e1, e2] + phi + th_tr)
+        g1.append(gr[0])
+        g2.append(gr[1])
+        g_k = list(gr[2:]) if g_k is None else [a + b for a, b in zip(g_k, gr[2:])]
+        regs.append(det[3].detach())
+        xs_all.append(svae_ref.subsample_x(x_k.detach(), z_draws[sl])[:, 0, :])
+        lz_all.append(log_z.detach())
+    r_nk = torch.exp(torch.cat(lz_all))
+    if smm:
+        theta_new = svae_ref.update_gmm_params([th[0]], [svae_ref.m_step_smm(gmm_prior, r_nk)], lrcvi)
+    else:
+        theta_new = svae_ref.update_gmm_params(th, svae_ref.m_step(gmm_prior, torch.cat(xs_all), r_nk), lrcvi)
+    return dict(reg=torch.stack(regs).sum(), g_eta1=torch.cat(g1), g_eta2d=torch.cat(g2), g_phi=g_k[:3], g_theta=g_k[3:],
+                theta_new=[t.detach() for t in theta_new], log_z=torch.cat(lz_all), x_samples=torch.cat(xs_all))

@@ -1,5 +1,5 @@
 """In-kernel noise (reference models/svae.py:113-114: tf.random_normal inside the step = TensorFlow's Philox stream).
-CPU: the oracle's Philox4x32-10 against the Random123 known-answer vectors.  GPU: the kernels' stream equals the
+CPU: the oracle's Philox4x32 at 7 rounds (the product's stream) and 10 rounds against the Random123 known-answer vectors.  GPU: the kernels' stream equals the
 oracle's element for element; the in-kernel E-step equals the E-step fed with the materialised stream; statistics of
 1e7 draws (moments, Kolmogorov-Smirnov); the ELBO of a training step under both noise sources agrees in distribution."""
 import numpy as np
@@ -19,10 +19,40 @@ KAT = [
 ]
 
 
+# Random123 kat_vectors, philox4x32 7 rounds (the round count of the product's stream)
+KAT7 = [
+    ((0x00000000, 0x00000000, 0x00000000, 0x00000000), (0x00000000, 0x00000000),
+     (0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48)),
+    ((0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff), (0xffffffff, 0xffffffff),
+     (0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662)),
+    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+     (0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a)),
+]
+
+
 def test_oracle_philox_known_answers():
-    for ctr, key, want in KAT:
-        got = philox.philox4x32_10(np.array([ctr], dtype=np.uint32), np.array([key], dtype=np.uint32))[0]
-        assert tuple(int(v) for v in got) == want
+    assert philox.ROUNDS == 7
+    for rounds, kat in ((10, KAT), (7, KAT7)):
+        for ctr, key, want in kat:
+            got = philox.philox4x32(np.array([ctr], dtype=np.uint32), np.array([key], dtype=np.uint32), rounds)[0]
+            assert tuple(int(v) for v in got) == want
+
+
+def test_oracle_block_layout_uses_disjoint_bits():
+    """every one of the six 21-bit integers of a block is an independent function of the block's 128 bits"""
+    rng = np.random.Generator(np.random.PCG64(5))
+    base = rng.integers(0, 2 ** 32, size=(1, 4), dtype=np.uint64).astype(np.uint32)
+    ref = philox.box_muller6(base)[0]
+    owners = np.zeros((4, 32), dtype=int) - 1
+    for w in range(4):
+        for bit in range(32):
+            v = base.copy()
+            v[0, w] ^= np.uint32(1 << bit)
+            ch = np.argwhere(np.abs(philox.box_muller6(v)[0] - ref).max(axis=-1) > 0).ravel()
+            assert len(ch) <= 1                              # a bit feeds at most one pair
+            owners[w, bit] = ch[0] if len(ch) else -1
+    assert (owners >= 0).sum() == 126 and owners[1, 10] == -1 and owners[3, 10] == -1
+    assert all((owners == t).sum() == 42 for t in range(3))
 
 
 def test_oracle_box_muller_is_standard_normal():

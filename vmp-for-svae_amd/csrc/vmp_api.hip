@@ -21,6 +21,24 @@ int check_launch(const char* what) {
     return 0;
 }
 
+size_t lds_budget() {
+    int dev = 0, v = 0;
+    size_t cap = 160 * 1024;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0 && (size_t)v < cap)
+        cap = (size_t)v;
+    return cap;
+}
+
+int set_dyn_lds(const void* kernel, size_t bytes, const char* what) {
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("%s: %zu bytes of dynamic LDS refused (%s); the device offers %zu", what, bytes, hipGetErrorString(e), lds_budget());
+        return (int)e;
+    }
+    return 0;
+}
+
 }  // namespace vmp
 
 extern "C" {

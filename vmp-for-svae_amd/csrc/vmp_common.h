@@ -139,6 +139,11 @@ __device__ __forceinline__ float rows4_sum(float v) {
 // ---- error plumbing (thread-local message) ------------------------------------------------
 void set_error(const char* fmt, ...);
 int  check_launch(const char* what);
+// LDS a workgroup may ask for on the current device (hipDeviceAttributeMaxSharedMemoryPerBlock, at most the 160 KB of a gfx950
+// CU); the launch plans size their per-wave buffers against it instead of a constant.
+size_t lds_budget();
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) with its status checked: 0, or the HIP error code with the message set
+int  set_dyn_lds(const void* kernel, size_t bytes, const char* what);
 
 // ---- geometry of the mixture kernels -----------------------------------------------------------------
 template <int D>

@@ -1106,7 +1106,7 @@ int dec_bwd_launch(const DecArgs& a0, int blocks, hipStream_t s) {
     const bool bt2 = a.R >= (unsigned)VMP_DEC_BT2_ROWS;
 #define DEC_BWD_L(UTV, FSV, BTV)                                                                                      \
     do {                                                                                                              \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<UTV, FSV, GIN, BTV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        if (const int rc_ = set_dyn_lds(reinterpret_cast<const void*>(dec_bwd_kernel<UTV, FSV, GIN, BTV>), (size_t)lds, "dec_bwd_kernel")) return rc_; \
         hipLaunchKernelGGL((dec_bwd_kernel<UTV, FSV, GIN, BTV>), dim3(blocks), dim3(BWD_THREADS), lds, s, a);         \
     } while (0)
 #define DEC_BWD(UTV)                                                                                                  \
@@ -1176,7 +1176,7 @@ int decoder_fwd_impl(const char* what, float vscale, const float* x, const float
 #define DEC_FWD(UTV)                                                                                                  \
     do {                                                                                                              \
         const int lds = Img<UTV>::FWD_END * (int)sizeof(float);                                                       \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fwd_kernel<UTV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        if (const int rc_ = set_dyn_lds(reinterpret_cast<const void*>(dec_fwd_kernel<UTV>), (size_t)lds, "dec_fwd_kernel")) return rc_; \
         hipLaunchKernelGGL((dec_fwd_kernel<UTV>), dim3(blocks), dim3(FWD_THREADS), lds, s, a);                        \
     } while (0)
     DEC_DISPATCH(U, DEC_FWD);

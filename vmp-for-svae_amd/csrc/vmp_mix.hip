@@ -1648,7 +1648,7 @@ template <int D>
 int launch_pass_xdl(const PassArgs& a, const Plan& p, int flavour, bool stats, hipStream_t s) {
     dim3 grid(p.blocks), block(p.nw * WAVE);
 #define VMP_LAUNCH_X(FL, S) do { \
-        if (p.lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pass_xdl_kernel<D, FL, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
+        if (p.lds > 64 * 1024) { if (const int rc_ = set_dyn_lds(reinterpret_cast<const void*>(pass_xdl_kernel<D, FL, S>), p.lds, "pass_xdl_kernel")) return rc_; } \
         hipLaunchKernelGGL((pass_xdl_kernel<D, FL, S>), grid, block, p.lds, s, a); } while (0)
     if (flavour == VMP_GMM) { if (stats) VMP_LAUNCH_X(VMP_GMM, true); else VMP_LAUNCH_X(VMP_GMM, false); }
     else { if (stats) VMP_LAUNCH_X(VMP_SMM, true); else VMP_LAUNCH_X(VMP_SMM, false); }

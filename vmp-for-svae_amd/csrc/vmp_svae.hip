@@ -40,7 +40,7 @@ struct EFwdArgs {
     float* Tp;              // (N,K)
     long long N;
     int K, S, vec_ok;
-    unsigned long long seed;   // in-kernel noise (noise == NULL): Philox4x32-10 key
+    unsigned long long seed;   // in-kernel noise (noise == NULL): Philox4x32-7 key
     const unsigned long long* seed_dev;   // non-NULL: the key is read from this device word (graph-captured steps refresh it)
 #ifdef VMP_DEBUG_TS
     long long* dbg_t;
@@ -721,15 +721,24 @@ __global__ __launch_bounds__(SV_FWD_MAX_NW * WAVE) void svae_estep_fwd3_kernel(E
 
 // ---------------------------------------------------------------------------------------------------------
 // In-kernel noise (reference models/svae.py:113-114 draws eps inside the step with TensorFlow's Philox stream).
-// Philox4x32-10 (Salmon et al., SC'11; Random123 known-answer vectors in tests/test_philox.py) keyed by the seed, counter
-// = (cell id low, cell id high, block, 0) with cell = n K + k; block b = (i >> 1) ceil(S/2) + (s >> 1) yields the four
-// standard normals of elements (i, s), (i, s+1), (i+1, s), (i+1, s+1) by Box-Muller (radius from the top 24 bits of one
-// word, angle from the top 24 bits of the next; v_log / v_sqrt / v_sin / v_cos).  Stateless: any kernel (or the host
-// oracle, oracle/philox.py) can regenerate the same element from (seed, n, k, i, s).
+// Generator (round 5): Philox4x32-7 - Random123's philox4x32 at R = 7 rounds, the smallest round count its authors report as
+// Crush-resistant (Salmon et al., SC'11, table 2; R = 10 is their safety-margin default) - keyed by the seed, pinned by the
+// Random123 known-answer vectors for 7 AND 10 rounds (tests/test_philox.py).  Counter = (cell id low, cell id high, block, 0) with
+// cell = n K + k.  One 128-bit block yields THREE Box-Muller pairs from 21-bit uniforms (radius: u in (0,1) on a 2^-21 grid,
+// |eps| <= 5.4; angle: 2^21 directions) instead of two pairs from 24 of every 32 bits: block b = p ceil(L/3) + j of a cell holds,
+// for the sample pair (2p, 2p+1), coordinates i = 3j, 3j+1, 3j+2; pair t of a block = (eps[i, 2p], eps[i, 2p+1]) = r (cos, sin).
+// Bits: pair 0 = (c0[0..20], c1[11..31]), pair 1 = (c2[0..20], c3[11..31]), pair 2 = (c0[21..31] | c1[0..9] << 11,
+// c2[21..31] | c3[0..9] << 11).  Stateless: any kernel (or the host oracle, oracle/philox.py) can regenerate the same element from
+// (seed, n, k, i, s).  Cost per normal at L = 8 (round 4: 10 rounds, 4 normals per block = 5 v_mad_u64_u32 + 10 v_xor per
+// normal): 3 blocks of 7 rounds per 16 normals = 2.6 + 5.3.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#ifndef VMP_PHILOX_ROUNDS
+#define VMP_PHILOX_ROUNDS 7
+#endif
+template <int R>
+__device__ __forceinline__ void philox4x32(unsigned (&c)[4], unsigned k0, unsigned k1) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < R; ++r) {
         if (r) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
         const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
         const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
@@ -737,37 +746,41 @@ __device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, uns
         c[1] = (unsigned)p1; c[3] = (unsigned)p0; c[0] = n0; c[2] = n2;
     }
 }
-__device__ __forceinline__ v2f box_muller(unsigned a, unsigned b) {
-    const float u1 = ((float)(a >> 8) + 0.5f) * 5.9604644775390625e-08f;         // (0, 1)
-    const float ang = (float)(b >> 8) * 5.9604644775390625e-08f;                  // revolutions, [0, 1)
+// two 21-bit integers -> one Box-Muller pair
+__device__ __forceinline__ v2f box_muller21(unsigned a, unsigned b) {
+    const float u1 = fmaf((float)a, 4.76837158203125e-07f, 2.384185791015625e-07f);   // (a + 1/2) 2^-21 in (0, 1)
+    const float ang = (float)b * 4.76837158203125e-07f;                            // revolutions, [0, 1)
     const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1), v_log_f32 = log2
     return v2f{rad * __builtin_amdgcn_cosf(ang), rad * __builtin_amdgcn_sinf(ang)};
 }
-// the four normals of block `blk` of cell `cell`: (i,s), (i,s+1), (i+1,s), (i+1,s+1)
-__device__ __forceinline__ void philox_normal4(unsigned long long cell, unsigned blk, unsigned long long seed, v2f& lo, v2f& hi) {
+// the three pairs of block `blk` of cell `cell`: coordinates 3j, 3j+1, 3j+2 of sample pair p (blk = p ceil(L/3) + j)
+__device__ __forceinline__ void philox_normal6(unsigned long long cell, unsigned blk, unsigned long long seed, v2f& p0, v2f& p1, v2f& p2) {
     unsigned c[4] = {(unsigned)cell, (unsigned)(cell >> 32), blk, 0u};
-    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
-    lo = box_muller(c[0], c[1]);
-    hi = box_muller(c[2], c[3]);
+    philox4x32<VMP_PHILOX_ROUNDS>(c, (unsigned)seed, (unsigned)(seed >> 32));
+    p0 = box_muller21(c[0] & 0x1FFFFFu, c[1] >> 11);
+    p1 = box_muller21(c[2] & 0x1FFFFFu, c[3] >> 11);
+    p2 = box_muller21(__builtin_amdgcn_alignbit(c[1], c[0], 21) & 0x1FFFFFu, __builtin_amdgcn_alignbit(c[3], c[2], 21) & 0x1FFFFFu);
 }
 
 struct NoiseArgs { float* out; long long cells; int L, S; unsigned long long seed; const unsigned long long* seed_dev; };
 // Materialises the same stream as a (cells, L, S) tensor: for shapes the in-kernel path does not cover, and for tests.
 __global__ __launch_bounds__(256) void philox_noise_kernel(NoiseArgs a) {
-    const int SP = (a.S + 1) >> 1, LP = (a.L + 1) >> 1, NB = SP * LP;
+    const int SP = (a.S + 1) >> 1, L3 = (a.L + 2) / 3, NB = SP * L3;
     const long long total = a.cells * NB;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const long long cell = e / NB;
-        const int b = (int)(e - cell * NB), ip = b / SP, sp = b - ip * SP;
-        v2f lo, hi;
-        philox_normal4((unsigned long long)cell, (unsigned)b, a.seed_dev ? *a.seed_dev : a.seed, lo, hi);
+        const int b = (int)(e - cell * NB), sp = b / L3, j = b - sp * L3;
+        v2f pr[3];
+        philox_normal6((unsigned long long)cell, (unsigned)b, a.seed_dev ? *a.seed_dev : a.seed, pr[0], pr[1], pr[2]);
         float* o = a.out + cell * a.L * a.S;
-        const int i = 2 * ip, s2 = 2 * sp;
-        o[i * a.S + s2] = lo.x;
-        if (s2 + 1 < a.S) o[i * a.S + s2 + 1] = lo.y;
-        if (i + 1 < a.L) {
-            o[(i + 1) * a.S + s2] = hi.x;
-            if (s2 + 1 < a.S) o[(i + 1) * a.S + s2 + 1] = hi.y;
+        const int s2 = 2 * sp;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int i = 3 * j + t;
+            if (i < a.L) {
+                o[i * a.S + s2] = pr[t].x;
+                if (s2 + 1 < a.S) o[i * a.S + s2 + 1] = pr[t].y;
+            }
         }
     }
 }
@@ -782,7 +795,7 @@ __global__ __launch_bounds__(256) void philox_noise_kernel(NoiseArgs a) {
 // cell's last float4.  One s_waitcnt vmcnt(0) per tile retires the tile's DMA (issued a whole tile earlier) and
 // the previous tile's stores; the row loads of the tile are consumed BEFORE the next DMA is issued, so no
 // compiler-generated wait ever covers a DMA in flight.
-// RNG = true: no noise tensor at all - eps is generated in registers (Philox4x32-10, above) right where it is consumed;
+// RNG = true: no noise tensor at all - eps is generated in registers (Philox4x32-7, above) right where it is consumed;
 // the LDS tile then only serves the (cell, S, L) output transposition.
 // Noise-tensor form: the tile's noise DMA carries nt (bit 1) and its sample stores are streaming stores (bit 0) - a tile's 20 KB are
 // requested once, whole lines at a time, and its 20 KB of samples are not read again by this kernel.  Same box: K = 16 2.00 -> 1.88
@@ -1043,17 +1056,18 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
 
         // ---- samples (two at a time) and the per-cell regulariser term
         v2f eps2 = v2f{0.f, 0.f}, qth = v2f{0.f, 0.f};
-        float* cell = et + lane * CS;
+        float* cell = et + (lane_on ? lane : 0) * CS;         // lanes past the tile's last cell read (and discard) cell 0: no LDS access outside the wave's buffer
         const unsigned long long cellid = (unsigned long long)(on ? row : 0) * (unsigned long long)K + (unsigned long long)kc;
         auto read_pair = [&](int s2, v2f (&eo)[L]) {
             if constexpr (RNG) {
-                const unsigned SPn = (unsigned)(S + 1) >> 1;
+                constexpr int L3 = (L + 2) / 3;
 #pragma unroll
-                for (int ip = 0; ip < LP; ++ip) {
-                    v2f lo, hi;
-                    philox_normal4(cellid, (unsigned)ip * SPn + ((unsigned)s2 >> 1), rng_seed, lo, hi);
-                    eo[2 * ip] = lo;
-                    if (2 * ip + 1 < L) eo[2 * ip + 1] = hi;
+                for (int j = 0; j < L3; ++j) {
+                    v2f p0, p1, p2;
+                    philox_normal6(cellid, ((unsigned)s2 >> 1) * L3 + j, rng_seed, p0, p1, p2);
+                    eo[3 * j] = p0;
+                    if (3 * j + 1 < L) eo[3 * j + 1] = p1;
+                    if (3 * j + 2 < L) eo[3 * j + 2] = p2;
                 }
                 return;
             }
@@ -1357,7 +1371,7 @@ struct SubArgs {
     long long* z_out;       // (N,S_out) chosen component (may be NULL)
     long long N;
     int K, S, L, S_out;
-    int rng;                // u == z == NULL: uniforms from Philox4x32-10, key = seed, counter = (n, s, tag)
+    int rng;                // u == z == NULL: uniforms from Philox4x32-7, key = seed, counter = (n, s, tag)
     unsigned long long seed;
     const unsigned long long* seed_dev;   // non-NULL: key read from this device word
 };
@@ -1411,7 +1425,7 @@ __global__ __launch_bounds__(256) void subsample_kernel(SubArgs a) {
                     if (a.rng) {
                         // one Philox block per (row, draw); the tag word keeps this stream apart from the E-step's normals
                         unsigned c[4] = {(unsigned)n[q], (unsigned)((unsigned long long)n[q] >> 32), (unsigned)s, 0x5bb5a3c1u};
-                        philox4x32_10(c, (unsigned)sub_seed, (unsigned)(sub_seed >> 32));
+                        philox4x32<VMP_PHILOX_ROUNDS>(c, (unsigned)sub_seed, (unsigned)(sub_seed >> 32));
                         uu[q] = (float)(c[0] >> 8) * 5.9604644775390625e-08f;      // [0, 1)
                     } else {
                         uu[q] = on[q] ? a.u[n[q] * a.S_out + s] : 0.f;
@@ -1513,14 +1527,16 @@ static int fwd4_plan(int K, int L, int S, int& CS, size_t& lds4, bool rng = fals
     size_t pw = (size_t)((rng ? 1 : 2) * BC * CS) * sizeof(float);
     // the tile-buffer forms: whole 16-byte pieces per cell, and a cell's noise block inside the per-wave LDS tile
     const bool fits = (L * S) % 4 == 0 && (size_t)(L * S | 1) * WAVE * sizeof(float) <= 36 * 1024;
-    int nw4 = fits ? (int)((160 * 1024 - table) / pw) : 0;
+    const size_t budget = lds_budget();
+    int nw4 = (fits && budget > table) ? (int)((budget - table) / pw) : 0;
     if (nw4 > (rng ? 8 : 4)) nw4 = rng ? 8 : 4;
     if (rng && L == 8 && VMP_FWD_PAIR_STAGE && nw4 < 8 && pair_stage) {
         // in-kernel noise, and the tile buffer leaves a wave slot empty (K = 16: seven waves) or does not fit at all (large S:
         // evaluation runs use S = 100, experiments.py:283): the per-pair staging form (PST), which has no S-sized buffer
         *pair_stage = true;
         pw = (size_t)WAVE * 16 * sizeof(float);
-        nw4 = 8;
+        nw4 = budget > table ? (int)((budget - table) / pw) : 0;
+        if (nw4 > 8) nw4 = 8;
     }
     if (nw4 < 1) return 0;
     lds4 = table + pw * nw4;
@@ -1548,17 +1564,17 @@ static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
         VMP_DISPATCH_L(L, {
             if (LL == 8 && ps) {
                 if (S == 10) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<8, 10, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                    if ((rc = set_dyn_lds(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<8, 10, true, true>), lds4, "svae_estep_fwd")) != 0) return rc;
                     hipLaunchKernelGGL((svae_estep_fwd4_kernel<8, 10, true, true>), dim3((int)bl), dim3(nw4 * WAVE), lds4, static_cast<hipStream_t>(stream), a, CS);
                 } else {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<8, 0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                    if ((rc = set_dyn_lds(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<8, 0, true, true>), lds4, "svae_estep_fwd")) != 0) return rc;
                     hipLaunchKernelGGL((svae_estep_fwd4_kernel<8, 0, true, true>), dim3((int)bl), dim3(nw4 * WAVE), lds4, static_cast<hipStream_t>(stream), a, CS);
                 }
             } else if (S == 10) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<LL, 10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                if ((rc = set_dyn_lds(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<LL, 10, true>), lds4, "svae_estep_fwd")) != 0) return rc;
                 hipLaunchKernelGGL((svae_estep_fwd4_kernel<LL, 10, true>), dim3((int)bl), dim3(nw4 * WAVE), lds4, static_cast<hipStream_t>(stream), a, CS);
             } else {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<LL, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                if ((rc = set_dyn_lds(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<LL, 0, true>), lds4, "svae_estep_fwd")) != 0) return rc;
                 hipLaunchKernelGGL((svae_estep_fwd4_kernel<LL, 0, true>), dim3((int)bl), dim3(nw4 * WAVE), lds4, static_cast<hipStream_t>(stream), a, CS);
             }
             rc = check_launch("svae_estep_fwd4_kernel<rng>");
@@ -1575,7 +1591,7 @@ static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
         if (bl > 1024) bl = 1024;
         rc = -1;
         VMP_DISPATCH_L(L, {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd_chunked_kernel<LL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(pw * nwc));
+            if ((rc = set_dyn_lds(reinterpret_cast<const void*>(svae_estep_fwd_chunked_kernel<LL>), (pw * nwc), "svae_estep_fwd")) != 0) return rc;
             hipLaunchKernelGGL((svae_estep_fwd_chunked_kernel<LL>), dim3((int)bl), dim3(nwc * WAVE), pw * nwc, static_cast<hipStream_t>(stream), a, SC);
             rc = check_launch("svae_estep_fwd_chunked_kernel");
         });
@@ -1588,7 +1604,8 @@ static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
         const size_t table = (size_t)((K * ((L * (L + 1) / 2) | 1) + 3) & ~3) * sizeof(float);
         const int BC = VMP_FWD_BC_TILE ? (WAVE / K) * K : WAVE;   // cells per tile buffer (the kernel's BC)
         const size_t pw = (size_t)(2 * BC * CS) * sizeof(float);      // (the row-reduction scratch lies in the idle buffer)
-        int nw4 = (int)((160 * 1024 - table) / pw);
+        const size_t budget = lds_budget();
+        int nw4 = budget > table ? (int)((budget - table) / pw) : 0;
         if (nw4 > 4) nw4 = 4;
         if (nw4 >= 1) {
             const size_t lds4 = table + pw * nw4;
@@ -1598,10 +1615,10 @@ static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
             rc = -1;
             VMP_DISPATCH_L(L, {
                 if (S == 10) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<LL, 10, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                    if ((rc = set_dyn_lds(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<LL, 10, false>), lds4, "svae_estep_fwd")) != 0) return rc;
                     hipLaunchKernelGGL((svae_estep_fwd4_kernel<LL, 10, false>), dim3((int)bl), dim3(nw4 * WAVE), lds4, static_cast<hipStream_t>(stream), a, CS);
                 } else {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<LL, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                    if ((rc = set_dyn_lds(reinterpret_cast<const void*>(svae_estep_fwd4_kernel<LL, 0, false>), lds4, "svae_estep_fwd")) != 0) return rc;
                     hipLaunchKernelGGL((svae_estep_fwd4_kernel<LL, 0, false>), dim3((int)bl), dim3(nw4 * WAVE), lds4, static_cast<hipStream_t>(stream), a, CS);
                 }
                 rc = check_launch("svae_estep_fwd4_kernel");
@@ -1612,7 +1629,8 @@ static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
     {   // register-staged kernel: L*S not a multiple of 4, or a misaligned noise tensor
         const size_t table = (size_t)K * ((L * (L + 1) / 2) | 1) * sizeof(float);
         const size_t pw = (size_t)(WAVE * (L * S | 1) + WAVE) * sizeof(float);
-        int nw3 = (int)((150 * 1024 - table) / pw);        // one block per CU, as many waves as 160 KiB of LDS hold
+        const size_t budget3 = lds_budget() - 10 * 1024;
+        int nw3 = budget3 > table ? (int)((budget3 - table) / pw) : 0;        // one block per CU, as many waves as 160 KiB of LDS hold
         if (nw3 > SV_FWD_MAX_NW) nw3 = SV_FWD_MAX_NW;
         if (nw3 < 1) nw3 = 1;
         const size_t lds3 = table + pw * nw3;
@@ -1623,11 +1641,11 @@ static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
         VMP_DISPATCH_L(L, {
             if (S == 10) {
                 if (lds3 > 64 * 1024)
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd3_kernel<LL, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+                    if ((rc = set_dyn_lds(reinterpret_cast<const void*>(svae_estep_fwd3_kernel<LL, 10>), lds3, "svae_estep_fwd")) != 0) return rc;
                 hipLaunchKernelGGL((svae_estep_fwd3_kernel<LL, 10>), dim3((int)bl), dim3(nw3 * WAVE), lds3, static_cast<hipStream_t>(stream), a);
             } else {
                 if (lds3 > 64 * 1024)
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(svae_estep_fwd3_kernel<LL, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+                    if ((rc = set_dyn_lds(reinterpret_cast<const void*>(svae_estep_fwd3_kernel<LL, 0>), lds3, "svae_estep_fwd")) != 0) return rc;
                 hipLaunchKernelGGL((svae_estep_fwd3_kernel<LL, 0>), dim3((int)bl), dim3(nw3 * WAVE), lds3, static_cast<hipStream_t>(stream), a);
             }
             rc = check_launch("svae_estep_fwd3_kernel");
@@ -1662,7 +1680,7 @@ static int philox_noise_impl(uint64_t seed, const uint64_t* seed_dev, int64_t N,
     if (rc) return rc;
     if (!noise) { set_error("vmp_svae_philox_noise: null pointer"); return VMP_E_BADARG; }
     NoiseArgs na{noise, (long long)N * K, L, S, (unsigned long long)seed, reinterpret_cast<const unsigned long long*>(seed_dev)};
-    const long long total = na.cells * ((S + 1) / 2) * ((L + 1) / 2);
+    const long long total = na.cells * ((S + 1) / 2) * ((L + 2) / 3);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(philox_noise_kernel, dim3((int)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), na);

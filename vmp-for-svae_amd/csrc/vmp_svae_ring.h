@@ -823,7 +823,8 @@ int launch_n(const EBwdArgs& a, int nblk_abi, void* stream) {
     const int tab = ((K * (TRI | 1) + 3) & ~3) + ((STUDENT && NSTG == 2) ? K * SvRingTab<L>::TST : 0);
     const int per_wave = NSTG * svr_stage_floats<L>() + PWa * 16 + (NSTG == 4 ? 5 * WAVE : 0);
     const int maxw = NSTG == 2 ? SVR_NW : 4;
-    int nw = (int)((160 * 1024 / sizeof(float) - tab) / per_wave);
+    const size_t budget = vmp::lds_budget() / sizeof(float);
+    int nw = budget > (size_t)tab ? (int)((budget - tab) / per_wave) : 0;
     if (nw > maxw) nw = maxw;
 #ifdef VMP_RING_MAXW
     if (nw > VMP_RING_MAXW) nw = VMP_RING_MAXW;            // A/B builds: fewer waves per CU
@@ -834,7 +835,7 @@ int launch_n(const EBwdArgs& a, int nblk_abi, void* stream) {
     if (bl > 256) bl = 256;                                  // one block per CU
     const size_t lds = (size_t)(tab + nw * per_wave) * sizeof(float);
     auto kern = svae_estep_bwd_ring_kernel<L, K16, STUDENT, NSTG>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (const int rc = vmp::set_dyn_lds(reinterpret_cast<const void*>(kern), lds, "svae_estep_bwd_ring_kernel")) return rc;
     hipLaunchKernelGGL(kern, dim3((int)bl), dim3(nw * WAVE), lds, static_cast<hipStream_t>(stream), a, nblk_abi);
     return check_launch("svae_estep_bwd_ring_kernel");
 }
