@@ -742,14 +742,17 @@ __device__ __forceinline__ void philox4x32(unsigned (&c)[4], unsigned k0, unsign
         if (r) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
         const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
         const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
-        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+        // a ^ b ^ c in ONE instruction: v_bitop3_b32 with truth table 0x96 (gfx950)
+        const unsigned n0 = __builtin_amdgcn_bitop3_b32((unsigned)(p1 >> 32), c[1], k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32((unsigned)(p0 >> 32), c[3], k1, 0x96);
         c[1] = (unsigned)p1; c[3] = (unsigned)p0; c[0] = n0; c[2] = n2;
     }
 }
 // two 21-bit integers -> one Box-Muller pair
 __device__ __forceinline__ v2f box_muller21(unsigned a, unsigned b) {
     const float u1 = fmaf((float)a, 4.76837158203125e-07f, 2.384185791015625e-07f);   // (a + 1/2) 2^-21 in (0, 1)
-    const float ang = (float)b * 4.76837158203125e-07f;                            // revolutions, [0, 1)
+    // angle in revolutions: the 21 bits become the top mantissa bits of a float in [1, 2) - v_sin / v_cos take revolutions and are
+    // periodic, so 1 + b 2^-21 is as good as b 2^-21 (one v_lshl_or instead of v_cvt + v_mul; exact either way)
+    const float ang = __uint_as_float((b << 2) | 0x3F800000u);
     const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1), v_log_f32 = log2
     return v2f{rad * __builtin_amdgcn_cosf(ang), rad * __builtin_amdgcn_sinf(ang)};
 }
@@ -814,6 +817,18 @@ __device__ __forceinline__ void st_x4(float4* p, const float4& v) {
 #ifndef VMP_FWD_BC_TILE
 #define VMP_FWD_BC_TILE 1
 #endif
+#ifndef VMP_PST_NOSTORE
+#define VMP_PST_NOSTORE 0            // exploration builds: 1 = the pair-staging form without its global stores
+#endif
+#ifndef VMP_FWD_PAIR_STAGE_BELOW
+#define VMP_FWD_PAIR_STAGE_BELOW 7     // the pair-staging form where the tile buffer admits fewer waves than this (round 4: 8)
+#endif
+#ifndef VMP_FWD_PST2_ALWAYS
+#define VMP_FWD_PST2_ALWAYS 0         // exploration builds: the two-pair staging form also where the tile buffer admits eight waves
+#endif
+#ifndef VMP_FWD_PAIR_STAGE2
+#define VMP_FWD_PAIR_STAGE2 1         // 0: A/B builds without the two-pair staging form
+#endif
 #ifndef VMP_FWD_PAIR_STAGE
 #define VMP_FWD_PAIR_STAGE 1          // 0: A/B builds without the per-pair staging form
 #endif
@@ -849,7 +864,13 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
     // the host picks it only when it adds a wave: fwd4_plan.)  Piece j of cell c lies at position
     // j ^ ((c >> 1) & 3) of the cell's 64 bytes: every 8-lane group of both the writes and the reads covers all 32 banks.
     constexpr bool PST = RNG && L == 8 && PS;
-    float* buf0 = smem + tab + wave * (PST ? WAVE * 16 : NBUF * BC * CS);
+    constexpr bool PST2 = PST && ST != 0 && (ST & 3) == 2 && VMP_FWD_PAIR_STAGE2;       // two pairs per flush (S / 2 odd), below
+    // OIMG (in-kernel noise, L = 8, compile-time even S, tile-buffer form): the LDS image of the tile is written in OUTPUT order
+    // [cell][s][l] - four ds_write_b128 per sample pair (the pair-staging form's pieces; conflict-free at the padded cell stride:
+    // eight consecutive cells start at eight different 16-byte slots of the 128-byte bank window) - and leaves by ds_read_b128 +
+    // coalesced float4 stores: 20 + 20 LDS instructions per cell instead of 40 ds_write_b64 + 80 gathered ds_read_b32.
+    constexpr bool OIMG = RNG && L == 8 && ST != 0 && (ST & 1) == 0 && !PST;
+    float* buf0 = smem + tab + wave * (PST2 ? 2 * (WAVE * 16 + 16) : PST ? WAVE * 16 : NBUF * BC * CS);
     const bool lane_on = lane < CT;
     const int r = lane / K, k = lane - r * K, rbase = lane_on ? r * K : 0;
     const bool k16 = (K == 16);
@@ -914,7 +935,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
 #pragma unroll
         for (int it = 0; it < Qc; ++it) {
             const int s = rem / L4c, l4 = rem - s * L4c;
-            co_off[it] = c2 * CS + (4 * l4) * S + s;
+            co_off[it] = OIMG ? c2 * CS + 4 * rem : c2 * CS + (4 * l4) * S + s;
             c2 += dco; rem += dro;
             if (rem >= Q) { rem -= Q; c2 += 1; }
         }
@@ -1058,17 +1079,21 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
         v2f eps2 = v2f{0.f, 0.f}, qth = v2f{0.f, 0.f};
         float* cell = et + (lane_on ? lane : 0) * CS;         // lanes past the tile's last cell read (and discard) cell 0: no LDS access outside the wave's buffer
         const unsigned long long cellid = (unsigned long long)(on ? row : 0) * (unsigned long long)K + (unsigned long long)kc;
+        // the noise of sample pair `pr` (samples 2 pr, 2 pr + 1) of this lane's cell, generated in registers; pr may differ per lane
+        auto gen_pair = [&](unsigned pr, v2f (&eo)[L]) {
+            constexpr int L3 = (L + 2) / 3;
+#pragma unroll
+            for (int j = 0; j < L3; ++j) {
+                v2f p0, p1, p2;
+                philox_normal6(cellid, pr * L3 + j, rng_seed, p0, p1, p2);
+                eo[3 * j] = p0;
+                if (3 * j + 1 < L) eo[3 * j + 1] = p1;
+                if (3 * j + 2 < L) eo[3 * j + 2] = p2;
+            }
+        };
         auto read_pair = [&](int s2, v2f (&eo)[L]) {
             if constexpr (RNG) {
-                constexpr int L3 = (L + 2) / 3;
-#pragma unroll
-                for (int j = 0; j < L3; ++j) {
-                    v2f p0, p1, p2;
-                    philox_normal6(cellid, ((unsigned)s2 >> 1) * L3 + j, rng_seed, p0, p1, p2);
-                    eo[3 * j] = p0;
-                    if (3 * j + 1 < L) eo[3 * j + 1] = p1;
-                    if (3 * j + 2 < L) eo[3 * j + 2] = p2;
-                }
+                gen_pair((unsigned)s2 >> 1, eo);
                 return;
             }
 #pragma unroll
@@ -1077,19 +1102,13 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
                 else eo[i] = v2f{cell[i * S + s2], cell[i * S + s2 + 1]};
             }
         };
-        v2f en[L];                                         // next pair's noise, read while this pair is computed
-        read_pair(0, en);
-#pragma unroll 1
-        for (int s = 0; s < S; s += 2) {
-            const bool hv = s + 1 < S;
-            v2f z[L], ec[L];
-#pragma unroll
-            for (int i = 0; i < L; ++i) ec[i] = en[i];
-            if (!RNG || s + 2 < S) read_pair((s + 2 < S) ? s + 2 : s, en);
+        // the two samples x = Ltilde^-T (a + eps) of a pair and their contributions to the cell's sums of eps^2 and of the theta term
+        auto compute_pair = [&](const v2f (&ec)[L], bool hv, v2f (&z)[L]) {
 #pragma unroll
             for (int i = 0; i < L; ++i) {
                 v2f e = ec[i];
-                if (!lane_on) e = v2f{0.f, 0.f};
+                // (in-kernel noise: lanes past the tile's last cell draw the noise of cell 0 - finite, and nothing of theirs is stored)
+                if (!RNG && !lane_on) e = v2f{0.f, 0.f};
                 if (!hv) e.y = 0.f;
                 eps2 = __builtin_elementwise_fma(e, e, eps2);
                 z[i] = pk_add_b(e, av2[i >> 1], i & 1);
@@ -1120,6 +1139,100 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
             } else {
                 qth += del2;
             }
+        };
+        if constexpr (PST2) {
+            // Pair staging, TWO pairs per flush, every global store a whole 128-byte line.  A cell's S L floats are P = S / 2 chunks of
+            // 64 bytes (one sample pair each), P odd: cells with an EVEN absolute index start on a line, odd ones in mid-line, and the
+            // five lines of such a couple are [e0 e1][e2 e3][e4 o0][o1 o2][o3 o4].  So odd cells take their pairs one step ahead
+            // (step t: pair (t + 1) mod P): steps (0,1), (2,3), .. then complete one line per cell, written by eight adjacent lanes, and
+            // the last step's two 64-byte chunks of a couple are neighbours in memory and in the lanes.  (The one-pair form's
+            // 64-byte segment stores did not overlap with the arithmetic: 1.30 ms without them, 1.78 ms with, K = 16, N = 1e6.)
+            constexpr int P = ST / 2;
+            constexpr int SLOT = WAVE * 16 + 16;             // second slot 64 bytes further: a cell's two chunks in different bank halves
+            const unsigned abs0 = (unsigned)tu * (unsigned)CT;                   // parity of the tile's first cell
+            const unsigned par = (abs0 + (unsigned)lane) & 1u;
+            auto stage = [&](const v2f (&z)[L], int slot) {
+                float* wp = buf0 + slot * SLOT + lane * 16;
+                const int sw = (lane >> 1) & 3;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {               // piece j = [sample j >> 1][coordinates 4 (j & 1) ..]
+                    const int i0 = 4 * (j & 1), h2 = j >> 1;
+                    *reinterpret_cast<f32x4*>(wp + 4 * (j ^ sw)) = f32x4{z[i0][h2], z[i0 + 1][h2], z[i0 + 2][h2], z[i0 + 3][h2]};
+                }
+            };
+            auto store16 = [&](unsigned off_floats, const f32x4& v, bool ok) {
+                if (ok) {
+                    if (a.vec_ok) {
+                        asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(off_floats * 4u), "v"(v), "s"(xtile) : "memory");
+                    } else {
+                        float* dst = xtile + off_floats;
+                        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+                    }
+                }
+            };
+#pragma unroll 1
+            for (int t2 = 0; t2 < P; t2 += 2) {
+                const bool dbl = t2 + 1 < P;
+                {
+                    v2f z[L], ec[L];
+                    unsigned q = (unsigned)t2 + par;
+                    if (q >= (unsigned)P) q -= P;
+                    gen_pair(q, ec);
+                    compute_pair(ec, true, z);
+                    stage(z, 0);
+                }
+                if (dbl) {
+                    v2f z[L], ec[L];
+                    unsigned q = (unsigned)t2 + 1u + par;
+                    if (q >= (unsigned)P) q -= P;
+                    gen_pair(q, ec);
+                    compute_pair(ec, true, z);
+                    stage(z, 1);
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (dbl) {
+                    // lane -> (cell 8 it + (lane >> 3), slot (lane >> 2) & 1, piece lane & 3); swizzle ((cell >> 1) & 3) = (lane >> 4) & 3
+                    const int sl = (lane >> 2) & 1, pc = lane & 3;
+                    const float* rp = buf0 + sl * SLOT + (lane >> 3) * 16 + 4 * (pc ^ ((lane >> 4) & 3));
+                    f32x4 ov[8];
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) ov[it] = *reinterpret_cast<const f32x4*>(rp + it * 128);
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const unsigned cc = 8u * it + ((unsigned)lane >> 3);
+                        const unsigned parc = (abs0 + cc) & 1u;
+                        store16(cc * (unsigned)LSn + 16u * ((unsigned)t2 + parc + (unsigned)sl) + 4u * pc, ov[it], (int)cc < ncell_t);
+                    }
+                } else {
+                    const int pc = lane & 3;
+                    const float* rp = buf0 + (lane >> 2) * 16 + 4 * (pc ^ ((lane >> 3) & 3));
+                    f32x4 ov[4];
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) ov[it] = *reinterpret_cast<const f32x4*>(rp + it * 256);
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const unsigned cc = 16u * it + ((unsigned)lane >> 2);
+                        const unsigned parc = (abs0 + cc) & 1u;
+                        store16(cc * (unsigned)LSn + (parc ? 0u : 16u * (P - 1)) + 4u * pc, ov[it], (int)cc < ncell_t);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+        v2f en[L];                                         // noise tensor: next pair's noise, read from LDS while this pair is computed
+        if constexpr (!RNG) read_pair(0, en);
+#pragma unroll 1
+        for (int s = 0; s < S; s += 2) {
+            const bool hv = (ST != 0 && (ST & 1) == 0) ? true : (s + 1 < S);
+            v2f z[L], ec[L];
+            if constexpr (RNG) {
+                read_pair(s, ec);                           // generated where it is consumed: nothing to prefetch, no copies
+            } else {
+#pragma unroll
+                for (int i = 0; i < L; ++i) ec[i] = en[i];
+                read_pair((s + 2 < S) ? s + 2 : s, en);
+            }
+            compute_pair(ec, hv, z);
             if constexpr (PST) {
                 float* wp = buf0 + lane * 16;
                 const int sw = (lane >> 1) & 3;
@@ -1140,7 +1253,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int cc = 16 * it + (lane >> 2);
-                    if (cc < ncell_t && pok) {
+                    if (cc < ncell_t && pok && !(VMP_PST_NOSTORE)) {
                         const unsigned ob = (unsigned)(cc * LSn + 4 * pc) * 4u;
                         if (a.vec_ok) {
                             asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(ob), "v"(ov[it]), "s"(gs) : "memory");
@@ -1172,6 +1285,15 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
                         for (int i = 0; i < L; ++i) { xo[i] = z[i].x; if (hv) xo[L + i] = z[i].y; }
                     }
                 }
+            } else if (OIMG) {
+                if (lane_on) {
+                    float* wp = cell + s * L;                 // 64 bytes: [sample s: l 0-3 | 4-7][sample s + 1: l 0-3 | 4-7]
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i0 = 4 * (j & 1), h2 = j >> 1;
+                        *reinterpret_cast<f32x4*>(wp + 4 * j) = f32x4{z[i0][h2], z[i0 + 1][h2], z[i0 + 2][h2], z[i0 + 3][h2]};
+                    }
+                }
             } else if (lane_on) {
 #pragma unroll
                 for (int i = 0; i < L; ++i) {
@@ -1184,6 +1306,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
                 }
             }
         }
+        }   // !PST2
         if (on) {
             a.lz[row * K + k] = lz;
             a.Tp[row * K + k] = -0.5f * L * LOG_2PI + ld - 0.5f * invS * (eps2.x + eps2.y) + 0.5f * invS * (qth.x + qth.y) - kappak;
@@ -1208,7 +1331,12 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
                         for (int u = 0; u < CB; ++u) {
                             if (it0 + u < Qc) {
                                 const float* src = et + ((it0 + u) * WAVE + lane < nf4 ? co_off[it0 + u] : 0);
-                                v[u].x = src[0]; v[u].y = src[S]; v[u].z = src[2 * S]; v[u].w = src[3 * S];
+                                if constexpr (OIMG) {
+                                    const f32x4 q4 = *reinterpret_cast<const f32x4*>(src);
+                                    v[u] = float4{q4[0], q4[1], q4[2], q4[3]};
+                                } else {
+                                    v[u].x = src[0]; v[u].y = src[S]; v[u].z = src[2 * S]; v[u].w = src[3 * S];
+                                }
                             }
                         }
 #pragma unroll
@@ -1530,11 +1658,16 @@ static int fwd4_plan(int K, int L, int S, int& CS, size_t& lds4, bool rng = fals
     const size_t budget = lds_budget();
     int nw4 = (fits && budget > table) ? (int)((budget - table) / pw) : 0;
     if (nw4 > (rng ? 8 : 4)) nw4 = rng ? 8 : 4;
-    if (rng && L == 8 && VMP_FWD_PAIR_STAGE && nw4 < 8 && pair_stage) {
-        // in-kernel noise, and the tile buffer leaves a wave slot empty (K = 16: seven waves) or does not fit at all (large S:
-        // evaluation runs use S = 100, experiments.py:283): the per-pair staging form (PST), which has no S-sized buffer
+    // S = 10 (the compiled-in sample count): the two-pair staging form, eight waves, whole-line stores - where the tile buffer
+    // admits fewer than eight waves (K = 16, 7, 8, 9)
+    const bool pst2 = VMP_FWD_PAIR_STAGE2 && S == 10 && (nw4 < 8 || VMP_FWD_PST2_ALWAYS);
+    if (rng && L == 8 && VMP_FWD_PAIR_STAGE && (nw4 < VMP_FWD_PAIR_STAGE_BELOW || pst2) && pair_stage) {
+        // in-kernel noise, and the tile buffer admits few waves or does not fit at all (large S: evaluation runs use S = 100,
+        // experiments.py:283): the per-pair staging form (PST), which has no S-sized buffer.  (Round 4 also chose it where the tile
+        // buffer admits seven waves - K = 16, 7, 8, 9 at S = 10.  With round 5's cheaper generator the ONE-pair form is bound by its
+        // 64-byte segment stores: same box, K = 16 1.78 -> 1.52 ms, K = 8 1.04 -> 0.90, K = 7 0.91 -> 0.84 with the seven-wave tile buffer.)
         *pair_stage = true;
-        pw = (size_t)WAVE * 16 * sizeof(float);
+        pw = (size_t)(pst2 ? 2 * (WAVE * 16 + 16) : WAVE * 16) * sizeof(float);
         nw4 = budget > table ? (int)((budget - table) / pw) : 0;
         if (nw4 > 8) nw4 = 8;
     }
