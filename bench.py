@@ -231,8 +231,8 @@ def bench_t2(N, Ld, K, S, steps, warmup, dev, dist=None, world=1, smm=False, cpu
                 st = buf[:st.numel()].reshape(st.shape)
             if smm:
                 svae.update_gmm_params(theta[:1], [prior + st[:, 0].float()], 0.2)
-            else:
-                svae.update_gmm_params(theta, svae.m_step_from_stats(prior, st), 0.2)
+            else:                                                 # svae.m_step + update_gmm_params in one launch, as SVAETrainer.step does
+                svae.cvi_update_from_stats(prior, theta, st.double(), 0.2, want_star=False)
 
         for i in range(warmup):
             one(i, False)
@@ -434,10 +434,10 @@ def time_t1(loop, steps, warmup, reps, barrier, dist, dev):
             loop.finalize_phase()
             if i % EV_EVERY == 0:
                 ev[i // EV_EVERY][0].record()
-                loop.estep()                             # exactly one launch: the fused streaming pass
+                loop.stream_phase()                      # exactly one launch: the streaming pass (one-launch form: with the posterior in its head)
                 ev[i // EV_EVERY][1].record()
             else:
-                loop.estep()
+                loop.stream_phase()
         barrier()
         dt = max_over_ranks(dist, time.perf_counter() - t0, dev)
         walls.append(dt)

@@ -662,10 +662,50 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
 // coordinates 0..3 (operands of the one-MFMA tiles, see below) | pad; 144 B = 9 16-byte slots: 16 rows hit 16 bank groups
 constexpr int AIS = 36;
 
+#ifndef VMP_STEP_SCOPE
+#define VMP_STEP_SCOPE __HIP_MEMORY_SCOPE_SYSTEM     // scope of the tagged-pack stores / loads of the one-launch step (A/B builds: __HIP_MEMORY_SCOPE_AGENT)
+#endif
+struct FinArgs {
+    const double* partials;    // [K][MAX_BLOCKS][PF + 1]   (src == 0)
+    const double* stats_in;    // [K][SW]         (src == 1)
+    int nblk, K, flavour, src, do_post;
+    const float *alpha0, *beta0, *m0, *C0, *v0, *kappa;
+    const float* pivot;        // the shift the pass kernel applied to x (src == 0 only; NULL: none)
+    float *alpha, *beta, *m, *C, *v, *xbar, *S, *pi, *pack;
+    double* stats_out;
+    // one-launch data-parallel form (vmp_mix_finalize_exchange): peer[g] = rank g's exchange buffer; nranks = 0: no exchange
+    double* peer[VMP_EXCH_MAX_RANKS];
+    int nranks, rank;
+    unsigned long long iter;
+    int* status;
+    // one-launch step (vmp_mix_step): the block runs as the HEAD of the streaming launch.  Every pack word is ALSO written as a
+    // self-validating 64-bit word (iteration tag << 32 | float bits) with a system-scope write-through store into tpack
+    // (K x PACK words); the waves of the same launch poll those words: data and "ready" arrive in one memory round trip, and the
+    // writer never waits (a separate sequence word behind a drained store queue cost two more round trips: +3.5 us per step).
+    unsigned long long* tpack;
+    unsigned tag;
+#ifdef VMP_DEBUG_TS
+    long long* dbg_t;          // exploration builds only: 8 timestamps of block 0 / thread 0
+#endif
+};
+
+#ifdef VMP_DEBUG_TS
+#define FIN_TS(i) do { if (a.dbg_t && blockIdx.x == 0 && tid == 0) { a.dbg_t[i] = clock64(); if ((i) == 0) a.dbg_t[6] = wall_clock64(); if ((i) == 5) a.dbg_t[7] = wall_clock64(); } } while (0)
+#else
+#define FIN_TS(i) do { } while (0)
+#endif
+
+template <int D>
+__device__ void finalize_block(const FinArgs& a, const int k, const int tid, const int nthreads);   // defined below the pass kernels
+
 template <int D> constexpr int xdl_wave_floats() { return Geo<D>::XROWS * LS + TR * AIS; }
 
-template <int D, int FLAV, bool STATS>
-__global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
+// HEAD = true (vmp_mix_step, the one-launch iteration): blocks 0..K-1 first run finalize_block on the partials the PREVIOUS launch
+// left (visible across the kernel boundary) and publish their pack row; every wave of the launch stages its first rows, then polls
+// the K sequence words and reads the pack with system-scope loads (no cache between XCDs holds it).  All blocks wait for all K
+// words, so nobody overwrites a partial row that a head block has not read yet.
+template <int D, int FLAV, bool STATS, bool HEAD>
+__device__ __forceinline__ void pass_xdl_body(const PassArgs& a, const FinArgs* fin) {
     using G = Geo<D>;
     constexpr int FT = G::FT, KT = 1;
     constexpr bool SMM = (FLAV == VMP_SMM);
@@ -688,6 +728,11 @@ __global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
         *reinterpret_cast<u32x4*>(ai + lane * AIS + 16) = zeros;
     }
 
+    // HEAD: the K-sized posterior first - it is the head of the launch's critical path; the block's first rows are requested after it
+    // (the other blocks request theirs at once and then wait for the pack)
+    if constexpr (HEAD) {
+        if ((int)blockIdx.x < K) finalize_block<D>(*fin, (int)blockIdx.x, (int)threadIdx.x, (int)blockDim.x);
+    }
     const bool vec = a.vec_ok != 0;
     long long lo, hi;
     if (a.rpw_b == a.rpw) {
@@ -722,11 +767,46 @@ __global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
     u32x4 Bsm[NS], B1[NB > 0 ? NB : 1], B2[NB > 0 ? NB : 1];
     v2f pch;
     float pua, pub;
+    __shared__ float spk[HEAD ? 16 * G::PACK : 1];           // HEAD: the block's copy of the K pack rows
+    if constexpr (HEAD) {
+        // ONE wave per block polls the tagged pack (K x PACK 64-bit words, all loads of a round in flight together) until every
+        // word carries this launch's tag, and drops the values into LDS for the block - 2 048 waves polling and reading the same
+        // lines with system-scope loads made one memory channel the bottleneck of the launch (+18 us).  Bounded: ~2 s, then
+        // status = 2 and the launch runs on.
+        if (wave == 0) {
+            constexpr int NLD = (16 * G::PACK + WAVE - 1) / WAVE;
+            const unsigned want = fin->tag;
+            const long long t0 = wall_clock64();             // 100 MHz
+            unsigned long long pk[NLD];
+            for (;;) {
+                bool fresh = true;
+#pragma unroll
+                for (int q = 0; q < NLD; ++q) {              // all loads of a round in flight together
+                    const int e = q * WAVE + lane;
+                    pk[q] = __hip_atomic_load(fin->tpack + (e < K * G::PACK ? e : 0), __ATOMIC_RELAXED, VMP_STEP_SCOPE);
+                }
+#pragma unroll
+                for (int q = 0; q < NLD; ++q) fresh = fresh && (unsigned)(pk[q] >> 32) == want;
+                if (__builtin_amdgcn_ballot_w64(!fresh) == 0ull) break;
+                if (wall_clock64() - t0 > 200000000ll) { if (lane == 0 && fin->status) *fin->status = 2; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int q = 0; q < NLD; ++q) {
+                const int e = q * WAVE + lane;
+                if (e < K * G::PACK) spk[e] = __uint_as_float((unsigned)pk[q]);
+            }
+        }
+        __syncthreads();
+    }
     {
         const bool on = i16 < K;
         const float* __restrict__ p = a.pack + (on ? i16 : 0) * G::PACK;
         float raw[G::PACK];
-        if (G::PACK % 4 == 0 && (reinterpret_cast<uintptr_t>(a.pack) & 15) == 0) {
+        if constexpr (HEAD) {
+#pragma unroll
+            for (int j = 0; j < G::PACK; ++j) raw[j] = spk[(on ? i16 : 0) * G::PACK + j];
+        } else if (G::PACK % 4 == 0 && (reinterpret_cast<uintptr_t>(a.pack) & 15) == 0) {
 #pragma unroll
             for (int j = 0; j < G::PACK / 4; ++j) {
                 const float4 q = reinterpret_cast<const float4*>(p)[j];
@@ -1033,6 +1113,18 @@ __global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
     if constexpr (STATS) pass_epilogue<D, 1, FLAV>(a, smem, dacc, dn, lane, wave, nw);
 }
 
+template <int D, int FLAV, bool STATS>
+__global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
+    pass_xdl_body<D, FLAV, STATS, false>(a, nullptr);
+}
+
+// The whole VMP iteration (gmm.py:258-263 / smm.py:232-238) as ONE launch: K-sized posterior in the heads of blocks 0..K-1,
+// streaming E-pass with fused moments in all blocks.
+template <int D, int FLAV>
+__global__ __launch_bounds__(MAX_NW1 * WAVE) void step_xdl_kernel(PassArgs a, FinArgs f) {
+    pass_xdl_body<D, FLAV, true, true>(a, &f);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // K-sized posterior update (one block per component), fp64.
 // ---------------------------------------------------------------------------------------------------------
@@ -1043,30 +1135,6 @@ __device__ double digamma_d(double x) {
     return r + log(x) - 0.5 / x
            - f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f * (1.0 / 132 - f * (691.0 / 32760))))));
 }
-
-struct FinArgs {
-    const double* partials;    // [K][MAX_BLOCKS][PF + 1]   (src == 0)
-    const double* stats_in;    // [K][SW]         (src == 1)
-    int nblk, K, flavour, src, do_post;
-    const float *alpha0, *beta0, *m0, *C0, *v0, *kappa;
-    const float* pivot;        // the shift the pass kernel applied to x (src == 0 only; NULL: none)
-    float *alpha, *beta, *m, *C, *v, *xbar, *S, *pi, *pack;
-    double* stats_out;
-    // one-launch data-parallel form (vmp_mix_finalize_exchange): peer[g] = rank g's exchange buffer; nranks = 0: no exchange
-    double* peer[VMP_EXCH_MAX_RANKS];
-    int nranks, rank;
-    unsigned long long iter;
-    int* status;
-#ifdef VMP_DEBUG_TS
-    long long* dbg_t;          // exploration builds only: 8 timestamps of block 0 / thread 0
-#endif
-};
-
-#ifdef VMP_DEBUG_TS
-#define FIN_TS(i) do { if (a.dbg_t && blockIdx.x == 0 && tid == 0) { a.dbg_t[i] = clock64(); if ((i) == 0) a.dbg_t[6] = wall_clock64(); if ((i) == 5) a.dbg_t[7] = wall_clock64(); } } while (0)
-#else
-#define FIN_TS(i) do { } while (0)
-#endif
 
 template <int D>
 __device__ void write_pack(float* pack, int k, const double* m, const double* W /*lower, row-major full DxD*/,
@@ -1200,20 +1268,29 @@ __device__ void estep_constants(int k, int flavour, double alpha_k, double alpha
 }
 
 constexpr int FIN_THREADS = 1024;
-constexpr int FIN_GROUPS = FIN_THREADS / 64;
+constexpr int FIN_MAX_GROUPS = FIN_THREADS / 64;
 
-// One block per component.  Phase A: all 1024 threads reduce the per-block partials in a fixed order.
-// Phase B: 64 lanes build S_k, C_k element-wise.  Phase C: thread 0 factorises C_k while lanes 64.. evaluate
+// a pack word: plain store + (one-launch step) the tagged system-scope copy that the waves of the same launch poll
+__device__ __forceinline__ void st_pack(const FinArgs& a, int idx, float v) {
+    a.pack[idx] = v;
+    if (a.tpack)
+        __hip_atomic_store(a.tpack + idx, ((unsigned long long)a.tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, VMP_STEP_SCOPE);
+}
+
+// One block per component (k), `nthreads` threads (>= 192, a multiple of 64; the stand-alone kernel: 1024, the head of the
+// one-launch step: the streaming block's 512).  Phase A: all threads reduce the per-block partials in a fixed order.
+// Phase B: 64 lanes build S_k, C_k element-wise.  Phase C: wave 0 factorises C_k while lanes 64.. evaluate
 // the digamma / lgamma terms.  Phase D: constants + pack.
 template <int D>
-__global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
+__device__ void finalize_block(const FinArgs& a, const int k, const int tid, const int nthreads) {
     using G = Geo<D>;
-    __shared__ double part[FIN_GROUPS][64];
+    __shared__ double part[FIN_MAX_GROUPS][64];
     __shared__ double st[G::SW];           // canonical: Nk, Wk, sx[D], sxx[D*D]
     __shared__ double ntot;                // sum_j N_j over all components
     __shared__ double Ck[D * D], mk[D], sp[D + 4], scal[8];
     __shared__ double alpha0s[VMP_MAX_K];
-    const int k = blockIdx.x, tid = threadIdx.x, K = a.K;
+    const int K = a.K;
+    const int FIN_GROUPS = nthreads >> 6;
     // issue every small prior load up front so that its latency overlaps the partial-sum loads below
     const bool post = a.do_post != 0;
     const bool smm = a.flavour == VMP_SMM;
@@ -1233,35 +1310,39 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
     if (a.src == 0) {
         constexpr int PX = G::PF + 1;
         const int f = tid & 63, g = tid >> 6;
-        double s = 0.0;
         // all loads of a chunk are issued before the first add (fixed summation order: b ascending).  The rows of this
-        // component are contiguous: partials[k][b][PX].
+        // component are contiguous: partials[k][b][PX].  The order of the additions does not depend on the thread count: there are
+        // always FIN_MAX_GROUPS LOGICAL groups (group lg sums blocks lg, lg + 16, ..), a block of fewer waves takes several each -
+        // the head of the one-launch step (512 threads) is bit-identical to the stand-alone kernel (1024).
         const double* __restrict__ mine = a.partials + (long long)k * MAX_BLOCKS * PX;
-        for (int b0 = g; b0 < a.nblk; b0 += FIN_GROUPS * 16) {
-            double v1[16];
-            // unconditional loads from clamped (always valid) addresses, masked afterwards: a load under a
-            // per-element condition becomes a branch + full wait per element (32 serialised round trips)
-            const int fc = f < PX ? f : PX - 1;
+        for (int lg = g; lg < FIN_MAX_GROUPS; lg += FIN_GROUPS) {
+            double s = 0.0;
+            for (int b0 = lg; b0 < a.nblk; b0 += FIN_MAX_GROUPS * 16) {
+                double v1[16];
+                // unconditional loads from clamped (always valid) addresses, masked afterwards: a load under a
+                // per-element condition becomes a branch + full wait per element (32 serialised round trips)
+                const int fc = f < PX ? f : PX - 1;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int b = b0 + i * FIN_GROUPS;
-                const int bc = b < a.nblk ? b : a.nblk - 1;
-                v1[i] = mine[(long long)bc * PX + fc];
+                for (int i = 0; i < 16; ++i) {
+                    const int b = b0 + i * FIN_MAX_GROUPS;
+                    const int bc = b < a.nblk ? b : a.nblk - 1;
+                    v1[i] = mine[(long long)bc * PX + fc];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const bool in = b0 + i * FIN_MAX_GROUPS < a.nblk;
+                    v1[i] = (in && f < PX) ? v1[i] : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s += v1[i];
             }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const bool in = b0 + i * FIN_GROUPS < a.nblk;
-                v1[i] = (in && f < PX) ? v1[i] : 0.0;
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s += v1[i];
+            part[lg][f] = s;
         }
-        part[g][f] = s;
         __syncthreads();
         FIN_TS(1);
         if (tid < 64) {
             double t1 = 0.0;
-            for (int gg = 0; gg < FIN_GROUPS; ++gg) t1 += part[gg][tid];
+            for (int gg = 0; gg < FIN_MAX_GROUPS; ++gg) t1 += part[gg][tid];
             part[0][tid] = t1;
         }
         __syncthreads();
@@ -1273,7 +1354,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
             st[2 + D + tid] = part[0][1 + D + lo * D - lo * (lo - 1) / 2 + (hi - lo)];
         }
     } else {
-        for (int i = tid; i < G::SW; i += FIN_THREADS) st[i] = a.stats_in[(long long)k * G::SW + i];
+        for (int i = tid; i < G::SW; i += nthreads) st[i] = a.stats_in[(long long)k * G::SW + i];
         if (tid == 0) {
             double t = 0.0;
             for (int j = 0; j < K; ++j) t += a.stats_in[(long long)j * G::SW];
@@ -1354,7 +1435,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
         __syncthreads();
     }
     if (a.stats_out) {
-        for (int i = tid; i < G::SW; i += FIN_THREADS) {
+        for (int i = tid; i < G::SW; i += nthreads) {
             double val = st[i];
             if (shifted && i >= 2) {
                 const double W = st[1];
@@ -1418,10 +1499,10 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
         wave_chol_inverse<D>(Ck, tid, X, sumlog, ok);
         const double sv = ok ? sqrt(v_k) : nan("");
         if (a.pack && tid < D) {
-            float* p = a.pack + k * G::PACK + D;
+            const int p = k * G::PACK + D;
 #pragma unroll
             for (int i = 0; i < D; ++i)
-                if (i >= tid) p[i * (i + 1) / 2 + tid] = (float)(X[i] * sv);      // W = sqrt(v) L^{-1}, lower
+                if (i >= tid) st_pack(a, p + i * (i + 1) / 2 + tid, (float)(X[i] * sv));      // W = sqrt(v) L^{-1}, lower
         }
         if (tid == 0) { scal[0] = -2.0 * sumlog; scal[1] = ok ? 1.0 : 0.0; }
     } else if (tid >= 64 && tid < 64 + D + 2) {
@@ -1463,17 +1544,20 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
         if (scal[1] == 0.0) c = nan("");
         if (a.pi) a.pi[k] = (float)exp(elp);
         if (a.pack) {
-            float* p = a.pack + k * G::PACK + D + G::TRI;
+            const int p = k * G::PACK + D + G::TRI;
             const double LOG2E = 1.4426950408889634074;  // the pass kernel evaluates 2^(c - h q)
-            p[0] = (float)(c * LOG2E); p[1] = (float)(h * LOG2E); p[2] = (float)ua; p[3] = (float)ub;
+            st_pack(a, p, (float)(c * LOG2E)); st_pack(a, p + 1, (float)(h * LOG2E)); st_pack(a, p + 2, (float)ua); st_pack(a, p + 3, (float)ub);
         }
     }
-    if (a.pack) {
-        float* p = a.pack + k * G::PACK;
-        if (tid < D) p[tid] = (float)mk[tid];
-    }
+    if (a.pack && tid < D) st_pack(a, k * G::PACK + tid, (float)mk[tid]);
     FIN_TS(5);
 }
+
+template <int D>
+__global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(FinArgs a) {
+    finalize_block<D>(a, blockIdx.x, threadIdx.x, FIN_THREADS);
+}
+
 
 // E-step pack from explicit (alpha, beta, m, P, v): gmm.e_step / smm.e_step signature.
 struct PackArgs {
@@ -1718,6 +1802,45 @@ int run_finalize(FinArgs f, int D, hipStream_t s) {
     return rc;
 }
 
+// workspace layout: [per-block partials | tagged pack of the one-launch step: 16 x PACK 64-bit words | status word]
+constexpr size_t WS_TPACK_WORDS = 16 * (VMP_MAX_D + VMP_MAX_D * (VMP_MAX_D + 1) / 2 + 4);
+inline size_t ws_partial_bytes(int D, int K) { return (size_t)MAX_BLOCKS * K * (partial_words(D) + 1) * sizeof(double); }
+inline unsigned long long* ws_seq(void* ws, int D, int K) { return reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + ws_partial_bytes(D, K)); }
+inline int* ws_status(void* ws, int D, int K) { return reinterpret_cast<int*>(ws_seq(ws, D, K) + WS_TPACK_WORDS); }
+
+// one-launch iteration: 1 = launched, 0 = this shape takes the two-launch form (K > 16, too few rows for full blocks), < 0 / > 1: error
+template <int D>
+int launch_step_xdl(const PassArgs& a, const FinArgs& f, const Plan& p, int flavour, hipStream_t s) {
+    dim3 grid(p.blocks), block(p.nw * WAVE);
+    if (flavour == VMP_GMM) {
+        if (p.lds > 48 * 1024) { if (const int rc_ = set_dyn_lds(reinterpret_cast<const void*>(step_xdl_kernel<D, VMP_GMM>), p.lds, "step_xdl_kernel")) return rc_; }
+        hipLaunchKernelGGL((step_xdl_kernel<D, VMP_GMM>), grid, block, p.lds, s, a, f);
+    } else {
+        if (p.lds > 48 * 1024) { if (const int rc_ = set_dyn_lds(reinterpret_cast<const void*>(step_xdl_kernel<D, VMP_SMM>), p.lds, "step_xdl_kernel")) return rc_; }
+        hipLaunchKernelGGL((step_xdl_kernel<D, VMP_SMM>), grid, block, p.lds, s, a, f);
+    }
+    const int rc = check_launch("step_xdl_kernel");
+    return rc ? rc : 1;
+}
+
+int run_step(PassArgs a, FinArgs f, int D, int flavour, hipStream_t s) {
+    if (!use_xdl(a.K, true, false)) return 0;
+    Plan p = make_plan(a.N, D, a.K, flavour, true, true);
+    // every block needs the full complement of waves (the head runs on the block's own threads: >= 192) and the K heads need K blocks
+    if (p.nw != MAX_NW1 || p.blocks < a.K) return 0;
+    a.rpw = p.rpw;
+    a.rpw_b = p.rpw_b;
+    a.par_reduce = p.par_reduce;
+    f.nblk = p.blocks;
+#ifdef VMP_DEBUG_TS
+    a.dbg_t = g_dbg_pass;
+    f.dbg_t = g_dbg_t;
+#endif
+    int rc = -1;
+    VMP_DISPATCH_D(D, rc = launch_step_xdl<DD>(a, f, p, flavour, s));
+    return rc;
+}
+
 }  // namespace
 
 // =========================================================================================================
@@ -1735,7 +1858,8 @@ int vmp_mix_stats_words(int D) { return stats_words(D); }
 
 size_t vmp_mix_workspace_bytes(int64_t N, int D, int K) {
     (void)N;
-    return (size_t)MAX_BLOCKS * K * (partial_words(D) + 1) * sizeof(double);   // [K][MAX_BLOCKS][PF + 1] per-block partials
+    // [K][MAX_BLOCKS][PF + 1] per-block partials | sequence words + status of the one-launch step (vmp_mix_step)
+    return ws_partial_bytes(D, K) + (WS_TPACK_WORDS + 2) * sizeof(unsigned long long);
 }
 
 int vmp_mix_pivot(const float* x, int64_t N, int D, float* pivot_out, void* stream) {
@@ -1854,6 +1978,9 @@ int vmp_mix_stats_ws(const float* x, const float* r, const float* u, const float
     PassArgs a{};
     a.x = x; a.r_in = r; a.u_in = u; a.pivot = pivot; a.N = N; a.K = K; a.partials = static_cast<double*>(ws);
     a.vec_ok = aligned16(x) && aligned16(r) && (!u || aligned16(u));
+    // this call seeds the workspace of an iteration loop: the sequence words and the status of vmp_mix_step start at zero
+    hipError_t e = hipMemsetAsync(ws_seq(ws, D, K), 0, (WS_TPACK_WORDS + 2) * sizeof(unsigned long long), static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) { set_error("vmp_mix_stats_ws: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
     return run_pass(a, D, u ? VMP_SMM : VMP_GMM, false, true, false, static_cast<hipStream_t>(stream));
 }
 
@@ -1914,6 +2041,49 @@ int vmp_mix_iterate(const float* x, int64_t N, int D, int K, int flavour, const 
         rc = vmp_mix_estep_fused(x, N, D, K, flavour, pack, r, u, nullptr, pivot, ws, ws_bytes, stream);
         if (rc) return rc;
     }
+    return 0;
+}
+
+int vmp_mix_step(const float* x, int64_t N, int D, int K, int flavour, const float* alpha0, const float* beta0,
+                 const float* m0, const float* C0, const float* v0, const float* kappa, const float* pivot,
+                 float* r, float* u, float* logr, float* alpha, float* beta, float* m, float* C, float* v, float* xbar, float* S,
+                 float* pi, float* pack, void* ws, size_t ws_bytes, uint64_t first_iteration, int iterations, void* stream) {
+    int rc = check_dims(N, D, K);
+    if (rc) return rc;
+    if (iterations < 0 || first_iteration < 1 || !x || !r || !pack || !ws || !alpha0 || !beta0 || !m0 || !C0 || !v0) { set_error("vmp_mix_step: bad argument"); return VMP_E_BADARG; }
+    if (flavour != VMP_GMM && flavour != VMP_SMM) { set_error("vmp_mix_step: bad flavour %d", flavour); return VMP_E_BADARG; }
+    if (flavour == VMP_SMM && (!u || !kappa)) { set_error("vmp_mix_step: SMM needs u and kappa"); return VMP_E_BADARG; }
+    if (ws_bytes < vmp_mix_workspace_bytes(N, D, K)) { set_error("vmp_mix_step: workspace too small"); return VMP_E_WS; }
+    for (int it = 0; it < iterations; ++it) {
+        PassArgs a{};
+        a.x = x; a.pack = pack; a.r_out = r; a.u_out = u; a.logr_out = logr; a.pivot = pivot;
+        a.N = N; a.K = K; a.partials = static_cast<double*>(ws);
+        a.vec_ok = aligned16(x) && aligned16(r) && (!u || aligned16(u)) && (!logr || aligned16(logr));
+        FinArgs f{};
+        f.partials = static_cast<const double*>(ws);
+        f.K = K; f.flavour = flavour; f.src = 0; f.do_post = 1;
+        f.alpha0 = alpha0; f.beta0 = beta0; f.m0 = m0; f.C0 = C0; f.v0 = v0; f.kappa = kappa;
+        f.alpha = alpha; f.beta = beta; f.m = m; f.C = C; f.v = v; f.xbar = xbar; f.S = S; f.pi = pi; f.pack = pack;
+        f.pivot = pivot;
+        f.tpack = ws_seq(ws, D, K); f.tag = (unsigned)((first_iteration + (uint64_t)it) % 0xffffffffull) + 1u;   /* never 0: the cleared workspace */ f.status = ws_status(ws, D, K);
+        rc = run_step(a, f, D, flavour, static_cast<hipStream_t>(stream));
+        if (rc == 1) continue;
+        if (rc != 0) return rc;
+        // shapes outside the one-launch form: the two launches it fuses
+        rc = vmp_mix_finalize_ws(ws, pivot, N, D, K, flavour, alpha0, beta0, m0, C0, v0, kappa, alpha, beta, m, C, v, xbar, S, pi,
+                                 pack, nullptr, stream);
+        if (rc) return rc;
+        rc = vmp_mix_estep_fused(x, N, D, K, flavour, pack, r, u, logr, pivot, ws, ws_bytes, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int vmp_mix_step_status(const void* ws, int D, int K, int* status_out, void* stream) {
+    if (!ws || !status_out || D < 1 || D > VMP_MAX_D || K < 1 || K > VMP_MAX_K) { set_error("vmp_mix_step_status: bad argument"); return VMP_E_BADARG; }
+    hipError_t e = hipMemcpyAsync(status_out, ws_status(const_cast<void*>(ws), D, K), sizeof(int), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) { set_error("vmp_mix_step_status: %s", hipGetErrorString(e)); return (int)e; }
     return 0;
 }
 
