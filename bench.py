@@ -761,6 +761,14 @@ def main():
                              'flops_per_launch': t1_flops(n_loc, D, K),
                              'valu_frac': t1_flops(n_loc, D, K) / (kern_ms * 1e-3) / FP32_PEAK_FLOPS},
             })
+            if 'other_scaling' in extra:
+                # both scaling modes in the line's top-level config, so that a SCALE record cannot be read as the wrong mode (SURVEY 8e
+                # reads the >= 6x target at N / G rows per GPU = strong scaling)
+                o = extra['other_scaling']
+                vals = {args.scaling: out['value'], o['scaling']: o['value']}
+                out['config']['datapoints_per_sec_by_scaling'] = vals
+                out['config']['scaling_note'] = ('`value` is the %s-scaling number (%d rows per GPU); %s scaling (%d rows per GPU) measured right after it in the same '
+                                                 'launch: weak %.4g, strong %.4g datapoints/s' % (args.scaling, n_loc, o['scaling'], o['rows_per_rank'], vals['weak'], vals['strong']))
             if world == 1 and not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline(x_h, r0_h, args.workload)
                 out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']

@@ -406,6 +406,13 @@ def case_datasets():
         key = ds.replace('-', '_')
         o[key + '_X_tr'], o[key + '_X_te'] = npy(X_tr), npy(X_te)
         o[key + '_y_tr'], o[key + '_y_te'] = npy(y_tr), npy(y_te)
+    # validation split (data.py:91-105): the training part is split again and the VALIDATION rows come back as "test"
+    for ds in ('auto', 'noisy-pinwheel', 'geyser'):
+        X_tr, y_tr, X_te, y_te = rdata.make_minibatch(ds, ratio_tr=0.6, ratio_val=0.2, path_datadir=os.path.join(REF, 'datasets'),
+                                                      size_minibatch=-1, size_testbatch=-1, seed_split=3, noise_level=0.1)
+        key = 'val_' + ds.replace('-', '_')
+        o[key + '_X_tr'], o[key + '_X_te'] = npy(X_tr), npy(X_te)
+        o[key + '_y_tr'], o[key + '_y_te'] = npy(y_tr), npy(y_te)
     z = np.arange(60, dtype=np.float64).reshape(20, 3)
     o['perturb_in'] = z.copy()
     o['perturb_out'] = rdata.perturb_data(z.copy(), noise_ratio=0.25, noise_mean=1.0, noise_stddev=3.0, seed=7)

@@ -122,10 +122,13 @@ def test_peer_exchange_release_covers_every_storing_wave():
             st = [i for i, l in enumerate(ins) if l.startswith('global_store') and 'sc0 sc1' in l]
             assert len(st) >= 2, (name, st)                      # the slot loop's store and the sequence word's store
             first, flag = st[0], st[-1]
-            bar = next(i for i in range(first, len(ins)) if ins[i].startswith('s_barrier'))
+            bar = next((i for i in range(first, len(ins)) if ins[i].startswith('s_barrier')), None)
+            assert bar is not None, 'no workgroup barrier behind the slot stores of %s' % name
             assert first < bar < flag, name                      # data stores | barrier | flag store
-            # inside the storing threads' region: up to the instruction that restores exec
-            region_end = next(i for i in range(first, bar) if ins[i].startswith('s_or_b64 exec'))
+            # inside the storing threads' region: up to the instruction that restores exec (s_or_b64 exec, s_mov_b64 exec, s_andn2 ...:
+            # any scalar write of exec) - or, if the compiler kept exec as it was, up to the barrier
+            exec_write = re.compile(r'^s_\w+\s+exec\b')
+            region_end = next((i for i in range(first + 1, bar) if exec_write.match(ins[i])), bar)
             region = ins[first + 1:region_end]
             wb = [i for i, l in enumerate(region) if l.startswith('buffer_wbl2') and 'sc0' in l and 'sc1' in l]
             assert wb, (name, region)

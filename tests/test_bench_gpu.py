@@ -53,6 +53,8 @@ def test_t1_two_ranks_both_scaling_modes(scaling, exchange):
     assert o['scaling'] == ('strong' if scaling == 'weak' else 'weak') and o['exchange'] == exchange
     assert o['rows_job'] == (N if scaling == 'weak' else 2 * N)
     assert abs(o['value'] - o['rows_job'] / (o['ms_per_step'] * 1e-3)) < 1e-6 * o['value']
+    both = d['config']['datapoints_per_sec_by_scaling']                # both modes in the top-level config
+    assert both[scaling] == d['value'] and both[o['scaling']] == o['value'] and 'scaling_note' in d['config']
     r = d['roofline']
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and r['algorithmic_bytes_per_launch'] == 4.0 * d['config']['N_per_gpu'] * 48
 

@@ -38,6 +38,18 @@ def test_loaders_split_scaling_match_reference_make_minibatch():
         full = data.make_minibatch(ds, ratio_tr=0.7, path_datadir=DATADIR, size_minibatch=-1, device='cpu')
         assert np.allclose(full[0].numpy(), g[key + '_X_tr'], rtol=1e-6, atol=1e-6)
         assert np.allclose(full[1].numpy(), g[key + '_y_tr']) and np.allclose(full[3].numpy(), g[key + '_y_te'])
+    # validation split (data.py:91-105; ratio_tr 0.6, ratio_val 0.2, seed_split 3): train + VALIDATION rows come back
+    for ds in ('auto', 'noisy-pinwheel', 'geyser'):
+        key = 'val_' + ds.replace('-', '_')
+        full = data.make_minibatch(ds, ratio_tr=0.6, ratio_val=0.2, path_datadir=DATADIR, size_minibatch=-1, seed_split=3, device='cpu')
+        for got, name in zip(full, ('X_tr', 'y_tr', 'X_te', 'y_te')):
+            want = g[key + '_' + name]
+            if want.dtype == object or want.shape == ():              # unlabelled data set: None
+                assert got is None, (ds, name)
+                continue
+            assert tuple(got.shape) == want.shape, (ds, name)
+            assert np.allclose(got.numpy(), want.astype(np.float32), rtol=1e-6, atol=1e-6), (ds, name)
+    assert g['val_auto_X_tr'].shape[0] + g['val_auto_X_te'].shape[0] == 235            # 60 % of 392 rows, split 3 : 1
     assert g['auto_X_tr'].shape == (274, 6) and g['auto_X_te'].shape == (118, 6)
     assert np.array_equal(g['noisy_pinwheel_X_te'], g['pinwheel_X_te'])            # the test split stays clean
     assert (np.abs(g['noisy_pinwheel_X_tr'] - g['pinwheel_X_tr']).sum(1) > 0).sum() == 69

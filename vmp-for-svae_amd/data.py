@@ -44,10 +44,12 @@ def load_dataset(dataset, path_datadir=None):
     raise Exception("Dataset '%s' does not exist." % dataset)
 
 
-def split_and_scale(dataset, data, labels, ratio_tr=0.7, seed_split=0, noise_level=0.1):
+def split_and_scale(dataset, data, labels, ratio_tr=0.7, seed_split=0, noise_level=0.1, ratio_val=None):
     """data.py:82-120: sklearn train_test_split; 'noisy-pinwheel' perturbs the TRAINING rows only, after the split, with
     seed=seed_split (data.py:108-109); 'auto' is standardised and scaled by 5, pinwheel is left as is, everything else is
-    standardised.  Returns (X_tr, y_tr, X_te, y_te) with one-hot labels (or None)."""
+    standardised.  ratio_val (data.py:91-105): the training part is split once more with test_size = ratio_val / (ratio_tr +
+    ratio_val), and - as in the reference, which re-binds X_te / y_te there - the VALIDATION rows are what comes back as the
+    "test" outputs (the first split's test rows are only counted).  Returns (X_tr, y_tr, X_te, y_te) with one-hot labels (or None)."""
     from sklearn.model_selection import train_test_split
     from sklearn.preprocessing import StandardScaler
     onehot = None
@@ -58,6 +60,14 @@ def split_and_scale(dataset, data, labels, ratio_tr=0.7, seed_split=0, noise_lev
     else:
         X_tr, X_te = train_test_split(data, test_size=1 - ratio_tr, random_state=seed_split)
         y_tr = y_te = None
+    if ratio_val is not None:
+        if not ratio_tr > ratio_val:
+            raise AssertionError('ratio_tr > ratio_val (data.py:93)')
+        ratio_val_tr = ratio_val / (ratio_tr + ratio_val)
+        if labels is None:
+            X_tr, X_te = train_test_split(X_tr, test_size=ratio_val_tr, random_state=seed_split)
+        else:
+            X_tr, X_te, y_tr, y_te = train_test_split(X_tr, y_tr, test_size=ratio_val_tr, random_state=seed_split)
     if dataset == 'noisy-pinwheel':
         X_tr = perturb_data(np.array(X_tr, dtype=np.float64), noise_ratio=noise_level, noise_mean=0, noise_stddev=10,
                             seed=seed_split)
@@ -126,7 +136,7 @@ def make_minibatch(dataset, ratio_tr=None, ratio_val=None, binarise=False, path_
                    size_testbatch=-1, nb_towers=1, nb_threads=2, seed_split=0, seed_minibatch=0, dtype=None,
                    name='data_prep', noise_level=0.1, device='cuda', rank=None):
     """reference data.py:9-176 for the table datasets (pinwheel, noisy-pinwheel, auto, aggregation, geyser):
-    returns (y_tr, lbl_tr, y_te, lbl_te) like the reference.
+    returns (y_tr, lbl_tr, y_te, lbl_te) like the reference (with ratio_val: the validation rows as y_te / lbl_te, data.py:91-105).
       size_minibatch > 0: y_tr and lbl_tr are endless generators over the SAME shuffled stream (the reference's
         tf.train.shuffle_batch([X_tr, y_tr]) queue, data.py:130-150): the i-th next(lbl_tr) holds the labels of the rows of
         the i-th next(y_tr);
@@ -137,11 +147,9 @@ def make_minibatch(dataset, ratio_tr=None, ratio_val=None, binarise=False, path_
     import torch
     if dataset in ('mnist', 'mnist-small', 'fashion') or binarise:
         raise NotImplementedError('TFRecord image datasets are not built')
-    if ratio_val is not None:
-        raise NotImplementedError('validation split (data.py:91-105) is not built')
     data, labels = load_dataset(dataset, path_datadir)
     X_tr, l_tr, X_te, l_te = split_and_scale(dataset, data, labels, ratio_tr=0.7 if ratio_tr is None else ratio_tr,
-                                             seed_split=seed_split, noise_level=noise_level)
+                                             seed_split=seed_split, noise_level=noise_level, ratio_val=ratio_val)
     dev = torch.device(device)
     to_t = lambda a: None if a is None else torch.as_tensor(a, dtype=torch.float32).to(dev)
     Xtr, Xte, Ltr, Lte = to_t(X_tr), to_t(X_te), to_t(l_tr), to_t(l_te)

@@ -106,12 +106,20 @@ class PeerExchange(object):
         # rendezvous a start skew between the ranks (data generation, uploads) could time a rank out before its peers arrive,
         # after which the sequence words never match again
         torch.cuda.synchronize()
-        if gather is None and self.world > 1:
-            dist.barrier(group)
+        if self.world > 1:
+            if gather is None:
+                dist.barrier(group)
+            else:
+                gather(b'mapped'.ljust(64, b'\0'))        # a second round of the caller's all-gather is the rendezvous
+        self._closed_explicitly = False
 
     def __del__(self):
+        # Freeing or unmapping a buffer that a peer's finalize kernel may still be pushing into or polling is a GPU fault on
+        # THAT rank, not a time-out.  Only a single-rank exchange is released implicitly; with peers the buffers live until the
+        # owner calls close() after a barrier (or until the process exits).
         try:
-            self.close()
+            if self.world == 1:
+                self.close()
         except Exception:
             pass
 
@@ -124,7 +132,9 @@ class PeerExchange(object):
 
     def close(self):
         """Unmap the peers' buffers and free this rank's (idempotent).  With several ranks call it after a barrier: a peer
-        may still be polling or pushing."""
+        may still be polling or pushing.  This rank's own queued kernels are drained first."""
+        if torch.cuda.is_available() and getattr(self, '_buf', None) is not None:
+            torch.cuda.synchronize()
         peers, self._peers = getattr(self, '_peers', []), []
         for g, pp in enumerate(peers):
             if g != self.rank:
