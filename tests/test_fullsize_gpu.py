@@ -191,3 +191,86 @@ def test_t3_training_step_at_65536_vs_chunked_oracle(dims, towers, smm):
     for n_, gr in ref['grads'].items():                           # the oracle AVERAGES over towers (tf_utils.py:79)
         e = _rel(out['grads'][n_], gr * towers, 1e-4, 'grad ' + n_)
         assert e <= 1e-4, (n_, e)
+
+
+@pytest.mark.parametrize('N,K,smm', [(1_000_000, 16, False), (250_000, 16, True), (300_000, 10, False)], ids=['c3-1e6', 'c5-smm-250k', 'k10-300k'])
+def test_t2_step_at_full_size_vs_chunked_oracle(N, K, smm):
+    """The T2 unit of SURVEY 8d AT BASELINE configs[2]'s size (N=1e6, L=8, K=16, S=10) against the oracle's literal restatement in
+    fp64 (oracle.train_ref.vmp_step_t2: svae.e_step, the regulariser of compute_elbo(_smm), autodiff, subsample_x, m_step,
+    update_gmm_params; models/svae.py:14-262, 376-403), row chunks of 8192: every output of the fused E-step forward WITH
+    IN-KERNEL NOISE (the oracle gets the materialised stream: 2 048 waves of the two-pair staging form), both N-sized gradients
+    and the K-sized gradients that 2 048 waves of the ring backward kernel reduce over 1e6 rows, the M-step moments and the CVI
+    update.  (Round 4 stopped at N = 65 536 against the oracle; 1e6 was property-checked only.)  c5-smm-250k: Student-t theta;
+    k10-300k: the C2 / C4 component count on the ring kernel's K < 16 form."""
+    from oracle import svae_ref, train_ref
+    from vmp_for_svae_amd.models import svae, _svae_ops, _mix
+    Ld, S = 8, 10
+    rng = np.random.Generator(np.random.PCG64(21))
+    m_unif, pi_norm = rng.random((K, Ld)).astype(np.float32), rng.standard_normal(K).astype(np.float32)
+    Lk_low = np.tril(rng.standard_normal((K, Ld, Ld)) * 0.2, -1).astype(np.float32)
+    dev = 'cuda'
+    g = torch.Generator(device=dev).manual_seed(5)
+    eta1 = torch.randn(N, Ld, device=dev, generator=g).requires_grad_(True)
+    eta2d = (-0.5 * torch.nn.functional.softplus(torch.randn(N, Ld, device=dev, generator=g))).requires_grad_(True)
+    Gx = torch.randn(N, K, S, Ld, device=dev, generator=g) * 0.01
+    Glz = torch.randn(N, K, device=dev, generator=g) * 0.1
+    zd = torch.randint(0, K, (N, S), device=dev, generator=g)
+    prior, theta = svae.init_mm(K, Ld, seed=0, param_device=dev, m_uniform=torch.as_tensor(m_unif).cuda())
+    phi = [p.detach().clone() for p in svae.init_recognition_params(theta, K, seed=0, param_device=dev, pi_normal=torch.as_tensor(pi_norm).cuda())]
+    phi[1] = phi[1] + torch.as_tensor(Lk_low).cuda()
+    phi = [p.requires_grad_(True) for p in phi]
+    th_params = []
+    th_mu = (rng.standard_normal((K, Ld)) * 1.5).astype(np.float32)
+    if smm:
+        mu_t, L_t = svae.make_loc_scale_variables(prior, dev)
+        with torch.no_grad():
+            mu_t.add_(torch.as_tensor(th_mu).cuda())
+        theta = [theta[0].clone(), mu_t, L_t, torch.full((K,), 5.0, device=dev)]
+        th_params = [mu_t, L_t]
+    seed = 424242
+    x, lz, pt, _ = svae.e_step((eta1, eta2d), phi, S, seed=seed, noise='philox', theta=theta)
+    r = torch.exp(lz.detach())
+    # loss = -elbo_reg + <x, Gx> + <log z, Glz>,  elbo_reg = -sum_nk r (T' + log z):  d/dT' = r, d/dlog z = r (T' + log z + 1) + Glz
+    grads = torch.autograd.grad([x, lz, pt.T_prime], [eta1, eta2d] + phi + th_params, [Gx, Glz + r * (pt.T_prime.detach() + lz.detach() + 1.0), r])
+    xs = svae.subsample_x(x, lz, z_draws=zd[:, :1], nb_out=1)[:, 0, :].contiguous()
+    if smm:
+        from vmp_for_svae_amd.models import gmm as _gmm
+        th_new = [(0.8 * theta[0] + 0.2 * (prior[0] + _gmm.update_Nk(r.contiguous())))]
+    else:
+        th_new = [t.clone() for t in theta]
+        svae.cvi_update_from_stats(prior, th_new, _mix.raw_stats(xs, r).double(), 0.2, want_star=False)
+    reg = (r * (pt.T_prime.detach() + lz.detach())).double().sum()
+    noise = _svae_ops.PhiloxNoise(seed, S).materialise(N, K, Ld, dev).cpu().double()
+    torch.cuda.synchronize()
+
+    T = lambda a: torch.as_tensor(a).double()
+    o_prior, o_theta = svae_ref.init_mm(K, Ld, T(m_unif), torch.float64)
+    o_phi = list(svae_ref.init_recognition_params(o_theta, T(pi_norm)))
+    o_phi[1] = o_phi[1] + T(Lk_low)
+    if smm:
+        mu_p, L_p = svae_ref.make_loc_scale(o_prior)
+        o_theta = [o_theta[0], mu_p + T(th_mu), L_p, torch.full((K,), 5.0, dtype=torch.float64)]
+        o_prior = o_prior[0]
+    nt = torch.get_num_threads()
+    torch.set_num_threads(min(32, nt))                       # the intra-op pool collapses at 256 threads (bench.py cpu_baseline)
+    try:
+        ref = train_ref.vmp_step_t2(o_phi, o_theta, o_prior, eta1.detach().cpu().double(), eta2d.detach().cpu().double(), noise,
+                                    zd.cpu(), Gx.cpu().double(), Glz.cpu().double(), 0.2, smm=smm, chunk=8192)
+    finally:
+        torch.set_num_threads(nt)
+    del noise
+    e = _abs(torch.exp(lz), torch.exp(ref['log_z']), 1e-5, 't2 r_nk N=%d' % N)
+    assert e <= 1e-5, e
+    assert _rel(xs, ref['x_samples'], 1e-5, 't2 x_samples') <= 1e-5
+    e = abs(reg.item() - ref['reg'].item()) / abs(ref['reg'].item())
+    parity_log.record('rel', e, 1e-5, 't2 regulariser')
+    assert e <= 1e-5, ('reg', e, reg.item(), ref['reg'].item())
+    for name, got, want in (('g_eta1', grads[0], ref['g_eta1']), ('g_eta2d', grads[1], ref['g_eta2d'])):
+        e = _rel(got, want, 1e-4, 't2 ' + name)
+        assert e <= 1e-4, (name, e)
+    for name, got, want in zip(('phi_gmm/mu_k', 'phi_gmm/L_k', 'phi_gmm/log_pi_k', 'theta/mu_k', 'theta/L_k'), grads[2:], ref['g_phi'] + ref['g_theta']):
+        e = _rel(got, want, 1e-4, 't2 grad ' + name)
+        assert e <= 1e-4, (name, e)
+    for n_, got, want in zip(('alpha', 'A', 'b', 'beta', 'vhat'), th_new, ref['theta_new']):
+        e = _rel(got, want, 1e-5, 't2 theta_new ' + n_)
+        assert e <= 1e-5, (n_, e)
