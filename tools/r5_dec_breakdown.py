@@ -12,7 +12,7 @@ KERNEL = sys.argv[1] if len(sys.argv) > 1 else 'dec_bwd_kernelILi4ELb1ELb0ELi2E'
 tmp = tempfile.mkdtemp()
 obj = os.path.join(tmp, 'dec.o')
 subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-gline-tables-only', '-Wno-unused-variable',
-                       '-Wno-unused-but-set-variable', '-c', SRC, '-o', obj], stderr=subprocess.DEVNULL)
+                       '-Wno-unused-but-set-variable'] + os.environ.get('EXTRA', '').split() + ['-c', SRC, '-o', obj], stderr=subprocess.DEVNULL)
 img = E.code_objects(open(obj, 'rb').read())[0]
 co = os.path.join(tmp, 'dec.co')
 open(co, 'wb').write(img)
@@ -55,30 +55,51 @@ for i, (a, op, text, _) in enumerate(ins):
 nm, j0, j1 = best
 loop = ins[j0:j1 + 1]
 src = open(SRC).read().splitlines()
+# categories by ANCHOR lines found in the source text (no hard-coded line numbers): a line belongs to the last anchor at or before it
+ANCHORS = [
+    ('__device__ __forceinline__ float rcp_f', 'tanh / softplus / sigmoid evaluation'),
+    ('__device__ __forceinline__ int kslot_unit', 'loop control / other'),
+    ('__device__ __forceinline__ f32x4 lds4', 'MFMA + operand fetch from the weight images (ds_read_b128)'),
+    ('struct RowMap {', 'tile inputs: row -> (cell, n) map and loads'),
+    ('__device__ __forceinline__ void split_tiles', 'bf16 splitting (v = h + m + l)'),
+    ('__device__ __forceinline__ void gemm_units', 'MFMA + operand fetch from the weight images (ds_read_b128)'),
+    ('__device__ __forceinline__ void dec_forward_tile', 'forward recompute glue (bias loads, ones unit)'),
+    ('__device__ __forceinline__ void wave_lds_order', '(unit,row) <-> (row,unit) transposes through the LDS scratch'),
+    ('void dec_bwd_kernel(DecArgs a) {', 'loop control / other'),
+    ('    struct TileIn {', 'tile inputs: row -> (cell, n) map and loads'),
+    ('        unsigned xs[3];', '(unit,row) <-> (row,unit) transposes through the LDS scratch'),
+    ('        f32x4 h0[UT], h1[UT], O;', 'forward recompute glue (bias loads, ones unit)'),
+    ('        // ---- reconstruction term: gradients w.r.t. the output slots', 'reconstruction term: log-likelihood value and output gradients'),
+    ('        // ---- dh1 = W2 . dO', 'MFMA + operand fetch from the weight images (ds_read_b128)'),
+    ('        // ---- through tanh of layer 1', 'tanh derivative (1 - h^2) and bias-gradient sums'),
+    ('        // ---- dh0 = W1 . dh1pre', 'MFMA + operand fetch from the weight images (ds_read_b128)'),
+    ('        // ---- through tanh of layer 0', 'tanh derivative (1 - h^2) and bias-gradient sums'),
+    ('        // ---- dx = W0 . dh0pre', 'MFMA + operand fetch from the weight images (ds_read_b128)'),
+    ('    // ---- reduce the per-wave accumulators through LDS', 'loop control / other'),
+]
+_anch = []
+for needle, cat in ANCHORS:
+    hits = [i + 1 for i, l in enumerate(src) if l.startswith(needle) or (needle.startswith(' ') and l.rstrip() == needle.rstrip()) or needle in l and needle.startswith('void ')]
+    if not hits:
+        raise SystemExit('anchor not found in the source: %r' % needle)
+    _anch.append((hits[0], cat))
+_anch.sort()
+common = open(os.path.join(os.path.dirname(SRC), 'vmp_common.h')).read().splitlines()
+_split0 = next(i + 1 for i, l in enumerate(common) if 'void split_bf16(' in l)
+_cvt0 = next((i + 1 for i, l in enumerate(common) if 'cvt_pk_bf16(' in l and '__device__' in l), None)
 def fn_of(file, line):
     """category of a source line"""
     if file == 'vmp_common.h':
-        return 'bf16 splitting (v = h + m + l)' if 30 <= line <= 46 else 'common helpers (row sums ...)'
+        if _split0 - 2 <= line <= _split0 + 12 or (_cvt0 is not None and _cvt0 - 1 <= line <= _cvt0 + 8):
+            return 'bf16 splitting (v = h + m + l)'
+        return 'common helpers (row sums ...)'
     if file != 'vmp_decoder.hip':
-        return 'other file'
-    L = line
-    def within(name_start, name_end):
-        return name_start <= L <= name_end
-    if 137 <= L <= 186: return 'tanh / softplus / sigmoid evaluation'
-    if 364 <= L <= 381: return 'tile inputs: row -> (cell, n) map and loads'
-    if 382 <= L <= 397: return 'bf16 splitting (v = h + m + l)'
-    if 354 <= L <= 363: return 'MFMA + operand fetch from the weight images (ds_read_b128)'
-    if 399 <= L <= 479: return 'MFMA + operand fetch from the weight images (ds_read_b128)'
-    if 480 <= L <= 516: return 'forward recompute glue (bias loads, ones unit)'
-    if 575 <= L <= 627: return '(unit,row) <-> (row,unit) transposes through the LDS scratch'
-    if 687 <= L <= 722: return 'tile inputs: row -> (cell, n) map and loads'
-    if 723 <= L <= 736: return '(unit,row) <-> (row,unit) transposes through the LDS scratch'
-    if 746 <= L <= 777: return 'reconstruction term: log-likelihood value and output gradients'
-    if 778 <= L <= 812: return 'MFMA + operand fetch from the weight images (ds_read_b128)'
-    if 813 <= L <= 821 or 852 <= L <= 859: return 'tanh derivative (1 - h^2) and bias-gradient sums'
-    if 822 <= L <= 851 or 860 <= L <= 888: return 'MFMA + operand fetch from the weight images (ds_read_b128)'
-    if 713 <= L <= 722: return 'tile inputs: row -> (cell, n) map and loads'
-    return 'loop control / other'
+        return 'library math inlined from other headers (expf, logf ...)'
+    cat = 'loop control / other'
+    for l0, c in _anch:
+        if l0 <= line:
+            cat = c
+    return cat
 def kind(op):
     if op.startswith('v_mfma'): return 'MFMA'
     if op.startswith('v_'): return 'VALU'
@@ -96,6 +117,7 @@ for a, op, text, (f, l) in loop:
 tot = collections.Counter()
 for c in tab:
     tot.update(tab[c])
+print(os.environ.get('TITLE', ''))
 print('Fused decoder backward, tile loop of %s (one 16-row tile per iteration and wave; U = 50 -> UT = 4 unit tiles, 2-term operands on the' % KERNEL)
 print('backward data path).  Instructions of ONE iteration, attributed to the source lines they were generated from (llvm-objdump -l on a')
 print('-gline-tables-only build of csrc/vmp_decoder.hip; tools/r5_dec_breakdown.py).  %d instructions: %s' % (len(loop), dict(tot)))

@@ -38,6 +38,9 @@ using namespace vmp;
 
 namespace {
 
+#ifndef VMP_DEC_FWD_TERMS_FOLLOW_BT
+#define VMP_DEC_FWD_TERMS_FOLLOW_BT 1      // the backward kernel's forward recompute uses its BT-term operands (0: always 3 terms, A/B builds)
+#endif
 constexpr int FWD_THREADS = 256;       // forward: 2+ blocks per CU
 constexpr int BWD_THREADS = 512;       // backward: 1 block per CU (8 waves share one set of operand images)
 constexpr int BWD_WAVES = BWD_THREADS / WAVE;
@@ -477,7 +480,13 @@ __device__ __forceinline__ f32x4 gemm_slots(const float* __restrict__ img, int l
 // forward of one 16-row tile.  onev >= 0 on the lanes that own the free padding unit of the last tile: that unit's
 // activation is forced to 1 (its weights are zero everywhere), see the bias-gradient note at dec_bwd_kernel.
 // h0s / h1s = bf16 terms of the activations (the backward pass transposes them for the weight gradients).
-template <int UT, bool ONES>
+// TERMS = 2 (round 5: the backward kernel's recompute at >= 2^19 rows, VMP_DEC_FWD_TERMS_FOLLOW_BT): 2-term operands for the two
+// hidden layers and the output layer as well - 2^-17 per product on activations whose every consumer is a sum over >= 2^19 rows or
+// the per-row dx.  profiles/r05_decoder_tile_breakdown.txt: the 3-term splits of h0 / h1 were 128 of the tile's 808 VALU
+// instructions and 60 of its 160 MFMAs carried their third-term products; same box 7.14 -> 6.29 ms per 4.2e7 rows.  Against the
+// fp64 oracle at N = 65 536 (1e7 rows): every gradient <= 3.5e-6 relative (3-term recompute: <= 6e-7; bar 1e-4; the reference's own
+// fp32 arithmetic: 3e-7 .. 1e-5), ELBO 2.7e-8.
+template <int UT, bool ONES, int TERMS = 3>
 __device__ __forceinline__ void dec_forward_tile(const float* __restrict__ sm, int lane, const XOps& xo, int onev,
                                                  f32x4 (&h0)[UT], unsigned (&h0s)[3][4 * Img<UT>::KB], f32x4 (&h1)[UT],
                                                  unsigned (&h1s)[3][4 * Img<UT>::KB], f32x4& O) {
@@ -503,15 +512,15 @@ __device__ __forceinline__ void dec_forward_tile(const float* __restrict__ sm, i
 #pragma unroll
         for (int v = 0; v < 4; ++v) h0[UT - 1][v] = onev == v ? 1.0f : h0[UT - 1][v];
     }
-    split_tiles<UT>(h0, h0s);
+    split_tiles<UT, TERMS>(h0, h0s);
 #pragma unroll
     for (int tp = 0; tp < UT; ++tp) h1[tp] = lds4(sm + I::BIAS1 + 16 * tp + 4 * g);
-    gemm_units<UT, UT>(sm + I::F1, lane, h0s, h1);
+    gemm_units<UT, UT, TERMS>(sm + I::F1, lane, h0s, h1);
 #pragma unroll
     for (int tp = 0; tp < UT; ++tp) h1[tp] = tanh4(h1[tp]);
-    split_tiles<UT>(h1, h1s);
+    split_tiles<UT, TERMS>(h1, h1s);
     const f32x4 os = gemm_dims(sm + I::F2SA, sm + I::F2SB, lane, xo, f32x4{0.f, 0.f, 0.f, 0.f});
-    O = gemm_units_1<UT>(sm + I::F2, lane, h1s, lds4(sm + I::BIASO + 4 * g)) + os;
+    O = gemm_units_1<UT, TERMS>(sm + I::F2, lane, h1s, lds4(sm + I::BIASO + 4 * g)) + os;
 }
 
 template <int UT>
@@ -737,7 +746,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
         f32x4 h0[UT], h1[UT], O;
         {
             unsigned h0s[3][4 * KB], h1s[3][4 * KB];
-            dec_forward_tile<UT, FS>(sm, lane, xo, onev, h0, h0s, h1, h1s, O);
+            dec_forward_tile<UT, FS, (VMP_DEC_FWD_TERMS_FOLLOW_BT ? BT : 3)>(sm, lane, xo, onev, h0, h0s, h1, h1s, O);
             trb_write<UT>(scrPb, g, c, h0s);
             trb_write<UT>(scrQb, g, c, h1s);
         }
