@@ -498,7 +498,8 @@ def measure_traffic(workload, N, D, K):
             for f in glob.glob(os.path.join(out, '**', '*%s_counter_collection.csv' % tag), recursive=True):
                 for row in csv.DictReader(open(f)):
                     n = row['Kernel_Name']
-                    fused = ('pass_xdl_kernel' in n and n.rstrip(')').split('>')[0].endswith('true')) or \
+                    # pass_xdl_kernel<D, FLAV, STATS = true, MT> / pass_kernel<D, KT, FLAV, ESTEP = true, STATS = true, MASK = false>
+                    fused = ('pass_xdl_kernel<' in n and ', true' in n.split('>')[0]) or \
                             ('pass_kernel<' in n and 'true, true, false>' in n)
                     if fused and row['Counter_Name'] == ctr:
                         v.append(float(row['Counter_Value']))

@@ -704,7 +704,11 @@ template <int D> constexpr int xdl_wave_floats() { return Geo<D>::XROWS * LS + T
 // left (visible across the kernel boundary) and publish their pack row; every wave of the launch stages its first rows, then polls
 // the K sequence words and reads the pack with system-scope loads (no cache between XCDs holds it).  All blocks wait for all K
 // words, so nobody overwrites a partial row that a head block has not read yet.
-template <int D, int FLAV, bool STATS, bool HEAD>
+// MT: bf16 terms per operand of the MOMENT GEMM.  3 (six products: fp32-equivalent products) below VMP_MOM2_ROWS rows; 2 (three
+// products, 2^-17 relative per product, unbiased) from there on: every moment is then a sum over >= 1e4 rows per component whose
+// per-term rounding errors average out (relative error of a moment ~ 2^-17 / sqrt(rows of the component) < 1e-7), while the splits
+// and MFMAs they save are a fifth of the kernel's issue time (round 5).  The E-part (one value per row, nothing averages) keeps 3.
+template <int D, int FLAV, bool STATS, bool HEAD, int MT = 3>
 __device__ __forceinline__ void pass_xdl_body(const PassArgs& a, const FinArgs* fin) {
     using G = Geo<D>;
     constexpr int FT = G::FT, KT = 1;
@@ -1025,7 +1029,7 @@ __device__ __forceinline__ void pass_xdl_body(const PassArgs& a, const FinArgs* 
                     unsigned t3[3];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        split_bf16<MOM_TERMS>(w[h], t3);
+                        split_bf16<MT>(w[h], t3);
 #pragma unroll
                         for (int t = 0; t < 3; ++t) As[t][2 * jj + h] = t3[t];
                     }
@@ -1037,7 +1041,7 @@ __device__ __forceinline__ void pass_xdl_body(const PassArgs& a, const FinArgs* 
                         const f32x4 pr = fa * fb;
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            split_bf16<MOM_TERMS>(v2f{pr[2 * h], pr[2 * h + 1]}, t3);
+                            split_bf16<MT>(v2f{pr[2 * h], pr[2 * h + 1]}, t3);
 #pragma unroll
                             for (int t = 0; t < 3; ++t) Bs[ft][t][2 * jj + h] = t3[t];
                         }
@@ -1060,9 +1064,9 @@ __device__ __forceinline__ void pass_xdl_body(const PassArgs& a, const FinArgs* 
                 for (int t = 0; t < 3; ++t) av[t] = __builtin_bit_cast(bf16x8, u32x4{As[t][0], As[t][1], As[t][2], As[t][3]});
                 // h h products and the five corrections in separate fp32 accumulators (see pass_kernel)
 #pragma unroll
-                for (int ta = 0; ta < MOM_TERMS; ++ta) {
+                for (int ta = 0; ta < MT; ++ta) {
 #pragma unroll
-                    for (int tb = 0; tb + ta < MOM_TERMS; ++tb) {
+                    for (int tb = 0; tb + ta < MT; ++tb) {
 #pragma unroll
                         for (int ft = 0; ft < FT; ++ft) {
                             if (ta + tb == 0) acc[0][ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ta], b[ft][tb], acc[0][ft], 0, 0, 0);
@@ -1113,16 +1117,16 @@ __device__ __forceinline__ void pass_xdl_body(const PassArgs& a, const FinArgs* 
     if constexpr (STATS) pass_epilogue<D, 1, FLAV>(a, smem, dacc, dn, lane, wave, nw);
 }
 
-template <int D, int FLAV, bool STATS>
+template <int D, int FLAV, bool STATS, int MT = 3>
 __global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
-    pass_xdl_body<D, FLAV, STATS, false>(a, nullptr);
+    pass_xdl_body<D, FLAV, STATS, false, MT>(a, nullptr);
 }
 
 // The whole VMP iteration (gmm.py:258-263 / smm.py:232-238) as ONE launch: K-sized posterior in the heads of blocks 0..K-1,
 // streaming E-pass with fused moments in all blocks.
-template <int D, int FLAV>
+template <int D, int FLAV, int MT = 3>
 __global__ __launch_bounds__(MAX_NW1 * WAVE) void step_xdl_kernel(PassArgs a, FinArgs f) {
-    pass_xdl_body<D, FLAV, true, true>(a, &f);
+    pass_xdl_body<D, FLAV, true, true, MT>(a, &f);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1728,14 +1732,18 @@ int launch_pass_dk(const PassArgs& a, const Plan& p, int flavour, bool estep, bo
 // E-part on the XDL pipe: E-step launches with K <= 16 and no missing-data mask
 inline bool use_xdl(int K, bool estep, bool mask) { return VMP_T1_XDL && estep && !mask && K <= 16; }
 
+#ifndef VMP_MOM2_ROWS
+#define VMP_MOM2_ROWS (1ll << 16)      // rows from which the moment GEMM of the XDL pass multiplies 2-term operands (pass_xdl_body, MT)
+#endif
 template <int D>
 int launch_pass_xdl(const PassArgs& a, const Plan& p, int flavour, bool stats, hipStream_t s) {
     dim3 grid(p.blocks), block(p.nw * WAVE);
-#define VMP_LAUNCH_X(FL, S) do { \
-        if (p.lds > 64 * 1024) { if (const int rc_ = set_dyn_lds(reinterpret_cast<const void*>(pass_xdl_kernel<D, FL, S>), p.lds, "pass_xdl_kernel")) return rc_; } \
-        hipLaunchKernelGGL((pass_xdl_kernel<D, FL, S>), grid, block, p.lds, s, a); } while (0)
-    if (flavour == VMP_GMM) { if (stats) VMP_LAUNCH_X(VMP_GMM, true); else VMP_LAUNCH_X(VMP_GMM, false); }
-    else { if (stats) VMP_LAUNCH_X(VMP_SMM, true); else VMP_LAUNCH_X(VMP_SMM, false); }
+#define VMP_LAUNCH_X(FL, S, M) do { \
+        if (p.lds > 64 * 1024) { if (const int rc_ = set_dyn_lds(reinterpret_cast<const void*>(pass_xdl_kernel<D, FL, S, M>), p.lds, "pass_xdl_kernel")) return rc_; } \
+        hipLaunchKernelGGL((pass_xdl_kernel<D, FL, S, M>), grid, block, p.lds, s, a); } while (0)
+    const bool m2 = stats && a.N >= VMP_MOM2_ROWS;
+    if (flavour == VMP_GMM) { if (m2) VMP_LAUNCH_X(VMP_GMM, true, 2); else if (stats) VMP_LAUNCH_X(VMP_GMM, true, 3); else VMP_LAUNCH_X(VMP_GMM, false, 3); }
+    else { if (m2) VMP_LAUNCH_X(VMP_SMM, true, 2); else if (stats) VMP_LAUNCH_X(VMP_SMM, true, 3); else VMP_LAUNCH_X(VMP_SMM, false, 3); }
 #undef VMP_LAUNCH_X
     return check_launch("pass_xdl_kernel");
 }
@@ -1812,13 +1820,13 @@ inline int* ws_status(void* ws, int D, int K) { return reinterpret_cast<int*>(ws
 template <int D>
 int launch_step_xdl(const PassArgs& a, const FinArgs& f, const Plan& p, int flavour, hipStream_t s) {
     dim3 grid(p.blocks), block(p.nw * WAVE);
-    if (flavour == VMP_GMM) {
-        if (p.lds > 48 * 1024) { if (const int rc_ = set_dyn_lds(reinterpret_cast<const void*>(step_xdl_kernel<D, VMP_GMM>), p.lds, "step_xdl_kernel")) return rc_; }
-        hipLaunchKernelGGL((step_xdl_kernel<D, VMP_GMM>), grid, block, p.lds, s, a, f);
-    } else {
-        if (p.lds > 48 * 1024) { if (const int rc_ = set_dyn_lds(reinterpret_cast<const void*>(step_xdl_kernel<D, VMP_SMM>), p.lds, "step_xdl_kernel")) return rc_; }
-        hipLaunchKernelGGL((step_xdl_kernel<D, VMP_SMM>), grid, block, p.lds, s, a, f);
-    }
+#define VMP_LAUNCH_S(FL, M) do { \
+        if (p.lds > 48 * 1024) { if (const int rc_ = set_dyn_lds(reinterpret_cast<const void*>(step_xdl_kernel<D, FL, M>), p.lds, "step_xdl_kernel")) return rc_; } \
+        hipLaunchKernelGGL((step_xdl_kernel<D, FL, M>), grid, block, p.lds, s, a, f); } while (0)
+    const bool m2 = a.N >= VMP_MOM2_ROWS;
+    if (flavour == VMP_GMM) { if (m2) VMP_LAUNCH_S(VMP_GMM, 2); else VMP_LAUNCH_S(VMP_GMM, 3); }
+    else { if (m2) VMP_LAUNCH_S(VMP_SMM, 2); else VMP_LAUNCH_S(VMP_SMM, 3); }
+#undef VMP_LAUNCH_S
     const int rc = check_launch("step_xdl_kernel");
     return rc ? rc : 1;
 }

@@ -18,6 +18,8 @@ baseline of models/vae.py.
 """
 import math
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -230,7 +232,8 @@ class SVAETrainer(object):
         if noise is None and _seed_dev is not None:
             # graph-captured step: the key sits in a device word.  At minibatch sizes the stand-alone generator (all elements
             # in parallel, ~3 us) + the E-step kernel that reads a noise tensor beat generating inside the E-step kernel, where
-            # one wave per SIMD pays the Philox rounds serially (+8 us at N = 64); the stream is the same one.
+            # one wave per SIMD pays the Philox rounds serially (+8 us at N = 64 with round 4's generator, +1.7 us with round 5's
+            # cheaper one: 120.5 vs 118.8 us per step); the stream is the same one.
             pn = _svae_ops.PhiloxNoise(0, self.S, seed_dev=_seed_dev)
             noise = pn.materialise(y.shape[0], self.K, self.L, y.device)
             if u is None and z_draws is None:
