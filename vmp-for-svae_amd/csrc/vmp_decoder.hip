@@ -1160,7 +1160,7 @@ int decoder_loglike_bwd_impl(const char* what, float logw, const TailArgs* tail,
     const int red_blocks = (q.PW + 63) / 64;
     if (tail) {
         hipLaunchKernelGGL(dec_reduce_tail_kernel, dim3(red_blocks + tail_blocks), dim3(64 * DEC_RED_GROUPS), 0, s, r, *tail, red_blocks);
-        hipLaunchKernelGGL(dec_elbo_final_kernel, dim3(1), dim3(WAVE), 0, s, *tail, tail_blocks);      // the three scalars, behind a kernel boundary
+        if (tail_blocks > 1) hipLaunchKernelGGL(dec_elbo_final_kernel, dim3(1), dim3(WAVE), 0, s, *tail, tail_blocks);      // the three scalars, behind a kernel boundary (one tail block: written by that block)
     }
     else hipLaunchKernelGGL(dec_reduce_kernel, dim3(red_blocks), dim3(64 * DEC_RED_GROUPS), 0, s, r);
     return check_launch(what);

@@ -169,7 +169,7 @@ int vmp_svae_elbo_tail(const float* log_z, const float* T_prime, const float* ll
     TailArgs a{};
     const unsigned blocks = tail_setup(a, log_z, T_prime, ll, N, K, S, Dy, sigma, scalars, g_log_z, g_T_prime, r, ws, TAIL_THREADS);
     hipLaunchKernelGGL(elbo_tail_kernel, dim3(blocks), dim3(TAIL_THREADS), 0, static_cast<hipStream_t>(stream), a);
-    hipLaunchKernelGGL(elbo_final_kernel, dim3(1), dim3(WAVE), 0, static_cast<hipStream_t>(stream), a, blocks);
+    if (blocks > 1) hipLaunchKernelGGL(elbo_final_kernel, dim3(1), dim3(WAVE), 0, static_cast<hipStream_t>(stream), a, blocks);   // one block: it wrote the scalars itself
     return check_launch("vmp_svae_elbo_tail");
 }
 

@@ -66,6 +66,15 @@ __device__ __forceinline__ void elbo_tail_body(const TailArgs& a, const unsigned
         for (int i = 0; i < nwv; ++i) { s0 += sm[0][i]; s1 += sm[1][i]; }
         a.part[2 * tb] = s0;
         a.part[2 * tb + 1] = s1;
+        if (ntb == 1) {
+            // a batch of ONE tail block (N K <= the block size: the reference's minibatches): this block holds the whole sums - the
+            // three scalars are written here and the host skips the final launch (one graph node less per training step).  The same
+            // arithmetic as elbo_final_body on one partial pair.
+            const double rec = -s0 - a.cst;
+            a.scal[0] = (float)(rec - s1);
+            a.scal[1] = (float)rec;
+            a.scal[2] = (float)s1;
+        }
     }
 }
 

@@ -23,7 +23,7 @@ class GradSeed(object):
 
 
 class PhiloxNoise(object):
-    """Stand-in for the (N,K,L,S) noise tensor: "generate it in the kernel" (csrc/vmp_svae.hip, Philox4x32-10 keyed by
+    """Stand-in for the (N,K,L,S) noise tensor: "generate it in the kernel" (csrc/vmp_svae.hip, Philox4x32-7 keyed by
     `seed`; include/vmp_hip.h vmp_svae_estep_fwd_rng).  The reference draws eps inside the step the same way
     (models/svae.py:113-114).  materialise() returns the identical stream as a tensor."""
 

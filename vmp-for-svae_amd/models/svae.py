@@ -168,7 +168,7 @@ def compute_log_z_given_y(eta1_phi1, eta2_phi1, eta1_phi2, eta2_phi2, pi_phi2, n
 def e_step(phi_enc, phi_gmm, nb_samples, seed=0, name="e_step", noise=None, theta=None):
     """reference svae.py:14-47.  Returns (x_k_samples (N,K,S,L), log_z (N,K), phi_tilde, dbg).
     `noise` (N,K,L,S) replaces tf.random_normal (default: torch.randn with `seed`); noise='philox' draws eps INSIDE the
-    kernel (Philox4x32-10 keyed by `seed`, as the reference's tf.random_normal does inside its step, svae.py:113-114):
+    kernel (Philox4x32-7 keyed by `seed`, as the reference's tf.random_normal does inside its step, svae.py:113-114):
     no (N,K,L,S) tensor is written or read.  When `theta` (natural NIW / Dirichlet parameters) is given, the per-sample
     densities compute_elbo needs are evaluated in the same pass."""
     eta1_phi1, eta2_diag = phi_enc
@@ -218,7 +218,7 @@ def sample_x_per_comp(eta1, eta2, nb_samples, seed=0, noise=None):
 def subsample_x(x_k_samples, log_q_z_given_y, seed=0, z_draws=None, nb_out=None, u=None):
     """reference svae.py:122-151: z_ns ~ Cat(exp log_q), gather x[n, z_ns, s].  HIP kernel vmp_svae_subsample;
     `z_draws` (N,S) replaces tf.multinomial (default: inverse CDF of torch.rand with `seed`; u='philox': of uniforms
-    drawn inside the kernel from Philox4x32-10 keyed by `seed`).  `nb_out` < S only
+    drawn inside the kernel from Philox4x32-7 keyed by `seed`).  `nb_out` < S only
     produces the first nb_out sample columns (the reference's caller keeps s = 0, svae.py:514)."""
     x = L.dev_f32(x_k_samples.detach(), 'x_k_samples')
     N, K, S, Ld = x.shape
@@ -226,7 +226,7 @@ def subsample_x(x_k_samples, log_q_z_given_y, seed=0, z_draws=None, nb_out=None,
     So = S if nb_out is None else int(nb_out)
     z = None
     if z_draws is None and (isinstance(u, str) or isinstance(u, _svae_ops.PhiloxNoise)):
-        # uniforms drawn inside the kernel (Philox4x32-10 keyed by `seed`, or by the device word of a PhiloxNoise)
+        # uniforms drawn inside the kernel (Philox4x32-7 keyed by `seed`, or by the device word of a PhiloxNoise)
         if isinstance(u, str) and u != 'philox':
             raise ValueError("u must be a tensor, None or 'philox'")
         sd = u.seed_dev if isinstance(u, _svae_ops.PhiloxNoise) else None
