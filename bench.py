@@ -223,7 +223,7 @@ def bench_t2(N, Ld, K, S, steps, warmup, dev, dist=None, world=1, smm=False, cpu
                 from vmp_for_svae_amd.models import gmm as _gmm
                 st = _gmm.update_Nk(r.contiguous()).double().reshape(-1, 1)
             else:
-                st = _mix.raw_stats(xs, r)
+                st = _mix.raw_stats(xs, r, pivot=False)           # as SVAETrainer.step: the natural-parameter M-step uses the raw moments
             if dist is not None:
                 from vmp_for_svae_amd.models.parallel_mix import allreduce_sum_
                 buf = torch.cat([st.reshape(-1)] + [gg.reshape(-1).double() for gg in grads[2:]])

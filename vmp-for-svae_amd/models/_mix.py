@@ -34,10 +34,15 @@ SMALL_STATS_MAX_N = 512        # csrc/vmp_mix.hip: small_stats_kernel
 
 
 def raw_stats(x, r, u=None, pivot=None):
-    """(K, 2+D+D*D) fp64 raw moments [Nk | Wk | sum w x | sum w x x^T] (vmp_mix_stats)."""
+    """(K, 2+D+D*D) fp64 raw moments [Nk | Wk | sum w x | sum w x x^T] (vmp_mix_stats).
+    pivot=None: the data are shifted by a pivot near their mean before the products are formed (vmp_mix_pivot; what makes the
+    one-pass moments match the reference's two-pass CENTRED S_k of gmm.py:39-46); pivot=False: no shift - for callers that use
+    the raw moments as they are (the SVAE M-step in natural parameters, svae.py:154-176: theta* = prior + raw moments)."""
     x = L.dev_f32(x, 'x')
     N, K = r.shape
-    if pivot is None and N > SMALL_STATS_MAX_N:          # small batches: the library sums them directly in fp64 (one launch)
+    if pivot is False:
+        pivot = None
+    elif pivot is None and N > SMALL_STATS_MAX_N:        # small batches: the library sums them directly in fp64 (one launch)
         pivot = pivot_of(x)
     _, D = _dims(x, K)
     r = L.dev_f32(r, 'r_nk', (N, K))

@@ -285,7 +285,7 @@ class SVAETrainer(object):
                 from .models import gmm as _gmm
                 st = _gmm.update_Nk(r_nk.contiguous()).double().reshape(-1, 1)
             else:
-                st = _mix.raw_stats(x_s.detach().contiguous(), r_nk.contiguous())  # HIP: (K, 2+L+L*L) fp64
+                st = _mix.raw_stats(x_s.detach().contiguous(), r_nk.contiguous(), pivot=False)  # HIP: (K, 2+L+L*L) fp64; raw, un-centred: no pivot pass
             grads = g if grads is None else [a + b for a, b in zip(grads, g)]
             if not fused_m:
                 stats = st if stats is None else stats + st
