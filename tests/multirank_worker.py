@@ -76,6 +76,35 @@ def main():
     res['run_params'] = np.concatenate([t.detach().cpu().numpy().reshape(-1) for t in params2])
     res['run_theta'] = np.concatenate([t.cpu().numpy().reshape(-1) for t in tr2.theta])
     res['run_elbo'] = np.float64(hist[-1]['neg_normed_elbo'])
+    # ---- the data-parallel training step captured as TWO HIP graphs around its one collective (training.GraphedSVAEStep with
+    # several ranks, round 5) against the same step run eagerly: call i of the graphed stepper == training step i, on both ranks
+    try:
+        from vmp_for_svae_amd.training import GraphedSVAEStep
+        Kg, Lg, Ug, Dg, Sg, Ng = 10, 8, 50, 6, 10, 64
+        gsl = data_mod.tower_slice(Ng, rank, world)
+        gg = torch.Generator(device='cuda').manual_seed(17)
+        ys = [(torch.randn(Ng, Dg, device='cuda', generator=gg) * 2)[gsl].contiguous() for _ in range(4)]
+
+        def fresh():
+            vae.reset_variables()
+            return SVAETrainer(Kg, Lg, Ug, Dg, nb_samples=Sg, lr=3e-3, lrcvi=0.2, decay_rate=0.95, stddev_init_nn=0.1, seed=3)
+        tr_e = fresh()
+        el_e = [float(tr_e.step(ys[i])['elbo']) for i in range(4)]
+        want = [t.detach().clone() for t in tr_e.trainables()[1]] + [t.clone() for t in tr_e.theta]
+        tr_g = fresh()
+        gs = GraphedSVAEStep(tr_g, ys[0], warmup=2)
+        res['dpg_two_graphs'] = np.int64(gs.graph_back is not None)
+        el_g = [float(gs(ys[i])['elbo']) for i in range(4)]
+        got = list(tr_g.trainables()[1]) + list(tr_g.theta)
+        res['dpg_elbo_eager'], res['dpg_elbo_graphed'] = np.array(el_e), np.array(el_g)
+        res['dpg_param_err'] = np.array([((a.detach() - b).abs().max() / b.abs().max().clamp_min(1e-30)).item() for a, b in zip(got, want)])
+        res['dpg_params'] = np.concatenate([t.detach().cpu().numpy().reshape(-1) for t in got])
+        res['dpg_steps'] = np.array([tr_g.global_step, tr_g.opt.t])
+    except Exception as e:
+        import traceback
+        res['dpg_error'] = np.array(traceback.format_exc())
+    dist.barrier()
+
     # ---- T1 again with the ONE-LAUNCH exchange (vmp_mix_finalize_exchange): the finalize kernels of the two processes push
     # their moments into each other's IPC-mapped buffers and sum them in rank order; no host staging, no collective library
     try:

@@ -215,6 +215,20 @@ def test_driver_run_shards_minibatches_and_keeps_replicas_identical(two_ranks):
     assert float(ranks[0]['run_elbo']) == float(ranks[1]['run_elbo'])          # the all-reduced ELBO, not a per-shard one
 
 
+def test_data_parallel_graphed_step_matches_the_eager_step(two_ranks):
+    """GraphedSVAEStep with two ranks = two HIP graphs around the step's one collective (round 5; round 4 fell back to the eager
+    step): four calls must be training steps 0..3 of the same trainer stepped eagerly (in-kernel noise keyed by the step), on both
+    ranks, and leave both ranks with bit-identical parameters."""
+    _, ranks = two_ranks
+    for r in ranks:
+        assert 'dpg_error' not in r.files, str(r['dpg_error'])
+        assert int(r['dpg_two_graphs']) == 1 and list(r['dpg_steps']) == [4, 4]
+        assert np.allclose(r['dpg_elbo_graphed'], r['dpg_elbo_eager'], rtol=2e-5, atol=0)
+        assert float(r['dpg_param_err'].max()) <= 2e-5, r['dpg_param_err']
+    assert np.array_equal(ranks[0]['dpg_params'], ranks[1]['dpg_params'])
+    assert np.array_equal(ranks[0]['dpg_elbo_graphed'], ranks[1]['dpg_elbo_graphed'])
+
+
 def test_c_abi_rccl_communicator_single_rank():
     """vmp_comm_* + vmp_pack_allreduce (the exchange a non-torch host binds): a 1-rank RCCL communicator leaves the packed
     buffer unchanged, and DistributedVMPLoop driven through it reproduces the plain loop."""

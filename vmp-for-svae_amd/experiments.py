@@ -128,8 +128,7 @@ def run(config, nb_iters=2000, size_minibatch=100, nb_samples=10, nb_samples_te=
                      lrcvi=config['lrcvi'], decay_rate=config.get('decay_rate', 1), seed=config.get('seed', 0),
                      device=dev, smm=smm, dof=config.get('DoF', 5), group=group)
     batches = data_mod.minibatches_device(Xtr, size_minibatch, seed=config.get('seed', 0), rank=rank, world=world)
-    if world > 1:
-        graph = False                      # the data-parallel step has a collective in the middle: not captured
+    # (the data-parallel step is captured as well: two graphs around its one collective, training.GraphedSVAEStep)
     log_id = generate_log_id(config)
     missing_data_mask = losses.generate_missing_data_mask(Xte, ratio_missing_data, seed=config.get('seed', 0))
     history = []

@@ -407,12 +407,18 @@ def init_mm(nb_components, latent_dims, seed=0, param_device='cuda', name='init_
 
 def make_loc_scale_variables(theta, param_device='cuda', name='copy_m_v'):
     """reference svae.py:474-485."""
-    std = niw.natural_to_standard(theta[1], theta[2], theta[3], theta[4])
+    # K-sized, once per model: evaluated on the HOST (LAPACK) and copied to the parameter device.  torch's GPU factorisations
+    # (MAGMA / rocSOLVER batched kernels) are not on any hot path here, and they returned a wrong Cholesky factor for a trainer
+    # constructed after a data-parallel graphed step had run in a process that shares its GPU with another rank (round 5,
+    # tools/r5_dpg_debug.py); under rocprofv3 --pmc they misbehave as well (tools/t2_prof_target.py).
+    dev = theta[1].device
+    th = [t.detach().cpu() for t in theta]
+    std = niw.natural_to_standard(th[1], th[2], th[3], th[4])
     mu, sigma = niw.expected_values(std)
     # contiguous copies: cholesky returns a column-major batch, and one oddly-strided parameter drops the optimiser's
     # multi-tensor updates onto the per-tensor slow path
-    return (torch.nn.Parameter(mu.detach().clone(memory_format=torch.contiguous_format)),
-            torch.nn.Parameter(torch.linalg.cholesky(sigma).detach().clone(memory_format=torch.contiguous_format)))
+    return (torch.nn.Parameter(mu.clone(memory_format=torch.contiguous_format).to(dev)),
+            torch.nn.Parameter(torch.linalg.cholesky(sigma).clone(memory_format=torch.contiguous_format).to(dev)))
 
 
 def init_recognition_params(theta, nb_components, seed=0, param_device='cuda', var_scope='phi_gmm', pi_normal=None):

@@ -255,9 +255,22 @@ class SVAETrainer(object):
         """One training step.  `chunk` rows at a time (the ELBO is a sum over datapoints, so gradients and
         moments simply accumulate over chunks) - needed when N*K*S decoder rows do not fit at once.
         `u` (N,1) supplies the uniforms of the categorical sub-sampling; `_dev_scalars` = (lrcvi, lr_t[, Philox key]) as
-        one-element device tensors is what GraphedSVAEStep captures with (step counters are then advanced by the caller)."""
+        one-element device tensors is what GraphedSVAEStep captures with (step counters are then advanced by the caller).
+        The step is three pieces - everything a rank does on its own rows (_step_front), the ONE exchange of a data-parallel
+        step (_step_exchange) and the identical update every rank applies (_step_back) - so that a data-parallel step can be
+        captured as two HIP graphs around its collective (GraphedSVAEStep)."""
+        ctx = self._step_front(y, noise, z_draws, chunk, u, _dev_scalars)
+        self._step_exchange(ctx)
+        return self._step_back(ctx, _dev_scalars)
+
+    def _world(self):
         import torch.distributed as dist
-        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def _step_front(self, y, noise=None, z_draws=None, chunk=None, u=None, _dev_scalars=None):
+        """Forward, backward, M-step moments of this rank's rows (experiments.py:196-244 for one tower) and, with more than one
+        rank, the packed exchange buffer [moments | all gradients | elbo, rec, reg] (one launch)."""
+        world = self._world()
         rows = y.shape[0]
         chunk = rows if chunk is None else int(chunk)
         names, params = None, None
@@ -298,14 +311,29 @@ class SVAETrainer(object):
                 keep = dict(log_z=log_z.detach(), x_samples=x_s.detach(), x_k=x_k.detach())
                 r_whole = r_nk
             del elbo, details, x_k, x_s, log_z
+        ctx = dict(world=world, names=names, params=params, grads=grads, stats=stats, fused_m=fused_m, keep=keep,
+                   r_whole=r_whole, scal=(elbo_t, rec_t, reg_t), buf=None, goffs=None)
+        if world > 1:
+            # ONE pack launch, ONE all-reduce, and (in _step_back) ONE Adam launch that reads the averaged gradients from the
+            # buffer: the exchange adds three launches to the step (it was a torch.cat over ~25 fp64 copies, ~25 slices and 21 divisions)
+            ctx['grads'] = [g.contiguous() for g in grads]
+            ctx['buf'], ctx['goffs'] = pack_exchange_buffer(stats, ctx['grads'], [elbo_t, rec_t, reg_t])
+        return ctx
+
+    def _step_exchange(self, ctx):
+        """the one collective of a data-parallel step: sum of the packed buffer over the ranks (experiments.py:247-260 + tf_utils.py:52-87)"""
+        if ctx['world'] > 1:
+            from .models.parallel_mix import allreduce_sum_
+            allreduce_sum_(ctx['buf'], self.group)
+
+    def _step_back(self, ctx, _dev_scalars=None):
+        """CVI update of theta and the Adam step from the (summed) moments and gradients: identical on every rank"""
+        world, names, params, grads, stats = ctx['world'], ctx['names'], ctx['params'], ctx['grads'], ctx['stats']
+        fused_m, keep, r_whole = ctx['fused_m'], ctx['keep'], ctx['r_whole']
+        elbo_t, rec_t, reg_t = ctx['scal']
         packed = None
         if world > 1:
-            # ONE pack launch, ONE all-reduce, and (below) ONE Adam launch that reads the averaged gradients from the buffer:
-            # the exchange adds three launches to the step (it was a torch.cat over ~25 fp64 copies, ~25 slices and 21 divisions)
-            grads = [g.contiguous() for g in grads]
-            buf, goffs = pack_exchange_buffer(stats, grads, [elbo_t, rec_t, reg_t])
-            from .models.parallel_mix import allreduce_sum_
-            allreduce_sum_(buf, self.group)
+            buf, goffs = ctx['buf'], ctx['goffs']
             ns = stats.numel()
             stats = buf[:ns].reshape(stats.shape)
             elbo_t, rec_t, reg_t = buf[-3], buf[-2], buf[-1]
@@ -346,13 +374,13 @@ class SVAETrainer(object):
         return out
 
 
-
 class GraphedSVAEStep(object):
     """The whole training step of a fixed minibatch size captured ONCE as a HIP graph and replayed: at the reference's
     operating point (minibatches of 64-100 rows, experiments.py:26) the step is ~150 launches of microsecond kernels
     and is bound by launch overhead, not by the GPU.  Per call: copy the minibatch into the static input, refresh the
     noise / uniforms in place, write the two step-dependent scalars (CVI step size, bias-corrected Adam step size) to
-    device memory, replay.  GMM- and SMM-SVAE, one process (the data-parallel step has a collective in the middle).
+    device memory, replay.  GMM- and SMM-SVAE; with several ranks (one process per GPU) the step is TWO graphs around its one
+    collective (round 5).
     Noise.  Trainer with rng='philox' (the default): eps and the uniforms of the categorical draw are generated INSIDE the
     captured kernels from a Philox key the kernels read from a device word at run time; a call writes [key | CVI step size |
     Adam step size] with ONE launch (vmp_svae_step_scalars) and replays - the very stream of the same trainer stepped eagerly
@@ -413,10 +441,24 @@ class GraphedSVAEStep(object):
         self.gen.set_state(snap['gen'])
         self._refresh()
         self.graph = torch.cuda.CUDAGraph()
+        self.graph_back = None
         cap_stream = torch.cuda.Stream(device=dev)
-        with torch.cuda.graph(self.graph, stream=cap_stream):
-            self.out = tr.step(self.y, noise=self.noise, u=self.u,
-                               _dev_scalars=(self.rho, self.lr_t) + ((self.seed_dev,) if self.in_kernel_rng else ()))
+        dev_scalars = (self.rho, self.lr_t) + ((self.seed_dev,) if self.in_kernel_rng else ())
+        self.world = tr._world()
+        if self.world == 1:
+            with torch.cuda.graph(self.graph, stream=cap_stream):
+                self.out = tr.step(self.y, noise=self.noise, u=self.u, _dev_scalars=dev_scalars)
+        else:
+            # Data-parallel step (one process per GPU): TWO graphs around the ONE collective of the step.  Graph 1 = everything this
+            # rank does on its own rows up to the packed exchange buffer (SVAETrainer._step_front), then the all-reduce of that
+            # buffer is issued eagerly on the replay stream (RCCL; gloo stages it through the host), graph 2 = the CVI update and
+            # the packed Adam step every rank applies identically (_step_back).  The buffer and everything graph 2 reads live in
+            # the shared graph pool.  (Round 4 fell back to the eager step here: 0.87 ms instead of 0.12 ms at minibatch 64.)
+            with torch.cuda.graph(self.graph, stream=cap_stream):
+                self._ctx = tr._step_front(self.y, self.noise, None, None, self.u, dev_scalars)
+            self.graph_back = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_back, stream=cap_stream, pool=self.graph.pool()):
+                self.out = tr._step_back(self._ctx, dev_scalars)
         self.gen.set_state(snap['gen'])     # the capture-time refresh drew nothing that a replay uses
         # the captured kernels hold raw pointers into the scratch buffers in use during the capture: keep exactly those
         # alive with the graph, and drop the warm-up side stream's buffers (never used again)
@@ -441,6 +483,9 @@ class GraphedSVAEStep(object):
         self._refresh()
         self.out['lrcvi'] = exponential_decay(tr.lrcvi0, tr.global_step, 1000, tr.decay_rate)
         self.graph.replay()
+        if self.graph_back is not None:
+            tr._step_exchange(self._ctx)                     # the one collective of the step, between the two replays
+            self.graph_back.replay()
         tr.opt.t += 1
         tr.global_step += 1
         return self.out
