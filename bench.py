@@ -548,7 +548,8 @@ def dec_bwd_side_measurement(N, K, S, Ld, U, dev):
     UT = (U + 15) // 16
     KB = (UT + 1) // 2
     p = 3 if float(N) * K * S >= 2 ** 19 else 6
-    mf = (2 * UT + 6 * UT * KB + 6 * KB + 2) + ((3 if p == 6 else 2) * UT + 2 * UT + 2 + UT * KB * p + 2 * UT * UT + KB * p + (3 if p == 6 else 2) + 2 * UT)
+    # (round 5: the forward recompute inside the backward kernel follows the data path's operand terms: p products per k-block)
+    mf = (2 * UT + p * UT * KB + p * KB + 2) + ((3 if p == 6 else 2) * UT + 2 * UT + 2 + UT * KB * p + 2 * UT * UT + KB * p + (3 if p == 6 else 2) + 2 * UT)
     issued = mf * 16384.0 * rows / 16.0
     return ms * (float(N) / n), useful * (float(N) / n), issued * (float(N) / n), mf
 
@@ -720,7 +721,7 @@ def main():
                                     'valu_frac': t1_flops(Nb, D, K) / (bk_ms * 1e-3) / FP32_PEAK_FLOPS}
                 del bloop, xb, rb
                 torch.cuda.empty_cache()
-            extra['t2_svae_vmp'] = bench_t2(N, D, K, args.s, 5, 2, dev, None, 1, cpu=not args.no_cpu_baseline)
+            extra['t2_svae_vmp'] = bench_t2(N, D, K, args.s, 10, 3, dev, None, 1, cpu=not args.no_cpu_baseline)
             torch.cuda.empty_cache()
             extra['t3_svae_train'] = bench_t3(N, D, K, args.s, args.u, 5, 3, dev, None, cpu=not args.no_cpu_baseline)
             torch.cuda.empty_cache()
