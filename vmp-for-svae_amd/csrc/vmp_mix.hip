@@ -647,7 +647,8 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
 //     M = data row (16 per MFMA),  N = component k (lane & 15),  one MFMA tile per output coordinate i of y,
 //     contraction = the D coordinates of x' - only 8 of the 32 k-slots - so the slots carry SEVERAL bf16 TERMS of the
 //     same values (v = h + m + l, 8 bits each): lane group g = lane >> 4 of the two MFMAs of a tile multiplies
-//         MFMA 1:  x'_h W_h | x'_h W_m | x'_m W_h | x'_h W_l        MFMA 2:  x'_l W_h | x'_m W_m | (1,1,1) (b_h,b_m,b_l) | 0
+//         MFMA 1:  x'_h W_h | (1,1,1) (b_h,b_m,b_l) | x'_h W_m | x'_m W_h        MFMA 2:  x'_h W_l | x'_l W_h | x'_m W_m | 0
+//     (round 5 order: the bias that cancels most of the leading products sits in the SAME MFMA as they do, see below)
 //     i.e. the six products of order <= 2 (dropped: <= 2^-24 relative, the fp32 rounding level) plus the bias.
 // No expanded quadratic form x^T Theta x is ever evaluated: y is formed exactly as the fp32 chain formed it (same
 // cancellation between W x' and W m'), then q = sum_i y_i^2 costs 8 FMAs per cell in the accumulator registers.
@@ -851,10 +852,16 @@ __device__ __forceinline__ void pass_xdl_body(const PassArgs& a, const FinArgs* 
                 Bsm[i] = on ? w : u32x4{0u, 0u, 0u, 0u};
             } else {
                 const int ib = i - 4;
-                // MFMA 1: W_h | W_m | W_h | W_l      MFMA 2: W_h | W_m | bias | 0
-                const u32x4 w1 = kk == 1 ? u32x4{tm[0], tm[1], tm[2], tm[3]} : kk == 3 ? u32x4{tl[0], tl[1], tl[2], tl[3]} : u32x4{th[0], th[1], th[2], th[3]};
-                const u32x4 w2 = kk == 0 ? u32x4{th[0], th[1], th[2], th[3]} : kk == 1 ? u32x4{tm[0], tm[1], tm[2], tm[3]}
-                               : kk == 2 ? u32x4{bias0, bias1, 0u, 0u} : u32x4{0u, 0u, 0u, 0u};
+                // MFMA 1: W_h | bias | W_m | W_h  (x x'_h | ones | x'_h | x'_m: the leading products, the bias that cancels most of them and the
+                //          first-order corrections)      MFMA 2: W_l | W_h | W_m | 0  (x x'_h | x'_l | x'_m: the second-order corrections).
+                // The MFMA rounds its sum ONCE, at the exponent of its LARGEST term (tools/ubench/mfma_cancel_numerics.hip): with the
+                // bias beside the leading products the first MFMA leaves y itself (|y| ~ 3 where |W x'|, |b| ~ 15) and the second one adds
+                // terms of 2^-16 of that to it - one rounding at the scale of the large terms instead of two (round 4 had the bias in the
+                // second MFMA); tools/r5_smm_error_budget.py: max |r - r_fp64| of the SMM 6.1e-6 -> 2.4e-6 in emulation.
+                const u32x4 w1 = kk == 0 ? u32x4{th[0], th[1], th[2], th[3]} : kk == 1 ? u32x4{bias0, bias1, 0u, 0u}
+                               : kk == 2 ? u32x4{tm[0], tm[1], tm[2], tm[3]} : u32x4{th[0], th[1], th[2], th[3]};
+                const u32x4 w2 = kk == 0 ? u32x4{tl[0], tl[1], tl[2], tl[3]} : kk == 1 ? u32x4{th[0], th[1], th[2], th[3]}
+                               : kk == 2 ? u32x4{tm[0], tm[1], tm[2], tm[3]} : u32x4{0u, 0u, 0u, 0u};
                 B1[ib < 0 ? 0 : ib] = on ? w1 : u32x4{0u, 0u, 0u, 0u};
                 B2[ib < 0 ? 0 : ib] = on ? w2 : u32x4{0u, 0u, 0u, 0u};
             }
@@ -862,8 +869,8 @@ __device__ __forceinline__ void pass_xdl_body(const PassArgs& a, const FinArgs* 
     }
     // A operands: lane (m = i16, g = kk) reads term T[g] of tile row rho(m) = 4 (m & 3) + (m >> 2)
     const int rho = 4 * (i16 & 3) + (i16 >> 2);
-    const int offA1 = rho * AIS + (kk == 2 ? 4 : 0);                       // x_h | x_h | x_m | x_h
-    const int offA2 = rho * AIS + (kk == 0 ? 8 : (kk == 1 ? 4 : (kk == 2 ? 12 : 16)));   // x_l | x_m | ones | zeros
+    const int offA1 = rho * AIS + (kk == 1 ? 12 : (kk == 3 ? 4 : 0));                    // x_h | ones | x_h | x_m
+    const int offA2 = rho * AIS + (kk == 0 ? 0 : (kk == 1 ? 8 : (kk == 2 ? 4 : 16)));    // x_h | x_l | x_m | zeros
     const int offA3 = rho * AIS + (kk == 3 ? 12 : 20 + 4 * kk);                           // (x_h|x_h) | (x_m|x_h) | (x_l|x_m) | ones
 
     // ---- moment GEMM B-operand addressing: lane = (feature column i16, k-slot group kk)
