@@ -143,13 +143,28 @@ def make_minibatch(dataset, ratio_tr=None, ratio_val=None, binarise=False, path_
       size_minibatch <= 0: the full training tensors (data.py:151-153), as gmm.py:316 / smm.py:285 / vae.py:363 use it.
     nb_towers > 1 (data.py:174-175): each minibatch is the list of its nb_towers contiguous splits; with `rank` given
     (one process per GPU) only that tower's split is produced.
-    The MNIST-style TFRecord inputs (data.py:13-33,179-213) are not built: there are no such files in this image."""
+    The MNIST-style TFRecord inputs (data.py:13-33,179-213) are read by read_from_tfrec_file below when the files exist (there are
+    none in this image: FileNotFoundError)."""
     import torch
-    if dataset in ('mnist', 'mnist-small', 'fashion') or binarise:
-        raise NotImplementedError('TFRecord image datasets are not built')
-    data, labels = load_dataset(dataset, path_datadir)
-    X_tr, l_tr, X_te, l_te = split_and_scale(dataset, data, labels, ratio_tr=0.7 if ratio_tr is None else ratio_tr,
-                                             seed_split=seed_split, noise_level=noise_level, ratio_val=ratio_val)
+    if dataset in ('mnist', 'mnist-small', 'fashion'):
+        # data.py:13-33: <datadir>/<dataset>_new/{train, test | validation}.tfrecords, 784 pixels, one-hot labels of 10 classes;
+        # the split is the files' own (ratio_tr is ignored, as in the reference)
+        import os
+        base = os.path.join(path_datadir, dataset + '_new')
+        f_tr = os.path.join(base, 'train.tfrecords')
+        f_te = os.path.join(base, 'test.tfrecords' if ratio_val is None else 'validation.tfrecords')
+        for f in (f_tr, f_te):
+            if not os.path.exists(f):
+                raise FileNotFoundError("'%s' not found: the image data sets are not shipped with this repository" % f)
+        X_tr, y_tr_i = read_from_tfrec_file(f_tr, 784, binarise=binarise, seed=seed_split)
+        X_te, y_te_i = read_from_tfrec_file(f_te, 784, binarise=binarise, seed=seed_split)
+        l_tr, l_te = np.eye(10, dtype=np.float32)[y_tr_i], np.eye(10, dtype=np.float32)[y_te_i]
+    else:
+        if binarise:
+            raise NotImplementedError                            # data.py:36-37
+        data, labels = load_dataset(dataset, path_datadir)
+        X_tr, l_tr, X_te, l_te = split_and_scale(dataset, data, labels, ratio_tr=0.7 if ratio_tr is None else ratio_tr,
+                                                 seed_split=seed_split, noise_level=noise_level, ratio_val=ratio_val)
     dev = torch.device(device)
     to_t = lambda a: None if a is None else torch.as_tensor(a, dtype=torch.float32).to(dev)
     Xtr, Xte, Ltr, Lte = to_t(X_tr), to_t(X_te), to_t(l_tr), to_t(l_te)
@@ -174,3 +189,120 @@ def make_minibatch(dataset, ratio_tr=None, ratio_val=None, binarise=False, path_
     else:
         y_te, lbl_te = Xte, Lte
     return y_tr, lbl_tr, y_te, lbl_te
+
+
+# ---------------------------------------------------------------------------------------------------------
+# TFRecord image files (reference data.py:179-213: mnist / mnist-small / fashion).  No TensorFlow here: the record framing
+# (u64 length | u32 masked crc | payload | u32 masked crc) and the tf.train.Example wire format are read directly.
+# ---------------------------------------------------------------------------------------------------------
+def _pb_fields(buf):
+    """(field number, wire type, value) of one protobuf message: varint -> int, length-delimited -> bytes"""
+    i, n = 0, len(buf)
+    while i < n:
+        tag, sh = 0, 0
+        while True:
+            c = buf[i]; i += 1
+            tag |= (c & 0x7F) << sh; sh += 7
+            if c < 0x80:
+                break
+        fn, wt = tag >> 3, tag & 7
+        if wt == 0:
+            v, sh = 0, 0
+            while True:
+                c = buf[i]; i += 1
+                v |= (c & 0x7F) << sh; sh += 7
+                if c < 0x80:
+                    break
+        elif wt == 2:
+            ln, sh = 0, 0
+            while True:
+                c = buf[i]; i += 1
+                ln |= (c & 0x7F) << sh; sh += 7
+                if c < 0x80:
+                    break
+            v = bytes(buf[i:i + ln]); i += ln
+        elif wt == 1:
+            v = bytes(buf[i:i + 8]); i += 8
+        elif wt == 5:
+            v = bytes(buf[i:i + 4]); i += 4
+        else:
+            raise ValueError('unsupported protobuf wire type %d' % wt)
+        yield fn, wt, v
+
+
+def _parse_example(payload):
+    """tf.train.Example -> {name: bytes | list of ints}: Example.features(1) . Features.feature(1: map entry key(1), value(2)) .
+    Feature.{bytes_list(1), int64_list(3)} . value(1)"""
+    out = {}
+    for fn, _, feats in _pb_fields(payload):
+        if fn != 1:
+            continue
+        for fn2, _, entry in _pb_fields(feats):
+            if fn2 != 1:
+                continue
+            key, feat = None, None
+            for fn3, _, v in _pb_fields(entry):
+                if fn3 == 1:
+                    key = v.decode()
+                elif fn3 == 2:
+                    feat = v
+            if key is None or feat is None:
+                continue
+            for fn4, _, lst in _pb_fields(feat):
+                if fn4 == 1:                                   # BytesList
+                    out[key] = [v for f5, _, v in _pb_fields(lst) if f5 == 1][0]
+                elif fn4 == 3:                                 # Int64List (packed or not)
+                    vals = []
+                    for f5, wt5, v in _pb_fields(lst):
+                        if f5 != 1:
+                            continue
+                        if wt5 == 0:
+                            vals.append(v)
+                        else:
+                            vals += _packed_varints(v)
+                    out[key] = vals
+    return out
+
+
+def _packed_varints(b):
+    vals, i = [], 0
+    while i < len(b):
+        v, sh = 0, 0
+        while True:
+            c = b[i]; i += 1
+            v |= (c & 0x7F) << sh; sh += 7
+            if c < 0x80:
+                break
+        vals.append(v)
+    return vals
+
+
+def read_from_tfrec_file(filename_q, D, binarise=False, seed=0):
+    """reference data.py:179-213 without TensorFlow: every record of the TFRecord file(s) `filename_q` (a path or a list of paths -
+    the reference passes a filename queue) is a tf.train.Example with 'image_raw' (D uint8 bytes) and 'label' (int64).
+    Returns (images (M, D) float32, labels (M,) int64): pixel values / 255 (data.py:196), or - binarise=True - stochastically
+    binarised to {-1, +1} with the intensity as the probability of +1 (data.py:199-206; numpy Generator(seed) replaces
+    tf.multinomial's stream)."""
+    import struct
+    paths = [filename_q] if isinstance(filename_q, (str, bytes)) else list(filename_q)
+    imgs, labels = [], []
+    for path in paths:
+        with open(path, 'rb') as f:
+            while True:
+                head = f.read(12)
+                if len(head) < 12:
+                    break
+                ln, = struct.unpack('<Q', head[:8])
+                payload = f.read(ln)
+                f.read(4)                                      # crc of the payload (not verified)
+                ex = _parse_example(payload)
+                img = np.frombuffer(ex['image_raw'], dtype=np.uint8)
+                if img.size != D:
+                    raise ValueError('%s: record with %d bytes, expected D=%d' % (path, img.size, D))
+                imgs.append(img)
+                labels.append(int(ex['label'][0]))
+    X = np.stack(imgs).astype(np.float32) * np.float32(1.0 / 255) if imgs else np.zeros((0, D), np.float32)
+    if binarise:
+        rng = np.random.Generator(np.random.PCG64(seed))
+        X = np.where(rng.random(X.shape) < X, 1.0, -1.0).astype(np.float32)
+    return X, np.asarray(labels, dtype=np.int64)

@@ -14,6 +14,11 @@ def _rank1(u, w):
     return torch.einsum('kd,ke->kde', u, w)
 
 
+def _outer(a, b):
+    """reference niw.py:46-49: batched outer product a[..., :, None] * b[..., None, :] (the helper its conversions call)."""
+    return a.unsqueeze(-1) * b.unsqueeze(-2)
+
+
 def expected_values(niw_standard_params):
     """reference niw.py:8-17.  (beta, m, C, v) -> (E[mu] = m, E[Sigma] = (v * sym(C^-1))^-1)."""
     beta, m, C, v = niw_standard_params
