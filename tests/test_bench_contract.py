@@ -91,3 +91,28 @@ def test_traffic_measurement_never_takes_the_line_down(monkeypatch):
     monkeypatch.setattr(shutil, 'which', lambda _: '/bin/false')        # a "profiler" that exits 1
     val, why = b.measure_traffic('gmm', 1000, 8, 16)
     assert val is None and 'failed' in why
+
+
+def test_round5_driver_line_carries_cpu_baselines_for_t1_t2_t3():
+    """the reference CPU path is timed beside T1 AND beside T2 / T3 (round-4 verdict, missing item 1); the T2 unit times a
+    self-contained step - eps drawn inside it - against the in-kernel-noise bytes 4N(2KSL + 2K + 4L)."""
+    d = json.loads(open(os.path.join(ROOT, 'profiles', 'r05_bench_driver_cmd.json')).read().strip().splitlines()[-1])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['steps'] == 20 and d['warmup'] == 5 and d['vs_baseline'] is None and 'workload' in d['config']
+    N, D, K = d['config']['N_per_gpu'], d['config']['D'], d['config']['K']
+    r = d['roofline']
+    assert abs(r['algorithmic_bytes_per_launch'] - 4.0 * N * (2 * D + 2 * K)) < 1 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    assert r['traffic'] is None or 0.4 * r['algorithmic_bytes_per_launch'] < r['traffic'] < 2 * r['algorithmic_bytes_per_launch']
+    t2, t3 = d['extra']['t2_svae_vmp'], d['extra']['t3_svae_train']
+    S = 10
+    assert abs(t2['algorithmic_bytes_per_step'] - 4.0 * N * (2.0 * K * S * D + 2 * K + 4 * D)) < 1
+    assert abs(t2['noise_tensor']['algorithmic_bytes_per_step'] - 4.0 * N * (4.0 * K * S * D + 2 * K + 4 * D)) < 1
+    assert t2['noise_tensor']['ms_per_step'] > t2['ms_per_step'] + 0.8 * t2['noise_tensor']['randn_ms']     # its normal_() is inside the step
+    for blk in (d, t2, t3):
+        c = blk['cpu_baseline']
+        for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+            assert k in c, k
+        assert c['kind'] == 'port' and c['unit'] == 'datapoints/s' and c['cores'] >= 1
+    assert t2['speedup_vs_cpu_baseline'] >= 100 and t3['speedup_vs_cpu_baseline'] >= 100 and d['speedup_vs_cpu_baseline'] >= 100
