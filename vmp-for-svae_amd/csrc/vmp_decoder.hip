@@ -622,6 +622,42 @@ __device__ __forceinline__ void trb_write(unsigned char* __restrict__ T, int g, 
 }
 __device__ __forceinline__ u32x4 trb_read(const unsigned char* __restrict__ p) { return *reinterpret_cast<const u32x4*>(p); }
 
+// Round 5: the same transposition by gfx950's LDS TRANSPOSE READ (ds_read_b64_tr_b16) instead of VALU lane exchanges.
+// Layout per (term, tile): the 16 rows x 16 units of bf16 ROW-major (512 bytes, as before): lane (g, c) writes its four units
+// 4g..4g+3 of row c as ONE 8-byte chunk (no v_mov_dpp / v_perm: 136 VALU instructions per tile less); an operand read is two
+// transpose reads - within a 16-lane group lane i passes the address of 8-byte chunk i of a 4-row x 16-unit block (chunk 4j + q =
+// row j, units 4q..4q+3) and receives column i: unit i of the 4 rows (tools/ubench/ds_read_tr16.hip) - i.e. the 8 k-slots
+// "rows 8 (g & 1) .. + 7 of unit c" that one ds_read_b128 of the old layout delivered.  Bank spread: the chunks of a row are
+// XOR-swizzled by the row's bits 2..3 (lanes c, c + 4, .. of a write instruction hit different banks), and the block of rows
+// 8..15 is rotated by 128 bytes (the two 16-lane groups of a read cycle, rows 0..3 and 8..11, use different bank halves).
+#ifndef VMP_DEC_TR16
+#define VMP_DEC_TR16 1            // 0: A/B builds with the VALU transposition (trb_write / trb_read)
+#endif
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int tr_row_off(int r) { return r < 8 ? 32 * r : 256 + ((32 * (r - 8) + 128) & 255); }
+// byte offset of lane (g, c)'s chunk inside a (term, tile) image
+__device__ __forceinline__ int tr_write_off(int g, int c) { return tr_row_off(c) + 8 * (g ^ ((c >> 2) & 3)); }
+// byte offsets of the two transpose reads of lane (g, c): rows r0 .. r0 + 3 and r0 + 4 .. r0 + 7, r0 = 8 (g & 1)
+__device__ __forceinline__ void tr_read_offs(int g, int c, int& o1, int& o2) {
+    const int r0 = 8 * (g & 1), j = c >> 2, q = c & 3;
+    o1 = tr_row_off(r0 + j) + 8 * (q ^ ((r0 >> 2) & 3));
+    o2 = tr_row_off(r0 + 4 + j) + 8 * (q ^ (((r0 + 4) >> 2) & 3));
+}
+template <int NT, int NTS>
+__device__ __forceinline__ void trt_write(unsigned char* __restrict__ T, int woff, const unsigned (&ts)[3][NTS]) {
+#pragma unroll
+    for (int term = 0; term < 2; ++term)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            *reinterpret_cast<u32x2*>(T + (term * NT + t) * 512 + woff) = u32x2{ts[term][2 * t], ts[term][2 * t + 1]};
+}
+__device__ __forceinline__ u32x4 trt_read(const unsigned char* __restrict__ img, int o1, int o2) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + o1));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + o2));
+    const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+    return u32x4{ua[0], ua[1], ub[0], ub[1]};
+}
+
 // Bias gradients ride in the zero padding of the weight-gradient products: the x tile (A operand of dW0 and of the
 // shortcut product) has rows L..15 free, so a row of ones at "dim 8" makes row 8 of those accumulators equal to
 // sum_row dh0pre (= db0) and sum_row dO (= db2, dbs1); likewise a ones "unit U" in h0 gives db1 as row U of dW1 when U
@@ -660,6 +696,13 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
     const int rd_hm = (((g >> 1) * UT) * 2 + (g & 1)) * 256 + rd_c;        // operand (h|m) of a UT-tile set: + tile * 512
     const int rd_hm1 = ((g >> 1) * 2 + (g & 1)) * 256 + rd_c;              // operand (h|m) of a 1-tile set
     const int rd_xx = (g & 1) * 256 + rd_c;                               // operand (h|h): + tile * 512; (m|m): + (NT + tile) * 512
+    // transpose-read form (P / Q scratch; the x tile keeps the VALU form): chunk offset of this lane's writes, offsets of its two
+    // reads, and the image of its lane group's term for (h|m) operands
+    const int tr_w = tr_write_off(g, c);
+    int tr_o1, tr_o2;
+    tr_read_offs(g, c, tr_o1, tr_o2);
+    const int tr_hm = (g >> 1) * UT * 512;                                // (h|m) of a UT-tile set: + tile * 512
+    const int tr_hm1 = (g >> 1) * 512;                                    // (h|m) of a 1-tile set
     const unsigned ntiles = (a.R + 15u) / 16u;
     const int L = a.L, Dy = a.Dy, U = a.U;
     const float invS = 1.0f / (float)a.S, invK = 1.0f / (float)a.K;
@@ -747,8 +790,8 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
         {
             unsigned h0s[3][4 * KB], h1s[3][4 * KB];
             dec_forward_tile<UT, FS, (VMP_DEC_FWD_TERMS_FOLLOW_BT ? BT : 3)>(sm, lane, xo, onev, h0, h0s, h1, h1s, O);
-            trb_write<UT>(scrPb, g, c, h0s);
-            trb_write<UT>(scrQb, g, c, h1s);
+            if constexpr (VMP_DEC_TR16) { trt_write<UT>(scrPb, tr_w, h0s); trt_write<UT>(scrQb, tr_w, h1s); }
+            else { trb_write<UT>(scrPb, g, c, h0s); trb_write<UT>(scrQb, g, c, h1s); }
         }
 
         DEC_TT(2);
@@ -781,7 +824,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             split_bf16<3>(v2f{dO[2 * p], dO[2 * p + 1]}, t3);
             dOs[0][p] = t3[0]; dOs[1][p] = t3[1]; dOs[2][p] = t3[2];
         }
-        trb_write<1>(scrOb, g, c, dOs);
+        if constexpr (VMP_DEC_TR16) trt_write<1>(scrOb, tr_w, dOs); else trb_write<1>(scrOb, g, c, dOs);
         const SOps so = slot_operands(dOs);
         DEC_TT(3);
         // ---- dh1 = W2 . dO
@@ -807,11 +850,12 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
         wave_lds_order();
         u32x4 xT;
         {
-            const u32x4 dTh = trb_read(scrOb + rd_xx), dTm = trb_read(scrOb + rd_xx + 512);
+            const u32x4 dTh = VMP_DEC_TR16 ? trt_read(scrOb, tr_o1, tr_o2) : trb_read(scrOb + rd_xx);
+            const u32x4 dTm = VMP_DEC_TR16 ? trt_read(scrOb + 512, tr_o1, tr_o2) : trb_read(scrOb + rd_xx + 512);
             xT = trb_read(scrXb + rd_hm1);
 #pragma unroll
             for (int t = 0; t < UT; ++t) {
-                const u32x4 h1T = trb_read(scrQb + rd_hm + t * 512);
+                const u32x4 h1T = VMP_DEC_TR16 ? trt_read(scrQb + tr_hm + t * 512, tr_o1, tr_o2) : trb_read(scrQb + rd_hm + t * 512);
                 aW2[t] = mfma_bf(h1T, dTh, aW2[t]);
                 aW2[t] = mfma_bf(h1T, dTm, aW2[t]);
             }
@@ -835,7 +879,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
         {
             unsigned d1s[3][4 * KB];
             split_tiles<UT, BT>(dh1, d1s);
-            trb_write<UT>(scrQb, g, c, d1s);
+            if constexpr (VMP_DEC_TR16) trt_write<UT>(scrQb, tr_w, d1s); else trb_write<UT>(scrQb, g, c, d1s);
             gemm_units<UT, UT, BT>(sm + I::B2, lane, d1s, dh0);
         }
         DEC_TT(7);
@@ -845,12 +889,12 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
             u32x4 dTh[UT], dTm[UT];
 #pragma unroll
             for (int t = 0; t < UT; ++t) {
-                dTh[t] = trb_read(scrQb + rd_xx + t * 512);
-                dTm[t] = trb_read(scrQb + rd_xx + (UT + t) * 512);
+                dTh[t] = VMP_DEC_TR16 ? trt_read(scrQb + t * 512, tr_o1, tr_o2) : trb_read(scrQb + rd_xx + t * 512);
+                dTm[t] = VMP_DEC_TR16 ? trt_read(scrQb + (UT + t) * 512, tr_o1, tr_o2) : trb_read(scrQb + rd_xx + (UT + t) * 512);
             }
 #pragma unroll
             for (int ti = 0; ti < UT; ++ti) {
-                const u32x4 h0T = trb_read(scrPb + rd_hm + ti * 512);
+                const u32x4 h0T = VMP_DEC_TR16 ? trt_read(scrPb + tr_hm + ti * 512, tr_o1, tr_o2) : trb_read(scrPb + rd_hm + ti * 512);
 #pragma unroll
                 for (int tj = 0; tj < UT; ++tj) aW1[ti][tj] = mfma_bf(h0T, dTh[tj], aW1[ti][tj]);
 #pragma unroll
@@ -870,7 +914,7 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
         {
             unsigned d0s[3][4 * KB];
             split_tiles<UT, BT>(dh0, d0s);
-            trb_write<UT>(scrPb, g, c, d0s);
+            if constexpr (VMP_DEC_TR16) trt_write<UT>(scrPb, tr_w, d0s); else trb_write<UT>(scrPb, g, c, d0s);
             const f32x4 ds_ = gemm_slots<BT>(sm + I::B3S, lane, so, zero4);
             const f32x4 dxv = gemm_units_1<UT, BT>(sm + I::B3, lane, d0s, zero4) + ds_;        // [dim 4g+v][row c]
             if (ok && a.dx) {
@@ -888,7 +932,8 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
         wave_lds_order();
 #pragma unroll
         for (int tj = 0; tj < UT; ++tj) {
-            const u32x4 dTh = trb_read(scrPb + rd_xx + tj * 512), dTm = trb_read(scrPb + rd_xx + (UT + tj) * 512);
+            const u32x4 dTh = VMP_DEC_TR16 ? trt_read(scrPb + tj * 512, tr_o1, tr_o2) : trb_read(scrPb + rd_xx + tj * 512);
+            const u32x4 dTm = VMP_DEC_TR16 ? trt_read(scrPb + (UT + tj) * 512, tr_o1, tr_o2) : trb_read(scrPb + rd_xx + (UT + tj) * 512);
             aW0[tj] = mfma_bf(xT, dTh, aW0[tj]);
             aW0[tj] = mfma_bf(xT, dTm, aW0[tj]);
         }
