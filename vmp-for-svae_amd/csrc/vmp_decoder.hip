@@ -155,6 +155,7 @@ __device__ __forceinline__ float sigmoid_f(float v) { return rcp_f(1.0f + __expf
 #define VMP_TANH_RATIONAL 0
 #endif
 #if VMP_TANH_RATIONAL
+#define TANH_PRESCALE 1.0f
 __device__ __forceinline__ v2f tanh2(v2f x) {
     const float lim = 7.90531110763549805f;
     x[0] = __builtin_amdgcn_fmed3f(x[0], -lim, lim);
@@ -180,8 +181,21 @@ __device__ __forceinline__ f32x4 tanh4(f32x4 z) {
     return f32x4{a[0], a[1], b[0], b[1]};
 }
 #else
+// tanh of a pre-activation that arrives ALREADY scaled by TANH_PRESCALE = 2 log2(e): fill_images folds the factor into the two
+// hidden layers' forward weight images and biases (one multiply per weight per block instead of one per unit per row - 32 of a
+// tile's 605 VALU instructions), so e^(2z) is a bare v_exp_f32 of the accumulator.
+#ifndef VMP_DEC_TANH_FOLD
+#define VMP_DEC_TANH_FOLD 1
+#endif
+#if VMP_DEC_TANH_FOLD
+#define TANH_PRESCALE 2.8853900817779268f
+#define TANH_INSCALE 1.0f
+#else
+#define TANH_PRESCALE 1.0f
+#define TANH_INSCALE 2.8853900817779268f
+#endif
 __device__ __forceinline__ float tanh1(float x) {
-    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);      // e^(2x)
+    const float e = __builtin_amdgcn_exp2f(x * TANH_INSCALE);              // e^(2z), x = z * 2 log2(e) when folded
     return fmaf(-2.0f, rcp_f(e + 1.0f), 1.0f);
 }
 __device__ __forceinline__ f32x4 tanh4(f32x4 z) { return f32x4{tanh1(z[0]), tanh1(z[1]), tanh1(z[2]), tanh1(z[3])}; }
@@ -217,8 +231,8 @@ __device__ void fill_images(float* __restrict__ sm, const DecArgs& a) {
         if (i < N0) {
             if (tp < UT) {
                 const int unit = 16 * tp + c;
-                w[0] = (g < L && unit < U) ? a.W0[g * U + unit] : 0.f;
-                w[1] = (4 + g < L && unit < U) ? a.W0[(4 + g) * U + unit] : 0.f;
+                w[0] = (g < L && unit < U) ? TANH_PRESCALE * a.W0[g * U + unit] : 0.f;
+                w[1] = (4 + g < L && unit < U) ? TANH_PRESCALE * a.W0[(4 + g) * U + unit] : 0.f;
             } else {
                 const int d = slot_d(c), ty = slot_ty(c);
                 w[0] = (g < L && d < Dy && ty == 0) ? a.Ws[g * Dy + d] : 0.f;
@@ -238,7 +252,7 @@ __device__ void fill_images(float* __restrict__ sm, const DecArgs& a) {
         for (int h = 0; h < 2; ++h) {
             const int j = 2 * dw + h, ku = kslot_unit(g, j, kb), mu = 16 * tp + c;
             const int in = bw ? mu : ku, out = bw ? ku : mu;
-            w1[it][h] = (ku < 16 * UT && in < U && out < U) ? a.W1[in * U + out] : 0.f;
+            w1[it][h] = (ku < 16 * UT && in < U && out < U) ? (bw ? 1.0f : TANH_PRESCALE) * a.W1[in * U + out] : 0.f;
         }
     }
     // F2: A[i = slot c][k-slot -> unit] = W2[unit][ty*Dy + d];  B3: A[i = dim c][k-slot -> unit] = W0[dim][unit]
@@ -281,8 +295,8 @@ __device__ void fill_images(float* __restrict__ sm, const DecArgs& a) {
 #pragma unroll
     for (int it = 0; it < (16 * UT + THREADS - 1) / THREADS; ++it) {
         const int i = tid + it * THREADS;
-        bias0[it] = i < U ? a.b0[i] : 0.f;
-        bias1[it] = i < U ? a.b1[i] : 0.f;
+        bias0[it] = i < U ? TANH_PRESCALE * a.b0[i] : 0.f;
+        bias1[it] = i < U ? TANH_PRESCALE * a.b1[i] : 0.f;
     }
     float bo = 0.f, bsp = 0.f;
     if (tid < 16) {
