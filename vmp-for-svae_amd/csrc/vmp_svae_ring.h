@@ -13,16 +13,16 @@
 // rows of a tile are summed across lanes first (fixed order), so a wave keeps [rows][16] floats instead of a lane-private
 // [rows][64] column set.  One block per CU.  Even L >= 4 and even S >= 4 (a sample pair is L/2 16-byte pieces).
 //
-// Tile = RPT whole data rows = CT = RPT*K consecutive cells, one cell per lane (lane = cell index inside the tile):
-//   K = 16   RPT = 4: a data row is one 16-lane DPP row, lanes l, l^16, l^32, l^48 own the same component - row sums by DPP
-//            rotations, component sums by v_permlane32_swap / v_permlane16_swap;
+// Tile = RPT whole data rows = CT = RPT*K consecutive cells, one cell per lane:
+//   K = 16   RPT = 4, lane = cell index: a data row is one 16-lane DPP row, lanes l, l^16, l^32, l^48 own the same component - row
+//            sums by DPP rotations, component sums by v_permlane32_swap / v_permlane16_swap;
 //   8 <= K < 16 (round 4; C2/C4's K = 10: 60 of 64 lanes busy - a 16-lane-per-row layout with masked lanes would run the
-//            VALU-bound cell arithmetic at K/16 of the lanes and lose to the generic kernel): RPT = 64 / K in {4..8}
-//            rows whose lanes do NOT line up with the DPP rows.  Every value that has to be summed across lanes is first GATHERED
-//            into the K = 16 arrangement - ds_bpermute: lane (dr, col) of gather g takes the value of tile cell
-//            (4g + dr) * K + col, or 0 - after which the very same DPP / permlane reductions apply; two gathers cover
-//            8 rows.  ds_bpermute uses the LDS crossbar but no LDS memory (~130 per tile; the K = 16 kernel ran 90 of them per
-//            tile before round 3's permlane form and lost < 1 % to them).
+//            VALU-bound cell arithmetic at K/16 of the lanes and lose to the generic kernel): RPT = 64 / K in {4..8} rows.
+//            Round 5: tile rows 0..3 sit in columns 0..K-1 of the four DPP rows - already the K = 16 arrangement - and the cells of
+//            rows 4..RPT-1 fill the 16 - K spare lanes of each DPP row (the map is spelled out at `cell_of_slot` below).  A value that
+//            is summed across lanes costs ONE ds_bpermute (a main lane pulls the value of the cell four rows below it) or none
+//            (K >= 13) before the very same DPP / permlane reductions apply.  Round 4 laid the cells out as lane = r K + k, which no
+//            DPP row matches, and gathered every value twice (~130 ds_bpermute and their selects per tile at K = 10).
 // Row sums (d eta of the encoder): a reduce-scatter over the 16 lanes of a data row leaves value c in lane c; one store per tile.
 // Student-t theta (round 4; BASELINE configs[4]): the theta term of T' is (nu+L)/2 log1p(delta^2/nu), so the sample loop
 // scales W^T W (x - m) by c_s = (nu+L)/(nu+delta_s^2), and theta/mu_k, theta/L_k are trainable: per cell
@@ -87,6 +87,9 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 #ifndef VMP_RING_NT
 #define VMP_RING_NT 0        // A/B: 2 = the sample DMA carries nt
 #endif
+#ifndef VMP_RING_INPUTS_AHEAD
+#define VMP_RING_INPUTS_AHEAD 0   // A/B: 1 = the tile's small inputs are loaded one tile ahead into registers (round 5: no gain, see below)
+#endif
 #ifdef VMP_DEBUG_TS
 // exploration builds: clock64 stamps of ONE tile (the 9th of block 0, wave 0) - tools/ring_ts.py
 #define RG_TS(i) do { if (a.dbg_t && blockIdx.x == 0 && wave == 0 && tile_it == 8 && lane == 0) a.dbg_t[i] = clock64(); } while (0)
@@ -95,8 +98,25 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 #define RG_TS(i) do { } while (0)
 #define RG_USE(v) do { } while (0)
 #endif
-template <int L, bool K16, bool STUDENT, int NSTG>
+// KS = 16: K = 16.  KS = 0: any 8 <= K <= 15 at run time (spare-lane cells in linear order, one ds_bpermute per summed value).
+// KS in {8, 10, 11, 12}: K = KS at compile time, spare-lane cells in DPP-rotation order (no ds_bpermute at all) - see the lane map.
+template <int KS> struct SvRingRot {
+    static constexpr int K = KS, E = 16 - K, XR = 64 / K - 4;          // spare lanes per DPP row; tile rows beyond the fourth
+    static constexpr int CPR = XR > 0 ? 4 / XR : 1;                     // DPP rows that share one extra tile row (its "chunks")
+    static constexpr int U = (K + CPR - 1) / CPR;                       // components per chunk
+    static constexpr bool ok = XR > 0 && (XR == 1 || XR == 2 || XR == 4) && U <= E;
+};
+template <int N, int ROWS> __device__ __forceinline__ float row_ror_masked(float v) {
+    // rows of ROWS: the value of the lane N columns to the left (rotating inside the 16-lane row); other rows: -0.0
+    // (-0.0, the identity of the float add, in the rows left out: lets the compiler fold move + add into one v_add_f32_dpp)
+    return __int_as_float(__builtin_amdgcn_update_dpp((int)0x80000000u, __float_as_int(v), 0x120 + N, ROWS, 0xf, false));
+}
+template <int L, int KS, bool STUDENT, int NSTG>
 __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bwd_ring_kernel(EBwdArgs a, int nblk_abi) {
+    constexpr bool K16 = KS == 16;
+    constexpr bool KR = KS != 16 && KS != 0;                 // compile-time K < 16, rotation layout
+    using RT = SvRingRot<KR ? KS : 8>;
+    static_assert(!KR || RT::ok, "no rotation layout for this K");
     constexpr bool SP = STUDENT && NSTG == 4;                // Student-t, parameters in registers, packed sample loop
     constexpr bool ST = STUDENT && NSTG == 2;                // Student-t, parameters in an LDS table, scalar sample loop
     constexpr bool PF = NSTG == 4;                           // small inputs of a tile prefetched by DMA
@@ -109,9 +129,9 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: tile indices and DMA bases stay scalar
-    const int K = K16 ? 16 : a.K, S = a.S;
+    const int K = KS ? KS : a.K, S = a.S;
     const int LSn = L * S, NP = S >> 1;
-    const int RPT = K16 ? 4 : WAVE / K, CT = RPT * K;
+    const int RPT = KS ? WAVE / KS : WAVE / K, CT = RPT * K;
     constexpr int PSTR = TRI | 1;
     // Student-t: the theta parameters of a component live in an LDS table instead of 52 VGPRs per lane (with the 44 theta-side
     // sums of the cell the L = 8 sample loop spilled): [W rows, each padded to whole 16-byte pieces | m | h], stride = odd
@@ -124,17 +144,67 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
     float* accw = smem + tab + nw * (NSTG * STG) + wave * (PWa * 16);   // this wave's per-component sums [PWa][16]
     constexpr int PFW = PF ? 5 * WAVE : 0;                   // [eta1 rows | eta2d rows | dL/dT' | dL/dlog z | log z] of the next tile
     float* pfb = smem + tab + nw * (NSTG * STG) + nw * (PWa * 16) + wave * PFW;
-    const bool lane_on = K16 ? true : lane < CT;
-    const int r = K16 ? lane >> 4 : lane / K, k = K16 ? lane & 15 : lane - r * K;
-
-    // ---- the K = 16 arrangement of a tile with K < 16: gather g puts tile row 4g + dr into DPP row dr, component col in column col
+    // ---- lane <-> cell map of a tile (round 5 for K < 16).  DPP row dr = lanes 16 dr .. 16 dr + 15, column col = lane & 15:
+    //   columns 0 .. K-1   MAIN cells: component col of tile row dr - rows 0..3 sit in the K = 16 arrangement as they are;
+    //   columns K .. 15    the E = 16 - K spare lanes of the four DPP rows take the cells of tile rows 4 .. RPT-1 in linear order:
+    //                      spare x = dr E + (col - K)  <->  cell (4 + x / K, x % K)   (4 E >= (RPT - 4) K for every 8 <= K <= 15).
+    // A value that is summed across lanes needs ONE ds_bpermute per value ("pull": main lane (dr, col) fetches the value of cell
+    // (4 + dr, col) and adds it to its own) or none (K >= 13: RPT = 4) before the DPP / permlane reductions of the K = 16 kernel;
+    // the round-4 layout lane = r K + k needed two gathers per value (90 of them per tile for the component sums at K = 10).
+    // The DMA slot of a cell is its lane, so only the per-lane source offsets (cbyte) know about the map.
     const int dr = lane >> 4, col = lane & 15;
-    const bool gv0 = !K16 && col < K && dr < RPT, gv1 = !K16 && col < K && 4 + dr < RPT;
-    const int ga0 = 4 * (gv0 ? dr * K + col : 0), ga1 = 4 * (gv1 ? (4 + dr) * K + col : 0);   // byte addresses for ds_bpermute
-    // (the exchange is executed by ALL lanes and the result selected afterwards: inside `gv ? bpermute(..) : 0` it would run
-    //  under the exec mask of the gv lanes only, and a ds_bpermute that reads from a disabled lane returns 0)
-    auto gat0 = [&](float v) { const float t_ = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga0, __float_as_uint(v))); return gv0 ? t_ : 0.f; };
-    auto gat1 = [&](float v) { const float t_ = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga1, __float_as_uint(v))); return gv1 ? t_ : 0.f; };
+    const int E = 16 - K, XR = RPT - 4;                     // spare lanes per DPP row; tile rows beyond the fourth
+    // K known at compile time (KS = 8, 10, 11, 12; the reference's K = 10): the spare lanes are filled in DPP-ROTATION order instead -
+    // an extra tile row 4 + xr is cut into CPR = 4 / (RPT - 4) chunks of U components, chunk c of it sits in columns K .. K+U-1 of DPP
+    // row xr CPR + c - so that ONE masked row rotation per chunk (v_add_f32 with row_ror:(16 - K + c U) row_mask) drops every spare
+    // value onto the main lane of its component: no ds_bpermute, no LDS round trip; the row sums of an extra row are the sums over
+    // the spare lanes of its CPR DPP rows (one permlane swap + add per doubling).
+    auto cell_of_slot = [&](int sl) -> int {                // tile cell index held by lane / DMA slot sl, or -1
+        if constexpr (K16) return sl;
+        const int d_ = sl >> 4, c_ = sl & 15;
+        if (c_ < K) return d_ * K + c_;
+        if constexpr (KR) {
+            const int j_ = c_ - K, cp_ = (d_ % RT::CPR) * RT::U + j_;
+            return (j_ < RT::U && cp_ < K) ? (4 + d_ / RT::CPR) * K + cp_ : -1;
+        } else {
+            const int x_ = d_ * E + (c_ - K);
+            return x_ < XR * K ? 4 * K + x_ : -1;
+        }
+    };
+    const bool mainl = K16 ? true : col < K;
+    const int own = cell_of_slot(lane);
+    const bool lane_on = own >= 0;
+    const int r = (K16 || mainl) ? dr : (lane_on ? own / K : RPT), k = (K16 || mainl) ? col : (lane_on ? own - (own / K) * K : 0);
+    // pull: main lane (dr, col) takes the value of cell (4 + dr, col) = spare x' = dr K + col
+    const bool pv = !K16 && !KR && mainl && dr < XR;
+    const int xq_ = dr * K + col;
+    const int pa = 4 * (pv ? (xq_ / (E > 0 ? E : 1)) * 16 + K + xq_ % (E > 0 ? E : 1) : 0);      // byte address for ds_bpermute
+    // (the exchange is executed by ALL lanes and the result selected afterwards: inside `pv ? bpermute(..) : 0` it would run
+    //  under the exec mask of the pv lanes only, and a ds_bpermute that reads from a disabled lane returns 0)
+    auto pull = [&](float v) { const float t_ = __uint_as_float(__builtin_amdgcn_ds_bpermute(pa, __float_as_uint(v))); return pv ? t_ : 0.f; };
+    // rotation layout: the spare lanes' values of e (zero elsewhere) dropped onto the main lanes of their components
+    auto rot_in = [&](float e) -> float {
+        if constexpr (KR) {
+            float t_ = row_ror_masked<RT::E, RT::CPR == 1 ? 0xF : RT::CPR == 2 ? 0x5 : 0x1>(e);
+            if constexpr (RT::CPR >= 2) t_ += row_ror_masked<RT::E + RT::U, RT::CPR == 2 ? 0xA : 0x2>(e);
+            if constexpr (RT::CPR == 4) { t_ += row_ror_masked<RT::E + 2 * RT::U, 0x4>(e); t_ += row_ror_masked<RT::E + 3 * RT::U, 0x8>(e); }
+            return t_;
+        } else return 0.f;
+    };
+    // ... and a per-DPP-row quantity of the spare lanes summed over the CPR DPP rows that share an extra tile row (all of them get it)
+    auto rows_total = [&](float t_) -> float {
+        if constexpr (KR) {
+            if constexpr (RT::CPR >= 2) {
+                const auto s_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(t_), __float_as_uint(t_), false, false);
+                t_ = __uint_as_float(s_[0]) + __uint_as_float(s_[1]);
+            }
+            if constexpr (RT::CPR == 4) {
+                const auto s_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(t_), __float_as_uint(t_), false, false);
+                t_ = __uint_as_float(s_[0]) + __uint_as_float(s_[1]);
+            }
+        }
+        return t_;
+    };
     // The TH values a cell contributes to its component's sums -> this wave's LDS accumulator rows [row0, row0 + TH).
     // Four values at a time are summed over the tile's rows by a REDUCE-SCATTER across the four DPP rows: v_permlane32_swap of two
     // values leaves [a.lo | b.lo], [a.hi | b.hi], whose sum holds a's half-sums in lanes 0..31 and b's in lanes 32..63 (one swap + one
@@ -154,22 +224,25 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
             if constexpr (K16) {
 #pragma unroll
                 for (int u = 0; u < 4 * GC; ++u) w[u] = (4 * g0 + u < TH) ? vals[4 * g0 + u < TH ? 4 * g0 + u : 0] : 0.f;
-            } else {
-                float t0[4 * GC], t1[4 * GC];
+            } else if constexpr (KR) {
 #pragma unroll
                 for (int u = 0; u < 4 * GC; ++u) {
-                    t0[u] = 0.f; t1[u] = 0.f;
-                    if (4 * g0 + u < TH) {
-                        t0[u] = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga0, __float_as_uint(vals[4 * g0 + u < TH ? 4 * g0 + u : 0])));
-                        if (RPT > 4) t1[u] = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga1, __float_as_uint(vals[4 * g0 + u < TH ? 4 * g0 + u : 0])));
-                    }
+                    const float v_ = (4 * g0 + u < TH) ? vals[4 * g0 + u < TH ? 4 * g0 + u : 0] : 0.f;
+                    w[u] = (4 * g0 + u < TH) ? (mainl ? v_ : 0.f) + rot_in((!mainl && lane_on) ? v_ : 0.f) : 0.f;
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else {
+                float t1[4 * GC];
 #pragma unroll
                 for (int u = 0; u < 4 * GC; ++u) {
-                    asm volatile("" : "+v"(t0[u]));
-                    w[u] = gv0 ? t0[u] : 0.f;
-                    if (RPT > 4) { asm volatile("" : "+v"(t1[u])); w[u] += gv1 ? t1[u] : 0.f; }
+                    t1[u] = 0.f;
+                    w[u] = (4 * g0 + u < TH && mainl) ? vals[4 * g0 + u < TH ? 4 * g0 + u : 0] : 0.f;
+                    if (4 * g0 + u < TH && RPT > 4)
+                        t1[u] = __uint_as_float(__builtin_amdgcn_ds_bpermute(pa, __float_as_uint(vals[4 * g0 + u < TH ? 4 * g0 + u : 0])));
+                }
+                if (RPT > 4) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int u = 0; u < 4 * GC; ++u) { asm volatile("" : "+v"(t1[u])); w[u] += pv ? t1[u] : 0.f; }
                 }
             }
             float R[GC], oldv[GC];
@@ -196,9 +269,8 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
                 }
         }
     };
-    // where lane (r, k) finds the sum of ITS row after the gathered row sums: DPP row r & 3, columns 0..7 hold gather 0's sum
-    // (rows 0..3), columns 8..15 gather 1's (rows 4..7)
-    const int back = 4 * ((r & 3) * 16 + (r < 4 ? 0 : 8));
+    // where a spare lane finds the sum of ITS tile row r >= 4 after the pulled row sums: any lane of DPP row r - 4
+    const int back = 4 * (((mainl ? dr : r - 4) & 3) * 16);
 
     for (int e = threadIdx.x; e < K * TRI; e += blockDim.x) {
         const int kk = e / TRI, idx = e - kk * TRI;
@@ -280,7 +352,8 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
     for (int j = 0; j < PP; ++j) {
         const int dc = (PP == 4) ? ((j * WAVE + lane) >> 2) : dcell[j];
         const int dp = (PP == 4) ? ((lane & 3) ^ ((dc >> 2) & 3)) : dpiece[j];
-        const int cc = dc < CT ? dc : CT - 1;                // K < 16: slots past the tile's CT cells re-fetch its last cell
+        const int ci = cell_of_slot(dc);
+        const int cc = ci >= 0 ? ci : CT - 1;                // K < 16: lanes without a cell re-fetch the tile's last cell
         cbyte[j] = (unsigned)(cc * LSn + 4 * dp) * 4u;
         cpar[j] = (unsigned)cc & 1u;
     }
@@ -309,7 +382,8 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
         for (int j = 0; j < PP; ++j) {
             const int dc = (PP == 4) ? ((j * WAVE + lane) >> 2) : dcell[j];
             const int dp = (PP == 4) ? ((lane & 3) ^ ((dc >> 2) & 3)) : dpiece[j];
-            const int cc = dc < ncell ? dc : ncell - 1;
+            const int ci = cell_of_slot(dc);
+            const int cc = (ci >= 0 && ci < ncell) ? ci : ncell - 1;
             int pe = pp;
             if (rotate) { pe = pp + ((cc + (int)par0) & 1); pe = pe >= NP ? pe - NP : pe; }
             const long long off = tile0 + (long long)cc * LSn + pe * 2 * L + 4 * dp;
@@ -360,6 +434,28 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
         const int younger = outst - 1;
         return younger * (2 * PP) + ((PF && p + younger >= NP) ? 5 : 0);
     };
+    // Round 5 (two-stage form): the small inputs of a tile - its RPT rows of eta1 / eta2d and the three (N, K) values of every cell -
+    // are loaded ONE TILE AHEAD into five registers per lane, right after the tile's last pair was re-requested: lane e holds element
+    // e of the tile's RPT L eta floats (coalesced), a lane's own row is read back with 2 L ds_bpermute.  Loaded at the top of the
+    // tile they cost an exposed memory round trip per tile behind the two stage requests already queued (vmcnt returns in order):
+    // the stage stamps put 2.3 k (K = 16) to 8.3 k (K = 10) cycles on "eta, P_k table, Cholesky, mean", of which ~2 k is arithmetic.
+    constexpr bool NX = VMP_RING_INPUTS_AHEAD && !PF;
+    float nx_e1 = 0.f, nx_e2 = -0.5f, nx_gT = 0.f, nx_glz = 0.f, nx_lz = 0.f;
+    auto load_inputs = [&](long long tt) {
+        if constexpr (NX) {
+            if (tt < ntiles) {
+                const long long rows_left = a.N - tt * RPT;
+                const int ne = (rows_left < RPT ? (int)rows_left : RPT) * L;
+                const long long e0 = tt * (long long)RPT * L;
+                const int le = lane < ne ? lane : ne - 1;                      // clamped: always a valid element
+                nx_e1 = a.eta1[e0 + le]; nx_e2 = a.eta2d[e0 + le];
+                const long long rw = tt * RPT + r;
+                const long long cid = (lane_on && rw < a.N ? rw : tt * RPT) * K + kc;
+                nx_gT = a.GT[cid]; nx_glz = a.Glz[cid]; nx_lz = a.lz[cid];
+            }
+        }
+    };
+    load_inputs(t);
     int tile_it = -1;
     for (; t < ntiles; t += tstride) {
         ++tile_it;
@@ -378,7 +474,10 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
         for (int i = 0; i < L; ++i) {
             float e1v, e2v;
             if constexpr (PF) { e1v = pfb[ro + i]; e2v = pfb[WAVE + ro + i]; }
-            else { e1v = a.eta1[rowc * L + i]; e2v = a.eta2d[rowc * L + i]; }
+            else if constexpr (NX) {
+                e1v = __uint_as_float(__builtin_amdgcn_ds_bpermute(4 * (ro + i), __float_as_uint(nx_e1)));
+                e2v = __uint_as_float(__builtin_amdgcn_ds_bpermute(4 * (ro + i), __float_as_uint(nx_e2)));
+            } else { e1v = a.eta1[rowc * L + i]; e2v = a.eta2d[rowc * L + i]; }
             const float e1 = on ? e1v : 0.f;
             const float e2 = on ? e2v : -0.5f;
             Lm[tri(i, i)] = fmaf(-2.f, e2, lane_on ? Lm[tri(i, i)] : 0.f);
@@ -386,7 +485,8 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
             else av[i] = e1 + hkk[i];
         }
         float glzv, gTv, lzv;
-        if constexpr (PF) { const int pl = lane_on ? lane : 0; gTv = pfb[2 * WAVE + pl]; glzv = pfb[3 * WAVE + pl]; lzv = pfb[4 * WAVE + pl]; }
+        if constexpr (PF) { const int pl = lane_on ? r * K + k : 0; gTv = pfb[2 * WAVE + pl]; glzv = pfb[3 * WAVE + pl]; lzv = pfb[4 * WAVE + pl]; }
+        else if constexpr (NX) { glzv = nx_glz; gTv = nx_gT; lzv = nx_lz; }
         else { glzv = a.Glz[cellid]; gTv = a.GT[cellid]; lzv = a.lz[cellid]; }
         float ld;
         cell_cholesky<L>(Lm, ld);
@@ -403,8 +503,15 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
         if constexpr (K16) {
             gsum = row16_sum(glz);
         } else {
-            const float t0 = row16_sum(gat0(glz)), t1 = RPT > 4 ? row16_sum(gat1(glz)) : 0.f;
-            gsum = __uint_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_uint(col < 8 ? t0 : t1)));
+            gsum = row16_sum(mainl ? glz : 0.f);             // tile rows 0..3: the row's components are the DPP row's main lanes
+            if constexpr (KR) {
+                const float t1 = rows_total(row16_sum(mainl ? 0.f : glz));     // (glz is zero on lanes without a cell)
+                gsum = mainl ? gsum : t1;
+            } else if (RPT > 4) {
+                const float t1 = row16_sum(pull(glz));         // DPP row dr: total of tile row 4 + dr
+                const float tb = __uint_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_uint(t1)));
+                gsum = mainl ? gsum : tb;
+            }
         }
         const float Gc = glz - rnk * gsum;                  // through the log-sum-exp normalisation
         const float Gld = gT - Gc;                          // T' has +ld, c has -ld
@@ -627,6 +734,7 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
             if constexpr (ST) { RG_USE(M[0]); } else { RG_USE(M2[0]); }
             RG_TS(6 + 4 * p);
         }
+        load_inputs(t + tstride);                            // (every value of this tile's inputs has been consumed above)
         auto MM = [&](int i, int j) -> float {               // i >= j
             if constexpr (ST) return M[tri(i, j)];
             else return M2[RO(i) + j / 2][j & 1];
@@ -748,8 +856,9 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
         // a reduce-scatter over the row's 16 lanes (row16_reduce_scatter) and leave with ONE store instruction per tile: lane
         // (row, c) stores value c - d eta1[c] for c < L, d eta2d[c - L] for L <= c < 2 L - to two contiguous 4 L-byte rows (the
         // first form stored them with 2 L instructions from one lane per row; the four-stage kernel counts its memory operations)
-        auto store_row_sums = [&](float (&v)[16], long long row_, bool row_ok) {
-            const float tot = row16_reduce_scatter(v, col);
+        auto store_row_sums = [&](float (&v)[16], long long row_, bool row_ok, bool spare = false) {
+            float tot = row16_reduce_scatter(v, col);
+            if (spare) tot = rows_total(tot);
             const bool is1 = col < L;
             float* dst = (is1 ? a.g_eta1 : a.g_eta2d) + row_ * L + (is1 ? col : col - L);
             if (row_ok && col < 2 * L) *dst = is1 ? tot : -2.f * tot;      // p = -2 eta2d
@@ -759,28 +868,34 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = i < L ? (on ? gh[i < L ? i : 0] : 0.f) : i < 2 * L ? (on ? gP[tri(i < 2 * L && i >= L ? i - L : 0, i < 2 * L && i >= L ? i - L : 0)] : 0.f) : 0.f;
             store_row_sums(v, t * RPT + dr, t * RPT + dr < a.N);
+        } else if constexpr (KR) {
+            // main lanes: tile row dr; spare lanes: a chunk of tile row 4 + dr / CPR, summed over that row's CPR DPP rows
+            float va[16], vb[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float x_ = i < L ? (on ? gh[i < L ? i : 0] : 0.f) : i < 2 * L ? (on ? gP[tri(i < 2 * L && i >= L ? i - L : 0, i < 2 * L && i >= L ? i - L : 0)] : 0.f) : 0.f;
+                va[i] = mainl ? x_ : 0.f; vb[i] = mainl ? 0.f : x_;
+            }
+            const long long rowa = t * RPT + dr, rowb = t * RPT + 4 + dr / RT::CPR;
+            store_row_sums(va, rowa, rowa < a.N);
+            store_row_sums(vb, rowb, dr % RT::CPR == 0 && rowb < a.N, true);
         } else {
-            // gathered: DPP row dr holds tile row dr (gather 0) and tile row 4 + dr (gather 1)
+            // DPP row dr holds tile row dr in its main lanes; tile row 4 + dr is pulled into them from the spare lanes
             float va[16], vb[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {                  // all exchanges first, one wait, then the sums
                 const float x_ = i < L ? (on ? gh[i < L ? i : 0] : 0.f) : i < 2 * L ? (on ? gP[tri(i < 2 * L && i >= L ? i - L : 0, i < 2 * L && i >= L ? i - L : 0)] : 0.f) : 0.f;
-                va[i] = 0.f; vb[i] = 0.f;
-                if (i < 2 * L) {
-                    va[i] = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga0, __float_as_uint(x_)));
-                    if (RPT > 4) vb[i] = __uint_as_float(__builtin_amdgcn_ds_bpermute(ga1, __float_as_uint(x_)));
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < 2 * L; ++i) {
-                asm volatile("" : "+v"(va[i]));
-                va[i] = gv0 ? va[i] : 0.f;
-                if (RPT > 4) { asm volatile("" : "+v"(vb[i])); vb[i] = gv1 ? vb[i] : 0.f; }
+                va[i] = mainl ? x_ : 0.f; vb[i] = 0.f;
+                if (i < 2 * L && RPT > 4) vb[i] = __uint_as_float(__builtin_amdgcn_ds_bpermute(pa, __float_as_uint(x_)));
             }
             const long long rowa = t * RPT + dr, rowb = rowa + 4;
-            store_row_sums(va, rowa, dr < RPT && rowa < a.N);
-            if (RPT > 4) store_row_sums(vb, rowb, 4 + dr < RPT && rowb < a.N);
+            if (RPT > 4) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < 2 * L; ++i) { asm volatile("" : "+v"(vb[i])); vb[i] = pv ? vb[i] : 0.f; }
+            }
+            store_row_sums(va, rowa, rowa < a.N);
+            if (RPT > 4) store_row_sums(vb, rowb, dr < XR && rowb < a.N);
         }
         RG_TS(25);
         // ---- per-component sums (acc_batches above)
@@ -816,7 +931,7 @@ __global__ __launch_bounds__((NSTG == 2 ? SVR_NW : 4) * WAVE) void svae_estep_bw
     }
 }
 
-template <int L, bool K16, bool STUDENT, int NSTG>
+template <int L, int KS, bool STUDENT, int NSTG>
 int launch_n(const EBwdArgs& a, int nblk_abi, void* stream) {
     constexpr int TRI = L * (L + 1) / 2, TH = L + TRI + 1, PWa = STUDENT ? 2 * TH : TH;
     const int K = a.K, RPT = WAVE / K;
@@ -834,7 +949,7 @@ int launch_n(const EBwdArgs& a, int nblk_abi, void* stream) {
     long long bl = (ntiles + nw - 1) / nw;
     if (bl > 256) bl = 256;                                  // one block per CU
     const size_t lds = (size_t)(tab + nw * per_wave) * sizeof(float);
-    auto kern = svae_estep_bwd_ring_kernel<L, K16, STUDENT, NSTG>;
+    auto kern = svae_estep_bwd_ring_kernel<L, KS, STUDENT, NSTG>;
     if (const int rc = vmp::set_dyn_lds(reinterpret_cast<const void*>(kern), lds, "svae_estep_bwd_ring_kernel")) return rc;
     hipLaunchKernelGGL(kern, dim3((int)bl), dim3(nw * WAVE), lds, static_cast<hipStream_t>(stream), a, nblk_abi);
     return check_launch("svae_estep_bwd_ring_kernel");
@@ -843,18 +958,18 @@ int launch_n(const EBwdArgs& a, int nblk_abi, void* stream) {
 #ifndef VMP_RING_STAGES
 #define VMP_RING_STAGES 2      // 2: eight waves per CU, two stages each (shipped).  4: one wave per SIMD, four stages, where S / 2 >= 4 and
 #endif                         //    the batch has >= 1024 wave tiles - measured SLOWER; A/B builds only
-template <int L, bool K16, bool STUDENT>
+template <int L, int KS, bool STUDENT>
 int launch(const EBwdArgs& a, int nblk_abi, void* stream) {
     if constexpr (VMP_RING_STAGES == 4) {
         const long long ntiles = (a.N + WAVE / a.K - 1) / (WAVE / a.K);
         // four stages need S / 2 >= 4 pairs per tile (a request never runs more than one tile ahead) and enough tiles to give every
         // one of the 1024 waves of the chip work; smaller batches keep the eight-wave form
         if ((a.S >> 1) >= 4 && ntiles >= 1024) {
-            const int rc = launch_n<L, K16, STUDENT, 4>(a, nblk_abi, stream);
+            const int rc = launch_n<L, KS, STUDENT, 4>(a, nblk_abi, stream);
             if (rc != -2) return rc;
         }
     }
-    return launch_n<L, K16, STUDENT, 2>(a, nblk_abi, stream);
+    return launch_n<L, KS, STUDENT, 2>(a, nblk_abi, stream);
 }
 
 }  // namespace

@@ -10,11 +10,13 @@ int svae_bwd_ring_launch_t(const EBwdArgs& a, int L, int nblk_abi, void* stream)
 int svae_bwd_ring_launch(const EBwdArgs& a, int L, int nblk_abi, void* stream) {
     if (a.K < 8 || a.K > 16 || (L & 1) || L < 4 || L > 8 || (a.S & 1) || a.S < 4 || !a.vec_ok) return -2;
     if (a.nu != nullptr) return svae_bwd_ring_launch_t(a, L, nblk_abi, stream);
-    const bool k16 = a.K == 16;
+    // K = 16 and the reference's K = 10 (experiments.py: nb_components of the Auto / pinwheel schedules) have their own instances
+    // (compile-time lane maps); any other 8 <= K <= 15 runs the run-time-K form
+    const int ks = a.K == 16 ? 16 : (a.K == 10 && L == 8) ? 10 : 0;
     switch (L) {
-        case 4: return k16 ? launch<4, true, false>(a, nblk_abi, stream) : launch<4, false, false>(a, nblk_abi, stream);
-        case 6: return k16 ? launch<6, true, false>(a, nblk_abi, stream) : launch<6, false, false>(a, nblk_abi, stream);
-        case 8: return k16 ? launch<8, true, false>(a, nblk_abi, stream) : launch<8, false, false>(a, nblk_abi, stream);
+        case 4: return ks == 16 ? launch<4, 16, false>(a, nblk_abi, stream) : launch<4, 0, false>(a, nblk_abi, stream);
+        case 6: return ks == 16 ? launch<6, 16, false>(a, nblk_abi, stream) : launch<6, 0, false>(a, nblk_abi, stream);
+        case 8: return ks == 16 ? launch<8, 16, false>(a, nblk_abi, stream) : ks == 10 ? launch<8, 10, false>(a, nblk_abi, stream) : launch<8, 0, false>(a, nblk_abi, stream);
         default: return -2;
     }
 }
