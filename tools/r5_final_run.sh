@@ -22,6 +22,9 @@ export REPS=5
 timeout 400 bash tools/pmc.sh r05/pmc_t1 tools/t1_prof_target.py > /dev/null 2>&1
 python3 tools/pmc_summary.py gpurun_out/r05/pmc_t1 pass_xdl > $O/t1_pmc_summary.txt 2>&1
 rm -rf gpurun_out/r05/pmc_t1
+timeout 300 bash tools/pmc.sh r05/pmc_dec tools/dec_perf.py > /dev/null 2>&1
+{ echo "# decoder kernels, counters per launch (tools/dec_perf.py: 65 536 data rows = 1.05e7 decoder rows = 655 360 tiles of 16 rows; U = 50);"; echo "# SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles"; python3 tools/pmc_summary.py gpurun_out/r05/pmc_dec dec_bwd_kernel; python3 tools/pmc_summary.py gpurun_out/r05/pmc_dec dec_fwd_kernel; } > $O/decoder_pmc_summary.txt 2>&1
+rm -rf gpurun_out/r05/pmc_dec
 export REPS=3
 timeout 400 bash tools/pmc.sh r05/pmc_t2f tools/t2_fwd_rng_prof.py > /dev/null 2>&1
 python3 tools/pmc_summary.py gpurun_out/r05/pmc_t2f svae_estep_fwd4 > $O/t2_fwd_rng_pmc_summary.txt 2>&1
@@ -37,6 +40,7 @@ VARIANTS="16_0 10_0 16_1 10_1" bash tools/r4_t2_pmc.sh
 for v in 16_0 10_0 16_1 10_1; do mv gpurun_out/r4_t2_pmc_$v.txt $O/t2_pmc_$v.txt; done
 bash tools/kseq.sh r05mb step_scalars tools/r5_mb_graph.py > $O/minibatch64_kernel_seq.txt 2>&1
 python tools/ubench/hbm_rw.py > $O/hbm_rw.txt 2>&1
+for i in 1 2; do python3 tools/dec_perf.py 262144 2>&1 | tail -1; done > $O/dec_perf.txt
 grep "pass_xdl\|pass_kernel\|finalize" $O/headline_kernel_stats.csv | cut -c1-200
 head -c 300 $O/bench_driver_cmd.json; echo
 for f in t2 t2_k10 t2_smm t2_smm_k10 t3 t3_smm smm; do python3 - <<PY

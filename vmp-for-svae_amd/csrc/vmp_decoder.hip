@@ -231,8 +231,8 @@ __device__ void fill_images(float* __restrict__ sm, const DecArgs& a) {
         if (i < N0) {
             if (tp < UT) {
                 const int unit = 16 * tp + c;
-                w[0] = (g < L && unit < U) ? TANH_PRESCALE * a.W0[g * U + unit] : 0.f;
-                w[1] = (4 + g < L && unit < U) ? TANH_PRESCALE * a.W0[(4 + g) * U + unit] : 0.f;
+                w[0] = (g < L && unit < U) ? a.W0[g * U + unit] : 0.f;
+                w[1] = (4 + g < L && unit < U) ? a.W0[(4 + g) * U + unit] : 0.f;
             } else {
                 const int d = slot_d(c), ty = slot_ty(c);
                 w[0] = (g < L && d < Dy && ty == 0) ? a.Ws[g * Dy + d] : 0.f;
@@ -252,7 +252,7 @@ __device__ void fill_images(float* __restrict__ sm, const DecArgs& a) {
         for (int h = 0; h < 2; ++h) {
             const int j = 2 * dw + h, ku = kslot_unit(g, j, kb), mu = 16 * tp + c;
             const int in = bw ? mu : ku, out = bw ? ku : mu;
-            w1[it][h] = (ku < 16 * UT && in < U && out < U) ? (bw ? 1.0f : TANH_PRESCALE) * a.W1[in * U + out] : 0.f;
+            w1[it][h] = (ku < 16 * UT && in < U && out < U) ? a.W1[in * U + out] : 0.f;
         }
     }
     // F2: A[i = slot c][k-slot -> unit] = W2[unit][ty*Dy + d];  B3: A[i = dim c][k-slot -> unit] = W0[dim][unit]
@@ -295,8 +295,8 @@ __device__ void fill_images(float* __restrict__ sm, const DecArgs& a) {
 #pragma unroll
     for (int it = 0; it < (16 * UT + THREADS - 1) / THREADS; ++it) {
         const int i = tid + it * THREADS;
-        bias0[it] = i < U ? TANH_PRESCALE * a.b0[i] : 0.f;
-        bias1[it] = i < U ? TANH_PRESCALE * a.b1[i] : 0.f;
+        bias0[it] = i < U ? a.b0[i] : 0.f;
+        bias1[it] = i < U ? a.b1[i] : 0.f;
     }
     float bo = 0.f, bsp = 0.f;
     if (tid < 16) {
@@ -304,14 +304,15 @@ __device__ void fill_images(float* __restrict__ sm, const DecArgs& a) {
         bo = d < Dy ? (ty == 0 ? a.b2[d] + a.bs1[d] : a.b2[Dy + d]) : 0.f;
     }
     if (tid < 8) bsp = tid < Dy ? a.bs2[tid] : 0.f;
-    // ---- phase 2: split and store
+    // ---- phase 2: split and store (the hidden layers' FORWARD images and biases carry the tanh prescale - applied here, not at the
+    //      loads: a multiply behind each predicated load would bring back one exposed round trip per load)
 #pragma unroll
     for (int it = 0; it < IT0; ++it) {
         const int i = tid + it * THREADS;
         if (i >= N0) break;
         const int l = i & 63, tp = i >> 6;
         unsigned t3[3];
-        split_bf16<3>(w0[it], t3);
+        split_bf16<3>(w0[it] * (tp < UT ? TANH_PRESCALE : 1.0f), t3);
         unsigned* __restrict__ pa = smu + (tp < UT ? I::F0A + (tp * 64 + l) * 4 : I::F2SA + l * 4);
         unsigned* __restrict__ pb = smu + (tp < UT ? I::F0B + (tp * 64 + l) * 2 : I::F2SB + l * 2);
         pa[0] = t3[0]; pa[1] = t3[1]; pa[2] = t3[2]; pa[3] = t3[0];
@@ -322,7 +323,7 @@ __device__ void fill_images(float* __restrict__ sm, const DecArgs& a) {
         const int i = tid + it * THREADS;
         const int dw = i & 3, l = (i >> 2) & 63, e0 = i >> 8, bw = e0 >= UT * KB, e = bw ? e0 - UT * KB : e0;
         unsigned t3[3];
-        split_bf16<3>(w1[it], t3);
+        split_bf16<3>(w1[it] * (bw ? 1.0f : TANH_PRESCALE), t3);
 #pragma unroll
         for (int term = 0; term < 3; ++term) smu[(bw ? I::B2 : I::F1) + ((e * 3 + term) * 64 + l) * 4 + dw] = t3[term];
     }
@@ -339,8 +340,8 @@ __device__ void fill_images(float* __restrict__ sm, const DecArgs& a) {
     for (int it = 0; it < (16 * UT + THREADS - 1) / THREADS; ++it) {
         const int i = tid + it * THREADS;
         if (i < 16 * UT) {
-            sm[I::BIAS0 + i] = bias0[it];
-            sm[I::BIAS1 + i] = bias1[it];
+            sm[I::BIAS0 + i] = TANH_PRESCALE * bias0[it];
+            sm[I::BIAS1 + i] = TANH_PRESCALE * bias1[it];
         }
     }
     if (tid < 16) sm[I::BIASO + tid] = bo;
