@@ -165,7 +165,14 @@ def compute_log_z_given_y(eta1_phi1, eta2_phi1, eta1_phi2, eta2_phi2, pi_phi2, n
     return lz, (None, None)
 
 
-def e_step(phi_enc, phi_gmm, nb_samples, seed=0, name="e_step", noise=None, theta=None):
+def recognition_prep(phi_gmm, theta=None):
+    """unpack_recognition_gmm + the k-only part of compute_log_z_given_y in one launch (autograd: one more); a natural
+    GMM theta is packed by the same launch (reference svae.py:342-358, 70-92)"""
+    gmm_theta = theta is not None and len(theta) == 5
+    return _svae_ops.PhiPrepFn.apply(*phi_gmm, *([t.detach() for t in theta] if gmm_theta else []))
+
+
+def e_step(phi_enc, phi_gmm, nb_samples, seed=0, name="e_step", noise=None, theta=None, prep=None):
     """reference svae.py:14-47.  Returns (x_k_samples (N,K,S,L), log_z (N,K), phi_tilde, dbg).
     `noise` (N,K,L,S) replaces tf.random_normal (default: torch.randn with `seed`); noise='philox' draws eps INSIDE the
     kernel (Philox4x32-7 keyed by `seed`, as the reference's tf.random_normal does inside its step, svae.py:113-114):
@@ -173,10 +180,10 @@ def e_step(phi_enc, phi_gmm, nb_samples, seed=0, name="e_step", noise=None, thet
     densities compute_elbo needs are evaluated in the same pass."""
     eta1_phi1, eta2_diag = phi_enc
     N, Ld = eta1_phi1.shape
-    # unpack_recognition_gmm + the k-only part of compute_log_z_given_y in one launch (autograd: one more); a natural
-    # GMM theta is packed by the same launch
+    # (`prep`: recognition_prep(phi_gmm, theta) already launched by the caller - a graph-captured step runs it beside the encoder)
     gmm_theta = theta is not None and len(theta) == 5
-    prep = _svae_ops.PhiPrepFn.apply(*phi_gmm, *([t.detach() for t in theta] if gmm_theta else []))
+    if prep is None:
+        prep = recognition_prep(phi_gmm, theta)
     eta1_phi2, P, bias = prep[:3]
     K = eta1_phi2.shape[0]
     if isinstance(noise, str):
@@ -192,6 +199,8 @@ def e_step(phi_enc, phi_gmm, nb_samples, seed=0, name="e_step", noise=None, thet
         mk, Wk, kap, nu = prep[3], prep[4], prep[5], None
     else:
         mk, Wk, kap, nu = _theta_pack(theta) if theta is not None else _neutral_theta(K, Ld, eta1_phi1.device)
+    if _svae_ops.FORK is not None:
+        _svae_ops.FORK.join('noise', 'prep')
     x, lz, Tp = _svae_ops.SvaeEStepFn.apply(eta1_phi1, eta2_diag, eta1_phi2, P, bias, noise, mk, Wk, kap, nu)
     # without theta the (phi, noise) the E-step ran on stay attached, so that compute_elbo can evaluate the theta term
     # afterwards; with theta (the training path) nothing extra is kept alive
@@ -432,11 +441,11 @@ def init_recognition_params(theta, nb_components, seed=0, param_device='cuda', v
 
 
 def inference(y, phi_gmm, encoder_layers, decoder_layers, nb_samples=10, stddev_init_nn=0.01, seed=0, name='inference',
-              param_device='cuda', noise=None, z_draws=None, theta=None, lazy_decoder=False, u=None):
+              param_device='cuda', noise=None, z_draws=None, theta=None, lazy_decoder=False, u=None, prep=None):
     """reference svae.py:499-516.  Returns (y_reconstruction, x_given_y_phi, x_k_samples, x_samples, log_z, phi_gmm,
     phi_tilde).  lazy_decoder=True: y_reconstruction is a vae.LazyReconstruction (fused decoder kernels)."""
     x_given_y_phi = vae.make_encoder(y, layerspecs=encoder_layers, stddev_init=stddev_init_nn, seed=seed)
-    x_k_samples, log_z, phi_tilde, _ = e_step(x_given_y_phi, phi_gmm, nb_samples, seed=seed, noise=noise, theta=theta)
+    x_k_samples, log_z, phi_tilde, _ = e_step(x_given_y_phi, phi_gmm, nb_samples, seed=seed, noise=noise, theta=theta, prep=prep)
     y_rec = vae.make_decoder(x_k_samples, layerspecs=decoder_layers, stddev_init=stddev_init_nn, seed=seed,
                              lazy=lazy_decoder)
     if u is None and z_draws is None and (isinstance(noise, str) or isinstance(noise, _svae_ops.PhiloxNoise)):
