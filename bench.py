@@ -526,7 +526,7 @@ def dec_bwd_side_measurement(N, K, S, Ld, U, dev):
     """The dominant kernel of the T3 step (fused decoder backward: value + all gradients of the reconstruction term from
     one launch) timed on its own stream position with HIP events on a bounded row count, for the t3 roofline."""
     from vmp_for_svae_amd.models import vae, _svae_ops
-    n = min(N, 262144)
+    n = min(N, 1 << 20)                               # C3's N = 1e6 is timed whole (round 5; 262 144 rows scaled up over-stated it by 8 %)
     g = torch.Generator(device=dev).manual_seed(3)
     x = torch.randn(n, K, S, Ld, device=dev, generator=g).requires_grad_(True)
     y = torch.randn(n, Ld, device=dev, generator=g)
@@ -799,7 +799,7 @@ def main():
                     'kernel': 'dec_bwd_kernel (bf16 split operands on the XDL pipe: %d v_mfma_f32_16x16x32_bf16 per 16-row tile)' % mf,
                     'kernel_ms': k_ms, 'useful_fp32_TFLOPs': tf_s, 'useful_frac_of_fp32_vector_peak': tf_s * 1e12 / FP32_PEAK_FLOPS,
                     'issued_over_useful': issued / useful,
-                    'note': 'timed on min(N, 262144) rows and scaled to N (the kernel is linear in rows); achieved = ISSUED bf16 MFMA '
+                    'note': 'timed on min(N, 2^20) data rows (scaled to N beyond that; the kernel is linear in rows); achieved = ISSUED bf16 MFMA '
                             'flops (operand splits, 50 -> 64 unit padding and k-slot padding included), useful = fp32-equivalent flops'}
             metric, wl = 'svae_train_step_datapoints_per_sec', 'T3 %ssvae training step (experiments.py:196-267), L=Dy=%d, K=%d, S=%d, U=%d' % ('Student-t (smm) ' if args.smm else '', D, K, S, U)
             extra['t3'] = res
