@@ -175,7 +175,7 @@ def bench_t2(N, Ld, K, S, steps, warmup, dev, dist=None, world=1, smm=False, cpu
     measurement (`noise_tensor`): the same step with a noise TENSOR, its per-step normal_() INSIDE the timed step; 4N(4KSL + 2K + 4L).
     smm=True: Student-t theta (svae.py:265-322; theta/mu_k, theta/L_k trainable, M-step = N_k only, experiments.py:154-176)."""
     import vmp_for_svae_amd as V
-    from vmp_for_svae_amd.models import svae, _mix
+    from vmp_for_svae_amd.models import svae, _mix, _svae_ops
     g = torch.Generator(device=dev).manual_seed(1234)
     eta1 = torch.randn(N, Ld, device=dev, generator=g).requires_grad_(True)
     eta2d = (-0.5 * torch.nn.functional.softplus(torch.randn(N, Ld, device=dev, generator=g))).requires_grad_(True)
@@ -212,16 +212,22 @@ def bench_t2(N, Ld, K, S, steps, warmup, dev, dist=None, world=1, smm=False, cpu
                 x, lz, pt, _ = svae.e_step((eta1, eta2d), phi, S, seed=1000 + i, noise='philox', theta=theta)
             if timed:
                 ev[2][i].record()
-            r = torch.exp(lz.detach())
+            # what the forward kernel's epilogue left (in-kernel noise): r = exp(log_z), the sub-sample, moment partials (K = 16)
+            r = pt.r_nk if pt.r_nk is not None else torch.exp(lz.detach())
             if timed:
                 ev[3][i].record()
             grads = torch.autograd.grad([x, lz, pt.T_prime], [eta1, eta2d] + phi + th_params, [Gx, Glz, r])
             if timed:
                 ev[4][i].record()
-            xs = svae.subsample_x(x, lz, seed=i, nb_out=1)[:, 0, :].contiguous()
+            xs = pt.x_samples if pt.x_samples is not None else svae.subsample_x(x, lz, seed=1000 + i, nb_out=1, u='philox' if mode != 'tensor' else None)[:, 0, :].contiguous()
+            mom = None if (smm or dist is not None) else pt.mom
             if smm:                                               # svae.m_step_smm: N_k only (svae.py:179-196)
                 from vmp_for_svae_amd.models import gmm as _gmm
                 st = _gmm.update_Nk(r.contiguous()).double().reshape(-1, 1)
+            elif mom is not None:
+                st = None                                         # partials -> moments -> CVI in ONE launch below, as SVAETrainer.step does
+            elif pt.mom is not None:
+                st = _svae_ops.mom_cvi(pt.mom)[0]
             else:
                 st = _mix.raw_stats(xs, r, pivot=False)           # as SVAETrainer.step: the natural-parameter M-step uses the raw moments
             if dist is not None:
@@ -231,6 +237,8 @@ def bench_t2(N, Ld, K, S, steps, warmup, dev, dist=None, world=1, smm=False, cpu
                 st = buf[:st.numel()].reshape(st.shape)
             if smm:
                 svae.update_gmm_params(theta[:1], [prior + st[:, 0].float()], 0.2)
+            elif mom is not None:
+                _svae_ops.mom_cvi(mom, prior, theta, 0.2, want_star=False, want_stats=False)
             else:                                                 # svae.m_step + update_gmm_params in one launch, as SVAETrainer.step does
                 svae.cvi_update_from_stats(prior, theta, st.double(), 0.2, want_star=False)
 

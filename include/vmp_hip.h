@@ -169,9 +169,9 @@ int    vmp_svae_estep_fwd(const float* eta1, const float* eta2d, const float* hk
                           int64_t N, int K, int L, int S, float* x, float* lz, float* Tp, void* stream);
 /* In-kernel noise (models/svae.py:113-114 draws eps inside the step: tf.random_normal, i.e. TensorFlow's Philox stream).
  * Same operation with eps generated where it is consumed: Philox4x32-7 (Random123's philox4x32 at 7 rounds) keyed by `seed`,
- * counter = (cell low, cell high, block, 0), cell = n K + k, block b = (s >> 1) ceil(L/3) + j -> three Box-Muller pairs from
- * 21-bit uniforms: (eps[i,s], eps[i,s+1]) for i = 3j, 3j+1, 3j+2 of the cell's (L,S) noise block (bit layout: csrc/vmp_svae.hip,
- * oracle/philox.py).  No (N,K,L,S) tensor is read or written; the backward pass needs
+ * counter = (cell low, cell high, block, 0), cell = n K + k, block b = (s >> 1) ceil(L/4) + j -> four Box-Muller pairs, one per
+ * 32-bit word (radius uniform from the word's top 20 bits, angle from its low 12): (eps[i,s], eps[i,s+1]) for i = 4j .. 4j+3 of
+ * the cell's (L,S) noise block (csrc/vmp_svae.hip, oracle/philox.py).  No (N,K,L,S) tensor is read or written; the backward pass needs
  * none (it works from the saved samples x).  Shapes outside the in-kernel path (vmp_svae_rng_in_kernel == 0: L < 8 and L*S
  * not a multiple of 4 or a cell tile larger than the LDS; L = 8 is covered for every S) materialise the same stream in `noise_ws` (N,K,L,S) first.
  * vmp_svae_philox_noise writes that stream as a tensor (tests; callers that want to keep the draw).               */
@@ -187,6 +187,27 @@ int    vmp_svae_estep_fwd_rng_dev(const float* eta1, const float* eta2d, const f
                                   const uint64_t* seed_dev, const float* mk, const float* Wk, const float* kappa,
                                   const float* nu, int64_t N, int K, int L, int S, float* x, float* lz, float* Tp,
                                   void* stream);
+/* The in-kernel-noise E-step with the step's next three operations done in its epilogue, while a cell's values are in
+ * registers (in-kernel shapes only; key = `seed`, or *seed_dev when seed_dev != NULL):
+ *   x_samples (N,L) = subsample_x(x, lz) with ONE draw per row (models/svae.py:122-151 as its caller uses it, svae.py:514:
+ *                     z_n ~ Cat(exp lz_n), x_samples[n] = x[n, z_n, 0, :]) - bit-identical to vmp_svae_subsample_rng with the same
+ *                     key and S_out = 1 (same uniforms, same inverse-CDF arithmetic);
+ *   r (N,K)         = exp(lz) (svae.py:216; may be NULL);
+ *   mom             = per-block fp64 partials of the M-step's raw moments sum_n r_nk [x_n | 1 | x_n x_n^T lower-packed | 0 0 0]
+ *                     with x_n = x_samples[n] (svae.m_step -> gmm.update_Nk/xk/Sk, svae.py:154-176, gmm.py:25-46), laid out
+ *                     (vmp_svae_fwd_mom_blocks(N,K,L,S), 16, 48); NULL = not wanted.  Exists for K = 16, L = 8
+ *                     (vmp_svae_fwd_mom_blocks returns 0 otherwise: use vmp_mix_stats on x_samples and r).
+ * vmp_svae_mom_cvi adds the partials in a fixed order into stats_out (K, 2+L+L*L) fp64 (vmp_mix_stats layout; may be NULL when
+ * theta is given) and, when t_alpha != NULL, applies vmp_svae_cvi_update from them in the same launch.                    */
+int    vmp_svae_fwd_mom_blocks(int64_t N, int K, int L, int S);
+int    vmp_svae_estep_fwd_rng_epi(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
+                                  uint64_t seed, const uint64_t* seed_dev, const float* mk, const float* Wk, const float* kappa,
+                                  const float* nu, int64_t N, int K, int L, int S, float* x, float* lz, float* Tp,
+                                  float* x_samples, float* r, double* mom, size_t mom_bytes, void* stream);
+int    vmp_svae_mom_cvi(const double* mom, int nblk, const float* p_alpha, const float* p_A, const float* p_b,
+                        const float* p_beta, const float* p_vhat, float* t_alpha, float* t_A, float* t_b, float* t_beta,
+                        float* t_vhat, float* s_alpha, float* s_A, float* s_b, float* s_beta, float* s_vhat,
+                        const float* rho_dev, float rho, int K, int L, double* stats_out, void* stream);
 
 /* Backward of the above: given dLoss/dx (N,K,S,L) (from the decoder), dLoss/dlog_z (N,K), dLoss/dT' (N,K), writes
  * dLoss/deta1, dLoss/deta2d (N,L) and per-block partial sums over n of dLoss/d{hk, Pk, bias}:

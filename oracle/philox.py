@@ -1,7 +1,8 @@
 """Oracle: Philox4x32-R (Salmon, Moraes, Dror, Shaw - "Parallel random numbers: as easy as 1, 2, 3", SC'11; the
 counter-based generator behind tf.random_normal / cuRAND / torch on GPUs, which use R = 10) and the Box-Muller map, in numpy.
 The product's in-kernel stream uses R = 7 (Random123's philox4x32_7, the smallest round count its authors report as
-Crush-resistant) and takes three Box-Muller pairs of 21-bit uniforms from every 128-bit block.
+Crush-resistant) and takes FOUR Box-Muller pairs from every 128-bit block - one per 32-bit word: the top 20 bits are the radius
+uniform, the low 12 bits the angle (round 5: three pairs of 21 + 21 bits).
 
 TEST INFRASTRUCTURE (see oracle/__init__.py).  The reference draws its noise inside the step with TF's own Philox
 stream (models/svae.py:113-114); TF 1.3's exact counter layout is a TensorFlow internal that is absent from the reference
@@ -39,21 +40,15 @@ def philox4x32_10(ctr, key):
     return philox4x32(ctr, key, 10)
 
 
-def box_muller6(u):
-    """(..., 4) uint32 -> (..., 3, 2) float64: three Box-Muller pairs r (cos, sin) from 21-bit uniforms.
-    pair 0 = (c0[0..20], c1[11..31]); pair 1 = (c2[0..20], c3[11..31]); pair 2 = (c0[21..31] | c1[0..9] << 11, c2[21..31] | c3[0..9] << 11)."""
+def box_muller8(u):
+    """(..., 4) uint32 -> (..., 4, 2) float64: one Box-Muller pair r (cos, sin) per 32-bit word;
+    radius uniform (a + 1/2) 2^-20 from the word's top 20 bits, angle b 2^-12 revolutions from its low 12 bits."""
     u = np.asarray(u, dtype=np.uint32)
-    m21, s11, s21 = np.uint32(0x1FFFFF), np.uint32(11), np.uint32(21)
-    c0, c1, c2, c3 = (u[..., i] for i in range(4))
-    rad = [c0 & m21, c2 & m21, ((c0 >> s21) | (c1 << s11)) & m21]
-    ang = [c1 >> s11, c3 >> s11, ((c2 >> s21) | (c3 << s11)) & m21]
-    out = []
-    for a, b in zip(rad, ang):
-        u1 = (a.astype(np.float64) + 0.5) * 2.0 ** -21
-        th = b.astype(np.float64) * 2.0 ** -21
-        r = np.sqrt(-2.0 * np.log(u1))
-        out.append(np.stack([r * np.cos(2 * np.pi * th), r * np.sin(2 * np.pi * th)], axis=-1))
-    return np.stack(out, axis=-2)
+    a = (u >> np.uint32(12)).astype(np.float64)
+    b = (u & np.uint32(0xFFF)).astype(np.float64)
+    r = np.sqrt(-2.0 * np.log((a + 0.5) * 2.0 ** -20))
+    th = 2 * np.pi * b * 2.0 ** -12
+    return np.stack([r * np.cos(th), r * np.sin(th)], axis=-1)
 
 
 def box_muller4(u):
@@ -71,10 +66,10 @@ def box_muller4(u):
 
 def cell_noise(seed, cells, L, S):
     """The (len(cells), L, S) noise blocks of the given cell ids (n*K + k) under `seed`.
-    Block b = (s >> 1) * ceil(L/3) + j of a cell holds the pairs (eps[i, s], eps[i, s+1]) of coordinates i = 3j, 3j+1, 3j+2."""
+    Block b = (s >> 1) * ceil(L/4) + j of a cell holds the pairs (eps[i, s], eps[i, s+1]) of coordinates i = 4j .. 4j+3."""
     cells = np.asarray(cells, dtype=np.uint64)
-    SP, L3 = (S + 1) // 2, (L + 2) // 3
-    blk = np.arange(SP * L3, dtype=np.uint32)
+    SP, L4 = (S + 1) // 2, (L + 3) // 4
+    blk = np.arange(SP * L4, dtype=np.uint32)
     ctr = np.zeros((cells.size, blk.size, 4), dtype=np.uint32)
     ctr[..., 0] = (cells & np.uint64(0xFFFFFFFF)).astype(np.uint32)[:, None]
     ctr[..., 1] = (cells >> np.uint64(32)).astype(np.uint32)[:, None]
@@ -82,16 +77,16 @@ def cell_noise(seed, cells, L, S):
     key = np.zeros((cells.size, blk.size, 2), dtype=np.uint32)
     key[..., 0] = np.uint32(seed & 0xFFFFFFFF)
     key[..., 1] = np.uint32((seed >> 32) & 0xFFFFFFFF)
-    z = box_muller6(philox4x32(ctr, key))                    # (cells, blocks, 3, 2)
+    z = box_muller8(philox4x32(ctr, key))                    # (cells, blocks, 4, 2)
     out = np.zeros((cells.size, L, S))
     for sp in range(SP):
-        for j in range(L3):
-            for t in range(3):
-                i = 3 * j + t
+        for j in range(L4):
+            for t in range(4):
+                i = 4 * j + t
                 if i < L:
-                    out[:, i, 2 * sp] = z[:, sp * L3 + j, t, 0]
+                    out[:, i, 2 * sp] = z[:, sp * L4 + j, t, 0]
                     if 2 * sp + 1 < S:
-                        out[:, i, 2 * sp + 1] = z[:, sp * L3 + j, t, 1]
+                        out[:, i, 2 * sp + 1] = z[:, sp * L4 + j, t, 1]
     return out
 
 

@@ -229,16 +229,27 @@ def test_t2_step_at_full_size_vs_chunked_oracle(N, K, smm):
         th_params = [mu_t, L_t]
     seed = 424242
     x, lz, pt, _ = svae.e_step((eta1, eta2d), phi, S, seed=seed, noise='philox', theta=theta)
-    r = torch.exp(lz.detach())
+    # round 6: the forward kernel's epilogue already holds r = exp(log z), the one-draw sub-sample and (K = 16) the moment partials
+    assert pt.x_samples is not None and pt.r_nk is not None and (pt.mom is not None) == (K == 16)
+    r = pt.r_nk
+    assert (r - torch.exp(lz.detach())).abs().max().item() <= 2e-7
     # loss = -elbo_reg + <x, Gx> + <log z, Glz>,  elbo_reg = -sum_nk r (T' + log z):  d/dT' = r, d/dlog z = r (T' + log z + 1) + Glz
     grads = torch.autograd.grad([x, lz, pt.T_prime], [eta1, eta2d] + phi + th_params, [Gx, Glz + r * (pt.T_prime.detach() + lz.detach() + 1.0), r])
-    xs = svae.subsample_x(x, lz, z_draws=zd[:, :1], nb_out=1)[:, 0, :].contiguous()
+    # the draw: the stand-alone kernel with the same key picks the same component and the same row, bit for bit; the ORACLE's
+    # inverse CDF of the same uniforms (its own fp64 log z) agrees on all but the rows whose u sits within rounding of a CDF step
+    xs_sa, z_gpu = svae.subsample_x(x, lz, seed=seed, nb_out=1, u='philox', return_z=True)
+    xs = pt.x_samples
+    assert torch.equal(xs, xs_sa[:, 0, :])
+    zd[:, 0] = z_gpu[:, 0]
     if smm:
         from vmp_for_svae_amd.models import gmm as _gmm
         th_new = [(0.8 * theta[0] + 0.2 * (prior[0] + _gmm.update_Nk(r.contiguous())))]
     else:
         th_new = [t.clone() for t in theta]
-        svae.cvi_update_from_stats(prior, th_new, _mix.raw_stats(xs, r).double(), 0.2, want_star=False)
+        if pt.mom is not None:                               # partials -> raw moments -> CVI update in one launch
+            _svae_ops.mom_cvi(pt.mom, prior, th_new, 0.2, want_star=False, want_stats=False)
+        else:
+            svae.cvi_update_from_stats(prior, th_new, _mix.raw_stats(xs, r, pivot=False).double(), 0.2, want_star=False)
     reg = (r * (pt.T_prime.detach() + lz.detach())).double().sum()
     noise = _svae_ops.PhiloxNoise(seed, S).materialise(N, K, Ld, dev).cpu().double()
     torch.cuda.synchronize()
@@ -259,8 +270,15 @@ def test_t2_step_at_full_size_vs_chunked_oracle(N, K, smm):
     finally:
         torch.set_num_threads(nt)
     del noise
-    e = _abs(torch.exp(lz), torch.exp(ref['log_z']), 1e-5, 't2 r_nk N=%d' % N)
+    e = _abs(r, torch.exp(ref['log_z']), 1e-5, 't2 r_nk N=%d' % N)
     assert e <= 1e-5, e
+    from oracle import philox
+    u_o = torch.as_tensor(philox.subsample_uniforms(seed, N, 1)[:, 0]).double()
+    cdf = torch.cumsum(torch.exp(ref['log_z']), dim=1)
+    z_o = (cdf[:, :K - 1] <= u_o[:, None]).sum(1)
+    nmis = int((z_o != z_gpu[:, 0].cpu()).sum())
+    parity_log.record('abs', nmis / N, 1e-5, 't2 draws that differ from the oracle inverse CDF (fraction)')
+    assert nmis <= max(2, N // 100000), nmis
     assert _rel(xs, ref['x_samples'], 1e-5, 't2 x_samples') <= 1e-5
     e = abs(reg.item() - ref['reg'].item()) / abs(ref['reg'].item())
     parity_log.record('rel', e, 1e-5, 't2 regulariser')

@@ -39,20 +39,31 @@ def test_oracle_philox_known_answers():
 
 
 def test_oracle_block_layout_uses_disjoint_bits():
-    """every one of the six 21-bit integers of a block is an independent function of the block's 128 bits"""
+    """every one of the four Box-Muller pairs of a block is a function of its own 32-bit word alone, and every bit is used"""
     rng = np.random.Generator(np.random.PCG64(5))
     base = rng.integers(0, 2 ** 32, size=(1, 4), dtype=np.uint64).astype(np.uint32)
-    ref = philox.box_muller6(base)[0]
+    ref = philox.box_muller8(base)[0]
     owners = np.zeros((4, 32), dtype=int) - 1
     for w in range(4):
         for bit in range(32):
             v = base.copy()
             v[0, w] ^= np.uint32(1 << bit)
-            ch = np.argwhere(np.abs(philox.box_muller6(v)[0] - ref).max(axis=-1) > 0).ravel()
-            assert len(ch) <= 1                              # a bit feeds at most one pair
-            owners[w, bit] = ch[0] if len(ch) else -1
-    assert (owners >= 0).sum() == 126 and owners[1, 10] == -1 and owners[3, 10] == -1
-    assert all((owners == t).sum() == 42 for t in range(3))
+            ch = np.argwhere(np.abs(philox.box_muller8(v)[0] - ref).max(axis=-1) > 0).ravel()
+            assert len(ch) == 1                              # a bit feeds exactly one pair
+            owners[w, bit] = ch[0]
+    assert all((owners[t] == t).all() for t in range(4))     # all 128 bits in use, word t -> pair t
+
+
+def test_oracle_angle_grid_integrates_the_marginal_exactly():
+    """4096 directions: the marginal of r cos(theta) over the angle grid is a periodic trapezoid rule - P(eps <= t) by exact
+    summation over the grid (radius continuous) equals the normal CDF far below what any sample test can see"""
+    from scipy import stats
+    th = 2 * np.pi * np.arange(4096) / 4096.0
+    for t in (0.1, 0.7, 1.9, 3.2):
+        c = np.cos(th)
+        # P(r cos(theta) <= t) with r^2 ~ chi2_2:  c <= 0: always when t >= 0;  c > 0: r <= t / c  (c = 6e-17 at the two poles: certain)
+        p = np.where(c > 1e-9, 1.0 - np.exp(-0.5 * (t / np.maximum(c, 1e-9)) ** 2), 1.0).mean()
+        assert abs(p - stats.norm.cdf(t)) < 1e-12
 
 
 def test_oracle_box_muller_is_standard_normal():
@@ -97,6 +108,53 @@ def test_in_kernel_noise_equals_materialised_stream(N, K, Ld, S):
     for a, b in zip(*outs):
         scale = b.abs().max().clamp_min(1e-30)
         assert ((a - b).abs().max() / scale).item() < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,K,Ld,S', [(1000, 16, 8, 10), (5003, 16, 8, 10), (3, 16, 8, 10), (200_000, 16, 8, 10),   # two-pair staging form + moments
+                                      (37, 16, 8, 5), (9, 16, 8, 100), (301, 16, 8, 4),                           # one-pair staging form + moments
+                                      (130, 9, 8, 10), (77, 10, 6, 10), (50, 5, 2, 10), (2000, 10, 8, 10)])        # no in-kernel moments
+def test_estep_epilogue_equals_the_standalone_kernels(N, K, Ld, S):
+    """Round 6: the in-kernel-noise E-step also does what the step does next - subsample_x with one draw per row
+    (svae.py:122-151, 514), r = exp(log z) (svae.py:216) and, for K = 16 / L = 8, the M-step's raw moments (svae.py:154-176) as
+    per-block partials.  Against the stand-alone kernels on the same inputs: the sub-sample bit for bit (same uniforms, same
+    inverse-CDF arithmetic), the primary outputs bit for bit those of the launch without epilogue, the moments against an fp64
+    evaluation of sum_n r_nk [1 | x | x x^T], and the one-launch reduce + CVI against vmp_svae_cvi_update on those moments."""
+    from vmp_for_svae_amd.models import svae, _svae_ops, _mix
+    dev = 'cuda'
+    g = torch.Generator(device=dev).manual_seed(11)
+    eta1 = torch.randn(N, Ld, device=dev, generator=g)
+    eta2d = -0.5 * torch.nn.functional.softplus(torch.randn(N, Ld, device=dev, generator=g))
+    prior, theta = svae.init_mm(K, Ld, seed=0, param_device=dev)
+    phi = list(svae.init_recognition_params(theta, K, seed=0, param_device=dev))
+    seed = 0xABCDEF0123
+    with torch.no_grad():
+        x, lz, pt, _ = svae.e_step((eta1, eta2d), phi, S, seed=seed, noise='philox', theta=theta)
+        x0, lz0, pt0, _ = svae.e_step((eta1, eta2d), phi, S, noise=_svae_ops.PhiloxNoise(seed, S), theta=theta)    # no epilogue
+    assert pt0.x_samples is None and pt.x_samples is not None and pt.r_nk is not None
+    assert torch.equal(x, x0) and torch.equal(lz, lz0) and torch.equal(pt.T_prime, pt0.T_prime)
+    xs_sa, z = svae.subsample_x(x, lz, seed=seed, nb_out=1, u='philox', return_z=True)
+    assert torch.equal(pt.x_samples, xs_sa[:, 0, :])
+    assert torch.equal(pt.x_samples, x[torch.arange(N, device=dev), z[:, 0], 0, :])
+    assert (pt.r_nk - torch.exp(lz)).abs().max().item() <= 2e-7
+    assert (pt.mom is not None) == (K == 16 and Ld == 8)
+    if pt.mom is None:
+        return
+    stats, _ = _svae_ops.mom_cvi(pt.mom)
+    xd, rd = pt.x_samples.double(), pt.r_nk.double()
+    want = torch.cat([rd.sum(0)[:, None], rd.sum(0)[:, None], rd.t() @ xd,
+                      torch.einsum('nk,ni,nj->kij', rd, xd, xd).reshape(K, Ld * Ld)], dim=1)
+    scale = torch.cat([want[:, :2].abs(), (rd.t() @ xd.abs()), torch.einsum('nk,ni,nj->kij', rd, xd.abs(), xd.abs()).reshape(K, Ld * Ld)], dim=1)
+    err = ((stats - want).abs() / scale.clamp_min(1e-30)).max().item()
+    assert err < 2e-6, err                                   # fp32 products and per-wave sums of a few hundred rows, fp64 beyond
+    lib_stats = _mix.raw_stats(pt.x_samples, pt.r_nk, pivot=False)
+    assert ((lib_stats - want).abs() / scale.clamp_min(1e-30)).max().item() < 2e-6
+    th_a, th_b = [t.clone() for t in theta], [t.clone() for t in theta]
+    st_a, star_a = _svae_ops.mom_cvi(pt.mom, prior, th_a, 0.2)
+    star_b = svae.cvi_update_from_stats(prior, th_b, stats, 0.2)
+    assert torch.equal(st_a, stats)
+    for a_, b_ in zip(th_a + star_a, th_b + star_b):
+        assert torch.equal(a_, b_)
 
 
 @pytest.mark.gpu

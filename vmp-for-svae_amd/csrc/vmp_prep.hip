@@ -299,6 +299,48 @@ __global__ __launch_bounds__(SMALL_STATS_GROUPS * 80) void stats_cvi_kernel(Smal
     for (int f = threadIdx.x; f < L * L + L + 3; f += blockDim.x) cvi_element(a, st, k, f, rho);
 }
 
+// M-step moments from the fused E-step forward kernel's per-block partials AND the CVI update in one launch (round 6): the forward
+// kernel (csrc/vmp_svae.hip, epilogue) leaves (nblk, 16, 48) fp64 partial sums of r_nk [x | 1 | x x^T lower-packed | 0 0 0] over its
+// blocks' rows; block k adds component k's partials in a fixed order (MOM_GROUPS interleaved chains, then the chains in order),
+// expands them to the raw-moment row [N_k | W_k = N_k | sum r x | sum r x x^T] (svae.m_step -> gmm.update_Nk/xk/Sk,
+// svae.py:154-176, gmm.py:25-46, in the natural-parameter form of SURVEY appendix A.6) and - when theta is given - updates
+// component k of theta from the copy in LDS (svae.update_gmm_params, svae.py:376-403).
+constexpr int MOM_F = 48, MOM_GROUPS = 8, MOM_L = 8;
+struct MomArgs { const double* mom; double* stats; int nblk, K; };
+__global__ __launch_bounds__(64 * MOM_GROUPS) void mom_cvi_kernel(MomArgs m, CviArgs a, int do_cvi) {
+    __shared__ double part[MOM_GROUPS][64];
+    __shared__ double st[2 + MOM_L + MOM_L * MOM_L];
+    constexpr int L = MOM_L, SW = 2 + L + L * L;
+    const int k = blockIdx.x, f = threadIdx.x & 63, bg = threadIdx.x >> 6;
+    double s = 0.0;
+    if (f < MOM_F)
+        for (int b = bg; b < m.nblk; b += MOM_GROUPS) s += m.mom[((size_t)b * m.K + k) * MOM_F + f];
+    part[bg][f] = s;
+    __syncthreads();
+    if (bg == 0) {
+        for (int g2 = 1; g2 < MOM_GROUPS; ++g2) s += part[g2][f];
+        part[0][f] = s;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < SW; e += blockDim.x) {
+        double v;
+        if (e < 2) v = part[0][L];                          // N_k; W_k = N_k (no per-row scale in the SVAE M-step)
+        else if (e < 2 + L) v = part[0][e - 2];
+        else {
+            const int i = (e - 2 - L) / L, j = (e - 2 - L) - i * L;
+            const int hi = i > j ? i : j, lo = i > j ? j : i;
+            v = part[0][L + 1 + hi * (hi + 1) / 2 + lo];
+        }
+        st[e] = v;
+        if (m.stats) m.stats[(size_t)k * SW + e] = v;
+    }
+    __syncthreads();
+    if (do_cvi) {
+        const float rho = a.rho_dev ? *a.rho_dev : a.rho;
+        for (int e = threadIdx.x; e < L * L + L + 3; e += blockDim.x) cvi_element(a, st, k, e, rho);
+    }
+}
+
 // Reduction of the fused E-step backward kernel's per-block partial sums (vmp_svae_estep_bwd: (nblk, K, PW) with
 // PW = 2 (L + TRI + 1): [g_hk | g_Pk lower | g_bias | g_mk | g_Wk lower | g_kappa]) in a fixed order in fp64, unpacked
 // into the K-sized gradient tensors: g_P symmetric (both triangles carry the packed lower value), g_W lower.
@@ -446,6 +488,24 @@ int vmp_svae_stats_cvi(const float* x_samples, const float* r, int64_t N, const 
               s_alpha, s_A, s_b, s_beta, s_vhat, rho_dev, rho, K, L};
     hipLaunchKernelGGL(stats_cvi_kernel, dim3(K), dim3(SMALL_STATS_GROUPS * 80), 0, static_cast<hipStream_t>(stream), sa, a);
     return check_launch("vmp_svae_stats_cvi");
+}
+
+int vmp_svae_mom_cvi(const double* mom, int nblk, const float* p_alpha, const float* p_A, const float* p_b, const float* p_beta,
+                     const float* p_vhat, float* t_alpha, float* t_A, float* t_b, float* t_beta, float* t_vhat,
+                     float* s_alpha, float* s_A, float* s_b, float* s_beta, float* s_vhat, const float* rho_dev, float rho, int K,
+                     int L, double* stats_out, void* stream) {
+    if (int e = prep_check("vmp_svae_mom_cvi", K, L)) return e;
+    if (K != 16 || L != MOM_L) { set_error("vmp_svae_mom_cvi: the in-kernel moments exist for K = 16, L = 8 (vmp_svae_fwd_mom_blocks)"); return VMP_E_DIM; }
+    const bool cvi = t_alpha != nullptr;
+    if (!mom || nblk < 1 || (!cvi && !stats_out) || (cvi && (!p_alpha || !p_A || !p_b || !p_beta || !p_vhat || !t_A || !t_b || !t_beta || !t_vhat))) {
+        set_error("vmp_svae_mom_cvi: bad argument");
+        return VMP_E_BADARG;
+    }
+    MomArgs m{mom, stats_out, nblk, K};
+    CviArgs a{stats_out, p_alpha, p_A, p_b, p_beta, p_vhat, t_alpha, t_A, t_b, t_beta, t_vhat,
+              s_alpha, s_A, s_b, s_beta, s_vhat, rho_dev, rho, K, L};
+    hipLaunchKernelGGL(mom_cvi_kernel, dim3(K), dim3(64 * MOM_GROUPS), 0, static_cast<hipStream_t>(stream), m, a, cvi ? 1 : 0);
+    return check_launch("vmp_svae_mom_cvi");
 }
 
 int vmp_svae_cvi_update(const double* stats, const float* p_alpha, const float* p_A, const float* p_b, const float* p_beta,

@@ -42,10 +42,22 @@ struct EFwdArgs {
     int K, S, vec_ok;
     unsigned long long seed;   // in-kernel noise (noise == NULL): Philox4x32-7 key
     const unsigned long long* seed_dev;   // non-NULL: the key is read from this device word (graph-captured steps refresh it)
+    // epilogue of the in-kernel-noise forms (all NULL: off) - what the step does next with the cell's values while they are in
+    // registers: subsample_x with nb_out = 1 (svae.py:122-151: z_n ~ Cat(exp log_z_n), x_samples[n] = x[n, z_n, 0]; the draw's
+    // uniform = the stand-alone sub-sampling kernel's, same key), r = exp(log_z) (svae.py:216), and - K = 16, L = 8, the
+    // pair-staging forms - the raw M-step moments sum_n r_nk [1 | x_n | x_n x_n^T] of gmm.update_Nk/xk/Sk on x_samples
+    // (svae.py:154-176, gmm.py:25-46) as per-block fp64 partials (K, 48)
+    float* xs;              // (N,L)
+    float* r;               // (N,K)
+    double* mom;            // (blocks, 16, 48): features [x_0..x_7 | 1 | x_a x_b (a >= b, packed lower) | 0 0 0]
 #ifdef VMP_DEBUG_TS
     long long* dbg_t;
 #endif
 };
+__device__ __forceinline__ bool al16_dev(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+constexpr unsigned SUBSAMPLE_TAG = 0x5bb5a3c1u;  // 4th counter word of the categorical draw's Philox block (keeps it apart from the normals)
+constexpr int MOMF = 48;                         // feature slots of the in-kernel moment partials (three 16-wide MFMA tiles)
+constexpr int XSEL = 12;                         // per-row LDS record of the drawn sample: [x_0..x_7 | 1 | 0 | pad pad]
 
 
 // ONE = every wave owns at most one tile (small batches: the reference's minibatches of 64-100 rows).  Nothing can then
@@ -721,16 +733,16 @@ __global__ __launch_bounds__(SV_FWD_MAX_NW * WAVE) void svae_estep_fwd3_kernel(E
 
 // ---------------------------------------------------------------------------------------------------------
 // In-kernel noise (reference models/svae.py:113-114 draws eps inside the step with TensorFlow's Philox stream).
-// Generator (round 5): Philox4x32-7 - Random123's philox4x32 at R = 7 rounds, the smallest round count its authors report as
+// Generator: Philox4x32-7 - Random123's philox4x32 at R = 7 rounds, the smallest round count its authors report as
 // Crush-resistant (Salmon et al., SC'11, table 2; R = 10 is their safety-margin default) - keyed by the seed, pinned by the
 // Random123 known-answer vectors for 7 AND 10 rounds (tests/test_philox.py).  Counter = (cell id low, cell id high, block, 0) with
-// cell = n K + k.  One 128-bit block yields THREE Box-Muller pairs from 21-bit uniforms (radius: u in (0,1) on a 2^-21 grid,
-// |eps| <= 5.4; angle: 2^21 directions) instead of two pairs from 24 of every 32 bits: block b = p ceil(L/3) + j of a cell holds,
-// for the sample pair (2p, 2p+1), coordinates i = 3j, 3j+1, 3j+2; pair t of a block = (eps[i, 2p], eps[i, 2p+1]) = r (cos, sin).
-// Bits: pair 0 = (c0[0..20], c1[11..31]), pair 1 = (c2[0..20], c3[11..31]), pair 2 = (c0[21..31] | c1[0..9] << 11,
-// c2[21..31] | c3[0..9] << 11).  Stateless: any kernel (or the host oracle, oracle/philox.py) can regenerate the same element from
-// (seed, n, k, i, s).  Cost per normal at L = 8 (round 4: 10 rounds, 4 normals per block = 5 v_mad_u64_u32 + 10 v_xor per
-// normal): 3 blocks of 7 rounds per 16 normals = 2.6 + 5.3.
+// cell = n K + k.  Round 6: one 128-bit block yields FOUR Box-Muller pairs, one per 32-bit word (round 5: three pairs of 21 + 21
+// bits): the word's top 20 bits are the radius uniform u = (a + 1/2) 2^-20 in (0,1) (|eps| <= 5.4, as before), its low 12 bits
+// the angle (4096 directions; each normal's marginal is a 4096-point periodic trapezoid rule over the angle of a smooth function
+// of the radius - exact to rounding).  Block b = p ceil(L/4) + j of a cell holds, for the sample pair (2p, 2p+1), coordinates
+// i = 4j .. 4j+3; word t of the block = (eps[4j+t, 2p], eps[4j+t, 2p+1]) = r (cos, sin): at L = 8 a sample pair is 2 blocks
+// instead of 3 with one pair unused (28 instead of 42 v_mad_u64_u32 per 16 normals, no cross-word bit extraction).  Stateless: any
+// kernel (or the host oracle, oracle/philox.py) can regenerate the same element from (seed, n, k, i, s).
 // ---------------------------------------------------------------------------------------------------------
 #ifndef VMP_PHILOX_ROUNDS
 #define VMP_PHILOX_ROUNDS 7
@@ -747,39 +759,38 @@ __device__ __forceinline__ void philox4x32(unsigned (&c)[4], unsigned k0, unsign
         c[1] = (unsigned)p1; c[3] = (unsigned)p0; c[0] = n0; c[2] = n2;
     }
 }
-// two 21-bit integers -> one Box-Muller pair
-__device__ __forceinline__ v2f box_muller21(unsigned a, unsigned b) {
-    const float u1 = fmaf((float)a, 4.76837158203125e-07f, 2.384185791015625e-07f);   // (a + 1/2) 2^-21 in (0, 1)
-    // angle in revolutions: the 21 bits become the top mantissa bits of a float in [1, 2) - v_sin / v_cos take revolutions and are
-    // periodic, so 1 + b 2^-21 is as good as b 2^-21 (one v_lshl_or instead of v_cvt + v_mul; exact either way)
-    const float ang = __uint_as_float((b << 2) | 0x3F800000u);
+// one 32-bit word -> one Box-Muller pair: radius from the top 20 bits, angle from the low 12
+__device__ __forceinline__ v2f box_muller_word(unsigned w) {
+    const float u1 = fmaf((float)(w >> 12), 9.5367431640625e-07f, 4.76837158203125e-07f);   // (a + 1/2) 2^-20 in (0, 1)
+    // angle in revolutions: the 12 bits become the top mantissa bits of a float in [1, 2) - v_sin / v_cos take revolutions and are
+    // periodic, so 1 + b 2^-12 is as good as b 2^-12 (shift + v_and_or instead of v_cvt + v_mul; exact either way)
+    const float ang = __uint_as_float(((w << 11) & 0x007FF800u) | 0x3F800000u);
     const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1), v_log_f32 = log2
     return v2f{rad * __builtin_amdgcn_cosf(ang), rad * __builtin_amdgcn_sinf(ang)};
 }
-// the three pairs of block `blk` of cell `cell`: coordinates 3j, 3j+1, 3j+2 of sample pair p (blk = p ceil(L/3) + j)
-__device__ __forceinline__ void philox_normal6(unsigned long long cell, unsigned blk, unsigned long long seed, v2f& p0, v2f& p1, v2f& p2) {
+// the four pairs of block `blk` of cell `cell`: coordinates 4j .. 4j+3 of sample pair p (blk = p ceil(L/4) + j)
+__device__ __forceinline__ void philox_normal8(unsigned long long cell, unsigned blk, unsigned long long seed, v2f (&p)[4]) {
     unsigned c[4] = {(unsigned)cell, (unsigned)(cell >> 32), blk, 0u};
     philox4x32<VMP_PHILOX_ROUNDS>(c, (unsigned)seed, (unsigned)(seed >> 32));
-    p0 = box_muller21(c[0] & 0x1FFFFFu, c[1] >> 11);
-    p1 = box_muller21(c[2] & 0x1FFFFFu, c[3] >> 11);
-    p2 = box_muller21(__builtin_amdgcn_alignbit(c[1], c[0], 21) & 0x1FFFFFu, __builtin_amdgcn_alignbit(c[3], c[2], 21) & 0x1FFFFFu);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) p[t] = box_muller_word(c[t]);
 }
 
 struct NoiseArgs { float* out; long long cells; int L, S; unsigned long long seed; const unsigned long long* seed_dev; };
 // Materialises the same stream as a (cells, L, S) tensor: for shapes the in-kernel path does not cover, and for tests.
 __global__ __launch_bounds__(256) void philox_noise_kernel(NoiseArgs a) {
-    const int SP = (a.S + 1) >> 1, L3 = (a.L + 2) / 3, NB = SP * L3;
+    const int SP = (a.S + 1) >> 1, L4 = (a.L + 3) / 4, NB = SP * L4;
     const long long total = a.cells * NB;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const long long cell = e / NB;
-        const int b = (int)(e - cell * NB), sp = b / L3, j = b - sp * L3;
-        v2f pr[3];
-        philox_normal6((unsigned long long)cell, (unsigned)b, a.seed_dev ? *a.seed_dev : a.seed, pr[0], pr[1], pr[2]);
+        const int b = (int)(e - cell * NB), sp = b / L4, j = b - sp * L4;
+        v2f pr[4];
+        philox_normal8((unsigned long long)cell, (unsigned)b, a.seed_dev ? *a.seed_dev : a.seed, pr);
         float* o = a.out + cell * a.L * a.S;
         const int s2 = 2 * sp;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int i = 3 * j + t;
+        for (int t = 0; t < 4; ++t) {
+            const int i = 4 * j + t;
             if (i < a.L) {
                 o[i * a.S + s2] = pr[t].x;
                 if (s2 + 1 < a.S) o[i * a.S + s2 + 1] = pr[t].y;
@@ -848,8 +859,14 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
     constexpr int QSc = ST ? (CS_ct >> 2) : 1, Qc = ST ? ((L * ST) >> 2) : 1;
     const int RPT = WAVE / K, CT = RPT * K;
     constexpr int PSTR = TRI | 1;
-    const int tab = (K * PSTR + 3) & ~3;
+    constexpr bool PST_ = RNG && L == 8 && PS;
+    // pair-staging forms: h_k, bias_k, kappa_k of the lane's component are used once per tile - they come from an LDS table
+    // [K][HKS] instead of living in 10 VGPRs across the sample loop (the round-6 epilogue needs those registers)
+    constexpr int HKS = 12;
+    const int tab0 = (K * PSTR + 3) & ~3;
+    const int tab = tab0 + (PST_ ? K * HKS : 0);
     float* pk_lds = smem;
+    float* hk_lds = smem + tab0;
     // two tile buffers per wave (the noise of the next tile arrives by DMA while this one is processed); with in-kernel noise
     // nothing is prefetched: ONE buffer, which lets 7 waves instead of 4 share the LDS of a CU
     constexpr int NBUF = RNG ? 1 : 2;
@@ -863,14 +880,18 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
     // (Where the tile buffer already admits eight waves - K = 10, 12: 60-cell tiles - this form measured 0-5 % SLOWER, same box;
     // the host picks it only when it adds a wave: fwd4_plan.)  Piece j of cell c lies at position
     // j ^ ((c >> 1) & 3) of the cell's 64 bytes: every 8-lane group of both the writes and the reads covers all 32 banks.
-    constexpr bool PST = RNG && L == 8 && PS;
+    constexpr bool PST = PST_;
     constexpr bool PST2 = PST && ST != 0 && (ST & 3) == 2 && VMP_FWD_PAIR_STAGE2;       // two pairs per flush (S / 2 odd), below
     // OIMG (in-kernel noise, L = 8, compile-time even S, tile-buffer form): the LDS image of the tile is written in OUTPUT order
     // [cell][s][l] - four ds_write_b128 per sample pair (the pair-staging form's pieces; conflict-free at the padded cell stride:
     // eight consecutive cells start at eight different 16-byte slots of the 128-byte bank window) - and leaves by ds_read_b128 +
     // coalesced float4 stores: 20 + 20 LDS instructions per cell instead of 40 ds_write_b64 + 80 gathered ds_read_b32.
     constexpr bool OIMG = RNG && L == 8 && ST != 0 && (ST & 1) == 0 && !PST;
-    float* buf0 = smem + tab + wave * (PST2 ? 2 * (WAVE * 16 + 16) : PST ? WAVE * 16 : NBUF * BC * CS);
+    // in-kernel moments (PST forms, K = 16): a [4 rows][XSEL] record of the tile's drawn samples per wave, in front of the buffers
+    const bool momon = RNG && PST && a.mom != nullptr;
+    const int xsel_words = momon ? nw * 4 * XSEL : 0;
+    float* xsel = smem + tab + wave * (4 * XSEL);
+    float* buf0 = smem + tab + xsel_words + wave * (PST2 ? 2 * (WAVE * 16 + 16) : PST ? WAVE * 16 : NBUF * BC * CS);
     const bool lane_on = lane < CT;
     const int r = lane / K, k = lane - r * K, rbase = lane_on ? r * K : 0;
     const bool k16 = (K == 16);
@@ -889,8 +910,12 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
     }
 #pragma unroll
     for (int i = 0; i < L; ++i) {
-        const float hv = a.hk[kc * L + i];
-        hkk[i] = lane_on ? hv : 0.f;
+        if constexpr (!PST_) {
+            const float hv = a.hk[kc * L + i];
+            hkk[i] = lane_on ? hv : 0.f;
+        } else {
+            hkk[i] = 0.f;
+        }
 #pragma unroll
         for (int j = 0; j <= i; ++j) {
             const float wv = a.Wk[(kc * L + i) * L + j];
@@ -898,10 +923,14 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
         }
     }
     if (TRI & 1) Wt2[TP - 1][1] = 0.f;
-    float biask, kappak, nuk;
+    float biask = 0.f, kappak = 0.f, nuk;
     {
-        const float bv = a.bias[kc], kv = a.kappa[kc], nv = *(student ? a.nu + kc : a.bias);
-        biask = lane_on ? bv : 0.f; kappak = lane_on ? kv : 0.f; nuk = (student && lane_on) ? nv : 1.f;
+        const float nv = *(student ? a.nu + kc : a.bias);
+        nuk = (student && lane_on) ? nv : 1.f;
+        if constexpr (!PST_) {
+            const float bv = a.bias[kc], kv = a.kappa[kc];
+            biask = lane_on ? bv : 0.f; kappak = lane_on ? kv : 0.f;
+        }
     }
     const float inv_nu = 1.0f / nuk;
     SV_USE(inv_nu + hkk[0] + Wt2[0][0] + biask); SV_TS(18);
@@ -985,8 +1014,37 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
         const int j = idx - tri(i, 0);
         pk_lds[kk * PSTR + idx] = a.Pk[(kk * L + i) * L + j];
     }
+    if constexpr (PST_) {
+        for (int e = threadIdx.x; e < K * HKS; e += blockDim.x) {
+            const int kk = e / HKS, i = e - kk * HKS;
+            hk_lds[e] = i < L ? a.hk[kk * L + i] : i == L ? a.bias[kk] : i == L + 1 ? a.kappa[kk] : 0.f;
+        }
+    }
     __syncthreads();
     SV_TS(17);
+    // ---- epilogue state (in-kernel noise only)
+    const bool epi = RNG && a.xs != nullptr;
+    const unsigned long long rowmask = (K < 64 ? (1ull << K) : 0ull) - 1ull;
+    f32x4 accm[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    unsigned fsel = 0;                                     // six 5-bit record offsets: features 16 g + (lane & 15), g = 0..2, as products rec[ia] * rec[ib]
+    if (momon) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int f = 16 * g + (lane & 15);
+            int ia = 9, ib = 9;                            // slot 9 = 0: the three unused feature slots
+            if (f < 8) { ia = f; ib = 8; }                 // x_f * 1
+            else if (f == 8) { ia = 8; ib = 8; }           // 1
+            else if (f < 9 + 36) {
+                const int tq = f - 9;
+                int i2 = 0;
+                while (tri(i2 + 1, 0) <= tq) ++i2;
+                ia = i2; ib = tq - tri(i2, 0);
+            }
+            fsel |= (unsigned)(ia | (ib << 5)) << (10 * g);
+        }
+        if (lane < 4 * XSEL) { const int sl = lane % XSEL; xsel[lane] = (sl == 8) ? 1.f : 0.f; }
+        __builtin_amdgcn_wave_barrier();
+    }
 #ifdef VMP_DEBUG_TS
     int fw_it = -1;
 #define FW_TS(i) do { if (a.dbg_t && blockIdx.x == 0 && wave == 0 && fw_it == 8 && lane == 0) a.dbg_t[64 + (i)] = clock64(); } while (0)
@@ -1023,8 +1081,10 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
             const float e1 = on ? e1r[i] : 0.f;
             const float e2 = on ? e2r[i] : -0.5f;
             Lm[tri(i, i)] = fmaf(-2.f, e2, Lm[tri(i, i)]);
-            av[i] = e1 + hkk[i];
+            if constexpr (PST_) { const float hv = hk_lds[kc * HKS + i]; av[i] = e1 + (lane_on ? hv : 0.f); }
+            else av[i] = e1 + hkk[i];
         }
+        if constexpr (PST_) { const float bv = hk_lds[kc * HKS + L]; biask = lane_on ? bv : 0.f; }
         float ld;
         cell_cholesky<L>(Lm, ld);
         solve_lower<L>(Lm, av);
@@ -1048,6 +1108,29 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
         }
         const float lz = c - mx - __logf(se);
         SV_USE(lz); SV_TS(19); FW_TS(1);
+        // ---- epilogue, part 1: the categorical draw of subsample_x (nb_out = 1) and r = exp(log_z).  Same arithmetic as
+        // subsample_kernel (inclusive prefix sum of __expf(log_z) over the row's lanes, u from Philox block (n, 0, TAG)): the
+        // two paths pick the same component for every row.
+        bool sel = false;
+        float rv = 0.f;
+        if constexpr (RNG) {
+            if (epi) {
+                const unsigned long long rw = on ? (unsigned long long)row : 0ull;
+                unsigned c4[4] = {(unsigned)rw, (unsigned)(rw >> 32), 0u, SUBSAMPLE_TAG};
+                philox4x32<VMP_PHILOX_ROUNDS>(c4, (unsigned)rng_seed, (unsigned)(rng_seed >> 32));
+                const float uu = (float)(c4[0] >> 8) * 5.9604644775390625e-08f;      // [0, 1)
+                float cum = on ? __expf(lz) : 0.f;
+                for (int o = 1; o < K; o <<= 1) {
+                    const float up = __shfl_up(cum, o);
+                    if (k >= o) cum += up;
+                }
+                const unsigned long long below = __ballot(on && k < K - 1 && cum <= uu);
+                const int zk = __popcll((below >> rbase) & rowmask);
+                sel = on && k == zk;
+                rv = on ? expf(lz) : 0.f;
+                if (on && a.r) a.r[row * K + k] = rv;
+            }
+        }
 
         // The factorisation above needed no noise: the previous tile's stores had that long to drain.  Now: next tile's
         // rows (plain loads), then ONE wait that retires this tile's DMA (issued a tile ago), the old stores and those
@@ -1081,14 +1164,14 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
         const unsigned long long cellid = (unsigned long long)(on ? row : 0) * (unsigned long long)K + (unsigned long long)kc;
         // the noise of sample pair `pr` (samples 2 pr, 2 pr + 1) of this lane's cell, generated in registers; pr may differ per lane
         auto gen_pair = [&](unsigned pr, v2f (&eo)[L]) {
-            constexpr int L3 = (L + 2) / 3;
+            constexpr int L4 = (L + 3) / 4;
 #pragma unroll
-            for (int j = 0; j < L3; ++j) {
-                v2f p0, p1, p2;
-                philox_normal6(cellid, pr * L3 + j, rng_seed, p0, p1, p2);
-                eo[3 * j] = p0;
-                if (3 * j + 1 < L) eo[3 * j + 1] = p1;
-                if (3 * j + 2 < L) eo[3 * j + 2] = p2;
+            for (int j = 0; j < L4; ++j) {
+                v2f p4[4];
+                philox_normal8(cellid, pr * L4 + j, rng_seed, p4);
+#pragma unroll
+                for (int t2 = 0; t2 < 4; ++t2)
+                    if (4 * j + t2 < L) eo[4 * j + t2] = p4[t2];
             }
         };
         auto read_pair = [&](int s2, v2f (&eo)[L]) {
@@ -1140,6 +1223,28 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
                 qth += del2;
             }
         };
+        // epilogue, part 2: sample 0 of the drawn component IS x_samples[n] (its lane holds it in registers during pair 0)
+        auto emit_sel = [&](const v2f (&z)[L]) {
+            if (sel) {
+                float* __restrict__ xo = a.xs + row * L;
+                if ((L & 3) == 0 && al16_dev(a.xs)) {
+#pragma unroll
+                    for (int q = 0; q < L / 4; ++q)
+                        reinterpret_cast<float4*>(xo)[q] = float4{z[4 * q].x, z[4 * q + 1].x, z[4 * q + 2].x, z[4 * q + 3].x};
+                } else {
+#pragma unroll
+                    for (int i = 0; i < L; ++i) xo[i] = z[i].x;
+                }
+                if constexpr (PST) {
+                    if (momon) {
+                        float* xr = xsel + r * XSEL;
+#pragma unroll
+                        for (int q = 0; q < L / 4; ++q)
+                            *reinterpret_cast<f32x4*>(xr + 4 * q) = f32x4{z[4 * q].x, z[4 * q + 1].x, z[4 * q + 2].x, z[4 * q + 3].x};
+                    }
+                }
+            }
+        };
         if constexpr (PST2) {
             // Pair staging, TWO pairs per flush, every global store a whole 128-byte line.  A cell's S L floats are P = S / 2 chunks of
             // 64 bytes (one sample pair each), P odd: cells with an EVEN absolute index start on a line, odd ones in mid-line, and the
@@ -1179,6 +1284,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
                     if (q >= (unsigned)P) q -= P;
                     gen_pair(q, ec);
                     compute_pair(ec, true, z);
+                    if constexpr (RNG) { if (epi && q == 0u) emit_sel(z); }
                     stage(z, 0);
                 }
                 if (dbl) {
@@ -1187,6 +1293,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
                     if (q >= (unsigned)P) q -= P;
                     gen_pair(q, ec);
                     compute_pair(ec, true, z);
+                    if constexpr (RNG) { if (epi && q == 0u) emit_sel(z); }
                     stage(z, 1);
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -1233,6 +1340,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
                 read_pair((s + 2 < S) ? s + 2 : s, en);
             }
             compute_pair(ec, hv, z);
+            if constexpr (RNG) { if (epi && s == 0) emit_sel(z); }
             if constexpr (PST) {
                 float* wp = buf0 + lane * 16;
                 const int sw = (lane >> 1) & 3;
@@ -1307,6 +1415,22 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
             }
         }
         }   // !PST2
+        if constexpr (PST) {
+            if (momon) {
+                // epilogue, part 3 (K = 16): the tile's contribution to sum_n r_nk phi(x_n), phi = [x | 1 | x x^T lower], as three
+                // v_mfma_f32_16x16x4_f32: A = r (lane = (row, component) is the operand layout: M = component, k-slot = row of the
+                // tile), B = this lane's feature of its row's drawn sample, built from the row's LDS record
+                __builtin_amdgcn_wave_barrier();
+                const float* xr = xsel + (lane >> 4) * XSEL;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const float fa = xr[(fsel >> (10 * g)) & 31u], fb = xr[(fsel >> (10 * g + 5)) & 31u];
+                    accm[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(rv, fa * fb, accm[g], 0, 0, 0);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if constexpr (PST_) { const float kv = hk_lds[kc * HKS + L + 1]; kappak = lane_on ? kv : 0.f; }
         if (on) {
             a.lz[row * K + k] = lz;
             a.Tp[row * K + k] = -0.5f * L * LOG_2PI + ld - 0.5f * invS * (eps2.x + eps2.y) + 0.5f * invS * (qth.x + qth.y) - kappak;
@@ -1367,6 +1491,25 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
         __builtin_amdgcn_wave_barrier();
         SV_TS(22); FW_TS(4);
         cur ^= 1;
+    }
+    if constexpr (PST) {
+        if (momon) {
+            // the waves' fp32 accumulators (a few hundred rows each) -> one fp64 partial per block, waves in a fixed order;
+            // accumulator register v of lane l = (component 4 (l >> 4) + v, feature 16 g + (l & 15))
+            __syncthreads();
+            float* red = smem + tab;                        // [nw][3 * 4 * 64]: the staging areas are idle now
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) red[wave * 768 + (g * 4 + v) * WAVE + lane] = accm[g][v];
+            __syncthreads();
+            for (int e = threadIdx.x; e < 768; e += blockDim.x) {
+                double sacc = 0.0;
+                for (int w = 0; w < nw; ++w) sacc += (double)red[w * 768 + e];
+                const int gv = e >> 6, ln = e & 63, g = gv >> 2, v = gv & 3;
+                a.mom[((size_t)blockIdx.x * 16 + 4 * (ln >> 4) + v) * MOMF + 16 * g + (ln & 15)] = sacc;
+            }
+        }
     }
 }
 
@@ -1488,7 +1631,6 @@ __global__ __launch_bounds__(SV_FWD_MAX_NW * WAVE) void svae_estep_fwd_chunked_k
     }
 }
 
-__device__ __forceinline__ bool al16_dev(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 struct SubArgs {
     const float* x;         // (N,K,S,L)
@@ -1552,7 +1694,7 @@ __global__ __launch_bounds__(256) void subsample_kernel(SubArgs a) {
                 for (int q = 0; q < UN; ++q) {
                     if (a.rng) {
                         // one Philox block per (row, draw); the tag word keeps this stream apart from the E-step's normals
-                        unsigned c[4] = {(unsigned)n[q], (unsigned)((unsigned long long)n[q] >> 32), (unsigned)s, 0x5bb5a3c1u};
+                        unsigned c[4] = {(unsigned)n[q], (unsigned)((unsigned long long)n[q] >> 32), (unsigned)s, SUBSAMPLE_TAG};
                         philox4x32<VMP_PHILOX_ROUNDS>(c, (unsigned)sub_seed, (unsigned)(sub_seed >> 32));
                         uu[q] = (float)(c[0] >> 8) * 5.9604644775390625e-08f;      // [0, 1)
                     } else {
@@ -1650,7 +1792,7 @@ static int fwd4_plan(int K, int L, int S, int& CS, size_t& lds4, bool rng = fals
     if (pair_stage) *pair_stage = false;
     CS = L * S;
     if (((CS >> 2) & 1) == 0) CS += 4;
-    const size_t table = (size_t)((K * ((L * (L + 1) / 2) | 1) + 3) & ~3) * sizeof(float);
+    size_t table = (size_t)((K * ((L * (L + 1) / 2) | 1) + 3) & ~3) * sizeof(float);
     const int BC = VMP_FWD_BC_TILE ? (WAVE / K) * K : WAVE;      // cells per tile buffer (the kernel's BC)
     size_t pw = (size_t)((rng ? 1 : 2) * BC * CS) * sizeof(float);
     // the tile-buffer forms: whole 16-byte pieces per cell, and a cell's noise block inside the per-wave LDS tile
@@ -1667,6 +1809,7 @@ static int fwd4_plan(int K, int L, int S, int& CS, size_t& lds4, bool rng = fals
         // buffer admits seven waves - K = 16, 7, 8, 9 at S = 10.  With round 5's cheaper generator the ONE-pair form is bound by its
         // 64-byte segment stores: same box, K = 16 1.78 -> 1.52 ms, K = 8 1.04 -> 0.90, K = 7 0.91 -> 0.84 with the seven-wave tile buffer.)
         *pair_stage = true;
+        table += (size_t)K * 12 * sizeof(float);             // the kernel's [K][HKS] table of h_k | bias_k | kappa_k
         pw = (size_t)(pst2 ? 2 * (WAVE * 16 + 16) : WAVE * 16) * sizeof(float);
         nw4 = budget > table ? (int)((budget - table) / pw) : 0;
         if (nw4 > 8) nw4 = 8;
@@ -1693,6 +1836,14 @@ static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
         const int RPT4 = WAVE / K;
         long long bl = ((N + RPT4 - 1) / RPT4 + nw4 - 1) / nw4;
         if (bl > 256) bl = 256;
+        if (a.mom) {
+            if (!(ps && K == 16 && L == 8)) { set_error("in-kernel moments cover K = 16, L = 8 (vmp_svae_fwd_mom_blocks)"); return VMP_E_DIM; }
+            lds4 += (size_t)nw4 * 4 * XSEL * sizeof(float);          // the waves' drawn-sample records
+            if (lds4 < (size_t)(((K * ((L * (L + 1) / 2) | 1) + 3) & ~3) + K * 12) * sizeof(float) + (size_t)nw4 * 768 * sizeof(float)) {
+                set_error("in-kernel moments: staging area smaller than the block reduction");
+                return VMP_E_WS;
+            }
+        }
         rc = -1;
         VMP_DISPATCH_L(L, {
             if (LL == 8 && ps) {
@@ -1813,7 +1964,7 @@ static int philox_noise_impl(uint64_t seed, const uint64_t* seed_dev, int64_t N,
     if (rc) return rc;
     if (!noise) { set_error("vmp_svae_philox_noise: null pointer"); return VMP_E_BADARG; }
     NoiseArgs na{noise, (long long)N * K, L, S, (unsigned long long)seed, reinterpret_cast<const unsigned long long*>(seed_dev)};
-    const long long total = na.cells * ((S + 1) / 2) * ((L + 2) / 3);
+    const long long total = na.cells * ((S + 1) / 2) * ((L + 3) / 4);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(philox_noise_kernel, dim3((int)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), na);
@@ -1866,6 +2017,45 @@ int vmp_svae_estep_fwd_rng_dev(const float* eta1, const float* eta2d, const floa
     }
     EFwdArgs a{eta1, eta2d, hk, Pk, bias, nullptr, mk, Wk, kappa, nu, x, lz, Tp, N, K, S, 0, 0ull,
                reinterpret_cast<const unsigned long long*>(seed_dev)};
+    a.vec_ok = al16(x);
+    return run_fwd(a, L, stream, true);
+}
+
+int vmp_svae_fwd_mom_blocks(int64_t N, int K, int L, int S) {
+    int CS = 0;
+    size_t lds4 = 0;
+    bool ps = false;
+    if (N <= 0 || K != 16 || L != 8) return 0;
+    const int nw4 = fwd4_plan(K, L, S, CS, lds4, true, &ps);
+    if (nw4 < 1 || !ps) return 0;
+    if (lds4 + (size_t)nw4 * 4 * XSEL * sizeof(float) > lds_budget()) return 0;
+    const int RPT4 = WAVE / K;
+    long long bl = ((N + RPT4 - 1) / RPT4 + nw4 - 1) / nw4;
+    if (bl > 256) bl = 256;
+    return (int)bl;
+}
+
+int vmp_svae_estep_fwd_rng_epi(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
+                               uint64_t seed, const uint64_t* seed_dev, const float* mk, const float* Wk, const float* kappa,
+                               const float* nu, int64_t N, int K, int L, int S, float* x, float* lz, float* Tp,
+                               float* x_samples, float* r, double* mom, size_t mom_bytes, void* stream) {
+    int rc = check_sv(N, K, L, S);
+    if (rc) return rc;
+    if (!eta1 || !eta2d || !hk || !Pk || !bias || !mk || !Wk || !kappa || !x || !lz || !Tp || !x_samples) {
+        set_error("vmp_svae_estep_fwd_rng_epi: null pointer");
+        return VMP_E_BADARG;
+    }
+    if (!vmp_svae_rng_in_kernel(K, L, S)) {
+        set_error("vmp_svae_estep_fwd_rng_epi: K=%d L=%d S=%d is outside the in-kernel generator's shapes (vmp_svae_rng_in_kernel)", K, L, S);
+        return VMP_E_DIM;
+    }
+    if (mom) {
+        const int nb = vmp_svae_fwd_mom_blocks(N, K, L, S);
+        if (nb < 1) { set_error("vmp_svae_estep_fwd_rng_epi: no in-kernel moments for K=%d L=%d S=%d (vmp_svae_fwd_mom_blocks)", K, L, S); return VMP_E_DIM; }
+        if (mom_bytes < (size_t)nb * 16 * MOMF * sizeof(double)) { set_error("vmp_svae_estep_fwd_rng_epi: moment buffer too small"); return VMP_E_WS; }
+    }
+    EFwdArgs a{eta1, eta2d, hk, Pk, bias, nullptr, mk, Wk, kappa, nu, x, lz, Tp, N, K, S, 0, (unsigned long long)seed,
+               reinterpret_cast<const unsigned long long*>(seed_dev), x_samples, r, mom};
     a.vec_ok = al16(x);
     return run_fwd(a, L, stream, true);
 }

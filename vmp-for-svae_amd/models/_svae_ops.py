@@ -72,11 +72,17 @@ class PhiloxNoise(object):
     `seed`; include/vmp_hip.h vmp_svae_estep_fwd_rng).  The reference draws eps inside the step the same way
     (models/svae.py:113-114).  materialise() returns the identical stream as a tensor."""
 
-    def __init__(self, seed, nb_samples, seed_dev=None):
+    def __init__(self, seed, nb_samples, seed_dev=None, epilogue=False):
         """seed_dev: a one-element int64 device tensor that holds the key instead of `seed` - read by the kernel when it
-        RUNS, so that a launch captured in a HIP graph draws fresh noise per replay (in-kernel shapes only)."""
+        RUNS, so that a launch captured in a HIP graph draws fresh noise per replay (in-kernel shapes only).
+        epilogue: ask the E-step kernel that consumes this object to also do what the step does next with a cell's values
+        (vmp_svae_estep_fwd_rng_epi): the one-draw-per-row sub-sampling (svae.py:122-151, 514), r = exp(log_z) and - where the
+        kernel covers it (K = 16, L = 8) - per-block partials of the M-step's raw moments; SvaeEStepFn leaves them in
+        .x_samples (N,L), .r_nk (N,K), .mom ((blocks,16,48) fp64 or None).  All three None when the shape is not in-kernel."""
         self.seed, self.S = int(seed) & 0xFFFFFFFFFFFFFFFF, int(nb_samples)
         self.seed_dev = seed_dev
+        self.epilogue = bool(epilogue)
+        self.x_samples = self.r_nk = self.mom = None
 
     def materialise(self, N, K, Ld, device):
         out = torch.empty(N, K, Ld, self.S, dtype=torch.float32, device=device)
@@ -115,7 +121,19 @@ class SvaeEStepFn(torch.autograd.Function):
         x = torch.empty(N, K, S, Ld, **f32)
         lz = torch.empty(N, K, **f32)
         Tp = torch.empty(N, K, **f32)
-        if rng is not None and rng.seed_dev is not None:
+        if rng is not None:
+            rng.x_samples = rng.r_nk = rng.mom = None
+        if rng is not None and rng.epilogue and L.lib().vmp_svae_rng_in_kernel(K, Ld, S):
+            xs, r = torch.empty(N, Ld, **f32), torch.empty(N, K, **f32)
+            nb = L.lib().vmp_svae_fwd_mom_blocks(N, K, Ld, S)
+            mom = torch.empty(nb, 16, 48, dtype=torch.float64, device=eta1.device) if nb > 0 else None
+            L.check(L.lib().vmp_svae_estep_fwd_rng_epi(L.ptr(eta1), L.ptr(eta2d), L.ptr(hk), L.ptr(Pk), L.ptr(bias), rng.seed,
+                                                       L.ptr(rng.seed_dev), L.ptr(mk), L.ptr(Wk), L.ptr(kappa), L.ptr(nu), N, K, Ld,
+                                                       S, L.ptr(x), L.ptr(lz), L.ptr(Tp), L.ptr(xs), L.ptr(r), L.ptr(mom),
+                                                       0 if mom is None else mom.numel() * 8, L.stream()),
+                    'vmp_svae_estep_fwd_rng_epi')
+            rng.x_samples, rng.r_nk, rng.mom = xs, r, mom
+        elif rng is not None and rng.seed_dev is not None:
             L.check(L.lib().vmp_svae_estep_fwd_rng_dev(L.ptr(eta1), L.ptr(eta2d), L.ptr(hk), L.ptr(Pk), L.ptr(bias),
                                                        L.ptr(rng.seed_dev), L.ptr(mk), L.ptr(Wk), L.ptr(kappa), L.ptr(nu), N, K,
                                                        Ld, S, L.ptr(x), L.ptr(lz), L.ptr(Tp), L.stream()),
@@ -648,6 +666,28 @@ def cvi_update(gmm_prior, theta, stats, rho, want_star=True, rho_dev=None):
     for t in theta:
         torch.autograd.graph.increment_version(t)
     return star if want_star else None
+
+
+def mom_cvi(mom, gmm_prior=None, theta=None, rho=0.0, want_star=True, rho_dev=None, want_stats=True):
+    """The fused E-step kernel's moment partials (PhiloxNoise.mom, (blocks,16,48) fp64) -> raw moments (K, 2+L+L*L) fp64 and, when
+    theta is given, svae.m_step + update_gmm_params from them (svae.py:154-176, 376-403) in the same launch (vmp_svae_mom_cvi).
+    Returns (stats or None, theta* or None)."""
+    nb, K, Ld = mom.shape[0], 16, 8
+    stats = torch.empty(K, 2 + Ld + Ld * Ld, dtype=torch.float64, device=mom.device) if (want_stats or theta is None) else None
+    if theta is None:
+        L.check(L.lib().vmp_svae_mom_cvi(L.ptr(mom), nb, *([None] * 15), None, 0.0, K, Ld, L.ptr(stats), L.stream()), 'vmp_svae_mom_cvi')
+        return stats, None
+    pri = [_c(t.detach(), 'prior') for t in gmm_prior]
+    for t in theta:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise L.VmpError('theta must be contiguous fp32 GPU tensors')
+    star = [torch.empty_like(t) for t in theta] if want_star else [None] * 5
+    L.check(L.lib().vmp_svae_mom_cvi(L.ptr(mom), nb, *[L.ptr(t) for t in pri], *[L.ptr(t) for t in theta],
+                                     *[L.ptr(t) for t in star], L.ptr(rho_dev), float(rho), K, Ld, L.ptr(stats), L.stream()),
+            'vmp_svae_mom_cvi')
+    for t in theta:
+        torch.autograd.graph.increment_version(t)
+    return stats, (star if want_star else None)
 
 
 STATS_CVI_MAX_ROWS = 512          # SMALL_STATS_MAX_N of the library

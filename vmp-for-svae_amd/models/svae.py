@@ -87,6 +87,9 @@ class PhiTilde(object):
         self.T_prime = T_prime
         self.theta_key = theta_key
         self._bias, self._noise, self._x = bias, noise, x
+        # what the E-step kernel's epilogue already produced (in-kernel noise; None otherwise): the one-draw sub-sample
+        # x_samples (N,L) with the key it was drawn with, r = exp(log_z), per-block partials of the M-step moments
+        self.x_samples = self.r_nk = self.mom = self.draw_key = None
 
     def theta_term(self, theta, x_k_samps):
         """T'_nk = mean_s[log N(x_nks; phi~_nk) - log p(x_nks, z=k | theta)] (reference svae.py:229-243) for a theta the
@@ -189,7 +192,7 @@ def e_step(phi_enc, phi_gmm, nb_samples, seed=0, name="e_step", noise=None, thet
     if isinstance(noise, str):
         if noise != 'philox':
             raise ValueError("noise must be a tensor, None or 'philox'")
-        noise = _svae_ops.PhiloxNoise(seed, nb_samples)
+        noise = _svae_ops.PhiloxNoise(seed, nb_samples, epilogue=True)
     elif isinstance(noise, _svae_ops.PhiloxNoise):
         pass                                                 # caller-built (e.g. with the key in a device word)
     elif noise is None:
@@ -206,6 +209,10 @@ def e_step(phi_enc, phi_gmm, nb_samples, seed=0, name="e_step", noise=None, thet
     # afterwards; with theta (the training path) nothing extra is kept alive
     keep = dict(bias=bias, noise=noise, x=x) if theta is None else {}
     phi_tilde = PhiTilde(eta1_phi1, eta2_diag, eta1_phi2, P, Tp if theta is not None else None, _theta_key(theta), **keep)
+    if isinstance(noise, _svae_ops.PhiloxNoise) and noise.x_samples is not None:
+        phi_tilde.x_samples, phi_tilde.r_nk, phi_tilde.mom = noise.x_samples, noise.r_nk, noise.mom
+        phi_tilde.draw_key = (noise.seed, noise.seed_dev)
+        noise.x_samples = noise.r_nk = noise.mom = None      # (a caller-built object may be reused: do not pin the tensors)
     return x, lz, phi_tilde, (None, None)
 
 
@@ -224,11 +231,12 @@ def sample_x_per_comp(eta1, eta2, nb_samples, seed=0, noise=None):
     return (mu + nz).transpose(-1, -2)
 
 
-def subsample_x(x_k_samples, log_q_z_given_y, seed=0, z_draws=None, nb_out=None, u=None):
+def subsample_x(x_k_samples, log_q_z_given_y, seed=0, z_draws=None, nb_out=None, u=None, return_z=False):
     """reference svae.py:122-151: z_ns ~ Cat(exp log_q), gather x[n, z_ns, s].  HIP kernel vmp_svae_subsample;
     `z_draws` (N,S) replaces tf.multinomial (default: inverse CDF of torch.rand with `seed`; u='philox': of uniforms
     drawn inside the kernel from Philox4x32-7 keyed by `seed`).  `nb_out` < S only
-    produces the first nb_out sample columns (the reference's caller keeps s = 0, svae.py:514)."""
+    produces the first nb_out sample columns (the reference's caller keeps s = 0, svae.py:514).  return_z: also the drawn
+    component indices (N, nb_out) int64 (the reference's z_samps)."""
     x = L.dev_f32(x_k_samples.detach(), 'x_k_samples')
     N, K, S, Ld = x.shape
     lz = L.dev_f32(log_q_z_given_y.detach(), 'log_q_z_given_y', (N, K))
@@ -241,9 +249,10 @@ def subsample_x(x_k_samples, log_q_z_given_y, seed=0, z_draws=None, nb_out=None,
         sd = u.seed_dev if isinstance(u, _svae_ops.PhiloxNoise) else None
         key = (u.seed if isinstance(u, _svae_ops.PhiloxNoise) else int(seed)) & 0xFFFFFFFFFFFFFFFF
         out = torch.empty(N, So, Ld, dtype=torch.float32, device=x.device)
-        L.check(L.lib().vmp_svae_subsample_rng(L.ptr(x), L.ptr(lz), key, L.ptr(sd), N, K, S, Ld, So, L.ptr(out), None, L.stream()),
+        zo = torch.empty(N, So, dtype=torch.int64, device=x.device) if return_z else None
+        L.check(L.lib().vmp_svae_subsample_rng(L.ptr(x), L.ptr(lz), key, L.ptr(sd), N, K, S, Ld, So, L.ptr(out), L.ptr(zo), L.stream()),
                 'vmp_svae_subsample_rng')
-        return out
+        return (out, zo) if return_z else out
     if z_draws is not None:
         u = None
         z = z_draws[:, :So].to(torch.int64).contiguous()
@@ -253,9 +262,10 @@ def subsample_x(x_k_samples, log_q_z_given_y, seed=0, z_draws=None, nb_out=None,
         g = torch.Generator(device=x.device).manual_seed(int(seed))
         u = torch.rand(N, So, generator=g, device=x.device)
     out = torch.empty(N, So, Ld, dtype=torch.float32, device=x.device)
-    L.check(L.lib().vmp_svae_subsample(L.ptr(x), L.ptr(lz), L.ptr(u), L.ptr(z), N, K, S, Ld, So, L.ptr(out), None,
+    zo = torch.empty(N, So, dtype=torch.int64, device=x.device) if return_z else None
+    L.check(L.lib().vmp_svae_subsample(L.ptr(x), L.ptr(lz), L.ptr(u), L.ptr(z), N, K, S, Ld, So, L.ptr(out), L.ptr(zo),
                                        L.stream()), 'vmp_svae_subsample')
-    return out
+    return (out, zo) if return_z else out
 
 
 def m_step(gmm_prior, x_samples, r_nk):
@@ -312,6 +322,7 @@ def compute_elbo(y, reconstructions, theta, phi_tilde, x_k_samps, log_z_given_y_
                                                           *reconstructions.params)
         details = ElboDetails(rec, reg, phi_tilde, x_k_samps, log_z_given_y_phi)
         details.r_nk = r_nk
+        details.mom = phi_tilde.mom
         return elbo, details
     r_nk = torch.exp(log_z_given_y_phi)
     if decoder_type == 'bernoulli':                               # svae.py:222-223: out_2 = logits
@@ -340,6 +351,7 @@ class ElboDetails(object):
     def __init__(self, rec, reg, phi_tilde, x_k, log_z):
         self._rec, self._reg = rec, reg
         self.r_nk = None            # exp(log_z) when the fused tail produced it (the M-step reuses it)
+        self.mom = None             # per-block partials of the M-step moments when the E-step kernel's epilogue produced them
         self._lazy = (phi_tilde, x_k, log_z)
         self._nd = None
 
@@ -448,9 +460,15 @@ def inference(y, phi_gmm, encoder_layers, decoder_layers, nb_samples=10, stddev_
     x_k_samples, log_z, phi_tilde, _ = e_step(x_given_y_phi, phi_gmm, nb_samples, seed=seed, noise=noise, theta=theta, prep=prep)
     y_rec = vae.make_decoder(x_k_samples, layerspecs=decoder_layers, stddev_init=stddev_init_nn, seed=seed,
                              lazy=lazy_decoder)
-    if u is None and z_draws is None and (isinstance(noise, str) or isinstance(noise, _svae_ops.PhiloxNoise)):
+    own_draw = u is None and z_draws is None and (isinstance(noise, str) or isinstance(noise, _svae_ops.PhiloxNoise))
+    if own_draw:
         u = noise                                            # in-kernel noise: the draw's uniforms come from the same generator
-    x_samples = subsample_x(x_k_samples, log_z, seed, z_draws=z_draws, nb_out=1, u=u)[:, 0, :]
+    key = None if not own_draw else ((int(seed) & 0xFFFFFFFFFFFFFFFF, None) if isinstance(noise, str) else (noise.seed, noise.seed_dev))
+    dk = phi_tilde.draw_key
+    if own_draw and phi_tilde.x_samples is not None and dk is not None and dk[0] == key[0] and dk[1] is key[1]:
+        x_samples = phi_tilde.x_samples                      # drawn in the E-step kernel's epilogue: same uniforms, same arithmetic
+    else:
+        x_samples = subsample_x(x_k_samples, log_z, seed, z_draws=z_draws, nb_out=1, u=u)[:, 0, :]
     return y_rec, x_given_y_phi, x_k_samples, x_samples, log_z, phi_gmm, phi_tilde
 
 

@@ -284,6 +284,7 @@ class SVAETrainer(object):
         r_whole = None
         # the M-step moments and the CVI update are one launch when nothing has to be summed in between (chunks, ranks)
         fused_m = (not self.smm) and world == 1 and rows <= chunk and 0 < rows <= _svae_ops.STATS_CVI_MAX_ROWS
+        mom_whole = None            # one chunk, one rank, and the E-step kernel left moment partials: reduce + CVI in one launch (_step_back)
         for ci, i in enumerate(range(0, rows, chunk)):
             ys = y[i:i + chunk]
             ns = None if noise is None else noise[i:i + chunk]
@@ -296,15 +297,20 @@ class SVAETrainer(object):
             g = torch.autograd.grad(elbo, params, grad_outputs=self._neg_one.tensor, allow_unused=True)   # loss = -elbo
             g = [torch.zeros_like(p) if gi is None else gi for gi, p in zip(g, params)]
             r_nk = details.r_nk if details.r_nk is not None else torch.exp(log_z.detach())
+            mom = None if self.smm else getattr(details, 'mom', None)
             if fused_m:
                 st = None                                                             # moments + CVI in one launch below
+            elif mom is not None and world == 1 and rows <= chunk:
+                st, mom_whole = None, mom                                             # partials -> moments -> CVI in one launch below
+            elif mom is not None:                                                     # summed over chunks / ranks first
+                st = _svae_ops.mom_cvi(mom)[0]
             elif self.smm:                                                            # svae.m_step_smm: N_k only
                 from .models import gmm as _gmm
                 st = _gmm.update_Nk(r_nk.contiguous()).double().reshape(-1, 1)
             else:
                 st = _mix.raw_stats(x_s.detach().contiguous(), r_nk.contiguous(), pivot=False)  # HIP: (K, 2+L+L*L) fp64; raw, un-centred: no pivot pass
             grads = g if grads is None else [a + b for a, b in zip(grads, g)]
-            if not fused_m:
+            if not fused_m and mom_whole is None:
                 stats = st if stats is None else stats + st
             rec, reg = details[0], details[3]                # the two debug scalars in between are computed on access only
             if ci == 0:
@@ -316,7 +322,7 @@ class SVAETrainer(object):
                 r_whole = r_nk
             del elbo, details, x_k, x_s, log_z
         ctx = dict(world=world, names=names, params=params, grads=grads, stats=stats, fused_m=fused_m, keep=keep,
-                   r_whole=r_whole, scal=(elbo_t, rec_t, reg_t), buf=None, goffs=None)
+                   r_whole=r_whole, scal=(elbo_t, rec_t, reg_t), buf=None, goffs=None, mom_whole=mom_whole)
         if world > 1:
             # ONE pack launch, ONE all-reduce, and (in _step_back) ONE Adam launch that reads the averaged gradients from the
             # buffer: the exchange adds three launches to the step (it was a torch.cat over ~25 fp64 copies, ~25 slices and 21 divisions)
@@ -351,6 +357,10 @@ class SVAETrainer(object):
                                               0.0 if rho_dev is not None else lrcvi, rho_dev=rho_dev)
             # (graph capture: theta's update is a branch beside the Adam step - disjoint variables)
             stats, theta_star = cvi() if _svae_ops.FORK is None else _svae_ops.FORK.run('cvi', cvi)
+        elif ctx.get('mom_whole') is not None:                                      # large single-process batch, K = 16, L = 8
+            rho_dev = None if _dev_scalars is None else _dev_scalars[0]
+            stats, theta_star = _svae_ops.mom_cvi(ctx['mom_whole'], self.gmm_prior, self.theta,
+                                                  0.0 if rho_dev is not None else lrcvi, rho_dev=rho_dev, want_stats=False)
         elif self.smm:                                                              # experiments.py:252-256
             theta_star = [self.gmm_prior + stats[:, 0].float()]
             if _dev_scalars is not None:                                            # graph capture: the step size is a device word
