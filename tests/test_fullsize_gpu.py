@@ -230,9 +230,9 @@ def test_t2_step_at_full_size_vs_chunked_oracle(N, K, smm):
     seed = 424242
     x, lz, pt, _ = svae.e_step((eta1, eta2d), phi, S, seed=seed, noise='philox', theta=theta)
     # round 6: the forward kernel's epilogue already holds r = exp(log z), the one-draw sub-sample and (K = 16) the moment partials
-    assert pt.x_samples is not None and pt.r_nk is not None and (pt.mom is not None) == (K == 16)
+    assert pt.x_samples is not None and pt.r_nk is not None and (pt.mom is not None) == (K == 16)     # (L = 8, S = 10: the pair-staging form)
     r = pt.r_nk
-    assert (r - torch.exp(lz.detach())).abs().max().item() <= 2e-7
+    assert (r - torch.exp(lz.detach())).abs().max().item() <= 1e-6
     # loss = -elbo_reg + <x, Gx> + <log z, Glz>,  elbo_reg = -sum_nk r (T' + log z):  d/dT' = r, d/dlog z = r (T' + log z + 1) + Glz
     grads = torch.autograd.grad([x, lz, pt.T_prime], [eta1, eta2d] + phi + th_params, [Gx, Glz + r * (pt.T_prime.detach() + lz.detach() + 1.0), r])
     # the draw: the stand-alone kernel with the same key picks the same component and the same row, bit for bit; the ORACLE's

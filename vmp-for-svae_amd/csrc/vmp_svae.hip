@@ -759,21 +759,37 @@ __device__ __forceinline__ void philox4x32(unsigned (&c)[4], unsigned k0, unsign
         c[1] = (unsigned)p1; c[3] = (unsigned)p0; c[0] = n0; c[2] = n2;
     }
 }
-// one 32-bit word -> one Box-Muller pair: radius from the top 20 bits, angle from the low 12
-__device__ __forceinline__ v2f box_muller_word(unsigned w) {
+// one 32-bit word -> one Box-Muller pair: radius from the top 20 bits, angle from the low 12.
+// TAB: (cos, sin) of the 4096 directions come from an LDS table the block fills at start WITH THE SAME v_cos / v_sin instructions
+// (bit-identical to the direct form) - one ds_read_b64 instead of two quarter-rate transcendentals per pair: the sample loop of the
+// forward kernel is bound by VALU issue, and of its ~1.5 k cycles per sample pair 512 were v_log / v_sqrt / v_sin / v_cos.
+#ifndef VMP_FWD_SINCOS_TAB
+#define VMP_FWD_SINCOS_TAB 1
+#endif
+constexpr int SCT_WORDS = 2 * 4096;
+__device__ __forceinline__ float bm_angle(unsigned b12) { return __uint_as_float((b12 << 11) | 0x3F800000u); }   // 1 + b 2^-12 revolutions
+template <bool TAB>
+__device__ __forceinline__ v2f box_muller_word(unsigned w, const float* __restrict__ sct) {
     const float u1 = fmaf((float)(w >> 12), 9.5367431640625e-07f, 4.76837158203125e-07f);   // (a + 1/2) 2^-20 in (0, 1)
-    // angle in revolutions: the 12 bits become the top mantissa bits of a float in [1, 2) - v_sin / v_cos take revolutions and are
-    // periodic, so 1 + b 2^-12 is as good as b 2^-12 (shift + v_and_or instead of v_cvt + v_mul; exact either way)
-    const float ang = __uint_as_float(((w << 11) & 0x007FF800u) | 0x3F800000u);
     const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1), v_log_f32 = log2
-    return v2f{rad * __builtin_amdgcn_cosf(ang), rad * __builtin_amdgcn_sinf(ang)};
+    if constexpr (TAB) {
+        const v2f cs = *reinterpret_cast<const v2f*>(sct + ((w << 1) & 0x1FFEu));
+        return v2f{rad, rad} * cs;
+    } else {
+        // angle in revolutions: the 12 bits become the top mantissa bits of a float in [1, 2) - v_sin / v_cos take revolutions and
+        // are periodic, so 1 + b 2^-12 is as good as b 2^-12 (shift + v_and_or instead of v_cvt + v_mul; exact either way)
+        const float ang = __uint_as_float(((w << 11) & 0x007FF800u) | 0x3F800000u);
+        return v2f{rad * __builtin_amdgcn_cosf(ang), rad * __builtin_amdgcn_sinf(ang)};
+    }
 }
 // the four pairs of block `blk` of cell `cell`: coordinates 4j .. 4j+3 of sample pair p (blk = p ceil(L/4) + j)
-__device__ __forceinline__ void philox_normal8(unsigned long long cell, unsigned blk, unsigned long long seed, v2f (&p)[4]) {
+template <bool TAB = false>
+__device__ __forceinline__ void philox_normal8(unsigned long long cell, unsigned blk, unsigned long long seed, v2f (&p)[4],
+                                               const float* __restrict__ sct = nullptr) {
     unsigned c[4] = {(unsigned)cell, (unsigned)(cell >> 32), blk, 0u};
     philox4x32<VMP_PHILOX_ROUNDS>(c, (unsigned)seed, (unsigned)(seed >> 32));
 #pragma unroll
-    for (int t = 0; t < 4; ++t) p[t] = box_muller_word(c[t]);
+    for (int t = 0; t < 4; ++t) p[t] = box_muller_word<TAB>(c[t], sct);
 }
 
 struct NoiseArgs { float* out; long long cells; int L, S; unsigned long long seed; const unsigned long long* seed_dev; };
@@ -863,10 +879,13 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
     // pair-staging forms: h_k, bias_k, kappa_k of the lane's component are used once per tile - they come from an LDS table
     // [K][HKS] instead of living in 10 VGPRs across the sample loop (the round-6 epilogue needs those registers)
     constexpr int HKS = 12;
+    constexpr bool SCT = PST_ && VMP_FWD_SINCOS_TAB;     // (cos, sin) of the generator's 4096 directions in LDS (box_muller_word)
     const int tab0 = (K * PSTR + 3) & ~3;
-    const int tab = tab0 + (PST_ ? K * HKS : 0);
+    const int tab1 = tab0 + (PST_ ? K * HKS : 0);
+    const int tab = tab1 + (SCT ? SCT_WORDS : 0);
     float* pk_lds = smem;
     float* hk_lds = smem + tab0;
+    float* sct = smem + tab1;
     // two tile buffers per wave (the noise of the next tile arrives by DMA while this one is processed); with in-kernel noise
     // nothing is prefetched: ONE buffer, which lets 7 waves instead of 4 share the LDS of a CU
     constexpr int NBUF = RNG ? 1 : 2;
@@ -1020,6 +1039,12 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
             hk_lds[e] = i < L ? a.hk[kk * L + i] : i == L ? a.bias[kk] : i == L + 1 ? a.kappa[kk] : 0.f;
         }
     }
+    if constexpr (SCT) {
+        for (int e = threadIdx.x; e < 4096; e += blockDim.x) {
+            const float ang = bm_angle((unsigned)e);
+            *reinterpret_cast<v2f*>(sct + 2 * e) = v2f{__builtin_amdgcn_cosf(ang), __builtin_amdgcn_sinf(ang)};
+        }
+    }
     __syncthreads();
     SV_TS(17);
     // ---- epilogue state (in-kernel noise only)
@@ -1119,7 +1144,8 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
                 unsigned c4[4] = {(unsigned)rw, (unsigned)(rw >> 32), 0u, SUBSAMPLE_TAG};
                 philox4x32<VMP_PHILOX_ROUNDS>(c4, (unsigned)rng_seed, (unsigned)(rng_seed >> 32));
                 const float uu = (float)(c4[0] >> 8) * 5.9604644775390625e-08f;      // [0, 1)
-                float cum = on ? __expf(lz) : 0.f;
+                rv = on ? __expf(lz) : 0.f;                      // r = exp(log z); also the first term of the row's CDF
+                float cum = rv;
                 for (int o = 1; o < K; o <<= 1) {
                     const float up = __shfl_up(cum, o);
                     if (k >= o) cum += up;
@@ -1127,7 +1153,6 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
                 const unsigned long long below = __ballot(on && k < K - 1 && cum <= uu);
                 const int zk = __popcll((below >> rbase) & rowmask);
                 sel = on && k == zk;
-                rv = on ? expf(lz) : 0.f;
                 if (on && a.r) a.r[row * K + k] = rv;
             }
         }
@@ -1168,7 +1193,7 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
 #pragma unroll
             for (int j = 0; j < L4; ++j) {
                 v2f p4[4];
-                philox_normal8(cellid, pr * L4 + j, rng_seed, p4);
+                philox_normal8<SCT>(cellid, pr * L4 + j, rng_seed, p4, sct);
 #pragma unroll
                 for (int t2 = 0; t2 < 4; ++t2)
                     if (4 * j + t2 < L) eo[4 * j + t2] = p4[t2];
@@ -1810,6 +1835,7 @@ static int fwd4_plan(int K, int L, int S, int& CS, size_t& lds4, bool rng = fals
         // 64-byte segment stores: same box, K = 16 1.78 -> 1.52 ms, K = 8 1.04 -> 0.90, K = 7 0.91 -> 0.84 with the seven-wave tile buffer.)
         *pair_stage = true;
         table += (size_t)K * 12 * sizeof(float);             // the kernel's [K][HKS] table of h_k | bias_k | kappa_k
+        if (VMP_FWD_SINCOS_TAB) table += (size_t)SCT_WORDS * sizeof(float);   // and its (cos, sin) table of the generator's directions
         pw = (size_t)(pst2 ? 2 * (WAVE * 16 + 16) : WAVE * 16) * sizeof(float);
         nw4 = budget > table ? (int)((budget - table) / pw) : 0;
         if (nw4 > 8) nw4 = 8;
@@ -1839,7 +1865,7 @@ static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
         if (a.mom) {
             if (!(ps && K == 16 && L == 8)) { set_error("in-kernel moments cover K = 16, L = 8 (vmp_svae_fwd_mom_blocks)"); return VMP_E_DIM; }
             lds4 += (size_t)nw4 * 4 * XSEL * sizeof(float);          // the waves' drawn-sample records
-            if (lds4 < (size_t)(((K * ((L * (L + 1) / 2) | 1) + 3) & ~3) + K * 12) * sizeof(float) + (size_t)nw4 * 768 * sizeof(float)) {
+            if (lds4 < (size_t)(((K * ((L * (L + 1) / 2) | 1) + 3) & ~3) + K * 12 + (VMP_FWD_SINCOS_TAB ? SCT_WORDS : 0)) * sizeof(float) + (size_t)nw4 * 768 * sizeof(float)) {
                 set_error("in-kernel moments: staging area smaller than the block reduction");
                 return VMP_E_WS;
             }
