@@ -125,7 +125,7 @@ def _smm_theta(prior, theta, rng, K, Ld):
     return [theta[0].clone(), mu_t, L_t, torch.full((K,), 5.0)], prior[0]
 
 
-def cpu_baseline_t2(K, Ld, S, smm=False, Ns=8192, reps=2):
+def cpu_baseline_t2(K, Ld, S, smm=False, Ns=1 << 14, reps=3, chunk=1 << 14):
     """The reference CPU path of the T2 unit ("fwd+bwd+M-step for T2/T3"): oracle.train_ref.vmp_step_t2 - the
     literal restatement of svae.e_step, the regulariser of compute_elbo(_smm), autodiff, subsample_x, m_step and
     update_gmm_params (models/svae.py:14-262, 376-403) in fp32 torch-CPU - on a bounded sample of Ns rows of the same shape."""
@@ -139,15 +139,15 @@ def cpu_baseline_t2(K, Ld, S, smm=False, Ns=8192, reps=2):
     Glz = torch.as_tensor(rng.standard_normal((Ns, K)).astype(np.float32)) * 0.1
     ncpu = os.cpu_count() or 1
     cands = sorted({t for t in (8, 32) if t <= ncpu}) or [ncpu]
-    best, best_t = _best_threads(lambda: train_ref.vmp_step_t2(phi, theta, prior, e1, e2, noise, zd, Gx, Glz, 0.2, smm=smm, chunk=4096), cands, reps)
+    best, best_t = _best_threads(lambda: train_ref.vmp_step_t2(phi, theta, prior, e1, e2, noise, zd, Gx, Glz, 0.2, smm=smm, chunk=chunk), cands, reps)
     return {'value': Ns / best, 'unit': 'datapoints/s', 'cores': best_t, 'kind': 'port', 'host_hw_threads': ncpu,
             'thread_counts_tried': cands, 'seconds_per_step_at_sample': best,
             'sample': 'one T2 %s-svae VMP step (oracle.train_ref.vmp_step_t2: e_step fwd + regulariser + autodiff + subsample + m_step + CVI, '
-                      'fp32 torch-CPU, N-chunks of 4096) on %d rows of the workload shape (K=%d, L=%d, S=%d); fastest of %d timed runs at each of %s threads'
-                      % ('smm' if smm else 'gmm', Ns, K, Ld, S, reps, cands)}
+                      'fp32 torch-CPU, N-chunks of %d) on %d rows of the workload shape (K=%d, L=%d, S=%d); fastest of %d timed runs at each of %s threads'
+                      % ('smm' if smm else 'gmm', chunk, Ns, K, Ld, S, reps, cands)}
 
 
-def cpu_baseline_t3(K, Ld, S, U, smm=False, Ns=8192, reps=2):
+def cpu_baseline_t3(K, Ld, S, U, smm=False, Ns=1 << 14, reps=3, tower=1 << 14):
     """The reference CPU path of the T3 unit: oracle.train_ref.train_step (experiments.py:196-267 op for op: encoder, E-step,
     decoder, ELBO, autodiff of all 21 / 23 variables, M-step, CVI, TF-Adam) in fp32 torch-CPU on a bounded sample of Ns rows."""
     from oracle import nets, train_ref
@@ -159,15 +159,15 @@ def cpu_baseline_t3(K, Ld, S, U, smm=False, Ns=8192, reps=2):
     y = torch.as_tensor(synth(Ns, Ld, K, seed=7)[0])
     ncpu = os.cpu_count() or 1
     cands = sorted({t for t in (8, 32) if t <= ncpu}) or [ncpu]
-    best, best_t = _best_threads(lambda: train_ref.train_step(st, y, noise, zd, 3e-4, 0.2, 0.95, towers=max(1, Ns // 4096)), cands, reps)
+    best, best_t = _best_threads(lambda: train_ref.train_step(st, y, noise, zd, 3e-4, 0.2, 0.95, towers=max(1, Ns // tower)), cands, reps)
     return {'value': Ns / best, 'unit': 'datapoints/s', 'cores': best_t, 'kind': 'port', 'host_hw_threads': ncpu,
             'thread_counts_tried': cands, 'seconds_per_step_at_sample': best,
-            'sample': 'one T3 %s-svae training step (oracle.train_ref.train_step = experiments.py:196-267, fp32 torch-CPU, towers of 4096 rows) '
+            'sample': 'one T3 %s-svae training step (oracle.train_ref.train_step = experiments.py:196-267, fp32 torch-CPU, towers of %d rows) '
                       'on %d rows of the workload shape (K=%d, L=Dy=%d, S=%d, U=%d); fastest of %d timed runs at each of %s threads'
-                      % ('smm' if smm else 'gmm', Ns, K, Ld, S, U, reps, cands)}
+                      % ('smm' if smm else 'gmm', tower, Ns, K, Ld, S, U, reps, cands)}
 
 
-def bench_t2(N, Ld, K, S, steps, warmup, dev, dist=None, world=1, smm=False, cpu=False):
+def bench_t2(N, Ld, K, S, steps, warmup, dev, dist=None, world=1, smm=False, cpu=False, tensor_mode=True):
     """T2: SVAE VMP step without the MLPs - fused E-step forward (log_z, samples, regulariser terms),
     its backward (given decoder-side gradients), categorical sub-sampling, M-step moments and the CVI update.
     The step draws its OWN noise, as sample_x_per_comp does (svae.py:113-114).  Headline (`ms_per_step`): the form SVAETrainer runs
@@ -260,6 +260,8 @@ def bench_t2(N, Ld, K, S, steps, warmup, dev, dist=None, world=1, smm=False, cpu
         return dt_, ms
 
     dt, (_, f_ms, b_ms) = run('philox')
+    if not tensor_mode:                                       # shard-size side measurements: the headline form only
+        return {'ms_per_step': dt / steps * 1e3, 'fwd_kernel_ms': f_ms, 'bwd_kernel_ms': b_ms, 'rows': N}
     dt_n, (rn_ms, fn_ms, bn_ms) = run('tensor')
     alg = 4.0 * N * (2.0 * K * S * Ld + 2 * K + 4 * Ld)          # SURVEY 8d T2 bytes per step, in-kernel generator
     alg_n = 4.0 * N * (4.0 * K * S * Ld + 2 * K + 4 * Ld)        # ... with an injected noise tensor
@@ -271,7 +273,16 @@ def bench_t2(N, Ld, K, S, steps, warmup, dev, dist=None, world=1, smm=False, cpu
            'noise': 'drawn inside the forward kernel, fresh key every step (SVAETrainer default)',
            'algorithmic_bytes_per_step': alg, 'algorithmic_GBps_whole_step': alg / (dt / steps) / 1e9,
            'frac_hbm_whole_step': alg / (dt / steps) / 1e9 / HBM_PEAK_GBS,
-           'fwd_kernel_ms': f_ms, 'bwd_kernel_ms': b_ms,
+           'fwd_kernel_ms': f_ms, 'bwd_kernel_ms': b_ms, 'tail_ms': dt / steps * 1e3 - f_ms - b_ms,
+           # what the two kernels MOVE: the contract's algorithmic bytes have the backward read dL/dx only (x re-derived from eps); the
+           # ring backward reads x AND dL/dx instead of regenerating eps and redoing the forward's VALU work (1.3 ms at C3)
+           'moved_bytes_per_step': fwd_bytes + bwd_bytes, 'moved_over_algorithmic': (fwd_bytes + bwd_bytes) / alg,
+           'moved_GBps_whole_step': (fwd_bytes + bwd_bytes) / (dt / steps) / 1e9,
+           'moved_frac_hbm_whole_step': (fwd_bytes + bwd_bytes) / (dt / steps) / 1e9 / HBM_PEAK_GBS,
+           'moved_note': 'the step moves fwd %.2f GB (eta in, x + log_z + T\' + r + x_samples out) + bwd %.2f GB (x, dL/dx and the (N,K) terms in, d eta out) '
+                         'against %.2f GB algorithmic (SURVEY 8d counts dL/dx only for the backward): re-reading x costs 5.1 GB = 0.8 ms of HBM time, '
+                         're-deriving it from the noise stream would cost the forward\'s 1.3 ms of VALU work again' % (fwd_bytes / 1e9, bwd_bytes / 1e9, alg / 1e9),
+           'epilogue': 'sub-sampling draw, r = exp(log_z) and (K = 16, L = 8) the M-step moment partials come out of the forward kernel; reduce + CVI is one launch',
            'fwd_GBps': gb(fwd_bytes, f_ms), 'bwd_GBps': gb(bwd_bytes, b_ms),
            'fwd_frac_hbm': gb(fwd_bytes, f_ms) / HBM_PEAK_GBS, 'bwd_frac_hbm': gb(bwd_bytes, b_ms) / HBM_PEAK_GBS,
            'noise_tensor': {'ms_per_step': dt_n / steps * 1e3, 'includes': 'the per-step normal_() of the (N,K,L,S) tensor',
@@ -285,7 +296,7 @@ def bench_t2(N, Ld, K, S, steps, warmup, dev, dist=None, world=1, smm=False, cpu
     return res
 
 
-def bench_t3(N, Ld, K, S, U, steps, warmup, dev, chunk, smm=False, cpu=False):
+def bench_t3(N, Ld, K, S, U, steps, warmup, dev, chunk, smm=False, cpu=False, randn_mode=True):
     """T3: the full training step of experiments.py:196-267 (encoder / decoder MLP + reconstruction term in the fused
     MFMA kernels; fused E-step kernels; all gradients, TF-Adam, CVI) on synthetic y = GMM data with Dy = L.  Timed with
     eps drawn inside the E-step kernel (the trainer's default, rng='philox') and, next to it, read from a torch.randn
@@ -324,6 +335,8 @@ def bench_t3(N, Ld, K, S, U, steps, warmup, dev, chunk, smm=False, cpu=False):
         return dt_, per, elbo
 
     dt, per, elbo = timed('philox')
+    if not randn_mode:                                        # shard-size side measurements: the headline form only
+        return {'ms_per_step': dt / steps * 1e3, 'per_step_ms_median': float(np.median(per)), 'rows': N}
     dt_p, per_p, _ = timed('torch')
     rows = float(N) * K * S
     dec_flop = 3 * 2.0 * rows * (Ld * U + U * U + U * 2 * Ld + Ld * Ld)     # fwd + 2x bwd, useful flops of the decoder
@@ -562,6 +575,54 @@ def dec_bwd_side_measurement(N, K, S, Ld, U, dev):
     return ms * (float(N) / n), useful * (float(N) / n), issued * (float(N) / n), mf
 
 
+def t3_roofline(N, K, S, Ld, U, dev):
+    """roofline object of the T3 step's dominant kernel (fused decoder backward), from dec_bwd_side_measurement"""
+    k_ms, useful, issued, mf = dec_bwd_side_measurement(N, K, S, Ld, U, dev)
+    tf_s = useful / (k_ms * 1e-3) / 1e12
+    is_s = issued / (k_ms * 1e-3) / 1e12
+    return {'bound': 'mfma', 'achieved': is_s, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': is_s / 2500.0, 'traffic': None,
+            'kernel': 'dec_bwd_kernel (bf16 split operands on the XDL pipe: %d v_mfma_f32_16x16x32_bf16 per 16-row tile)' % mf,
+            'kernel_ms': k_ms, 'useful_fp32_TFLOPs': tf_s, 'useful_frac_of_fp32_vector_peak': tf_s * 1e12 / FP32_PEAK_FLOPS,
+            'issued_over_useful': issued / useful,
+            'note': 'timed on min(N, 2^20) data rows (scaled to N beyond that; the kernel is linear in rows); achieved = ISSUED bf16 MFMA '
+                    'flops (operand splits, 50 -> 64 unit padding and k-slot padding included), useful = fp32-equivalent flops'}
+
+
+def shard_steps(N, D, K, S, U, flav, kappa, dev, ms1, exch_us, exch_detail):
+    """Strong scaling on driver-timed ground without a multi-GPU box: the step a rank of a G-GPU run executes on its N / G rows (the
+    reference's tf.split of one minibatch over its towers, data.py:174-175; experiments.py:196-248), timed HERE for G = 2, 4, 8 and
+    all three units, plus the one-rank cost of the step's single exchange (T1: the RCCL / peer forms of t1_forced_dist_1rank; T2 / T3:
+    one in-place RCCL all-reduce of the packed fp64 buffer).  Implied factors: strong_G = t(N) / (t(N / G) + exchange), weak_G = G t(N) /
+    (t(N) + exchange).  The inter-GPU hop itself (xGMI latency, ~2 us per store-and-poll, 15-25 us for an 8-rank ring of a 20-100 KB
+    message) is NOT in these numbers: nothing here can measure it."""
+    from vmp_for_svae_amd.models import _mix
+    out = {'rows_per_rank': {}, 'note': 'one-GPU timings of the per-rank step at N/G rows; exchange = one-rank overhead measured by this run; no xGMI hop included'}
+    t = {'t1': {}, 't2': {}, 't3': {}}
+    for G in (2, 4, 8):
+        n = N // G
+        x_h, r0_h = synth(n, D, K, seed=50 + G)
+        lp = _mix.VMPLoop(torch.as_tensor(x_h).to(dev), torch.as_tensor(r0_h).to(dev), flav, kappa=kappa)
+        w, _ = time_t1(lp, 20, 5, 7, lambda: torch.cuda.synchronize(), None, dev)
+        t['t1'][G] = float(np.median(w)) / 20 * 1e3
+        del lp
+        torch.cuda.empty_cache()
+        t['t2'][G] = bench_t2(n, D, K, S, 6, 2, dev, None, 1, cpu=False, tensor_mode=False)['ms_per_step']
+        torch.cuda.empty_cache()
+        t['t3'][G] = bench_t3(n, D, K, S, U, 5, 3, dev, None, cpu=False, randn_mode=False)['ms_per_step']
+        torch.cuda.empty_cache()
+        out['rows_per_rank'][str(G)] = n
+    ex = {'t1': exch_us['t1_peer'] * 1e-3, 't2': exch_us['t2'] * 1e-3, 't3': exch_us['t3'] * 1e-3}       # ms
+    for u in ('t1', 't2', 't3'):
+        out[u] = {'ms_per_step_full': ms1[u], 'ms_per_step_at_rows_per_rank': {str(G): t[u][G] for G in (2, 4, 8)},
+                  'exchange_ms_1rank': ex[u],
+                  'implied_strong_scaling': {str(G): ms1[u] / (t[u][G] + ex[u]) for G in (2, 4, 8)},
+                  'implied_weak_scaling': {str(G): G * ms1[u] / (ms1[u] + ex[u]) for G in (2, 4, 8)}}
+    out['t1']['exchange_ms_1rank_rccl_form'] = exch_us['t1_rccl'] * 1e-3
+    out['t1']['implied_strong_scaling_rccl_form'] = {str(G): ms1['t1'] / (t['t1'][G] + exch_us['t1_rccl'] * 1e-3) for G in (2, 4, 8)}
+    out['exchange_detail'] = exch_detail
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -696,6 +757,21 @@ def main():
             dist1.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
             dloop = DistributedVMPLoop(x, r0, flav, kappa=kappa)
             dw, _ = time_t1(dloop, args.steps, args.warmup, max(1, args.reps), lambda: torch.cuda.synchronize(), None, dev)
+            # the ONE collective of a T2 / T3 data-parallel step (packed fp64 buffer: moments + K-sized gradients [+ MLP gradients]),
+            # in place on this stream, one rank: what the exchange adds to a step before any inter-GPU hop
+            exch_us = {}
+            for tag, nd in (('t2', K * (2 + D + D * D) + K * (D + D * D + 1) + 3), ('t3', K * (2 + D + D * D) + K * (D + D * D + 1) + 3 + 2 * (D * args.u + args.u + args.u * args.u + args.u + args.u * 2 * D + 2 * D + D * D + 2 * D))):
+                bufx = torch.zeros(nd, dtype=torch.float64, device=dev)
+                for _ in range(5):
+                    dist1.all_reduce(bufx)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(50):
+                    dist1.all_reduce(bufx)
+                e1.record()
+                torch.cuda.synchronize()
+                exch_us[tag] = {'doubles': nd, 'allreduce_us_1rank': e0.elapsed_time(e1) / 50 * 1e3}
             dist1.destroy_process_group()
             d_us = float(np.median(dw)) / args.steps * 1e6
             del dloop
@@ -733,6 +809,15 @@ def main():
             torch.cuda.empty_cache()
             extra['t3_svae_train'] = bench_t3(N, D, K, args.s, args.u, 5, 3, dev, None, cpu=not args.no_cpu_baseline)
             torch.cuda.empty_cache()
+            extra['t3_svae_train']['roofline'] = t3_roofline(N, K, args.s, D, args.u, dev)     # dominant kernel of T3, timed by this run
+            torch.cuda.empty_cache()
+            if (N, D, K) == (1_000_000, 8, 16):
+                # (c) the per-GPU steps of a STRONG-scaling run, timed on this one GPU: N / 2, N / 4, N / 8 rows per rank
+                extra['shard_steps'] = shard_steps(N, D, K, args.s, args.u, flav, kappa, dev, ms1={
+                    't1': dt / args.steps * 1e3, 't2': extra['t2_svae_vmp']['ms_per_step'], 't3': extra['t3_svae_train']['ms_per_step']},
+                    exch_us={'t1_rccl': extra['t1_forced_dist_1rank']['rccl_overhead_us'], 't1_peer': extra['t1_forced_dist_1rank']['dist_overhead_us'],
+                             't2': exch_us['t2']['allreduce_us_1rank'], 't3': exch_us['t3']['allreduce_us_1rank']}, exch_detail=exch_us)
+                torch.cuda.empty_cache()
             # BASELINE configs[3]-sized model at the reference's minibatch size (Auto: Dy=6, L=8, K=10, U=50)
             extra['t3_minibatch64'] = bench_minibatch(64, 10, 8, 6, args.s, args.u, dev, cpu=not args.no_cpu_baseline)
             torch.cuda.empty_cache()
@@ -800,15 +885,7 @@ def main():
         else:
             res = bench_t3(n_loc, D, K, S, U, steps, warm, dev, None, smm=args.smm, cpu=(world == 1 and not args.no_cpu_baseline))
             ms = res['ms_per_step']
-            k_ms, useful, issued, mf = dec_bwd_side_measurement(n_loc, K, S, D, U, dev)
-            tf_s = useful / (k_ms * 1e-3) / 1e12
-            is_s = issued / (k_ms * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'achieved': is_s, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': is_s / 2500.0, 'traffic': None,
-                    'kernel': 'dec_bwd_kernel (bf16 split operands on the XDL pipe: %d v_mfma_f32_16x16x32_bf16 per 16-row tile)' % mf,
-                    'kernel_ms': k_ms, 'useful_fp32_TFLOPs': tf_s, 'useful_frac_of_fp32_vector_peak': tf_s * 1e12 / FP32_PEAK_FLOPS,
-                    'issued_over_useful': issued / useful,
-                    'note': 'timed on min(N, 2^20) data rows (scaled to N beyond that; the kernel is linear in rows); achieved = ISSUED bf16 MFMA '
-                            'flops (operand splits, 50 -> 64 unit padding and k-slot padding included), useful = fp32-equivalent flops'}
+            roof = t3_roofline(n_loc, K, S, D, U, dev)
             metric, wl = 'svae_train_step_datapoints_per_sec', 'T3 %ssvae training step (experiments.py:196-267), L=Dy=%d, K=%d, S=%d, U=%d' % ('Student-t (smm) ' if args.smm else '', D, K, S, U)
             extra['t3'] = res
         ms = max_over_ranks(dist, ms, dev)

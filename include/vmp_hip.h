@@ -131,23 +131,6 @@ int    vmp_mix_iterate(const float* x, int64_t N, int D, int K, int flavour,
                        float* alpha, float* beta, float* m, float* C, float* v, float* xbar, float* S, float* pi,
                        float* pack, void* ws, size_t ws_bytes, int iterations, void* stream);
 
-/* The whole VMP iteration - `sess.run(step)` of models/gmm.py:258-263 / models/smm.py:232-238: M-step posterior from the current
- * moments, E-step, assign - as ONE launch per iteration (round 5; vmp_mix_iterate / vmp_mix_finalize_ws + vmp_mix_estep_fused
- * are the two-launch form and produce bit-identical results).  Blocks 0..K-1 of the streaming launch first do what
- * vmp_mix_finalize_ws does for component k (on the partials the previous launch left in `ws`), write their pack row with
- * system-scope write-through stores and publish sequence word k = iteration number; every wave of the launch stages its first
- * rows, polls the K words (bounded; status 2 on a time-out, see vmp_mix_step_status) and reads the pack past the caches.
- * `iterations` launches are enqueued by one call, numbered first_iteration, first_iteration + 1, ..: the numbers a workspace
- * sees must be >= 1 and strictly increasing; vmp_mix_stats_ws (which seeds `ws`) resets them.  logr (N,K) optional.
- * Shapes outside the one-launch form (K > 16, fewer rows than K full blocks) run the two launches.                           */
-int    vmp_mix_step(const float* x, int64_t N, int D, int K, int flavour,
-                    const float* alpha0, const float* beta0, const float* m0, const float* C0, const float* v0,
-                    const float* kappa, const float* pivot, float* r, float* u, float* logr,
-                    float* alpha, float* beta, float* m, float* C, float* v, float* xbar, float* S, float* pi,
-                    float* pack, void* ws, size_t ws_bytes, uint64_t first_iteration, int iterations, void* stream);
-/* synchronises the stream and returns the workspace's status word: 0, or 2 = a wave gave up waiting for a pack row */
-int    vmp_mix_step_status(const void* ws, int D, int K, int* status_out, void* stream);
-
 /* ------------------------------------------------------------------------------------------------
  * T2: SVAE E-step fused with the ELBO regulariser (models/svae.py:14-119 and :229-252)
  * ------------------------------------------------------------------------------------------------

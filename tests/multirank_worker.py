@@ -89,8 +89,13 @@ def main():
             vae.reset_variables()
             return SVAETrainer(Kg, Lg, Ug, Dg, nb_samples=Sg, lr=3e-3, lrcvi=0.2, decay_rate=0.95, stddev_init_nn=0.1, seed=3)
         tr_e = fresh()
+        phi_first = [t.detach().clone() for t in tr_e.phi_gmm]
         el_e = [float(tr_e.step(ys[i])['elbo']) for i in range(4)]
         want = [t.detach().clone() for t in tr_e.trainables()[1]] + [t.clone() for t in tr_e.theta]
+        Xte_e = (torch.randn(96, Dg, device='cuda', generator=torch.Generator(device='cuda').manual_seed(23)) * 2)
+        lab_e = torch.randint(0, 3, (96,), device='cuda', generator=torch.Generator(device='cuda').manual_seed(24)).float()
+        m_e = experiments.evaluate(tr_e, Xte_e, lab_e, 4, seed=0)
+        res['dpg_eval_eager'] = np.array([m_e[k_] for k_ in sorted(m_e)], dtype=np.float64)
         tr_g = fresh()
         gs = GraphedSVAEStep(tr_g, ys[0], warmup=2)
         res['dpg_two_graphs'] = np.int64(gs.graph_back is not None)
@@ -100,6 +105,28 @@ def main():
         res['dpg_param_err'] = np.array([((a.detach() - b).abs().max() / b.abs().max().clamp_min(1e-30)).item() for a, b in zip(got, want)])
         res['dpg_params'] = np.concatenate([t.detach().cpu().numpy().reshape(-1) for t in got])
         res['dpg_steps'] = np.array([tr_g.global_step, tr_g.opt.t])
+        # round 6: what runs AFTER graphed data-parallel steps must not depend on torch's device solvers - evaluation
+        # metrics of the graphed trainer against the eager one's, and the package's K-sized factorisations (host LAPACK through
+        # _klinalg) on device tensors against the same call on host tensors; the raw device Cholesky is recorded, not asserted
+        from vmp_for_svae_amd.distributions import gaussian, niw
+        from vmp_for_svae_amd.models import svae as svae_mod
+        Xte = (torch.randn(96, Dg, device='cuda', generator=torch.Generator(device='cuda').manual_seed(23)) * 2)
+        lab = torch.randint(0, 3, (96,), device='cuda', generator=torch.Generator(device='cuda').manual_seed(24)).float()
+        m_g = experiments.evaluate(tr_g, Xte, lab, 4, seed=0)
+        res['dpg_eval_graphed'] = np.array([m_g[k_] for k_ in sorted(m_g)], dtype=np.float64)
+        res['dpg_eval_keys'] = np.array(sorted(m_g))
+        gh = torch.Generator().manual_seed(5)
+        A_ = torch.randn(Kg, Lg, Lg, generator=gh)
+        spd = A_ @ A_.transpose(-1, -2) + Lg * torch.eye(Lg)
+        mu_ = torch.randn(Kg, Lg, generator=gh)
+        dev_out = list(gaussian.standard_to_natural(mu_.cuda(), spd.cuda())) + list(gaussian.natural_to_standard(*gaussian.standard_to_natural(mu_.cuda(), spd.cuda()))) \
+            + [niw._inv(spd.cuda()), svae_mod._recognition_bias(mu_.cuda(), -0.5 * spd.cuda(), torch.softmax(mu_[:, 0], 0).cuda())[1]]
+        host_out = list(gaussian.standard_to_natural(mu_, spd)) + list(gaussian.natural_to_standard(*gaussian.standard_to_natural(mu_, spd))) \
+            + [niw._inv(spd), svae_mod._recognition_bias(mu_, -0.5 * spd, torch.softmax(mu_[:, 0], 0))[1]]
+        res['dpg_klinalg_err'] = np.array([((a.cpu() - b).abs().max() / b.abs().max()).item() for a, b in zip(dev_out, host_out)])
+        res['dpg_raw_device_cholesky_err'] = np.float64((torch.linalg.cholesky(spd.cuda()).cpu() - torch.linalg.cholesky(spd)).abs().max().item())
+        tr_l = fresh()                                          # a trainer built after the graphed steps == one built before them
+        res['dpg_late_trainer_phi_err'] = np.float64(max((a.detach() - b.detach()).abs().max().item() for a, b in zip(tr_l.phi_gmm, phi_first)))
     except Exception as e:
         import traceback
         res['dpg_error'] = np.array(traceback.format_exc())

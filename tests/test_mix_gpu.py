@@ -426,36 +426,3 @@ def test_uneven_wave_shares_cover_every_row_once(flavour, N, D, K):
     sx = w.t() @ xd.double()
     assert ((st[:, 2:2 + D] - sx).abs().max() / sx.abs().max()).item() < 1e-6
     assert abs(st[:, 0].sum().item() - rs.sum().item()) < 1e-6 * N
-
-
-@pytest.mark.parametrize('flavour,N,D,K', [('gmm', 1_000_000, 8, 16), ('smm', 1_000_000, 8, 16), ('gmm', 100_000, 2, 10),
-                                           ('gmm', 125_000, 8, 16), ('smm', 40_001, 5, 7), ('gmm', 9_000, 8, 16),
-                                           ('gmm', 3_000, 3, 4), ('gmm', 50_000, 6, 33)])
-def test_one_launch_step_is_bit_identical_to_the_two_launch_form(flavour, N, D, K):
-    """vmp_mix_step (round 5: the K-sized posterior runs in the heads of blocks 0..K-1 of the streaming launch, its pack row
-    published to the waves of the SAME launch through write-through stores and sequence words) against the two launches it
-    fuses (vmp_mix_finalize_ws + vmp_mix_estep_fused, gmm.py:258-263): responsibilities, u, every posterior tensor and the
-    moments after 5 iterations must agree bit for bit, no wave may have timed out, and a second run must reproduce the first
-    (shapes: C3 / C5 / C2 / the 8-GPU strong-scaling shard / ragged / fewer blocks than CUs / shapes that fall back to two
-    launches: too few rows for K full blocks, K > 16)."""
-    from vmp_for_svae_amd import _lib as L
-    from vmp_for_svae_amd.models import _mix
-    flav = L.VMP_SMM if flavour == 'smm' else L.VMP_GMM
-    g = torch.Generator(device='cuda').manual_seed(N % 9973 + K)
-    c = torch.randn(K, D, device='cuda', generator=g) * 5
-    x = c[torch.randint(0, K, (N,), device='cuda', generator=g)] + torch.randn(N, D, device='cuda', generator=g)
-    r0 = torch.softmax(3 * torch.randn(N, K, device='cuda', generator=g), 1)
-    kap = torch.full((K,), 5.0, device='cuda') if flav == L.VMP_SMM else None
-    outs = []
-    for mode in (False, True, True):
-        loop = _mix.VMPLoop(x, r0, flav, kappa=kap, one_launch=mode)
-        for _ in range(3):
-            loop.step()
-        loop.run(2)
-        if mode:
-            loop.check()
-        outs.append([loop.r.clone()] + ([loop.u.clone()] if loop.u is not None else []) + [v.clone() for v in loop.post.values()]
-                    + [loop.stats.clone()])
-    for name, other in (('one launch vs two', outs[1]), ('one launch, second run', outs[2])):
-        for a, b in zip(outs[0], other):
-            assert torch.equal(a, b) or (torch.isnan(a) == torch.isnan(b)).all() and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)), name

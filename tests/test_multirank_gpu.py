@@ -229,6 +229,23 @@ def test_data_parallel_graphed_step_matches_the_eager_step(two_ranks):
     assert np.array_equal(ranks[0]['dpg_elbo_graphed'], ranks[1]['dpg_elbo_graphed'])
 
 
+def test_nothing_after_graphed_data_parallel_steps_depends_on_device_solvers(two_ranks):
+    """after graphed data-parallel steps torch's device Cholesky returned a wrong factor (first call, two processes
+    on one GPU; pinned down in round 6: inputs bit-equal, only the solver output wrong - tools/r6_dpg_repro.py).  What the package
+    does afterwards must not go through it: evaluation metrics of the graphed trainer == the eager trainer's, the K-sized
+    factorisations behind gaussian / niw / svae (host LAPACK, _klinalg) on device tensors == on host tensors, and a trainer built
+    after the graphed steps == one built before them.  The raw device Cholesky error is logged (parity log), not asserted."""
+    import parity_log
+    _, ranks = two_ranks
+    for r in ranks:
+        assert 'dpg_error' not in r.files, str(r['dpg_error'])
+        assert list(r['dpg_eval_keys']) and np.allclose(r['dpg_eval_graphed'], r['dpg_eval_eager'], rtol=5e-4, atol=1e-6), (r['dpg_eval_keys'], r['dpg_eval_graphed'], r['dpg_eval_eager'])
+        assert float(r['dpg_klinalg_err'].max()) <= 1e-5, r['dpg_klinalg_err']
+        assert float(r['dpg_late_trainer_phi_err']) <= 1e-6
+        parity_log.record('abs', float(r['dpg_raw_device_cholesky_err']), None, 'raw torch.linalg.cholesky on the device after graphed data-parallel steps (not asserted)')
+    assert np.array_equal(ranks[0]['dpg_eval_graphed'], ranks[1]['dpg_eval_graphed'])
+
+
 def test_c_abi_rccl_communicator_single_rank():
     """vmp_comm_* + vmp_pack_allreduce (the exchange a non-torch host binds): a 1-rank RCCL communicator leaves the packed
     buffer unchanged, and DistributedVMPLoop driven through it reproduces the plain loop."""

@@ -631,28 +631,3 @@ def test_subsample_inverse_cdf(N, K, S, Ld):
     zi = rng.integers(0, K, size=(N, S))
     out2 = svae.subsample_x(dev(x), dev(lz), z_draws=dev(zi, torch.int64)).cpu().numpy()
     assert np.array_equal(out2, x[np.arange(N)[:, None], zi, np.arange(S)[None, :]])
-
-
-@pytest.mark.gpu
-def test_graphed_step_with_side_stream_branches_is_bit_identical():
-    """GraphedSVAEStep(fork=True) captures independent kernels of the step (experiments.py:196-267 at minibatch 64) on side streams
-    - parallel branches of the HIP graph; autograd puts the backward of the forked prep on its own branch.  Measured slower than the
-    one-stream capture (profiles/r05_minibatch_fork_ab.txt) and off by default; what it computes must still be the same step."""
-    from vmp_for_svae_amd.models import vae
-    from vmp_for_svae_amd.training import SVAETrainer, GraphedSVAEStep
-    dev = torch.device('cuda', 0)
-    outs = []
-    for fork in (False, True):
-        vae.reset_variables()
-        g = torch.Generator(device=dev).manual_seed(11)
-        y = torch.randn(64, 6, device=dev, generator=g) * 2
-        tr = SVAETrainer(10, 8, 50, 6, nb_samples=10, device=dev)
-        gs = GraphedSVAEStep(tr, y, fork=fork)
-        for _ in range(4):
-            out = gs(y)
-        torch.cuda.synchronize()
-        _, params = tr.trainables()
-        outs.append((float(out['elbo']), [p.detach().clone() for p in params], [t.detach().clone() for t in tr.theta]))
-    assert outs[0][0] == outs[1][0]
-    for a, b in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):
-        assert torch.equal(a, b)

@@ -32,8 +32,6 @@ _SIGNATURES = {
     'vmp_mix_estep_fused': (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
     'vmp_mix_stats_ws': (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _P, _c.c_size_t, _P]),
     'vmp_mix_iterate': (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int] + [_P] * 7 + [_P] * 11 + [_P, _c.c_size_t, _c.c_int, _P]),
-    'vmp_mix_step': (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int] + [_P] * 7 + [_P] * 12 + [_P, _c.c_size_t, _c.c_uint64, _c.c_int, _P]),
-    'vmp_mix_step_status': (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _P]),
     'vmp_svae_estep_fwd': (_c.c_int, [_P] * 10 + [_c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P]),
     'vmp_svae_rng_in_kernel': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int]),
     'vmp_svae_philox_noise': (_c.c_int, [_c.c_uint64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P]),

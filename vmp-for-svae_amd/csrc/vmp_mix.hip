@@ -663,9 +663,6 @@ __global__ __launch_bounds__(max_nw(KT) * WAVE) void pass_kernel(PassArgs a) {
 // coordinates 0..3 (operands of the one-MFMA tiles, see below) | pad; 144 B = 9 16-byte slots: 16 rows hit 16 bank groups
 constexpr int AIS = 36;
 
-#ifndef VMP_STEP_SCOPE
-#define VMP_STEP_SCOPE __HIP_MEMORY_SCOPE_SYSTEM     // scope of the tagged-pack stores / loads of the one-launch step (A/B builds: __HIP_MEMORY_SCOPE_AGENT)
-#endif
 struct FinArgs {
     const double* partials;    // [K][MAX_BLOCKS][PF + 1]   (src == 0)
     const double* stats_in;    // [K][SW]         (src == 1)
@@ -679,12 +676,6 @@ struct FinArgs {
     int nranks, rank;
     unsigned long long iter;
     int* status;
-    // one-launch step (vmp_mix_step): the block runs as the HEAD of the streaming launch.  Every pack word is ALSO written as a
-    // self-validating 64-bit word (iteration tag << 32 | float bits) with a system-scope write-through store into tpack
-    // (K x PACK words); the waves of the same launch poll those words: data and "ready" arrive in one memory round trip, and the
-    // writer never waits (a separate sequence word behind a drained store queue cost two more round trips: +3.5 us per step).
-    unsigned long long* tpack;
-    unsigned tag;
 #ifdef VMP_DEBUG_TS
     long long* dbg_t;          // exploration builds only: 8 timestamps of block 0 / thread 0
 #endif
@@ -701,16 +692,12 @@ __device__ void finalize_block(const FinArgs& a, const int k, const int tid, con
 
 template <int D> constexpr int xdl_wave_floats() { return Geo<D>::XROWS * LS + TR * AIS; }
 
-// HEAD = true (vmp_mix_step, the one-launch iteration): blocks 0..K-1 first run finalize_block on the partials the PREVIOUS launch
-// left (visible across the kernel boundary) and publish their pack row; every wave of the launch stages its first rows, then polls
-// the K sequence words and reads the pack with system-scope loads (no cache between XCDs holds it).  All blocks wait for all K
-// words, so nobody overwrites a partial row that a head block has not read yet.
 // MT: bf16 terms per operand of the MOMENT GEMM.  3 (six products: fp32-equivalent products) below VMP_MOM2_ROWS rows; 2 (three
 // products, 2^-17 relative per product, unbiased) from there on: every moment is then a sum over >= 1e4 rows per component whose
 // per-term rounding errors average out (relative error of a moment ~ 2^-17 / sqrt(rows of the component) < 1e-7), while the splits
 // and MFMAs they save are a fifth of the kernel's issue time (round 5).  The E-part (one value per row, nothing averages) keeps 3.
-template <int D, int FLAV, bool STATS, bool HEAD, int MT = 3>
-__device__ __forceinline__ void pass_xdl_body(const PassArgs& a, const FinArgs* fin) {
+template <int D, int FLAV, bool STATS, int MT = 3>
+__device__ __forceinline__ void pass_xdl_body(const PassArgs& a) {
     using G = Geo<D>;
     constexpr int FT = G::FT, KT = 1;
     constexpr bool SMM = (FLAV == VMP_SMM);
@@ -733,11 +720,6 @@ __device__ __forceinline__ void pass_xdl_body(const PassArgs& a, const FinArgs* 
         *reinterpret_cast<u32x4*>(ai + lane * AIS + 16) = zeros;
     }
 
-    // HEAD: the K-sized posterior first - it is the head of the launch's critical path; the block's first rows are requested after it
-    // (the other blocks request theirs at once and then wait for the pack)
-    if constexpr (HEAD) {
-        if ((int)blockIdx.x < K) finalize_block<D>(*fin, (int)blockIdx.x, (int)threadIdx.x, (int)blockDim.x);
-    }
     const bool vec = a.vec_ok != 0;
     long long lo, hi;
     if (a.rpw_b == a.rpw) {
@@ -772,46 +754,11 @@ __device__ __forceinline__ void pass_xdl_body(const PassArgs& a, const FinArgs* 
     u32x4 Bsm[NS], B1[NB > 0 ? NB : 1], B2[NB > 0 ? NB : 1];
     v2f pch;
     float pua, pub;
-    __shared__ float spk[HEAD ? 16 * G::PACK : 1];           // HEAD: the block's copy of the K pack rows
-    if constexpr (HEAD) {
-        // ONE wave per block polls the tagged pack (K x PACK 64-bit words, all loads of a round in flight together) until every
-        // word carries this launch's tag, and drops the values into LDS for the block - 2 048 waves polling and reading the same
-        // lines with system-scope loads made one memory channel the bottleneck of the launch (+18 us).  Bounded: ~2 s, then
-        // status = 2 and the launch runs on.
-        if (wave == 0) {
-            constexpr int NLD = (16 * G::PACK + WAVE - 1) / WAVE;
-            const unsigned want = fin->tag;
-            const long long t0 = wall_clock64();             // 100 MHz
-            unsigned long long pk[NLD];
-            for (;;) {
-                bool fresh = true;
-#pragma unroll
-                for (int q = 0; q < NLD; ++q) {              // all loads of a round in flight together
-                    const int e = q * WAVE + lane;
-                    pk[q] = __hip_atomic_load(fin->tpack + (e < K * G::PACK ? e : 0), __ATOMIC_RELAXED, VMP_STEP_SCOPE);
-                }
-#pragma unroll
-                for (int q = 0; q < NLD; ++q) fresh = fresh && (unsigned)(pk[q] >> 32) == want;
-                if (__builtin_amdgcn_ballot_w64(!fresh) == 0ull) break;
-                if (wall_clock64() - t0 > 200000000ll) { if (lane == 0 && fin->status) *fin->status = 2; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-#pragma unroll
-            for (int q = 0; q < NLD; ++q) {
-                const int e = q * WAVE + lane;
-                if (e < K * G::PACK) spk[e] = __uint_as_float((unsigned)pk[q]);
-            }
-        }
-        __syncthreads();
-    }
     {
         const bool on = i16 < K;
         const float* __restrict__ p = a.pack + (on ? i16 : 0) * G::PACK;
         float raw[G::PACK];
-        if constexpr (HEAD) {
-#pragma unroll
-            for (int j = 0; j < G::PACK; ++j) raw[j] = spk[(on ? i16 : 0) * G::PACK + j];
-        } else if (G::PACK % 4 == 0 && (reinterpret_cast<uintptr_t>(a.pack) & 15) == 0) {
+        if (G::PACK % 4 == 0 && (reinterpret_cast<uintptr_t>(a.pack) & 15) == 0) {
 #pragma unroll
             for (int j = 0; j < G::PACK / 4; ++j) {
                 const float4 q = reinterpret_cast<const float4*>(p)[j];
@@ -1126,14 +1073,7 @@ __device__ __forceinline__ void pass_xdl_body(const PassArgs& a, const FinArgs* 
 
 template <int D, int FLAV, bool STATS, int MT = 3>
 __global__ __launch_bounds__(MAX_NW1 * WAVE) void pass_xdl_kernel(PassArgs a) {
-    pass_xdl_body<D, FLAV, STATS, false, MT>(a, nullptr);
-}
-
-// The whole VMP iteration (gmm.py:258-263 / smm.py:232-238) as ONE launch: K-sized posterior in the heads of blocks 0..K-1,
-// streaming E-pass with fused moments in all blocks.
-template <int D, int FLAV, int MT = 3>
-__global__ __launch_bounds__(MAX_NW1 * WAVE) void step_xdl_kernel(PassArgs a, FinArgs f) {
-    pass_xdl_body<D, FLAV, true, true, MT>(a, &f);
+    pass_xdl_body<D, FLAV, STATS, MT>(a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1281,12 +1221,7 @@ __device__ void estep_constants(int k, int flavour, double alpha_k, double alpha
 constexpr int FIN_THREADS = 1024;
 constexpr int FIN_MAX_GROUPS = FIN_THREADS / 64;
 
-// a pack word: plain store + (one-launch step) the tagged system-scope copy that the waves of the same launch poll
-__device__ __forceinline__ void st_pack(const FinArgs& a, int idx, float v) {
-    a.pack[idx] = v;
-    if (a.tpack)
-        __hip_atomic_store(a.tpack + idx, ((unsigned long long)a.tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, VMP_STEP_SCOPE);
-}
+__device__ __forceinline__ void st_pack(const FinArgs& a, int idx, float v) { a.pack[idx] = v; }
 
 // One block per component (k), `nthreads` threads (>= 192, a multiple of 64; the stand-alone kernel: 1024, the head of the
 // one-launch step: the streaming block's 512).  Phase A: all threads reduce the per-block partials in a fixed order.
@@ -1817,44 +1752,10 @@ int run_finalize(FinArgs f, int D, hipStream_t s) {
     return rc;
 }
 
-// workspace layout: [per-block partials | tagged pack of the one-launch step: 16 x PACK 64-bit words | status word]
+// workspace layout: [per-block partials | reserved words (zeroed by vmp_mix_stats_ws) | status word]
 constexpr size_t WS_TPACK_WORDS = 16 * (VMP_MAX_D + VMP_MAX_D * (VMP_MAX_D + 1) / 2 + 4);
 inline size_t ws_partial_bytes(int D, int K) { return (size_t)MAX_BLOCKS * K * (partial_words(D) + 1) * sizeof(double); }
 inline unsigned long long* ws_seq(void* ws, int D, int K) { return reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + ws_partial_bytes(D, K)); }
-inline int* ws_status(void* ws, int D, int K) { return reinterpret_cast<int*>(ws_seq(ws, D, K) + WS_TPACK_WORDS); }
-
-// one-launch iteration: 1 = launched, 0 = this shape takes the two-launch form (K > 16, too few rows for full blocks), < 0 / > 1: error
-template <int D>
-int launch_step_xdl(const PassArgs& a, const FinArgs& f, const Plan& p, int flavour, hipStream_t s) {
-    dim3 grid(p.blocks), block(p.nw * WAVE);
-#define VMP_LAUNCH_S(FL, M) do { \
-        if (p.lds > 48 * 1024) { if (const int rc_ = set_dyn_lds(reinterpret_cast<const void*>(step_xdl_kernel<D, FL, M>), p.lds, "step_xdl_kernel")) return rc_; } \
-        hipLaunchKernelGGL((step_xdl_kernel<D, FL, M>), grid, block, p.lds, s, a, f); } while (0)
-    const bool m2 = a.N >= VMP_MOM2_ROWS;
-    if (flavour == VMP_GMM) { if (m2) VMP_LAUNCH_S(VMP_GMM, 2); else VMP_LAUNCH_S(VMP_GMM, 3); }
-    else { if (m2) VMP_LAUNCH_S(VMP_SMM, 2); else VMP_LAUNCH_S(VMP_SMM, 3); }
-#undef VMP_LAUNCH_S
-    const int rc = check_launch("step_xdl_kernel");
-    return rc ? rc : 1;
-}
-
-int run_step(PassArgs a, FinArgs f, int D, int flavour, hipStream_t s) {
-    if (!use_xdl(a.K, true, false)) return 0;
-    Plan p = make_plan(a.N, D, a.K, flavour, true, true);
-    // every block needs the full complement of waves (the head runs on the block's own threads: >= 192) and the K heads need K blocks
-    if (p.nw != MAX_NW1 || p.blocks < a.K) return 0;
-    a.rpw = p.rpw;
-    a.rpw_b = p.rpw_b;
-    a.par_reduce = p.par_reduce;
-    f.nblk = p.blocks;
-#ifdef VMP_DEBUG_TS
-    a.dbg_t = g_dbg_pass;
-    f.dbg_t = g_dbg_t;
-#endif
-    int rc = -1;
-    VMP_DISPATCH_D(D, rc = launch_step_xdl<DD>(a, f, p, flavour, s));
-    return rc;
-}
 
 }  // namespace
 
@@ -1873,7 +1774,7 @@ int vmp_mix_stats_words(int D) { return stats_words(D); }
 
 size_t vmp_mix_workspace_bytes(int64_t N, int D, int K) {
     (void)N;
-    // [K][MAX_BLOCKS][PF + 1] per-block partials | sequence words + status of the one-launch step (vmp_mix_step)
+    // [K][MAX_BLOCKS][PF + 1] per-block partials | reserved words + status
     return ws_partial_bytes(D, K) + (WS_TPACK_WORDS + 2) * sizeof(unsigned long long);
 }
 
@@ -1993,7 +1894,7 @@ int vmp_mix_stats_ws(const float* x, const float* r, const float* u, const float
     PassArgs a{};
     a.x = x; a.r_in = r; a.u_in = u; a.pivot = pivot; a.N = N; a.K = K; a.partials = static_cast<double*>(ws);
     a.vec_ok = aligned16(x) && aligned16(r) && (!u || aligned16(u));
-    // this call seeds the workspace of an iteration loop: the sequence words and the status of vmp_mix_step start at zero
+    // this call seeds the workspace of an iteration loop: the reserved words and the status word start at zero
     hipError_t e = hipMemsetAsync(ws_seq(ws, D, K), 0, (WS_TPACK_WORDS + 2) * sizeof(unsigned long long), static_cast<hipStream_t>(stream));
     if (e != hipSuccess) { set_error("vmp_mix_stats_ws: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
     return run_pass(a, D, u ? VMP_SMM : VMP_GMM, false, true, false, static_cast<hipStream_t>(stream));
@@ -2056,49 +1957,6 @@ int vmp_mix_iterate(const float* x, int64_t N, int D, int K, int flavour, const 
         rc = vmp_mix_estep_fused(x, N, D, K, flavour, pack, r, u, nullptr, pivot, ws, ws_bytes, stream);
         if (rc) return rc;
     }
-    return 0;
-}
-
-int vmp_mix_step(const float* x, int64_t N, int D, int K, int flavour, const float* alpha0, const float* beta0,
-                 const float* m0, const float* C0, const float* v0, const float* kappa, const float* pivot,
-                 float* r, float* u, float* logr, float* alpha, float* beta, float* m, float* C, float* v, float* xbar, float* S,
-                 float* pi, float* pack, void* ws, size_t ws_bytes, uint64_t first_iteration, int iterations, void* stream) {
-    int rc = check_dims(N, D, K);
-    if (rc) return rc;
-    if (iterations < 0 || first_iteration < 1 || !x || !r || !pack || !ws || !alpha0 || !beta0 || !m0 || !C0 || !v0) { set_error("vmp_mix_step: bad argument"); return VMP_E_BADARG; }
-    if (flavour != VMP_GMM && flavour != VMP_SMM) { set_error("vmp_mix_step: bad flavour %d", flavour); return VMP_E_BADARG; }
-    if (flavour == VMP_SMM && (!u || !kappa)) { set_error("vmp_mix_step: SMM needs u and kappa"); return VMP_E_BADARG; }
-    if (ws_bytes < vmp_mix_workspace_bytes(N, D, K)) { set_error("vmp_mix_step: workspace too small"); return VMP_E_WS; }
-    for (int it = 0; it < iterations; ++it) {
-        PassArgs a{};
-        a.x = x; a.pack = pack; a.r_out = r; a.u_out = u; a.logr_out = logr; a.pivot = pivot;
-        a.N = N; a.K = K; a.partials = static_cast<double*>(ws);
-        a.vec_ok = aligned16(x) && aligned16(r) && (!u || aligned16(u)) && (!logr || aligned16(logr));
-        FinArgs f{};
-        f.partials = static_cast<const double*>(ws);
-        f.K = K; f.flavour = flavour; f.src = 0; f.do_post = 1;
-        f.alpha0 = alpha0; f.beta0 = beta0; f.m0 = m0; f.C0 = C0; f.v0 = v0; f.kappa = kappa;
-        f.alpha = alpha; f.beta = beta; f.m = m; f.C = C; f.v = v; f.xbar = xbar; f.S = S; f.pi = pi; f.pack = pack;
-        f.pivot = pivot;
-        f.tpack = ws_seq(ws, D, K); f.tag = (unsigned)((first_iteration + (uint64_t)it) % 0xffffffffull) + 1u;   /* never 0: the cleared workspace */ f.status = ws_status(ws, D, K);
-        rc = run_step(a, f, D, flavour, static_cast<hipStream_t>(stream));
-        if (rc == 1) continue;
-        if (rc != 0) return rc;
-        // shapes outside the one-launch form: the two launches it fuses
-        rc = vmp_mix_finalize_ws(ws, pivot, N, D, K, flavour, alpha0, beta0, m0, C0, v0, kappa, alpha, beta, m, C, v, xbar, S, pi,
-                                 pack, nullptr, stream);
-        if (rc) return rc;
-        rc = vmp_mix_estep_fused(x, N, D, K, flavour, pack, r, u, logr, pivot, ws, ws_bytes, stream);
-        if (rc) return rc;
-    }
-    return 0;
-}
-
-int vmp_mix_step_status(const void* ws, int D, int K, int* status_out, void* stream) {
-    if (!ws || !status_out || D < 1 || D > VMP_MAX_D || K < 1 || K > VMP_MAX_K) { set_error("vmp_mix_step_status: bad argument"); return VMP_E_BADARG; }
-    hipError_t e = hipMemcpyAsync(status_out, ws_status(const_cast<void*>(ws), D, K), sizeof(int), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream));
-    if (e == hipSuccess) e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
-    if (e != hipSuccess) { set_error("vmp_mix_step_status: %s", hipGetErrorString(e)); return (int)e; }
     return 0;
 }
 

@@ -941,9 +941,6 @@ int launch_n(const EBwdArgs& a, int nblk_abi, void* stream) {
     const size_t budget = vmp::lds_budget() / sizeof(float);
     int nw = budget > (size_t)tab ? (int)((budget - tab) / per_wave) : 0;
     if (nw > maxw) nw = maxw;
-#ifdef VMP_RING_MAXW
-    if (nw > VMP_RING_MAXW) nw = VMP_RING_MAXW;            // A/B builds: fewer waves per CU
-#endif
     if (nw < 4) return -2;
     const long long ntiles = (a.N + RPT - 1) / RPT;
     long long bl = (ntiles + nw - 1) / nw;
@@ -955,20 +952,10 @@ int launch_n(const EBwdArgs& a, int nblk_abi, void* stream) {
     return check_launch("svae_estep_bwd_ring_kernel");
 }
 
-#ifndef VMP_RING_STAGES
-#define VMP_RING_STAGES 2      // 2: eight waves per CU, two stages each (shipped).  4: one wave per SIMD, four stages, where S / 2 >= 4 and
-#endif                         //    the batch has >= 1024 wave tiles - measured SLOWER; A/B builds only
+// (The kernel template still carries NSTG: the four-stage, one-wave-per-SIMD form measured SLOWER in round 4 - profiles/NOTES_r01-r04.md -
+//  and is no longer instantiated or selectable; the shipped form is NSTG = 2: eight waves per CU, two stages each.)
 template <int L, int KS, bool STUDENT>
 int launch(const EBwdArgs& a, int nblk_abi, void* stream) {
-    if constexpr (VMP_RING_STAGES == 4) {
-        const long long ntiles = (a.N + WAVE / a.K - 1) / (WAVE / a.K);
-        // four stages need S / 2 >= 4 pairs per tile (a request never runs more than one tile ahead) and enough tiles to give every
-        // one of the 1024 waves of the chip work; smaller batches keep the eight-wave form
-        if ((a.S >> 1) >= 4 && ntiles >= 1024) {
-            const int rc = launch_n<L, KS, STUDENT, 4>(a, nblk_abi, stream);
-            if (rc != -2) return rc;
-        }
-    }
     return launch_n<L, KS, STUDENT, 2>(a, nblk_abi, stream);
 }
 

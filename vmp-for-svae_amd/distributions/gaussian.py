@@ -6,17 +6,19 @@ training step uses).
 """
 import torch
 
+from .. import _klinalg
+
 
 def standard_to_natural(mu, sigma, name='gauss_to_nat'):
     """reference gaussian.py:11-19: eta2 = -1/2 Sigma^-1, eta1 = Sigma^-1 mu."""
-    prec = torch.linalg.inv(sigma)
+    prec = _klinalg.inv(sigma)
     eta1 = torch.einsum('...ij,...j->...i', prec, mu)
     return eta1, -0.5 * prec
 
 
 def natural_to_standard(eta1, eta2, name='gauss_to_stndrd'):
     """reference gaussian.py:22-27: Sigma = (-2 eta2)^-1, mu = Sigma eta1."""
-    sigma = torch.linalg.inv(-2.0 * eta2)
+    sigma = _klinalg.inv(-2.0 * eta2)
     return torch.einsum('...ij,...j->...i', sigma, eta1), sigma
 
 

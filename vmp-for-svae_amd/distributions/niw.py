@@ -5,9 +5,11 @@ device they live on (autograd-capable).  Symmetric-positive-definite inverses go
 """
 import torch
 
+from .. import _klinalg
+
 
 def _spd_inverse(M):
-    return torch.cholesky_inverse(torch.linalg.cholesky(M))
+    return _klinalg.cholesky_inverse_spd(M)
 
 
 def _rank1(u, w):

@@ -111,7 +111,13 @@ def run(config, nb_iters=2000, size_minibatch=100, nb_samples=10, nb_samples_te=
     gradients over ranks (helpers/tf_utils.py:52-87), i.e. the run equals the reference's nb_gpu = world run; a
     single-process run on the whole minibatch SUMS the gradient over all rows instead (world x larger gradient).
     Rank 0 alone prints and writes checkpoints (every rank holds identical parameters); metrics are evaluated by all
-    ranks, identically."""
+    ranks, identically.
+    graph: True = capture the fixed-size training step once as a HIP graph and replay it - single-process runs only; a
+    data-parallel run (several ranks) steps eagerly unless graph='dp' asks for the two-graphs-around-the-collective form
+    (training.GraphedSVAEStep, round 5).  It is opt-in because of a finding that is not ours to fix: after HIP-graph replays in a
+    process that shares its GPU with another rank, torch's device Cholesky has returned a wrong factor on its first call
+    (tools/r6_dpg_repro.py, profiles/r06_dpg_linalg.txt); this package keeps every K-sized factorisation on the host
+    (_klinalg), but a caller's own GPU linalg after such a run is exposed."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank(group) if world > 1 else 0
@@ -128,7 +134,6 @@ def run(config, nb_iters=2000, size_minibatch=100, nb_samples=10, nb_samples_te=
                      lrcvi=config['lrcvi'], decay_rate=config.get('decay_rate', 1), seed=config.get('seed', 0),
                      device=dev, smm=smm, dof=config.get('DoF', 5), group=group)
     batches = data_mod.minibatches_device(Xtr, size_minibatch, seed=config.get('seed', 0), rank=rank, world=world)
-    # (the data-parallel step is captured as well: two graphs around its one collective, training.GraphedSVAEStep)
     log_id = generate_log_id(config)
     missing_data_mask = losses.generate_missing_data_mask(Xte, ratio_missing_data, seed=config.get('seed', 0))
     history = []
@@ -137,7 +142,7 @@ def run(config, nb_iters=2000, size_minibatch=100, nb_samples=10, nb_samples_te=
     stepper = None
     for i in range(nb_iters):
         yb = next(batches)
-        if graph and dev.type == 'cuda':
+        if graph and dev.type == 'cuda' and (world == 1 or graph == 'dp'):
             if stepper is None:
                 from .training import GraphedSVAEStep
                 stepper = GraphedSVAEStep(tr, yb)

@@ -1,11 +1,13 @@
 """Mirror of the hot-path part of reference helpers/tf_utils.py (logdet :25-49, average_gradients :52-87)."""
 import torch
 
+from .. import _klinalg
+
 
 def logdet(A, name='logdet'):
     """log det of SPD matrices (..., D, D) = 2 * sum log diag chol(A)  (reference tf_utils.py:25-49).
     K-sized use only; the per-(n,k) log-determinants of the hot path live inside the HIP kernels."""
-    return 2.0 * torch.linalg.cholesky(A).diagonal(dim1=-2, dim2=-1).log().sum(-1)
+    return 2.0 * _klinalg.cholesky(A).diagonal(dim1=-2, dim2=-1).log().sum(-1)
 
 
 def average_gradients(tower_grads):

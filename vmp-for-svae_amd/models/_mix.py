@@ -141,13 +141,10 @@ class VMPLoop(object):
       vmp_mix_estep_fused  (streaming)  E-pass that also accumulates the raw moments of ITS OWN output,
     which are exactly the M-pass input of the next iteration; only the very first iteration needs a
     stand-alone M-pass (vmp_mix_stats_ws).
-    one_launch=True (or VMP_T1_ONE_LAUNCH=1): the same iteration as ONE launch (vmp_mix_step, round 5: the K-sized posterior runs
-    in the heads of blocks 0..K-1 of the streaming launch and hands its pack to the waves of the same launch through tagged
-    write-through words).  Bit-identical results (tests/test_mix_gpu.py) - and no faster on MI355X: a coherent store -> poll ->
-    load hand-off between XCDs costs what the kernel boundary it replaces costs, so the
-    two-launch form stays the default."""
+    (A one-launch form of the iteration - posterior in the heads of the streaming launch - was built and measured in round 5:
+    bit-identical and no faster; removed in round 6.)"""
 
-    def __init__(self, x, r_init, flavour, kappa=None, u_init=None, prior=None, one_launch=None):
+    def __init__(self, x, r_init, flavour, kappa=None, u_init=None, prior=None):
         self.x = L.dev_f32(x, 'x')
         self.N, self.D = self.x.shape
         self.K = K = r_init.shape[1]
@@ -174,10 +171,6 @@ class VMPLoop(object):
         L.check(L.lib().vmp_mix_stats_ws(L.ptr(self.x), L.ptr(self.r), L.ptr(self.u), L.ptr(self.pivot), self.N, D, K,
                                          L.ptr(self.ws), self.nb, L.stream()), 'vmp_mix_stats_ws')
         self.iterations = 0
-        if one_launch is None:
-            one_launch = os.environ.get('VMP_T1_ONE_LAUNCH', '0') == '1'
-        self.one_launch = bool(one_launch)
-        self._seq = 0                                                     # launches of vmp_mix_step this workspace has seen
 
     def finalize(self, stats_out=None):
         p, pr = self.post, self.prior
@@ -188,24 +181,11 @@ class VMPLoop(object):
                                             L.ptr(p['pack']), L.ptr(stats_out), L.stream()), 'vmp_mix_finalize_ws')
 
     def finalize_phase(self):
-        """everything of an iteration that is not the streaming launch (bench.py brackets that launch with events): nothing in the
-        one-launch form, the finalize launch in the two-launch form"""
-        if not self.one_launch:
-            self.finalize()
-
-    def _steps(self, n, want_logr=False):
-        p, pr = self.post, self.prior
-        L.check(L.lib().vmp_mix_step(L.ptr(self.x), self.N, self.D, self.K, self.flavour, L.ptr(pr[0]), L.ptr(pr[1]),
-                                     L.ptr(pr[2]), L.ptr(pr[3]), L.ptr(pr[4]), L.ptr(self.kappa), L.ptr(self.pivot),
-                                     L.ptr(self.r), L.ptr(self.u), L.ptr(self.logr if want_logr else None),
-                                     L.ptr(p['alpha']), L.ptr(p['beta']), L.ptr(p['m']),
-                                     L.ptr(p['C']), L.ptr(p['v']), L.ptr(p['xbar']), L.ptr(p['S']), L.ptr(p['pi']),
-                                     L.ptr(p['pack']), L.ptr(self.ws), self.nb, self._seq + 1, int(n), L.stream()),
-                'vmp_mix_step')
-        self._seq += int(n)
+        """everything of an iteration that is not the streaming launch (bench.py brackets that launch with events): the finalize launch"""
+        self.finalize()
 
     def estep(self, want_logr=False):
-        """E-pass with fused moments on the current pack (the second launch of the two-launch form)"""
+        """E-pass with fused moments on the current pack (the second launch of an iteration)"""
         if want_logr and self.logr is None:
             self.logr = torch.empty_like(self.r)
         L.check(L.lib().vmp_mix_estep_fused(L.ptr(self.x), self.N, self.D, self.K, self.flavour, L.ptr(self.post['pack']),
@@ -213,13 +193,8 @@ class VMPLoop(object):
                                             L.ptr(self.pivot), L.ptr(self.ws), self.nb, L.stream()), 'vmp_mix_estep_fused')
 
     def stream_phase(self, want_logr=False):
-        """the streaming launch of an iteration: the whole iteration in the one-launch form, the E-pass in the two-launch form"""
-        if self.one_launch:
-            if want_logr and self.logr is None:
-                self.logr = torch.empty_like(self.r)
-            self._steps(1, want_logr)
-        else:
-            self.estep(want_logr)
+        """the streaming launch of an iteration: the E-pass with the moments of its own output"""
+        self.estep(want_logr)
 
     def step(self, want_logr=False):
         self.finalize_phase()
@@ -228,11 +203,7 @@ class VMPLoop(object):
         return self.r
 
     def run(self, iterations):
-        """`iterations` VMP iterations enqueued by one C call (vmp_mix_step / vmp_mix_iterate): no host work between launches."""
-        if self.one_launch:
-            self._steps(iterations)
-            self.iterations += int(iterations)
-            return self.r
+        """`iterations` VMP iterations enqueued by one C call (vmp_mix_iterate): no host work between launches."""
         p, pr = self.post, self.prior
         L.check(L.lib().vmp_mix_iterate(L.ptr(self.x), self.N, self.D, self.K, self.flavour, L.ptr(pr[0]), L.ptr(pr[1]),
                                         L.ptr(pr[2]), L.ptr(pr[3]), L.ptr(pr[4]), L.ptr(self.kappa), L.ptr(self.pivot),
@@ -242,14 +213,6 @@ class VMPLoop(object):
                 'vmp_mix_iterate')
         self.iterations += int(iterations)
         return self.r
-
-    def check(self):
-        """raise if a wave of a one-launch step gave up waiting for a pack row (synchronises the stream)"""
-        import ctypes
-        st = ctypes.c_int(0)
-        L.check(L.lib().vmp_mix_step_status(L.ptr(self.ws), self.D, self.K, ctypes.byref(st), L.stream()), 'vmp_mix_step_status')
-        if st.value != 0:
-            raise L.VmpError('vmp_mix_step: a wave timed out waiting for the posterior of its launch (status %d)' % st.value)
 
     @property
     def stats(self):

@@ -4,7 +4,7 @@ import threading
 
 import torch
 
-from .. import _lib as L
+from .. import _klinalg, _lib as L
 
 
 def _c(t, name, shape=None):
@@ -20,51 +20,6 @@ class GradSeed(object):
     def __init__(self, value, device):
         self.value = float(value)
         self.tensor = torch.full((), float(value), dtype=torch.float32, device=device)
-
-
-class StepFork(object):
-    """Side streams of a graph-captured training step (training.GraphedSVAEStep, round 5).  At the reference's operating point
-    (minibatches of 64-100 rows, experiments.py:26) every kernel of the step is a few microseconds of dependent latency, and a
-    capture on ONE stream chains them all; kernels that do not depend on each other - the noise generator, the K-sized
-    recognition-GMM prep and the encoder in front of the E-step; the CVI update beside the Adam step - are captured on side
-    streams instead, which makes them parallel branches of the graph (autograd runs a node's backward on the stream of its
-    forward, so the prep's backward becomes a branch beside the encoder's backward by itself).
-    run(name, fn): fn() on side stream `name`, which first waits for the current stream; join(names): the current stream waits
-    for those side streams.  Every fork must be joined before the capture ends."""
-
-    def __init__(self, device):
-        self.device = device
-        self.streams = {}
-        self.pending = set()
-
-    def run(self, name, fn):
-        main = torch.cuda.current_stream(self.device)
-        s = self.streams.get(name)
-        if s is None:
-            s = self.streams[name] = torch.cuda.Stream(device=self.device)
-        s.wait_stream(main)
-        with torch.cuda.stream(s):
-            out = fn()
-        stack = [out]
-        while stack:                                         # what the branch allocated is consumed on the main stream
-            o = stack.pop()
-            if isinstance(o, torch.Tensor):
-                if o.is_cuda:
-                    o.record_stream(main)
-            elif isinstance(o, (list, tuple)):
-                stack.extend(o)
-        self.pending.add(name)
-        return out
-
-    def join(self, *names):
-        main = torch.cuda.current_stream(self.device)
-        for n in names:
-            if n in self.pending:
-                main.wait_stream(self.streams[n])
-                self.pending.discard(n)
-
-
-FORK = None          # set by GraphedSVAEStep around its warm-up and capture only
 
 
 class PhiloxNoise(object):
@@ -340,7 +295,7 @@ def student_t_logprob(y, mu, sigma, v):
     if tuple(mu.shape) != (K, D) or tuple(sigma.shape) != (K, D, D) or tuple(v.shape) != (K,):
         raise AssertionError('shape mismatch')
     sig = sigma.double()
-    Lc = torch.linalg.cholesky(0.5 * (sig + sig.transpose(-1, -2)))
+    Lc = _klinalg.cholesky(0.5 * (sig + sig.transpose(-1, -2)))
     eye = torch.eye(D, dtype=Lc.dtype, device=Lc.device).expand_as(Lc)
     W = torch.linalg.solve_triangular(Lc, eye, upper=False)
     vd = v.detach().double()

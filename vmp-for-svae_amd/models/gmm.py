@@ -6,7 +6,7 @@ on the device (vmp_mix_finalize, used by m_step / inference).
 """
 import torch
 
-from .. import _lib as L
+from .. import _klinalg, _lib as L
 from . import _mix
 
 
@@ -69,7 +69,7 @@ def compute_expct_log_det_prec(v_k, P_k):
     """reference gmm.py:117-131, including the det <= 1e-20 -> log det := 0 guard (K-sized, torch fp64)."""
     P = P_k.double()
     D = P.shape[-1]
-    sign, lad = torch.linalg.slogdet(P)
+    sign, lad = _klinalg.slogdet(P)
     thresh = torch.log(torch.tensor(1e-20, dtype=torch.float64, device=P.device))
     ld = torch.where((sign > 0) & (lad > thresh), lad, torch.zeros_like(lad))
     i = torch.arange(D, dtype=torch.float64, device=P.device)

@@ -151,7 +151,7 @@ class DistributedVMPLoop(_mix.VMPLoop):
 
     def __init__(self, x, r_init, flavour, kappa=None, u_init=None, prior=None, group=None, comm=None, exchange=None):
         # (the data-parallel iteration keeps two launches: the exchange sits between the partial sums and the posterior)
-        super().__init__(x, r_init, flavour, kappa=kappa, u_init=u_init, prior=prior, one_launch=False)
+        super().__init__(x, r_init, flavour, kappa=kappa, u_init=u_init, prior=prior)
         self.group, self.comm, self.exchange = group, comm, exchange
         self._stats = torch.empty((self.K, L.lib().vmp_mix_stats_words(self.D)), dtype=torch.float64,
                                   device=self.x.device)

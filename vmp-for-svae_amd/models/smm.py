@@ -5,7 +5,7 @@ import math
 
 import torch
 
-from .. import _lib as L
+from .. import _klinalg, _lib as L
 from . import _mix
 
 
@@ -70,7 +70,7 @@ def expct_log_det_prec(v_k, P_k):
     """reference smm.py:99-110: Cholesky log-det (no guard), digamma arguments without the +1."""
     P = P_k.double()
     D = P.shape[-1]
-    ld = 2.0 * torch.log(torch.diagonal(torch.linalg.cholesky(P), dim1=-2, dim2=-1)).sum(-1)
+    ld = 2.0 * torch.log(torch.diagonal(_klinalg.cholesky(P), dim1=-2, dim2=-1)).sum(-1)
     i = torch.arange(D, dtype=torch.float64, device=P.device)
     sdg = torch.special.digamma(0.5 * (v_k.double()[:, None] + i[None, :])).sum(1)
     return (sdg + D * math.log(2.0) + ld).to(P_k.dtype)

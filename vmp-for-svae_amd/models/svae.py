@@ -10,7 +10,7 @@ import math
 
 import torch
 
-from .. import _lib as L
+from .. import _klinalg, _lib as L
 from ..distributions import dirichlet, gaussian, niw
 from . import _mix, _svae_ops, gmm, vae
 
@@ -45,7 +45,7 @@ def _recognition_bias(eta1_k, eta2_k, pi_k):
     """bias_k = B_k + log pi_k with B_k = -1/2 h_k^T P_k^-1 h_k + 1/2 log det P_k: the
     k-only part of log N(mu_n; mu_k, Sigma_n + Sigma_k) the reference builds in svae.py:70-92."""
     P = -2.0 * eta2_k
-    Lc = torch.linalg.cholesky(P)
+    Lc = _klinalg.cholesky(P)
     sol = torch.linalg.solve_triangular(Lc, eta1_k.unsqueeze(-1), upper=False).squeeze(-1)
     B = -0.5 * (sol * sol).sum(-1) + torch.log(torch.diagonal(Lc, dim1=-2, dim2=-1)).sum(-1)
     return P, B + torch.log(pi_k)
@@ -202,8 +202,6 @@ def e_step(phi_enc, phi_gmm, nb_samples, seed=0, name="e_step", noise=None, thet
         mk, Wk, kap, nu = prep[3], prep[4], prep[5], None
     else:
         mk, Wk, kap, nu = _theta_pack(theta) if theta is not None else _neutral_theta(K, Ld, eta1_phi1.device)
-    if _svae_ops.FORK is not None:
-        _svae_ops.FORK.join('noise', 'prep')
     x, lz, Tp = _svae_ops.SvaeEStepFn.apply(eta1_phi1, eta2_diag, eta1_phi2, P, bias, noise, mk, Wk, kap, nu)
     # without theta the (phi, noise) the E-step ran on stay attached, so that compute_elbo can evaluate the theta term
     # afterwards; with theta (the training path) nothing extra is kept alive
@@ -428,18 +426,15 @@ def init_mm(nb_components, latent_dims, seed=0, param_device='cuda', name='init_
 
 def make_loc_scale_variables(theta, param_device='cuda', name='copy_m_v'):
     """reference svae.py:474-485."""
-    # K-sized, once per model: evaluated on the HOST (LAPACK) and copied to the parameter device.  torch's GPU factorisations
-    # (MAGMA / rocSOLVER batched kernels) are not on any hot path here, and they returned a wrong Cholesky factor for a trainer
-    # constructed after a data-parallel graphed step had run in a process that shares its GPU with another rank (round 5,
-    # tools/r5_dpg_debug.py); under rocprofv3 --pmc they misbehave as well (tools/t2_prof_target.py).
-    dev = theta[1].device
-    th = [t.detach().cpu() for t in theta]
-    std = niw.natural_to_standard(th[1], th[2], th[3], th[4])
+    # K-sized, once per model: the factorisations run on the host (_klinalg: torch's GPU Cholesky returned a wrong factor on its
+    # first call after HIP-graph replays in a process that shares its GPU with another rank - rounds 5 / 6, tools/r6_dpg_repro.py)
+    std = niw.natural_to_standard(theta[1].detach(), theta[2].detach(), theta[3].detach(), theta[4].detach())
     mu, sigma = niw.expected_values(std)
     # contiguous copies: cholesky returns a column-major batch, and one oddly-strided parameter drops the optimiser's
     # multi-tensor updates onto the per-tensor slow path
+    dev = theta[1].device
     return (torch.nn.Parameter(mu.clone(memory_format=torch.contiguous_format).to(dev)),
-            torch.nn.Parameter(torch.linalg.cholesky(sigma).clone(memory_format=torch.contiguous_format).to(dev)))
+            torch.nn.Parameter(_klinalg.cholesky(sigma).clone(memory_format=torch.contiguous_format).to(dev)))
 
 
 def init_recognition_params(theta, nb_components, seed=0, param_device='cuda', var_scope='phi_gmm', pi_normal=None):

@@ -236,15 +236,13 @@ class SVAETrainer(object):
             # cheaper one: 120.5 vs 118.8 us per step); the stream is the same one.
             pn = _svae_ops.PhiloxNoise(0, self.S, seed_dev=_seed_dev)
             gen = lambda: pn.materialise(y.shape[0], self.K, self.L, y.device)
-            noise = gen() if _svae_ops.FORK is None else _svae_ops.FORK.run('noise', gen)
+            noise = gen()
             if u is None and z_draws is None:
                 u = pn
         elif noise is None and self.rng == 'philox':
             noise = 'philox'
         theta_in = None if self.reference_call_order else self.theta
         prep = None
-        if _svae_ops.FORK is not None:                       # graph capture: the K-sized prep is a branch beside the encoder
-            prep = _svae_ops.FORK.run('prep', lambda: svae.recognition_prep(self.phi_gmm, theta_in))
         out = svae.inference(y, self.phi_gmm, self.encoder_layers, self.decoder_layers, self.S,
                              stddev_init_nn=self.stddev_init_nn, seed=self._step_seed(chunk_index), noise=noise,
                              z_draws=z_draws, theta=theta_in, lazy_decoder=self.fused_decoder, u=u, prep=prep)
@@ -353,10 +351,8 @@ class SVAETrainer(object):
             self.opt = TFAdam(params, self.lr)
         if fused_m:                                                                 # whole minibatch, one process, <= 512 rows
             rho_dev = None if _dev_scalars is None else _dev_scalars[0]
-            cvi = lambda: _svae_ops.stats_cvi(keep['x_samples'], r_whole, self.gmm_prior, self.theta,
-                                              0.0 if rho_dev is not None else lrcvi, rho_dev=rho_dev)
-            # (graph capture: theta's update is a branch beside the Adam step - disjoint variables)
-            stats, theta_star = cvi() if _svae_ops.FORK is None else _svae_ops.FORK.run('cvi', cvi)
+            stats, theta_star = _svae_ops.stats_cvi(keep['x_samples'], r_whole, self.gmm_prior, self.theta,
+                                                    0.0 if rho_dev is not None else lrcvi, rho_dev=rho_dev)
         elif ctx.get('mom_whole') is not None:                                      # large single-process batch, K = 16, L = 8
             rho_dev = None if _dev_scalars is None else _dev_scalars[0]
             stats, theta_star = _svae_ops.mom_cvi(ctx['mom_whole'], self.gmm_prior, self.theta,
@@ -384,8 +380,6 @@ class SVAETrainer(object):
         else:
             self.opt.apply_gradients(grads)                                         # experiments.py:264-265
             self.global_step += 1
-        if _svae_ops.FORK is not None:
-            _svae_ops.FORK.join('cvi')
         out = dict(elbo=elbo_t, neg_rec_err=rec_t, regulariser=reg_t, grads=dict(zip(names, grads)),
                    theta_star=theta_star, lrcvi=lrcvi)
         out.update(keep)
@@ -405,15 +399,12 @@ class GraphedSVAEStep(object):
     (call i here == step i there).  Trainer with rng='torch': the graph reads eps / u from static tensors that every call
     refills with torch's generator (three more launches per call), again the stream of that trainer stepped eagerly."""
 
-    def __init__(self, trainer, y_example, warmup=3, fork=False):
-        """fork: capture independent kernels of the step on side streams (_svae_ops.StepFork) - parallel branches of the graph: the
-        noise generator, the recognition-GMM prep (forward and, through autograd's stream rule, backward) beside the encoder, the
-        CVI update beside Adam.  Bit-identical, and SLOWER on this runtime: 164.5-166.1 us per replay against 116.5-116.9 at
-        minibatch 64 (profiles/r05_minibatch_fork_ab.txt) - a dependency between two streams of a HIP graph costs more (~6 us per
-        fork + join) than the 4-7 us kernel it lets run in parallel.  Off by default; kept as the measurement's build."""
+    def __init__(self, trainer, y_example, warmup=3):
+        """(Parallel graph branches on side streams - noise generator / recognition prep beside the encoder, CVI beside Adam - were
+        built and measured in round 5: bit-identical and 42 % SLOWER, a cross-stream edge of a HIP graph costs ~6 us on this runtime
+        (profiles/r05_minibatch_fork_ab.txt); removed in round 6.)"""
         tr = self.tr = trainer
         dev = tr.device
-        self._fork = _svae_ops.StepFork(dev) if fork else None
         N = y_example.shape[0]
         f32 = dict(dtype=torch.float32, device=dev)
         self.y = y_example.to(**f32).clone()
@@ -448,11 +439,7 @@ class GraphedSVAEStep(object):
         ws_before = L.snapshot_workspaces()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
-        _svae_ops.FORK = self._fork
-        try:
-            self._warm_and_capture(side, params, snap, had_opt, dev, warmup, ws_before)
-        finally:
-            _svae_ops.FORK = None
+        self._warm_and_capture(side, params, snap, had_opt, dev, warmup, ws_before)
 
     def _warm_and_capture(self, side, params, snap, had_opt, dev, warmup, ws_before):
         tr = self.tr
@@ -498,10 +485,6 @@ class GraphedSVAEStep(object):
         self._ws_refs = L.take_workspaces(cap_stream, ws_before)    # graph-pool memory: owned by this graph alone from here on
         _svae_ops.release_tail_workspaces(side)
         self._tail_refs = _svae_ops.release_tail_workspaces(cap_stream)    # graph-pool memory the captured tail launch points into
-        if self._fork is not None:                # scratch of the launches captured on the side streams: same ownership
-            for s_ in self._fork.streams.values():
-                self._ws_refs.update(L.take_workspaces(s_, ws_before))
-                self._tail_refs += _svae_ops.release_tail_workspaces(s_)
 
     def _refresh(self):
         tr = self.tr
