@@ -727,9 +727,9 @@ def main():
         if world > 1:
             # the OTHER scaling mode, same launch: fewer repetitions, same timed-region protocol
             other = 'strong' if args.scaling == 'weak' else 'weak'
-            barrier()
             if loop.exchange is not None:
-                loop.exchange.close()                             # after the barrier: no peer is polling or pushing any more
+                loop.exchange.close_collective()                  # barrier, then unmap: no peer is polling or pushing any more
+            barrier()
             del loop
             torch.cuda.empty_cache()
             n2, job2 = rows_for(other)
@@ -741,9 +741,9 @@ def main():
             extra['other_scaling'] = {'scaling': other, 'rows_per_rank': n2, 'rows_job': job2, 'ms_per_step': d2 / args.steps * 1e3,
                                       'value': job2 / (d2 / args.steps), 'kernel_ms': float(np.median(k2)),
                                       'exchange': args.exchange}
-            barrier()
             if loop2.exchange is not None:
-                loop2.exchange.close()
+                loop2.exchange.close_collective()
+            barrier()
             del loop2
         # side measurements: single-GPU experiments (nothing after the timed region may take the JSON line down with it)
         if not args.no_extra and world == 1:

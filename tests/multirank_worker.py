@@ -159,8 +159,7 @@ def main():
             res['t1x_%s_r200' % name] = loop.r.cpu().numpy()
             res['t1x_%s_m200' % name] = loop.theta()[2].cpu().numpy()
             res['t1x_%s_status' % name] = ex.status.cpu().numpy()
-            dist.barrier()
-            ex.close()
+            ex.close_collective()                              # barrier over the ranks, then unmap / free
     except Exception as e:                                   # reported by the test, the other sections stay usable
         res['t1x_error'] = np.array(repr(e))
     np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), **res)

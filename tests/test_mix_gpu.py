@@ -128,10 +128,11 @@ def test_vmp_steps_vs_oracle(N, D, K):
     for it in range(2):
         ro, _, th_o, aux_o = mixtures.gmm_inference_step(xo, ro)
         r = step()
-        assert abserr(r, ro.numpy(), 'gmm r_nk', 2e-5) <= 2e-5, ('gmm r', it)
+        # the stated tolerance (BASELINE north_star): 1e-5 - absolute on the responsibilities, relative on the parameters
+        assert abserr(r, ro.numpy(), 'gmm r_nk', 1e-5) <= 1e-5, ('gmm r', it)
         for n_, t, o in zip(('alpha', 'beta', 'm', 'C', 'v'), theta(), th_o):
-            assert relerr(t, o.numpy(), 'gmm ' + n_, 2e-5) <= 2e-5
-        tol_S = 2e-5 * max(1.0, float((xo ** 2).max()))
+            assert relerr(t, o.numpy(), 'gmm ' + n_, 1e-5) <= 1e-5
+        tol_S = 1e-5 * max(1.0, float((xo ** 2).max()))
         assert abserr(aux()[1], aux_o[1].numpy(), 'gmm S_k', tol_S) <= tol_S
     ro, uo = torch.as_tensor(r0).double(), torch.ones(N, K, dtype=torch.float64)
     r32, u32, x32 = torch.as_tensor(r0), torch.ones(N, K), torch.as_tensor(x)     # the same run in the reference's own dtype
@@ -140,15 +141,15 @@ def test_vmp_steps_vs_oracle(N, D, K):
         ro, uo, th_o, aux_o = mixtures.smm_inference_step(xo, ro, uo, 5.0)
         r32, u32, _, _ = mixtures.smm_inference_step(x32, r32, u32, 5.0)
         r = step()
-        # 5e-5, or no worse than the reference's own fp32 arithmetic on this free-running step where that
-        # is further from the fp64 truth (the SMM's log rho carries (D + kappa) / 2 times the Mahalanobis term and early
-        # iterations amplify ~13x: at (20000, 8, 16) the fp32 oracle is 1.5e-4 off after two iterations)
+        # 1e-5, or no worse than the reference's own fp32 arithmetic on this free-running step where THAT is
+        # further from the fp64 truth - measured here, never a bare constant (the SMM's log rho carries (D + kappa) / 2 times the
+        # Mahalanobis term and early iterations amplify ~13x: at (20000, 8, 16) the fp32 oracle is 3e-3 off after two iterations)
         ref32 = float((r32.double() - ro).abs().max())
         parity_log.record('abs', ref32, None, 'smm r_nk: fp32 oracle (reference dtype) vs fp64 truth')
-        bar_r = max(5e-5, ref32)
+        bar_r = max(1e-5, ref32)
         assert abserr(r, ro.numpy(), 'smm r_nk', bar_r) <= bar_r, ('smm r', it, ref32)
         for n_, t, o in zip(('alpha', 'beta', 'm', 'C', 'v'), theta()[:5], th_o[:5]):
-            assert relerr(t, o.numpy(), 'smm ' + n_, 5e-5) <= 5e-5
+            assert relerr(t, o.numpy(), 'smm ' + n_, 1e-5) <= 1e-5
 
 
 def test_empty_component_and_far_offsets():

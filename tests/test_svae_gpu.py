@@ -17,10 +17,10 @@ def dev(a, dtype=torch.float32):
     return torch.as_tensor(np.asarray(a)).to('cuda', dtype)
 
 
-def rel(got, want):
+def rel(got, want, what=None, tol=None):
     want = np.asarray(want, dtype=np.float64)
     got = got.detach().double().cpu().numpy()
-    return parity_log.record('rel', np.abs(got - want).max() / max(np.abs(want).max(), 1e-300))
+    return parity_log.record('rel', np.abs(got - want).max() / max(np.abs(want).max(), 1e-300), tol, what)
 
 
 def bar(g, key, base):
@@ -151,9 +151,28 @@ def test_estep_vs_oracle_shapes():
         loss_p = (x_p * wx.float().cuda()).sum() + (torch.exp(lz_p) * (pt_p.T_prime + lz_p)).sum()
         gp = torch.autograd.grad(loss_p, [pe1, pe2, pmu, pL, ppi])
         tag = (N, K, Ld, S)
-        assert rel(x_p, x_o.detach().numpy()) < 3e-5, tag
-        assert np.abs(np.exp(lz_p.detach().double().cpu().numpy()) - np.exp(lz_o.detach().numpy())).max() < 2e-5, tag
-        assert rel(pt_p.T_prime, Tp_o.detach().numpy()) < 5e-5, tag
+        # bars: the stated 1e-5 (x, T' relative to their largest entry; r absolute), or 3 x what the reference's OWN fp32 arithmetic
+        # loses on this very shape where that is more - the oracle's literal graph in fp32, measured here
+        with torch.no_grad():
+            f32c = lambda a: torch.tensor(a, dtype=torch.float32)
+            pr32, th32 = svae_ref.init_mm(K, Ld, f32c(m_unif), torch.float32)
+            x32, lz32, pt32, _ = svae_ref.e_step((f32c(e1), f32c(e2)), [f32c(mu_k), f32c(Lraw), f32c(pir)], f32c(noise))
+            b32, m32, C32, v32 = dists.niw_natural_to_standard(*th32[1:])
+            mu32, sig32 = dists.niw_expected_values(b32, m32, C32, v32)
+            e1t32, e2t32 = dists.gauss_standard_to_natural(mu32, sig32)
+            elp32 = dists.dir_expected_log_pi(dists.dir_natural_to_standard(th32[0]))
+            Tp32 = (dists.gauss_log_probability_nat_per_samp(x32, pt32[0].reshape(N, K, Ld), pt32[1])
+                    - dists.gauss_log_probability_nat_per_samp(x32, e1t32.unsqueeze(0).repeat(N, 1, 1), e2t32.unsqueeze(0).repeat(N, 1, 1, 1))
+                    - elp32.view(1, K, 1)).mean(-1)
+        ref_x = float((x32.double() - x_o.detach()).abs().max() / x_o.detach().abs().max())
+        ref_r = float((torch.exp(lz32).double() - torch.exp(lz_o.detach())).abs().max())
+        ref_T = float((Tp32.double() - Tp_o.detach()).abs().max() / Tp_o.detach().abs().max())
+        bx, br, bT = max(1e-5, 3 * ref_x), max(1e-5, 3 * ref_r), max(1e-5, 3 * ref_T)
+        assert rel(x_p, x_o.detach().numpy(), 'e_step shapes x', bx) <= bx, (tag, ref_x)
+        e_r = np.abs(np.exp(lz_p.detach().double().cpu().numpy()) - np.exp(lz_o.detach().numpy())).max()
+        parity_log.record('abs', e_r, br, 'e_step shapes r_nk')
+        assert e_r <= br, (tag, e_r, ref_r)
+        assert rel(pt_p.T_prime, Tp_o.detach().numpy(), "e_step shapes T'", bT) <= bT, (tag, ref_T)
         for a_, b_, n_ in zip(gp, go, ('eta1', 'eta2d', 'mu_k', 'L_k', 'log_pi_k')):
             # fp32 accumulation over N*S sample adjoints: tolerance 2e-4 at S<=10, growing as sqrt(S/10)
             assert rel(a_, b_.numpy()) < 2e-4 * max(1.0, S / 10.0) ** 0.5, (tag, n_, rel(a_, b_.numpy()))
@@ -206,9 +225,28 @@ def test_estep_vs_oracle_shapes_student_t():
         loss_p = (x_p * wx.float().cuda()).sum() + (torch.exp(lz_p) * (pt_p.T_prime + lz_p)).sum()
         gp = torch.autograd.grad(loss_p, [pe1, pe2, pmu, pL, ppi, ptm, ptL])
         tag = (N, K, Ld, S)
-        assert rel(x_p, x_o.detach().numpy()) < 3e-5, tag
-        assert np.abs(np.exp(lz_p.detach().double().cpu().numpy()) - np.exp(lz_o.detach().numpy())).max() < 2e-5, tag
-        assert rel(pt_p.T_prime, Tp_o.detach().numpy()) < 5e-5, tag
+        # bars: the stated 1e-5 (x, T' relative to their largest entry; r absolute), or 3 x what the reference's OWN fp32 arithmetic
+        # loses on this very shape where that is more - the oracle's literal graph in fp32, measured here
+        with torch.no_grad():
+            f32c = lambda a: torch.tensor(a, dtype=torch.float32)
+            pr32, th32 = svae_ref.init_mm(K, Ld, f32c(m_unif), torch.float32)
+            x32, lz32, pt32, _ = svae_ref.e_step((f32c(e1), f32c(e2)), [f32c(mu_k), f32c(Lraw), f32c(pir)], f32c(noise))
+            b32, m32, C32, v32 = dists.niw_natural_to_standard(*th32[1:])
+            mu32, sig32 = dists.niw_expected_values(b32, m32, C32, v32)
+            e1t32, e2t32 = dists.gauss_standard_to_natural(mu32, sig32)
+            elp32 = dists.dir_expected_log_pi(dists.dir_natural_to_standard(th32[0]))
+            Tp32 = (dists.gauss_log_probability_nat_per_samp(x32, pt32[0].reshape(N, K, Ld), pt32[1])
+                    - dists.gauss_log_probability_nat_per_samp(x32, e1t32.unsqueeze(0).repeat(N, 1, 1), e2t32.unsqueeze(0).repeat(N, 1, 1, 1))
+                    - elp32.view(1, K, 1)).mean(-1)
+        ref_x = float((x32.double() - x_o.detach()).abs().max() / x_o.detach().abs().max())
+        ref_r = float((torch.exp(lz32).double() - torch.exp(lz_o.detach())).abs().max())
+        ref_T = float((Tp32.double() - Tp_o.detach()).abs().max() / Tp_o.detach().abs().max())
+        bx, br, bT = max(1e-5, 3 * ref_x), max(1e-5, 3 * ref_r), max(1e-5, 3 * ref_T)
+        assert rel(x_p, x_o.detach().numpy(), 'e_step shapes x', bx) <= bx, (tag, ref_x)
+        e_r = np.abs(np.exp(lz_p.detach().double().cpu().numpy()) - np.exp(lz_o.detach().numpy())).max()
+        parity_log.record('abs', e_r, br, 'e_step shapes r_nk')
+        assert e_r <= br, (tag, e_r, ref_r)
+        assert rel(pt_p.T_prime, Tp_o.detach().numpy(), "e_step shapes T'", bT) <= bT, (tag, ref_T)
         for a_, b_, n_ in zip(gp, go, ('eta1', 'eta2d', 'mu_k', 'L_k', 'log_pi_k', 'theta/mu_k', 'theta/L_k')):
             e = rel(a_, b_.numpy())
             assert e < 2e-4 * max(1.0, S / 10.0) ** 0.5, (tag, n_, e)

@@ -282,7 +282,11 @@ def read_from_tfrec_file(filename_q, D, binarise=False, seed=0):
     the reference passes a filename queue) is a tf.train.Example with 'image_raw' (D uint8 bytes) and 'label' (int64).
     Returns (images (M, D) float32, labels (M,) int64): pixel values / 255 (data.py:196), or - binarise=True - stochastically
     binarised to {-1, +1} with the intensity as the probability of +1 (data.py:199-206; numpy Generator(seed) replaces
-    tf.multinomial's stream)."""
+    tf.multinomial's stream; seed defaults to 0 as the reference's does, whose make_minibatch passes none).
+    DELIBERATE DIVERGENCE (out-of-scope pipeline): the reference binarises DYNAMICALLY - a fresh tf.multinomial
+    draw every time a record is dequeued - whereas this reader binarises the whole set ONCE: every epoch sees the same binary
+    image per example.  A caller that needs the reference's regulariser reads with binarise=False and draws
+    `np.where(rng.random(batch.shape) < batch, 1, -1)` per minibatch."""
     import struct
     paths = [filename_q] if isinstance(filename_q, (str, bytes)) else list(filename_q)
     imgs, labels = [], []

@@ -70,7 +70,16 @@ class PeerExchange(object):
     vmp_mix_finalize_exchange): every rank allocates vmp_exch_bytes(G, K, D) of uncached device memory, exports its IPC
     handle, gathers the G handles (any out-of-band channel; here torch.distributed's object all-gather - a one-time
     set-up exchange of 64 bytes per rank) and maps the peers' buffers.  No collective library is on the step path: the
-    finalize kernels push their fp64 moments into each other's buffers and sum them in rank order."""
+    finalize kernels push their fp64 moments into each other's buffers and sum them in rank order.
+
+    Lifetime: the mapped peer buffers and this rank's buffer are released by close_collective() (barrier, then close()) or by
+    using the object as a context manager (`with PeerExchange(K, D) as ex:` - the exit is collective: EVERY rank must leave the
+    block); close() alone is for after a barrier of the caller's own.  A multi-rank exchange that is garbage-collected unclosed
+    keeps its mappings until the process exits and says so with a ResourceWarning.
+    gather: a caller-supplied all-gather `gather(bytes64) -> list of world bytes64` used instead of torch.distributed.  It is called
+    TWICE by the constructor, with 64-byte payloads both times: once with this rank's IPC handle, and - world > 1 - once more with
+    the constant b'mapped' (zero-padded) as the rendezvous that tells every rank all buffers are mapped; the callback must accept
+    arbitrary 64-byte payloads and may not assume a single call."""
 
     def __init__(self, K, D, group=None, rank=None, world=None, gather=None):
         import ctypes
@@ -111,7 +120,25 @@ class PeerExchange(object):
                 dist.barrier(group)
             else:
                 gather(b'mapped'.ljust(64, b'\0'))        # a second round of the caller's all-gather is the rendezvous
-        self._closed_explicitly = False
+        self._group, self._gather = group, gather
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close_collective()
+        return False
+
+    def close_collective(self):
+        """barrier over the ranks (nobody is polling or pushing any more), then close(): the collective way to end an exchange"""
+        if self.world > 1 and getattr(self, '_buf', None) is not None:
+            torch.cuda.synchronize()
+            if self._gather is None:
+                import torch.distributed as dist
+                dist.barrier(self._group)
+            else:
+                self._gather(b'closing'.ljust(64, b'\0'))
+        self.close()
 
     def __del__(self):
         # Freeing or unmapping a buffer that a peer's finalize kernel may still be pushing into or polling is a GPU fault on
@@ -120,6 +147,10 @@ class PeerExchange(object):
         try:
             if self.world == 1:
                 self.close()
+            elif getattr(self, '_buf', None) is not None:
+                import warnings
+                warnings.warn('PeerExchange of %d ranks garbage-collected without close_collective(): its IPC mappings and device '
+                              'buffer stay allocated until the process exits' % self.world, ResourceWarning)
         except Exception:
             pass
 
