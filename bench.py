@@ -724,6 +724,14 @@ def main():
         assert torch.isfinite(loop.r).all()
         if world > 1:
             loop.check()                                          # a timed-out in-kernel wait voids the line: fail, do not print it
+        if world == 1 and args.workload == 'smm':
+            # the opt-in accurate E-part (fp64 from an fp64 pack + a separate M-pass: VMPLoop(accurate=True)) beside the default
+            aloop = _mix.VMPLoop(x, r0, flav, kappa=kappa, accurate=True)
+            aw, _ = time_t1(aloop, args.steps, args.warmup, 7, barrier, None, dev)
+            extra['accurate_mode'] = {'ms_per_step': float(np.median(aw)) / args.steps * 1e3, 'default_ms_per_step': dt / args.steps * 1e3,
+                                      'what': 'VMPLoop(accurate=True): vmp_mix_finalize_ws64 + vmp_mix_estep_accurate (fp64 E-part) + vmp_mix_stats_ws; '
+                                              'meets the literal 1e-5 on r_nk at C5 (tests/test_fullsize_gpu.py smm-c5-accurate)'}
+            del aloop
         if world > 1:
             # the OTHER scaling mode, same launch: fewer repetitions, same timed-region protocol
             other = 'strong' if args.scaling == 'weak' else 'weak'

@@ -125,6 +125,19 @@ int    vmp_mix_finalize_ws(const void* ws, const float* pivot, int64_t N, int D,
 /* `iterations` VMP iterations enqueued back-to-back from one call (2 launches each, no host round trip):
  * the loop `for i in range(nb_iters): sess.run(update)` of models/gmm.py:377-379.  ws must hold the partial moments
  * of the current (r, u) (vmp_mix_stats_ws or a previous iteration).                                             */
+/* Opt-in ACCURATE E-part (round 6).  The SMM's log rho_nk = c_k - (D + kappa)/2 q_nk (models/smm.py:119-128) is LINEAR in the
+ * expected Mahalanobis distance with a factor 6.5 at D = 8, kappa = 5: rows without a close component have |log rho| ~ 1e2..1e3,
+ * where an fp32 q (absolute error 1e-7 q) and an fp32 log rho cost 1..4e-5 on r_nk - above the 1e-5 the north-star states.
+ * vmp_mix_finalize_ws64 = vmp_mix_finalize_ws that also writes the E-step pack in fp64 (pack64: K x vmp_mix_pack_words(D) doubles);
+ * vmp_mix_estep_accurate evaluates compute_expct_mahalanobis_dist / compute_rnk / compute_expct_unk (models/gmm.py:84-94,141-151,
+ * models/smm.py:88-96,119-137) from it entirely in fp64 and rounds r (u, log r) once on the way out.  It does NOT accumulate
+ * moments: follow it with vmp_mix_stats_ws.  Three streaming launches per iteration instead of one - the default stays the fused pass. */
+int    vmp_mix_finalize_ws64(const void* ws, const float* pivot, int64_t N, int D, int K, int flavour,
+                             const float* alpha0, const float* beta0, const float* m0, const float* C0, const float* v0,
+                             const float* kappa, float* alpha, float* beta, float* m, float* C, float* v, float* xbar,
+                             float* S, float* pi, float* pack, double* pack64, double* stats_out, void* stream);
+int    vmp_mix_estep_accurate(const float* x, int64_t N, int D, int K, int flavour, const double* pack64, float* r_out,
+                              float* u_out, float* logr_out, void* stream);
 int    vmp_mix_iterate(const float* x, int64_t N, int D, int K, int flavour,
                        const float* alpha0, const float* beta0, const float* m0, const float* C0, const float* v0,
                        const float* kappa, const float* pivot, float* r, float* u,

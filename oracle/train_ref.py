@@ -54,23 +54,34 @@ def tower_forward(st, y, noise, z_draws):
     return elbo, details, x_s, log_z
 
 
-def train_step(st, y, noise, z_draws, lr, lrcvi0, decay_rate, towers=1, b1=0.9, b2=0.999, eps=1e-8):
+def train_step(st, y, noise, z_draws, lr, lrcvi0, decay_rate, towers=1, b1=0.9, b2=0.999, eps=1e-8, workers=None):
     """One `sess.run(training_step)`.  With towers=G the minibatch is split in G contiguous shards
     (data.py:174-175), per-tower gradients of -elbo are AVERAGED (helpers/tf_utils.py:52-87), log_z and
     x_samples are concatenated for the M-step (experiments.py:247-260).  Everything reads OLD values.
     Returns dict(elbo (sum over towers), details, grads (averaged), theta_star, lrcvi)."""
     names, params = st.trainables()
     ys, ns, zs = torch.chunk(y, towers), torch.chunk(noise, towers), torch.chunk(z_draws, towers)
-    grads_sum, elbos, details, xs_all, lz_all = None, [], [], [], []
-    for g in range(towers):
+    def one_tower(g):
         elbo, det, x_s, log_z = tower_forward(st, ys[g], ns[g], zs[g])
         gr = torch.autograd.grad(-elbo, params, allow_unused=True)
         gr = [torch.zeros_like(p) if g_ is None else g_ for g_, p in zip(gr, params)]
+        return gr, elbo.detach(), torch.stack([d.detach() for d in det]), x_s.detach(), log_z.detach()
+
+    if workers and workers > 1 and towers > 1:
+        # test infrastructure only: the towers are independent graphs - several at a time on a thread pool (ATen releases the GIL),
+        # combined in tower order below, so the sums do not depend on the pool
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=int(workers)) as ex:
+            outs = list(ex.map(one_tower, range(towers)))
+    else:
+        outs = [one_tower(g) for g in range(towers)]
+    grads_sum, elbos, details, xs_all, lz_all = None, [], [], [], []
+    for gr, elbo_g, det_g, x_s, log_z in outs:
         grads_sum = gr if grads_sum is None else [a + b for a, b in zip(grads_sum, gr)]
-        elbos.append(elbo.detach())
-        details.append(torch.stack([d.detach() for d in det]))
-        xs_all.append(x_s.detach())
-        lz_all.append(log_z.detach())
+        elbos.append(elbo_g)
+        details.append(det_g)
+        xs_all.append(x_s)
+        lz_all.append(log_z)
     grads = [g_ / towers for g_ in grads_sum]
     lrcvi = lrcvi0 * decay_rate ** (st.global_step / 1000.0)
     r_nk = torch.exp(torch.cat(lz_all))
@@ -100,7 +111,7 @@ def train_step(st, y, noise, z_draws, lr, lrcvi0, decay_rate, towers=1, b1=0.9, 
                 theta_star=theta_star, lrcvi=lrcvi, x_samples=torch.cat(xs_all), log_z=torch.cat(lz_all))
 
 
-def vmp_step_t2(phi_gmm, theta, gmm_prior, eta1, eta2d, noise, z_draws, Gx, Glz, lrcvi, smm=False, chunk=None):
+def vmp_step_t2(phi_gmm, theta, gmm_prior, eta1, eta2d, noise, z_draws, Gx, Glz, lrcvi, smm=False, chunk=None, workers=None):
     """The T2 unit of SURVEY 8d on the reference graph: svae.e_step (svae.py:14-119), the regulariser part of compute_elbo(_smm)
     (svae.py:229-254 / 265-322), autodiff of  -elbo_reg + <x_k, Gx> + <log_z, Glz>  w.r.t. the encoder outputs and phi_gmm (+ the
     trainable theta/mu_k, theta/L_k of the Student-t model) - Gx, Glz standing for what the decoder and the reconstruction term send
@@ -117,8 +128,7 @@ def vmp_step_t2(phi_gmm, theta, gmm_prior, eta1, eta2d, noise, z_draws, Gx, Glz,
         th[1].requires_grad_(True)
         th[2].requires_grad_(True)
         th_tr = [th[1], th[2]]
-    g_k, g1, g2, regs, xs_all, lz_all = None, [], [], [], [], []
-    for lo in range(0, N, chunk):
+    def one_chunk(lo):
         sl = slice(lo, min(N, lo + chunk))
         e1 = eta1[sl].detach().clone().requires_grad_(True)
         e2 = eta2d[sl].detach().clone().requires_grad_(True)
@@ -126,12 +136,25 @@ def vmp_step_t2(phi_gmm, theta, gmm_prior, eta1, eta2d, noise, z_draws, Gx, Glz,
         elbo, det = (svae_ref.compute_elbo_smm if smm else svae_ref.compute_elbo)(None, None, th, phi_tilde, x_k, log_z)
         loss = -elbo + (x_k * Gx[sl]).sum() + (log_z * Glz[sl]).sum()
         gr = torch.autograd.grad(loss, [e1, e2] + phi + th_tr)
+        return gr, det[3].detach(), svae_ref.subsample_x(x_k.detach(), z_draws[sl])[:, 0, :], log_z.detach()
+
+    starts = list(range(0, N, chunk))
+    if workers and workers > 1 and len(starts) > 1:
+        # test infrastructure only: the row chunks are independent graphs - several at a time on a thread pool (ATen releases the
+        # GIL), results combined in chunk order, so the sums do not depend on the pool
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=int(workers)) as ex:
+            outs = list(ex.map(one_chunk, starts))
+    else:
+        outs = [one_chunk(lo) for lo in starts]
+    g_k, g1, g2, regs, xs_all, lz_all = None, [], [], [], [], []
+    for gr, reg_c, xs_c, lz_c in outs:
         g1.append(gr[0])
         g2.append(gr[1])
         g_k = list(gr[2:]) if g_k is None else [a + b for a, b in zip(g_k, gr[2:])]
-        regs.append(det[3].detach())
-        xs_all.append(svae_ref.subsample_x(x_k.detach(), z_draws[sl])[:, 0, :])
-        lz_all.append(log_z.detach())
+        regs.append(reg_c)
+        xs_all.append(xs_c)
+        lz_all.append(lz_c)
     r_nk = torch.exp(torch.cat(lz_all))
     if smm:
         theta_new = svae_ref.update_gmm_params([th[0]], [svae_ref.m_step_smm(gmm_prior, r_nk)], lrcvi)

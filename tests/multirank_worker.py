@@ -93,7 +93,7 @@ def main():
         el_e = [float(tr_e.step(ys[i])['elbo']) for i in range(4)]
         want = [t.detach().clone() for t in tr_e.trainables()[1]] + [t.clone() for t in tr_e.theta]
         Xte_e = (torch.randn(96, Dg, device='cuda', generator=torch.Generator(device='cuda').manual_seed(23)) * 2)
-        lab_e = torch.randint(0, 3, (96,), device='cuda', generator=torch.Generator(device='cuda').manual_seed(24)).float()
+        lab_e = torch.nn.functional.one_hot(torch.randint(0, 3, (96,), device='cuda', generator=torch.Generator(device='cuda').manual_seed(24)), 3).float()
         m_e = experiments.evaluate(tr_e, Xte_e, lab_e, 4, seed=0)
         res['dpg_eval_eager'] = np.array([m_e[k_] for k_ in sorted(m_e)], dtype=np.float64)
         tr_g = fresh()
@@ -111,7 +111,7 @@ def main():
         from vmp_for_svae_amd.distributions import gaussian, niw
         from vmp_for_svae_amd.models import svae as svae_mod
         Xte = (torch.randn(96, Dg, device='cuda', generator=torch.Generator(device='cuda').manual_seed(23)) * 2)
-        lab = torch.randint(0, 3, (96,), device='cuda', generator=torch.Generator(device='cuda').manual_seed(24)).float()
+        lab = torch.nn.functional.one_hot(torch.randint(0, 3, (96,), device='cuda', generator=torch.Generator(device='cuda').manual_seed(24)), 3).float()
         m_g = experiments.evaluate(tr_g, Xte, lab, 4, seed=0)
         res['dpg_eval_graphed'] = np.array([m_g[k_] for k_ in sorted(m_g)], dtype=np.float64)
         res['dpg_eval_keys'] = np.array(sorted(m_g))

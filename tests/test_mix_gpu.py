@@ -152,6 +152,38 @@ def test_vmp_steps_vs_oracle(N, D, K):
             assert relerr(t, o.numpy(), 'smm ' + n_, 1e-5) <= 1e-5
 
 
+@pytest.mark.parametrize('flavour', ['gmm', 'smm'])
+@pytest.mark.parametrize('N,D,K', [(1, 2, 3), (65, 8, 16), (5000, 5, 17), (20000, 8, 16), (3000, 4, 64), (40001, 8, 10)])
+def test_accurate_mode_vs_oracle(flavour, N, D, K):
+    """VMPLoop(accurate=True) (round 6: vmp_mix_finalize_ws64 + vmp_mix_estep_accurate + vmp_mix_stats_ws - the E-part in fp64 from
+    an fp64 pack; gmm.py:84-151 / smm.py:88-137): two same-input steps against the fp64 oracle at the literal 1e-5 (r absolute; u,
+    theta relative), no reference-fp32 clause, also for the SMM on the shapes where the default arithmetic needs it; log r too."""
+    from oracle import mixtures
+    from vmp_for_svae_amd import _lib as L
+    from vmp_for_svae_amd.models import _mix
+    x, r0 = _synth(N, D, K, seed=3 * N + D + K)
+    xo = torch.as_tensor(x).double()
+    smm_ = flavour == 'smm'
+    loop = _mix.VMPLoop(dev(x), dev(r0), L.VMP_SMM if smm_ else L.VMP_GMM, kappa=torch.full((K,), 5.0, device='cuda') if smm_ else None,
+                        accurate=True)
+    r_prev, u_prev = torch.as_tensor(r0).double(), torch.ones(N, K, dtype=torch.float64)
+    for it in range(2):
+        r = loop.step(want_logr=True)
+        if smm_:
+            ro, uo, th_o, _ = mixtures.smm_inference_step(xo, r_prev, u_prev, 5.0)
+        else:
+            ro, _, th_o, _ = mixtures.gmm_inference_step(xo, r_prev)
+        assert abserr(r, ro.numpy(), 'accurate %s r_nk' % flavour, 1e-5) <= 1e-5, it
+        big = ro > 1e-30
+        assert (loop.logr.double().cpu()[big] - torch.log(ro[big])).abs().max().item() <= 1e-4 * max(1.0, float(torch.log(ro[big]).abs().max())), it
+        if smm_:
+            assert relerr(loop.u, uo.numpy(), 'accurate smm u_nk', 1e-5) <= 1e-5, it
+        for n_, t, o in zip(('alpha', 'beta', 'm', 'C', 'v'), loop.theta(), th_o[:5]):
+            assert relerr(t, o.numpy(), 'accurate %s %s' % (flavour, n_), 1e-5) <= 1e-5, (it, n_)
+        r_prev = r.double().cpu()
+        u_prev = loop.u.double().cpu() if smm_ else u_prev
+
+
 def test_empty_component_and_far_offsets():
     """N_k == 0 exercises the NaN->un-normalised fallback (gmm.py:34-36,44-46); a 1e3 offset of the data
     exercises the raw-moment centring in fp64."""

@@ -229,24 +229,20 @@ def test_estep_vs_oracle_shapes_student_t():
         # loses on this very shape where that is more - the oracle's literal graph in fp32, measured here
         with torch.no_grad():
             f32c = lambda a: torch.tensor(a, dtype=torch.float32)
-            pr32, th32 = svae_ref.init_mm(K, Ld, f32c(m_unif), torch.float32)
             x32, lz32, pt32, _ = svae_ref.e_step((f32c(e1), f32c(e2)), [f32c(mu_k), f32c(Lraw), f32c(pir)], f32c(noise))
-            b32, m32, C32, v32 = dists.niw_natural_to_standard(*th32[1:])
-            mu32, sig32 = dists.niw_expected_values(b32, m32, C32, v32)
-            e1t32, e2t32 = dists.gauss_standard_to_natural(mu32, sig32)
-            elp32 = dists.dir_expected_log_pi(dists.dir_natural_to_standard(th32[0]))
+            mu32, sig32 = svae_ref.unpack_smm([f32c(th_mu), f32c(th_L)])
+            elp32 = dists.dir_expected_log_pi(dists.dir_natural_to_standard(f32c(alpha_nat)))
             Tp32 = (dists.gauss_log_probability_nat_per_samp(x32, pt32[0].reshape(N, K, Ld), pt32[1])
-                    - dists.gauss_log_probability_nat_per_samp(x32, e1t32.unsqueeze(0).repeat(N, 1, 1), e2t32.unsqueeze(0).repeat(N, 1, 1, 1))
-                    - elp32.view(1, K, 1)).mean(-1)
+                    - dists.student_t_log_probability_per_samp(x32, mu32, sig32, f32c(dof)) - elp32.view(1, K, 1)).mean(-1)
         ref_x = float((x32.double() - x_o.detach()).abs().max() / x_o.detach().abs().max())
         ref_r = float((torch.exp(lz32).double() - torch.exp(lz_o.detach())).abs().max())
         ref_T = float((Tp32.double() - Tp_o.detach()).abs().max() / Tp_o.detach().abs().max())
         bx, br, bT = max(1e-5, 3 * ref_x), max(1e-5, 3 * ref_r), max(1e-5, 3 * ref_T)
-        assert rel(x_p, x_o.detach().numpy(), 'e_step shapes x', bx) <= bx, (tag, ref_x)
+        assert rel(x_p, x_o.detach().numpy(), 'e_step shapes (Student-t) x', bx) <= bx, (tag, ref_x)
         e_r = np.abs(np.exp(lz_p.detach().double().cpu().numpy()) - np.exp(lz_o.detach().numpy())).max()
-        parity_log.record('abs', e_r, br, 'e_step shapes r_nk')
+        parity_log.record('abs', e_r, br, 'e_step shapes (Student-t) r_nk')
         assert e_r <= br, (tag, e_r, ref_r)
-        assert rel(pt_p.T_prime, Tp_o.detach().numpy(), "e_step shapes T'", bT) <= bT, (tag, ref_T)
+        assert rel(pt_p.T_prime, Tp_o.detach().numpy(), "e_step shapes (Student-t) T'", bT) <= bT, (tag, ref_T)
         for a_, b_, n_ in zip(gp, go, ('eta1', 'eta2d', 'mu_k', 'L_k', 'log_pi_k', 'theta/mu_k', 'theta/L_k')):
             e = rel(a_, b_.numpy())
             assert e < 2e-4 * max(1.0, S / 10.0) ** 0.5, (tag, n_, e)

@@ -670,6 +670,7 @@ struct FinArgs {
     const float *alpha0, *beta0, *m0, *C0, *v0, *kappa;
     const float* pivot;        // the shift the pass kernel applied to x (src == 0 only; NULL: none)
     float *alpha, *beta, *m, *C, *v, *xbar, *S, *pi, *pack;
+    double* pack64;            // the same E-step pack in fp64 (vmp_mix_estep_accurate), or NULL
     double* stats_out;
     // one-launch data-parallel form (vmp_mix_finalize_exchange): peer[g] = rank g's exchange buffer; nranks = 0: no exchange
     double* peer[VMP_EXCH_MAX_RANKS];
@@ -1221,7 +1222,10 @@ __device__ void estep_constants(int k, int flavour, double alpha_k, double alpha
 constexpr int FIN_THREADS = 1024;
 constexpr int FIN_MAX_GROUPS = FIN_THREADS / 64;
 
-__device__ __forceinline__ void st_pack(const FinArgs& a, int idx, float v) { a.pack[idx] = v; }
+__device__ __forceinline__ void st_pack(const FinArgs& a, int idx, double v) {
+    a.pack[idx] = (float)v;
+    if (a.pack64) a.pack64[idx] = v;
+}
 
 // One block per component (k), `nthreads` threads (>= 192, a multiple of 64; the stand-alone kernel: 1024, the head of the
 // one-launch step: the streaming block's 512).  Phase A: all threads reduce the per-block partials in a fixed order.
@@ -1448,7 +1452,7 @@ __device__ void finalize_block(const FinArgs& a, const int k, const int tid, con
             const int p = k * G::PACK + D;
 #pragma unroll
             for (int i = 0; i < D; ++i)
-                if (i >= tid) st_pack(a, p + i * (i + 1) / 2 + tid, (float)(X[i] * sv));      // W = sqrt(v) L^{-1}, lower
+                if (i >= tid) st_pack(a, p + i * (i + 1) / 2 + tid, X[i] * sv);      // W = sqrt(v) L^{-1}, lower
         }
         if (tid == 0) { scal[0] = -2.0 * sumlog; scal[1] = ok ? 1.0 : 0.0; }
     } else if (tid >= 64 && tid < 64 + D + 2) {
@@ -1492,10 +1496,10 @@ __device__ void finalize_block(const FinArgs& a, const int k, const int tid, con
         if (a.pack) {
             const int p = k * G::PACK + D + G::TRI;
             const double LOG2E = 1.4426950408889634074;  // the pass kernel evaluates 2^(c - h q)
-            st_pack(a, p, (float)(c * LOG2E)); st_pack(a, p + 1, (float)(h * LOG2E)); st_pack(a, p + 2, (float)ua); st_pack(a, p + 3, (float)ub);
+            st_pack(a, p, c * LOG2E); st_pack(a, p + 1, h * LOG2E); st_pack(a, p + 2, ua); st_pack(a, p + 3, ub);
         }
     }
-    if (a.pack && tid < D) st_pack(a, k * G::PACK + tid, (float)mk[tid]);
+    if (a.pack && tid < D) st_pack(a, k * G::PACK + tid, mk[tid]);
     FIN_TS(5);
 }
 
@@ -1752,6 +1756,62 @@ int run_finalize(FinArgs f, int D, hipStream_t s) {
     return rc;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Opt-in ACCURATE E-part (round 6): the whole cell arithmetic in fp64, from an fp64 copy of the pack.
+// Why it exists: the SMM's log rho_nk = c_k - (D + kappa)/2 * q_nk (smm.py:119-128, linear in the expected Mahalanobis distance q with
+// a factor 6.5 at D = 8, kappa = 5) reaches 1e2..1e3 for rows without a close component; an fp32 q carries an absolute error of
+// 1e-7 q, i.e. up to 6e-5 in log rho and 1..4e-5 in r_nk (same-input r at C5: 9e-6 / 8e-6 / 4e-5), and an fp32 log rho cannot
+// even represent the difference.  Here d = x - m, y = W d, q = |y|^2, log2 rho = c' - h' q, the row max, the exponentials and their
+// sum are fp64; r (and u = ua / (q + ub), smm.py:131-137) are rounded once, on the way out.  One thread per data row, the K pack
+// rows in LDS; two sweeps over k (max, then normalise) recompute q instead of holding K doubles per thread.
+// ---------------------------------------------------------------------------------------------------------
+struct AccArgs { const float* x; const double* pack; float* r; float* u; float* logr; long long N; int K; };
+template <int D, bool SMM>
+__global__ __launch_bounds__(256) void estep_f64_kernel(AccArgs a) {
+    using G = Geo<D>;
+    extern __shared__ double spk[];                          // [K][PACK]
+    for (int e = threadIdx.x; e < a.K * G::PACK; e += blockDim.x) spk[e] = a.pack[e];
+    __syncthreads();
+    const double LN2 = 0.69314718055994530942;
+    for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < a.N; n += (long long)gridDim.x * blockDim.x) {
+        double xd[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) xd[j] = (double)a.x[n * D + j];
+        auto quad = [&](int k) {
+            const double* __restrict__ p = spk + k * G::PACK;
+            double q = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double y = 0.0;
+#pragma unroll
+                for (int j = 0; j <= i; ++j) y = fma(p[D + i * (i + 1) / 2 + j], xd[j] - p[j], y);
+                q = fma(y, y, q);
+            }
+            return q;
+        };
+        double mx = -INFINITY;
+        for (int k = 0; k < a.K; ++k) {
+            const double* __restrict__ p = spk + k * G::PACK;
+            const double l2 = p[D + G::TRI] - p[D + G::TRI + 1] * quad(k);
+            mx = l2 > mx ? l2 : mx;                           // (NaN packs - a failed factorisation - propagate through the sum below)
+        }
+        double ssum = 0.0;
+        for (int k = 0; k < a.K; ++k) {
+            const double* __restrict__ p = spk + k * G::PACK;
+            ssum += exp2(p[D + G::TRI] - p[D + G::TRI + 1] * quad(k) - mx);
+        }
+        const double inv = 1.0 / ssum, l2s = log2(ssum);
+        for (int k = 0; k < a.K; ++k) {
+            const double* __restrict__ p = spk + k * G::PACK;
+            const double q = quad(k);
+            const double l2 = p[D + G::TRI] - p[D + G::TRI + 1] * q - mx;
+            a.r[n * a.K + k] = (float)(exp2(l2) * inv);
+            if (a.logr) a.logr[n * a.K + k] = (float)((l2 - l2s) * LN2);
+            if constexpr (SMM) a.u[n * a.K + k] = (float)(p[D + G::TRI + 2] / (q + p[D + G::TRI + 3]));
+        }
+    }
+}
+
 // workspace layout: [per-block partials | reserved words (zeroed by vmp_mix_stats_ws) | status word]
 constexpr size_t WS_TPACK_WORDS = 16 * (VMP_MAX_D + VMP_MAX_D * (VMP_MAX_D + 1) / 2 + 4);
 inline size_t ws_partial_bytes(int D, int K) { return (size_t)MAX_BLOCKS * K * (partial_words(D) + 1) * sizeof(double); }
@@ -1943,6 +2003,43 @@ int vmp_mix_finalize_ws(const void* ws, const float* pivot, int64_t N, int D, in
     f.alpha = alpha; f.beta = beta; f.m = m; f.C = C; f.v = v; f.xbar = xbar; f.S = S; f.pi = pi; f.pack = pack;
     f.stats_out = stats_out; f.pivot = pivot;
     return run_finalize(f, D, static_cast<hipStream_t>(stream));
+}
+
+int vmp_mix_finalize_ws64(const void* ws, const float* pivot, int64_t N, int D, int K, int flavour, const float* alpha0, const float* beta0,
+                          const float* m0, const float* C0, const float* v0, const float* kappa, float* alpha,
+                          float* beta, float* m, float* C, float* v, float* xbar, float* S, float* pi, float* pack, double* pack64,
+                          double* stats_out, void* stream) {
+    int rc = check_dims(N, D, K);
+    if (rc) return rc;
+    if (!ws || !alpha0 || !beta0 || !m0 || !C0 || !v0 || !pack || !pack64) { set_error("vmp_mix_finalize_ws64: null pointer"); return VMP_E_BADARG; }
+    if (flavour == VMP_SMM && !kappa) { set_error("vmp_mix_finalize_ws64: SMM needs kappa"); return VMP_E_BADARG; }
+    FinArgs f{};
+    f.partials = static_cast<const double*>(ws);
+    f.nblk = make_plan(N, D, K, flavour, true).blocks;
+    f.K = K; f.flavour = flavour; f.src = 0; f.do_post = 1;
+    f.alpha0 = alpha0; f.beta0 = beta0; f.m0 = m0; f.C0 = C0; f.v0 = v0; f.kappa = kappa;
+    f.alpha = alpha; f.beta = beta; f.m = m; f.C = C; f.v = v; f.xbar = xbar; f.S = S; f.pi = pi; f.pack = pack; f.pack64 = pack64;
+    f.stats_out = stats_out; f.pivot = pivot;
+    return run_finalize(f, D, static_cast<hipStream_t>(stream));
+}
+
+int vmp_mix_estep_accurate(const float* x, int64_t N, int D, int K, int flavour, const double* pack64, float* r_out, float* u_out,
+                           float* logr_out, void* stream) {
+    int rc = check_dims(N, D, K);
+    if (rc) return rc;
+    if (!x || !pack64 || !r_out) { set_error("vmp_mix_estep_accurate: null pointer"); return VMP_E_BADARG; }
+    if (flavour != VMP_GMM && flavour != VMP_SMM) { set_error("vmp_mix_estep_accurate: bad flavour %d", flavour); return VMP_E_BADARG; }
+    if (flavour == VMP_SMM && !u_out) { set_error("vmp_mix_estep_accurate: SMM needs u_out"); return VMP_E_BADARG; }
+    AccArgs a{x, pack64, r_out, u_out, logr_out, N, K};
+    long long blocks = (N + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    const size_t lds = (size_t)K * pack_words(D) * sizeof(double);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    VMP_DISPATCH_D(D, {
+        if (flavour == VMP_SMM) hipLaunchKernelGGL((estep_f64_kernel<DD, true>), dim3((int)blocks), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((estep_f64_kernel<DD, false>), dim3((int)blocks), dim3(256), lds, s, a);
+    });
+    return check_launch("estep_f64_kernel");
 }
 
 int vmp_mix_iterate(const float* x, int64_t N, int D, int K, int flavour, const float* alpha0, const float* beta0,
