@@ -131,13 +131,18 @@ int    vmp_mix_finalize_ws(const void* ws, const float* pivot, int64_t N, int D,
  * vmp_mix_finalize_ws64 = vmp_mix_finalize_ws that also writes the E-step pack in fp64 (pack64: K x vmp_mix_pack_words(D) doubles);
  * vmp_mix_estep_accurate evaluates compute_expct_mahalanobis_dist / compute_rnk / compute_expct_unk (models/gmm.py:84-94,141-151,
  * models/smm.py:88-96,119-137) from it entirely in fp64 and rounds r (u, log r) once on the way out.  It does NOT accumulate
- * moments: follow it with vmp_mix_stats_ws.  Three streaming launches per iteration instead of one - the default stays the fused pass. */
+ * moments: follow it with vmp_mix_stats_ws_accurate - gmm.update_Nk/xk/Sk (gmm.py:25-46) / smm.update_* (smm.py:25-50) with every
+ * product and sum in fp64, into the same workspace partials vmp_mix_stats_ws leaves (a 5e-8 relative error of P_k, the level of the
+ * default moments, is 1e-4 on the SMM's log rho of rows without a close component).  Three streaming launches per iteration
+ * instead of one - the default stays the fused pass.                                                                       */
 int    vmp_mix_finalize_ws64(const void* ws, const float* pivot, int64_t N, int D, int K, int flavour,
                              const float* alpha0, const float* beta0, const float* m0, const float* C0, const float* v0,
                              const float* kappa, float* alpha, float* beta, float* m, float* C, float* v, float* xbar,
                              float* S, float* pi, float* pack, double* pack64, double* stats_out, void* stream);
 int    vmp_mix_estep_accurate(const float* x, int64_t N, int D, int K, int flavour, const double* pack64, float* r_out,
                               float* u_out, float* logr_out, void* stream);
+int    vmp_mix_stats_ws_accurate(const float* x, const float* r, const float* u, const float* pivot, int64_t N, int D, int K,
+                                 void* ws, size_t ws_bytes, void* stream);
 int    vmp_mix_iterate(const float* x, int64_t N, int D, int K, int flavour,
                        const float* alpha0, const float* beta0, const float* m0, const float* C0, const float* v0,
                        const float* kappa, const float* pivot, float* r, float* u,

@@ -120,9 +120,9 @@ def main():
         spd = A_ @ A_.transpose(-1, -2) + Lg * torch.eye(Lg)
         mu_ = torch.randn(Kg, Lg, generator=gh)
         dev_out = list(gaussian.standard_to_natural(mu_.cuda(), spd.cuda())) + list(gaussian.natural_to_standard(*gaussian.standard_to_natural(mu_.cuda(), spd.cuda()))) \
-            + [niw._inv(spd.cuda()), svae_mod._recognition_bias(mu_.cuda(), -0.5 * spd.cuda(), torch.softmax(mu_[:, 0], 0).cuda())[1]]
+            + [niw._spd_inverse(spd.cuda()), svae_mod._recognition_bias(mu_.cuda(), -0.5 * spd.cuda(), torch.softmax(mu_[:, 0], 0).cuda())[1]]
         host_out = list(gaussian.standard_to_natural(mu_, spd)) + list(gaussian.natural_to_standard(*gaussian.standard_to_natural(mu_, spd))) \
-            + [niw._inv(spd), svae_mod._recognition_bias(mu_, -0.5 * spd, torch.softmax(mu_[:, 0], 0))[1]]
+            + [niw._spd_inverse(spd), svae_mod._recognition_bias(mu_, -0.5 * spd, torch.softmax(mu_[:, 0], 0))[1]]
         res['dpg_klinalg_err'] = np.array([((a.cpu() - b).abs().max() / b.abs().max()).item() for a, b in zip(dev_out, host_out)])
         res['dpg_raw_device_cholesky_err'] = np.float64((torch.linalg.cholesky(spd.cuda()).cpu() - torch.linalg.cholesky(spd)).abs().max().item())
         tr_l = fresh()                                          # a trainer built after the graphed steps == one built before them

@@ -218,6 +218,29 @@ def test_towers_average_gradients(golden):
         close(b, a.numpy(), 1e-12)
 
 
+def test_thread_pool_does_not_change_the_chunked_oracles(golden):
+    """The full-size GPU tests run the oracle's row chunks / towers several at a time (workers=8): independent graphs, combined in
+    chunk order - the results must be bit-identical to the sequential evaluation."""
+    g = golden('svae_paper')
+    st1, (N, K, L, S, Dy, U, steps, smm) = _svae_state(g, torch.float64)
+    st2, _ = _svae_state(g, torch.float64)
+    y, noise, zd = T(g['in_y']), T(g['in_noise'][0]), T(g['in_zdraw'][0])
+    o1 = train_ref.train_step(st1, y, noise, zd, 3e-4, 0.2, 0.95, towers=2)
+    o2 = train_ref.train_step(st2, y, noise, zd, 3e-4, 0.2, 0.95, towers=2, workers=2)
+    assert torch.equal(o1['elbo'], o2['elbo']) and all(torch.equal(o1['grads'][n_], o2['grads'][n_]) for n_ in o1['grads'])
+    rng = np.random.Generator(np.random.PCG64(3))
+    Nn = 50
+    prior, theta = svae_ref.init_mm(K, L, T(rng.random((K, L))), torch.float64)
+    phi = svae_ref.init_recognition_params(theta, T(rng.standard_normal(K)))
+    e1, e2 = T(rng.standard_normal((Nn, L))), -0.5 * torch.nn.functional.softplus(T(rng.standard_normal((Nn, L))))
+    nz, zz = T(rng.standard_normal((Nn, K, L, S))), torch.as_tensor(rng.integers(0, K, size=(Nn, S)))
+    Gx, Glz = T(rng.standard_normal((Nn, K, S, L))), T(rng.standard_normal((Nn, K)))
+    a = train_ref.vmp_step_t2(phi, theta, prior, e1, e2, nz, zz, Gx, Glz, 0.2, chunk=16)
+    b = train_ref.vmp_step_t2(phi, theta, prior, e1, e2, nz, zz, Gx, Glz, 0.2, chunk=16, workers=3)
+    assert torch.equal(a['reg'], b['reg']) and torch.equal(a['g_eta1'], b['g_eta1']) and torch.equal(a['x_samples'], b['x_samples'])
+    assert all(torch.equal(x_, y_) for x_, y_ in zip(a['g_phi'] + a['theta_new'], b['g_phi'] + b['theta_new']))
+
+
 @pytest.mark.parametrize('case', ['metrics', 'metrics_s100'])
 @pytest.mark.parametrize('dtype,suf,rtol', [(torch.float64, '', 1e-12), (torch.float32, '__f32', 1e-4)])
 def test_metrics(golden, case, dtype, suf, rtol):

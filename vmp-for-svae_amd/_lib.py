@@ -31,6 +31,7 @@ _SIGNATURES = {
                                  _c.c_size_t, _P]),
     'vmp_mix_estep_fused': (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
     'vmp_mix_finalize_ws64': (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int] + [_P] * 6 + [_P] * 10 + [_P, _P]),
+    'vmp_mix_stats_ws_accurate': (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _P, _c.c_size_t, _P]),
     'vmp_mix_estep_accurate': (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _P]),
     'vmp_mix_stats_ws': (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _P, _c.c_size_t, _P]),
     'vmp_mix_iterate': (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int] + [_P] * 7 + [_P] * 11 + [_P, _c.c_size_t, _c.c_int, _P]),

@@ -1812,6 +1812,94 @@ __global__ __launch_bounds__(256) void estep_f64_kernel(AccArgs a) {
     }
 }
 
+// fp64 M-pass of the accurate mode: sum_n w_nk [1 | x' | x' x'^T (upper)] and N_k = sum_n r_nk with every product and every sum in
+// fp64 (x' = x - pivot, w = r (GMM) / r u (SMM): products of fp32 values are exact in fp64), into the same per-block partial rows
+// the fused pass leaves for finalize_kernel.  Why: the SMM's log rho = c - 6.5 q with q up to 1e2..1e3 turns a 5e-8 relative
+// error of P_k (the fp32-product moments' level) into 1e-4 on log rho of rows without a close component.
+// Block b owns a contiguous row range; thread t owns the (component, feature) items t, t + blockDim, ..; rows are staged
+// through LDS RS at a time.
+constexpr int ACC_RS = 128, ACC_THREADS = 1024, ACC_ITEMS = 3;   // 64 components x 46 features <= 3 x 1024
+struct AccStatArgs { const float *x, *r, *u, *pivot; double* partials; long long N, rows_per_block; int K; };
+template <int D>
+__global__ __launch_bounds__(ACC_THREADS) void stats_f64_kernel(AccStatArgs a) {
+    using G = Geo<D>;
+    constexpr int FP = G::F + 1;                             // features + the N_k column
+    constexpr int XS = D + 1;                                // staged row: x' and a constant 1
+    extern __shared__ float sm[];
+    const int K = a.K;
+    float* xs = sm;                                          // [RS][XS]
+    float* ws_ = sm + ACC_RS * XS;                           // [RS][K]  w = r (u)
+    float* us_ = ws_ + ACC_RS * K;                           // [RS][K]  u (SMM) - the N_k column needs r alone
+    const bool smm = a.u != nullptr;
+    int ik[ACC_ITEMS], ia[ACC_ITEMS], ib[ACC_ITEMS], isn[ACC_ITEMS];
+    double acc[ACC_ITEMS];
+#pragma unroll
+    for (int q = 0; q < ACC_ITEMS; ++q) {
+        const int it = (int)threadIdx.x + q * ACC_THREADS;
+        const bool on = it < K * FP;
+        const int k = on ? it / FP : 0, f = on ? it - k * FP : 0;
+        ik[q] = on ? k : -1; isn[q] = (f == G::F);
+        int a_ = D, b_ = D;                                  // f = 0 (W_k) and f = F (N_k): feature 1 * 1
+        if (f >= 1 && f <= D) a_ = f - 1;
+        else if (f > D && f < G::F) {
+            int lo = 0, rem = f - 1 - D;
+            while (rem >= D - lo) { rem -= D - lo; ++lo; }
+            a_ = lo; b_ = lo + rem;
+        }
+        ia[q] = a_; ib[q] = b_; acc[q] = 0.0;
+    }
+    const long long lo_row = (long long)blockIdx.x * a.rows_per_block;
+    long long hi_row = lo_row + a.rows_per_block;
+    if (hi_row > a.N) hi_row = a.N;
+    for (long long base = lo_row; base < hi_row; base += ACC_RS) {
+        const int nr = (int)((hi_row - base) < ACC_RS ? (hi_row - base) : ACC_RS);
+        __syncthreads();
+        for (int e = threadIdx.x; e < nr * XS; e += blockDim.x) {
+            const int n = e / XS, d = e - n * XS;
+            xs[e] = d < D ? a.x[(base + n) * D + d] - (a.pivot ? a.pivot[d] : 0.f) : 1.f;    // (x - pivot in fp32, as the fused pass shifts it;
+        }                                                                                   //  finalize un-shifts with the same fp32 pivot in fp64)
+        for (int e = threadIdx.x; e < nr * K; e += blockDim.x) {
+            ws_[e] = a.r[base * K + e];
+            if (smm) us_[e] = a.u[base * K + e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < ACC_ITEMS; ++q) {
+            if (ik[q] < 0) continue;
+            const int k = ik[q];
+            double s = 0.0;
+            for (int n = 0; n < nr; ++n) {
+                const double rr = (double)ws_[n * K + k];
+                const double w = (smm && !isn[q]) ? rr * (double)us_[n * K + k] : rr;
+                s = fma(w, (double)xs[n * XS + ia[q]] * (double)xs[n * XS + ib[q]], s);
+            }
+            acc[q] += s;
+        }
+    }
+    // N_k of this block -> LDS, block total in a fixed order; then the partial rows
+    __syncthreads();
+    double* nk = reinterpret_cast<double*>(sm);              // [K] (+1: total)
+#pragma unroll
+    for (int q = 0; q < ACC_ITEMS; ++q)
+        if (ik[q] >= 0 && isn[q]) nk[ik[q]] = acc[q];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < K; ++k) t += nk[k];
+        nk[K] = t;
+    }
+    __syncthreads();
+    constexpr int PX = G::PF + 1;
+#pragma unroll
+    for (int q = 0; q < ACC_ITEMS; ++q) {
+        if (ik[q] < 0) continue;
+        const int it = (int)threadIdx.x + q * ACC_THREADS, f = it - ik[q] * FP;
+        double* row = a.partials + ((long long)ik[q] * MAX_BLOCKS + blockIdx.x) * PX;
+        row[f] = acc[q];                                     // f = F is the N_k slot
+        if (f == 0) row[G::PF] = nk[K];
+    }
+}
+
 // workspace layout: [per-block partials | reserved words (zeroed by vmp_mix_stats_ws) | status word]
 constexpr size_t WS_TPACK_WORDS = 16 * (VMP_MAX_D + VMP_MAX_D * (VMP_MAX_D + 1) / 2 + 4);
 inline size_t ws_partial_bytes(int D, int K) { return (size_t)MAX_BLOCKS * K * (partial_words(D) + 1) * sizeof(double); }
@@ -1958,6 +2046,28 @@ int vmp_mix_stats_ws(const float* x, const float* r, const float* u, const float
     hipError_t e = hipMemsetAsync(ws_seq(ws, D, K), 0, (WS_TPACK_WORDS + 2) * sizeof(unsigned long long), static_cast<hipStream_t>(stream));
     if (e != hipSuccess) { set_error("vmp_mix_stats_ws: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
     return run_pass(a, D, u ? VMP_SMM : VMP_GMM, false, true, false, static_cast<hipStream_t>(stream));
+}
+
+int vmp_mix_stats_ws_accurate(const float* x, const float* r, const float* u, const float* pivot, int64_t N, int D, int K,
+                              void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_dims(N, D, K);
+    if (rc) return rc;
+    if (!x || !r || !ws) { set_error("vmp_mix_stats_ws_accurate: null pointer"); return VMP_E_BADARG; }
+    if (ws_bytes < vmp_mix_workspace_bytes(N, D, K)) { set_error("vmp_mix_stats_ws_accurate: workspace too small"); return VMP_E_WS; }
+    // the block count finalize_kernel will read (vmp_mix_finalize_ws / _ws64 derive it from the same plan)
+    const int blocks = make_plan(N, D, K, u ? VMP_SMM : VMP_GMM, true).blocks;
+    AccStatArgs a{x, r, u, pivot, static_cast<double*>(ws), N, (N + blocks - 1) / blocks, K};
+    const size_t lds = (size_t)ACC_RS * (D + 1 + 2 * K) * sizeof(float);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(ws_seq(ws, D, K), 0, (WS_TPACK_WORDS + 2) * sizeof(unsigned long long), s);
+    if (e != hipSuccess) { set_error("vmp_mix_stats_ws_accurate: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+    rc = -1;
+    VMP_DISPATCH_D(D, {
+        if (lds > 48 * 1024) { if ((rc = set_dyn_lds(reinterpret_cast<const void*>(stats_f64_kernel<DD>), lds, "stats_f64_kernel")) != 0) return rc; }
+        hipLaunchKernelGGL((stats_f64_kernel<DD>), dim3(blocks), dim3(ACC_THREADS), lds, s, a);
+        rc = check_launch("stats_f64_kernel");
+    });
+    return rc;
 }
 
 int vmp_mix_finalize_exchange(const void* ws, const float* pivot, int64_t N, int D, int K, int flavour, const float* alpha0,

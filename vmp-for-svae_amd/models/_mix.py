@@ -142,7 +142,7 @@ class VMPLoop(object):
     which are exactly the M-pass input of the next iteration; only the very first iteration needs a
     stand-alone M-pass (vmp_mix_stats_ws).
     accurate=True (round 6, opt-in): the E-part runs entirely in fp64 from an fp64 copy of the pack (vmp_mix_finalize_ws64 +
-    vmp_mix_estep_accurate) and the moments of its output come from a separate M-pass (vmp_mix_stats_ws): three streaming launches
+    vmp_mix_estep_accurate) and the moments of its output come from a separate fp64 M-pass (vmp_mix_stats_ws_accurate): three launches
     per iteration instead of one.  It is what meets the stated 1e-5 on the SMM's responsibilities at C5 (whose log rho is linear in
     the Mahalanobis distance with a factor (D + kappa) / 2 and reaches 1e2..1e3: beyond fp32); the default stays the fused pass.
     (A one-launch form of the iteration - posterior in the heads of the streaming launch - was built and measured in round 5:
@@ -172,10 +172,11 @@ class VMPLoop(object):
         self.nb = L.lib().vmp_mix_workspace_bytes(self.N, D, K)
         self.ws = torch.empty(self.nb, dtype=torch.uint8, device=dev)      # private: partials live across calls
         self.pivot = pivot_of(self.x)                                     # once per dataset
-        L.check(L.lib().vmp_mix_stats_ws(L.ptr(self.x), L.ptr(self.r), L.ptr(self.u), L.ptr(self.pivot), self.N, D, K,
-                                         L.ptr(self.ws), self.nb, L.stream()), 'vmp_mix_stats_ws')
-        self.iterations = 0
         self.accurate = bool(accurate)
+        seed_fn = L.lib().vmp_mix_stats_ws_accurate if self.accurate else L.lib().vmp_mix_stats_ws
+        L.check(seed_fn(L.ptr(self.x), L.ptr(self.r), L.ptr(self.u), L.ptr(self.pivot), self.N, D, K,
+                        L.ptr(self.ws), self.nb, L.stream()), 'vmp_mix_stats_ws')
+        self.iterations = 0
         self.pack64 = torch.empty(K, L.lib().vmp_mix_pack_words(D), dtype=torch.float64, device=dev) if self.accurate else None
 
     def finalize(self, stats_out=None):
@@ -204,8 +205,8 @@ class VMPLoop(object):
         if self.accurate:
             L.check(L.lib().vmp_mix_estep_accurate(L.ptr(self.x), self.N, self.D, self.K, self.flavour, L.ptr(self.pack64), L.ptr(self.r),
                                                    L.ptr(self.u), L.ptr(self.logr if want_logr else None), L.stream()), 'vmp_mix_estep_accurate')
-            L.check(L.lib().vmp_mix_stats_ws(L.ptr(self.x), L.ptr(self.r), L.ptr(self.u), L.ptr(self.pivot), self.N, self.D, self.K,
-                                             L.ptr(self.ws), self.nb, L.stream()), 'vmp_mix_stats_ws')
+            L.check(L.lib().vmp_mix_stats_ws_accurate(L.ptr(self.x), L.ptr(self.r), L.ptr(self.u), L.ptr(self.pivot), self.N, self.D,
+                                                      self.K, L.ptr(self.ws), self.nb, L.stream()), 'vmp_mix_stats_ws_accurate')
             return
         L.check(L.lib().vmp_mix_estep_fused(L.ptr(self.x), self.N, self.D, self.K, self.flavour, L.ptr(self.post['pack']),
                                             L.ptr(self.r), L.ptr(self.u), L.ptr(self.logr if want_logr else None),
