@@ -729,7 +729,7 @@ def main():
             aloop = _mix.VMPLoop(x, r0, flav, kappa=kappa, accurate=True)
             aw, _ = time_t1(aloop, args.steps, args.warmup, 7, barrier, None, dev)
             extra['accurate_mode'] = {'ms_per_step': float(np.median(aw)) / args.steps * 1e3, 'default_ms_per_step': dt / args.steps * 1e3,
-                                      'what': 'VMPLoop(accurate=True): vmp_mix_finalize_ws64 + vmp_mix_estep_accurate (fp64 E-part) + vmp_mix_stats_ws; '
+                                      'what': 'VMPLoop(accurate=True): vmp_mix_finalize_ws64 + vmp_mix_estep_accurate (fp64 E-part) + vmp_mix_stats_ws_accurate (fp64 M-pass); '
                                               'meets the literal 1e-5 on r_nk at C5 (tests/test_fullsize_gpu.py smm-c5-accurate)'}
             del aloop
         if world > 1:

@@ -189,23 +189,38 @@ def _chunks(N, chunk):
     return [(i, min(N, i + chunk)) for i in range(0, N, chunk)]
 
 
+WORKERS = 1          # test infrastructure: > 1 evaluates the row chunks of the *_chunked functions several at a time (thread pool)
+
+
+def _pmap(fn, chunks):
+    """[fn(a, b) for (a, b) in chunks], in chunk order - on a thread pool when WORKERS > 1 (ATen releases the GIL; the partial
+    results are combined by the caller in chunk order, so nothing depends on the pool)"""
+    if WORKERS > 1 and len(chunks) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=int(WORKERS)) as ex:
+            return list(ex.map(lambda ab: fn(*ab), chunks))
+    return [fn(a, b) for a, b in chunks]
+
+
 def _m_step_sums_chunked(x, w, chunk):
     """(sum_n w, x_k (NaN/eps handling left to the caller: returns the raw sum too), centred scatter sum)."""
     K, D = w.shape[1], x.shape[1]
     W_k = torch.zeros(K, dtype=x.dtype)
     sx = torch.zeros(K, D, dtype=x.dtype)
-    for a, b in _chunks(x.shape[0], chunk):
-        W_k += w[a:b].sum(0)
-        sx += torch.einsum('nk,nd->kd', w[a:b], x[a:b])
+    for wk_c, sx_c in _pmap(lambda a, b: (w[a:b].sum(0), torch.einsum('nk,nd->kd', w[a:b], x[a:b])), _chunks(x.shape[0], chunk)):
+        W_k += wk_c
+        sx += sx_c
     return W_k, sx
 
 
 def _scatter_chunked(x, w, x_k, chunk):
     K, D = w.shape[1], x.shape[1]
     S = torch.zeros(K, D, D, dtype=x.dtype)
-    for a, b in _chunks(x.shape[0], chunk):
+    def one(a, b):
         d = x[a:b].unsqueeze(1) - x_k.unsqueeze(0)
-        S += torch.einsum('nk,nkd,nke->kde', w[a:b], d, d)
+        return torch.einsum('nk,nkd,nke->kde', w[a:b], d, d)
+    for S_c in _pmap(one, _chunks(x.shape[0], chunk)):
+        S += S_c
     return S
 
 
@@ -226,7 +241,7 @@ def gmm_inference_step_chunked(x, r, chunk=1 << 15):
     C_k = C_0 + N_k.view(-1, 1, 1) * S_k + torch.einsum('k,kd,ke->kde', beta_0 * N_k / beta_k, q0, q0)
     v_k = v_0 + N_k + 1
     P_k = dists.inv(C_k)
-    r_new = torch.cat([gmm_e_step(x[a:b], alpha_k, beta_k, m_k, P_k, v_k)[0] for a, b in _chunks(x.shape[0], chunk)])
+    r_new = torch.cat(_pmap(lambda a, b: gmm_e_step(x[a:b], alpha_k, beta_k, m_k, P_k, v_k)[0], _chunks(x.shape[0], chunk)))
     return r_new, torch.log(r_new), (alpha_k, beta_k, m_k, C_k, v_k), (x_k, S_k, torch.exp(gmm_log_pi(alpha_k)))
 
 
@@ -249,8 +264,7 @@ def smm_inference_step_chunked(x, r, u, kappa, chunk=1 << 15, eps=1e-20):
     P_k = dists.inv(C_k)
     kap = torch.full((K,), float(kappa), dtype=x.dtype) if not torch.is_tensor(kappa) else kappa
     rs, us = [], []
-    for a, b in _chunks(x.shape[0], chunk):
-        r_c, u_c, pi = smm_e_step(x[a:b], alpha_k, beta_k, m_k, P_k, v_k, kap)
+    for r_c, u_c, pi in _pmap(lambda a, b: smm_e_step(x[a:b], alpha_k, beta_k, m_k, P_k, v_k, kap), _chunks(x.shape[0], chunk)):
         rs.append(r_c)
         us.append(u_c)
     return torch.cat(rs), torch.cat(us), (alpha_k, beta_k, m_k, C_k, v_k, kap), (x_k, S_k, pi)

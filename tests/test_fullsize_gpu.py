@@ -58,6 +58,7 @@ def test_t1_three_iterations_at_1e6_vs_chunked_oracle(flavour, shape):
     from vmp_for_svae_amd import _lib as L
     from vmp_for_svae_amd.models import _mix
     N1, D1, K1 = shape                      # c3 / c5: BASELINE configs[2] / [4];  c2: the T1 leg of configs[1]
+    mixtures.WORKERS = 8                    # (row chunks of the oracle on a thread pool, combined in chunk order: oracle/mixtures.py)
     x, r0 = _synth(N1, D1, K1, seed=0)
     xo = torch.as_tensor(x).double()
     xd, rd = torch.as_tensor(x).cuda(), torch.as_tensor(r0).cuda()
