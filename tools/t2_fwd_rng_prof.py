@@ -1,4 +1,4 @@
-"""Profiling target: the T2 forward with in-kernel Philox noise (the trainer's default path) at C3 shape."""
+"""Profiling target: the T2 forward with in-kernel Philox noise and the round-6 epilogue (the trainer's default path) at C3 shape."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vmp_for_svae_amd.models import svae, _svae_ops
@@ -14,6 +14,6 @@ eta1 = torch.randn(N, Ld, device='cuda', generator=g)
 eta2d = -0.5 * torch.log1p(torch.exp(torch.randn(N, Ld, device='cuda', generator=g)))
 for it in range(int(os.environ.get('REPS', 3))):
     with torch.no_grad():
-        x, lz, Tp = _svae_ops.SvaeEStepFn.apply(eta1, eta2d, hk, P, bias, _svae_ops.PhiloxNoise(it, S), mk, Wk, kap, None)
+        x, lz, Tp = _svae_ops.SvaeEStepFn.apply(eta1, eta2d, hk, P, bias, _svae_ops.PhiloxNoise(it, S, epilogue=True), mk, Wk, kap, None)
     del x, lz, Tp
 torch.cuda.synchronize()
