@@ -111,7 +111,8 @@ def test_in_kernel_noise_equals_materialised_stream(N, K, Ld, S):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('N,K,Ld,S', [(1000, 16, 8, 10), (5003, 16, 8, 10), (3, 16, 8, 10), (200_000, 16, 8, 10),   # two-pair staging form + moments
+@pytest.mark.parametrize('N,K,Ld,S', [(1000, 16, 8, 10), (3, 16, 8, 10),                                           # minibatch form (one block per tile)
+                                      (5003, 16, 8, 10), (200_000, 16, 8, 10),                                    # two-pair staging form + moments
                                       (9, 16, 8, 100), (50, 16, 8, 20),                                           # one-pair staging form + moments
                                       (37, 16, 8, 5), (301, 16, 8, 4),                                            # tile-buffer forms, K = 16
                                       (130, 9, 8, 10), (77, 10, 6, 10), (50, 5, 2, 10), (2000, 10, 8, 10)])        # K != 16
@@ -139,7 +140,7 @@ def test_estep_epilogue_equals_the_standalone_kernels(N, K, Ld, S):
     assert torch.equal(pt.x_samples, x[torch.arange(N, device=dev), z[:, 0], 0, :])
     assert (pt.r_nk - torch.exp(lz)).abs().max().item() <= 1e-6
     from vmp_for_svae_amd import _lib as L
-    assert (pt.mom is not None) == (L.lib().vmp_svae_fwd_mom_blocks(N, K, Ld, S) > 0) and (pt.mom is not None or (N, K, Ld, S) not in ((1000, 16, 8, 10), (9, 16, 8, 100)))
+    assert (pt.mom is not None) == (L.lib().vmp_svae_fwd_mom_blocks(N, K, Ld, S) > 0) and (pt.mom is not None or (N, K, Ld, S) not in ((5003, 16, 8, 10), (9, 16, 8, 100)))
     if pt.mom is None:
         return
     stats, _ = _svae_ops.mom_cvi(pt.mom)
@@ -157,6 +158,28 @@ def test_estep_epilogue_equals_the_standalone_kernels(N, K, Ld, S):
     assert torch.equal(st_a, stats)
     for a_, b_ in zip(th_a + star_a, th_b + star_b):
         assert torch.equal(a_, b_)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_small,N,K,Ld,S', [(64, 3000, 10, 8, 10), (1000, 5003, 16, 8, 10), (96, 4000, 7, 5, 4), (40, 9000, 3, 2, 8), (200, 5000, 16, 6, 10)])
+def test_minibatch_form_equals_the_streaming_forms(n_small, N, K, Ld, S):
+    """svae_estep_fwd1_kernel (round 6: one block per tile, one wave per sample pair - the launch a minibatch of the reference's
+    size takes) against the streaming kernels on the same rows: same noise stream and per-sample arithmetic, so the samples, log z,
+    the drawn sub-sample and r are bit-identical; T' sums its per-pair partial sums in another order (last bits)."""
+    from vmp_for_svae_amd.models import svae
+    dev = 'cuda'
+    g = torch.Generator(device=dev).manual_seed(13)
+    eta1 = torch.randn(N, Ld, device=dev, generator=g)
+    eta2d = -0.5 * torch.nn.functional.softplus(torch.randn(N, Ld, device=dev, generator=g))
+    prior, theta = svae.init_mm(K, Ld, seed=0, param_device=dev)
+    phi = list(svae.init_recognition_params(theta, K, seed=0, param_device=dev))
+    with torch.no_grad():
+        xb, lzb, ptb, _ = svae.e_step((eta1, eta2d), phi, S, seed=77, noise='philox', theta=theta)                        # streaming form
+        xs_, lzs, pts, _ = svae.e_step((eta1[:n_small].contiguous(), eta2d[:n_small].contiguous()), phi, S, seed=77, noise='philox', theta=theta)
+    assert torch.equal(xs_, xb[:n_small]) and torch.equal(lzs, lzb[:n_small])
+    assert torch.equal(pts.x_samples, ptb.x_samples[:n_small]) and torch.equal(pts.r_nk, ptb.r_nk[:n_small])
+    scale = ptb.T_prime[:n_small].abs().max()
+    assert ((pts.T_prime - ptb.T_prime[:n_small]).abs().max() / scale).item() < 2e-6
 
 
 @pytest.mark.gpu

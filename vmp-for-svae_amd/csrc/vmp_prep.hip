@@ -305,16 +305,26 @@ __global__ __launch_bounds__(SMALL_STATS_GROUPS * 80) void stats_cvi_kernel(Smal
 // expands them to the raw-moment row [N_k | W_k = N_k | sum r x | sum r x x^T] (svae.m_step -> gmm.update_Nk/xk/Sk,
 // svae.py:154-176, gmm.py:25-46, in the natural-parameter form of SURVEY appendix A.6) and - when theta is given - updates
 // component k of theta from the copy in LDS (svae.update_gmm_params, svae.py:376-403).
-constexpr int MOM_F = 48, MOM_GROUPS = 8, MOM_L = 8;
+constexpr int MOM_F = 48, MOM_GROUPS = 16, MOM_L = 8;
 struct MomArgs { const double* mom; double* stats; int nblk, K; };
 __global__ __launch_bounds__(64 * MOM_GROUPS) void mom_cvi_kernel(MomArgs m, CviArgs a, int do_cvi) {
     __shared__ double part[MOM_GROUPS][64];
     __shared__ double st[2 + MOM_L + MOM_L * MOM_L];
     constexpr int L = MOM_L, SW = 2 + L + L * L;
     const int k = blockIdx.x, f = threadIdx.x & 63, bg = threadIdx.x >> 6;
-    double s = 0.0;
-    if (f < MOM_F)
-        for (int b = bg; b < m.nblk; b += MOM_GROUPS) s += m.mom[((size_t)b * m.K + k) * MOM_F + f];
+    // group bg adds the partials b = bg, bg + G, ..: four independent chains (loads in flight together), combined in a fixed order
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (f < MOM_F) {
+        const double* __restrict__ p = m.mom + (size_t)k * MOM_F + f;
+        const size_t bs = (size_t)m.K * MOM_F;
+        int b = bg;
+        for (; b + 3 * MOM_GROUPS < m.nblk; b += 4 * MOM_GROUPS) {
+            s0 += p[(size_t)b * bs]; s1 += p[(size_t)(b + MOM_GROUPS) * bs];
+            s2 += p[(size_t)(b + 2 * MOM_GROUPS) * bs]; s3 += p[(size_t)(b + 3 * MOM_GROUPS) * bs];
+        }
+        for (; b < m.nblk; b += MOM_GROUPS) s0 += p[(size_t)b * bs];
+    }
+    double s = (s0 + s1) + (s2 + s3);
     part[bg][f] = s;
     __syncthreads();
     if (bg == 0) {
@@ -362,9 +372,20 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void svae_bwd_reduce_kernel(RedArg
     const int e = blockIdx.x * 64 + eg;
     const bool live = e < a.K * half;
     const int k = live ? e / half : 0, f = live ? e - k * half : 0;
-    double s = 0.0;
-    if (live)
-        for (int b = bg; b < a.nblk; b += RED_GROUPS) s += (double)a.partials[((size_t)b * a.K + k) * PW + f];
+    // four independent chains per thread (their loads are in flight together: one chain of nblk / 16 dependent loads was most of
+    // this launch at 512 blocks), combined in a fixed order
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (live) {
+        const float* __restrict__ p = a.partials + (size_t)k * PW + f;
+        const size_t bs = (size_t)a.K * PW;
+        int b = bg;
+        for (; b + 3 * RED_GROUPS < a.nblk; b += 4 * RED_GROUPS) {
+            s0 += (double)p[(size_t)b * bs]; s1 += (double)p[(size_t)(b + RED_GROUPS) * bs];
+            s2 += (double)p[(size_t)(b + 2 * RED_GROUPS) * bs]; s3 += (double)p[(size_t)(b + 3 * RED_GROUPS) * bs];
+        }
+        for (; b < a.nblk; b += RED_GROUPS) s0 += (double)p[(size_t)b * bs];
+    }
+    double s = (s0 + s1) + (s2 + s3);
     part[bg][eg] = s;
     __syncthreads();
     if (bg == 0 && live) {

@@ -1538,6 +1538,172 @@ __global__ __launch_bounds__((RNG ? 8 : 4) * WAVE) void svae_estep_fwd4_kernel(E
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Minibatch form of the in-kernel-noise forward (round 6): lane = (cell, sample PAIR).  At the reference's operating point
+// (experiments.py:26: minibatches of 64-100 rows) a wave of the streaming kernels owns ONE tile and walks its S / 2 sample pairs one
+// after the other - a chain of five generator + solve + theta-term bodies behind the factorisation, 15.6 us for N = 64.  Here a
+// BLOCK owns the tile and wave p of it takes pair p: every wave repeats the cell factorisation (it is the shorter part) and does one
+// pair; the per-cell sums over samples (|eps|^2, the theta term) meet in LDS, wave 0 adds them in pair order and writes log z, T'
+// and the epilogue outputs (its pair holds sample 0, the one subsample_x keeps).  Same stream, same per-sample arithmetic as the
+// streaming forms (x bit-identical); T' differs from theirs in the last bits (partial sums per pair instead of one running sum).
+// ---------------------------------------------------------------------------------------------------------
+#ifndef VMP_FWD1
+#define VMP_FWD1 1                  // 0: A/B builds without the minibatch form
+#endif
+constexpr int FWD1_MAX_PAIRS = 8;        // block = S / 2 waves (S <= 16; 256 registers per lane)
+constexpr int FWD1_MAX_TILES = 256;      // beyond that the streaming forms take over (one block per CU is then no longer latency-bound)
+template <int L>
+__global__ __launch_bounds__(FWD1_MAX_PAIRS * WAVE) void svae_estep_fwd1_kernel(EFwdArgs a) {
+    constexpr int TRI = SvGeo<L>::TRI;
+    constexpr int TP = (TRI + 1) / 2, LP = (L + 1) / 2, L4 = (L + 3) / 4;
+    __shared__ float scr_all[FWD1_MAX_PAIRS][WAVE];
+    __shared__ v2f red[FWD1_MAX_PAIRS][2][WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int K = a.K, S = a.S, LSn = L * S;
+    const int RPT = WAVE / K, CT = RPT * K;
+    const bool lane_on = lane < CT;
+    const int r = lane / K, k = lane - r * K, rbase = lane_on ? r * K : 0, kc = lane_on ? k : 0;
+    const long long t = blockIdx.x, row = t * RPT + r;
+    const bool on = lane_on && row < a.N;
+    const long long rowc = on ? row : 0;
+    const unsigned long long rng_seed = a.seed_dev ? *a.seed_dev : a.seed;
+    const bool student = a.nu != nullptr;
+    float* scr = scr_all[wave];
+    // ---- cell factorisation (every wave: all inputs requested at once)
+    float Lm[TRI], av[L];
+    v2f mk2[LP], Wt2[TP];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const float e1 = a.eta1[rowc * L + i], e2 = a.eta2d[rowc * L + i], hv = a.hk[kc * L + i], mv = a.mk[kc * L + i];
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            const float pv = a.Pk[(kc * L + i) * L + j], wv = a.Wk[(kc * L + i) * L + j];
+            Lm[tri(i, j)] = lane_on ? pv : 0.f;
+            Wt2[tri(i, j) >> 1][tri(i, j) & 1] = lane_on ? wv : 0.f;
+        }
+        Lm[tri(i, i)] = fmaf(-2.f, on ? e2 : -0.5f, Lm[tri(i, i)]);
+        av[i] = (on ? e1 : 0.f) + (lane_on ? hv : 0.f);
+        mk2[i >> 1][i & 1] = lane_on ? mv : 0.f;
+    }
+    if (L & 1) mk2[LP - 1][1] = 0.f;
+    if (TRI & 1) Wt2[TP - 1][1] = 0.f;
+    const float bv = a.bias[kc], kv = a.kappa[kc], nv = *(student ? a.nu + kc : a.bias);
+    const float biask = lane_on ? bv : 0.f, kappak = lane_on ? kv : 0.f, nuk = (student && lane_on) ? nv : 1.f;
+    const float inv_nu = 1.0f / nuk;
+    float ld;
+    cell_cholesky<L>(Lm, ld);
+    solve_lower<L>(Lm, av);
+    float aa = 0.f;
+#pragma unroll
+    for (int i = 0; i < L; ++i) aa = fmaf(av[i], av[i], aa);
+    const float c = on ? (biask + 0.5f * aa - ld) : -INFINITY;
+    const float mx = row_max(c, scr, lane, rbase, K);
+    const float ex = on ? __expf(c - mx) : 0.f;
+    const float se = row_sum(ex, scr, lane, rbase, K);
+    const float lz = c - mx - __logf(se);
+    // ---- this wave's sample pair
+    v2f Lm2[TP], av2[LP];
+#pragma unroll
+    for (int i = 0; i < 2 * TP; ++i) Lm2[i >> 1][i & 1] = (i < TRI) ? Lm[i < TRI ? i : 0] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2 * LP; ++i) av2[i >> 1][i & 1] = (i < L) ? av[i < L ? i : 0] : 0.f;
+    const unsigned long long cellid = (unsigned long long)rowc * (unsigned long long)K + (unsigned long long)kc;
+    const int s0 = 2 * wave;
+    const bool hv = s0 + 1 < S;
+    v2f eps2 = v2f{0.f, 0.f}, qth = v2f{0.f, 0.f}, z[L];
+    {
+        v2f ec[L];
+#pragma unroll
+        for (int j = 0; j < L4; ++j) {
+            v2f p4[4];
+            philox_normal8<false>((unsigned long long)cellid, (unsigned)(wave * L4 + j), rng_seed, p4);
+#pragma unroll
+            for (int t2 = 0; t2 < 4; ++t2)
+                if (4 * j + t2 < L) ec[4 * j + t2] = p4[t2];
+        }
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            v2f e = ec[i];
+            if (!hv) e.y = 0.f;
+            eps2 = __builtin_elementwise_fma(e, e, eps2);
+            z[i] = pk_add_b(e, av2[i >> 1], i & 1);
+        }
+#pragma unroll
+        for (int i = L - 1; i >= 0; --i) {
+            v2f tt = z[i];
+#pragma unroll
+            for (int p2 = i + 1; p2 < L; ++p2) tt = pk_fnma_b(z[p2], Lm2[tri(p2, i) >> 1], tt, tri(p2, i) & 1);
+            z[i] = pk_mul_b(tt, Lm2[tri(i, i) >> 1], tri(i, i) & 1);
+        }
+        v2f d[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) d[i] = pk_sub_b(z[i], mk2[i >> 1], i & 1);
+        v2f del2 = v2f{0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            v2f y = pk_mul_b(d[0], Wt2[tri(i, 0) >> 1], tri(i, 0) & 1);
+#pragma unroll
+            for (int j = 1; j <= i; ++j) y = pk_fma_b(d[j], Wt2[tri(i, j) >> 1], y, tri(i, j) & 1);
+            del2 = __builtin_elementwise_fma(y, y, del2);
+        }
+        if (!hv) del2.y = 0.f;
+        if (student) {
+            const float sc = nuk + (float)L;
+            qth.x = sc * log1p_f(del2.x * inv_nu);
+            qth.y = sc * log1p_f(del2.y * inv_nu);
+        } else {
+            qth = del2;
+        }
+    }
+    if (on) {
+        float* __restrict__ xo = a.x + cellid * (unsigned long long)LSn + (unsigned)(s0 * L);
+        if ((L & 3) == 0 && a.vec_ok) {
+#pragma unroll
+            for (int q = 0; q < L / 4; ++q) reinterpret_cast<float4*>(xo)[q] = float4{z[4 * q].x, z[4 * q + 1].x, z[4 * q + 2].x, z[4 * q + 3].x};
+            if (hv) {
+#pragma unroll
+                for (int q = 0; q < L / 4; ++q) reinterpret_cast<float4*>(xo + L)[q] = float4{z[4 * q].y, z[4 * q + 1].y, z[4 * q + 2].y, z[4 * q + 3].y};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < L; ++i) { xo[i] = z[i].x; if (hv) xo[L + i] = z[i].y; }
+        }
+    }
+    red[wave][0][lane] = eps2;
+    red[wave][1][lane] = qth;
+    __syncthreads();
+    if (wave != 0) return;
+    // ---- wave 0: sums over the pairs in pair order, log z, T', epilogue
+    v2f e2s = red[0][0][lane], qts = red[0][1][lane];
+    for (int w = 1; w < nw; ++w) { e2s += red[w][0][lane]; qts += red[w][1][lane]; }
+    const float invS = 1.0f / (float)S;
+    if (on) {
+        a.lz[row * K + k] = lz;
+        a.Tp[row * K + k] = -0.5f * L * LOG_2PI + ld - 0.5f * invS * (e2s.x + e2s.y) + 0.5f * invS * (qts.x + qts.y) - kappak;
+    }
+    if (a.xs) {
+        // the categorical draw of subsample_x (one draw per row): same arithmetic as subsample_kernel / the streaming forms' epilogue
+        const unsigned long long rowmask = (K < 64 ? (1ull << K) : 0ull) - 1ull;
+        unsigned c4[4] = {(unsigned)rowc, (unsigned)((unsigned long long)rowc >> 32), 0u, SUBSAMPLE_TAG};
+        philox4x32<VMP_PHILOX_ROUNDS>(c4, (unsigned)rng_seed, (unsigned)(rng_seed >> 32));
+        const float uu = (float)(c4[0] >> 8) * 5.9604644775390625e-08f;
+        const float rv = on ? __expf(lz) : 0.f;
+        float cum = rv;
+        for (int o = 1; o < K; o <<= 1) {
+            const float up = __shfl_up(cum, o);
+            if (k >= o) cum += up;
+        }
+        const unsigned long long below = __ballot(on && k < K - 1 && cum <= uu);
+        const int zk = __popcll((below >> rbase) & rowmask);
+        if (on && a.r) a.r[row * K + k] = rv;
+        if (on && k == zk) {
+            float* __restrict__ xo = a.xs + row * L;
+#pragma unroll
+            for (int i = 0; i < L; ++i) xo[i] = z[i].x;
+        }
+    }
+}
+
 // Large-S form of the forward kernel (evaluation runs use S=100, experiments.py:283): the cell's L*S noise block no
 // longer fits the per-wave LDS tile, so the samples are processed SC at a time.  Same lane mapping and arithmetic
 // order per sample as svae_estep_fwd_kernel; eps^2 / q_theta accumulate across chunks in sample order.
@@ -1857,6 +2023,18 @@ static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
         int CS = 0;
         size_t lds4 = 0;
         bool ps = false;
+        {   // minibatch sizes: one block per tile, one wave per sample pair (svae_estep_fwd1_kernel)
+            const long long nt1 = (N + WAVE / K - 1) / (WAVE / K);
+            const int P = (S + 1) / 2;
+            if (VMP_FWD1 && !a.mom && nt1 <= FWD1_MAX_TILES && P <= FWD1_MAX_PAIRS) {
+                rc = -1;
+                VMP_DISPATCH_L(L, {
+                    hipLaunchKernelGGL((svae_estep_fwd1_kernel<LL>), dim3((int)nt1), dim3(P * WAVE), 0, static_cast<hipStream_t>(stream), a);
+                    rc = check_launch("svae_estep_fwd1_kernel");
+                });
+                return rc;
+            }
+        }
         const int nw4 = fwd4_plan(K, L, S, CS, lds4, true, &ps);
         if (nw4 < 1) { set_error("in-kernel noise covers L = 8, and L < 8 with L*S %% 4 == 0 tiles that fit the LDS (L=%d, S=%d)", L, S); return VMP_E_DIM; }
         const int RPT4 = WAVE / K;
@@ -2052,6 +2230,7 @@ int vmp_svae_fwd_mom_blocks(int64_t N, int K, int L, int S) {
     size_t lds4 = 0;
     bool ps = false;
     if (N <= 0 || K != 16 || L != 8) return 0;
+    if (VMP_FWD1 && (N + 3) / 4 <= FWD1_MAX_TILES && (S + 1) / 2 <= FWD1_MAX_PAIRS) return 0;   // minibatch form (svae_estep_fwd1_kernel): no in-kernel moments
     const int nw4 = fwd4_plan(K, L, S, CS, lds4, true, &ps);
     if (nw4 < 1 || !ps) return 0;
     if (lds4 + (size_t)nw4 * 4 * XSEL * sizeof(float) > lds_budget()) return 0;

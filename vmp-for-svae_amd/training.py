@@ -230,15 +230,18 @@ class SVAETrainer(object):
 
     def forward(self, y, noise=None, z_draws=None, u=None, chunk_index=0, _seed_dev=None):
         if noise is None and _seed_dev is not None:
-            # graph-captured step: the key sits in a device word.  At minibatch sizes the stand-alone generator (all elements
-            # in parallel, ~3 us) + the E-step kernel that reads a noise tensor beat generating inside the E-step kernel, where
-            # one wave per SIMD pays the Philox rounds serially (+8 us at N = 64 with round 4's generator, +1.7 us with round 5's
-            # cheaper one: 120.5 vs 118.8 us per step); the stream is the same one.
-            pn = _svae_ops.PhiloxNoise(0, self.S, seed_dev=_seed_dev)
-            gen = lambda: pn.materialise(y.shape[0], self.K, self.L, y.device)
-            noise = gen()
-            if u is None and z_draws is None:
-                u = pn
+            # graph-captured step: the key sits in a device word.  Round 6: where the E-step kernel's own generator covers the shape,
+            # eps is drawn INSIDE it and its epilogue also does the one-draw sub-sampling - the stand-alone generator node
+            # (philox_noise_kernel, ~5 us per replay) and the sub-sampling node (~6.5 us) are gone from the graph (rounds 4 / 5 kept the
+            # stand-alone generator + the noise-tensor kernel there: in-kernel generation alone cost +8 / +1.7 us at N = 64).  Other
+            # shapes materialise the same stream first.
+            if L.lib().vmp_svae_rng_in_kernel(self.K, self.L, self.S):
+                noise = _svae_ops.PhiloxNoise(0, self.S, seed_dev=_seed_dev, epilogue=True)
+            else:
+                pn = _svae_ops.PhiloxNoise(0, self.S, seed_dev=_seed_dev)
+                noise = pn.materialise(y.shape[0], self.K, self.L, y.device)
+                if u is None and z_draws is None:
+                    u = pn
         elif noise is None and self.rng == 'philox':
             noise = 'philox'
         theta_in = None if self.reference_call_order else self.theta
