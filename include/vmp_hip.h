@@ -223,6 +223,15 @@ int    vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk
                           const float* mk, const float* Wk, const float* nu, const float* x, const float* lz,
                           const float* Gx, const float* Glz, const float* GT, int64_t N, int K, int L, int S,
                           float* g_eta1, float* g_eta2d, float* partials, size_t partial_bytes, void* stream);
+/* The same with the number of partial rows stated by the caller (round 6).  nblk = vmp_svae_bwd_blocks_for(N, K, L, S, nu != NULL)
+ * selects the launch geometry of that query: at minibatch sizes (the reference's operating point, experiments.py:26) and a
+ * Gaussian theta that is one block per tile of 64 / K rows with one wave per sample pair - one partial row per TILE instead of
+ * per 4-wave block; nblk = vmp_svae_bwd_blocks(N, K) is vmp_svae_estep_bwd.  The caller reduces exactly nblk rows.     */
+int    vmp_svae_bwd_blocks_for(int64_t N, int K, int L, int S, int student);
+int    vmp_svae_estep_bwd_n(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
+                            const float* mk, const float* Wk, const float* nu, const float* x, const float* lz,
+                            const float* Gx, const float* Glz, const float* GT, int64_t N, int K, int L, int S,
+                            float* g_eta1, float* g_eta2d, float* partials, size_t partial_bytes, int nblk, void* stream);
 
 /* subsample_x (models/svae.py:122-151): z_ns ~ Cat(exp lz_n) and x_samples[n,s,:] = x[n, z_ns, s, :] for s < S_out
  * (the reference draws all S and keeps s = 0, svae.py:514).  The draw is the inverse CDF of the supplied uniform

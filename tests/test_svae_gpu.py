@@ -178,6 +178,39 @@ def test_estep_vs_oracle_shapes():
             assert rel(a_, b_.numpy()) < 2e-4 * max(1.0, S / 10.0) ** 0.5, (tag, n_, rel(a_, b_.numpy()))
 
 
+@pytest.mark.parametrize('N,K,Ld,S', [(64, 10, 8, 10), (100, 16, 8, 10), (7, 3, 2, 3), (130, 7, 5, 4), (300, 5, 8, 16), (64, 10, 6, 1), (1000, 16, 8, 10)])
+def test_minibatch_backward_form_equals_the_streaming_forms(N, K, Ld, S):
+    """svae_estep_bwd1_kernel (round 6: one block per tile, one wave per sample pair; vmp_svae_estep_bwd_n with
+    nblk = vmp_svae_bwd_blocks_for) against the generic / ring kernels (vmp_svae_estep_bwd) on the same inputs: the N-sized
+    gradients and the reduced K-sized gradients agree to fp32 rounding (the per-cell sums over samples are formed per pair first)."""
+    from vmp_for_svae_amd import _lib as L
+    from vmp_for_svae_amd.models import svae
+    g = torch.Generator(device='cuda').manual_seed(N + K)
+    f32 = dict(dtype=torch.float32, device='cuda')
+    eta1 = torch.randn(N, Ld, generator=g, **f32)
+    eta2d = -0.5 * torch.nn.functional.softplus(torch.randn(N, Ld, generator=g, **f32))
+    prior, theta = svae.init_mm(K, Ld, seed=0, param_device='cuda')
+    phi = list(svae.init_recognition_params(theta, K, seed=0, param_device='cuda'))
+    with torch.no_grad():
+        hk, P, bias, mk, Wk, kap = svae.recognition_prep(phi, theta)
+        noise = torch.randn(N, K, Ld, S, generator=g, **f32)
+        x, lz, pt, _ = svae.e_step((eta1, eta2d), phi, S, noise=noise, theta=theta)
+    Gx, Glz, GT = torch.randn(N, K, S, Ld, generator=g, **f32), torch.randn(N, K, generator=g, **f32), torch.rand(N, K, generator=g, **f32)
+    PW = L.lib().vmp_svae_bwd_partial_words(Ld)
+    outs = []
+    for mode in ('minibatch', 'streaming'):
+        nblk = L.lib().vmp_svae_bwd_blocks_for(N, K, Ld, S, 0) if mode == 'minibatch' else L.lib().vmp_svae_bwd_blocks(N, K)
+        g1, g2, part = torch.empty(N, Ld, **f32), torch.empty(N, Ld, **f32), torch.empty(nblk, K, PW, **f32)
+        L.check(L.lib().vmp_svae_estep_bwd_n(L.ptr(eta1), L.ptr(eta2d), L.ptr(hk.contiguous()), L.ptr(P.contiguous()), L.ptr(bias), L.ptr(mk), L.ptr(Wk), None,
+                                             L.ptr(x), L.ptr(lz), L.ptr(Gx), L.ptr(Glz), L.ptr(GT), N, K, Ld, S, L.ptr(g1), L.ptr(g2), L.ptr(part),
+                                             part.numel() * 4, nblk, L.stream()), 'vmp_svae_estep_bwd_n')
+        outs.append((g1, g2, part.double().sum(0)[:, :PW // 2]))
+    assert L.lib().vmp_svae_bwd_blocks_for(N, K, Ld, S, 0) == (N + 64 // K - 1) // (64 // K)      # one partial row per tile
+    for a_, b_, n_ in zip(outs[0], outs[1], ('g_eta1', 'g_eta2d', 'K-sized sums')):
+        e = ((a_ - b_).abs().max() / b_.abs().max().clamp_min(1e-30)).item()
+        assert e < 2e-5, (n_, e)
+
+
 def test_estep_vs_oracle_shapes_student_t():
     """The same comparison with a Student-t theta (svae.py:265-322, student_t.py:7-39: the theta term of T' is
     (nu+L)/2 log1p(delta^2/nu), theta/mu_k and theta/L_k are trainable): shapes with SEVERAL blocks of the backward kernels, so

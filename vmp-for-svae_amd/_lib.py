@@ -48,6 +48,8 @@ _SIGNATURES = {
     'vmp_svae_bwd_partial_words': (_c.c_int, [_c.c_int]),
     'vmp_svae_bwd_blocks': (_c.c_int, [_c.c_int64, _c.c_int]),
     'vmp_svae_workspace_bytes': (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int]),
+    'vmp_svae_bwd_blocks_for': (_c.c_int, [_c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    'vmp_svae_estep_bwd_n': (_c.c_int, [_P] * 13 + [_c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _c.c_size_t, _c.c_int, _P]),
     'vmp_svae_estep_bwd': (_c.c_int, [_P] * 13 + [_c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _c.c_size_t, _P]),
     'vmp_svae_subsample': (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
     'vmp_gauss_logprob_nat_per_samp': (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P]),

@@ -1962,6 +1962,15 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
         default: break;                     \
     }
 
+#ifndef VMP_BWD1
+#define VMP_BWD1 1                  // 0: A/B builds without the minibatch form of the backward kernel
+#endif
+constexpr int BWD1_MAX_PAIRS = 8, BWD1_MAX_TILES = 256;         // (kernel: vmp_svae_mini.hip)
+bool bwd1_applies(int64_t N, int K, int L, int S, bool student) {
+    const long long nt = (N + WAVE / K - 1) / (WAVE / K);
+    return VMP_BWD1 && !student && nt <= BWD1_MAX_TILES && (S + 1) / 2 <= BWD1_MAX_PAIRS;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2265,10 +2274,16 @@ int vmp_svae_estep_fwd_rng_epi(const float* eta1, const float* eta2d, const floa
     return run_fwd(a, L, stream, true);
 }
 
-int vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
-                       const float* mk, const float* Wk, const float* nu, const float* x, const float* lz, const float* Gx,
-                       const float* Glz, const float* GT, int64_t N, int K, int L, int S, float* g_eta1, float* g_eta2d,
-                       float* partials, size_t partial_bytes, void* stream) {
+int vmp_svae_bwd_blocks_for(int64_t N, int K, int L, int S, int student) {
+    if (N <= 0 || K < 1 || K > WAVE) return 0;
+    if (bwd1_applies(N, K, L, S, student != 0)) return (int)((N + WAVE / K - 1) / (WAVE / K));
+    return sv_blocks(N, K);
+}
+
+int vmp_svae_estep_bwd_n(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
+                         const float* mk, const float* Wk, const float* nu, const float* x, const float* lz, const float* Gx,
+                         const float* Glz, const float* GT, int64_t N, int K, int L, int S, float* g_eta1, float* g_eta2d,
+                         float* partials, size_t partial_bytes, int nblk, void* stream) {
     int rc = check_sv(N, K, L, S);
     if (rc) return rc;
     if (!eta1 || !eta2d || !hk || !Pk || !bias || !mk || !Wk || !x || !lz || !Gx || !Glz || !GT || !g_eta1 || !g_eta2d || !partials) {
@@ -2277,7 +2292,13 @@ int vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk, c
     }
     const int blocks = sv_blocks(N, K);
     const int PW = vmp_svae_bwd_partial_words(L);
-    if (partial_bytes < (size_t)blocks * K * PW * sizeof(float)) { set_error("vmp_svae_estep_bwd: partials buffer too small"); return VMP_E_WS; }
+    const bool use1 = bwd1_applies(N, K, L, S, nu != nullptr) && nblk == vmp_svae_bwd_blocks_for(N, K, L, S, nu != nullptr);
+    if (!use1 && nblk != blocks) {
+        set_error("vmp_svae_estep_bwd_n: nblk = %d is neither vmp_svae_bwd_blocks_for (%d) nor vmp_svae_bwd_blocks (%d)", nblk,
+                  vmp_svae_bwd_blocks_for(N, K, L, S, nu != nullptr), blocks);
+        return VMP_E_BADARG;
+    }
+    if (partial_bytes < (size_t)nblk * K * PW * sizeof(float)) { set_error("vmp_svae_estep_bwd: partials buffer too small"); return VMP_E_WS; }
     EBwdArgs a{eta1, eta2d, hk, Pk, bias, mk, Wk, nu, x, lz, Gx, Glz, GT, g_eta1, g_eta2d, partials, N, K, S, 0};
     a.vec_ok = al16(x) && al16(Gx);
 #ifdef VMP_DEBUG_TS
@@ -2287,6 +2308,13 @@ int vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk, c
 #define VMP_T2_RING 1         // 0: build without the LDS-ring backward kernel (A/B measurements: tools/build_variant.sh)
 #endif
     const long long ntiles_g = (N + WAVE / K - 1) / (WAVE / K);
+    if (use1) {
+        // minibatch sizes, Gaussian theta: one block per tile, one wave per sample pair (svae_estep_bwd1_kernel)
+        const int P = (S + 1) / 2;
+        rc = -1;
+        rc = svae_bwd1_launch(a, L, (int)ntiles_g, P, stream);
+        return rc;
+    }
     const bool one = ntiles_g <= (long long)blocks * SV_NW;       // every wave has at most one tile: latency form
     if (VMP_T2_RING && (K == 16 || !one)) {
         // LDS-ring kernels (vmp_svae_ring.hip: quad-coalesced LDS-DMA of sample pairs, two pairs in flight per wave; 8 <= K <= 16,
@@ -2304,6 +2332,14 @@ int vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk, c
         rc = check_launch("svae_estep_bwd_kernel");
     });
     return rc;
+}
+
+int vmp_svae_estep_bwd(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
+                       const float* mk, const float* Wk, const float* nu, const float* x, const float* lz, const float* Gx,
+                       const float* Glz, const float* GT, int64_t N, int K, int L, int S, float* g_eta1, float* g_eta2d,
+                       float* partials, size_t partial_bytes, void* stream) {
+    return vmp_svae_estep_bwd_n(eta1, eta2d, hk, Pk, bias, mk, Wk, nu, x, lz, Gx, Glz, GT, N, K, L, S, g_eta1, g_eta2d, partials,
+                                partial_bytes, N > 0 && K >= 1 && K <= WAVE ? sv_blocks(N, K) : 0, stream);
 }
 
 static int subsample_impl(const char* what, const float* x, const float* lz, const float* u, const int64_t* z, int rng, uint64_t seed,

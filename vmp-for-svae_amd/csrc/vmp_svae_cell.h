@@ -140,4 +140,5 @@ namespace vmp {
 // otherwise the launch status.  nblk_abi = number of partial rows the ABI sized the buffer for (rows the ring grid does not
 // write are zeroed by the kernel).
 int svae_bwd_ring_launch(const EBwdArgs& a, int L, int nblk_abi, void* stream);
+int svae_bwd1_launch(const EBwdArgs& a, int L, int ntiles, int P, void* stream);      // vmp_svae_mini.hip: one block per tile, one wave per sample pair
 }

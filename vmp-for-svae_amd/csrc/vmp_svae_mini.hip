@@ -1,0 +1,259 @@
+// Minibatch form of the SVAE E-step backward (round 6; launcher: vmp_svae_estep_bwd_n in vmp_svae.hip).  A separate translation unit
+// built with -fno-slp-vectorize, like the ring kernels: the SLP vectoriser packs this scalar cell arithmetic into v_pk_*_f32 with
+// op_sel on src1, the operand form of the hardware note in vmp_common.h (tools/erratum_scan.py, tests/test_abi.py).
+#include "vmp_svae_cell.h"
+
+using namespace vmp;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// Minibatch form of the backward kernel (round 6, Gaussian theta): lane = (cell, sample PAIR), the mirror of svae_estep_fwd1_kernel.
+// One block per tile, wave p takes the sample pair p: every wave repeats the cell factorisation and runs the adjoint of ITS two
+// samples (w_s = Lt^-1 gx_s, the sums W = sum_s w_s and M = sum_s e_s w_s^T); the L + TRI per-cell sums meet in LDS, wave 0 adds them
+// in pair order and does the assembly (Cholesky adjoint, rank-one terms), the per-row gradients and the tile's per-component sums,
+// which are this block's partial row.  (The generic kernel's one-tile form walks the S / 2 pairs one after the other behind the
+// factorisation: 19 us at N = 64; partial rows: one per TILE here - vmp_svae_bwd_blocks_for.)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int BWD1_MAX_PAIRS = 8;
+template <int L>
+__global__ __launch_bounds__(BWD1_MAX_PAIRS * WAVE) void svae_estep_bwd1_kernel(EBwdArgs a) {
+    constexpr int TRI = SvGeo<L>::TRI, TH = L + TRI + 1, PW = 2 * TH, NV = L + TRI;
+    constexpr int AST = SV_AST;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int K = a.K, S = a.S, LSn = L * S;
+    const int RPT = WAVE / K, CT = RPT * K;
+    float* scr = smem + wave * WAVE;                         // [nw][64] row-reduction scratch
+    float* red = smem + nw * WAVE;                           // [nw][NV][64] per-pair sums
+    float* accl = red;                                       // wave 0, after the sums are read: [TH][AST] per-lane values of the tile
+    float* rows = red + TH * AST;                            //                                  [2L][AST] row-sum scratch
+    const bool lane_on = lane < CT;
+    const int r = lane / K, k = lane - r * K, rbase = lane_on ? r * K : 0, kc = lane_on ? k : 0;
+    const long long t = blockIdx.x, row = t * RPT + r;
+    const bool on = lane_on && row < a.N;
+    const long long rowc = on ? row : 0, cellid = rowc * K + kc;
+    // ---- everything this lane needs, requested at once
+    const int s0 = 2 * wave;
+    const bool h1 = s0 + 1 < S;
+    float xp[2 * L], gp[2 * L];
+    {
+        const float* __restrict__ xc = a.x + cellid * LSn + s0 * L;
+        const float* __restrict__ gc = a.Gx + cellid * LSn + s0 * L;
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const float xv = xc[i], gv = gc[i], xw = xc[h1 ? L + i : i], gw = gc[h1 ? L + i : i];
+            xp[i] = on ? xv : 0.f; gp[i] = on ? gv : 0.f;
+            xp[L + i] = (on && h1) ? xw : 0.f; gp[L + i] = (on && h1) ? gw : 0.f;
+        }
+    }
+    float Lm[TRI], av[L], mu[L], hkk[L], mkk[L], Wt[TRI];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const float e1 = a.eta1[rowc * L + i], e2 = a.eta2d[rowc * L + i], hv = a.hk[kc * L + i], mv = a.mk[kc * L + i];
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            const float pv = a.Pk[(kc * L + i) * L + j], wv = a.Wk[(kc * L + i) * L + j];
+            Lm[tri(i, j)] = lane_on ? pv : 0.f;
+            Wt[tri(i, j)] = lane_on ? wv : 0.f;
+        }
+        Lm[tri(i, i)] = fmaf(-2.f, on ? e2 : -0.5f, Lm[tri(i, i)]);
+        hkk[i] = lane_on ? hv : 0.f; mkk[i] = lane_on ? mv : 0.f;
+        av[i] = (on ? e1 : 0.f) + hkk[i];
+    }
+    const float glzv = a.Glz[cellid], gTv = a.GT[cellid], lzv = a.lz[cellid];
+    float ld;
+    cell_cholesky<L>(Lm, ld);
+    solve_lower<L>(Lm, av);
+#pragma unroll
+    for (int i = 0; i < L; ++i) mu[i] = av[i];
+    solve_lower_t<L>(Lm, mu);                               // mu~ = Pt^-1 ht
+    const float gT = on ? gTv : 0.f;
+    const float gts = gT * (1.0f / (float)S);
+    // ---- this wave's two samples
+    float Wsum[L], M[TRI];
+#pragma unroll
+    for (int i = 0; i < L; ++i) Wsum[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < TRI; ++i) M[i] = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h == 1 && !h1) break;
+        float xs[L], gx[L], d[L], y[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) { xs[i] = xp[h * L + i]; gx[i] = gp[h * L + i]; d[i] = xs[i] - mkk[i]; }
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            float yy = 0.f;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) yy = fmaf(Wt[tri(i, j)], d[j], yy);
+            y[i] = yy;
+        }
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const float gy = gts * y[i];
+#pragma unroll
+            for (int j = 0; j <= i; ++j) gx[j] = fmaf(Wt[tri(i, j)], gy, gx[j]);
+        }
+        solve_lower<L>(Lm, gx);                             // w_s = Lt^-1 gx_s
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            Wsum[i] += gx[i];
+            const float e = xs[i] - mu[i];                  // e_s = Lt^-T eps_s
+#pragma unroll
+            for (int j = 0; j <= i; ++j) M[tri(i, j)] = fmaf(e, gx[j], M[tri(i, j)]);
+        }
+    }
+    {
+        float* rw = red + wave * (NV * WAVE) + lane;
+#pragma unroll
+        for (int i = 0; i < L; ++i) rw[i * WAVE] = Wsum[i];
+#pragma unroll
+        for (int i = 0; i < TRI; ++i) rw[(L + i) * WAVE] = M[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+    for (int w = 1; w < nw; ++w) {
+        const float* rw = red + w * (NV * WAVE) + lane;
+#pragma unroll
+        for (int i = 0; i < L; ++i) Wsum[i] += rw[i * WAVE];
+#pragma unroll
+        for (int i = 0; i < TRI; ++i) M[i] += rw[(L + i) * WAVE];
+    }
+    __builtin_amdgcn_wave_barrier();                         // (accl / rows below overlay the sums just read)
+    const float glz = on ? glzv : 0.f;
+    const float rnk = on ? __expf(lzv) : 0.f;
+    const float gsum = row_sum(glz, scr, lane, rbase, K);
+    const float Gc = glz - rnk * gsum;                      // through the log-sum-exp normalisation
+    const float Gld = gT - Gc;                              // T' has +ld, c has -ld
+    // ---- assemble dLoss/dht and dLoss/dPt (symmetric, lower triangle): as svae_estep_bwd_kernel
+    float V[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) V[i] = Wsum[i];
+    solve_lower_t<L>(Lm, V);                                // V = Pt^-1 sum_s gx_s
+    float gh[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) gh[i] = fmaf(Gc, mu[i], V[i]);
+    float Cs[TRI], dg[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) dg[i] = 1.0f / Lm[tri(i, i)];
+#pragma unroll
+    for (int i = 0; i < L; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int p = i; p < L; ++p) {
+                const float lpi = (p == i) ? dg[i] : Lm[tri(p, i)];
+                s2 = fmaf(lpi, -M[tri(p, j)], s2);
+            }
+            Cs[tri(i, j)] = (i == j) ? (s2 + Gld) : s2;
+        }
+    float Y[TRI];
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        Y[tri(j, j)] = Lm[tri(j, j)];
+#pragma unroll
+        for (int i = j + 1; i < L; ++i) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int p = j; p < i; ++p) s2 = fmaf(Lm[tri(i, p)], Y[tri(p, j)], s2);
+            Y[tri(i, j)] = -s2 * Lm[tri(i, i)];
+        }
+    }
+    float gP[TRI];
+#pragma unroll
+    for (int i = 0; i < TRI; ++i) gP[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        float Zc[L];
+#pragma unroll
+        for (int q = 0; q < L; ++q) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int p = j; p < L; ++p) {
+                const float cqp = (q >= p) ? Cs[tri(q, p)] : Cs[tri(p, q)];
+                s2 = fmaf(cqp, Y[tri(p, j)], s2);
+            }
+            Zc[q] = s2;
+        }
+#pragma unroll
+        for (int i = j; i < L; ++i) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int p = i; p < L; ++p) s2 = fmaf(Y[tri(p, i)], Zc[p], s2);
+            gP[tri(i, j)] = 0.5f * s2;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < L; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j)
+            gP[tri(i, j)] += -0.5f * (V[i] * mu[j] + mu[i] * V[j]) - 0.5f * Gc * mu[i] * mu[j];
+    // ---- the tile's values to LDS: per-row sums (encoder gradients) and per-component sums (this block's partial row)
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        accl[i * AST + lane] = on ? gh[i] : 0.f;
+        rows[i * AST + lane] = on ? gh[i] : 0.f;
+        rows[(L + i) * AST + lane] = on ? gP[tri(i, i)] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TRI; ++i) accl[(L + i) * AST + lane] = on ? gP[i] : 0.f;
+    accl[(L + TRI) * AST + lane] = on ? Gc : 0.f;
+    }   // wave 0
+    // ---- the whole block shares the two output loops (the other waves have been waiting for wave 0's assembly)
+    __syncthreads();
+    for (int q0 = threadIdx.x; q0 < 2 * L * RPT; q0 += blockDim.x) {
+        const int rr = q0 / (2 * L), i0 = q0 - rr * (2 * L);
+        const float* __restrict__ p0 = rows + i0 * AST + rr * K;
+        float sq = 0.f;
+#pragma unroll 4
+        for (int j = 0; j < K; ++j) sq += p0[j];
+        const long long row0 = t * RPT + rr;
+        if (row0 < a.N) {
+            if (i0 < L) a.g_eta1[row0 * L + i0] = sq;
+            else a.g_eta2d[row0 * L + (i0 - L)] = -2.f * sq;   // p = -2 eta2d
+        }
+    }
+    float* out = a.partials + (long long)blockIdx.x * K * PW;
+    for (int e = threadIdx.x; e < K * PW; e += blockDim.x) {
+        const int kk = e / PW, f = e - kk * PW;
+        float sq = 0.f;
+        if (f < TH)
+            for (int rr = 0; rr < RPT; ++rr) sq += accl[f * AST + rr * K + kk];
+        out[e] = sq;
+    }
+}
+
+template <int L>
+int launch_bwd1(const EBwdArgs& a, int ntiles, int P, void* stream) {
+    constexpr int TRI = L * (L + 1) / 2;
+    constexpr int NV = L + TRI;
+    constexpr int TH = L + TRI + 1;
+    const int epi = TH * SV_AST + 2 * L * SV_AST;
+    const int work = P * NV * WAVE > epi ? P * NV * WAVE : epi;
+    const size_t lds1 = (size_t)(P * WAVE + work) * sizeof(float);
+    if (lds1 > 48 * 1024) {
+        if (const int rc = set_dyn_lds(reinterpret_cast<const void*>(svae_estep_bwd1_kernel<L>), lds1, "svae_estep_bwd1_kernel")) return rc;
+    }
+    hipLaunchKernelGGL((svae_estep_bwd1_kernel<L>), dim3(ntiles), dim3(P * WAVE), lds1, static_cast<hipStream_t>(stream), a);
+    return check_launch("svae_estep_bwd1_kernel");
+}
+
+}  // namespace
+
+namespace vmp {
+int svae_bwd1_launch(const EBwdArgs& a, int L, int ntiles, int P, void* stream) {
+    switch (L) {
+        case 1: return launch_bwd1<1>(a, ntiles, P, stream);
+        case 2: return launch_bwd1<2>(a, ntiles, P, stream);
+        case 3: return launch_bwd1<3>(a, ntiles, P, stream);
+        case 4: return launch_bwd1<4>(a, ntiles, P, stream);
+        case 5: return launch_bwd1<5>(a, ntiles, P, stream);
+        case 6: return launch_bwd1<6>(a, ntiles, P, stream);
+        case 7: return launch_bwd1<7>(a, ntiles, P, stream);
+        case 8: return launch_bwd1<8>(a, ntiles, P, stream);
+        default: return -1;
+    }
+}
+}  // namespace vmp

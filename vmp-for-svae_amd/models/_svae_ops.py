@@ -120,13 +120,13 @@ class SvaeEStepFn(torch.autograd.Function):
         g_T = torch.zeros_like(lz) if g_T is None else g_T.contiguous()
         g_eta1 = torch.empty(N, Ld, **f32)
         g_eta2d = torch.empty(N, Ld, **f32)
-        nblk = L.lib().vmp_svae_bwd_blocks(N, K)
+        nblk = L.lib().vmp_svae_bwd_blocks_for(N, K, Ld, S, int(nu is not None))   # minibatch sizes: one partial row per tile
         PW = L.lib().vmp_svae_bwd_partial_words(Ld)
         partials = torch.empty(nblk, K, PW, **f32)
-        L.check(L.lib().vmp_svae_estep_bwd(L.ptr(eta1), L.ptr(eta2d), L.ptr(hk), L.ptr(Pk), L.ptr(bias), L.ptr(mk),
-                                           L.ptr(Wk), L.ptr(nu), L.ptr(x), L.ptr(lz), L.ptr(g_x), L.ptr(g_lz), L.ptr(g_T),
-                                           N, K, Ld, S, L.ptr(g_eta1), L.ptr(g_eta2d), L.ptr(partials),
-                                           partials.numel() * 4, L.stream()), 'vmp_svae_estep_bwd')
+        L.check(L.lib().vmp_svae_estep_bwd_n(L.ptr(eta1), L.ptr(eta2d), L.ptr(hk), L.ptr(Pk), L.ptr(bias), L.ptr(mk),
+                                             L.ptr(Wk), L.ptr(nu), L.ptr(x), L.ptr(lz), L.ptr(g_x), L.ptr(g_lz), L.ptr(g_T),
+                                             N, K, Ld, S, L.ptr(g_eta1), L.ptr(g_eta2d), L.ptr(partials),
+                                             partials.numel() * 4, nblk, L.stream()), 'vmp_svae_estep_bwd_n')
         # fixed-order fp64 reduction of the per-block partials + unpacking into the K-sized gradients: one launch
         g_hk, g_P, g_bias = torch.empty(K, Ld, **f32), torch.empty(K, Ld, Ld, **f32), torch.empty(K, **f32)
         g_mk = g_W = g_kappa = None
