@@ -608,7 +608,8 @@ def shard_steps(N, D, K, S, U, flav, kappa, dev, ms1, exch_us, exch_detail):
         torch.cuda.empty_cache()
         t['t2'][G] = bench_t2(n, D, K, S, 6, 2, dev, None, 1, cpu=False, tensor_mode=False)['ms_per_step']
         torch.cuda.empty_cache()
-        t['t3'][G] = bench_t3(n, D, K, S, U, 5, 3, dev, None, cpu=False, randn_mode=False)['ms_per_step']
+        t['t3'][G] = bench_t3(n, D, K, S, U, 5, 3, dev, None, cpu=False, randn_mode=False)['per_step_ms_median']     # (median of the per-step HIP-event times:
+        #                                                            one allocator-growth step in five would otherwise decide the factor)
         torch.cuda.empty_cache()
         out['rows_per_rank'][str(G)] = n
     ex = {'t1': exch_us['t1_peer'] * 1e-3, 't2': exch_us['t2'] * 1e-3, 't3': exch_us['t3'] * 1e-3}       # ms
@@ -822,7 +823,7 @@ def main():
             if (N, D, K) == (1_000_000, 8, 16):
                 # (c) the per-GPU steps of a STRONG-scaling run, timed on this one GPU: N / 2, N / 4, N / 8 rows per rank
                 extra['shard_steps'] = shard_steps(N, D, K, args.s, args.u, flav, kappa, dev, ms1={
-                    't1': dt / args.steps * 1e3, 't2': extra['t2_svae_vmp']['ms_per_step'], 't3': extra['t3_svae_train']['ms_per_step']},
+                    't1': dt / args.steps * 1e3, 't2': extra['t2_svae_vmp']['ms_per_step'], 't3': extra['t3_svae_train']['per_step_ms']['median']},
                     exch_us={'t1_rccl': extra['t1_forced_dist_1rank']['rccl_overhead_us'], 't1_peer': extra['t1_forced_dist_1rank']['dist_overhead_us'],
                              't2': exch_us['t2']['allreduce_us_1rank'], 't3': exch_us['t3']['allreduce_us_1rank']}, exch_detail=exch_us)
                 torch.cuda.empty_cache()
