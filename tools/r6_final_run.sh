@@ -49,3 +49,5 @@ j=json.loads(open('$O/bench_$f.json').read().strip().splitlines()[-1]); r=j['roo
 print('$f', 'ms/step %.3f' % j['ms_per_step'], 'kernel %.3f ms' % r['kernel_ms'], 'frac %.3f' % r['frac'], 'cpu x%.0f' % j.get('speedup_vs_cpu_baseline', float('nan')))
 PY
 done
+# C2-shaped T2 line (verdict r5, item 8): N = 1e5, L = 2, K = 10 - the generic backward kernel's shape (the ring needs even L >= 4)
+python bench.py --workload t2 --n 100000 --d 2 --k 10 --steps 20 --warmup 5 > $O/bench_t2_c2.json 2>> $O/bench.err
