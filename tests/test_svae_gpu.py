@@ -117,7 +117,9 @@ def test_estep_vs_oracle_shapes():
                           # >= 1024 wave tiles with S / 2 >= 4: the shapes a four-stage build (-DVMP_RING_STAGES=4) takes
                           (4101, 16, 8, 10), (6201, 10, 8, 8),
                           # odd K (an odd number of cells per tile: the parity of a tile's first cell alternates) with rotated pairs
-                          (8301, 15, 8, 6), (14405, 9, 8, 6)]:
+                          (8301, 15, 8, 6), (14405, 9, 8, 6),
+                          # small L at streaming sizes (C2's latent dimension): several blocks per CU since round 6 (> 512 backward blocks)
+                          (40000, 10, 2, 10), (30000, 7, 3, 4), (25000, 16, 1, 6)]:
         e1 = rng.standard_normal((N, Ld))
         e2 = -0.5 * (0.3 + rng.random((N, Ld)))
         mu_k = rng.standard_normal((K, Ld)) * 2

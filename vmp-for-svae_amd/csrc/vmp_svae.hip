@@ -1936,6 +1936,25 @@ int check_sv(long long N, int K, int L, int S) {
 #ifdef VMP_DEBUG_TS
 static long long* g_dbg_svae = nullptr;
 #endif
+// Small latent dimensions (C1 / C2: L = 2) leave most of a SIMD's registers and of the CU's LDS idle at one block per CU, and their
+// tiles are short dependent chains: several blocks per CU (round 6; the big-L geometries stay as tuned).  Per-lane registers by L
+// (tools/kreg.py): forward 77 / 95 (L = 2 / 3), generic backward 71 / 95.
+inline int fwd4_blocks_per_cu(int L, size_t lds_block) {
+    const int by_regs = L <= 2 ? 3 : L == 3 ? 2 : 1;                 // 8-wave blocks: 6 / 4 / 2 waves per SIMD
+    const int by_lds = lds_block ? (int)(lds_budget() / lds_block) : 1;
+    const int b = by_regs < by_lds ? by_regs : by_lds;
+    return b < 1 ? 1 : b;
+}
+inline int sv_blocks_l(long long N, int K, int L) {
+    const int RPT = WAVE / K;
+    const long long ntiles = (N + RPT - 1) / RPT;
+    long long b = (ntiles + SV_NW - 1) / SV_NW;
+    const long long cap = L <= 2 ? 2048 : L == 3 ? 1280 : 512;     // 4-wave blocks: 8 / 5 / 2 per CU
+    if (b > cap) b = cap;
+    if (b > SV_MAX_BLOCKS) b = SV_MAX_BLOCKS;
+    return (int)b;
+}
+
 int sv_blocks(long long N, int K) {
     const int RPT = WAVE / K;
     const long long ntiles = (N + RPT - 1) / RPT;
@@ -2048,7 +2067,8 @@ static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
         if (nw4 < 1) { set_error("in-kernel noise covers L = 8, and L < 8 with L*S %% 4 == 0 tiles that fit the LDS (L=%d, S=%d)", L, S); return VMP_E_DIM; }
         const int RPT4 = WAVE / K;
         long long bl = ((N + RPT4 - 1) / RPT4 + nw4 - 1) / nw4;
-        if (bl > 256) bl = 256;
+        const long long blcap = 256ll * fwd4_blocks_per_cu(L, lds4);
+        if (bl > blcap) bl = blcap;
         if (a.mom) {
             if (!(ps && K == 16 && L == 8)) { set_error("in-kernel moments cover K = 16, L = 8 (vmp_svae_fwd_mom_blocks)"); return VMP_E_DIM; }
             lds4 += (size_t)nw4 * 4 * XSEL * sizeof(float);          // the waves' drawn-sample records
@@ -2108,7 +2128,8 @@ static int run_fwd(EFwdArgs a, int L, void* stream, bool rng) {
             const size_t lds4 = table + pw * nw4;
             const int RPT4 = WAVE / K;
             long long bl = ((N + RPT4 - 1) / RPT4 + nw4 - 1) / nw4;
-            if (bl > 256) bl = 256;
+            const long long blcap = 256ll * fwd4_blocks_per_cu(L, lds4);
+            if (bl > blcap) bl = blcap;
             rc = -1;
             VMP_DISPATCH_L(L, {
                 if (S == 10) {
@@ -2277,7 +2298,7 @@ int vmp_svae_estep_fwd_rng_epi(const float* eta1, const float* eta2d, const floa
 int vmp_svae_bwd_blocks_for(int64_t N, int K, int L, int S, int student) {
     if (N <= 0 || K < 1 || K > WAVE) return 0;
     if (bwd1_applies(N, K, L, S, student != 0)) return (int)((N + WAVE / K - 1) / (WAVE / K));
-    return sv_blocks(N, K);
+    return sv_blocks_l(N, K, L);                              // L <= 3 (generic kernel): more blocks per CU; otherwise vmp_svae_bwd_blocks
 }
 
 int vmp_svae_estep_bwd_n(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
@@ -2293,7 +2314,8 @@ int vmp_svae_estep_bwd_n(const float* eta1, const float* eta2d, const float* hk,
     const int blocks = sv_blocks(N, K);
     const int PW = vmp_svae_bwd_partial_words(L);
     const bool use1 = bwd1_applies(N, K, L, S, nu != nullptr) && nblk == vmp_svae_bwd_blocks_for(N, K, L, S, nu != nullptr);
-    if (!use1 && nblk != blocks) {
+    const bool wide = !use1 && L <= 3 && nblk == sv_blocks_l(N, K, L);        // small L: the generic kernel on more blocks per CU
+    if (!use1 && !wide && nblk != blocks) {
         set_error("vmp_svae_estep_bwd_n: nblk = %d is neither vmp_svae_bwd_blocks_for (%d) nor vmp_svae_bwd_blocks (%d)", nblk,
                   vmp_svae_bwd_blocks_for(N, K, L, S, nu != nullptr), blocks);
         return VMP_E_BADARG;
@@ -2315,7 +2337,8 @@ int vmp_svae_estep_bwd_n(const float* eta1, const float* eta2d, const float* hk,
         rc = svae_bwd1_launch(a, L, (int)ntiles_g, P, stream);
         return rc;
     }
-    const bool one = ntiles_g <= (long long)blocks * SV_NW;       // every wave has at most one tile: latency form
+    const int gblocks = wide ? nblk : blocks;
+    const bool one = ntiles_g <= (long long)gblocks * SV_NW;      // every wave has at most one tile: latency form
     if (VMP_T2_RING && (K == 16 || !one)) {
         // LDS-ring kernels (vmp_svae_ring.hip: quad-coalesced LDS-DMA of sample pairs, two pairs in flight per wave; 8 <= K <= 16,
         // even L >= 4, even S >= 4, Gaussian or Student-t theta).  Batches of one tile per wave with K != 16 keep the generic
@@ -2327,8 +2350,8 @@ int vmp_svae_estep_bwd_n(const float* eta1, const float* eta2d, const float* hk,
     const size_t lds = (size_t)(K * ((L * (L + 1) / 2) | 1) + SV_NW * WAVE + SV_NW * 2 * L * SV_AST + SV_NW * PWa * SV_AST) * sizeof(float);
     rc = -1;
     VMP_DISPATCH_L(L, {
-        if (one) hipLaunchKernelGGL((svae_estep_bwd_kernel<LL, true>), dim3(blocks), dim3(SV_NW * WAVE), lds, static_cast<hipStream_t>(stream), a);
-        else hipLaunchKernelGGL((svae_estep_bwd_kernel<LL, false>), dim3(blocks), dim3(SV_NW * WAVE), lds, static_cast<hipStream_t>(stream), a);
+        if (one) hipLaunchKernelGGL((svae_estep_bwd_kernel<LL, true>), dim3(gblocks), dim3(SV_NW * WAVE), lds, static_cast<hipStream_t>(stream), a);
+        else hipLaunchKernelGGL((svae_estep_bwd_kernel<LL, false>), dim3(gblocks), dim3(SV_NW * WAVE), lds, static_cast<hipStream_t>(stream), a);
         rc = check_launch("svae_estep_bwd_kernel");
     });
     return rc;
