@@ -48,6 +48,39 @@ def test_in_kernel_noise_plan_is_host_logic():
     assert q(0, 8, 10) == 0 and q(65, 8, 10) == 0 and q(16, 9, 10) == 0
 
 
+def test_round6_entry_points_validate_on_the_host():
+    """The geometry queries and argument checks of the round-6 entry points are host logic (no launch happens before them):
+    vmp_svae_bwd_blocks_for / vmp_svae_estep_bwd_n (one partial row per tile at minibatch sizes, several blocks per CU at L <= 3),
+    vmp_svae_fwd_mom_blocks / vmp_svae_estep_fwd_rng_epi / vmp_svae_mom_cvi (in-kernel moments: K = 16, L = 8, streaming sizes),
+    vmp_mix_finalize_ws64 / vmp_mix_estep_accurate / vmp_mix_stats_ws_accurate."""
+    import ctypes
+    import vmp_for_svae_amd as V
+    lib = V._lib.lib()
+    P = ctypes.c_void_p(64)                                   # a non-NULL pointer that is never dereferenced: every call below fails its checks first
+    # backward partial rows: one per tile of 64 // K rows for minibatches of a Gaussian theta, the block count otherwise
+    assert lib.vmp_svae_bwd_blocks_for(64, 10, 8, 10, 0) == 11 and lib.vmp_svae_bwd_blocks_for(64, 10, 8, 10, 1) == lib.vmp_svae_bwd_blocks(64, 10)
+    assert lib.vmp_svae_bwd_blocks_for(64, 10, 8, 100, 0) == lib.vmp_svae_bwd_blocks(64, 10)             # S / 2 > 8 waves: not the minibatch form
+    assert lib.vmp_svae_bwd_blocks_for(10**6, 16, 8, 10, 0) == lib.vmp_svae_bwd_blocks(10**6, 16) == 512
+    assert lib.vmp_svae_bwd_blocks_for(10**5, 10, 2, 10, 0) == 2048 and lib.vmp_svae_bwd_blocks_for(10**5, 10, 3, 10, 0) == 1280   # small L
+    assert lib.vmp_svae_bwd_blocks_for(0, 10, 8, 10, 0) == 0
+    rc = lib.vmp_svae_estep_bwd_n(*([P] * 13), 64, 10, 8, 10, P, P, P, 1 << 20, 7, None)                    # 7 is neither count
+    assert rc < 0 and b'nblk' in lib.vmp_last_error()
+    # in-kernel moments
+    assert lib.vmp_svae_fwd_mom_blocks(10**6, 16, 8, 10) == 256 and lib.vmp_svae_fwd_mom_blocks(10**6, 10, 8, 10) == 0
+    assert lib.vmp_svae_fwd_mom_blocks(10**6, 16, 4, 10) == 0 and lib.vmp_svae_fwd_mom_blocks(512, 16, 8, 10) == 0       # minibatch form: none
+    rc = lib.vmp_svae_estep_fwd_rng_epi(*([P] * 5), 1, None, *([P] * 3), None, 10**6, 10, 8, 10, P, P, P, P, P, P, 1 << 30, None)
+    assert rc != 0 and b'moments' in lib.vmp_last_error()                                                # K = 10 has no in-kernel moments
+    rc = lib.vmp_svae_estep_fwd_rng_epi(*([P] * 5), 1, None, *([P] * 3), None, 10**6, 16, 8, 10, P, P, P, P, P, P, 16, None)
+    assert rc != 0 and b'too small' in lib.vmp_last_error()
+    rc = lib.vmp_svae_mom_cvi(P, 4, *([P] * 15), None, 0.2, 10, 8, P, None)
+    assert rc != 0 and b'K = 16' in lib.vmp_last_error()
+    # accurate mixture mode
+    assert lib.vmp_mix_estep_accurate(P, 100, 8, 16, 1, P, P, None, None, None) < 0 and b'u_out' in lib.vmp_last_error()
+    assert lib.vmp_mix_estep_accurate(P, 100, 9, 16, 0, P, P, None, None, None) != 0                       # D outside the compiled range
+    assert lib.vmp_mix_finalize_ws64(P, None, 100, 8, 16, 0, *([P] * 5), None, *([P] * 8), P, None, None, None) < 0   # pack64 missing
+    assert lib.vmp_mix_stats_ws_accurate(P, P, None, None, 100, 8, 16, P, 8, None) != 0 and b'workspace' in lib.vmp_last_error()
+
+
 def test_no_cpu_fallback():
     import vmp_for_svae_amd as V
     from vmp_for_svae_amd.models import gmm, _mix
