@@ -31,8 +31,9 @@ __device__ __forceinline__ void store_lines(char* tile, int lane, int first_coup
     *reinterpret_cast<f32x4*>(tile + (size_t)couple * (2 * CELL) + line * 128 + (lane & 7) * 16) = v;
 }
 template <int MODE>
-__global__ __launch_bounds__(512) void k(char* buf, long long ntiles, int gap) {
+__global__ __launch_bounds__(512) void k(char* buf, long long ntiles, int gap, unsigned long long* clk) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
     const f32x4 v = {1.f * lane, 2.f, 3.f, 4.f};
     for (long long t = (long long)blockIdx.x * nw + wave; t < ntiles; t += (long long)gridDim.x * nw) {
         char* tile = buf + t * TILE;
@@ -86,27 +87,30 @@ __global__ __launch_bounds__(512) void k(char* buf, long long ntiles, int gap) {
             for (int g = 0; g < 4; ++g) store_lines(tile, lane, 8 * g, 2, v);
         }
     }
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = clock64() - c0; clk[2 * blockIdx.x + 1] = wall_clock64() - w0; }   // shader cycles, 100 MHz ticks
 }
 int main() {
     const long long ntiles = 250000;                           // 1e6 rows x 16 cells / 64 = 5.12 GB
     char* buf; hipMalloc(&buf, ntiles * TILE);
+    unsigned long long* clk; hipMallocManaged(&clk, 512 * sizeof(unsigned long long));
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     const char* names[6] = {"seq ", "pst2", "pst4", "none", "1/20 ", "4/5  "};
-    for (int gap : {0, -4000, 2600, 3000, 3400, 4000}) {
+    for (int gap : {0, -4000, 3000, 4000}) {
         for (int mode = 0; mode < 6; ++mode) {
             float best = 1e9f;
             for (int rep = 0; rep < 5; ++rep) {
                 hipEventRecord(a);
-                if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(512), 0, 0, buf, ntiles, gap);
-                if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(512), 0, 0, buf, ntiles, gap);
-                if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(512), 0, 0, buf, ntiles, gap);
-                if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(256), dim3(512), 0, 0, buf, ntiles, gap);
-                if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(256), dim3(512), 0, 0, buf, ntiles, gap);
-                if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(256), dim3(512), 0, 0, buf, ntiles, gap);
+                if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(512), 0, 0, buf, ntiles, gap, clk);
+                if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(512), 0, 0, buf, ntiles, gap, clk);
+                if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(512), 0, 0, buf, ntiles, gap, clk);
+                if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(256), dim3(512), 0, 0, buf, ntiles, gap, clk);
+                if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(256), dim3(512), 0, 0, buf, ntiles, gap, clk);
+                if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(256), dim3(512), 0, 0, buf, ntiles, gap, clk);
                 hipEventRecord(b); hipEventSynchronize(b);
                 float ms; hipEventElapsedTime(&ms, a, b); if (rep && ms < best) best = ms;
             }
-            printf("gap %5d cycles/flush (%s)  %s : %.3f ms  %.0f GB/s\n", gap, gap < 0 ? "sleep" : "packed FMAs", names[mode], best, ntiles * (double)TILE / (best * 1e-3) / 1e9);
+            double cyc = 0, tick = 0; for (int bl = 0; bl < 256; ++bl) { cyc += clk[2 * bl]; tick += clk[2 * bl + 1]; }
+            printf("gap %5d cycles/flush (%s)  %s : %.3f ms  %.0f GB/s   shader clock %.0f MHz\n", gap, gap < 0 ? "sleep" : "packed FMAs", names[mode], best, ntiles * (double)TILE / (best * 1e-3) / 1e9, cyc / tick * 100.0);
         }
     }
     return 0;
