@@ -387,6 +387,77 @@ int    vmp_svae_elbo_tail(const float* log_z, const float* T_prime, const float*
                           float sigma, float* scalars, float* g_log_z, float* g_T_prime, float* r, void* ws,
                           size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * The minibatch training step in 7 + 1 launches (round 6; experiments.py:196-267 at its own operating point, minibatches
+ * of 64-100 rows, where a step is bound by the NUMBER of launches - 13 + the input copy before)
+ * ------------------------------------------------------------------------------------------------
+ *   vmp_svae_step_inputs         [eager, per replay] scalars of the step + the minibatch into the static input
+ *   vmp_mlp_gauss_head_fwd       encoder                                  (vae.make_encoder, vae.py:131-135)
+ *   vmp_svae_prep_fwd2           recognition unpacking + theta packing    (svae.py:342-358, 205-214)
+ *   vmp_svae_estep_fwd_rng_epi   E-step, sub-sample, r                    (svae.py:14-151)
+ *   vmp_decoder_elbo_lazy        decoder value + gradients; parameter partials stay in ws
+ *   vmp_svae_estep_bwd_tail      ELBO tail + E-step backward              (svae.py:216-254 and the autodiff of :14-119)
+ *   vmp_mlp_gauss_head_bwd_lazy  encoder backward; parameter partials stay in ws
+ *   vmp_svae_step_final          partial rows -> gradients of phi_gmm (autodiff of svae.py:342-358), both MLP partial
+ *                                reductions, Adam on all 21 tensors, M-step moments + CVI update, ELBO scalars
+ * Every value equals what the stand-alone launches produce (same device functions, same summation orders); the ELBO
+ * scalars are summed per tile instead of per tail block (fp64: equal to fp32 rounding).                              */
+
+/* vmp_svae_step_scalars (below) and the copy of the minibatch (n_floats fp32 words, y_src -> y_dst) in one launch. */
+int    vmp_svae_step_inputs(void* dst16, uint64_t philox_key, float cvi_step, float adam_step, const float* y_src,
+                            float* y_dst, int64_t n_floats, void* stream);
+/* Number of partial rows the fused MLP backward kernel writes for `rows` input rows (N*K*S for the decoder). */
+int    vmp_decoder_bwd_blocks(int64_t rows);
+/* vmp_decoder_elbo without its second launch: dx, ll as there; the (vmp_decoder_bwd_blocks(N*K*S), param_words) fp32
+ * parameter partials are left in ws for vmp_svae_step_final.  The scalar tail runs inside vmp_svae_estep_bwd_tail.  */
+int    vmp_decoder_elbo_lazy(const float* x, const float* y, const float* log_z, float sigma, const float* W0,
+                             const float* b0, const float* W1, const float* b1, const float* W2, const float* b2,
+                             const float* Ws, const float* bs1, const float* bs2, int64_t N, int K, int S, int L, int Dy,
+                             int U, float* dx, float* ll, void* ws, size_t ws_bytes, void* stream);
+/* vmp_mlp_gauss_head_bwd without the partial reduction ((vmp_decoder_bwd_blocks(R), param_words) partials stay in ws). */
+int    vmp_mlp_gauss_head_bwd_lazy(const float* x, const float* g_out1, const float* g_out2, float var_scale,
+                                   const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
+                                   const float* b2, const float* Ws, const float* bs1, const float* bs2, int64_t R, int L,
+                                   int Dy, int U, float* dx, void* ws, size_t ws_bytes, void* stream);
+/* 1 when vmp_svae_estep_bwd_tail covers the shape (the minibatch form: <= 256 tiles of 64 / K rows, S <= 16). */
+int    vmp_svae_bwd_tail_applies(int64_t N, int K, int L, int S);
+/* vmp_svae_elbo_tail's (N,K) pass + vmp_svae_estep_bwd_n in ONE launch, Gaussian theta: dLoss/dlog_z and dLoss/dT' are
+ * formed per cell inside the kernel (sigma * d elbo, as the tail) and never reach memory.  Gx = sigma * d elbo / dx from
+ * the decoder.  Outputs: g_eta1, g_eta2d, partials (one row per tile: vmp_svae_bwd_blocks_for) as vmp_svae_estep_bwd_n;
+ * r (N,K) = exp(log_z); tail_part (tiles, 2) fp64 = per-tile [sum r A / 2S, sum r (T' + log z)].                     */
+int    vmp_svae_estep_bwd_tail(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
+                               const float* mk, const float* Wk, const float* x, const float* lz, const float* T_prime,
+                               const float* ll, float sigma, const float* Gx, int64_t N, int K, int L, int S,
+                               float* g_eta1, float* g_eta2d, float* partials, size_t partial_bytes, float* r,
+                               double* tail_part, size_t tail_bytes, void* stream);
+/* vmp_svae_prep_fwd that also leaves log softmax(pi_raw) (K) fp64 in logpi (may be NULL): the backward forms below read it
+ * instead of the other components' pi_raw. */
+int    vmp_svae_prep_fwd2(const float* mu_k, const float* L_raw, const float* pi_raw, const float* alpha, const float* A,
+                          const float* b, const float* beta, const float* v_hat, int K, int L, float* Lk, float* P,
+                          float* bias, float* m, float* W, float* kappa, double* logpi, void* stream);
+/* vmp_svae_bwd_reduce (phi side) + vmp_svae_phi_prep_bwd in one launch (stand-alone form of what vmp_svae_step_final does for
+ * phi_gmm): block k sums component k's rows of `partials` (nblk, K, vmp_svae_bwd_partial_words) in the order of
+ * vmp_svae_bwd_reduce and differentiates the recognition unpacking on them. */
+int    vmp_svae_bwd_reduce_prep(const float* partials, int nblk, const float* mu_k, const float* L_raw, const float* pi_raw,
+                                const double* logpi, int K, int L, float* g_mu, float* g_Lraw, float* g_piraw, void* stream);
+/* The closing launch.  dec_* / enc_*: parameter partials of the two MLPs (rows: *_blocks; sizes: in, units, out = (L,U,Dy)
+ * for the decoder, (Dy,U,L) for the encoder), their 9 parameter / Adam-m / Adam-v tensors and 9 gradient outputs, in the
+ * order [W0,b0,W1,b1,W2,b2,Ws,bs1,bs2]; partials (nblk rows) of vmp_svae_estep_bwd_tail and logpi of vmp_svae_prep_fwd2;
+ * phi_*: the three phi_gmm tensors (mu_k (K,L), L_k (K,L,L), log_pi_k (K)), gradient outputs phi_g; x_samples (N,L), r (N,K): the M-step's inputs (N <= 512); prior, theta, theta_star: 5 natural
+ * NIW / Dirichlet tensors each [alpha, A, b, beta, v_hat] (theta updated in place, theta_star may be NULL);
+ * rho / rho_dev, lr_t / lr_t_dev as vmp_svae_cvi_update / vmp_adam_step; stats_out (K, 2+L+L*L) fp64;
+ * tail_part (tail_n, 2) from vmp_svae_estep_bwd_tail -> scalars [elbo, rec, reg].                                   */
+int    vmp_svae_step_final(const float* dec_part, int dec_blocks, int dec_in, int dec_units, int dec_out,
+                           float* const* dec_p, float* const* dec_m, float* const* dec_v, float* const* dec_g,
+                           const float* enc_part, int enc_blocks, int enc_in, int enc_units, int enc_out,
+                           float* const* enc_p, float* const* enc_m, float* const* enc_v, float* const* enc_g,
+                           const float* partials, int nblk, const double* logpi,
+                           float* const* phi_p, float* const* phi_g, float* const* phi_m, float* const* phi_v,
+                           const float* x_samples, const float* r, int64_t N, const float* const* prior,
+                           float* const* theta, float* const* theta_star, const float* rho_dev, float rho, int K, int L,
+                           double* stats_out, const double* tail_part, int tail_n, int Dy, float* scalars, double beta1,
+                           double beta2, double eps, double lr_t, const float* lr_t_dev, void* stream);
+
 /* Writes the 16 bytes [Philox key (u64) | CVI step size (f32) | Adam step size (f32)] that a graph-captured training step
  * reads at run time (vmp_svae_estep_fwd_rng_dev / vmp_svae_subsample_rng seed_dev, vmp_svae_cvi_update rho_dev,
  * vmp_adam_step lr_t_dev = dst16 + 0 / 8 / 12): one launch, values passed by value.                                  */

@@ -494,6 +494,49 @@ def test_graphed_step_matches_eager():
     assert torch.isfinite(out['elbo']) and all(torch.isfinite(p).all() for p in tr2.trainables()[1])
 
 
+@pytest.mark.parametrize('N,K,Ld,U,Dy,S', [(64, 10, 8, 50, 6, 10), (100, 16, 8, 64, 8, 10), (37, 7, 4, 33, 3, 8), (5, 3, 2, 16, 1, 4),
+                                          (512, 8, 6, 50, 6, 10)])
+def test_direct_minibatch_step_equals_the_autograd_step(N, K, Ld, U, Dy, S):
+    """Round 6: SVAETrainer._step_direct (7 launches: lazy partial reductions, the ELBO tail inside the E-step backward, ONE closing
+    launch for partial rows -> phi_gmm gradients, both reductions, Adam, moments + CVI, scalars) against the autograd step
+    over the stand-alone launches of the same device functions: every gradient, parameter, Adam slot, theta tensor and moment
+    BIT-identical over 4 steps; the three ELBO scalars (summed per tile instead of per tail block, fp64) to 1e-6.  Also the graphed
+    replay of the direct step against the eager one (same Philox stream: call i == step i)."""
+    from vmp_for_svae_amd.models import vae
+    from vmp_for_svae_amd.training import SVAETrainer, GraphedSVAEStep
+    g = torch.Generator(device='cuda').manual_seed(N + K)
+    ys = [torch.randn(N, Dy, device='cuda', generator=g) * 2 for _ in range(4)]
+
+    def run(direct, graphed=False):
+        vae.reset_variables()
+        tr = SVAETrainer(K, Ld, U, Dy, nb_samples=S, lr=3e-3, lrcvi=0.2, decay_rate=0.95, stddev_init_nn=0.1, seed=3, direct_step=direct)
+        assert tr._direct_ok(ys[0], None, None, None, None) == direct
+        stepper = GraphedSVAEStep(tr, ys[0]) if graphed else tr.step
+        outs = []
+        for i in range(4):
+            o = stepper(ys[i])
+            outs.append(dict(elbo=[o[k].item() for k in ('elbo', 'neg_rec_err', 'regulariser')],
+                             grads={k: v.detach().clone() for k, v in o['grads'].items()},
+                             star=[t.clone() for t in o['theta_star']], log_z=o['log_z'].clone(), xs=o['x_samples'].clone()))
+        assert tr.global_step == 4 and tr.opt.t == 4
+        state = [p.detach().clone() for p in tr.trainables()[1]] + [t.clone() for t in tr.theta] + [t.clone() for t in tr.opt.m] + \
+                [t.clone() for t in tr.opt.v]
+        return outs, state
+    want_o, want_s = run(False)
+    for graphed in (False, True):
+        got_o, got_s = run(True, graphed)
+        for i, (a, b) in enumerate(zip(got_o, want_o)):
+            for x, y_ in zip(a['elbo'], b['elbo']):
+                assert abs(x - y_) <= 1e-6 * max(abs(b['elbo'][1]), abs(b['elbo'][2])), (i, a['elbo'], b['elbo'])
+            for k in b['grads']:
+                assert torch.equal(a['grads'][k], b['grads'][k]), (graphed, i, k, rel(a['grads'][k], b['grads'][k].double().cpu().numpy()))
+            for x, y_ in zip(a['star'], b['star']):
+                assert torch.equal(x, y_), (graphed, i)
+            assert torch.equal(a['log_z'], b['log_z']) and torch.equal(a['xs'], b['xs'])
+        for j, (a, b) in enumerate(zip(got_s, want_s)):
+            assert torch.equal(a, b), (graphed, j)
+
+
 def test_sample_x_per_comp_standalone_matches_fused(golden):
     """svae.sample_x_per_comp (svae.py:95-119) on the materialised phi_tilde reproduces the samples of the fused E-step
     kernel and the reference's x_k."""

@@ -175,7 +175,7 @@ __device__ __forceinline__ double small_stats_component(const SmallStatsArgs& a,
     const int g = threadIdx.x / 80, i = threadIdx.x % 80;
     const int D = a.D, SW = 2 + D + D * D;
     double s = 0.0;
-    if (i < SW) {
+    if (i < SW && g < SMALL_STATS_GROUPS) {                 // (blocks of more than 12 x 80 threads: the surplus threads idle)
         const int d = i < 2 + D ? (i < 2 ? 0 : i - 2) : (i - 2 - D) / D, e = i < 2 + D ? 0 : (i - 2 - D) % D;
 #pragma unroll 2
         for (int n = g; n < a.N; n += SMALL_STATS_GROUPS) {
@@ -190,7 +190,7 @@ __device__ __forceinline__ double small_stats_component(const SmallStatsArgs& a,
             s += t;
         }
     }
-    part[g][i] = s;
+    if (g < SMALL_STATS_GROUPS) part[g][i] = s;
     __syncthreads();
     double t = part[0][i];
 #pragma unroll

@@ -33,6 +33,7 @@
 // XDL pipe overlaps the VALU only partially; the kernels are bound by VALU + MFMA issue.
 #include "vmp_common.h"
 #include "vmp_tail.h"
+#include "vmp_step_parts.h"
 
 using namespace vmp;
 
@@ -1079,28 +1080,12 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void dec_bwd_kernel(DecArgs a) {
     DEC_TS(5);
 }
 
-struct DecRedArgs {
-    const float* part;
-    const float* bs2;
-    float* out;
-    int blocks, PW, obs2, Dy;
-};
-// 64 consecutive parameters per block; lane group bg = tid / 64 sums the block rows b = bg, bg + 16, .. (independent coalesced
-// loads instead of one chain of `blocks` dependent ones), the 16 group sums are added in a fixed order.
-constexpr int DEC_RED_GROUPS = 16;
+// (partials -> parameter gradients: dec_reduce_sum, vmp_step_parts.h)
 __device__ __forceinline__ void dec_reduce_body(const DecRedArgs& r, const int blk) {
     __shared__ double part[DEC_RED_GROUPS][64];
-    const int eg = threadIdx.x & 63, bg = threadIdx.x >> 6;
-    const int i = blk * 64 + eg;
-    double s = 0.0;
-    if (i < r.PW)
-        for (int b = bg; b < r.blocks; b += DEC_RED_GROUPS) s += (double)r.part[(size_t)b * r.PW + i];
-    part[bg][eg] = s;
-    __syncthreads();
-    if (bg != 0 || i >= r.PW) return;
-    for (int g2 = 1; g2 < DEC_RED_GROUPS; ++g2) s += part[g2][eg];
-    if (i >= r.obs2) s *= 1.0 / (1.0 + exp(-(double)r.bs2[i - r.obs2]));
-    r.out[i] = (float)s;
+    const double s = dec_reduce_sum(r, blk, part);
+    const int i = blk * 64 + (threadIdx.x & 63);
+    if ((threadIdx.x >> 6) == 0 && i < r.PW) r.out[i] = (float)s;
 }
 __global__ __launch_bounds__(64 * DEC_RED_GROUPS) void dec_reduce_kernel(DecRedArgs r) { dec_reduce_body(r, blockIdx.x); }
 
@@ -1190,18 +1175,20 @@ int dec_bwd_launch(const DecArgs& a0, int blocks, hipStream_t s) {
     return check_launch(GIN ? "vmp_mlp_gauss_bwd" : "vmp_decoder_loglike_bwd");
 }
 
-int decoder_loglike_bwd_impl(const char* what, float logw, const TailArgs* tail, unsigned tail_blocks, const float* x, const float* y, const float* gA,
+// lazy: the per-block parameter partials stay in `ws` ((vmp_decoder_bwd_blocks, PW) fp32) for a later launch to reduce - no reduce launch here
+int decoder_loglike_bwd_impl(const char* what, float logw, const TailArgs* tail, unsigned tail_blocks, bool lazy, const float* x, const float* y, const float* gA,
                              const float* W0, const float* b0, const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws,
                             const float* bs1, const float* bs2, int64_t N, int K, int S, int L, int Dy, int U, float* dx,
                             float* dparams, float* ll, void* ws, size_t ws_bytes, void* stream) {
     if (int e = dec_check(what, N, K, S, L, Dy, U)) return e;
-    if (!x || !y || !gA || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !Ws || !bs1 || !bs2 || !dx || !dparams || !ws) {
+    if (!x || !y || !gA || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !Ws || !bs1 || !bs2 || !dx || (!dparams && !lazy) || !ws) {
         set_error("%s: NULL argument", what);
         return VMP_E_BADARG;
     }
     const DecGeo q = dec_geo(L, U, Dy);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (N == 0) {
+        if (lazy) { set_error("%s: N = 0", what); return VMP_E_DIM; }
         (void)hipMemsetAsync(dparams, 0, (size_t)q.PW * sizeof(float), s);
         return check_launch(what);
     }
@@ -1216,6 +1203,7 @@ int decoder_loglike_bwd_impl(const char* what, float logw, const TailArgs* tail,
     a.R = (unsigned)(N * K * S); a.K = (unsigned)K; a.S = (unsigned)S; a.L = L; a.Dy = Dy; a.U = U;
     const int blocks = dec_bwd_blocks((long long)a.R);
     if (int e = dec_bwd_launch<false>(a, blocks, s)) return e;
+    if (lazy) return 0;
     DecRedArgs r{a.part, bs2, dparams, blocks, q.PW, q.obs2, Dy};
     const int red_blocks = (q.PW + 63) / 64;
     if (tail) {
@@ -1253,18 +1241,19 @@ int decoder_fwd_impl(const char* what, float vscale, const float* x, const float
     return check_launch(what);
 }
 
-int mlp_gauss_bwd_impl(const char* what, float vscale, const float* x, const float* gmean, const float* gvar, const float* W0, const float* b0,
+int mlp_gauss_bwd_impl(const char* what, float vscale, bool lazy, const float* x, const float* gmean, const float* gvar, const float* W0, const float* b0,
                       const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws, const float* bs1,
                       const float* bs2, int64_t R, int L, int Dy, int U, float* dx, float* dparams, void* ws,
                       size_t ws_bytes, void* stream) {
     if (int e = dec_check(what, R, 1, 1, L, Dy, U)) return e;
-    if (!x || !gmean || !gvar || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !Ws || !bs1 || !bs2 || !dparams || !ws) {
+    if (!x || !gmean || !gvar || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !Ws || !bs1 || !bs2 || (!dparams && !lazy) || !ws) {
         set_error("%s: NULL argument", what);
         return VMP_E_BADARG;
     }
     const DecGeo q = dec_geo(L, U, Dy);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (R == 0) {
+        if (lazy) { set_error("%s: R = 0", what); return VMP_E_DIM; }
         (void)hipMemsetAsync(dparams, 0, (size_t)q.PW * sizeof(float), s);
         return check_launch(what);
     }
@@ -1278,6 +1267,7 @@ int mlp_gauss_bwd_impl(const char* what, float vscale, const float* x, const flo
     a.R = (unsigned)R; a.K = 1; a.S = 1; a.L = L; a.Dy = Dy; a.U = U;
     const int blocks = dec_bwd_blocks((long long)a.R);
     if (int e = dec_bwd_launch<true>(a, blocks, s)) return e;
+    if (lazy) return 0;
     DecRedArgs r{a.part, bs2, dparams, blocks, q.PW, q.obs2, Dy};
     hipLaunchKernelGGL(dec_reduce_kernel, dim3((q.PW + 63) / 64), dim3(64 * DEC_RED_GROUPS), 0, s, r);
     return check_launch(what);
@@ -1315,7 +1305,7 @@ int vmp_decoder_loglike_bwd(const float* x, const float* y, const float* gA, con
                             const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws,
                             const float* bs1, const float* bs2, int64_t N, int K, int S, int L, int Dy, int U, float* dx,
                             float* dparams, float* ll, void* ws, size_t ws_bytes, void* stream) {
-    return decoder_loglike_bwd_impl("vmp_decoder_loglike_bwd", 0.f, nullptr, 0, x, y, gA, W0, b0, W1, b1, W2, b2, Ws, bs1, bs2, N, K, S, L, Dy, U,
+    return decoder_loglike_bwd_impl("vmp_decoder_loglike_bwd", 0.f, nullptr, 0, false, x, y, gA, W0, b0, W1, b1, W2, b2, Ws, bs1, bs2, N, K, S, L, Dy, U,
                                     dx, dparams, ll, ws, ws_bytes, stream);
 }
 
@@ -1327,7 +1317,7 @@ int vmp_decoder_loglike_bwd_logw(const float* x, const float* y, const float* lo
         set_error("vmp_decoder_loglike_bwd_logw: w_scale must not be 0");
         return VMP_E_BADARG;
     }
-    return decoder_loglike_bwd_impl("vmp_decoder_loglike_bwd_logw", w_scale, nullptr, 0, x, y, log_w, W0, b0, W1, b1, W2, b2, Ws, bs1, bs2, N, K,
+    return decoder_loglike_bwd_impl("vmp_decoder_loglike_bwd_logw", w_scale, nullptr, 0, false, x, y, log_w, W0, b0, W1, b1, W2, b2, Ws, bs1, bs2, N, K,
                                     S, L, Dy, U, dx, dparams, ll, ws, ws_bytes, stream);
 }
 
@@ -1350,7 +1340,7 @@ int vmp_decoder_elbo(const float* x, const float* y, const float* log_z, const f
     }
     TailArgs t{};
     const unsigned tb = tail_setup(t, log_z, T_prime, ll, N, K, S, Dy, sigma, scalars, g_log_z, g_T_prime, r, tail_ws, 64 * DEC_RED_GROUPS);
-    return decoder_loglike_bwd_impl("vmp_decoder_elbo", -sigma * 0.5f / (float)S, &t, tb, x, y, log_z, W0, b0, W1, b1, W2, b2, Ws, bs1,
+    return decoder_loglike_bwd_impl("vmp_decoder_elbo", -sigma * 0.5f / (float)S, &t, tb, false, x, y, log_z, W0, b0, W1, b1, W2, b2, Ws, bs1,
                                     bs2, N, K, S, L, Dy, U, dx, dparams, ll, ws, ws_bytes, stream);
 }
 
@@ -1358,7 +1348,7 @@ int vmp_mlp_gauss_bwd(const float* x, const float* gmean, const float* gvar, con
                       const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws, const float* bs1,
                       const float* bs2, int64_t R, int L, int Dy, int U, float* dx, float* dparams, void* ws,
                       size_t ws_bytes, void* stream) {
-    return mlp_gauss_bwd_impl("vmp_mlp_gauss_bwd", 1.0f, x, gmean, gvar, W0, b0, W1, b1, W2, b2, Ws, bs1, bs2, R, L, Dy, U, dx, dparams,
+    return mlp_gauss_bwd_impl("vmp_mlp_gauss_bwd", 1.0f, false, x, gmean, gvar, W0, b0, W1, b1, W2, b2, Ws, bs1, bs2, R, L, Dy, U, dx, dparams,
                               ws, ws_bytes, stream);
 }
 
@@ -1366,8 +1356,37 @@ int vmp_mlp_gauss_head_bwd(const float* x, const float* g_out1, const float* g_o
                            const float* b0, const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws,
                            const float* bs1, const float* bs2, int64_t R, int L, int Dy, int U, float* dx, float* dparams,
                            void* ws, size_t ws_bytes, void* stream) {
-    return mlp_gauss_bwd_impl("vmp_mlp_gauss_head_bwd", var_scale, x, g_out1, g_out2, W0, b0, W1, b1, W2, b2, Ws, bs1, bs2, R, L, Dy, U,
+    return mlp_gauss_bwd_impl("vmp_mlp_gauss_head_bwd", var_scale, false, x, g_out1, g_out2, W0, b0, W1, b1, W2, b2, Ws, bs1, bs2, R, L, Dy, U,
                               dx, dparams, ws, ws_bytes, stream);
+}
+
+// ---- round 6: the minibatch training step reduces the parameter partials inside its ONE closing launch (vmp_svae_step_final,
+// vmp_step.hip); these entry points run the fused MLP backward kernel alone and leave (vmp_decoder_bwd_blocks(rows), PW) fp32
+// partials in `ws`.
+int vmp_decoder_bwd_blocks(int64_t rows) { return rows > 0 ? dec_bwd_blocks((long long)rows) : 0; }
+
+int vmp_decoder_elbo_lazy(const float* x, const float* y, const float* log_z, float sigma, const float* W0, const float* b0,
+                          const float* W1, const float* b1, const float* W2, const float* b2, const float* Ws, const float* bs1,
+                          const float* bs2, int64_t N, int K, int S, int L, int Dy, int U, float* dx, float* ll, void* ws,
+                          size_t ws_bytes, void* stream) {
+    if (sigma == 0.f || !ll || !log_z) {
+        set_error("vmp_decoder_elbo_lazy: NULL argument or sigma == 0");
+        return VMP_E_BADARG;
+    }
+    if (N <= 0 || K < 1 || S < 1) {
+        set_error("vmp_decoder_elbo_lazy: N = %lld, K = %d, S = %d", (long long)N, K, S);
+        return VMP_E_DIM;
+    }
+    return decoder_loglike_bwd_impl("vmp_decoder_elbo_lazy", -sigma * 0.5f / (float)S, nullptr, 0, true, x, y, log_z, W0, b0, W1, b1, W2, b2,
+                                    Ws, bs1, bs2, N, K, S, L, Dy, U, dx, nullptr, ll, ws, ws_bytes, stream);
+}
+
+int vmp_mlp_gauss_head_bwd_lazy(const float* x, const float* g_out1, const float* g_out2, float var_scale, const float* W0,
+                                const float* b0, const float* W1, const float* b1, const float* W2, const float* b2,
+                                const float* Ws, const float* bs1, const float* bs2, int64_t R, int L, int Dy, int U, float* dx,
+                                void* ws, size_t ws_bytes, void* stream) {
+    return mlp_gauss_bwd_impl("vmp_mlp_gauss_head_bwd_lazy", var_scale, true, x, g_out1, g_out2, W0, b0, W1, b1, W2, b2, Ws, bs1, bs2, R, L,
+                              Dy, U, dx, nullptr, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -5,12 +5,13 @@
 // these maps were ~120 tiny torch kernels (batched Cholesky / triangular solves with host-side error checks, tril,
 // softplus, digamma ...) and their autograd; here they are 4 launches.
 #include "vmp_common.h"
+#include "vmp_step_parts.h"
+#include "vmp_prep_parts.h"
 
 using namespace vmp;
 
 namespace {
 
-constexpr int PREP_THREADS = 64;     // K <= VMP_MAX_K = 64
 // L is a template parameter everywhere: with run-time loop bounds the per-thread matrices live in scratch memory and
 // every element access is a dependent round trip (measured: 50 us per launch instead of a few).
 #define PREP_DISPATCH_L(L, CALL)                                                     \
@@ -19,211 +20,13 @@ constexpr int PREP_THREADS = 64;     // K <= VMP_MAX_K = 64
         case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break; default: CALL(8); break; \
     }
 
-__device__ __forceinline__ double softplus_d(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
-
-__device__ double digamma_dd(double x) {
-    double r = 0.0;
-    while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
-    const double f = 1.0 / (x * x);
-    return r + log(x) - 0.5 / x
-           - f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f * (1.0 / 132 - f * (691.0 / 32760))))));
-}
-
-// L_k = tril(raw) with softplus on the diagonal (svae.py:347-352), rounded to fp32 as the tensors the reference holds
-template <int L>
-__device__ __forceinline__ void load_Lk(const float* __restrict__ raw, double (&Lm)[L][L]) {
-#pragma unroll
-    for (int i = 0; i < L; ++i)
-#pragma unroll
-        for (int j = 0; j < L; ++j) {
-            double v = 0.0;
-            if (j < i) v = (double)raw[i * L + j];
-            else if (j == i) v = (double)(float)softplus_d((double)raw[i * L + i]);
-            Lm[i][j] = v;
-        }
-}
-
-struct PhiArgs {
-    const float* mu;      // (K,L)  'phi_gmm/mu_k' (used as eta1, svae.py:345)
-    const float* Lraw;    // (K,L,L)
-    const float* piraw;   // (K)
-    const float* g_hk;    // bwd: (K,L)
-    const float* g_P;     // bwd: (K,L,L) gradient w.r.t. the full matrix P = L L^T
-    const float* g_bias;  // bwd: (K)
-    float* Lk;            // fwd out (K,L,L)
-    float* P;             // fwd out (K,L,L)
-    float* bias;          // fwd out (K): B_k + log softmax(piraw)_k
-    float* g_mu;          // bwd out
-    float* g_Lraw;        // bwd out
-    float* g_piraw;       // bwd out
-    int K, L;
-};
-
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ double wave_max_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
-}
-// r[idx] of a register array with a lane-dependent index (selects: no scratch memory)
-template <int L>
-__device__ __forceinline__ double pick(const double (&r)[L], int idx) {
-    double v = r[0];
-#pragma unroll
-    for (int q = 1; q < L; ++q) v = idx == q ? r[q] : v;
-    return v;
-}
-
-// One 64-lane block per component; lane (i, j) = (lane / L, lane % L) owns element (i, j) of the L x L matrices, lanes
-// j < K the K-sized softmax terms.  The transcendental work (softplus, log, exp - sequences of dozens of fp64
-// instructions each) is spread over the lanes; only the two triangular solves are serial (every lane runs them on
-// operands broadcast from LDS).  (One thread per component did all of it serially: 11-12 us per launch at L = 8.)
-template <int L, bool BWD>
-__device__ __forceinline__ void phi_prep_body(const PhiArgs& a, const int k) {
-    static_assert(L * L <= PREP_THREADS, "one lane per matrix element");
-    const int lane = threadIdx.x, K = a.K;
-    __shared__ double Ls[L][L + 1];
-    __shared__ double Gm[L][L + 1];
-    __shared__ double inv_d[L];
-    const int i = lane / L, j = lane % L;
-    const bool in = lane < L * L;
-    const float* __restrict__ raw = a.Lraw + (size_t)k * L * L;
-    double lij = 0.0;
-    if (in) {
-        if (j < i) lij = (double)raw[i * L + j];
-        else if (j == i) lij = (double)(float)softplus_d((double)raw[i * L + i]);
-        Ls[i][j] = lij;
-        if (i == j) inv_d[i] = 1.0 / lij;
-        if (BWD) Gm[i][j] = (double)a.g_P[(size_t)k * L * L + i * L + j];
-    }
-    const double pr = lane < K ? (double)a.piraw[lane] : -1e300;
-    const double mx = wave_max_d(pr);
-    const double se = wave_sum_d(lane < K ? exp(pr - mx) : 0.0);
-    const double logpi = (double)a.piraw[k] - (mx + log(se));
-    const double ld = wave_sum_d((in && i == j) ? log(lij) : 0.0);           // log det L
-    __syncthreads();
-    double s[L];                                        // s = L^-1 h
-    double q2 = 0.0;
-#pragma unroll
-    for (int r = 0; r < L; ++r) {
-        double t = (double)a.mu[k * L + r];
-#pragma unroll
-        for (int c = 0; c < r; ++c) t -= Ls[r][c] * s[c];
-        s[r] = t * inv_d[r];
-        q2 += s[r] * s[r];
-    }
-    if (!BWD) {
-        if (in) {
-            a.Lk[(size_t)k * L * L + lane] = (float)lij;
-            double p = 0.0;
-            const int m = i < j ? i : j;
-#pragma unroll
-            for (int q = 0; q < L; ++q) p += q <= m ? Ls[i][q] * Ls[j][q] : 0.0;
-            a.P[(size_t)k * L * L + lane] = (float)p;
-        }
-        if (lane == 0) a.bias[k] = (float)(-0.5 * q2 + ld + logpi);
-        return;
-    }
-    // ---- backward
-    double u[L];                                        // u = L^-T s = P^-1 h
-#pragma unroll
-    for (int r = L - 1; r >= 0; --r) {
-        double t = s[r];
-#pragma unroll
-        for (int c = r + 1; c < L; ++c) t -= Ls[c][r] * u[c];
-        u[r] = t * inv_d[r];
-    }
-    const double s_gb = wave_sum_d(lane < K ? (double)a.g_bias[lane] : 0.0);
-    const double gb = (double)a.g_bias[k];
-    if (lane < L) a.g_mu[k * L + lane] = (float)((double)a.g_hk[k * L + lane] - gb * pick<L>(u, lane));
-    if (lane == 0) a.g_piraw[k] = (float)(gb - exp(logpi) * s_gb);
-    if (in) {
-        double g = 0.0;
-        if (j <= i) {
-#pragma unroll
-            for (int q = 0; q < L; ++q) g += q >= j ? (Gm[i][q] + Gm[q][i]) * Ls[q][j] : 0.0;    // (G + G^T) L
-            g += gb * pick<L>(u, i) * pick<L>(s, j);
-            if (i == j) {
-                g += gb * inv_d[i];
-                const double r = (double)raw[i * L + i];
-                g *= 1.0 / (1.0 + exp(-r));             // softplus'
-            }
-        }
-        a.g_Lraw[(size_t)k * L * L + lane] = (float)g;
-    }
-}
-
-struct ThetaArgs {
-    const float *alpha, *A, *b, *beta, *vhat;     // natural NIW / Dirichlet parameters
-    float* m;        // (K,L)
-    float* W;        // (K,L,L) lower, W^T W = E[Sigma]^-1
-    float* kappa;    // (K)
-    int K, L;
-};
-
 // Block per component, lane (i, j) per matrix element as in phi_prep_kernel: the two digammas run side by side in lanes 0
 // and 1, the Cholesky factor is built column by column in LDS (rows in parallel), the columns of its inverse in parallel.
 template <int L, bool BWD>
 __global__ __launch_bounds__(PREP_THREADS) void phi_prep_kernel(PhiArgs a) { phi_prep_body<L, BWD>(a, blockIdx.x); }
-
 template <int L>
-__device__ __forceinline__ void theta_pack_body(const ThetaArgs& a, const int k) {
-    static_assert(L * L <= PREP_THREADS, "one lane per matrix element");
-    const int lane = threadIdx.x, K = a.K;
-    __shared__ double Cs[L][L + 1];                     // sym(C) / nu, overwritten by its Cholesky factor (lower)
-    __shared__ double inv_d[L];
-    const int i = lane / L, j = lane % L;
-    const bool in = lane < L * L;
-    const double asum = wave_sum_d(lane < K ? (double)a.alpha[lane] + 1.0 : 0.0);            // dirichlet.natural_to_standard
-    const double dg = lane < 2 ? digamma_dd(lane == 0 ? (double)a.alpha[k] + 1.0 : asum) : 0.0;
-    const double elp = __shfl(dg, 0) - __shfl(dg, 1);
-    const double beta = (double)a.beta[k], nu = (double)a.vhat[k] - (double)(L + 2);         // niw.natural_to_standard
-    const double inv_nu = 1.0 / nu;
-    if (in) {
-        const double bi = (double)a.b[k * L + i], bj = (double)a.b[k * L + j];
-        const double cij = (double)a.A[((size_t)k * L + i) * L + j] - bi * (bj / beta);
-        const double cji = (double)a.A[((size_t)k * L + j) * L + i] - bj * (bi / beta);
-        Cs[i][j] = 0.5 * (cij + cji) * inv_nu;          // E[Sigma] = sym(C) / nu  (niw.expected_values)
-    }
-    __syncthreads();
-    // Cholesky: column c; lanes r = lane < L take the rows r >= c; every lane also forms the pivot itself
-#pragma unroll
-    for (int c = 0; c < L; ++c) {
-        const int r = lane < L ? lane : c;
-        double t = Cs[r][c], d = Cs[c][c];
-#pragma unroll
-        for (int q = 0; q < c; ++q) {
-            t -= Cs[r][q] * Cs[c][q];
-            d -= Cs[c][q] * Cs[c][q];
-        }
-        const double sd = sqrt(d);
-        __syncthreads();
-        if (lane < L && lane >= c) Cs[lane][c] = lane == c ? sd : t / sd;
-        if (lane == c) inv_d[c] = 1.0 / sd;
-        __syncthreads();
-    }
-    // W = Lc^-1: lane c < L solves for column c
-    double wdiag = 1.0;
-    if (lane < L) {
-        const int c = lane;
-        double w[L];
-#pragma unroll
-        for (int r = 0; r < L; ++r) {
-            double t = r == c ? 1.0 : 0.0;
-#pragma unroll
-            for (int q = 0; q < r; ++q) t -= Cs[r][q] * w[q];
-            w[r] = r < c ? 0.0 : t * inv_d[r];
-            if (r == c) wdiag = w[r];
-            a.W[((size_t)k * L + r) * L + c] = (float)w[r];
-        }
-        a.m[k * L + lane] = (float)((double)a.b[k * L + lane] / beta);
-    }
-    const double lw = wave_sum_d(lane < L ? log(wdiag) : 0.0);
-    if (lane == 0) a.kappa[k] = (float)(-0.5 * L * 1.8378770664093454836 + elp + lw);
+__global__ __launch_bounds__(64 * RED_GROUPS) void bwd_reduce_prep_kernel(PhiArgs a, const float* partials, int nblk) {
+    phi_prep_body<L, true, true>(a, blockIdx.x, partials, nblk);
 }
 
 template <int L>
@@ -235,41 +38,6 @@ template <int L>
 __global__ __launch_bounds__(PREP_THREADS) void prep_both_kernel(PhiArgs a, ThetaArgs t) {
     if ((int)blockIdx.x < a.K) phi_prep_body<L, false>(a, blockIdx.x);
     else theta_pack_body<L>(t, blockIdx.x - a.K);
-}
-
-struct CviArgs {
-    const double* stats;                           // (K, 2+L+L*L): [Nk | Wk | sx | sxx]
-    const float *p_alpha, *p_A, *p_b, *p_beta, *p_vhat;   // prior (natural)
-    float *t_alpha, *t_A, *t_b, *t_beta, *t_vhat;         // theta (natural), updated in place
-    float *s_alpha, *s_A, *s_b, *s_beta, *s_vhat;         // theta* out (may be NULL)
-    const float* rho_dev;                          // step size on the device (NULL: use rho)
-    float rho;
-    int K, L;
-};
-
-__device__ __forceinline__ void cvi_one(float* __restrict__ t, float* __restrict__ s, float star, float rho, size_t i) {
-    if (s) s[i] = star;
-    t[i] = t[i] * (1.0f - rho) + rho * star;       // update_gmm_params: theta <- (1-rho) theta + rho theta*
-}
-
-// element f (< L*L + L + 3) of component k; st = that component's raw moments [Nk | Wk | sx | sxx]
-__device__ __forceinline__ void cvi_element(const CviArgs& a, const double* __restrict__ st, int k, int f, float rho) {
-    const int L = a.L;
-    const float Nk = (float)st[0];
-    if (f < L * L) {
-        const size_t i = (size_t)k * L * L + f;
-        cvi_one(a.t_A, a.s_A, a.p_A[i] + (float)st[2 + L + f], rho, i);
-    } else if (f < L * L + L) {
-        const int d = f - L * L;
-        const size_t i = (size_t)k * L + d;
-        cvi_one(a.t_b, a.s_b, a.p_b[i] + (float)st[2 + d], rho, i);
-    } else if (f == L * L + L) {
-        cvi_one(a.t_alpha, a.s_alpha, a.p_alpha[k] + Nk, rho, k);
-    } else if (f == L * L + L + 1) {
-        cvi_one(a.t_beta, a.s_beta, a.p_beta[k] + Nk, rho, k);
-    } else {
-        cvi_one(a.t_vhat, a.s_vhat, a.p_vhat[k] + Nk + 1.0f, rho, k);   // the +1 of gmm.update_vk (gmm.py:81)
-    }
 }
 
 __global__ __launch_bounds__(256) void cvi_kernel(CviArgs a) {
@@ -288,15 +56,7 @@ __global__ __launch_bounds__(256) void cvi_kernel(CviArgs a) {
 __global__ __launch_bounds__(SMALL_STATS_GROUPS * 80) void stats_cvi_kernel(SmallStatsArgs sa, CviArgs a) {
     __shared__ double part[SMALL_STATS_GROUPS][80];
     __shared__ double st[80];
-    const int k = blockIdx.x, L = a.L, SW = 2 + L + L * L, i = threadIdx.x % 80;
-    const double t = small_stats_component(sa, k, part);
-    if (threadIdx.x < 80 && i < SW) {
-        st[i] = t;
-        sa.stats[(long long)k * SW + i] = t;
-    }
-    __syncthreads();
-    const float rho = a.rho_dev ? *a.rho_dev : a.rho;
-    for (int f = threadIdx.x; f < L * L + L + 3; f += blockDim.x) cvi_element(a, st, k, f, rho);
+    stats_cvi_body(sa, a, blockIdx.x, part, st);
 }
 
 // M-step moments from the fused E-step forward kernel's per-block partials AND the CVI update in one launch (round 6): the forward
@@ -363,7 +123,6 @@ struct RedArgs {
 // A block sums 64 consecutive (k, f) elements: lane group bg = tid / 64 takes the rows b = bg, bg + 16, .. of the partials
 // (64 consecutive floats per row: coalesced, independent loads), the 16 group sums are then added in a fixed order.
 // (One thread per element walking all rows was a chain of nblk dependent strided loads: 390 us at nblk = 1024.)
-constexpr int RED_GROUPS = 16;
 __global__ __launch_bounds__(64 * RED_GROUPS) void svae_bwd_reduce_kernel(RedArgs a) {
     const int L = a.L, TRI = L * (L + 1) / 2, TH = L + TRI + 1, PW = 2 * TH;
     const int half = a.g_mk ? PW : TH;
@@ -372,20 +131,8 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void svae_bwd_reduce_kernel(RedArg
     const int e = blockIdx.x * 64 + eg;
     const bool live = e < a.K * half;
     const int k = live ? e / half : 0, f = live ? e - k * half : 0;
-    // four independent chains per thread (their loads are in flight together: one chain of nblk / 16 dependent loads was most of
-    // this launch at 512 blocks), combined in a fixed order
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    if (live) {
-        const float* __restrict__ p = a.partials + (size_t)k * PW + f;
-        const size_t bs = (size_t)a.K * PW;
-        int b = bg;
-        for (; b + 3 * RED_GROUPS < a.nblk; b += 4 * RED_GROUPS) {
-            s0 += (double)p[(size_t)b * bs]; s1 += (double)p[(size_t)(b + RED_GROUPS) * bs];
-            s2 += (double)p[(size_t)(b + 2 * RED_GROUPS) * bs]; s3 += (double)p[(size_t)(b + 3 * RED_GROUPS) * bs];
-        }
-        for (; b < a.nblk; b += RED_GROUPS) s0 += (double)p[(size_t)b * bs];
-    }
-    double s = (s0 + s1) + (s2 + s3);
+    // four independent chains per thread (red_group_sum: one chain of nblk / 16 dependent loads was most of this launch at 512 blocks)
+    double s = live ? red_group_sum(a.partials + (size_t)k * PW + f, (size_t)a.K * PW, a.nblk, bg) : 0.0;
     part[bg][eg] = s;
     __syncthreads();
     if (bg == 0 && live) {
@@ -461,6 +208,23 @@ int vmp_svae_bwd_reduce(const float* partials, int nblk, int K, int L, float* g_
     return check_launch("vmp_svae_bwd_reduce");
 }
 
+// round 6: vmp_svae_bwd_reduce (phi side) + vmp_svae_phi_prep_bwd in one launch - block k sums component k's partials and runs the
+// backward of the recognition unpacking on them (the minibatch step runs the same body inside vmp_svae_step_final)
+int vmp_svae_bwd_reduce_prep(const float* partials, int nblk, const float* mu_k, const float* L_raw, const float* pi_raw,
+                             const double* logpi, int K, int L, float* g_mu, float* g_Lraw, float* g_piraw, void* stream) {
+    if (int e = prep_check("vmp_svae_bwd_reduce_prep", K, L)) return e;
+    if (!partials || !mu_k || !L_raw || !pi_raw || !logpi || !g_mu || !g_Lraw || !g_piraw || nblk < 1) {
+        set_error("vmp_svae_bwd_reduce_prep: NULL argument or nblk < 1");
+        return VMP_E_BADARG;
+    }
+    PhiArgs a{};
+    a.mu = mu_k; a.Lraw = L_raw; a.piraw = pi_raw; a.g_mu = g_mu; a.g_Lraw = g_Lraw; a.g_piraw = g_piraw; a.K = K; a.L = L; a.logpi = logpi;
+#define PREP_CALL(LL) hipLaunchKernelGGL((bwd_reduce_prep_kernel<LL>), dim3(K), dim3(64 * RED_GROUPS), 0, static_cast<hipStream_t>(stream), a, partials, nblk)
+    PREP_DISPATCH_L(L, PREP_CALL)
+#undef PREP_CALL
+    return check_launch("vmp_svae_bwd_reduce_prep");
+}
+
 int vmp_svae_theta_pack(const float* alpha, const float* A, const float* b, const float* beta, const float* v_hat, int K,
                         int L, float* m, float* W, float* kappa, void* stream) {
     if (int e = prep_check("vmp_svae_theta_pack", K, L)) return e;
@@ -472,21 +236,27 @@ int vmp_svae_theta_pack(const float* alpha, const float* A, const float* b, cons
     return check_launch("vmp_svae_theta_pack");
 }
 
-int vmp_svae_prep_fwd(const float* mu_k, const float* L_raw, const float* pi_raw, const float* alpha, const float* A,
-                      const float* b, const float* beta, const float* v_hat, int K, int L, float* Lk, float* P, float* bias,
-                      float* m, float* W, float* kappa, void* stream) {
+int vmp_svae_prep_fwd2(const float* mu_k, const float* L_raw, const float* pi_raw, const float* alpha, const float* A,
+                       const float* b, const float* beta, const float* v_hat, int K, int L, float* Lk, float* P, float* bias,
+                       float* m, float* W, float* kappa, double* logpi, void* stream) {
     if (int e = prep_check("vmp_svae_prep_fwd", K, L)) return e;
     if (!mu_k || !L_raw || !pi_raw || !Lk || !P || !bias || !alpha || !A || !b || !beta || !v_hat || !m || !W || !kappa) {
         set_error("vmp_svae_prep_fwd: NULL argument");
         return VMP_E_BADARG;
     }
     PhiArgs a{};
-    a.mu = mu_k; a.Lraw = L_raw; a.piraw = pi_raw; a.Lk = Lk; a.P = P; a.bias = bias; a.K = K; a.L = L;
+    a.mu = mu_k; a.Lraw = L_raw; a.piraw = pi_raw; a.Lk = Lk; a.P = P; a.bias = bias; a.K = K; a.L = L; a.logpi_out = logpi;
     ThetaArgs t{alpha, A, b, beta, v_hat, m, W, kappa, K, L};
 #define PREP_CALL(LL) hipLaunchKernelGGL((prep_both_kernel<LL>), dim3(2 * K), dim3(PREP_THREADS), 0, static_cast<hipStream_t>(stream), a, t)
     PREP_DISPATCH_L(L, PREP_CALL)
 #undef PREP_CALL
     return check_launch("vmp_svae_prep_fwd");
+}
+
+int vmp_svae_prep_fwd(const float* mu_k, const float* L_raw, const float* pi_raw, const float* alpha, const float* A,
+                      const float* b, const float* beta, const float* v_hat, int K, int L, float* Lk, float* P, float* bias,
+                      float* m, float* W, float* kappa, void* stream) {
+    return vmp_svae_prep_fwd2(mu_k, L_raw, pi_raw, alpha, A, b, beta, v_hat, K, L, Lk, P, bias, m, W, kappa, nullptr, stream);
 }
 
 int vmp_svae_stats_cvi(const float* x_samples, const float* r, int64_t N, const float* p_alpha, const float* p_A, const float* p_b,

@@ -10,6 +10,8 @@
 // lr_t = lr sqrt(1-b2^t)/(1-b1^t); var -= lr_t m / (sqrt(v) + eps)) for ALL parameter tensors in one launch.
 #include "vmp_common.h"
 #include "vmp_tail.h"
+#include "vmp_step_parts.h"
+#include "vmp_prep_parts.h"
 
 using namespace vmp;
 
@@ -53,12 +55,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(AdamArgs a) {
     for (int j = 0; j < ADAM_CHUNK / ADAM_THREADS; ++j) {
         const unsigned i = base + j * ADAM_THREADS + threadIdx.x;
         if (i >= n) break;
-        const float gi = g[i];
-        const float mi = m[i] * a.b1 + c1 * gi;
-        const float vi = v[i] * a.b2 + c2 * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        p[i] -= lr_t * (mi / (__fsqrt_rn(vi) + a.eps));
+        adam_update(p, m, v, i, g[i], lr_t, a.b1, a.b2, c1, c2, a.eps);
     }
 }
 
@@ -123,11 +120,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_packed_kernel(AdamPackedArg
         if (i >= n) break;
         const float gi = (float)(g[i] * a.gscale);          // mean over the ranks in fp64, rounded once (tf_utils.py:79)
         if (go) go[i] = gi;
-        const float mi = m[i] * a.b1 + c1 * gi;
-        const float vi = v[i] * a.b2 + c2 * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        p[i] -= lr_t * (mi / (__fsqrt_rn(vi) + a.eps));
+        adam_update(p, m, v, i, gi, lr_t, a.b1, a.b2, c1, c2, a.eps);
     }
 }
 
@@ -135,6 +128,90 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_packed_kernel(AdamPackedArg
 // (by value), so the caller needs no staging buffer that an asynchronous copy could still be reading when it is rewritten.
 struct Words16 { unsigned long long key; float rho, lr_t; };
 __global__ void step_scalars_kernel(Words16* dst, Words16 v) { *dst = v; }
+// the same, and the minibatch copied into the captured step's static input by the same launch (round 6: one eager launch per replay, not two)
+constexpr int INPUT_THREADS = 256;
+__global__ __launch_bounds__(INPUT_THREADS) void step_inputs_kernel(Words16* dst, Words16 v, const float* __restrict__ src, float* __restrict__ y,
+                                                                    unsigned n) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *dst = v;
+    for (unsigned i = blockIdx.x * INPUT_THREADS + threadIdx.x; i < n; i += gridDim.x * INPUT_THREADS) y[i] = src[i];
+}
+
+// ---- the closing launch of the minibatch training step (round 6) -------------------------------------------------------------
+// Everything that waits for the encoder's backward kernel and for nothing else, as ONE grid whose blocks take roles:
+//   [decoder net | encoder net]  64 parameters per block: reduce the fused MLP backward kernel's per-block partials (dec_reduce_sum:
+//                                the order of dec_reduce_kernel), store the gradient, apply Adam to the 64 parameters
+//   [K blocks]                   phi_gmm: component k's rows of the E-step backward kernel's partials summed, the backward of the
+//                                recognition unpacking on them, Adam on component k's elements (phi_prep_body<L, true, true>)
+//   [K blocks]                   M-step moments of the minibatch + CVI update of theta_k (stats_cvi_body: vmp_svae_stats_cvi)
+//   [1 block]                    the three ELBO scalars from the per-tile sums of vmp_svae_estep_bwd_tail (elbo_final_body)
+// It replaces dec_reduce_tail_kernel's reduce blocks, svae_bwd_reduce_kernel, phi_prep_kernel<L, true>, dec_reduce_kernel,
+// stats_cvi_kernel and adam_kernel: 6 launches -> 1.
+// theta and the parameters are only written here; every role reads what the step's earlier launches left (experiments.py:267: the
+// CVI update and the Adam step both read OLD values).
+constexpr int FIN_THREADS = 64 * DEC_RED_GROUPS;
+constexpr int FIN_NET_TENSORS = 9;
+static_assert(FIN_THREADS == 64 * RED_GROUPS, "the phi role's reduction uses the block shape of svae_bwd_reduce_kernel");
+struct FinNet {
+    DecRedArgs red;                          // (out unused)
+    float* p[FIN_NET_TENSORS];
+    float* m[FIN_NET_TENSORS];
+    float* v[FIN_NET_TENSORS];
+    float* g[FIN_NET_TENSORS];               // reduced gradients out
+    int off[FIN_NET_TENSORS + 1];            // flat offsets of the tensors inside a partial row
+    int nb;                                  // blocks
+};
+struct FinArgs {
+    FinNet net[2];
+    PhiArgs phi;                             // (backward form: mu, Lraw, piraw, logpi in; g_mu, g_Lraw, g_piraw out)
+    PhiAdam phi_adam;
+    const float* partials;                   // (nblk, K, 2 (L + TRI + 1)) of the E-step backward kernel
+    int nblk;
+    SmallStatsArgs sa;
+    CviArgs cvi;
+    TailArgs tail;
+    unsigned tail_n;
+    const float* lr_t_dev;
+    float lr_t, b1, b2, c1, c2, eps;
+};
+template <int L>
+__global__ __launch_bounds__(FIN_THREADS) void step_final_kernel(FinArgs a) {
+    __shared__ double part[DEC_RED_GROUPS][64];
+    __shared__ double spart[SMALL_STATS_GROUPS][80];
+    __shared__ double st[80];
+    static_assert(SMALL_STATS_GROUPS * 80 <= FIN_THREADS, "the moment role needs 12 x 80 threads");
+    const float lr_t = a.lr_t_dev ? *a.lr_t_dev : a.lr_t;
+    int b = blockIdx.x;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const FinNet& q = a.net[n];
+        if (b < q.nb) {
+            const double s = dec_reduce_sum(q.red, b, part);
+            const int i = b * 64 + (threadIdx.x & 63);
+            if ((threadIdx.x >> 6) == 0 && i < q.red.PW) {
+                int t = 0;
+                while (t < FIN_NET_TENSORS - 1 && i >= q.off[t + 1]) ++t;
+                const unsigned j = (unsigned)(i - q.off[t]);
+                const float gi = (float)s;
+                q.g[t][j] = gi;
+                adam_update(q.p[t], q.m[t], q.v[t], j, gi, lr_t, a.b1, a.b2, a.c1, a.c2, a.eps);
+            }
+            return;
+        }
+        b -= q.nb;
+    }
+    if (b < a.phi.K) {
+        PhiAdam ad = a.phi_adam;
+        ad.lr_t = lr_t;
+        phi_prep_body<L, true, true>(a.phi, b, a.partials, a.nblk, &ad);
+        return;
+    }
+    b -= a.phi.K;
+    if (b < a.cvi.K) {
+        stats_cvi_body(a.sa, a.cvi, b, spart, st);
+        return;
+    }
+    if (threadIdx.x < WAVE) elbo_final_body(a.tail, a.tail_n);
+}
 
 }  // namespace
 
@@ -148,6 +225,104 @@ int vmp_svae_step_scalars(void* dst16, uint64_t philox_key, float cvi_step, floa
     hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), static_cast<Words16*>(dst16),
                        Words16{(unsigned long long)philox_key, cvi_step, adam_step});
     return check_launch("vmp_svae_step_scalars");
+}
+
+int vmp_svae_step_inputs(void* dst16, uint64_t philox_key, float cvi_step, float adam_step, const float* y_src, float* y_dst,
+                         int64_t n_floats, void* stream) {
+    if (!dst16 || (reinterpret_cast<uintptr_t>(dst16) & 7)) {
+        set_error("vmp_svae_step_inputs: dst16 must be an 8-byte aligned device pointer to 16 bytes");
+        return VMP_E_BADARG;
+    }
+    if (n_floats < 0 || n_floats >= 4294967296LL || (n_floats > 0 && (!y_src || !y_dst))) {
+        set_error("vmp_svae_step_inputs: bad minibatch copy (n = %lld)", (long long)n_floats);
+        return VMP_E_BADARG;
+    }
+    long long blocks = (n_floats + INPUT_THREADS - 1) / INPUT_THREADS;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(step_inputs_kernel, dim3((unsigned)blocks), dim3(INPUT_THREADS), 0, static_cast<hipStream_t>(stream),
+                       static_cast<Words16*>(dst16), Words16{(unsigned long long)philox_key, cvi_step, adam_step}, y_src, y_dst,
+                       (unsigned)n_floats);
+    return check_launch("vmp_svae_step_inputs");
+}
+
+int vmp_svae_step_final(const float* dec_part, int dec_blocks, int dec_in, int dec_units, int dec_out, float* const* dec_p,
+                        float* const* dec_m, float* const* dec_v, float* const* dec_g, const float* enc_part, int enc_blocks,
+                        int enc_in, int enc_units, int enc_out, float* const* enc_p, float* const* enc_m, float* const* enc_v,
+                        float* const* enc_g, const float* partials, int nblk, const double* logpi, float* const* phi_p,
+                        float* const* phi_g, float* const* phi_m, float* const* phi_v, const float* x_samples, const float* r, int64_t N, const float* const* prior,
+                        float* const* theta, float* const* theta_star, const float* rho_dev, float rho, int K, int L,
+                        double* stats_out, const double* tail_part, int tail_n, int Dy, float* scalars, double beta1, double beta2,
+                        double eps, double lr_t, const float* lr_t_dev, void* stream) {
+    if (K < 1 || K > VMP_MAX_K || L < 1 || L > VMP_MAX_D || N < 1 || N > SMALL_STATS_MAX_N || tail_n < 1 || tail_n > TAIL_MAX_BLOCKS || Dy < 1) {
+        set_error("vmp_svae_step_final: K=%d L=%d N=%lld tail_n=%d outside the minibatch step's range (N <= %d)", K, L, (long long)N, tail_n,
+                  SMALL_STATS_MAX_N);
+        return VMP_E_DIM;
+    }
+    if (!dec_part || !enc_part || dec_blocks < 1 || enc_blocks < 1 || !dec_p || !dec_m || !dec_v || !dec_g || !enc_p || !enc_m || !enc_v ||
+        !enc_g || !partials || nblk < 1 || !logpi || !phi_p || !phi_g || !phi_m || !phi_v || !x_samples || !r || !prior || !theta || !stats_out || !tail_part || !scalars) {
+        set_error("vmp_svae_step_final: NULL argument");
+        return VMP_E_BADARG;
+    }
+    FinArgs a{};
+    unsigned blocks = 0;
+    const struct { const float* part; int nblk, in, units, out; float* const* p; float* const* m; float* const* v; float* const* g; } nets[2] = {
+        {dec_part, dec_blocks, dec_in, dec_units, dec_out, dec_p, dec_m, dec_v, dec_g},
+        {enc_part, enc_blocks, enc_in, enc_units, enc_out, enc_p, enc_m, enc_v, enc_g}};
+    for (int n = 0; n < 2; ++n) {
+        const int Li = nets[n].in, U = nets[n].units, Do = nets[n].out;
+        if (Li < 1 || Li > 8 || Do < 1 || Do > 8 || U < 1 || U > 64) {
+            set_error("vmp_svae_step_final: net %d sizes in=%d units=%d out=%d outside the fused MLP's range", n, Li, U, Do);
+            return VMP_E_DIM;
+        }
+        const int sizes[FIN_NET_TENSORS] = {Li * U, U, U * U, U, U * 2 * Do, 2 * Do, Li * Do, Do, Do};   // the reference's variable order
+        FinNet& q = a.net[n];
+        int o = 0;
+        for (int t = 0; t < FIN_NET_TENSORS; ++t) {
+            if (!nets[n].p[t] || !nets[n].m[t] || !nets[n].v[t] || !nets[n].g[t]) {
+                set_error("vmp_svae_step_final: net %d tensor %d: NULL pointer", n, t);
+                return VMP_E_BADARG;
+            }
+            q.p[t] = nets[n].p[t]; q.m[t] = nets[n].m[t]; q.v[t] = nets[n].v[t]; q.g[t] = nets[n].g[t];
+            q.off[t] = o;
+            o += sizes[t];
+        }
+        q.off[FIN_NET_TENSORS] = o;
+        if (o != vmp_decoder_param_words(Li, U, Do)) {
+            set_error("vmp_svae_step_final: parameter layout mismatch (%d != %d words)", o, vmp_decoder_param_words(Li, U, Do));
+            return VMP_E_DIM;
+        }
+        q.red = DecRedArgs{nets[n].part, q.p[FIN_NET_TENSORS - 1], nullptr, nets[n].nblk, o, o - Do, Do};
+        q.nb = (o + 63) / 64;
+        blocks += (unsigned)q.nb;
+    }
+    for (int t = 0; t < 3; ++t) {                           // phi_gmm/mu_k (K,L), L_k (K,L,L), log_pi_k (K)
+        if (!phi_p[t] || !phi_g[t] || !phi_m[t] || !phi_v[t]) { set_error("vmp_svae_step_final: phi tensor %d: NULL pointer", t); return VMP_E_BADARG; }
+        a.phi_adam.p[t] = phi_p[t]; a.phi_adam.m[t] = phi_m[t]; a.phi_adam.v[t] = phi_v[t];
+    }
+    a.phi.mu = phi_p[0]; a.phi.Lraw = phi_p[1]; a.phi.piraw = phi_p[2]; a.phi.logpi = logpi;
+    a.phi.g_mu = phi_g[0]; a.phi.g_Lraw = phi_g[1]; a.phi.g_piraw = phi_g[2]; a.phi.K = K; a.phi.L = L;
+    a.partials = partials; a.nblk = nblk;
+    blocks += (unsigned)K;
+    for (int t = 0; t < 5; ++t)
+        if (!prior[t] || !theta[t]) { set_error("vmp_svae_step_final: prior / theta tensor %d: NULL pointer", t); return VMP_E_BADARG; }
+    a.sa = SmallStatsArgs{x_samples, r, nullptr, stats_out, (int)N, L, K};
+    a.cvi = CviArgs{stats_out, prior[0], prior[1], prior[2], prior[3], prior[4], theta[0], theta[1], theta[2], theta[3], theta[4],
+                    theta_star ? theta_star[0] : nullptr, theta_star ? theta_star[1] : nullptr, theta_star ? theta_star[2] : nullptr,
+                    theta_star ? theta_star[3] : nullptr, theta_star ? theta_star[4] : nullptr, rho_dev, rho, K, L};
+    blocks += (unsigned)K;
+    a.tail.part = const_cast<double*>(tail_part);
+    a.tail.scal = scalars;
+    a.tail.cst = (double)N * Dy * 0.5 * 1.8378770664093453;            // log(2 pi): as tail_setup
+    a.tail_n = (unsigned)tail_n;
+    blocks += 1;
+    a.lr_t_dev = lr_t_dev; a.lr_t = (float)lr_t; a.b1 = (float)beta1; a.b2 = (float)beta2;
+    a.c1 = (float)(1.0 - beta1); a.c2 = (float)(1.0 - beta2); a.eps = (float)eps;
+    a.phi_adam.b1 = a.b1; a.phi_adam.b2 = a.b2; a.phi_adam.c1 = a.c1; a.phi_adam.c2 = a.c2; a.phi_adam.eps = a.eps;
+#define FIN_CALL(LL) case LL: hipLaunchKernelGGL((step_final_kernel<LL>), dim3(blocks), dim3(FIN_THREADS), 0, static_cast<hipStream_t>(stream), a); break
+    switch (L) { FIN_CALL(1); FIN_CALL(2); FIN_CALL(3); FIN_CALL(4); FIN_CALL(5); FIN_CALL(6); FIN_CALL(7); default: FIN_CALL(8); }
+#undef FIN_CALL
+    return check_launch("vmp_svae_step_final");
 }
 
 size_t vmp_svae_elbo_tail_workspace_bytes(void) { return tail_workspace_bytes(); }

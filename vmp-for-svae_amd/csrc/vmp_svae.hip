@@ -2295,6 +2295,42 @@ int vmp_svae_estep_fwd_rng_epi(const float* eta1, const float* eta2d, const floa
     return run_fwd(a, L, stream, true);
 }
 
+// ---- round 6, the minibatch training step: E-step backward with the ELBO's scalar tail inside (svae_estep_bwd1_kernel<L, true>).
+// Replaces, for batches the minibatch form covers (vmp_svae_bwd_tail_applies), the tail launch (vmp_svae_elbo_tail / the tail blocks
+// of vmp_decoder_elbo) + vmp_svae_estep_bwd_n: dLoss/dlog_z, dLoss/dT' never reach memory.  Outputs as vmp_svae_estep_bwd_n
+// (partials: one row per tile = vmp_svae_bwd_blocks_for) plus r = exp(log_z) (N,K) and tail_part (tiles, 2) fp64 - the per-tile
+// terms of [sum w A, sum r (T' + log z)], summed by vmp_svae_step_final.
+int vmp_svae_bwd_tail_applies(int64_t N, int K, int L, int S) {
+    return N > 0 && K >= 1 && K <= WAVE && L >= 1 && L <= 8 && S >= 1 && bwd1_applies(N, K, L, S, false) ? 1 : 0;
+}
+
+int vmp_svae_estep_bwd_tail(const float* eta1, const float* eta2d, const float* hk, const float* Pk, const float* bias,
+                            const float* mk, const float* Wk, const float* x, const float* lz, const float* T_prime, const float* ll,
+                            float sigma, const float* Gx, int64_t N, int K, int L, int S, float* g_eta1, float* g_eta2d,
+                            float* partials, size_t partial_bytes, float* r, double* tail_part, size_t tail_bytes, void* stream) {
+    int rc = check_sv(N, K, L, S);
+    if (rc) return rc;
+    if (!eta1 || !eta2d || !hk || !Pk || !bias || !mk || !Wk || !x || !lz || !T_prime || !ll || !Gx || !g_eta1 || !g_eta2d || !partials ||
+        !r || !tail_part || sigma == 0.f) {
+        set_error("vmp_svae_estep_bwd_tail: null pointer or sigma == 0");
+        return VMP_E_BADARG;
+    }
+    if (!vmp_svae_bwd_tail_applies(N, K, L, S)) {
+        set_error("vmp_svae_estep_bwd_tail: N=%lld K=%d L=%d S=%d outside the minibatch form (<= %d tiles, S <= %d)", (long long)N, K, L, S,
+                  BWD1_MAX_TILES, 2 * BWD1_MAX_PAIRS);
+        return VMP_E_DIM;
+    }
+    const int nt = (int)((N + WAVE / K - 1) / (WAVE / K));
+    const int PW = vmp_svae_bwd_partial_words(L);
+    if (partial_bytes < (size_t)nt * K * PW * sizeof(float) || tail_bytes < (size_t)nt * 2 * sizeof(double)) {
+        set_error("vmp_svae_estep_bwd_tail: partials / tail_part buffer too small for %d tiles", nt);
+        return VMP_E_WS;
+    }
+    EBwdArgs a{eta1, eta2d, hk, Pk, bias, mk, Wk, nullptr, x, lz, Gx, nullptr, nullptr, g_eta1, g_eta2d, partials, N, K, S, 0};
+    a.Tp = T_prime; a.ll = ll; a.r_out = r; a.tail_part = tail_part; a.sigma = sigma;
+    return svae_bwd1_launch(a, L, nt, (S + 1) / 2, true, stream);
+}
+
 int vmp_svae_bwd_blocks_for(int64_t N, int K, int L, int S, int student) {
     if (N <= 0 || K < 1 || K > WAVE) return 0;
     if (bwd1_applies(N, K, L, S, student != 0)) return (int)((N + WAVE / K - 1) / (WAVE / K));
@@ -2334,7 +2370,7 @@ int vmp_svae_estep_bwd_n(const float* eta1, const float* eta2d, const float* hk,
         // minibatch sizes, Gaussian theta: one block per tile, one wave per sample pair (svae_estep_bwd1_kernel)
         const int P = (S + 1) / 2;
         rc = -1;
-        rc = svae_bwd1_launch(a, L, (int)ntiles_g, P, stream);
+        rc = svae_bwd1_launch(a, L, (int)ntiles_g, P, false, stream);
         return rc;
     }
     const int gblocks = wide ? nblk : blocks;

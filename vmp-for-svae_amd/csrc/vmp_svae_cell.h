@@ -24,6 +24,13 @@ struct EBwdArgs {
     float* partials;        // (nblk, K, 2(L+TRI+1)): g_hk | g_Pk (lower, symmetric gradient) | g_bias | g_mk | g_Wk (lower) | g_kappa
     long long N;
     int K, S, vec_ok;
+    // minibatch form with the ELBO's scalar tail inside (vmp_svae_estep_bwd_tail; Glz / GT unused): dLoss/dlog_z and dLoss/dT' are
+    // formed per cell from (lz, Tp, ll) exactly as elbo_tail_body does (vmp_tail.h)
+    const float* Tp;        // (N,K)
+    const float* ll;        // (N,K,S) per-sample reconstruction sums of the decoder kernel
+    float* r_out;           // (N,K) exp(log z)
+    double* tail_part;      // (tiles, 2) per-tile terms of the ELBO's two fp64 sums
+    float sigma;
 #ifdef VMP_DEBUG_TS
     long long* dbg_t;       // exploration builds only (tools/build_variant.sh ts -DVMP_DEBUG_TS): stage time stamps of block 0, wave 0
 #endif
@@ -140,5 +147,5 @@ namespace vmp {
 // otherwise the launch status.  nblk_abi = number of partial rows the ABI sized the buffer for (rows the ring grid does not
 // write are zeroed by the kernel).
 int svae_bwd_ring_launch(const EBwdArgs& a, int L, int nblk_abi, void* stream);
-int svae_bwd1_launch(const EBwdArgs& a, int L, int ntiles, int P, void* stream);      // vmp_svae_mini.hip: one block per tile, one wave per sample pair
+int svae_bwd1_launch(const EBwdArgs& a, int L, int ntiles, int P, bool tail, void* stream);      // vmp_svae_mini.hip: one block per tile, one wave per sample pair
 }

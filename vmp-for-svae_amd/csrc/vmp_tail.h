@@ -29,6 +29,20 @@ __device__ __forceinline__ double tail_wave_sum(double v) {
     return v;
 }
 
+// one cell: r = exp(log z), the two gradient seeds and the cell's terms of the two fp64 sums (hs = 1 / (2 S), A = sum_s ll_s)
+__device__ __forceinline__ void tail_cell(const float lz, const float tp, const float A, const float hs, const float sigma, float& r,
+                                          float& g_lz, float& g_Tp, double& wa, double& rg) {
+    // (no contraction here: the same roundings in every kernel this is inlined into, whatever the compiler would pick there)
+#pragma clang fp contract(off)
+    r = expf(lz);
+    const float w = hs * r;
+    wa = fma((double)w, (double)A, wa);
+    rg = fma((double)r, (double)(tp + lz), rg);
+    const float t1 = r * (tp + lz + 1.0f);
+    g_lz = -sigma * fmaf(w, A, t1);
+    g_Tp = -sigma * r;
+}
+
 // block tb of ntb (any block size that is a multiple of 64, <= 1024)
 __device__ __forceinline__ void elbo_tail_body(const TailArgs& a, const unsigned tb, const unsigned ntb) {
     __shared__ double sm[2][TAIL_MAX_WAVES];
@@ -40,7 +54,6 @@ __device__ __forceinline__ void elbo_tail_body(const TailArgs& a, const unsigned
     double wa = 0.0, rg = 0.0;
     for (long long c = (long long)tb * blockDim.x + threadIdx.x; c < a.NK; c += (long long)ntb * blockDim.x) {
         const float lz = a.lz[c], tp = a.Tp[c];
-        const float r = expf(lz);
         const float* __restrict__ lr = a.ll + c * a.S;
         float A = 0.f;
         if (ll2) {                                                  // even S, 8-byte aligned: half the load instructions, same order
@@ -49,12 +62,11 @@ __device__ __forceinline__ void elbo_tail_body(const TailArgs& a, const unsigned
         } else {
             for (int s = 0; s < a.S; ++s) A += lr[s];
         }
-        const float w = hs * r;
-        wa += (double)w * (double)A;
-        rg += (double)r * (double)(tp + lz);
+        float r, glz, gtp;
+        tail_cell(lz, tp, A, hs, a.sigma, r, glz, gtp, wa, rg);
         a.r[c] = r;
-        a.g_lz[c] = -a.sigma * (w * A + r * (tp + lz + 1.0f));
-        a.g_Tp[c] = -a.sigma * r;
+        a.g_lz[c] = glz;
+        a.g_Tp[c] = gtp;
     }
     wa = tail_wave_sum(wa);
     rg = tail_wave_sum(rg);

@@ -163,8 +163,11 @@ def unpack_after_allreduce(buf, stats_shape, grad_shapes, n_scalars):
 class SVAETrainer(object):
     def __init__(self, K, Ld, U, Dy, nb_samples=10, lr=3e-4, lrcvi=0.2, decay_rate=0.95, stddev_init_nn=0.01, seed=0,
                  device='cuda', m_uniform=None, pi_normal=None, group=None, smm=False, dof=5.0, fused_decoder=True,
-                 rng='philox', reference_call_order=False):
+                 rng='philox', reference_call_order=False, direct_step=True):
         self.K, self.L, self.S = K, Ld, nb_samples
+        # True (default): a whole-minibatch single-process GMM step on in-kernel noise runs as the 8-launch kernel sequence of
+        # _step_direct (round 6) instead of the autograd graph over the same kernels (13 launches); False: always autograd
+        self.direct_step = bool(direct_step)
         # True: build the step exactly as experiments.py:209-229 does - svae.inference(...) WITHOUT theta, then
         # svae.compute_elbo(..., theta, phi_tilde, ...), which evaluates the theta term in a second launch of the fused
         # kernel (models/svae.py PhiTilde.theta_term).  False (default): theta goes into the E-step, one launch.
@@ -264,9 +267,125 @@ class SVAETrainer(object):
         The step is three pieces - everything a rank does on its own rows (_step_front), the ONE exchange of a data-parallel
         step (_step_exchange) and the identical update every rank applies (_step_back) - so that a data-parallel step can be
         captured as two HIP graphs around its collective (GraphedSVAEStep)."""
+        if self._direct_ok(y, noise, z_draws, chunk, u):
+            return self._step_direct(y, _dev_scalars)
         ctx = self._step_front(y, noise, z_draws, chunk, u, _dev_scalars)
         self._step_exchange(ctx)
         return self._step_back(ctx, _dev_scalars)
+
+    def _direct_ok(self, y, noise, z_draws, chunk, u):
+        """Whether _step_direct covers this call: GMM-SVAE, one process, the whole minibatch at once (<= 512 rows, the minibatch
+        forms of the E-step kernels), noise drawn in the kernels, fused encoder / decoder."""
+        if not self.direct_step or self.smm or self.reference_call_order or not self.fused_decoder or self.rng != 'philox':
+            return False
+        if noise is not None or z_draws is not None or u is not None:
+            return False
+        if not (torch.is_tensor(y) and y.is_cuda and y.dtype == torch.float32 and y.dim() == 2):
+            return False
+        rows, Dy = y.shape
+        if (chunk is not None and rows > int(chunk)) or not (0 < rows <= _svae_ops.STATS_CVI_MAX_ROWS) or self._world() != 1:
+            return False
+        if not (vae._fused_mlp_eligible(Dy, self.encoder_layers) and vae.fused_decoder_eligible(self.L, self.decoder_layers)):
+            return False
+        lib = L.lib()
+        return bool(lib.vmp_svae_rng_in_kernel(self.K, self.L, self.S) and lib.vmp_svae_bwd_tail_applies(rows, self.K, self.L, self.S))
+
+    @torch.no_grad()
+    def _step_direct(self, y, _dev_scalars=None):
+        """experiments.py:196-267 for one whole minibatch as SEVEN launches, no autograd graph (include/vmp_hip.h, "The minibatch
+        training step"): encoder, recognition / theta prep, E-step (+ sub-sample), decoder value + gradients, ELBO tail + E-step
+        backward, encoder backward, and one closing launch (partial rows -> phi_gmm gradients, both parameter reductions, Adam on
+        the 21 tensors, M-step moments + CVI update, ELBO scalars).  Same kernels / device functions as the autograd step: every
+        gradient, moment and parameter it leaves is bit-identical to that step's (tests/test_svae_gpu.py); the three ELBO scalars
+        are summed per tile (fp64) and agree to fp32 rounding."""
+        import ctypes
+        lib, dev = L.lib(), y.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        y = L.dev_f32(y, 'y')
+        N, Dy = y.shape
+        K, Ld, S, U = self.K, self.L, self.S, self.encoder_layers[0][0]
+        names, params = self.trainables()
+        if self.opt is None:
+            self.opt = TFAdam(params, self.lr)
+        opt = self.opt
+        if not opt._fused_ok():
+            raise L.VmpError('SVAETrainer: parameters must be contiguous fp32 GPU tensors')
+        phi, enc, dec = params[:3], params[3:12], params[12:21]
+        prior = [L.dev_f32(t.detach(), 'prior') for t in self.gmm_prior]
+        for t in self.theta:
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise L.VmpError('theta must be contiguous fp32 GPU tensors')
+        st = L.stream()
+        pp = lambda ts: [L.ptr(t) for t in ts]
+        arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() if t is not None else None for t in ts])
+        seed_dev = None if _dev_scalars is None or len(_dev_scalars) < 3 else _dev_scalars[2]
+        rho_dev = None if _dev_scalars is None else _dev_scalars[0]
+        lr_dev = None if _dev_scalars is None else _dev_scalars[1]
+        lrcvi = exponential_decay(self.lrcvi0, self.global_step, 1000, self.decay_rate)
+        # 1: encoder (natparam head: eta1, -1/2 var)
+        eta1, eta2d = torch.empty(N, Ld, **f32), torch.empty(N, Ld, **f32)
+        L.check(lib.vmp_mlp_gauss_head_fwd(L.ptr(y), *pp(enc), N, Dy, Ld, U, -0.5, L.ptr(eta1), L.ptr(eta2d), st), 'vmp_mlp_gauss_head_fwd')
+        # 2: recognition unpacking + theta packing
+        mu_k, L_raw, pi_raw = phi
+        Lk, P, bias = torch.empty(K, Ld, Ld, **f32), torch.empty(K, Ld, Ld, **f32), torch.empty(K, **f32)
+        mk, Wk, kappa = torch.empty(K, Ld, **f32), torch.empty(K, Ld, Ld, **f32), torch.empty(K, **f32)
+        logpi = torch.empty(K, dtype=torch.float64, device=dev)
+        L.check(lib.vmp_svae_prep_fwd2(L.ptr(mu_k), L.ptr(L_raw), L.ptr(pi_raw), *pp(self.theta), K, Ld, L.ptr(Lk), L.ptr(P), L.ptr(bias),
+                                       L.ptr(mk), L.ptr(Wk), L.ptr(kappa), L.ptr(logpi), st), 'vmp_svae_prep_fwd2')
+        # 3: E-step on in-kernel noise; its epilogue draws the one sub-sample per row
+        x = torch.empty(N, K, S, Ld, **f32)
+        lz, Tp = torch.empty(N, K, **f32), torch.empty(N, K, **f32)
+        xs, r_epi = torch.empty(N, Ld, **f32), torch.empty(N, K, **f32)
+        key = 0 if seed_dev is not None else (self._step_seed(0) & 0xFFFFFFFFFFFFFFFF)
+        L.check(lib.vmp_svae_estep_fwd_rng_epi(L.ptr(eta1), L.ptr(eta2d), L.ptr(mu_k), L.ptr(P), L.ptr(bias), key, L.ptr(seed_dev),
+                                               L.ptr(mk), L.ptr(Wk), L.ptr(kappa), None, N, K, Ld, S, L.ptr(x), L.ptr(lz), L.ptr(Tp),
+                                               L.ptr(xs), L.ptr(r_epi), None, 0, st), 'vmp_svae_estep_fwd_rng_epi')
+        # 4: decoder value + gradients of loss = -elbo (sigma = -1); parameter partials stay in ws_dec
+        dx, ll = torch.empty_like(x), torch.empty(N, K, S, **f32)
+        nb_dec = lib.vmp_decoder_bwd_blocks(N * K * S)
+        ws_dec = torch.empty(lib.vmp_decoder_workspace_bytes(N, K, S, Ld, U, Dy), dtype=torch.uint8, device=dev)
+        L.check(lib.vmp_decoder_elbo_lazy(L.ptr(x), L.ptr(y), L.ptr(lz), -1.0, *pp(dec), N, K, S, Ld, Dy, U, L.ptr(dx), L.ptr(ll),
+                                          L.ptr(ws_dec), ws_dec.numel(), st), 'vmp_decoder_elbo_lazy')
+        # 5: ELBO tail + E-step backward
+        g_eta1, g_eta2d = torch.empty(N, Ld, **f32), torch.empty(N, Ld, **f32)
+        nt = lib.vmp_svae_bwd_blocks_for(N, K, Ld, S, 0)
+        partials = torch.empty(nt, K, lib.vmp_svae_bwd_partial_words(Ld), **f32)
+        r = torch.empty(N, K, **f32)
+        tail_part = torch.empty(nt, 2, dtype=torch.float64, device=dev)
+        L.check(lib.vmp_svae_estep_bwd_tail(L.ptr(eta1), L.ptr(eta2d), L.ptr(mu_k), L.ptr(P), L.ptr(bias), L.ptr(mk), L.ptr(Wk),
+                                            L.ptr(x), L.ptr(lz), L.ptr(Tp), L.ptr(ll), -1.0, L.ptr(dx), N, K, Ld, S, L.ptr(g_eta1),
+                                            L.ptr(g_eta2d), L.ptr(partials), partials.numel() * 4, L.ptr(r), L.ptr(tail_part),
+                                            tail_part.numel() * 8, st), 'vmp_svae_estep_bwd_tail')
+        # 6: encoder backward; parameter partials stay in ws_enc
+        nb_enc = lib.vmp_decoder_bwd_blocks(N)
+        ws_enc = torch.empty(lib.vmp_decoder_workspace_bytes(N, 1, 1, Dy, U, Ld), dtype=torch.uint8, device=dev)
+        L.check(lib.vmp_mlp_gauss_head_bwd_lazy(L.ptr(y), L.ptr(g_eta1), L.ptr(g_eta2d), -0.5, *pp(enc), N, Dy, Ld, U, None,
+                                                L.ptr(ws_enc), ws_enc.numel(), st), 'vmp_mlp_gauss_head_bwd_lazy')
+        # 7: the closing launch (phi_gmm gradients from the partial rows, both MLP reductions, Adam, moments + CVI, ELBO scalars)
+        g_phi = [torch.empty_like(t) for t in phi]
+        g_enc, g_dec = [torch.empty_like(t) for t in enc], [torch.empty_like(t) for t in dec]
+        stats = torch.empty(K, 2 + Ld + Ld * Ld, dtype=torch.float64, device=dev)
+        star = [torch.empty_like(t) for t in self.theta]
+        scal = torch.empty(3, **f32)
+        if lr_dev is None:
+            opt.t += 1
+            lr_t = opt.lr_t(opt.t)
+        else:
+            lr_t = 0.0
+        m, v = opt.m, opt.v
+        L.check(lib.vmp_svae_step_final(L.ptr(ws_dec), nb_dec, Ld, U, Dy, arr(dec), arr(m[12:21]), arr(v[12:21]), arr(g_dec),
+                                        L.ptr(ws_enc), nb_enc, Dy, U, Ld, arr(enc), arr(m[3:12]), arr(v[3:12]), arr(g_enc),
+                                        L.ptr(partials), nt, L.ptr(logpi), arr(phi), arr(g_phi), arr(m[:3]), arr(v[:3]), L.ptr(xs),
+                                        L.ptr(r), N,
+                                        arr(prior), arr(self.theta), arr(star), L.ptr(rho_dev),
+                                        0.0 if rho_dev is not None else float(lrcvi), K, Ld, L.ptr(stats), L.ptr(tail_part), nt, Dy,
+                                        L.ptr(scal), opt.b1, opt.b2, opt.eps, lr_t, L.ptr(lr_dev), st), 'vmp_svae_step_final')
+        for t in list(params) + list(self.theta):
+            torch.autograd.graph.increment_version(t)
+        if _dev_scalars is None:
+            self.global_step += 1
+        return dict(elbo=scal[0], neg_rec_err=scal[1], regulariser=scal[2], grads=dict(zip(names, g_phi + g_enc + g_dec)),
+                    theta_star=star, lrcvi=lrcvi, log_z=lz, x_samples=xs, x_k=x, stats=stats)
 
     def _world(self):
         import torch.distributed as dist
@@ -501,8 +620,17 @@ class GraphedSVAEStep(object):
 
     def __call__(self, y):
         tr = self.tr
-        self.y.copy_(y)
-        self._refresh()
+        if (self.in_kernel_rng and torch.is_tensor(y) and y.is_cuda and y.dtype == torch.float32 and y.is_contiguous()
+                and tuple(y.shape) == tuple(self.y.shape)):
+            # scalars of the step + the minibatch into the static input: ONE eager launch (round 6; it was a copy + a launch)
+            same = y.data_ptr() == self.y.data_ptr()
+            L.check(L.lib().vmp_svae_step_inputs(L.ptr(self._dev16), tr._step_seed(0) & 0xFFFFFFFFFFFFFFFF,
+                                                 exponential_decay(tr.lrcvi0, tr.global_step, 1000, tr.decay_rate),
+                                                 tr.opt.lr_t(tr.opt.t + 1), None if same else L.ptr(y), None if same else L.ptr(self.y),
+                                                 0 if same else y.numel(), L.stream()), 'vmp_svae_step_inputs')
+        else:
+            self.y.copy_(y)
+            self._refresh()
         self.out['lrcvi'] = exponential_decay(tr.lrcvi0, tr.global_step, 1000, tr.decay_rate)
         self.graph.replay()
         if self.graph_back is not None:
