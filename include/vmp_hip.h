@@ -388,12 +388,11 @@ int    vmp_svae_elbo_tail(const float* log_z, const float* T_prime, const float*
                           size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * The minibatch training step in 7 + 1 launches (round 6; experiments.py:196-267 at its own operating point, minibatches
- * of 64-100 rows, where a step is bound by the NUMBER of launches - 13 + the input copy before)
+ * The minibatch training step in 6 launches (round 6; experiments.py:196-267 at its own operating point, minibatches
+ * of 64-100 rows, where a step is bound by the NUMBER of launches - 13 + the input copy + an eager scalar launch before)
  * ------------------------------------------------------------------------------------------------
- *   vmp_svae_step_inputs         [eager, per replay] scalars of the step + the minibatch into the static input
- *   vmp_mlp_gauss_head_fwd       encoder                                  (vae.make_encoder, vae.py:131-135)
- *   vmp_svae_prep_fwd2           recognition unpacking + theta packing    (svae.py:342-358, 205-214)
+ *   vmp_mlp_gauss_head_fwd_prep  encoder (vae.make_encoder, vae.py:131-135) + recognition unpacking + theta packing
+ *                                (svae.py:342-358, 205-214) + the replayed step's scalars from a table
  *   vmp_svae_estep_fwd_rng_epi   E-step, sub-sample, r                    (svae.py:14-151)
  *   vmp_decoder_elbo_lazy        decoder value + gradients; parameter partials stay in ws
  *   vmp_svae_estep_bwd_tail      ELBO tail + E-step backward              (svae.py:216-254 and the autodiff of :14-119)
@@ -403,6 +402,18 @@ int    vmp_svae_elbo_tail(const float* log_z, const float* T_prime, const float*
  * Every value equals what the stand-alone launches produce (same device functions, same summation orders); the ELBO
  * scalars are summed per tile instead of per tail block (fp64: equal to fp32 rounding).                              */
 
+/* The step's first launch: vmp_mlp_gauss_head_fwd (the encoder: x (R,L) -> out1, out2 (R,Dy)) and vmp_svae_prep_fwd2 with latent
+ * size Dy (recognition unpacking + theta packing, K components) as ONE grid - they depend on the parameters and the minibatch only.
+ * scalar_table != NULL (a step replayed from a HIP graph): (table_rows, 2) 64-bit words [Philox key | CVI step size (f32), Adam step
+ * size (f32)] filled by the host for the coming steps; the launch copies row *counter (u64, device) to dst16 - the 16 bytes the
+ * later launches read, as vmp_svae_step_scalars writes them - and increments the counter: no eager launch per replay.         */
+int    vmp_mlp_gauss_head_fwd_prep(const float* x, const float* W0, const float* b0, const float* W1, const float* b1,
+                                   const float* W2, const float* b2, const float* Ws, const float* bs1, const float* bs2,
+                                   int64_t R, int L, int Dy, int U, float var_scale, float* out1, float* out2,
+                                   const float* mu_k, const float* L_raw, const float* pi_raw, const float* alpha,
+                                   const float* A, const float* b, const float* beta, const float* v_hat, int K, float* Lk,
+                                   float* P, float* bias, float* m, float* W, float* kappa, double* logpi,
+                                   const void* scalar_table, int table_rows, void* counter, void* dst16, void* stream);
 /* vmp_svae_step_scalars (below) and the copy of the minibatch (n_floats fp32 words, y_src -> y_dst) in one launch. */
 int    vmp_svae_step_inputs(void* dst16, uint64_t philox_key, float cvi_step, float adam_step, const float* y_src,
                             float* y_dst, int64_t n_floats, void* stream);

@@ -537,6 +537,42 @@ def test_direct_minibatch_step_equals_the_autograd_step(N, K, Ld, U, Dy, S):
             assert torch.equal(a, b), (graphed, j)
 
 
+def test_graphed_step_scalar_table_refills_and_follows_the_trainer():
+    """Round 6: a replayed direct step takes [Philox key | CVI step size | Adam step size] from a table the host fills for the coming
+    steps (no eager launch per replay).  With a 3-row table, 9 replays with an eager tr.step() in between (the trainer's counters move
+    outside the graph object: the table must be rebuilt) leave exactly the state of 10 eager steps; the minibatch is written
+    straight into the static input for some calls (no copy launch) and passed as another tensor for others."""
+    from vmp_for_svae_amd.models import vae
+    from vmp_for_svae_amd.training import SVAETrainer, GraphedSVAEStep
+    N, K, Ld, U, Dy, S = 64, 10, 8, 50, 6, 10
+    g = torch.Generator(device='cuda').manual_seed(77)
+    ys = [torch.randn(N, Dy, device='cuda', generator=g) * 2 for _ in range(10)]
+
+    def mk():
+        vae.reset_variables()
+        return SVAETrainer(K, Ld, U, Dy, nb_samples=S, lr=3e-3, lrcvi=0.2, decay_rate=0.5, stddev_init_nn=0.1, seed=11)
+    tr = mk()
+    want_elbo = [tr.step(y)['elbo'].item() for y in ys]
+    want = [p.detach().clone() for p in tr.trainables()[1]] + [t.clone() for t in tr.theta]
+    tr2 = mk()
+    gs = GraphedSVAEStep(tr2, ys[0])
+    assert gs.table_mode
+    gs.TABLE_ROWS = 3                                   # (instance attribute: the table tensor keeps its 1024 rows, 3 are used)
+    got_elbo = []
+    for i, y in enumerate(ys):
+        if i == 4:
+            got_elbo.append(tr2.step(y)['elbo'].item())                 # eager step in between
+        elif i % 2:
+            gs.y.copy_(y)
+            got_elbo.append(gs(gs.y)['elbo'].item())                    # minibatch already in the static input
+        else:
+            got_elbo.append(gs(y)['elbo'].item())
+    assert tr2.global_step == 10 and tr2.opt.t == 10
+    assert got_elbo == want_elbo
+    for a, b in zip([p.detach() for p in tr2.trainables()[1]] + list(tr2.theta), want):
+        assert torch.equal(a, b)
+
+
 def test_sample_x_per_comp_standalone_matches_fused(golden):
     """svae.sample_x_per_comp (svae.py:95-119) on the materialised phi_tilde reproduces the samples of the fused E-step
     kernel and the reference's x_k."""

@@ -77,6 +77,8 @@ _SIGNATURES = {
     'vmp_svae_elbo_tail_workspace_bytes': (_c.c_size_t, []),
     'vmp_svae_elbo_tail': (_c.c_int, [_P] * 3 + [_c.c_int64] + [_c.c_int] * 3 + [_c.c_float] + [_P] * 5 + [_c.c_size_t, _P]),
     'vmp_svae_step_scalars': (_c.c_int, [_P, _c.c_uint64, _c.c_float, _c.c_float, _P]),
+    'vmp_mlp_gauss_head_fwd_prep': (_c.c_int, [_P] * 10 + [_c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _P, _P] + [_P] * 8 + [_c.c_int]
+                                    + [_P] * 7 + [_P, _c.c_int, _P, _P, _P]),
     'vmp_svae_step_inputs': (_c.c_int, [_P, _c.c_uint64, _c.c_float, _c.c_float, _P, _P, _c.c_int64, _P]),
     'vmp_decoder_bwd_blocks': (_c.c_int, [_c.c_int64]),
     'vmp_decoder_elbo_lazy': (_c.c_int, [_P] * 3 + [_c.c_float] + [_P] * 9 + [_c.c_int64] + [_c.c_int] * 5 + [_P, _P, _P, _c.c_size_t, _P]),

@@ -34,6 +34,7 @@
 #include "vmp_common.h"
 #include "vmp_tail.h"
 #include "vmp_step_parts.h"
+#include "vmp_prep_parts.h"
 
 using namespace vmp;
 
@@ -539,19 +540,19 @@ __device__ __forceinline__ void dec_forward_tile(const float* __restrict__ sm, i
     O = gemm_units_1<UT, TERMS>(sm + I::F2, lane, h1s, lds4(sm + I::BIASO + 4 * g)) + os;
 }
 
+// block `bid` of `nb` blocks of FWD_THREADS threads
 template <int UT>
-__global__ __launch_bounds__(FWD_THREADS, 2) void dec_fwd_kernel(DecArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+__device__ __forceinline__ void dec_fwd_body(const DecArgs& a, float* __restrict__ sm, const unsigned bid, const unsigned nb) {
     using I = Img<UT>;
     fill_images<UT, false, FWD_THREADS>(sm, a);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
     const unsigned ntiles = (a.R + 15u) / 16u;
-    const unsigned nwaves = gridDim.x * (FWD_THREADS / WAVE);
+    const unsigned nwaves = nb * (FWD_THREADS / WAVE);
     const int L = a.L, Dy = a.Dy;
     const float invS = 1.0f / (float)a.S, invK = 1.0f / (float)a.K;
     const unsigned ncells = a.R / a.S;
-    for (unsigned tile = blockIdx.x * (FWD_THREADS / WAVE) + wave; tile < ntiles; tile += nwaves) {
+    for (unsigned tile = bid * (FWD_THREADS / WAVE) + wave; tile < ntiles; tile += nwaves) {
         asm volatile("" ::: "memory");                  // keep the (loop-invariant) operand-image reads inside the loop: hoisted, they spill
         const unsigned row = tile * 16u + c;
         const bool ok = row < a.R;
@@ -593,6 +594,44 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void dec_fwd_kernel(DecArgs a) {
             }
         }
     }
+}
+
+template <int UT>
+__global__ __launch_bounds__(FWD_THREADS, 2) void dec_fwd_kernel(DecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    dec_fwd_body<UT>(a, sm, blockIdx.x, gridDim.x);
+}
+
+// The first launch of the minibatch training step (round 6): everything that depends on the parameters and the minibatch only, as
+// ONE grid - blocks [0, nb) the encoder's forward pass (dec_fwd_body), blocks [nb, nb + K) the recognition unpacking and
+// [nb + K, nb + 2K) the theta packing (wave 0 of the block: phi_prep_body / theta_pack_body, vmp_prep_parts.h; prep_both_kernel was
+// a launch of its own), and - for a step replayed from a HIP graph - block nb, thread 64, moves the step's three scalars
+// [Philox key | CVI step size | Adam step size] from row `*counter` of a table the host filled in advance to the 16 bytes the
+// later launches read, and advances the counter (it was an eager launch per replay: vmp_svae_step_scalars).
+struct StepTable {
+    const unsigned long long* table;    // (rows, 2) 64-bit words: [key | (rho, lr_t) as two floats]
+    unsigned long long* counter;        // next row
+    unsigned long long* dst16;
+    unsigned rows;
+};
+template <int UT, int LP>
+__global__ __launch_bounds__(FWD_THREADS, 2) void enc_prep_kernel(DecArgs a, PhiArgs p, ThetaArgs t, StepTable st, unsigned nb) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    if (blockIdx.x < nb) {
+        dec_fwd_body<UT>(a, sm, blockIdx.x, nb);
+        return;
+    }
+    const unsigned b = blockIdx.x - nb;
+    if (b == 0 && threadIdx.x == WAVE && st.table) {
+        unsigned long long i = *st.counter;
+        *st.counter = i + 1;
+        if (i >= st.rows) i = st.rows - 1;
+        st.dst16[0] = st.table[2 * i];
+        st.dst16[1] = st.table[2 * i + 1];
+    }
+    if (threadIdx.x >= PREP_THREADS) return;
+    if (b < (unsigned)p.K) phi_prep_body<LP, false, false, true>(p, (int)b);
+    else theta_pack_body<LP, true>(t, (int)(b - p.K));
 }
 
 // Lanes of ONE wave exchange data through LDS: the LDS unit executes a wave's instructions in order, so no wait is
@@ -1299,6 +1338,56 @@ int vmp_mlp_gauss_head_fwd(const float* x, const float* W0, const float* b0, con
                            float var_scale, float* out1, float* out2, void* stream) {
     return decoder_fwd_impl("vmp_mlp_gauss_head_fwd", var_scale, x, nullptr, W0, b0, W1, b1, W2, b2, Ws, bs1, bs2, R, 1, 1, L, Dy, U,
                             nullptr, out1, out2, stream);
+}
+
+// ---- round 6: encoder forward + recognition unpacking + theta packing (+ the replayed step's scalars) in ONE launch
+int vmp_mlp_gauss_head_fwd_prep(const float* x, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
+                                const float* b2, const float* Ws, const float* bs1, const float* bs2, int64_t R, int L, int Dy, int U,
+                                float var_scale, float* out1, float* out2, const float* mu_k, const float* L_raw, const float* pi_raw,
+                                const float* alpha, const float* A, const float* b, const float* beta, const float* v_hat, int K,
+                                float* Lk, float* P, float* bias, float* m, float* W, float* kappa, double* logpi,
+                                const void* scalar_table, int table_rows, void* counter, void* dst16, void* stream) {
+    const char* what = "vmp_mlp_gauss_head_fwd_prep";
+    if (int e = dec_check(what, R, 1, 1, L, Dy, U)) return e;
+    if (R < 1 || K < 1 || K > VMP_MAX_K) { set_error("%s: R = %lld, K = %d", what, (long long)R, K); return VMP_E_DIM; }
+    if (!x || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !Ws || !bs1 || !bs2 || !out1 || !out2 || !mu_k || !L_raw || !pi_raw || !alpha || !A ||
+        !b || !beta || !v_hat || !Lk || !P || !bias || !m || !W || !kappa) {
+        set_error("%s: NULL argument", what);
+        return VMP_E_BADARG;
+    }
+    if (scalar_table && (table_rows < 1 || !counter || !dst16 || (reinterpret_cast<uintptr_t>(dst16) & 7) || (reinterpret_cast<uintptr_t>(scalar_table) & 7))) {
+        set_error("%s: scalar table without rows / counter / 8-byte aligned destination", what);
+        return VMP_E_BADARG;
+    }
+    DecArgs a{};
+    a.x = x; a.W0 = W0; a.b0 = b0; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Ws = Ws; a.bs1 = bs1; a.bs2 = bs2;
+    a.mean = out1; a.var = out2; a.vscale = var_scale;
+    a.R = (unsigned)R; a.K = 1; a.S = 1; a.L = L; a.Dy = Dy; a.U = U;
+    PhiArgs p{};
+    p.mu = mu_k; p.Lraw = L_raw; p.piraw = pi_raw; p.Lk = Lk; p.P = P; p.bias = bias; p.K = K; p.L = Dy; p.logpi_out = logpi;
+    ThetaArgs t{alpha, A, b, beta, v_hat, m, W, kappa, K, Dy};
+    StepTable st{static_cast<const unsigned long long*>(scalar_table), static_cast<unsigned long long*>(counter),
+                 static_cast<unsigned long long*>(dst16), (unsigned)(table_rows > 0 ? table_rows : 0)};
+    const unsigned nb = (unsigned)dec_fwd_blocks((long long)a.R);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define ENC_PREP_L(UTV, LP)                                                                                           \
+    do {                                                                                                              \
+        const int lds = Img<UTV>::FWD_END * (int)sizeof(float);                                                       \
+        if (const int rc_ = set_dyn_lds(reinterpret_cast<const void*>(enc_prep_kernel<UTV, LP>), (size_t)lds, "enc_prep_kernel")) return rc_; \
+        hipLaunchKernelGGL((enc_prep_kernel<UTV, LP>), dim3(nb + 2 * K), dim3(FWD_THREADS), lds, s, a, p, t, st, nb);  \
+    } while (0)
+#define ENC_PREP(UTV)                                                                                                 \
+    do {                                                                                                              \
+        switch (Dy) {                                                                                                 \
+            case 1: ENC_PREP_L(UTV, 1); break; case 2: ENC_PREP_L(UTV, 2); break; case 3: ENC_PREP_L(UTV, 3); break;  \
+            case 4: ENC_PREP_L(UTV, 4); break; case 5: ENC_PREP_L(UTV, 5); break; case 6: ENC_PREP_L(UTV, 6); break;  \
+            case 7: ENC_PREP_L(UTV, 7); break; default: ENC_PREP_L(UTV, 8); break;                                    \
+        }                                                                                                             \
+    } while (0)
+    DEC_DISPATCH(U, ENC_PREP);
+#undef ENC_PREP
+#undef ENC_PREP_L
+    return check_launch(what);
 }
 
 int vmp_decoder_loglike_bwd(const float* x, const float* y, const float* gA, const float* W0, const float* b0,

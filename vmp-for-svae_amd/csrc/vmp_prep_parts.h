@@ -8,6 +8,20 @@ namespace vmp {
 
 constexpr int PREP_THREADS = 64;     // K <= VMP_MAX_K = 64
 
+// The bodies below are ONE wave of work.  WS = false: the wave is the whole block and synchronises with the block barrier;
+// WS = true: the body runs in wave 0 of a larger block whose other waves have left (round 6: the K-sized maps as extra blocks of the
+// encoder's forward launch) - the LDS unit executes a wave's accesses in order, only the compiler must keep the program order.
+template <bool WS>
+__device__ __forceinline__ void prep_sync() {
+    if (WS) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ double softplus_d(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 
 __device__ inline double digamma_dd(double x) {
@@ -100,11 +114,12 @@ __device__ __forceinline__ double pick(const double (&r)[L], int idx) {
 // (and the g_bias column of all components), value for value in its order and rounded to fp32 as the tensors were; log softmax(pi)_k
 // comes from the forward pass (a.logpi), so that the block reads nothing of another component's parameters - with `ad` it may
 // update its own in place (Adam) while the other blocks run.  Waves 1.. only take part in the reduction.
-template <int L, bool BWD, bool RED = false>
+template <int L, bool BWD, bool RED = false, bool WS = false>
 __device__ __forceinline__ void phi_prep_body(const PhiArgs& a, const int k, const float* __restrict__ partials = nullptr, const int nblk = 0,
                                               const PhiAdam* ad = nullptr) {
     static_assert(L * L <= PREP_THREADS, "one lane per matrix element");
     static_assert(!RED || BWD, "RED is a backward form");
+    static_assert(!(RED && WS), "the RED form synchronises its whole block");
     const int lane = threadIdx.x, K = a.K;
     __shared__ double Ls[L][L + 1];
     __shared__ double Gm[L][L + 1];
@@ -157,7 +172,7 @@ __device__ __forceinline__ void phi_prep_body(const PhiArgs& a, const int k, con
         logpi = (double)a.piraw[k] - (mx + log(se));
     }
     const double ld = wave_sum_d((in && i == j) ? log(lij) : 0.0);           // log det L
-    __syncthreads();
+    prep_sync<WS>();
     double s[L];                                        // s = L^-1 h
     double q2 = 0.0;
 #pragma unroll
@@ -230,7 +245,7 @@ struct ThetaArgs {
     int K, L;
 };
 
-template <int L>
+template <int L, bool WS = false>
 __device__ __forceinline__ void theta_pack_body(const ThetaArgs& a, const int k) {
     static_assert(L * L <= PREP_THREADS, "one lane per matrix element");
     const int lane = threadIdx.x, K = a.K;
@@ -249,7 +264,7 @@ __device__ __forceinline__ void theta_pack_body(const ThetaArgs& a, const int k)
         const double cji = (double)a.A[((size_t)k * L + j) * L + i] - bj * (bi / beta);
         Cs[i][j] = 0.5 * (cij + cji) * inv_nu;          // E[Sigma] = sym(C) / nu  (niw.expected_values)
     }
-    __syncthreads();
+    prep_sync<WS>();
     // Cholesky: column c; lanes r = lane < L take the rows r >= c; every lane also forms the pivot itself
 #pragma unroll
     for (int c = 0; c < L; ++c) {
@@ -261,10 +276,10 @@ __device__ __forceinline__ void theta_pack_body(const ThetaArgs& a, const int k)
             d -= Cs[c][q] * Cs[c][q];
         }
         const double sd = sqrt(d);
-        __syncthreads();
+        prep_sync<WS>();
         if (lane < L && lane >= c) Cs[lane][c] = lane == c ? sd : t / sd;
         if (lane == c) inv_d[c] = 1.0 / sd;
-        __syncthreads();
+        prep_sync<WS>();
     }
     // W = Lc^-1: lane c < L solves for column c
     double wdiag = 1.0;

@@ -17,9 +17,11 @@ namespace {
 // factorisation: 19 us at N = 64; partial rows: one per TILE here - vmp_svae_bwd_blocks_for.)
 // ---------------------------------------------------------------------------------------------------------
 constexpr int BWD1_MAX_PAIRS = 8;
-// TAIL (round 6, the minibatch training step): the scalar tail of the ELBO runs in here instead of in a launch of its own - every wave
-// forms dLoss/dT' = -sigma r of its cell, wave 0 also dLoss/dlog_z from the cell's S reconstruction sums (tail_cell, vmp_tail.h: the
-// arithmetic of elbo_tail_body), writes r = exp(log z) and the tile's terms of the ELBO's two fp64 sums.
+// TAIL (round 6, the minibatch training step): the scalar tail of the ELBO runs in here instead of in a launch of its own - every pair
+// wave forms dLoss/dT' = -sigma r of its cell; ONE MORE wave (beside the S / 2 pair waves; with S = 16 the block is full and wave 0
+// does it) forms dLoss/dlog_z from the cell's S reconstruction sums (tail_cell, vmp_tail.h: the arithmetic of elbo_tail_body), writes
+// r = exp(log z) and the tile's terms of the ELBO's two fp64 sums, and hands dLoss/dlog_z to wave 0 through LDS - it is done long
+// before the pair waves reach the block barrier.
 template <int L, bool TAIL>
 __global__ __launch_bounds__(BWD1_MAX_PAIRS * WAVE) void svae_estep_bwd1_kernel(EBwdArgs a) {
     constexpr int TRI = SvGeo<L>::TRI, TH = L + TRI + 1, PW = 2 * TH, NV = L + TRI;
@@ -28,8 +30,10 @@ __global__ __launch_bounds__(BWD1_MAX_PAIRS * WAVE) void svae_estep_bwd1_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int K = a.K, S = a.S, LSn = L * S;
     const int RPT = WAVE / K, CT = RPT * K;
-    float* scr = smem + wave * WAVE;                         // [nw][64] row-reduction scratch
-    float* red = smem + nw * WAVE;                           // [nw][NV][64] per-pair sums
+    const int np = (S + 1) / 2;                              // pair waves; TAIL: one more wave, if the block has it, runs the scalar tail
+    const bool tailw = TAIL && nw > np;
+    float* scr = smem + wave * WAVE;                         // [nw][64] row-reduction scratch (the tail wave's slot: dLoss/dlog_z of the cells)
+    float* red = smem + nw * WAVE;                           // [np][NV][64] per-pair sums
     float* accl = red;                                       // wave 0, after the sums are read: [TH][AST] per-lane values of the tile
     float* rows = red + TH * AST;                            //                                  [2L][AST] row-sum scratch
     const bool lane_on = lane < CT;
@@ -37,6 +41,30 @@ __global__ __launch_bounds__(BWD1_MAX_PAIRS * WAVE) void svae_estep_bwd1_kernel(
     const long long t = blockIdx.x, row = t * RPT + r;
     const bool on = lane_on && row < a.N;
     const long long rowc = on ? row : 0, cellid = rowc * K + kc;
+    float Lm[TRI], mu[L], Wsum[L], M[TRI];
+    float glzv = 0.f, gT = 0.f;
+    const float lzv = a.lz[cellid];
+    if (TAIL && (tailw ? wave == np : wave == 0)) {
+        // ---- the scalar tail of the ELBO for this tile's cells (tail_cell: the arithmetic of elbo_tail_body)
+        const float* __restrict__ lr = a.ll + cellid * S;
+        float lv[2 * BWD1_MAX_PAIRS];                        // all loads in flight together (a run-time loop waits for each in turn)
+#pragma unroll
+        for (int s = 0; s < 2 * BWD1_MAX_PAIRS; ++s) lv[s] = lr[s < S ? s : 0];
+        const float tpv = a.Tp[cellid];
+        float A = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2 * BWD1_MAX_PAIRS; ++s)
+            if (s < S) A += lv[s];
+        float rr, gtp;
+        double wa = 0.0, rg = 0.0;
+        tail_cell(lzv, tpv, A, 0.5f / (float)S, a.sigma, rr, glzv, gtp, wa, rg);
+        if (on) a.r_out[cellid] = rr;
+        wa = tail_wave_sum(on ? wa : 0.0);
+        rg = tail_wave_sum(on ? rg : 0.0);
+        if (lane == 0) { a.tail_part[2 * blockIdx.x] = wa; a.tail_part[2 * blockIdx.x + 1] = rg; }
+        if (tailw) scr[lane] = glzv;                         // (read by wave 0 behind the block barrier)
+    }
+    if (wave < np) {
     // ---- everything this lane needs, requested at once
     const int s0 = 2 * wave;
     const bool h1 = s0 + 1 < S;
@@ -51,7 +79,7 @@ __global__ __launch_bounds__(BWD1_MAX_PAIRS * WAVE) void svae_estep_bwd1_kernel(
             xp[L + i] = (on && h1) ? xw : 0.f; gp[L + i] = (on && h1) ? gw : 0.f;
         }
     }
-    float Lm[TRI], av[L], mu[L], hkk[L], mkk[L], Wt[TRI];
+    float av[L], hkk[L], mkk[L], Wt[TRI];
 #pragma unroll
     for (int i = 0; i < L; ++i) {
         const float e1 = a.eta1[rowc * L + i], e2 = a.eta2d[rowc * L + i], hv = a.hk[kc * L + i], mv = a.mk[kc * L + i];
@@ -65,29 +93,11 @@ __global__ __launch_bounds__(BWD1_MAX_PAIRS * WAVE) void svae_estep_bwd1_kernel(
         hkk[i] = lane_on ? hv : 0.f; mkk[i] = lane_on ? mv : 0.f;
         av[i] = (on ? e1 : 0.f) + hkk[i];
     }
-    const float lzv = a.lz[cellid];
-    float glzv, gTv;
+    float gTv;
     if (TAIL) {
-        float A = 0.f, tpv = 0.f;
-        if (wave == 0) {                                     // (block-uniform branch)
-            const float* __restrict__ lr = a.ll + cellid * S;
-            float lv[2 * BWD1_MAX_PAIRS];                    // all loads in flight together (a run-time loop waits for each in turn)
-#pragma unroll
-            for (int s = 0; s < 2 * BWD1_MAX_PAIRS; ++s) lv[s] = lr[s < S ? s : 0];
-            tpv = a.Tp[cellid];
-#pragma unroll
-            for (int s = 0; s < 2 * BWD1_MAX_PAIRS; ++s)
-                if (s < S) A += lv[s];
-        }
-        float rr;
-        double wa = 0.0, rg = 0.0;
-        tail_cell(lzv, tpv, A, 0.5f / (float)S, a.sigma, rr, glzv, gTv, wa, rg);
-        if (wave == 0) {
-            if (on) a.r_out[cellid] = rr;
-            wa = tail_wave_sum(on ? wa : 0.0);
-            rg = tail_wave_sum(on ? rg : 0.0);
-            if (lane == 0) { a.tail_part[2 * blockIdx.x] = wa; a.tail_part[2 * blockIdx.x + 1] = rg; }
-        }
+        float rr, g0, g1;
+        double d0 = 0.0, d1 = 0.0;
+        tail_cell(lzv, 0.f, 0.f, 0.5f / (float)S, a.sigma, rr, g0, gTv, d0, d1);     // dLoss/dT' = -sigma exp(log z): every pair wave needs it
     } else {
         glzv = a.Glz[cellid];
         gTv = a.GT[cellid];
@@ -98,10 +108,9 @@ __global__ __launch_bounds__(BWD1_MAX_PAIRS * WAVE) void svae_estep_bwd1_kernel(
 #pragma unroll
     for (int i = 0; i < L; ++i) mu[i] = av[i];
     solve_lower_t<L>(Lm, mu);                               // mu~ = Pt^-1 ht
-    const float gT = on ? gTv : 0.f;
+    gT = on ? gTv : 0.f;
     const float gts = gT * (1.0f / (float)S);
     // ---- this wave's two samples
-    float Wsum[L], M[TRI];
 #pragma unroll
     for (int i = 0; i < L; ++i) Wsum[i] = 0.f;
 #pragma unroll
@@ -141,9 +150,11 @@ __global__ __launch_bounds__(BWD1_MAX_PAIRS * WAVE) void svae_estep_bwd1_kernel(
 #pragma unroll
         for (int i = 0; i < TRI; ++i) rw[(L + i) * WAVE] = M[i];
     }
+    }   // pair waves
     __syncthreads();
     if (wave == 0) {
-    for (int w = 1; w < nw; ++w) {
+    if (tailw) glzv = smem[np * WAVE + lane];
+    for (int w = 1; w < np; ++w) {
         const float* rw = red + w * (NV * WAVE) + lane;
 #pragma unroll
         for (int i = 0; i < L; ++i) Wsum[i] += rw[i * WAVE];
@@ -262,11 +273,12 @@ int launch_bwd1(const EBwdArgs& a, int ntiles, int P, void* stream) {
     constexpr int TH = L + TRI + 1;
     const int epi = TH * SV_AST + 2 * L * SV_AST;
     const int work = P * NV * WAVE > epi ? P * NV * WAVE : epi;
-    const size_t lds1 = (size_t)(P * WAVE + work) * sizeof(float);
+    const int nwv = (TAIL && P < BWD1_MAX_PAIRS) ? P + 1 : P;       // the tail wave (with S = 16 the block is full: wave 0 runs the tail)
+    const size_t lds1 = (size_t)(nwv * WAVE + work) * sizeof(float);
     if (lds1 > 48 * 1024) {
         if (const int rc = set_dyn_lds(reinterpret_cast<const void*>(svae_estep_bwd1_kernel<L, TAIL>), lds1, "svae_estep_bwd1_kernel")) return rc;
     }
-    hipLaunchKernelGGL((svae_estep_bwd1_kernel<L, TAIL>), dim3(ntiles), dim3(P * WAVE), lds1, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL((svae_estep_bwd1_kernel<L, TAIL>), dim3(ntiles), dim3(nwv * WAVE), lds1, static_cast<hipStream_t>(stream), a);
     return check_launch("svae_estep_bwd1_kernel");
 }
 

@@ -223,6 +223,11 @@ class SVAETrainer(object):
                 ts.append(p)
         return names, ts
 
+    def _step_seed_at(self, global_step, chunk_index=0):
+        import torch.distributed as dist
+        rank = dist.get_rank(self.group) if (dist.is_available() and dist.is_initialized()) else 0
+        return self.seed + int(global_step) + 1000003 * rank + 15485863 * int(chunk_index)
+
     def _step_seed(self, chunk_index=0):
         """Seed of this step's draws: every tower (rank) draws its own noise, as the reference's per-tower ops do, and
         every row chunk of a chunked step its own stream (the Philox counter of the in-kernel generator is the
@@ -292,8 +297,8 @@ class SVAETrainer(object):
 
     @torch.no_grad()
     def _step_direct(self, y, _dev_scalars=None):
-        """experiments.py:196-267 for one whole minibatch as SEVEN launches, no autograd graph (include/vmp_hip.h, "The minibatch
-        training step"): encoder, recognition / theta prep, E-step (+ sub-sample), decoder value + gradients, ELBO tail + E-step
+        """experiments.py:196-267 for one whole minibatch as SIX launches, no autograd graph (include/vmp_hip.h, "The minibatch
+        training step"): encoder + recognition / theta prep, E-step (+ sub-sample), decoder value + gradients, ELBO tail + E-step
         backward, encoder backward, and one closing launch (partial rows -> phi_gmm gradients, both parameter reductions, Adam on
         the 21 tensors, M-step moments + CVI update, ELBO scalars).  Same kernels / device functions as the autograd step: every
         gradient, moment and parameter it leaves is bit-identical to that step's (tests/test_svae_gpu.py); the three ELBO scalars
@@ -322,17 +327,19 @@ class SVAETrainer(object):
         rho_dev = None if _dev_scalars is None else _dev_scalars[0]
         lr_dev = None if _dev_scalars is None else _dev_scalars[1]
         lrcvi = exponential_decay(self.lrcvi0, self.global_step, 1000, self.decay_rate)
-        # 1: encoder (natparam head: eta1, -1/2 var)
+        # 1: encoder (natparam head: eta1, -1/2 var) + recognition unpacking + theta packing (+ a replayed step's scalars from its table)
         eta1, eta2d = torch.empty(N, Ld, **f32), torch.empty(N, Ld, **f32)
-        L.check(lib.vmp_mlp_gauss_head_fwd(L.ptr(y), *pp(enc), N, Dy, Ld, U, -0.5, L.ptr(eta1), L.ptr(eta2d), st), 'vmp_mlp_gauss_head_fwd')
-        # 2: recognition unpacking + theta packing
         mu_k, L_raw, pi_raw = phi
         Lk, P, bias = torch.empty(K, Ld, Ld, **f32), torch.empty(K, Ld, Ld, **f32), torch.empty(K, **f32)
         mk, Wk, kappa = torch.empty(K, Ld, **f32), torch.empty(K, Ld, Ld, **f32), torch.empty(K, **f32)
         logpi = torch.empty(K, dtype=torch.float64, device=dev)
-        L.check(lib.vmp_svae_prep_fwd2(L.ptr(mu_k), L.ptr(L_raw), L.ptr(pi_raw), *pp(self.theta), K, Ld, L.ptr(Lk), L.ptr(P), L.ptr(bias),
-                                       L.ptr(mk), L.ptr(Wk), L.ptr(kappa), L.ptr(logpi), st), 'vmp_svae_prep_fwd2')
-        # 3: E-step on in-kernel noise; its epilogue draws the one sub-sample per row
+        tab = _dev_scalars[3] if (_dev_scalars is not None and len(_dev_scalars) > 3) else None     # (table, rows, counter, dst16)
+        L.check(lib.vmp_mlp_gauss_head_fwd_prep(L.ptr(y), *pp(enc), N, Dy, Ld, U, -0.5, L.ptr(eta1), L.ptr(eta2d), L.ptr(mu_k), L.ptr(L_raw),
+                                                L.ptr(pi_raw), *pp(self.theta), K, L.ptr(Lk), L.ptr(P), L.ptr(bias), L.ptr(mk), L.ptr(Wk),
+                                                L.ptr(kappa), L.ptr(logpi), L.ptr(tab[0]) if tab else None, tab[1] if tab else 0,
+                                                L.ptr(tab[2]) if tab else None, L.ptr(tab[3]) if tab else None, st),
+                'vmp_mlp_gauss_head_fwd_prep')
+        # 2: E-step on in-kernel noise; its epilogue draws the one sub-sample per row
         x = torch.empty(N, K, S, Ld, **f32)
         lz, Tp = torch.empty(N, K, **f32), torch.empty(N, K, **f32)
         xs, r_epi = torch.empty(N, Ld, **f32), torch.empty(N, K, **f32)
@@ -340,13 +347,13 @@ class SVAETrainer(object):
         L.check(lib.vmp_svae_estep_fwd_rng_epi(L.ptr(eta1), L.ptr(eta2d), L.ptr(mu_k), L.ptr(P), L.ptr(bias), key, L.ptr(seed_dev),
                                                L.ptr(mk), L.ptr(Wk), L.ptr(kappa), None, N, K, Ld, S, L.ptr(x), L.ptr(lz), L.ptr(Tp),
                                                L.ptr(xs), L.ptr(r_epi), None, 0, st), 'vmp_svae_estep_fwd_rng_epi')
-        # 4: decoder value + gradients of loss = -elbo (sigma = -1); parameter partials stay in ws_dec
+        # 3: decoder value + gradients of loss = -elbo (sigma = -1); parameter partials stay in ws_dec
         dx, ll = torch.empty_like(x), torch.empty(N, K, S, **f32)
         nb_dec = lib.vmp_decoder_bwd_blocks(N * K * S)
         ws_dec = torch.empty(lib.vmp_decoder_workspace_bytes(N, K, S, Ld, U, Dy), dtype=torch.uint8, device=dev)
         L.check(lib.vmp_decoder_elbo_lazy(L.ptr(x), L.ptr(y), L.ptr(lz), -1.0, *pp(dec), N, K, S, Ld, Dy, U, L.ptr(dx), L.ptr(ll),
                                           L.ptr(ws_dec), ws_dec.numel(), st), 'vmp_decoder_elbo_lazy')
-        # 5: ELBO tail + E-step backward
+        # 4: ELBO tail + E-step backward
         g_eta1, g_eta2d = torch.empty(N, Ld, **f32), torch.empty(N, Ld, **f32)
         nt = lib.vmp_svae_bwd_blocks_for(N, K, Ld, S, 0)
         partials = torch.empty(nt, K, lib.vmp_svae_bwd_partial_words(Ld), **f32)
@@ -356,12 +363,12 @@ class SVAETrainer(object):
                                             L.ptr(x), L.ptr(lz), L.ptr(Tp), L.ptr(ll), -1.0, L.ptr(dx), N, K, Ld, S, L.ptr(g_eta1),
                                             L.ptr(g_eta2d), L.ptr(partials), partials.numel() * 4, L.ptr(r), L.ptr(tail_part),
                                             tail_part.numel() * 8, st), 'vmp_svae_estep_bwd_tail')
-        # 6: encoder backward; parameter partials stay in ws_enc
+        # 5: encoder backward; parameter partials stay in ws_enc
         nb_enc = lib.vmp_decoder_bwd_blocks(N)
         ws_enc = torch.empty(lib.vmp_decoder_workspace_bytes(N, 1, 1, Dy, U, Ld), dtype=torch.uint8, device=dev)
         L.check(lib.vmp_mlp_gauss_head_bwd_lazy(L.ptr(y), L.ptr(g_eta1), L.ptr(g_eta2d), -0.5, *pp(enc), N, Dy, Ld, U, None,
                                                 L.ptr(ws_enc), ws_enc.numel(), st), 'vmp_mlp_gauss_head_bwd_lazy')
-        # 7: the closing launch (phi_gmm gradients from the partial rows, both MLP reductions, Adam, moments + CVI, ELBO scalars)
+        # 6: the closing launch (phi_gmm gradients from the partial rows, both MLP reductions, Adam, moments + CVI, ELBO scalars)
         g_phi = [torch.empty_like(t) for t in phi]
         g_enc, g_dec = [torch.empty_like(t) for t in enc], [torch.empty_like(t) for t in dec]
         stats = torch.empty(K, 2 + Ld + Ld * Ld, dtype=torch.float64, device=dev)
@@ -521,6 +528,8 @@ class GraphedSVAEStep(object):
     (call i here == step i there).  Trainer with rng='torch': the graph reads eps / u from static tensors that every call
     refills with torch's generator (three more launches per call), again the stream of that trainer stepped eagerly."""
 
+    TABLE_ROWS = 1024
+
     def __init__(self, trainer, y_example, warmup=3):
         """(Parallel graph branches on side streams - noise generator / recognition prep beside the encoder, CVI beside Adam - were
         built and measured in round 5: bit-identical and 42 % SLOWER, a cross-stream edge of a HIP graph costs ~6 us on this runtime
@@ -544,6 +553,13 @@ class GraphedSVAEStep(object):
             self.noise = torch.empty(N, tr.K, tr.L, tr.S, **f32)
             self.u = torch.empty(N, 1, **f32)
         self.gen = torch.Generator(device=dev).manual_seed(int(tr.seed))
+        # Round 6: where the captured step is the trainer's direct kernel sequence, its FIRST launch also fetches the step's scalars from
+        # a table of the coming TABLE_ROWS steps that the host fills in advance (exactly the values the eager launch passed by value) -
+        # a replay whose minibatch already sits in the static input (self.y: the loader's copy target) is graph.replay() and nothing else
+        self.table_mode = bool(self.in_kernel_rng and tr._world() == 1 and tr._direct_ok(self.y, None, None, None, None))
+        self._table = torch.zeros(self.TABLE_ROWS, 2, dtype=torch.int64, device=dev) if self.table_mode else None
+        self._counter = torch.zeros(1, dtype=torch.int64, device=dev) if self.table_mode else None
+        self._table_base, self._table_used = None, 0
         # Warm-up steps (they create the variables / Adam slots and size the workspaces) must not train: everything a
         # step mutates is snapshotted first and put back before the capture, so that call number i of this object
         # is training step number i of the eager trainer (and of the reference).
@@ -585,6 +601,8 @@ class GraphedSVAEStep(object):
         self.graph_back = None
         cap_stream = torch.cuda.Stream(device=dev)
         dev_scalars = (self.rho, self.lr_t) + ((self.seed_dev,) if self.in_kernel_rng else ())
+        if self.table_mode:
+            dev_scalars = dev_scalars + ((self._table, self.TABLE_ROWS, self._counter, self._dev16),)
         self.world = tr._world()
         if self.world == 1:
             with torch.cuda.graph(self.graph, stream=cap_stream):
@@ -618,9 +636,29 @@ class GraphedSVAEStep(object):
                                               tr.opt.lr_t(tr.opt.t + 1) if tr.opt is not None else 0.0, L.stream()),
                 'vmp_svae_step_scalars')
 
+    def _fill_table(self):
+        """[Philox key | CVI step size | Adam step size] of the next TABLE_ROWS steps, from the trainer's counters as they stand"""
+        import numpy as np
+        tr, R = self.tr, self.TABLE_ROWS
+        rows = np.zeros(R, dtype=[('key', '<u8'), ('rho', '<f4'), ('lr', '<f4')])
+        for j in range(R):
+            rows['key'][j] = tr._step_seed_at(tr.global_step + j) & 0xFFFFFFFFFFFFFFFF
+            rows['rho'][j] = exponential_decay(tr.lrcvi0, tr.global_step + j, 1000, tr.decay_rate)
+            rows['lr'][j] = tr.opt.lr_t(tr.opt.t + 1 + j)
+        self._table[:R].copy_(torch.from_numpy(rows.view(np.int64).reshape(R, 2)))
+        self._counter.zero_()
+        self._table_base, self._table_used = (tr.global_step, tr.opt.t), 0
+
     def __call__(self, y):
         tr = self.tr
-        if (self.in_kernel_rng and torch.is_tensor(y) and y.is_cuda and y.dtype == torch.float32 and y.is_contiguous()
+        if self.table_mode:
+            b = self._table_base
+            if b is None or self._table_used >= self.TABLE_ROWS or (b[0] + self._table_used, b[1] + self._table_used) != (tr.global_step, tr.opt.t):
+                self._fill_table()                  # first call, table used up, or the trainer was stepped outside this object
+            if not (torch.is_tensor(y) and y.is_cuda and y.data_ptr() == self.y.data_ptr()):
+                self.y.copy_(y)                     # (a loader that writes into self.y directly saves this launch)
+            self._table_used += 1
+        elif (self.in_kernel_rng and torch.is_tensor(y) and y.is_cuda and y.dtype == torch.float32 and y.is_contiguous()
                 and tuple(y.shape) == tuple(self.y.shape)):
             # scalars of the step + the minibatch into the static input: ONE eager launch (round 6; it was a copy + a launch)
             same = y.data_ptr() == self.y.data_ptr()
