@@ -469,6 +469,18 @@ int    vmp_svae_step_final(const float* dec_part, int dec_blocks, int dec_in, in
                            double* stats_out, const double* tail_part, int tail_n, int Dy, float* scalars, double beta1,
                            double beta2, double eps, double lr_t, const float* lr_t_dev, void* stream);
 
+/* The closing launch of a DATA-PARALLEL minibatch step (one process per GPU; experiments.py:247-260, tf_utils.py:52-87): the block
+ * roles of vmp_svae_step_final, but nothing is updated - this rank's M-step moments, its 21 gradients and its three scalars go as
+ * doubles into xbuf = [moments (K, 2+L+L*L) | phi_gmm mu_k, L_k, log_pi_k | encoder net (9) | decoder net (9) | elbo, rec, reg],
+ * the packed buffer the step's ONE all-reduce sums; vmp_svae_cvi_update and vmp_adam_step_packed follow it.  The fp32
+ * gradients are also left in dec_g / enc_g / phi_g.  xbuf_doubles >= the layout's length.                              */
+int    vmp_svae_step_pack(double* xbuf, size_t xbuf_doubles, const float* dec_part, int dec_blocks, int dec_in, int dec_units,
+                          int dec_out, float* const* dec_p, float* const* dec_g, const float* enc_part, int enc_blocks,
+                          int enc_in, int enc_units, int enc_out, float* const* enc_p, float* const* enc_g,
+                          const float* partials, int nblk, const double* logpi, float* const* phi_p, float* const* phi_g,
+                          const float* x_samples, const float* r, int64_t N, int K, int L, const double* tail_part, int tail_n,
+                          int Dy, float* scalars, void* stream);
+
 /* Writes the 16 bytes [Philox key (u64) | CVI step size (f32) | Adam step size (f32)] that a graph-captured training step
  * reads at run time (vmp_svae_estep_fwd_rng_dev / vmp_svae_subsample_rng seed_dev, vmp_svae_cvi_update rho_dev,
  * vmp_adam_step lr_t_dev = dst16 + 0 / 8 / 12): one launch, values passed by value.                                  */

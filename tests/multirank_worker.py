@@ -96,6 +96,16 @@ def main():
         lab_e = torch.nn.functional.one_hot(torch.randint(0, 3, (96,), device='cuda', generator=torch.Generator(device='cuda').manual_seed(24)), 3).float()
         m_e = experiments.evaluate(tr_e, Xte_e, lab_e, 4, seed=0)
         res['dpg_eval_eager'] = np.array([m_e[k_] for k_ in sorted(m_e)], dtype=np.float64)
+        # round 6: the eager data-parallel step above ran as the direct kernel sequence up to the packed exchange buffer
+        # (SVAETrainer._step_direct(pack=True) -> vmp_svae_step_pack); the autograd step over the stand-alone launches must agree
+        # (its moments come from another kernel with another summation order: fp64, equal to rounding)
+        res['dpd_direct'] = np.int64(tr_e._direct_ok(ys[0], None, None, None, None))
+        vae.reset_variables()
+        tr_a = SVAETrainer(Kg, Lg, Ug, Dg, nb_samples=Sg, lr=3e-3, lrcvi=0.2, decay_rate=0.95, stddev_init_nn=0.1, seed=3, direct_step=False)
+        el_a = [float(tr_a.step(ys[i])['elbo']) for i in range(4)]
+        got_a = list(tr_a.trainables()[1]) + list(tr_a.theta)
+        res['dpd_elbo_direct'], res['dpd_elbo_autograd'] = np.array(el_e), np.array(el_a)
+        res['dpd_param_err'] = np.array([((a.detach() - b).abs().max() / b.abs().max().clamp_min(1e-30)).item() for a, b in zip(got_a, want)])
         tr_g = fresh()
         gs = GraphedSVAEStep(tr_g, ys[0], warmup=2)
         res['dpg_two_graphs'] = np.int64(gs.graph_back is not None)

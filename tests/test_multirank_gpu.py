@@ -229,6 +229,18 @@ def test_data_parallel_graphed_step_matches_the_eager_step(two_ranks):
     assert np.array_equal(ranks[0]['dpg_elbo_graphed'], ranks[1]['dpg_elbo_graphed'])
 
 
+def test_data_parallel_direct_step_equals_the_autograd_step(two_ranks):
+    """Round 6: with several ranks the whole-shard GMM step runs as the direct kernel sequence whose closing launch fills the packed
+    fp64 exchange buffer (vmp_svae_step_pack) instead of updating anything; four steps of it against four steps of the autograd
+    step (direct_step=False) on the same rows and Philox keys, on both ranks."""
+    _, ranks = two_ranks
+    for r in ranks:
+        assert 'dpg_error' not in r.files, str(r['dpg_error'])
+        assert int(r['dpd_direct']) == 1
+        assert np.allclose(r['dpd_elbo_direct'], r['dpd_elbo_autograd'], rtol=1e-6, atol=0), (r['dpd_elbo_direct'], r['dpd_elbo_autograd'])
+        assert float(r['dpd_param_err'].max()) <= 1e-6, r['dpd_param_err']
+
+
 def test_nothing_after_graphed_data_parallel_steps_depends_on_device_solvers(two_ranks):
     """after graphed data-parallel steps torch's device Cholesky returned a wrong factor (first call, two processes
     on one GPU; pinned down in round 6: inputs bit-equal, only the solver output wrong - tools/r6_dpg_repro.py).  What the package

@@ -88,6 +88,8 @@ _SIGNATURES = {
                                            _c.c_size_t, _P]),
     'vmp_svae_bwd_reduce_prep': (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _c.c_int, _c.c_int, _P, _P, _P, _P]),
     'vmp_svae_prep_fwd2': (_c.c_int, [_P] * 8 + [_c.c_int, _c.c_int] + [_P] * 8),
+    'vmp_svae_step_pack': (_c.c_int, [_P, _c.c_size_t] + [_P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P] * 2 + [_P, _c.c_int, _P, _P, _P, _P, _P,
+                                      _c.c_int64, _c.c_int, _c.c_int, _P, _c.c_int, _c.c_int, _P, _P]),
     'vmp_svae_step_final': (_c.c_int, [_P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P] * 2 + [_P, _c.c_int, _P] + [_P] * 4
                             + [_P, _P, _c.c_int64, _P, _P, _P, _P, _c.c_float, _c.c_int, _c.c_int, _P, _P, _c.c_int, _c.c_int, _P]
                             + [_c.c_double] * 4 + [_P, _P]),

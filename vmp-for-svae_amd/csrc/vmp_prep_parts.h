@@ -80,9 +80,10 @@ struct PhiArgs {
 // Adam applied to component k's phi_gmm elements right where their gradients are formed (round 6, step_final_kernel): the three
 // tensors mu_k, L_k, log_pi_k with their slots; NULL = gradients only.
 struct PhiAdam {
-    float* p[3];
+    float* p[3];                 // NULL: no update (data-parallel step: Adam follows the all-reduce)
     float* m[3];
     float* v[3];
+    double* gx[3];               // optional: the gradients also as doubles (the packed exchange buffer of a data-parallel step)
     float lr_t, b1, b2, c1, c2, eps;
 };
 
@@ -212,12 +213,14 @@ __device__ __forceinline__ void phi_prep_body(const PhiArgs& a, const int k, con
     if (lane < L) {
         const float g = (float)((double)(RED ? ghs[lane] : a.g_hk[k * L + lane]) - gb * pick<L>(u, lane));
         a.g_mu[k * L + lane] = g;
-        if (ad) adam_update(ad->p[0], ad->m[0], ad->v[0], (unsigned)(k * L + lane), g, ad->lr_t, ad->b1, ad->b2, ad->c1, ad->c2, ad->eps);
+        if (ad && ad->gx[0]) ad->gx[0][k * L + lane] = (double)g;
+        if (ad && ad->p[0]) adam_update(ad->p[0], ad->m[0], ad->v[0], (unsigned)(k * L + lane), g, ad->lr_t, ad->b1, ad->b2, ad->c1, ad->c2, ad->eps);
     }
     if (lane == 0) {
         const float g = (float)(gb - exp(logpi) * s_gb);
         a.g_piraw[k] = g;
-        if (ad) adam_update(ad->p[2], ad->m[2], ad->v[2], (unsigned)k, g, ad->lr_t, ad->b1, ad->b2, ad->c1, ad->c2, ad->eps);
+        if (ad && ad->gx[2]) ad->gx[2][k] = (double)g;
+        if (ad && ad->p[2]) adam_update(ad->p[2], ad->m[2], ad->v[2], (unsigned)k, g, ad->lr_t, ad->b1, ad->b2, ad->c1, ad->c2, ad->eps);
     }
     if (in) {
         double g = 0.0;
@@ -233,7 +236,8 @@ __device__ __forceinline__ void phi_prep_body(const PhiArgs& a, const int k, con
         }
         const float gf = (float)g;
         a.g_Lraw[(size_t)k * L * L + lane] = gf;
-        if (ad) adam_update(ad->p[1], ad->m[1], ad->v[1], (unsigned)(k * L * L + lane), gf, ad->lr_t, ad->b1, ad->b2, ad->c1, ad->c2, ad->eps);
+        if (ad && ad->gx[1]) ad->gx[1][(size_t)k * L * L + lane] = (double)gf;
+        if (ad && ad->p[1]) adam_update(ad->p[1], ad->m[1], ad->v[1], (unsigned)(k * L * L + lane), gf, ad->lr_t, ad->b1, ad->b2, ad->c1, ad->c2, ad->eps);
     }
 }
 

@@ -172,6 +172,10 @@ struct FinArgs {
     unsigned tail_n;
     const float* lr_t_dev;
     float lr_t, b1, b2, c1, c2, eps;
+    // data-parallel form (vmp_svae_step_pack): nothing is updated - moments, gradients and scalars go, as doubles, into the packed
+    // exchange buffer [moments | gradients in parameter order | elbo, rec, reg] that the step's ONE all-reduce sums
+    double* xnet[2];                         // where the two nets' gradients start in the buffer (NULL: the single-process form)
+    double* xscal;
 };
 template <int L>
 __global__ __launch_bounds__(FIN_THREADS) void step_final_kernel(FinArgs a) {
@@ -193,7 +197,8 @@ __global__ __launch_bounds__(FIN_THREADS) void step_final_kernel(FinArgs a) {
                 const unsigned j = (unsigned)(i - q.off[t]);
                 const float gi = (float)s;
                 q.g[t][j] = gi;
-                adam_update(q.p[t], q.m[t], q.v[t], j, gi, lr_t, a.b1, a.b2, a.c1, a.c2, a.eps);
+                if (a.xnet[n]) a.xnet[n][i] = (double)gi;
+                else adam_update(q.p[t], q.m[t], q.v[t], j, gi, lr_t, a.b1, a.b2, a.c1, a.c2, a.eps);
             }
             return;
         }
@@ -207,10 +212,16 @@ __global__ __launch_bounds__(FIN_THREADS) void step_final_kernel(FinArgs a) {
     }
     b -= a.phi.K;
     if (b < a.cvi.K) {
-        stats_cvi_body(a.sa, a.cvi, b, spart, st);
+        stats_cvi_body(a.sa, a.cvi, b, spart, st, a.xscal == nullptr);
         return;
     }
-    if (threadIdx.x < WAVE) elbo_final_body(a.tail, a.tail_n);
+    if (threadIdx.x < WAVE) {
+        elbo_final_body(a.tail, a.tail_n);
+        if (threadIdx.x == 0 && a.xscal) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) a.xscal[i] = (double)a.tail.scal[i];       // (this thread wrote them: program order)
+        }
+    }
 }
 
 }  // namespace
@@ -246,7 +257,8 @@ int vmp_svae_step_inputs(void* dst16, uint64_t philox_key, float cvi_step, float
     return check_launch("vmp_svae_step_inputs");
 }
 
-int vmp_svae_step_final(const float* dec_part, int dec_blocks, int dec_in, int dec_units, int dec_out, float* const* dec_p,
+namespace {
+int step_final_impl(const char* what, double* xbuf, const float* dec_part, int dec_blocks, int dec_in, int dec_units, int dec_out, float* const* dec_p,
                         float* const* dec_m, float* const* dec_v, float* const* dec_g, const float* enc_part, int enc_blocks,
                         int enc_in, int enc_units, int enc_out, float* const* enc_p, float* const* enc_m, float* const* enc_v,
                         float* const* enc_g, const float* partials, int nblk, const double* logpi, float* const* phi_p,
@@ -254,13 +266,15 @@ int vmp_svae_step_final(const float* dec_part, int dec_blocks, int dec_in, int d
                         float* const* theta, float* const* theta_star, const float* rho_dev, float rho, int K, int L,
                         double* stats_out, const double* tail_part, int tail_n, int Dy, float* scalars, double beta1, double beta2,
                         double eps, double lr_t, const float* lr_t_dev, void* stream) {
+    const bool pack = xbuf != nullptr;
     if (K < 1 || K > VMP_MAX_K || L < 1 || L > VMP_MAX_D || N < 1 || N > SMALL_STATS_MAX_N || tail_n < 1 || tail_n > TAIL_MAX_BLOCKS || Dy < 1) {
-        set_error("vmp_svae_step_final: K=%d L=%d N=%lld tail_n=%d outside the minibatch step's range (N <= %d)", K, L, (long long)N, tail_n,
+        set_error("vmp_svae_step_final / _pack: K=%d L=%d N=%lld tail_n=%d outside the minibatch step's range (N <= %d)", K, L, (long long)N, tail_n,
                   SMALL_STATS_MAX_N);
         return VMP_E_DIM;
     }
     if (!dec_part || !enc_part || dec_blocks < 1 || enc_blocks < 1 || !dec_p || !dec_m || !dec_v || !dec_g || !enc_p || !enc_m || !enc_v ||
-        !enc_g || !partials || nblk < 1 || !logpi || !phi_p || !phi_g || !phi_m || !phi_v || !x_samples || !r || !prior || !theta || !stats_out || !tail_part || !scalars) {
+        !enc_g || !partials || nblk < 1 || !logpi || !phi_p || !phi_g || !phi_m || !phi_v || !x_samples || !r || (!pack && (!prior || !theta)) ||
+        (!pack && !stats_out) || !tail_part || !scalars) {
         set_error("vmp_svae_step_final: NULL argument");
         return VMP_E_BADARG;
     }
@@ -304,12 +318,28 @@ int vmp_svae_step_final(const float* dec_part, int dec_blocks, int dec_in, int d
     a.phi.g_mu = phi_g[0]; a.phi.g_Lraw = phi_g[1]; a.phi.g_piraw = phi_g[2]; a.phi.K = K; a.phi.L = L;
     a.partials = partials; a.nblk = nblk;
     blocks += (unsigned)K;
+    if (pack) {
+        // [moments (K, 2+L+L*L) | phi_gmm/mu_k, L_k, log_pi_k | encoder net | decoder net | elbo, rec, reg]: the parameter order of
+        // SVAETrainer.trainables() (experiments.py:160-181), as training.pack_exchange_buffer lays it out
+        const int SW = 2 + L + L * L;
+        double* o = xbuf + (size_t)K * SW;
+        a.phi_adam.gx[0] = o; o += K * L;
+        a.phi_adam.gx[1] = o; o += K * L * L;
+        a.phi_adam.gx[2] = o; o += K;
+        a.xnet[1] = o; o += a.net[1].red.PW;                 // encoder first
+        a.xnet[0] = o; o += a.net[0].red.PW;
+        a.xscal = o;
+        for (int t = 0; t < 3; ++t) a.phi_adam.p[t] = nullptr;
+        a.sa = SmallStatsArgs{x_samples, r, nullptr, xbuf, (int)N, L, K};
+        a.cvi.K = K; a.cvi.L = L;
+    } else {
     for (int t = 0; t < 5; ++t)
         if (!prior[t] || !theta[t]) { set_error("vmp_svae_step_final: prior / theta tensor %d: NULL pointer", t); return VMP_E_BADARG; }
     a.sa = SmallStatsArgs{x_samples, r, nullptr, stats_out, (int)N, L, K};
     a.cvi = CviArgs{stats_out, prior[0], prior[1], prior[2], prior[3], prior[4], theta[0], theta[1], theta[2], theta[3], theta[4],
                     theta_star ? theta_star[0] : nullptr, theta_star ? theta_star[1] : nullptr, theta_star ? theta_star[2] : nullptr,
                     theta_star ? theta_star[3] : nullptr, theta_star ? theta_star[4] : nullptr, rho_dev, rho, K, L};
+    }
     blocks += (unsigned)K;
     a.tail.part = const_cast<double*>(tail_part);
     a.tail.scal = scalars;
@@ -322,7 +352,49 @@ int vmp_svae_step_final(const float* dec_part, int dec_blocks, int dec_in, int d
 #define FIN_CALL(LL) case LL: hipLaunchKernelGGL((step_final_kernel<LL>), dim3(blocks), dim3(FIN_THREADS), 0, static_cast<hipStream_t>(stream), a); break
     switch (L) { FIN_CALL(1); FIN_CALL(2); FIN_CALL(3); FIN_CALL(4); FIN_CALL(5); FIN_CALL(6); FIN_CALL(7); default: FIN_CALL(8); }
 #undef FIN_CALL
-    return check_launch("vmp_svae_step_final");
+    return check_launch(what);
+}
+}  // namespace
+
+int vmp_svae_step_final(const float* dec_part, int dec_blocks, int dec_in, int dec_units, int dec_out, float* const* dec_p,
+                        float* const* dec_m, float* const* dec_v, float* const* dec_g, const float* enc_part, int enc_blocks,
+                        int enc_in, int enc_units, int enc_out, float* const* enc_p, float* const* enc_m, float* const* enc_v,
+                        float* const* enc_g, const float* partials, int nblk, const double* logpi, float* const* phi_p,
+                        float* const* phi_g, float* const* phi_m, float* const* phi_v, const float* x_samples, const float* r, int64_t N,
+                        const float* const* prior, float* const* theta, float* const* theta_star, const float* rho_dev, float rho, int K,
+                        int L, double* stats_out, const double* tail_part, int tail_n, int Dy, float* scalars, double beta1, double beta2,
+                        double eps, double lr_t, const float* lr_t_dev, void* stream) {
+    return step_final_impl("vmp_svae_step_final", nullptr, dec_part, dec_blocks, dec_in, dec_units, dec_out, dec_p, dec_m, dec_v, dec_g,
+                           enc_part, enc_blocks, enc_in, enc_units, enc_out, enc_p, enc_m, enc_v, enc_g, partials, nblk, logpi, phi_p, phi_g,
+                           phi_m, phi_v, x_samples, r, N, prior, theta, theta_star, rho_dev, rho, K, L, stats_out, tail_part, tail_n, Dy,
+                           scalars, beta1, beta2, eps, lr_t, lr_t_dev, stream);
+}
+
+// The closing launch of a DATA-PARALLEL minibatch step: the same block roles, but nothing is updated - this rank's moments, its 21
+// gradients and its three scalars go as doubles into xbuf [moments (K, 2+L+L*L) | phi_gmm (3 tensors) | encoder (9) | decoder (9) |
+// elbo, rec, reg], the packed buffer the step's one all-reduce sums (training.pack_exchange_buffer's layout; experiments.py:247-260);
+// vmp_svae_cvi_update and vmp_adam_step_packed follow the all-reduce.  The fp32 gradients are also left in *_g.
+int vmp_svae_step_pack(double* xbuf, size_t xbuf_doubles, const float* dec_part, int dec_blocks, int dec_in, int dec_units, int dec_out,
+                       float* const* dec_p, float* const* dec_g, const float* enc_part, int enc_blocks, int enc_in, int enc_units,
+                       int enc_out, float* const* enc_p, float* const* enc_g, const float* partials, int nblk, const double* logpi,
+                       float* const* phi_p, float* const* phi_g, const float* x_samples, const float* r, int64_t N, int K, int L,
+                       const double* tail_part, int tail_n, int Dy, float* scalars, void* stream) {
+    if (!xbuf) { set_error("vmp_svae_step_pack: NULL exchange buffer"); return VMP_E_BADARG; }
+    if (K < 1 || L < 1 || dec_in < 1 || dec_units < 1 || dec_out < 1 || enc_in < 1 || enc_units < 1 || enc_out < 1) {
+        set_error("vmp_svae_step_pack: bad sizes");
+        return VMP_E_DIM;
+    }
+    const size_t need = (size_t)K * (2 + L + L * L) + (size_t)K * L + (size_t)K * L * L + K +
+                        (size_t)vmp_decoder_param_words(enc_in, enc_units, enc_out) + (size_t)vmp_decoder_param_words(dec_in, dec_units, dec_out) + 3;
+    if (xbuf_doubles < need) {
+        set_error("vmp_svae_step_pack: exchange buffer too small (%zu < %zu doubles)", xbuf_doubles, need);
+        return VMP_E_WS;
+    }
+    // (Adam slots are not touched in this form: the parameter tensors stand in for the pointer checks)
+    return step_final_impl("vmp_svae_step_pack", xbuf, dec_part, dec_blocks, dec_in, dec_units, dec_out, dec_p, dec_p, dec_p, dec_g, enc_part,
+                           enc_blocks, enc_in, enc_units, enc_out, enc_p, enc_p, enc_p, enc_g, partials, nblk, logpi, phi_p, phi_g, phi_p,
+                           phi_p, x_samples, r, N, nullptr, nullptr, nullptr, nullptr, 0.f, K, L, nullptr, tail_part, tail_n, Dy, scalars,
+                           0.9, 0.999, 1e-8, 0.0, nullptr, stream);
 }
 
 size_t vmp_svae_elbo_tail_workspace_bytes(void) { return tail_workspace_bytes(); }

@@ -85,13 +85,16 @@ __device__ __forceinline__ void cvi_element(const CviArgs& a, const double* __re
 
 // M-step moments of a small batch AND the CVI update of component k by one block of >= SMALL_STATS_GROUPS * 80 threads
 // (small_stats_component, vmp_common.h): sums component k's moments, publishes them, updates theta_k from the copy in LDS.
-__device__ __forceinline__ void stats_cvi_body(const SmallStatsArgs& sa, const CviArgs& a, const int k, double (*part)[80], double* st) {
+// (do_cvi = false: the moments only - a data-parallel step sums them over the ranks first)
+__device__ __forceinline__ void stats_cvi_body(const SmallStatsArgs& sa, const CviArgs& a, const int k, double (*part)[80], double* st,
+                                               const bool do_cvi = true) {
     const int L = a.L, SW = 2 + L + L * L, i = threadIdx.x % 80;
     const double t = small_stats_component(sa, k, part);
     if (threadIdx.x < 80 && i < SW) {
         st[i] = t;
         sa.stats[(long long)k * SW + i] = t;
     }
+    if (!do_cvi) return;
     __syncthreads();
     const float rho = a.rho_dev ? *a.rho_dev : a.rho;
     for (int f = threadIdx.x; f < L * L + L + 3; f += blockDim.x) cvi_element(a, st, k, f, rho);

@@ -273,13 +273,16 @@ class SVAETrainer(object):
         step (_step_exchange) and the identical update every rank applies (_step_back) - so that a data-parallel step can be
         captured as two HIP graphs around its collective (GraphedSVAEStep)."""
         if self._direct_ok(y, noise, z_draws, chunk, u):
-            return self._step_direct(y, _dev_scalars)
-        ctx = self._step_front(y, noise, z_draws, chunk, u, _dev_scalars)
+            if self._world() == 1:
+                return self._step_direct(y, _dev_scalars)
+            ctx = self._step_direct(y, _dev_scalars, pack=True)       # data-parallel: this rank's rows, up to the packed exchange buffer
+        else:
+            ctx = self._step_front(y, noise, z_draws, chunk, u, _dev_scalars)
         self._step_exchange(ctx)
         return self._step_back(ctx, _dev_scalars)
 
     def _direct_ok(self, y, noise, z_draws, chunk, u):
-        """Whether _step_direct covers this call: GMM-SVAE, one process, the whole minibatch at once (<= 512 rows, the minibatch
+        """Whether _step_direct covers this call: GMM-SVAE, this process's whole minibatch (shard) at once (<= 512 rows, the minibatch
         forms of the E-step kernels), noise drawn in the kernels, fused encoder / decoder."""
         if not self.direct_step or self.smm or self.reference_call_order or not self.fused_decoder or self.rng != 'philox':
             return False
@@ -288,7 +291,7 @@ class SVAETrainer(object):
         if not (torch.is_tensor(y) and y.is_cuda and y.dtype == torch.float32 and y.dim() == 2):
             return False
         rows, Dy = y.shape
-        if (chunk is not None and rows > int(chunk)) or not (0 < rows <= _svae_ops.STATS_CVI_MAX_ROWS) or self._world() != 1:
+        if (chunk is not None and rows > int(chunk)) or not (0 < rows <= _svae_ops.STATS_CVI_MAX_ROWS):
             return False
         if not (vae._fused_mlp_eligible(Dy, self.encoder_layers) and vae.fused_decoder_eligible(self.L, self.decoder_layers)):
             return False
@@ -296,13 +299,15 @@ class SVAETrainer(object):
         return bool(lib.vmp_svae_rng_in_kernel(self.K, self.L, self.S) and lib.vmp_svae_bwd_tail_applies(rows, self.K, self.L, self.S))
 
     @torch.no_grad()
-    def _step_direct(self, y, _dev_scalars=None):
+    def _step_direct(self, y, _dev_scalars=None, pack=False):
         """experiments.py:196-267 for one whole minibatch as SIX launches, no autograd graph (include/vmp_hip.h, "The minibatch
         training step"): encoder + recognition / theta prep, E-step (+ sub-sample), decoder value + gradients, ELBO tail + E-step
         backward, encoder backward, and one closing launch (partial rows -> phi_gmm gradients, both parameter reductions, Adam on
         the 21 tensors, M-step moments + CVI update, ELBO scalars).  Same kernels / device functions as the autograd step: every
         gradient, moment and parameter it leaves is bit-identical to that step's (tests/test_svae_gpu.py); the three ELBO scalars
-        are summed per tile (fp64) and agree to fp32 rounding."""
+        are summed per tile (fp64) and agree to fp32 rounding.
+        pack=True (several ranks): the closing launch updates nothing - moments, gradients and scalars go into the packed fp64 exchange
+        buffer (vmp_svae_step_pack) and the context of _step_exchange / _step_back is returned."""
         import ctypes
         lib, dev = L.lib(), y.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -374,6 +379,20 @@ class SVAETrainer(object):
         stats = torch.empty(K, 2 + Ld + Ld * Ld, dtype=torch.float64, device=dev)
         star = [torch.empty_like(t) for t in self.theta]
         scal = torch.empty(3, **f32)
+        if pack:
+            SW = 2 + Ld + Ld * Ld
+            sizes = [p.numel() for p in params]
+            goffs, o = [], K * SW
+            for n_ in sizes:
+                goffs.append(o)
+                o += n_
+            buf = torch.empty(o + 3, dtype=torch.float64, device=dev)
+            L.check(lib.vmp_svae_step_pack(L.ptr(buf), buf.numel(), L.ptr(ws_dec), nb_dec, Ld, U, Dy, arr(dec), arr(g_dec), L.ptr(ws_enc),
+                                           nb_enc, Dy, U, Ld, arr(enc), arr(g_enc), L.ptr(partials), nt, L.ptr(logpi), arr(phi), arr(g_phi),
+                                           L.ptr(xs), L.ptr(r), N, K, Ld, L.ptr(tail_part), nt, Dy, L.ptr(scal), st), 'vmp_svae_step_pack')
+            return dict(world=self._world(), names=names, params=params, grads=g_phi + g_enc + g_dec, stats=buf[:K * SW].view(K, SW),
+                        fused_m=False, keep=dict(log_z=lz, x_samples=xs, x_k=x), r_whole=r, scal=(scal[0], scal[1], scal[2]), buf=buf,
+                        goffs=goffs, mom_whole=None)
         if lr_dev is None:
             opt.t += 1
             lr_t = opt.lr_t(opt.t)
@@ -614,7 +633,10 @@ class GraphedSVAEStep(object):
             # the packed Adam step every rank applies identically (_step_back).  The buffer and everything graph 2 reads live in
             # the shared graph pool.  (Round 4 fell back to the eager step here: 0.87 ms instead of 0.12 ms at minibatch 64.)
             with torch.cuda.graph(self.graph, stream=cap_stream):
-                self._ctx = tr._step_front(self.y, self.noise, None, None, self.u, dev_scalars)
+                if tr._direct_ok(self.y, self.noise, None, None, self.u):
+                    self._ctx = tr._step_direct(self.y, dev_scalars, pack=True)
+                else:
+                    self._ctx = tr._step_front(self.y, self.noise, None, None, self.u, dev_scalars)
             self.graph_back = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_back, stream=cap_stream, pool=self.graph.pool()):
                 self.out = tr._step_back(self._ctx, dev_scalars)
