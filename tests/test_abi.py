@@ -81,6 +81,43 @@ def test_round6_entry_points_validate_on_the_host():
     assert lib.vmp_mix_stats_ws_accurate(P, P, None, None, 100, 8, 16, P, 8, None) != 0 and b'workspace' in lib.vmp_last_error()
 
 
+def test_minibatch_step_entry_points_validate_on_the_host():
+    """Round 6, the six-launch minibatch step (include/vmp_hip.h "The minibatch training step"): geometry queries and argument checks
+    are host logic - every call below fails its checks before any launch."""
+    import ctypes
+    import vmp_for_svae_amd as V
+    lib = V._lib.lib()
+    P = ctypes.c_void_p(64)
+    arr = (ctypes.c_void_p * 9)(*[64] * 9)
+    assert lib.vmp_decoder_bwd_blocks(6400) == 100 and lib.vmp_decoder_bwd_blocks(64) == 1 and lib.vmp_decoder_bwd_blocks(0) == 0
+    assert lib.vmp_svae_bwd_tail_applies(64, 10, 8, 10) == 1 and lib.vmp_svae_bwd_tail_applies(64, 10, 8, 16) == 1
+    assert lib.vmp_svae_bwd_tail_applies(64, 10, 8, 18) == 0 and lib.vmp_svae_bwd_tail_applies(10**6, 16, 8, 10) == 0
+    assert lib.vmp_svae_bwd_tail_applies(0, 10, 8, 10) == 0
+    rc = lib.vmp_svae_estep_bwd_tail(*([P] * 11), -1.0, P, 10**6, 16, 8, 10, P, P, P, 1 << 30, P, P, 1 << 20, None)
+    assert rc != 0 and b'minibatch form' in lib.vmp_last_error()
+    rc = lib.vmp_svae_estep_bwd_tail(*([P] * 11), -1.0, P, 64, 10, 8, 10, P, P, P, 16, P, P, 1 << 20, None)
+    assert rc != 0 and b'too small' in lib.vmp_last_error()
+    rc = lib.vmp_svae_estep_bwd_tail(*([P] * 11), 0.0, P, 64, 10, 8, 10, P, P, P, 1 << 20, P, P, 1 << 20, None)
+    assert rc != 0 and b'sigma' in lib.vmp_last_error()
+    assert lib.vmp_decoder_elbo_lazy(P, P, P, 0.0, *([P] * 9), 64, 10, 10, 8, 6, 50, P, P, P, 1 << 30, None) != 0            # sigma == 0
+    assert lib.vmp_decoder_elbo_lazy(P, P, P, -1.0, *([P] * 9), 64, 10, 10, 8, 6, 50, P, P, P, 16, None) != 0 and b'workspace' in lib.vmp_last_error()
+    assert lib.vmp_mlp_gauss_head_bwd_lazy(P, P, P, -0.5, *([P] * 9), 64, 6, 8, 50, None, P, 16, None) != 0 and b'workspace' in lib.vmp_last_error()
+    assert lib.vmp_svae_bwd_reduce_prep(P, 0, P, P, P, P, 10, 8, P, P, P, None) != 0                                       # nblk < 1
+    assert lib.vmp_svae_bwd_reduce_prep(P, 4, P, P, P, None, 10, 8, P, P, P, None) != 0                                    # logpi missing
+    rc = lib.vmp_mlp_gauss_head_fwd_prep(*([P] * 10), 64, 6, 8, 50, -0.5, P, P, *([P] * 8), 10, *([P] * 7), P, 0, None, None, None)
+    assert rc != 0 and b'scalar table' in lib.vmp_last_error()                                                              # a table without rows
+    rc = lib.vmp_mlp_gauss_head_fwd_prep(*([P] * 10), 64, 6, 9, 50, -0.5, P, P, *([P] * 8), 10, *([P] * 7), None, 0, None, None, None)
+    assert rc != 0                                                                                                          # latent size 9
+    rc = lib.vmp_svae_step_inputs(ctypes.c_void_p(68), 1, 0.1, 0.1, None, None, 0, None)
+    assert rc != 0 and b'aligned' in lib.vmp_last_error()
+    fin = lambda N, nblk: lib.vmp_svae_step_final(P, 100, 8, 50, 6, arr, arr, arr, arr, P, 1, 6, 50, 8, arr, arr, arr, arr, P, nblk, P, arr, arr, arr, arr,
+                                                  P, P, N, arr, arr, None, None, 0.2, 10, 8, P, P, 11, 6, P, 0.9, 0.999, 1e-8, 1e-3, None, None)
+    assert fin(513, 11) != 0 and b'range' in lib.vmp_last_error()                                                           # N > 512
+    assert fin(64, 0) != 0                                                                                                  # no partial rows
+    rc = lib.vmp_svae_step_pack(P, 10, P, 100, 8, 50, 6, arr, arr, P, 1, 6, 50, 8, arr, arr, P, 11, P, arr, arr, P, P, 64, 10, 8, P, 11, 6, P, None)
+    assert rc != 0 and b'too small' in lib.vmp_last_error()
+
+
 def test_no_cpu_fallback():
     import vmp_for_svae_amd as V
     from vmp_for_svae_amd.models import gmm, _mix

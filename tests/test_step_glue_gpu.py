@@ -233,3 +233,130 @@ def test_gauss_head_scale_inside_the_kernels():
         res.append([o1, o2] + list(gr))
     for a, b in zip(*res):
         assert rel(b, a) < 3e-6
+
+
+@pytest.mark.parametrize('N,K,Ld,S', [(64, 10, 8, 10), (37, 7, 4, 8), (5, 3, 2, 4), (100, 16, 8, 16), (512, 8, 6, 10), (1, 1, 1, 1)])
+def test_bwd_tail_equals_tail_plus_backward(N, K, Ld, S):
+    """Round 6: vmp_svae_estep_bwd_tail (the ELBO's scalar tail on a wave of the minibatch-form E-step backward; S = 16: no spare wave, wave
+    0 runs it) against vmp_svae_elbo_tail followed by vmp_svae_estep_bwd_n on the same inputs: gradients, partial rows and r
+    BIT-identical (dLoss/dlog_z, dLoss/dT' never reach memory in the fused form); the three scalars from the per-tile fp64 sums."""
+    import vmp_for_svae_amd as V
+    L = V._lib
+    lib = L.lib()
+    Dy = 6
+    f32 = dict(dtype=torch.float32, device='cuda')
+    g = torch.Generator(device='cuda').manual_seed(N * 7 + K)
+    rn = lambda *s: torch.randn(*s, generator=g, **f32)
+    x, Gx = rn(N, K, S, Ld), rn(N, K, S, Ld) * 0.3
+    lz = torch.log_softmax(rn(N, K) * 2, -1)
+    Tp, ll = rn(N, K) * 3 - 5, rn(N, K, S) * 3 + 8
+    eta1, eta2d = rn(N, Ld), -torch.rand(N, Ld, generator=g, **f32) - 0.5
+    hk, A_ = rn(K, Ld), rn(K, Ld, Ld) * 0.4
+    Pk = (A_ @ A_.transpose(1, 2) + torch.eye(Ld, **f32)).contiguous()
+    bias, mk, Wk = rn(K), rn(K, Ld), torch.tril(rn(K, Ld, Ld)).contiguous()
+    assert lib.vmp_svae_bwd_tail_applies(N, K, Ld, S) == 1
+    scal = torch.empty(3, **f32)
+    g_lz, g_Tp, r = torch.empty(N, K, **f32), torch.empty(N, K, **f32), torch.empty(N, K, **f32)
+    ws = torch.empty(lib.vmp_svae_elbo_tail_workspace_bytes(), dtype=torch.uint8, device='cuda')
+    L.check(lib.vmp_svae_elbo_tail(L.ptr(lz), L.ptr(Tp), L.ptr(ll), N, K, S, Dy, -1.0, L.ptr(scal), L.ptr(g_lz), L.ptr(g_Tp), L.ptr(r), L.ptr(ws),
+                                   ws.numel(), L.stream()), 'tail')
+    nt, PW = lib.vmp_svae_bwd_blocks_for(N, K, Ld, S, 0), lib.vmp_svae_bwd_partial_words(Ld)
+    assert nt == (N + 64 // K - 1) // (64 // K)
+    a1, a2, ap = torch.empty(N, Ld, **f32), torch.empty(N, Ld, **f32), torch.full((nt, K, PW), float('nan'), **f32)
+    L.check(lib.vmp_svae_estep_bwd_n(L.ptr(eta1), L.ptr(eta2d), L.ptr(hk), L.ptr(Pk), L.ptr(bias), L.ptr(mk), L.ptr(Wk), None, L.ptr(x), L.ptr(lz),
+                                     L.ptr(Gx), L.ptr(g_lz), L.ptr(g_Tp), N, K, Ld, S, L.ptr(a1), L.ptr(a2), L.ptr(ap), ap.numel() * 4, nt, L.stream()),
+            'bwd_n')
+    b1, b2, bp = torch.empty(N, Ld, **f32), torch.empty(N, Ld, **f32), torch.full((nt, K, PW), float('nan'), **f32)
+    r2, tp = torch.full((N, K), float('nan'), **f32), torch.full((nt, 2), float('nan'), dtype=torch.float64, device='cuda')
+    L.check(lib.vmp_svae_estep_bwd_tail(L.ptr(eta1), L.ptr(eta2d), L.ptr(hk), L.ptr(Pk), L.ptr(bias), L.ptr(mk), L.ptr(Wk), L.ptr(x), L.ptr(lz),
+                                        L.ptr(Tp), L.ptr(ll), -1.0, L.ptr(Gx), N, K, Ld, S, L.ptr(b1), L.ptr(b2), L.ptr(bp), bp.numel() * 4, L.ptr(r2),
+                                        L.ptr(tp), tp.numel() * 8, L.stream()), 'bwd_tail')
+    assert torch.equal(a1, b1) and torch.equal(a2, b2) and torch.equal(ap, bp) and torch.equal(r, r2)
+    tot = tp.sum(0)
+    rec = -tot[0].item() - N * Dy * 0.5 * math.log(2 * math.pi)
+    want = scal.double().cpu()
+    got = torch.tensor([rec - tot[1].item(), rec, tot[1].item()], dtype=torch.float64)
+    assert ((got - want).abs().max() / max(abs(want[1].item()), abs(want[2].item()))).item() < 2e-7
+
+
+@pytest.mark.parametrize('K,Ld,nblk', [(10, 8, 11), (16, 8, 1), (7, 4, 70), (3, 2, 300), (5, 5, 17)])
+def test_bwd_reduce_prep_equals_reduce_then_prep_backward(K, Ld, nblk):
+    """Round 6: vmp_svae_bwd_reduce_prep (block k sums component k's partial rows and differentiates the recognition unpacking on them;
+    log softmax(pi) from the forward's vmp_svae_prep_fwd2) against vmp_svae_bwd_reduce + vmp_svae_phi_prep_bwd: bit-identical."""
+    import vmp_for_svae_amd as V
+    L = V._lib
+    lib = L.lib()
+    f32 = dict(dtype=torch.float32, device='cuda')
+    g = torch.Generator(device='cuda').manual_seed(K * 31 + nblk)
+    rn = lambda *s: torch.randn(*s, generator=g, **f32)
+    PW = lib.vmp_svae_bwd_partial_words(Ld)
+    partials = rn(nblk, K, PW)
+    mu, Lraw, pi = rn(K, Ld), rn(K, Ld, Ld), rn(K)
+    th = [torch.rand(K, generator=g, **f32) + 0.5, None, rn(K, Ld), torch.rand(K, generator=g, **f32) + 1.0, torch.rand(K, generator=g, **f32) + Ld + 3.0]
+    A_ = rn(K, Ld, Ld)
+    th[1] = (A_ @ A_.transpose(1, 2) + Ld * torch.eye(Ld, **f32) + th[2].unsqueeze(2) * th[2].unsqueeze(1) / th[3].view(K, 1, 1)).contiguous()
+    Lk, P, bias = torch.empty(K, Ld, Ld, **f32), torch.empty(K, Ld, Ld, **f32), torch.empty(K, **f32)
+    m, W, kap = torch.empty(K, Ld, **f32), torch.empty(K, Ld, Ld, **f32), torch.empty(K, **f32)
+    logpi = torch.empty(K, dtype=torch.float64, device='cuda')
+    L.check(lib.vmp_svae_prep_fwd2(L.ptr(mu), L.ptr(Lraw), L.ptr(pi), *[L.ptr(t) for t in th], K, Ld, L.ptr(Lk), L.ptr(P), L.ptr(bias), L.ptr(m),
+                                   L.ptr(W), L.ptr(kap), L.ptr(logpi), L.stream()), 'prep_fwd2')
+    assert torch.allclose(logpi, torch.log_softmax(pi.double(), 0), rtol=0, atol=1e-14)
+    # the forward itself equals the launch without the extra output
+    P0, b0 = torch.empty_like(P), torch.empty_like(bias)
+    L.check(lib.vmp_svae_prep_fwd(L.ptr(mu), L.ptr(Lraw), L.ptr(pi), *[L.ptr(t) for t in th], K, Ld, L.ptr(torch.empty_like(Lk)), L.ptr(P0), L.ptr(b0),
+                                  L.ptr(torch.empty_like(m)), L.ptr(torch.empty_like(W)), L.ptr(torch.empty_like(kap)), L.stream()), 'prep_fwd')
+    assert torch.equal(P, P0) and torch.equal(bias, b0)
+    g_hk, g_P, g_b = torch.empty(K, Ld, **f32), torch.empty(K, Ld, Ld, **f32), torch.empty(K, **f32)
+    L.check(lib.vmp_svae_bwd_reduce(L.ptr(partials), nblk, K, Ld, L.ptr(g_hk), L.ptr(g_P), L.ptr(g_b), None, None, None, L.stream()), 'reduce')
+    w = [torch.empty_like(mu), torch.empty_like(Lraw), torch.empty_like(pi)]
+    L.check(lib.vmp_svae_phi_prep_bwd(L.ptr(mu), L.ptr(Lraw), L.ptr(pi), L.ptr(g_hk), L.ptr(g_P), L.ptr(g_b), K, Ld, *[L.ptr(t) for t in w],
+                                      L.stream()), 'prep_bwd')
+    o = [torch.full_like(mu, float('nan')), torch.full_like(Lraw, float('nan')), torch.full_like(pi, float('nan'))]
+    L.check(lib.vmp_svae_bwd_reduce_prep(L.ptr(partials), nblk, L.ptr(mu), L.ptr(Lraw), L.ptr(pi), L.ptr(logpi), K, Ld, *[L.ptr(t) for t in o],
+                                         L.stream()), 'reduce_prep')
+    for a, b in zip(o, w):
+        assert torch.equal(a, b)
+
+
+def test_step_inputs_and_the_first_launch_with_a_scalar_table():
+    """vmp_svae_step_inputs (scalars + minibatch copy in one launch) and vmp_mlp_gauss_head_fwd_prep (encoder forward + recognition /
+    theta prep + row `counter` of the scalar table -> the step's 16 bytes, counter advanced): against the stand-alone launches."""
+    import vmp_for_svae_amd as V
+    L = V._lib
+    lib = L.lib()
+    f32 = dict(dtype=torch.float32, device='cuda')
+    g = torch.Generator(device='cuda').manual_seed(9)
+    rn = lambda *s: torch.randn(*s, generator=g, **f32)
+    dst = torch.zeros(16, dtype=torch.uint8, device='cuda')
+    src, y = rn(1000, 7), torch.zeros(1000, 7, **f32)
+    L.check(lib.vmp_svae_step_inputs(L.ptr(dst), 0xDEADBEEF12345678, 0.125, 3e-4, L.ptr(src), L.ptr(y), src.numel(), L.stream()), 'step_inputs')
+    assert torch.equal(y, src)
+    assert dst[:8].view(torch.int64).item() == 0xDEADBEEF12345678 - (1 << 64)
+    assert dst[8:12].view(torch.float32).item() == 0.125 and dst[12:].view(torch.float32).item() == np.float32(3e-4)
+    for N, Dy, Ld, U, K in ((64, 6, 8, 50, 10), (5, 3, 2, 16, 3), (300, 8, 4, 64, 16)):
+        enc = [rn(Dy, U) * 0.3, rn(U) * 0.1, rn(U, U) * 0.2, rn(U) * 0.1, rn(U, 2 * Ld) * 0.2, rn(2 * Ld) * 0.1, rn(Dy, Ld) * 0.3, rn(Ld) * 0.1, rn(Ld) * 0.1]
+        yy = rn(N, Dy)
+        mu, Lraw, pi = rn(K, Ld), rn(K, Ld, Ld), rn(K)
+        th = [torch.rand(K, generator=g, **f32) + 0.5, None, rn(K, Ld), torch.rand(K, generator=g, **f32) + 1.0, torch.rand(K, generator=g, **f32) + Ld + 3.0]
+        A_ = rn(K, Ld, Ld)
+        th[1] = (A_ @ A_.transpose(1, 2) + Ld * torch.eye(Ld, **f32) + th[2].unsqueeze(2) * th[2].unsqueeze(1) / th[3].view(K, 1, 1)).contiguous()
+        mk = lambda: (torch.empty(N, Ld, **f32), torch.empty(N, Ld, **f32), torch.empty(K, Ld, Ld, **f32), torch.empty(K, Ld, Ld, **f32),
+                      torch.empty(K, **f32), torch.empty(K, Ld, **f32), torch.empty(K, Ld, Ld, **f32), torch.empty(K, **f32),
+                      torch.empty(K, dtype=torch.float64, device='cuda'))
+        a = mk()
+        L.check(lib.vmp_mlp_gauss_head_fwd(L.ptr(yy), *[L.ptr(t) for t in enc], N, Dy, Ld, U, -0.5, L.ptr(a[0]), L.ptr(a[1]), L.stream()), 'enc')
+        L.check(lib.vmp_svae_prep_fwd2(L.ptr(mu), L.ptr(Lraw), L.ptr(pi), *[L.ptr(t) for t in th], K, Ld, *[L.ptr(t) for t in a[2:]], L.stream()), 'prep')
+        b = mk()
+        rows = 5
+        table = torch.zeros(rows, 2, dtype=torch.int64, device='cuda')
+        table[:, 0] = torch.arange(100, 100 + rows, device='cuda')
+        table[:, 1] = torch.arange(7, 7 + rows, device='cuda') << 32
+        counter = torch.full((1,), 3, dtype=torch.int64, device='cuda')
+        d16 = torch.zeros(2, dtype=torch.int64, device='cuda')
+        for rep in range(3):                                   # rows 3, 4 and - the counter past the table - the last row again
+            L.check(lib.vmp_mlp_gauss_head_fwd_prep(L.ptr(yy), *[L.ptr(t) for t in enc], N, Dy, Ld, U, -0.5, L.ptr(b[0]), L.ptr(b[1]), L.ptr(mu), L.ptr(Lraw),
+                                                    L.ptr(pi), *[L.ptr(t) for t in th], K, *[L.ptr(t) for t in b[2:]], L.ptr(table), rows, L.ptr(counter),
+                                                    L.ptr(d16), L.stream()), 'enc_prep')
+            assert counter.item() == 4 + rep and d16[0].item() == 100 + min(3 + rep, rows - 1) and d16[1].item() == (7 + min(3 + rep, rows - 1)) << 32
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
