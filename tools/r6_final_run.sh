@@ -38,7 +38,7 @@ python bench.py --workload t3 --steps 5 --warmup 3 > $O/bench_t3.json 2>> $O/ben
 python bench.py --workload t3 --smm --steps 5 --warmup 3 > $O/bench_t3_smm.json 2>> $O/bench.err
 VARIANTS="16_0 10_0 16_1 10_1" bash tools/r4_t2_pmc.sh
 for v in 16_0 10_0 16_1 10_1; do mv gpurun_out/r4_t2_pmc_$v.txt $O/t2_pmc_$v.txt; done
-bash tools/kseq.sh r06mb step_scalars tools/r5_mb_graph.py > $O/minibatch64_kernel_seq.txt 2>&1
+bash tools/kseq.sh r06mb enc_prep tools/r5_mb_graph.py > $O/minibatch64_direct_kernel_seq.txt 2>&1     # (the mid-round 13-node sequence: profiles/r06_t3_minibatch64_kernel_seq.txt)
 python tools/ubench/hbm_rw.py > $O/hbm_rw.txt 2>&1
 for i in 1 2; do python3 tools/dec_perf.py 262144 2>&1 | tail -1; done > $O/dec_perf.txt
 grep "pass_xdl\|pass_kernel\|finalize" $O/headline_kernel_stats.csv | cut -c1-200
