@@ -80,11 +80,44 @@ __global__ __launch_bounds__(512) void k16(const char* __restrict__ a, const cha
     }
     if (acc.x + acc.y + acc.z + acc.w + w == 12345.678f) g_sink = acc.x;
 }
+// The same three patterns through the LDS-DMA path the ring kernel uses (global_load_lds_dwordx4: 16 bytes per lane straight into LDS),
+// 16 KB per wave in flight: a group of 16 instructions, s_waitcnt vmcnt(0), next group.
+template <int MODE>
+__global__ __launch_bounds__(512) void kdma(const char* __restrict__ a, const char* __restrict__ b, long long ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    float* ring = lds + wave * 4096;
+    for (long long t = (long long)blockIdx.x * nw + wave; t < ntiles; t += (long long)gridDim.x * nw) {
+        const char* ta = a + t * TILE;
+        const char* tb = b + t * TILE;
+#pragma unroll
+        for (int grp = 0; grp < 3; ++grp) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int it = grp * 8 + i;
+                if (it >= 20) continue;
+                int off;
+                if (MODE == 0) off = it * 1024 + lane * 16;
+                else if (MODE == 1) { const int p = it >> 2, q = it & 3; off = (16 * q + (lane >> 2)) * CELL + p * 64 + (lane & 3) * 16; }
+                else { const int j = it >> 2, q = it & 3; off = (8 * q + (lane >> 3)) * 640 + j * 128 + (lane & 7) * 16; }
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ta + off),
+                                                 (__attribute__((address_space(3))) void*)(ring + i * 256), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + off),
+                                                 (__attribute__((address_space(3))) void*)(ring + 2048 + i * 256), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    if (ring[lane] == 12345.678f) g_sink = ring[lane];
+}
 int main() {
     const long long ntiles = 250000;
     char *a, *b;
     hipMalloc(&a, ntiles * TILE); hipMalloc(&b, ntiles * TILE);
     hipMemset(a, 0, ntiles * TILE); hipMemset(b, 0, ntiles * TILE);
+    hipFuncSetAttribute((const void*)kdma<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
+    hipFuncSetAttribute((const void*)kdma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
+    hipFuncSetAttribute((const void*)kdma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const char* names[3] = {"seq   ", "seg64 ", "seg128"};
     for (int blocks : {256, 512, 1024}) for (int mode = 0; mode < 3; ++mode) {
@@ -98,6 +131,18 @@ int main() {
             float ms; hipEventElapsedTime(&ms, e0, e1); if (rep && ms < best) best = ms;
         }
         printf("%4d blocks x 8 waves  %s : %.3f ms  %.0f GB/s\n", blocks, names[mode], best, 2.0 * ntiles * TILE / (best * 1e-3) / 1e9);
+    }
+    for (int mode = 0; mode < 3; ++mode) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 5; ++rep) {
+            hipEventRecord(e0);
+            if (mode == 0) hipLaunchKernelGGL(kdma<0>, dim3(256), dim3(512), 8 * 16384, 0, a, b, ntiles);
+            if (mode == 1) hipLaunchKernelGGL(kdma<1>, dim3(256), dim3(512), 8 * 16384, 0, a, b, ntiles);
+            if (mode == 2) hipLaunchKernelGGL(kdma<2>, dim3(256), dim3(512), 8 * 16384, 0, a, b, ntiles);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); if (rep && ms < best) best = ms;
+        }
+        printf("LDS-DMA (global_load_lds_dwordx4), 16 KB per wave in flight  %s : %.3f ms  %.0f GB/s\n", names[mode], best, 2.0 * ntiles * TILE / (best * 1e-3) / 1e9);
     }
     for (int work : {0, 400, 800}) for (int mode = 0; mode < 3; ++mode) {
         float best = 1e9f;
