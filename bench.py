@@ -402,12 +402,28 @@ def bench_minibatch(N, K, Ld, Dy, S, U, dev, steps=200, cpu=True):
     torch.cuda.synchronize()
     resident = (time.perf_counter() - t0) / steps
     assert torch.isfinite(out['elbo'])
+    # four consecutive steps per replay (GraphedSVAEStep(steps_per_replay=4): step i reads minibatch i of the static input and its own
+    # row of the scalar table - the same four steps the eager trainer takes); the four minibatches are another device tensor, copied in
+    # with one launch per replay
+    y4 = torch.randn(4, N, Dy, device=dev, generator=g) * 2
+    gs4 = GraphedSVAEStep(tr, y, steps_per_replay=4)
+    for _ in range(5):
+        gs4(y4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps // 4):
+        outs = gs4(y4)
+    torch.cuda.synchronize()
+    graphed4 = (time.perf_counter() - t0) / (4 * (steps // 4))
+    assert all(torch.isfinite(o['elbo']) for o in outs)
     res = {'config': 'T3 svae-train minibatch N=%d, K=%d, L=%d, Dy=%d, S=%d, U=%d' % (N, K, Ld, Dy, S, U),
            'eager_steps_per_sec': 1.0 / eager, 'eager_ms_per_step': eager * 1e3,
            'graphed_steps_per_sec': 1.0 / graphed, 'graphed_ms_per_step': graphed * 1e3,
            'graphed_input_resident_ms_per_step': resident * 1e3,
+           'graphed_4_steps_per_replay_ms_per_step': graphed4 * 1e3,
            'graphed_note': 'graphed: the minibatch is another device tensor, copied into the static input per call (one eager copy + '
-                           'the replay); input_resident: it already sits there (replay only)'}
+                           'the replay); input_resident: it already sits there (replay only); 4_steps_per_replay: four consecutive '
+                           'steps in one graph, their four minibatches copied in by one launch per replay'}
     if cpu:
         from oracle import nets, svae_ref, train_ref
         # tiny tensors: more than a few threads only adds synchronisation (256 threads: ~30 s per step); the fastest

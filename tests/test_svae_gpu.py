@@ -573,6 +573,39 @@ def test_graphed_step_scalar_table_refills_and_follows_the_trainer():
         assert torch.equal(a, b)
 
 
+def test_graphed_multi_step_replay_equals_eager_steps():
+    """Round 6: GraphedSVAEStep(steps_per_replay=4) captures FOUR consecutive training steps in one graph (step i reads minibatch i of the
+    static input and the next row of the scalar table): two replays == eight eager steps, every parameter / Adam slot / theta tensor and
+    all eight ELBOs bit-identical; an eager step between the replays keeps the table aligned."""
+    from vmp_for_svae_amd.models import vae
+    from vmp_for_svae_amd.training import SVAETrainer, GraphedSVAEStep
+    N, K, Ld, U, Dy, S = 64, 10, 8, 50, 6, 10
+    g = torch.Generator(device='cuda').manual_seed(123)
+    ys = torch.randn(9, N, Dy, device='cuda', generator=g) * 2
+
+    def mk():
+        vae.reset_variables()
+        return SVAETrainer(K, Ld, U, Dy, nb_samples=S, lr=3e-3, lrcvi=0.2, decay_rate=0.9, stddev_init_nn=0.1, seed=5)
+    tr = mk()
+    want_elbo = [tr.step(ys[i])['elbo'].item() for i in range(9)]
+    want = [p.detach().clone() for p in tr.trainables()[1]] + [t.clone() for t in tr.theta] + [t.clone() for t in tr.opt.m + tr.opt.v]
+    tr2 = mk()
+    gs = GraphedSVAEStep(tr2, ys[0], steps_per_replay=4)
+    got = [o['elbo'].item() for o in gs(ys[0:4])]
+    got.append(tr2.step(ys[4])['elbo'].item())                        # an eager step in between
+    gs.ys.copy_(ys[5:9])
+    outs = gs(gs.ys)                                                   # minibatches already in the static input
+    got += [o['elbo'].item() for o in outs]
+    assert [o['lrcvi'] for o in outs] == [0.2 * 0.9 ** ((5 + i) / 1000.0) for i in range(4)]
+    assert tr2.global_step == 9 and tr2.opt.t == 9
+    assert got == want_elbo
+    have = [p.detach() for p in tr2.trainables()[1]] + list(tr2.theta) + tr2.opt.m + tr2.opt.v
+    for a, b in zip(have, want):
+        assert torch.equal(a, b)
+    with pytest.raises(Exception):
+        GraphedSVAEStep(SVAETrainer(K, Ld, U, Dy, nb_samples=S, rng='torch'), ys[0], steps_per_replay=2)   # no table mode: refused
+
+
 def test_sample_x_per_comp_standalone_matches_fused(golden):
     """svae.sample_x_per_comp (svae.py:95-119) on the materialised phi_tilde reproduces the samples of the fused E-step
     kernel and the reference's x_k."""

@@ -549,15 +549,24 @@ class GraphedSVAEStep(object):
 
     TABLE_ROWS = 1024
 
-    def __init__(self, trainer, y_example, warmup=3):
-        """(Parallel graph branches on side streams - noise generator / recognition prep beside the encoder, CVI beside Adam - were
+    def __init__(self, trainer, y_example, warmup=3, steps_per_replay=1):
+        """steps_per_replay = n > 1 (round 6; needs the table mode below: the direct kernel sequence of a single-process GMM step on
+        in-kernel noise): n CONSECUTIVE training steps are captured in one graph - step i reads minibatch i of the static input
+        self.ys (n, N, Dy) and row `counter + i` of the scalar table, exactly the n steps the eager trainer would take - and a call
+        takes the n minibatches, replays once and returns the n steps' outputs.  The ~5 us a replay costs besides its kernels (and the
+        copy of the minibatches, one launch for all n) are paid once per n steps.
+        (Parallel graph branches on side streams - noise generator / recognition prep beside the encoder, CVI beside Adam - were
         built and measured in round 5: bit-identical and 42 % SLOWER, a cross-stream edge of a HIP graph costs ~6 us on this runtime
         (profiles/r05_minibatch_fork_ab.txt); removed in round 6.)"""
         tr = self.tr = trainer
         dev = tr.device
         N = y_example.shape[0]
         f32 = dict(dtype=torch.float32, device=dev)
-        self.y = y_example.to(**f32).clone()
+        self.n_steps = int(steps_per_replay)
+        if self.n_steps < 1:
+            raise ValueError('steps_per_replay must be >= 1')
+        self.ys = y_example.to(**f32).unsqueeze(0).repeat(self.n_steps, 1, 1).contiguous()    # static input: n minibatches
+        self.y = self.ys[0]
         # the trainer's own Philox stream, keyed by a device word, generated by captured kernels (any shape: the graph uses the
         # stand-alone generator, which covers the shapes the E-step kernel's built-in generator does not)
         self.in_kernel_rng = tr.rng == 'philox'
@@ -579,6 +588,8 @@ class GraphedSVAEStep(object):
         self._table = torch.zeros(self.TABLE_ROWS, 2, dtype=torch.int64, device=dev) if self.table_mode else None
         self._counter = torch.zeros(1, dtype=torch.int64, device=dev) if self.table_mode else None
         self._table_base, self._table_used = None, 0
+        if self.n_steps > 1 and not self.table_mode:
+            raise L.VmpError('GraphedSVAEStep: steps_per_replay > 1 needs the direct single-process GMM step on in-kernel noise')
         # Warm-up steps (they create the variables / Adam slots and size the workspaces) must not train: everything a
         # step mutates is snapshotted first and put back before the capture, so that call number i of this object
         # is training step number i of the eager trainer (and of the reference).
@@ -625,7 +636,8 @@ class GraphedSVAEStep(object):
         self.world = tr._world()
         if self.world == 1:
             with torch.cuda.graph(self.graph, stream=cap_stream):
-                self.out = tr.step(self.y, noise=self.noise, u=self.u, _dev_scalars=dev_scalars)
+                self.outs = [tr.step(self.ys[i], noise=self.noise, u=self.u, _dev_scalars=dev_scalars) for i in range(self.n_steps)]
+            self.out = self.outs[-1]
         else:
             # Data-parallel step (one process per GPU): TWO graphs around the ONE collective of the step.  Graph 1 = everything this
             # rank does on its own rows up to the packed exchange buffer (SVAETrainer._step_front), then the all-reduce of that
@@ -672,14 +684,24 @@ class GraphedSVAEStep(object):
         self._table_base, self._table_used = (tr.global_step, tr.opt.t), 0
 
     def __call__(self, y):
+        """y: the minibatch (N, Dy) - steps_per_replay = n > 1: the n minibatches (n, N, Dy); passing self.y / self.ys themselves (a loader
+        that wrote into the static input) skips the copy.  Returns the step's output dict (n > 1: the list of the n steps' dicts)."""
         tr = self.tr
+        n = self.n_steps
         if self.table_mode:
             b = self._table_base
-            if b is None or self._table_used >= self.TABLE_ROWS or (b[0] + self._table_used, b[1] + self._table_used) != (tr.global_step, tr.opt.t):
+            if b is None or self._table_used + n > self.TABLE_ROWS or (b[0] + self._table_used, b[1] + self._table_used) != (tr.global_step, tr.opt.t):
                 self._fill_table()                  # first call, table used up, or the trainer was stepped outside this object
-            if not (torch.is_tensor(y) and y.is_cuda and y.data_ptr() == self.y.data_ptr()):
-                self.y.copy_(y)                     # (a loader that writes into self.y directly saves this launch)
-            self._table_used += 1
+            dst = self.ys if n > 1 else self.y
+            if not (torch.is_tensor(y) and y.is_cuda and y.data_ptr() == dst.data_ptr()):
+                dst.copy_(y if torch.is_tensor(y) else torch.stack(list(y)))     # (a loader that writes into the static input saves this launch)
+            self._table_used += n
+            for i, o in enumerate(self.outs):
+                o['lrcvi'] = exponential_decay(tr.lrcvi0, tr.global_step + i, 1000, tr.decay_rate)
+            self.graph.replay()
+            tr.opt.t += n
+            tr.global_step += n
+            return self.outs if n > 1 else self.out
         elif (self.in_kernel_rng and torch.is_tensor(y) and y.is_cuda and y.dtype == torch.float32 and y.is_contiguous()
                 and tuple(y.shape) == tuple(self.y.shape)):
             # scalars of the step + the minibatch into the static input: ONE eager launch (round 6; it was a copy + a launch)
