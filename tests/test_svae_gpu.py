@@ -495,7 +495,8 @@ def test_graphed_step_matches_eager():
 
 
 @pytest.mark.parametrize('N,K,Ld,U,Dy,S', [(64, 10, 8, 50, 6, 10), (100, 16, 8, 64, 8, 10), (37, 7, 4, 33, 3, 8), (5, 3, 2, 16, 1, 4),
-                                          (512, 8, 6, 50, 6, 10)])
+                                          (512, 8, 6, 50, 6, 10), (40, 20, 4, 32, 4, 6), (30, 33, 2, 16, 2, 4), (8, 64, 8, 64, 8, 10),
+                                          (64, 10, 8, 50, 6, 16), (1, 1, 1, 1, 1, 4)])
 def test_direct_minibatch_step_equals_the_autograd_step(N, K, Ld, U, Dy, S):
     """Round 6: SVAETrainer._step_direct (7 launches: lazy partial reductions, the ELBO tail inside the E-step backward, ONE closing
     launch for partial rows -> phi_gmm gradients, both reductions, Adam, moments + CVI, scalars) against the autograd step
