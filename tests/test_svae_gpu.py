@@ -574,6 +574,33 @@ def test_graphed_step_scalar_table_refills_and_follows_the_trainer():
         assert torch.equal(a, b)
 
 
+def test_graphed_step_across_the_scalar_table_boundary():
+    """1 100 replayed steps (the table holds 1 024 rows: one refill on the way) and 278 replays of four steps (1 112 steps, refill with the
+    table not used up to its last row) leave exactly the parameters of as many eager steps."""
+    from vmp_for_svae_amd.models import vae
+    from vmp_for_svae_amd.training import SVAETrainer, GraphedSVAEStep
+    N, K, Ld, U, Dy, S = 32, 5, 4, 16, 3, 4
+    g = torch.Generator(device='cuda').manual_seed(31)
+    y = torch.randn(N, Dy, device='cuda', generator=g)
+
+    def mk():
+        vae.reset_variables()
+        return SVAETrainer(K, Ld, U, Dy, nb_samples=S, lr=1e-3, lrcvi=0.2, decay_rate=0.95, stddev_init_nn=0.1, seed=2)
+    for n, calls in ((1, 1100), (4, 278)):
+        tr = mk()
+        for _ in range(n * calls):
+            tr.step(y)
+        want = [p.detach().clone() for p in tr.trainables()[1]] + [t.clone() for t in tr.theta]
+        tr2 = mk()
+        gs = GraphedSVAEStep(tr2, y, steps_per_replay=n)
+        src = gs.ys if n > 1 else gs.y
+        for _ in range(calls):
+            gs(src)
+        assert tr2.global_step == n * calls and gs._table_base[0] > 0          # the table was rebuilt on the way
+        for a, b in zip([p.detach() for p in tr2.trainables()[1]] + list(tr2.theta), want):
+            assert torch.equal(a, b), n
+
+
 def test_graphed_multi_step_replay_equals_eager_steps():
     """Round 6: GraphedSVAEStep(steps_per_replay=4) captures FOUR consecutive training steps in one graph (step i reads minibatch i of the
     static input and the next row of the scalar table): two replays == eight eager steps, every parameter / Adam slot / theta tensor and
