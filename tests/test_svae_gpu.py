@@ -2,6 +2,8 @@
 through the reference-shaped surface (models.svae / models.vae) against the golden vectors produced by the
 reference itself.  Tolerances: ELBO 1e-5 relative, responsibilities 1e-5 absolute, everything else
 1e-5 relative to the fp64 truth - or 3x the reference's own fp32-vs-fp64 error where that is larger."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -680,6 +682,29 @@ def test_driver_pinwheel_converges():
     assert last['loli'] > first['loli'] + 1.0
     assert last['mse'] < 0.5 * first['mse']
     assert 0.2 <= last['purity'] <= 1.0
+
+
+def test_driver_multi_step_replays_equal_single_step_replays(tmp_path):
+    """experiments.run(steps_per_replay=4): up to four consecutive iterations that no measurement / checkpoint iteration interrupts run
+    from one graph replay - the same steps on the same minibatches: history, final parameters and the checkpoints written on the way
+    are bit-identical to the one-step-per-replay run (pinwheel: 350 training rows, minibatches of 100 -> a ragged batch every epoch)."""
+    from vmp_for_svae_amd import experiments
+    cfg = {'dataset': 'pinwheel', 'method': 'svae-cvi', 'lr': 0.01, 'lrcvi': 0.1, 'K': 10, 'L': 2, 'U': 50, 'seed': 0}
+    res = []
+    for n in (1, 4):
+        d = tmp_path / ('n%d' % n)
+        tr, hist, log_id = experiments.run(cfg, nb_iters=43, measurement_freq=10, verbose=False, steps_per_replay=n,
+                                           checkpoint_freq=15, checkpoint_dir=str(d))
+        ck = {f: dict(np.load(os.path.join(str(d), f))) for f in sorted(os.listdir(str(d)))}
+        res.append((hist, [p.detach().clone() for p in tr.trainables()[1]] + [t.clone() for t in tr.theta], ck))
+    (h1, p1, c1), (h4, p4, c4) = res
+    assert [sorted(h.items()) for h in h1] == [sorted(h.items()) for h in h4]
+    for a, b in zip(p1, p4):
+        assert torch.equal(a, b)
+    assert sorted(c1) == sorted(c4) and len(c1) == 4
+    for f in c1:
+        for k in c1[f]:
+            assert np.array_equal(c1[f][k], c4[f][k]), (f, k)
 
 
 def test_predict_vs_oracle(golden):

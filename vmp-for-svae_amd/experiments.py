@@ -104,7 +104,7 @@ def load_checkpoint(tr, path):
 
 def run(config, nb_iters=2000, size_minibatch=100, nb_samples=10, nb_samples_te=100, measurement_freq=500,
         path_dataset=None, device='cuda', verbose=True, ratio_tr=0.7, imputation_freq=None, nb_samples_pert=20,
-        ratio_missing_data=0.1, checkpoint_freq=None, checkpoint_dir=None, graph=True, group=None):
+        ratio_missing_data=0.1, checkpoint_freq=None, checkpoint_dir=None, graph=True, group=None, steps_per_replay=1):
     """One run of the reference driver (experiments.py:86-457).  Under torch.distributed (one process per GPU) every
     rank draws the same shuffled minibatch stream and trains on its tower_slice of each minibatch - the reference's
     tf.split over towers (data.py:174-175, experiments.py:196-244); SVAETrainer.step sums moments / ELBO and AVERAGES
@@ -117,7 +117,10 @@ def run(config, nb_iters=2000, size_minibatch=100, nb_samples=10, nb_samples_te=
     (training.GraphedSVAEStep, round 5).  It is opt-in because of a finding that is not ours to fix: after HIP-graph replays in a
     process that shares its GPU with another rank, torch's device Cholesky has returned a wrong factor on its first call
     (tools/r6_dpg_repro.py, profiles/r06_dpg_linalg.txt); this package keeps every K-sized factorisation on the host
-    (_klinalg), but a caller's own GPU linalg after such a run is exposed."""
+    (_klinalg), but a caller's own GPU linalg after such a run is exposed.
+    steps_per_replay = n > 1 (single-process graph runs whose step is the trainer's direct kernel sequence): up to n consecutive
+    iterations that no measurement / imputation / checkpoint iteration interrupts run from ONE graph replay
+    (GraphedSVAEStep(steps_per_replay=n)); the same steps on the same minibatches, bit for bit - only the launches are batched."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank(group) if world > 1 else 0
@@ -139,16 +142,41 @@ def run(config, nb_iters=2000, size_minibatch=100, nb_samples=10, nb_samples_te=
     history = []
     t0 = time.time()
     # fixed-size minibatches: capture the training step once as a HIP graph and replay it (training.GraphedSVAEStep)
-    stepper = None
+    stepper = multi = None
+    nrep = max(1, int(steps_per_replay))
+
+    def observed(j):                                       # iterations after which the loop looks at the trainer or the step's output
+        return (j % measurement_freq == 0 or j == nb_iters - 1 or
+                bool(checkpoint_freq and checkpoint_dir and (j % checkpoint_freq == 0)))
+    pending = []                                           # outputs of the iterations a multi-step replay has already run
     for i in range(nb_iters):
-        yb = next(batches)
-        if graph and dev.type == 'cuda' and (world == 1 or graph == 'dp'):
-            if stepper is None:
-                from .training import GraphedSVAEStep
-                stepper = GraphedSVAEStep(tr, yb)
-            out = stepper(yb) if yb.shape[0] == stepper.y.shape[0] else tr.step(yb)
+        if pending:
+            out = pending.pop(0)
         else:
-            out = tr.step(yb)
+            yb = next(batches)
+            if graph and dev.type == 'cuda' and (world == 1 or graph == 'dp'):
+                if stepper is None:
+                    from .training import GraphedSVAEStep
+                    stepper = GraphedSVAEStep(tr, yb)
+                    if nrep > 1 and world == 1 and stepper.table_mode:
+                        multi = GraphedSVAEStep(tr, yb, steps_per_replay=nrep)
+                group_ok = (multi is not None and yb.shape[0] == stepper.y.shape[0] and i + nrep <= nb_iters and
+                            not any(observed(j) for j in range(i, i + nrep - 1)))
+                if group_ok:
+                    ybs = [yb] + [next(batches) for _ in range(nrep - 1)]
+                    if all(b.shape[0] == yb.shape[0] for b in ybs):
+                        outs = multi(torch.stack(ybs))
+                        # (the replay's output tensors are the graph's static outputs: what a later iteration reads is copied now)
+                        pending = [dict(o, elbo=o['elbo'].clone()) for o in outs[1:]]
+                        out = outs[0]
+                    else:                                  # a ragged batch inside the group: these iterations one by one
+                        res = [stepper(b) if b.shape[0] == stepper.y.shape[0] else tr.step(b) for b in ybs]
+                        pending = [dict(o, elbo=o['elbo'].clone()) for o in res[1:]]
+                        out = res[0]
+                else:
+                    out = stepper(yb) if yb.shape[0] == stepper.y.shape[0] else tr.step(yb)
+            else:
+                out = tr.step(yb)
         if i % measurement_freq == 0 or i == nb_iters - 1:
             m = evaluate(tr, Xte, Lte, nb_samples_te, seed=config.get('seed', 0))
             m['iter'], m['neg_normed_elbo'] = i, -float(out['elbo']) / size_minibatch      # experiments.py:318-320
