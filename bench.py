@@ -667,9 +667,11 @@ def main():
     ap.add_argument('--reps', type=int, default=31, help='repetitions of the timed region (gmm / smm); the median is reported')
     ap.add_argument('--workload', default='gmm', choices=['gmm', 'smm', 't2', 't3'])
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
-    ap.add_argument('--exchange', default='rccl', choices=['rccl', 'peer'],
+    ap.add_argument('--exchange', default='auto', choices=['auto', 'rccl', 'peer'],
                     help='T1 multi-rank exchange: rccl = local reduce + RCCL all-reduce + posterior (3 launches); '
-                         'peer = ONE finalize launch pushing the moments into IPC-mapped peer buffers')
+                         'peer = ONE finalize launch pushing the moments into IPC-mapped peer buffers; auto (default) = peer where every '
+                         'rank could map the buffers, three steps of it agree with the RCCL form, no wait timed out AND it is the faster '
+                         'of the two on every rank - otherwise rccl')
     ap.add_argument('--n', type=int, default=1_000_000)
     ap.add_argument('--d', type=int, default=8)
     ap.add_argument('--k', type=int, default=16)
@@ -741,11 +743,65 @@ def main():
         flav = L.VMP_SMM if args.workload == 'smm' else L.VMP_GMM
         kappa = torch.full((K,), 5.0, device=dev) if flav == L.VMP_SMM else None
 
+        chosen = {'exchange': args.exchange}
+
+        def pick_exchange(x_, r0_):
+            """--exchange auto, decided once per launch by all ranks together (every branch below is taken by every rank): the peer
+            form must (a) open on every rank, (b) reproduce the RCCL form's responsibilities after three steps on this rank's rows
+            without a timed-out wait, (c) be faster than it over 30 timed steps on every rank."""
+            ex = PeerExchange.try_open(K, D)
+            if ex is None:
+                chosen.update(exchange='rccl', why='peer buffers could not be opened: ' + PeerExchange.last_failure)
+                return None
+            ok, why, t = 1, '', {}
+            try:
+                loops = {'peer': DistributedVMPLoop(x_, r0_, flav, kappa=kappa, exchange=ex), 'rccl': DistributedVMPLoop(x_, r0_, flav, kappa=kappa)}
+                for name, lp_ in loops.items():
+                    barrier()
+                    for _ in range(3):
+                        lp_.step()
+                    barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(30):
+                        lp_.step()
+                    torch.cuda.synchronize()
+                    t[name] = time.perf_counter() - t0
+                err = (loops['peer'].r - loops['rccl'].r).abs().max().item()
+                if int(ex.status.item()) != 0:
+                    ok, why = 0, 'a wait of the peer form timed out'
+                elif not err <= 1e-5:
+                    ok, why = 0, 'peer and RCCL forms disagree (max |dr| = %.3g)' % err
+                elif not t['peer'] < t['rccl']:
+                    ok, why = 0, 'peer form slower on rank %d (%.1f vs %.1f us/step)' % (rank, t['peer'] / 30 * 1e6, t['rccl'] / 30 * 1e6)
+                del loops
+            except Exception as e:                           # noqa: BLE001
+                ok, why = 0, 'rank %d: %r' % (rank, e)
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                # a FRESH exchange for the measured loop: iteration counters and sequence words start from zero on every rank
+                ex.close_collective()
+                ex2 = PeerExchange.try_open(K, D)
+                if ex2 is not None:
+                    chosen.update(exchange='peer', why='verified against the RCCL form and faster: %.1f vs %.1f us/step on rank 0'
+                                  % (t['peer'] / 30 * 1e6, t['rccl'] / 30 * 1e6) if t else '')
+                    return ex2
+                chosen.update(exchange='rccl', why='peer buffers could not be re-opened: ' + PeerExchange.last_failure)
+                return None
+            ex.close_collective()
+            chosen.update(exchange='rccl', why=why or 'another rank rejected the peer form')
+            return None
+
         def make_loop(n_rows, seed):
             x_h_, r0_h_ = synth(n_rows, D, K, seed=seed)
             x_, r0_ = torch.as_tensor(x_h_).to(dev), torch.as_tensor(r0_h_).to(dev)
             if world > 1:
-                ex = PeerExchange(K, D) if args.exchange == 'peer' else None      # (its constructor ends with a rendezvous of the ranks)
+                if args.exchange == 'auto' and chosen['exchange'] == 'auto':
+                    ex = pick_exchange(x_, r0_)
+                elif chosen['exchange'] == 'peer':
+                    ex = PeerExchange(K, D)                 # (its constructor ends with a rendezvous of the ranks)
+                else:
+                    ex = None
                 lp = DistributedVMPLoop(x_, r0_, flav, kappa=kappa, exchange=ex)
             else:
                 lp = _mix.VMPLoop(x_, r0_, flav, kappa=kappa)
@@ -784,7 +840,7 @@ def main():
             d2 = float(np.median(w2))
             extra['other_scaling'] = {'scaling': other, 'rows_per_rank': n2, 'rows_job': job2, 'ms_per_step': d2 / args.steps * 1e3,
                                       'value': job2 / (d2 / args.steps), 'kernel_ms': float(np.median(k2)),
-                                      'exchange': args.exchange}
+                                      'exchange': chosen['exchange']}
             if loop2.exchange is not None:
                 loop2.exchange.close_collective()
             barrier()
@@ -886,7 +942,7 @@ def main():
                 'config': {'workload': 'T1 %s VMP step (M-step + E-step), synthetic GMM N=%d %s, D=%d, K=%d'
                                        % (args.workload, N, 'per GPU' if args.scaling == 'weak' else 'in total (rows split over the ranks)', D, K),
                            'N_per_gpu': n_loc, 'N_job': n_job, 'D': D, 'K': K,
-                           'parallelism': 'dp%d (rows sharded, 1 exchange of K-sized stats per step: %s)' % (world, args.exchange if world > 1 else 'none'),
+                           'parallelism': 'dp%d (rows sharded, 1 exchange of K-sized stats per step: %s)' % (world, chosen['exchange'] if world > 1 else 'none'),
                            'timing': 'median over `reps` timed regions of `steps` steps each'},
                 # `achieved`/`frac` follow the contract: ALGORITHMIC bytes (4N(2D+2K), the un-fused M-pass +
                 # E-pass) / kernel time.  The fused pass MOVES half of that (x read once, r written once): `moved_*` is the
@@ -901,6 +957,8 @@ def main():
                              'flops_per_launch': t1_flops(n_loc, D, K),
                              'valu_frac': t1_flops(n_loc, D, K) / (kern_ms * 1e-3) / FP32_PEAK_FLOPS},
             })
+            if world > 1:
+                out['config']['exchange_choice'] = dict(chosen, requested=args.exchange)
             if 'other_scaling' in extra:
                 # both scaling modes in the line's top-level config, so that a SCALE record cannot be read as the wrong mode (SURVEY 8e
                 # reads the >= 6x target at N / G rows per GPU = strong scaling)

@@ -40,11 +40,17 @@ def _run2(args):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize('scaling,exchange', [('weak', 'rccl'), ('strong', 'peer')])
+@pytest.mark.parametrize('scaling,exchange', [('weak', 'rccl'), ('strong', 'peer'), ('weak', 'auto')])
 def test_t1_two_ranks_both_scaling_modes(scaling, exchange):
     N = 40000
     d = _run2(['--n', str(N), '--steps', '5', '--warmup', '2', '--reps', '3', '--no-extra', '--no-cpu-baseline',
-               '--scaling', scaling, '--exchange', exchange])
+               '--scaling', scaling] + (['--exchange', exchange] if exchange != 'auto' else []))      # auto is the default
+    ch = d['config']['exchange_choice']
+    assert ch['requested'] == exchange
+    if exchange == 'auto':
+        # decided by the ranks together: the peer form if it opened, agreed with the all-reduce form and was faster, else the all-reduce
+        assert ch['exchange'] in ('peer', 'rccl') and ch['why']
+        exchange = ch['exchange']
     assert d['n_gpus'] == 2 and d['scaling'] == scaling and d['steps'] == 5 and d['warmup'] == 2
     job = 2 * N if scaling == 'weak' else N
     assert d['config']['N_job'] == job and d['config']['N_per_gpu'] == (N if scaling == 'weak' else N // 2)

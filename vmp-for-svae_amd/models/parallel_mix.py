@@ -122,6 +122,66 @@ class PeerExchange(object):
                 gather(b'mapped'.ljust(64, b'\0'))        # a second round of the caller's all-gather is the rendezvous
         self._group, self._gather = group, gather
 
+    @classmethod
+    def try_open(cls, K, D, group=None):
+        """Collective and exception-free: EVERY rank gets an exchange, or every rank gets None (some rank could not allocate, export or
+        map a buffer - the reason is in .last_failure of the class).  Each stage is followed by an exchange of success flags, so that a
+        rank that fails never leaves its peers waiting in a rendezvous.  For callers that want to fall back to the all-reduce form."""
+        import ctypes
+        import torch.distributed as dist
+        self = cls.__new__(cls)
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.K, self.D = int(K), int(D)
+        self._peers, self._buf, self._group, self._gather = [], None, group, None
+        why, raw = '', b''
+        try:
+            if not 1 <= self.world <= 16:
+                raise L.VmpError('PeerExchange supports 1..16 ranks')
+            buf = ctypes.c_void_p()
+            L.check(L.lib().vmp_exch_alloc(ctypes.byref(buf), L.lib().vmp_exch_bytes(self.world, self.K, self.D)), 'vmp_exch_alloc')
+            self._buf = buf
+            hb = ctypes.create_string_buffer(64)
+            L.check(L.lib().vmp_exch_export(buf, hb), 'vmp_exch_export')
+            raw = hb.raw
+        except Exception as e:                               # noqa: BLE001 - reported through the flags
+            why = 'rank %d: %r' % (self.rank, e)
+        got = [None] * self.world
+        dist.all_gather_object(got, (why, raw), group=group)
+        if not any(w for w, _ in got):
+            try:
+                for g, (_, h) in enumerate(got):
+                    if g == self.rank:
+                        self._peers.append(ctypes.c_void_p(self._buf.value))
+                    else:
+                        pp = ctypes.c_void_p()
+                        L.check(L.lib().vmp_exch_open(ctypes.create_string_buffer(h, 64), ctypes.byref(pp)), 'vmp_exch_open')
+                        self._peers.append(pp)
+            except Exception as e:                           # noqa: BLE001
+                why = 'rank %d: %r' % (self.rank, e)
+            # pad for close(): it walks the list by rank index
+            got2 = [None] * self.world
+            dist.all_gather_object(got2, why, group=group)
+        else:
+            got2 = [w for w, _ in got]
+        torch.cuda.synchronize()
+        dist.barrier(group)                                  # nobody unmaps / publishes before everybody is here
+        if any(got2):
+            cls.last_failure = '; '.join(w for w in got2 if w)
+            peers, self._peers = self._peers, []
+            for g, pp in enumerate(peers):
+                if g != self.rank:
+                    L.lib().vmp_exch_close(pp)
+            if self._buf is not None:
+                L.lib().vmp_exch_free(self._buf)
+                self._buf = None
+            return None
+        self.table = (ctypes.c_void_p * self.world)(*[p_.value for p_ in self._peers])
+        self.iteration = 0
+        self.status = torch.zeros(1, dtype=torch.int32, device='cuda')
+        return self
+
+    last_failure = ''
+
     def __enter__(self):
         return self
 
