@@ -168,6 +168,7 @@ class SVAETrainer(object):
         # True (default): a whole-minibatch single-process GMM step on in-kernel noise runs as the 8-launch kernel sequence of
         # _step_direct (round 6) instead of the autograd graph over the same kernels (13 launches); False: always autograd
         self.direct_step = bool(direct_step)
+        self._direct_shapes = {}
         # True: build the step exactly as experiments.py:209-229 does - svae.inference(...) WITHOUT theta, then
         # svae.compute_elbo(..., theta, phi_tilde, ...), which evaluates the theta term in a second launch of the fused
         # kernel (models/svae.py PhiTilde.theta_term).  False (default): theta goes into the E-step, one launch.
@@ -293,10 +294,14 @@ class SVAETrainer(object):
         rows, Dy = y.shape
         if (chunk is not None and rows > int(chunk)) or not (0 < rows <= _svae_ops.STATS_CVI_MAX_ROWS):
             return False
-        if not (vae._fused_mlp_eligible(Dy, self.encoder_layers) and vae.fused_decoder_eligible(self.L, self.decoder_layers)):
-            return False
-        lib = L.lib()
-        return bool(lib.vmp_svae_rng_in_kernel(self.K, self.L, self.S) and lib.vmp_svae_bwd_tail_applies(rows, self.K, self.L, self.S))
+        key = (rows, Dy)                                     # (the shape-only part of the answer is remembered: three library queries)
+        ok = self._direct_shapes.get(key)
+        if ok is None:
+            lib = L.lib()
+            ok = bool(vae._fused_mlp_eligible(Dy, self.encoder_layers) and vae.fused_decoder_eligible(self.L, self.decoder_layers)
+                      and lib.vmp_svae_rng_in_kernel(self.K, self.L, self.S) and lib.vmp_svae_bwd_tail_applies(rows, self.K, self.L, self.S))
+            self._direct_shapes[key] = ok
+        return ok
 
     @torch.no_grad()
     def _step_direct(self, y, _dev_scalars=None, pack=False):
@@ -332,47 +337,50 @@ class SVAETrainer(object):
         rho_dev = None if _dev_scalars is None else _dev_scalars[0]
         lr_dev = None if _dev_scalars is None else _dev_scalars[1]
         lrcvi = exponential_decay(self.lrcvi0, self.global_step, 1000, self.decay_rate)
+        # Scratch that nothing outside this step reads - encoder outputs, the K-sized prep, T', dL/dx, the per-sample reconstruction sums,
+        # partial rows, the two MLP workspaces ... - is ONE allocation addressed by offsets (twenty torch.empty calls cost more host time
+        # than the step's six launches); what the caller gets back (x, log z, the sub-sample, gradients, theta*, scalars) are tensors.
+        nt = lib.vmp_svae_bwd_blocks_for(N, K, Ld, S, 0)
+        PWp = lib.vmp_svae_bwd_partial_words(Ld)
+        nb_dec, nb_enc = lib.vmp_decoder_bwd_blocks(N * K * S), lib.vmp_decoder_bwd_blocks(N)
+        wsb_dec, wsb_enc = lib.vmp_decoder_workspace_bytes(N, K, S, Ld, U, Dy), lib.vmp_decoder_workspace_bytes(N, 1, 1, Dy, U, Ld)
+        sizes = dict(eta1=4 * N * Ld, eta2d=4 * N * Ld, Lk=4 * K * Ld * Ld, P=4 * K * Ld * Ld, bias=4 * K, mk=4 * K * Ld, Wk=4 * K * Ld * Ld,
+                     kappa=4 * K, logpi=8 * K, Tp=4 * N * K, r_epi=4 * N * K, dx=4 * N * K * S * Ld, ll=4 * N * K * S, g_eta1=4 * N * Ld,
+                     g_eta2d=4 * N * Ld, partials=4 * nt * K * PWp, r=4 * N * K, tail_part=16 * nt, ws_dec=wsb_dec, ws_enc=wsb_enc)
+        off, o = {}, 0
+        for k_, nb_ in sizes.items():
+            off[k_] = o
+            o += (nb_ + 255) & ~255
+        arena = torch.empty(o, dtype=torch.uint8, device=dev)
+        base = arena.data_ptr()
+        A = lambda k_: ctypes.c_void_p(base + off[k_])
         # 1: encoder (natparam head: eta1, -1/2 var) + recognition unpacking + theta packing (+ a replayed step's scalars from its table)
-        eta1, eta2d = torch.empty(N, Ld, **f32), torch.empty(N, Ld, **f32)
         mu_k, L_raw, pi_raw = phi
-        Lk, P, bias = torch.empty(K, Ld, Ld, **f32), torch.empty(K, Ld, Ld, **f32), torch.empty(K, **f32)
-        mk, Wk, kappa = torch.empty(K, Ld, **f32), torch.empty(K, Ld, Ld, **f32), torch.empty(K, **f32)
-        logpi = torch.empty(K, dtype=torch.float64, device=dev)
         tab = _dev_scalars[3] if (_dev_scalars is not None and len(_dev_scalars) > 3) else None     # (table, rows, counter, dst16)
-        L.check(lib.vmp_mlp_gauss_head_fwd_prep(L.ptr(y), *pp(enc), N, Dy, Ld, U, -0.5, L.ptr(eta1), L.ptr(eta2d), L.ptr(mu_k), L.ptr(L_raw),
-                                                L.ptr(pi_raw), *pp(self.theta), K, L.ptr(Lk), L.ptr(P), L.ptr(bias), L.ptr(mk), L.ptr(Wk),
-                                                L.ptr(kappa), L.ptr(logpi), L.ptr(tab[0]) if tab else None, tab[1] if tab else 0,
+        L.check(lib.vmp_mlp_gauss_head_fwd_prep(L.ptr(y), *pp(enc), N, Dy, Ld, U, -0.5, A('eta1'), A('eta2d'), L.ptr(mu_k), L.ptr(L_raw),
+                                                L.ptr(pi_raw), *pp(self.theta), K, A('Lk'), A('P'), A('bias'), A('mk'), A('Wk'),
+                                                A('kappa'), A('logpi'), L.ptr(tab[0]) if tab else None, tab[1] if tab else 0,
                                                 L.ptr(tab[2]) if tab else None, L.ptr(tab[3]) if tab else None, st),
                 'vmp_mlp_gauss_head_fwd_prep')
         # 2: E-step on in-kernel noise; its epilogue draws the one sub-sample per row
         x = torch.empty(N, K, S, Ld, **f32)
-        lz, Tp = torch.empty(N, K, **f32), torch.empty(N, K, **f32)
-        xs, r_epi = torch.empty(N, Ld, **f32), torch.empty(N, K, **f32)
+        lz = torch.empty(N, K, **f32)
+        xs = torch.empty(N, Ld, **f32)
         key = 0 if seed_dev is not None else (self._step_seed(0) & 0xFFFFFFFFFFFFFFFF)
-        L.check(lib.vmp_svae_estep_fwd_rng_epi(L.ptr(eta1), L.ptr(eta2d), L.ptr(mu_k), L.ptr(P), L.ptr(bias), key, L.ptr(seed_dev),
-                                               L.ptr(mk), L.ptr(Wk), L.ptr(kappa), None, N, K, Ld, S, L.ptr(x), L.ptr(lz), L.ptr(Tp),
-                                               L.ptr(xs), L.ptr(r_epi), None, 0, st), 'vmp_svae_estep_fwd_rng_epi')
+        L.check(lib.vmp_svae_estep_fwd_rng_epi(A('eta1'), A('eta2d'), L.ptr(mu_k), A('P'), A('bias'), key, L.ptr(seed_dev),
+                                               A('mk'), A('Wk'), A('kappa'), None, N, K, Ld, S, L.ptr(x), L.ptr(lz), A('Tp'),
+                                               L.ptr(xs), A('r_epi'), None, 0, st), 'vmp_svae_estep_fwd_rng_epi')
         # 3: decoder value + gradients of loss = -elbo (sigma = -1); parameter partials stay in ws_dec
-        dx, ll = torch.empty_like(x), torch.empty(N, K, S, **f32)
-        nb_dec = lib.vmp_decoder_bwd_blocks(N * K * S)
-        ws_dec = torch.empty(lib.vmp_decoder_workspace_bytes(N, K, S, Ld, U, Dy), dtype=torch.uint8, device=dev)
-        L.check(lib.vmp_decoder_elbo_lazy(L.ptr(x), L.ptr(y), L.ptr(lz), -1.0, *pp(dec), N, K, S, Ld, Dy, U, L.ptr(dx), L.ptr(ll),
-                                          L.ptr(ws_dec), ws_dec.numel(), st), 'vmp_decoder_elbo_lazy')
+        L.check(lib.vmp_decoder_elbo_lazy(L.ptr(x), L.ptr(y), L.ptr(lz), -1.0, *pp(dec), N, K, S, Ld, Dy, U, A('dx'), A('ll'),
+                                          A('ws_dec'), wsb_dec, st), 'vmp_decoder_elbo_lazy')
         # 4: ELBO tail + E-step backward
-        g_eta1, g_eta2d = torch.empty(N, Ld, **f32), torch.empty(N, Ld, **f32)
-        nt = lib.vmp_svae_bwd_blocks_for(N, K, Ld, S, 0)
-        partials = torch.empty(nt, K, lib.vmp_svae_bwd_partial_words(Ld), **f32)
-        r = torch.empty(N, K, **f32)
-        tail_part = torch.empty(nt, 2, dtype=torch.float64, device=dev)
-        L.check(lib.vmp_svae_estep_bwd_tail(L.ptr(eta1), L.ptr(eta2d), L.ptr(mu_k), L.ptr(P), L.ptr(bias), L.ptr(mk), L.ptr(Wk),
-                                            L.ptr(x), L.ptr(lz), L.ptr(Tp), L.ptr(ll), -1.0, L.ptr(dx), N, K, Ld, S, L.ptr(g_eta1),
-                                            L.ptr(g_eta2d), L.ptr(partials), partials.numel() * 4, L.ptr(r), L.ptr(tail_part),
-                                            tail_part.numel() * 8, st), 'vmp_svae_estep_bwd_tail')
+        L.check(lib.vmp_svae_estep_bwd_tail(A('eta1'), A('eta2d'), L.ptr(mu_k), A('P'), A('bias'), A('mk'), A('Wk'),
+                                            L.ptr(x), L.ptr(lz), A('Tp'), A('ll'), -1.0, A('dx'), N, K, Ld, S, A('g_eta1'),
+                                            A('g_eta2d'), A('partials'), sizes['partials'], A('r'), A('tail_part'),
+                                            sizes['tail_part'], st), 'vmp_svae_estep_bwd_tail')
         # 5: encoder backward; parameter partials stay in ws_enc
-        nb_enc = lib.vmp_decoder_bwd_blocks(N)
-        ws_enc = torch.empty(lib.vmp_decoder_workspace_bytes(N, 1, 1, Dy, U, Ld), dtype=torch.uint8, device=dev)
-        L.check(lib.vmp_mlp_gauss_head_bwd_lazy(L.ptr(y), L.ptr(g_eta1), L.ptr(g_eta2d), -0.5, *pp(enc), N, Dy, Ld, U, None,
-                                                L.ptr(ws_enc), ws_enc.numel(), st), 'vmp_mlp_gauss_head_bwd_lazy')
+        L.check(lib.vmp_mlp_gauss_head_bwd_lazy(L.ptr(y), A('g_eta1'), A('g_eta2d'), -0.5, *pp(enc), N, Dy, Ld, U, None,
+                                                A('ws_enc'), wsb_enc, st), 'vmp_mlp_gauss_head_bwd_lazy')
         # 6: the closing launch (phi_gmm gradients from the partial rows, both MLP reductions, Adam, moments + CVI, ELBO scalars)
         g_phi = [torch.empty_like(t) for t in phi]
         g_enc, g_dec = [torch.empty_like(t) for t in enc], [torch.empty_like(t) for t in dec]
@@ -387,11 +395,11 @@ class SVAETrainer(object):
                 goffs.append(o)
                 o += n_
             buf = torch.empty(o + 3, dtype=torch.float64, device=dev)
-            L.check(lib.vmp_svae_step_pack(L.ptr(buf), buf.numel(), L.ptr(ws_dec), nb_dec, Ld, U, Dy, arr(dec), arr(g_dec), L.ptr(ws_enc),
-                                           nb_enc, Dy, U, Ld, arr(enc), arr(g_enc), L.ptr(partials), nt, L.ptr(logpi), arr(phi), arr(g_phi),
-                                           L.ptr(xs), L.ptr(r), N, K, Ld, L.ptr(tail_part), nt, Dy, L.ptr(scal), st), 'vmp_svae_step_pack')
+            L.check(lib.vmp_svae_step_pack(L.ptr(buf), buf.numel(), A('ws_dec'), nb_dec, Ld, U, Dy, arr(dec), arr(g_dec), A('ws_enc'),
+                                           nb_enc, Dy, U, Ld, arr(enc), arr(g_enc), A('partials'), nt, A('logpi'), arr(phi), arr(g_phi),
+                                           L.ptr(xs), A('r'), N, K, Ld, A('tail_part'), nt, Dy, L.ptr(scal), st), 'vmp_svae_step_pack')
             return dict(world=self._world(), names=names, params=params, grads=g_phi + g_enc + g_dec, stats=buf[:K * SW].view(K, SW),
-                        fused_m=False, keep=dict(log_z=lz, x_samples=xs, x_k=x), r_whole=r, scal=(scal[0], scal[1], scal[2]), buf=buf,
+                        fused_m=False, keep=dict(log_z=lz, x_samples=xs, x_k=x), r_whole=None, scal=(scal[0], scal[1], scal[2]), buf=buf,
                         goffs=goffs, mom_whole=None)
         if lr_dev is None:
             opt.t += 1
@@ -399,12 +407,12 @@ class SVAETrainer(object):
         else:
             lr_t = 0.0
         m, v = opt.m, opt.v
-        L.check(lib.vmp_svae_step_final(L.ptr(ws_dec), nb_dec, Ld, U, Dy, arr(dec), arr(m[12:21]), arr(v[12:21]), arr(g_dec),
-                                        L.ptr(ws_enc), nb_enc, Dy, U, Ld, arr(enc), arr(m[3:12]), arr(v[3:12]), arr(g_enc),
-                                        L.ptr(partials), nt, L.ptr(logpi), arr(phi), arr(g_phi), arr(m[:3]), arr(v[:3]), L.ptr(xs),
-                                        L.ptr(r), N,
+        L.check(lib.vmp_svae_step_final(A('ws_dec'), nb_dec, Ld, U, Dy, arr(dec), arr(m[12:21]), arr(v[12:21]), arr(g_dec),
+                                        A('ws_enc'), nb_enc, Dy, U, Ld, arr(enc), arr(m[3:12]), arr(v[3:12]), arr(g_enc),
+                                        A('partials'), nt, A('logpi'), arr(phi), arr(g_phi), arr(m[:3]), arr(v[:3]), L.ptr(xs),
+                                        A('r'), N,
                                         arr(prior), arr(self.theta), arr(star), L.ptr(rho_dev),
-                                        0.0 if rho_dev is not None else float(lrcvi), K, Ld, L.ptr(stats), L.ptr(tail_part), nt, Dy,
+                                        0.0 if rho_dev is not None else float(lrcvi), K, Ld, L.ptr(stats), A('tail_part'), nt, Dy,
                                         L.ptr(scal), opt.b1, opt.b2, opt.eps, lr_t, L.ptr(lr_dev), st), 'vmp_svae_step_final')
         for t in list(params) + list(self.theta):
             torch.autograd.graph.increment_version(t)
